@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- variant TP/FP classifications/sec on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): BASELINE.json configs[2] -- per GPU 1 000 synthetic VCFs x
+1 000 000 SNP records on a 5 Mb reference, 100 000-key truth set, 256-threshold ROC sweep,
+generated on the device (DESIGN.md "Synthetic generator") and resident in HBM before the
+timed region.  A step = one pass of the whole path over that batch: classify (LDS-staged
+merge-join, ballot masks, ROC histograms) -> finalize -> TP/FP index compaction, plus, for
+N > 1, the one RCCL all-reduce of the per-truth-set confusion counters.  VCFs shard over
+ranks with no data-path collective (weak scaling: per-GPU work fixed).
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k_classify), timed
+with HIP events on its own stream inside the timed region; `cpu_baseline` is the oracle
+(a C restatement of the reference's awk/fgrep semantics) timed on this box's host cores
+on a bounded sample of the same VCFs -- a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--vcfs", type=int, default=int(os.environ.get("QM_BENCH_VCFS", "1000")), help="VCFs per GPU")
+    ap.add_argument("--records", type=int, default=1_000_000, help="records per VCF")
+    ap.add_argument("--genome", type=int, default=5_000_000)
+    ap.add_argument("--truth", type=int, default=100_000)
+    ap.add_argument("--bins", type=int, default=256)
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("QM_BENCH_CPU_VCFS", "100")),
+                    help="VCFs timed through the CPU oracle on rank 0 (N=1 only); 0 disables")
+    ap.add_argument("--shuffled", action="store_true", help="records permuted: every VCF takes the radix-sort path")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import quasimodo_amd as q
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    eng = q.Engine(local_rank)
+    tseed = 3
+    tid = eng.truth_synth(args.genome, args.truth, tseed)
+    t_unique = eng.truth_size(tid)
+    n_vcf = args.vcfs
+    batch = eng.batch([args.records] * n_vcf, [tid] * n_vcf, n_bins=args.bins)
+    # VCF v of rank r is global VCF r * n_vcf + v: seed 3000 + that
+    batch.synth(args.genome, args.truth, tseed, 3000 + rank * n_vcf, shuffled=args.shuffled)
+    stream = torch.cuda.current_stream()
+    glob = torch.zeros((eng.n_truth, 3, args.bins), dtype=torch.int64, device=dev)
+
+    def step():
+        batch.run(stream=stream.cuda_stream, global_dev=glob.data_ptr())
+        if args.shuffled:
+            batch.finish(stream=stream.cuda_stream)      # radix-sort path completes here
+        if world > 1:
+            dist.all_reduce(glob, op=dist.ReduceOp.SUM)   # the path's only collective
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    batch.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    tm = batch.timings()
+    batch.set_timing(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- correctness guards on the timed data (cheap, outside the timed region) ----
+    batch.finish(stream=stream.cuda_stream)
+    scal = batch.scalars()
+    roc = batch.roc()
+    assert int(scal[:, 6].sum()) == n_vcf * args.records
+    assert np.array_equal(roc[:, 0, 20].astype(np.int64), scal[:, 1]) and np.array_equal(roc[:, 1, 20].astype(np.int64), scal[:, 2])
+    local_sum = roc.sum(axis=0).astype(np.int64)
+    got = glob.cpu().numpy()[tid]
+    if world == 1:
+        assert np.array_equal(got, local_sum), "per-truth counters != sum of the per-VCF ROC rows"
+    else:
+        ref = torch.from_numpy(local_sum).to(dev)
+        dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+        assert np.array_equal(got, ref.cpu().numpy()), "all-reduced counters != sum over ranks of the per-VCF ROC rows"
+
+    total_records = float(n_vcf) * args.records * world
+    value = total_records * args.steps / dt
+    # algorithmic bytes of one k_classify launch: 17 B per record + 12 B per truth key per VCF
+    alg_bytes = n_vcf * (17.0 * args.records + 12.0 * t_unique)
+    k1_s = tm["classify_ms"] * 1e-3
+    achieved = alg_bytes / k1_s / 1e9 if k1_s > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes per launch from a separate --pmc pass
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("vcfs") == n_vcf and tj.get("records") == args.records and not args.shuffled:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "variant TP/FP classifications/sec across all caller x sample VCFs",
+        "value": value,
+        "unit": "classifications/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int32",
+        "data": "synthetic (generated on device; seeds 3000+v, truth seed 3)",
+        "config": {"workload": "BASELINE configs[2]: %d VCFs x %d SNPs per GPU, %d bp reference, %d truth keys, %d-threshold ROC%s"
+                               % (n_vcf, args.records, args.genome, t_unique, args.bins, ", records shuffled (radix-sort path)" if args.shuffled else ", position sorted"),
+                   "vcfs_per_gpu": n_vcf, "records_per_vcf": args.records, "parallelism": "vcf-shard x%d" % world,
+                   "collective": "1 all-reduce of [%d x 3 x %d] int64 per step" % (eng.n_truth, args.bins) if world > 1 else "none"},
+        "roofline": {"bound": "hbm", "kernel": "k_classify", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": tm["classify_ms"]},
+        "kernels_ms": tm,
+        "device_bytes": batch.device_bytes,
+    }
+
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        out["cpu_baseline"] = cpu_baseline(batch, args, min(args.cpu_sample, n_vcf), args.genome, args.truth, tseed)
+    if rank == 0:
+        print(json.dumps(out))
+    batch.close()
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(batch, args, n_sample, L, T, tseed):
+    """The oracle (single thread, C) on the first n_sample VCFs of this very batch; its
+    answers are also checked against the GPU's.  Reported, never used by the product."""
+    import numpy as np
+    from oracle import qm_oracle as O
+    from oracle.synth import synth_truth_keys
+    truth = synth_truth_keys(L, T, tseed)
+    cols = [batch.columns(v) for v in range(n_sample)]
+    roc = batch.roc()
+    t0 = time.perf_counter()
+    res = [O.classify_columns(*c, *truth, n_bins=args.bins) for c in cols]
+    dt = time.perf_counter() - t0
+    for v, (cls, oroc, sc) in enumerate(res):
+        assert np.array_equal(oroc, roc[v]), "GPU ROC row %d differs from the oracle" % v
+    assert np.array_equal(batch.cls(0), res[0][0]), "GPU class bits differ from the oracle"
+    n = float(sum(len(c[0]) for c in cols))
+    return {"value": n / dt, "unit": "classifications/s", "cores": 1, "kind": "port",
+            "sample": "first %d VCFs of the batch (%d records), oracle/qm_oracle.c classify_columns, 1 thread, %.1f s"
+                      % (n_sample, int(n), dt)}
+
+
+if __name__ == "__main__":
+    main()

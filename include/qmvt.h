@@ -1,0 +1,188 @@
+/*
+ * qmvt.h -- C ABI of libqmvt.so, the MI355X (gfx950) variant-truth engine.
+ *
+ * The reference (hzi-bifo/Quasimodo v0.4.2) has no FFI for this path: its
+ * boundary is a per-VCF process,
+ *     python program/extract_TP_FP_SNPs.py <vcf> <truth> {hcmv,custom} <outdir> <caller>
+ * (program/extract_TP_FP_SNPs.py:124-140, invoked by rules/extract_TP.smk:20 and
+ * eval_variant_custom.smk:73) that shells out to awk/grep.  Each entry point
+ * below names the reference stage it replaces.  All signatures are plain C:
+ * pointers + sizes, no C++/torch types.  Return value: 0 = QM_OK, negative =
+ * error (text via qm_last_error).  The library never falls back to a CPU
+ * implementation of the classification: without a usable HIP device every
+ * compute entry point fails with QM_E_NODEVICE.
+ *
+ * Column encoding (one record = one VCF data line):
+ *   pos   int32  POS, 0 <= pos < 2^28 (canonical decimal spelling on the text side)
+ *   ref   int32  0..3 = A,C,G,T; any other value = not a single-base allele
+ *   alt   int32  same
+ *   qual  float  "effective QUAL": floor(qual) >= t  <=>  the record passes the
+ *                awk test `$6>=t` (t = 0..n_bins-1); '.' and passing non-numeric
+ *                spellings are +inf, failing ones -inf
+ *   flags uint8  bit0 QM_F_PASS  = line kept by the A2 filter (extract_TP_FP_SNPs.py:24)
+ *                bit1 QM_F_IDDOT = ID column is exactly "."
+ */
+#ifndef QMVT_H
+#define QMVT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QM_ABI_VERSION 1
+
+#define QM_OK 0
+#define QM_E_INVAL (-1)     /* bad argument */
+#define QM_E_NODEVICE (-2)  /* no HIP device / HIP runtime failure at init */
+#define QM_E_HIP (-3)       /* a HIP call failed */
+#define QM_E_NOMEM (-4)
+#define QM_E_RANGE (-5)     /* position outside [0, 2^28) */
+#define QM_E_STATE (-6)     /* call order violated */
+#define QM_E_IO (-7)
+#define QM_E_NONCANON (-8)  /* text input the engine refuses to guess about (strict mode) */
+
+#define QM_F_PASS 1u
+#define QM_F_IDDOT 2u
+
+#define QM_CLS_KEPT 1u /* out_cls bit0: line is in <x>.filtered.vcf */
+#define QM_CLS_TP 2u   /* out_cls bit1: line is in tp/<x>.tp.vcf (else, if kept, fp/) */
+
+#define QM_MAX_BINS 256
+#define QM_POS_LIMIT (1 << 28)
+
+/* per-VCF scalar slots (int64 each) */
+enum {
+  QM_S_NPASS = 0,    /* kept lines = R `calleridentify` (caller_performance_compare.R:82) */
+  QM_S_TP_LINES = 1, /* data lines of tp.vcf  (fgrep -wf,  extract_TP_FP_SNPs.py:50) */
+  QM_S_FP_LINES = 2, /* data lines of fp.vcf  (fgrep -wvf, extract_TP_FP_SNPs.py:52) */
+  QM_S_TP_R = 3,     /* |unique(snp) & truth|  (caller_performance_compare.R:94) */
+  QM_S_FP_R = 4,     /* |unique(snp) \ truth|  (caller_performance_compare.R:95) */
+  QM_S_SORTED = 5,   /* 1 = positions non-decreasing as given, 0 = went through the radix sort */
+  QM_S_NREC = 6,     /* records in the VCF */
+  QM_S_TRUTH = 7,    /* distinct truth keys T' of the truth set used (FN_R = T' - TP_R) */
+  QM_N_SCALARS = 8
+};
+
+typedef struct qm_ctx qm_ctx;
+typedef struct qm_batch qm_batch;
+
+/* ---- lifecycle ------------------------------------------------------------ */
+int qm_abi_version(void);
+/* One context per process and GPU.  device_id indexes HIP devices (cuda:N in torch). */
+int qm_init(int device_id, qm_ctx** out);
+void qm_destroy(qm_ctx* ctx);
+/* Last error text of this thread (ctx may be NULL for errors raised before a ctx exists). */
+const char* qm_last_error(qm_ctx* ctx);
+
+/* ---- truth sets ------------------------------------------------------------
+ * Replaces the `awk ... {print $2,".",$4,$5}` pattern list fed to fgrep
+ * (extract_TP_FP_SNPs.py:47-48 hcmv, :92-93 custom): the engine keeps the set of
+ * single-base (pos,ref,alt) keys, sorted and de-duplicated, in HBM together
+ * with a coarse position index.  Host arrays are copied; rows whose ref/alt is
+ * not 0..3 are ignored (they can never match a kept line). */
+int qm_truth_load(qm_ctx* ctx, const int32_t* pos, const int32_t* ref, const int32_t* alt, int64_t n,
+                  int* truth_id);
+int qm_truth_size(qm_ctx* ctx, int truth_id, int64_t* n_unique);
+int qm_truth_count(qm_ctx* ctx);
+
+/* ---- one-shot, host buffers -------------------------------------------------
+ * What n_vcf invocations of the reference script compute (A2 flags in, A4/A5
+ * split + A6 counts + ROC out).  VCF v owns records rec_offsets[v]..rec_offsets[v+1].
+ * Unsorted VCFs are radix-sorted on the GPU transparently.  Blocking.
+ *   out_cls      [N]                QM_CLS_* per record, input order        (may be NULL)
+ *   out_roc      [n_vcf][3][n_bins] cumulative TP(t), FP(t), U(t); FN(t) = T' - U(t)
+ *   out_scalars  [n_vcf][QM_N_SCALARS]
+ *   out_idx      [N]  per VCF region: TP line indices ascending from the front,
+ *                     FP line indices ascending ending at the back           (may be NULL)
+ *   out_global   [n_truth_sets][3][n_bins] sums over the VCFs of each truth set (may be NULL)
+ */
+int qm_classify_batch(qm_ctx* ctx, int n_vcf, const int64_t* rec_offsets, const int32_t* pos,
+                      const int32_t* ref, const int32_t* alt, const float* qual, const uint8_t* flags,
+                      const int32_t* truth_id_per_vcf, int n_bins, uint8_t* out_cls, uint64_t* out_roc,
+                      int64_t* out_scalars, int32_t* out_idx, uint64_t* out_global);
+
+/* ---- resident batches (columns live in HBM across runs) -------------------- */
+int qm_batch_create(qm_ctx* ctx, int n_vcf, const int64_t* n_records, const int32_t* truth_id_per_vcf,
+                    int n_bins, qm_batch** out);
+void qm_batch_destroy(qm_batch* b);
+int qm_batch_upload(qm_batch* b, int vcf, const int32_t* pos, const int32_t* ref, const int32_t* alt,
+                    const float* qual, const uint8_t* flags);
+
+typedef struct qm_synth_cfg {
+  int64_t genome_len;   /* L: positions 1..L                                  */
+  uint64_t seed;        /* VCF v uses seed + v                                 */
+  uint64_t truth_seed;  /* must equal the seed passed to qm_truth_synth        */
+  int64_t truth_n;      /* T of that truth set                                  */
+  int32_t shuffled;     /* 0 = position sorted, 1 = records permuted            */
+  int32_t reserved;
+} qm_synth_cfg;
+/* Synthetic workload of BASELINE.json configs 3/4, generated on the device
+ * (DESIGN.md "Synthetic generator").  Every VCF of the batch is filled. */
+int qm_truth_synth(qm_ctx* ctx, int64_t genome_len, int64_t truth_n, uint64_t truth_seed, int* truth_id);
+int qm_batch_synth(qm_batch* b, const qm_synth_cfg* cfg);
+
+/* Enqueue the whole path on `stream` (a hipStream_t; NULL = the context's own
+ * stream): classify -> finalize (ROC suffix sums, tile offsets, per-truth sums)
+ * -> compaction of TP/FP line indices.  Asynchronous.  If global_dev is not
+ * NULL it must be a device buffer of [n_truth_sets][3][n_bins] uint64 that
+ * receives the per-truth sums (the caller all-reduces it across ranks). */
+int qm_batch_run(qm_batch* b, void* stream, void* global_dev);
+/* Wait for the stream, then redo VCFs found unsorted through the radix-sort path. */
+int qm_batch_finish(qm_batch* b, void* stream);
+/* Per-kernel device time, averaged over the (up to 32 latest) qm_batch_run calls made
+ * since qm_batch_set_timing(b, 1); HIP events recorded on the run's stream:
+ * ms[0]=classify ms[1]=finalize ms[2]=compact ms[3]=whole run. */
+int qm_batch_set_timing(qm_batch* b, int on);
+int qm_batch_timings(qm_batch* b, float* ms4);
+
+int qm_batch_get_cls(qm_batch* b, int vcf, uint8_t* out_cls);
+int qm_batch_get_idx(qm_batch* b, int vcf, int32_t* out_idx);
+int qm_batch_get_roc(qm_batch* b, uint64_t* out_roc /*[n_vcf][3][n_bins]*/);
+int qm_batch_get_scalars(qm_batch* b, int64_t* out /*[n_vcf][QM_N_SCALARS]*/);
+int qm_batch_get_global(qm_batch* b, uint64_t* out /*[n_truth_sets][3][n_bins]*/);
+int qm_batch_get_columns(qm_batch* b, int vcf, int32_t* pos, int32_t* ref, int32_t* alt, float* qual,
+                         uint8_t* flags);
+/* Bytes the engine holds in HBM for this batch. */
+int64_t qm_batch_device_bytes(qm_batch* b);
+
+/* ---- FP overlap (rules/compare_FP.smk + scripts/snpcaller_fp_compare.R:36-47) -
+ * n_sets (<= 5) key lists (fp.vcf rows as packed columns); regions[m] = number
+ * of distinct keys whose membership mask is m.  regions has 1 << n_sets slots. */
+int qm_fp_overlap(qm_ctx* ctx, int n_sets, const int64_t* set_offsets, const int32_t* pos,
+                  const int32_t* ref, const int32_t* alt, int64_t* regions);
+
+/* ---- host text side (no GPU): tokenizer / packer / writers ------------------
+ * Replaces the three awk passes + `grep -E "^#"` per VCF
+ * (extract_TP_FP_SNPs.py:24-32,50,52) with one scan.  qm_vcf_scan fills, for
+ * every line of the text (header lines included), its byte offset; for data
+ * lines the packed columns.  Returns the number of lines, or a negative code.
+ * line_kind: 0 = data, 1 = header ('#'), 2 = data line the engine refuses in
+ * strict mode (QM_E_NONCANON reasons).                        */
+typedef struct qm_vcf_cols {
+  int64_t n_lines;      /* all lines */
+  int64_t n_data;       /* data lines = records */
+  int64_t n_noncanon;   /* kept lines with locale-dependent / non-canonical matching */
+  int64_t first_noncanon_line; /* 1-based, 0 = none */
+} qm_vcf_cols;
+int64_t qm_vcf_count_lines(const uint8_t* text, size_t len);
+int qm_vcf_scan(const uint8_t* text, size_t len, int64_t cap_lines, int64_t* line_off /*cap+1*/,
+                uint8_t* line_kind, int32_t* pos, int32_t* ref, int32_t* alt, float* qual, uint8_t* flags,
+                qm_vcf_cols* info);
+/* Truth text -> key columns.  mode 0 = VCF as written by mummer2vcf.py
+ * (columns 2,4,5), mode 1 = 12-column show-snps TSV (columns 1,2,3).
+ * out_counts[0] = rows R counts as `genomediff`, [1] = keys emitted,
+ * [2] = rows with a pattern that can never match canonical lines, [3] = rows refused. */
+int64_t qm_truth_scan(const uint8_t* text, size_t len, int mode, int64_t cap, int32_t* pos, int32_t* ref,
+                      int32_t* alt, int64_t* out_counts);
+/* Writes header lines + selected data lines, verbatim, newline-terminated
+ * (SURVEY Q7).  select: 0 = kept (filtered.vcf), 1 = TP, 2 = FP. */
+int qm_vcf_write(const char* path, const uint8_t* text, size_t len, int64_t n_lines, const int64_t* line_off,
+                 const uint8_t* line_kind, const uint8_t* cls /*per data line*/, int select);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QMVT_H */

@@ -1,0 +1,110 @@
+"""ctypes loader for libqmvt.so (built in-tree by quasimodo_amd/csrc/Makefile)."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_SO = os.path.join(_CSRC, "libqmvt.so")
+
+QM_N_SCALARS = 8
+SCALAR_NAMES = ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R", "sorted", "n_records", "truth_unique")
+ERRORS = {-1: "QM_E_INVAL", -2: "QM_E_NODEVICE", -3: "QM_E_HIP", -4: "QM_E_NOMEM", -5: "QM_E_RANGE",
+          -6: "QM_E_STATE", -7: "QM_E_IO", -8: "QM_E_NONCANON"}
+
+# every symbol include/qmvt.h declares
+EXPORTS = (
+    "qm_abi_version", "qm_init", "qm_destroy", "qm_last_error", "qm_truth_load", "qm_truth_size", "qm_truth_count",
+    "qm_classify_batch", "qm_batch_create", "qm_batch_destroy", "qm_batch_upload", "qm_truth_synth", "qm_batch_synth",
+    "qm_batch_run", "qm_batch_finish", "qm_batch_set_timing", "qm_batch_timings", "qm_batch_get_cls", "qm_batch_get_idx",
+    "qm_batch_get_roc", "qm_batch_get_scalars", "qm_batch_get_global", "qm_batch_get_columns", "qm_batch_device_bytes",
+    "qm_fp_overlap", "qm_vcf_count_lines", "qm_vcf_scan", "qm_truth_scan", "qm_vcf_write",
+)
+
+
+class QmvtError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("%s (%d): %s" % (ERRORS.get(code, "QM_E_?"), code, message))
+        self.code = code
+
+
+class SynthCfg(C.Structure):
+    _fields_ = [("genome_len", C.c_int64), ("seed", C.c_uint64), ("truth_seed", C.c_uint64), ("truth_n", C.c_int64),
+                ("shuffled", C.c_int32), ("reserved", C.c_int32)]
+
+
+class VcfCols(C.Structure):
+    _fields_ = [("n_lines", C.c_int64), ("n_data", C.c_int64), ("n_noncanon", C.c_int64),
+                ("first_noncanon_line", C.c_int64)]
+
+
+def library_path():
+    return _SO
+
+
+def build_library(force=False):
+    """Compile libqmvt.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".cpp", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "qmvt.h"))
+    stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-s", "-C", _CSRC, "libqmvt.so"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Missing .so is a hard error: there is no Python/CPU substitute."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise QmvtError(-2, "libqmvt.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "or `make -C quasimodo_amd/csrc`" % _SO)
+    L = C.CDLL(_SO)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+    L.qm_abi_version.restype = i32
+    L.qm_last_error.restype = C.c_char_p
+    L.qm_last_error.argtypes = [vp]
+    L.qm_init.argtypes = [i32, C.POINTER(vp)]
+    L.qm_destroy.argtypes = [vp]
+    L.qm_destroy.restype = None
+    L.qm_truth_load.argtypes = [vp, vp, vp, vp, i64, C.POINTER(i32)]
+    L.qm_truth_synth.argtypes = [vp, i64, i64, C.c_uint64, C.POINTER(i32)]
+    L.qm_truth_size.argtypes = [vp, i32, C.POINTER(i64)]
+    L.qm_truth_count.argtypes = [vp]
+    L.qm_classify_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
+    L.qm_batch_create.argtypes = [vp, i32, vp, vp, i32, C.POINTER(vp)]
+    L.qm_batch_destroy.argtypes = [vp]
+    L.qm_batch_destroy.restype = None
+    L.qm_batch_upload.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+    L.qm_batch_synth.argtypes = [vp, C.POINTER(SynthCfg)]
+    L.qm_batch_run.argtypes = [vp, vp, vp]
+    L.qm_batch_finish.argtypes = [vp, vp]
+    L.qm_batch_set_timing.argtypes = [vp, i32]
+    L.qm_batch_timings.argtypes = [vp, C.POINTER(C.c_float)]
+    L.qm_batch_get_cls.argtypes = [vp, i32, vp]
+    L.qm_batch_get_idx.argtypes = [vp, i32, vp]
+    L.qm_batch_get_roc.argtypes = [vp, vp]
+    L.qm_batch_get_scalars.argtypes = [vp, vp]
+    L.qm_batch_get_global.argtypes = [vp, vp]
+    L.qm_batch_get_columns.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+    L.qm_batch_device_bytes.argtypes = [vp]
+    L.qm_batch_device_bytes.restype = i64
+    L.qm_fp_overlap.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+    L.qm_vcf_count_lines.argtypes = [C.c_char_p, C.c_size_t]
+    L.qm_vcf_count_lines.restype = i64
+    L.qm_vcf_scan.argtypes = [C.c_char_p, C.c_size_t, i64, vp, vp, vp, vp, vp, vp, vp, C.POINTER(VcfCols)]
+    L.qm_truth_scan.argtypes = [C.c_char_p, C.c_size_t, i32, i64, vp, vp, vp, vp]
+    L.qm_truth_scan.restype = i64
+    L.qm_vcf_write.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, i64, vp, vp, vp, i32]
+    _lib = L
+    return L
+
+
+def check(rc, ctx=None):
+    if rc < 0:
+        raise QmvtError(rc, lib().qm_last_error(ctx).decode("utf-8", "replace"))
+    return rc

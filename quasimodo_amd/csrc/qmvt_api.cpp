@@ -1,0 +1,705 @@
+// qmvt_api.cpp -- C ABI of libqmvt.so (include/qmvt.h): contexts, truth sets,
+// resident batches, the sort path for unsorted VCFs, FP overlap.  Host side of
+// the HIP engine; the text tokenizer/writers live in qmvt_host.cpp.
+//
+// There is deliberately no CPU implementation of the classification here: every
+// compute entry point needs a HIP device and fails loudly without one.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/qmvt.h"
+#include "qmvt_dev.h"
+
+using namespace qm;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) return fail(QM_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+struct Truth {
+  uint32_t* d_keys = nullptr;
+  int32_t* d_tidx = nullptr;
+  int32_t shift = 0, nb = 0;
+  int64_t n = 0;
+};
+
+struct qm_ctx {
+  int dev = 0;
+  hipStream_t stream = nullptr;
+  std::vector<Truth> truths;
+  TruthDev* d_truths = nullptr;  // device copy of the descriptors
+  int d_truths_cap = 0;
+};
+
+template <typename T>
+static int dalloc(T** p, size_t count) {
+  *p = nullptr;
+  if (count == 0) count = 1;
+  hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+  if (e != hipSuccess) return fail(QM_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+  return QM_OK;
+}
+#define DALLOC(p, n)                 \
+  do {                               \
+    int rc_ = dalloc(&(p), (n));     \
+    if (rc_ != QM_OK) return rc_;    \
+  } while (0)
+
+extern "C" int qm_abi_version(void) { return QM_ABI_VERSION; }
+extern "C" const char* qm_last_error(qm_ctx*) { return g_err.c_str(); }
+
+extern "C" int qm_init(int device_id, qm_ctx** out) {
+  if (!out) return fail(QM_E_INVAL, "qm_init: out is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(QM_E_NODEVICE, "qm_init: no HIP device (%s); the engine has no CPU fallback", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+  if (device_id < 0 || device_id >= n) return fail(QM_E_INVAL, "qm_init: device %d out of range (have %d)", device_id, n);
+  e = hipSetDevice(device_id);
+  if (e != hipSuccess) return fail(QM_E_NODEVICE, "hipSetDevice(%d): %s", device_id, hipGetErrorString(e));
+  qm_ctx* c = new qm_ctx();
+  c->dev = device_id;
+  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return fail(QM_E_NODEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
+  *out = c;
+  return QM_OK;
+}
+
+extern "C" void qm_destroy(qm_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->dev);
+  for (auto& t : c->truths) { (void)hipFree(t.d_keys); (void)hipFree(t.d_tidx); }
+  (void)hipFree(c->d_truths);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+// ---------------------------------------------------------------------------
+// truth sets
+// ---------------------------------------------------------------------------
+static int upload_truth_table(qm_ctx* c) {
+  const int n = (int)c->truths.size();
+  if (n > c->d_truths_cap) {
+    (void)hipFree(c->d_truths);
+    c->d_truths_cap = std::max(16, n * 2);
+    DALLOC(c->d_truths, (size_t)c->d_truths_cap);
+  }
+  std::vector<TruthDev> h((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    h[i].keys = c->truths[i].d_keys; h[i].tidx = c->truths[i].d_tidx;
+    h[i].shift = c->truths[i].shift; h[i].nb = c->truths[i].nb; h[i].n = c->truths[i].n;
+  }
+  HIPCHK(hipMemcpy(c->d_truths, h.data(), sizeof(TruthDev) * (size_t)n, hipMemcpyHostToDevice));
+  return QM_OK;
+}
+
+static int truth_from_keys(qm_ctx* c, std::vector<uint32_t>& keys, int* truth_id) {
+  std::sort(keys.begin(), keys.end());
+  keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+  Truth t;
+  t.n = (int64_t)keys.size();
+  const uint32_t maxpos = keys.empty() ? 0u : (keys.back() >> 4);
+  int shift = 0;
+  while ((maxpos >> shift) >= (1u << 16)) ++shift;  // <= 65536 buckets
+  t.shift = shift;
+  t.nb = (int32_t)(maxpos >> shift);
+  std::vector<int32_t> tidx((size_t)t.nb + 2);
+  {
+    size_t j = 0;
+    for (int32_t b = 0; b <= t.nb + 1; ++b) {
+      const uint64_t lim = ((uint64_t)b << shift) << 4;  // first key with pos >= b << shift
+      while (j < keys.size() && (uint64_t)keys[j] < lim) ++j;
+      tidx[(size_t)b] = (int32_t)j;
+    }
+    tidx[(size_t)t.nb + 1] = (int32_t)keys.size();
+  }
+  DALLOC(t.d_keys, keys.size());
+  DALLOC(t.d_tidx, tidx.size());
+  if (!keys.empty()) HIPCHK(hipMemcpy(t.d_keys, keys.data(), keys.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(t.d_tidx, tidx.data(), tidx.size() * 4, hipMemcpyHostToDevice));
+  c->truths.push_back(t);
+  int rc = upload_truth_table(c);
+  if (rc != QM_OK) return rc;
+  if (truth_id) *truth_id = (int)c->truths.size() - 1;
+  return QM_OK;
+}
+
+extern "C" int qm_truth_load(qm_ctx* c, const int32_t* pos, const int32_t* ref, const int32_t* alt, int64_t n, int* truth_id) {
+  if (!c) return fail(QM_E_INVAL, "qm_truth_load: ctx is NULL");
+  if (n < 0 || (n > 0 && (!pos || !ref || !alt))) return fail(QM_E_INVAL, "qm_truth_load: bad arguments");
+  HIPCHK(hipSetDevice(c->dev));
+  std::vector<uint32_t> keys;
+  keys.reserve((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    if ((uint32_t)ref[i] >= 4u || (uint32_t)alt[i] >= 4u) continue;  // can never match a kept line
+    if ((uint32_t)pos[i] >= (uint32_t)QM_POS_LIMIT)
+      return fail(QM_E_RANGE, "qm_truth_load: position %d of row %lld outside [0, 2^28)", pos[i], (long long)i);
+    keys.push_back(((uint32_t)pos[i] << 4) | ((uint32_t)ref[i] << 2) | (uint32_t)alt[i]);
+  }
+  return truth_from_keys(c, keys, truth_id);
+}
+
+extern "C" int qm_truth_synth(qm_ctx* c, int64_t L, int64_t T, uint64_t tseed, int* truth_id) {
+  if (!c) return fail(QM_E_INVAL, "qm_truth_synth: ctx is NULL");
+  if (T <= 0 || L <= 0 || L % T != 0 || L >= QM_POS_LIMIT) return fail(QM_E_INVAL, "qm_truth_synth: need T | L and L < 2^28");
+  HIPCHK(hipSetDevice(c->dev));
+  std::vector<uint32_t> keys((size_t)T);
+  for (int64_t j = 0; j < T; ++j) {
+    int32_t p, r, a;
+    synth_truth(L, T, tseed, j, &p, &r, &a);
+    keys[(size_t)j] = ((uint32_t)p << 4) | ((uint32_t)r << 2) | (uint32_t)a;
+  }
+  return truth_from_keys(c, keys, truth_id);
+}
+
+extern "C" int qm_truth_size(qm_ctx* c, int truth_id, int64_t* n_unique) {
+  if (!c || truth_id < 0 || truth_id >= (int)c->truths.size() || !n_unique) return fail(QM_E_INVAL, "qm_truth_size: bad arguments");
+  *n_unique = c->truths[(size_t)truth_id].n;
+  return QM_OK;
+}
+extern "C" int qm_truth_count(qm_ctx* c) { return c ? (int)c->truths.size() : 0; }
+
+// ---------------------------------------------------------------------------
+// batches
+// ---------------------------------------------------------------------------
+struct Layout {
+  std::vector<VcfDesc> vcfs;
+  std::vector<SpanDesc> spans;
+  std::vector<int32_t> tile_vcf;
+  int64_t n_pad = 0;     // records allocated
+  int64_t n_total = 0;   // records present
+  int64_t max_n = 0;
+};
+
+static void build_layout(const int64_t* n_records, const int32_t* truth_ids, int n_vcf, Layout& L) {
+  L.vcfs.assign((size_t)n_vcf, VcfDesc());
+  L.spans.clear();
+  L.tile_vcf.clear();
+  int64_t off = 0;
+  L.n_total = 0;
+  L.max_n = 0;
+  for (int v = 0; v < n_vcf; ++v) {
+    VcfDesc& d = L.vcfs[(size_t)v];
+    d.off = off;
+    d.n = n_records[v];
+    d.truth = truth_ids[v];
+    d.tile0 = (int32_t)L.tile_vcf.size();
+    d.ntiles = (int32_t)((d.n + K1_TILE - 1) / K1_TILE);
+    d.span0 = (int32_t)L.spans.size();
+    d.nspans = (d.ntiles + SPAN_TILES - 1) / SPAN_TILES;
+    d.pad = 0;
+    for (int t = 0; t < d.ntiles; ++t) L.tile_vcf.push_back(v);
+    for (int s = 0; s < d.nspans; ++s) {
+      SpanDesc sd;
+      sd.vcf = v;
+      sd.tile0 = d.tile0 + s * SPAN_TILES;
+      sd.begin = d.off + (int64_t)s * SPAN_TILES * K1_TILE;
+      sd.end = std::min(d.off + d.n, sd.begin + (int64_t)SPAN_TILES * K1_TILE);
+      L.spans.push_back(sd);
+    }
+    off += (d.n + VCF_ALIGN - 1) / VCF_ALIGN * VCF_ALIGN;
+    L.n_total += d.n;
+    L.max_n = std::max(L.max_n, d.n);
+  }
+  L.n_pad = off + K1_TILE;  // the last tile's vector loads may run past its VCF
+}
+
+struct qm_batch {
+  qm_ctx* ctx = nullptr;
+  int n_vcf = 0, n_bins = 256;
+  Layout L;
+  size_t cap_spans = 0, cap_tiles = 0;
+  // columns
+  int32_t *pos = nullptr, *ref = nullptr, *alt = nullptr;
+  float* qual = nullptr;
+  uint8_t* flags = nullptr;
+  // outputs / workspace
+  uint64_t *mask_pass = nullptr, *mask_tp = nullptr;
+  int32_t* idx = nullptr;
+  uint32_t *tile_tp = nullptr, *tile_fp = nullptr, *tile_tp_off = nullptr, *tile_fp_off = nullptr;
+  uint32_t *span_hist = nullptr, *span_scal = nullptr, *vcf_flags = nullptr;
+  uint64_t *roc = nullptr, *global_acc = nullptr;
+  int64_t* scalars = nullptr;
+  VcfDesc* d_vcfs = nullptr;
+  SpanDesc* d_spans = nullptr;
+  int32_t* d_tile_vcf = nullptr;
+  uint8_t* cls_scratch = nullptr;  // max_n bytes
+  int64_t dev_bytes = 0;
+  // sort path scratch (lazy)
+  qm_batch* sub = nullptr;
+  uint32_t *sk[2] = {nullptr, nullptr}, *sv[2] = {nullptr, nullptr}, *shist = nullptr;
+  // timing
+  bool timing = false;
+  static constexpr int EV_RING = 32;   // per-kernel events of the latest runs
+  hipEvent_t ev[EV_RING][4] = {};
+  int64_t n_timed = 0;
+  bool ran = false, finished = false;
+  uint64_t* last_global = nullptr;
+};
+
+static void batch_free(qm_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->ctx->dev);
+  if (b->sub) { batch_free(b->sub); b->sub = nullptr; }
+  void* ptrs[] = {b->pos, b->ref, b->alt, b->qual, b->flags, b->mask_pass, b->mask_tp, b->idx, b->tile_tp, b->tile_fp,
+                  b->tile_tp_off, b->tile_fp_off, b->span_hist, b->span_scal, b->vcf_flags, b->roc, b->global_acc,
+                  b->scalars, b->d_vcfs, b->d_spans, b->d_tile_vcf, b->cls_scratch, b->sk[0], b->sk[1], b->sv[0],
+                  b->sv[1], b->shist};
+  for (void* p : ptrs) (void)hipFree(p);
+  for (auto& r : b->ev) for (auto& e : r) if (e) (void)hipEventDestroy(e);
+  delete b;
+}
+
+static int upload_layout(qm_batch* b) {
+  const Layout& L = b->L;
+  HIPCHK(hipMemcpy(b->d_vcfs, L.vcfs.data(), sizeof(VcfDesc) * L.vcfs.size(), hipMemcpyHostToDevice));
+  if (!L.spans.empty()) HIPCHK(hipMemcpy(b->d_spans, L.spans.data(), sizeof(SpanDesc) * L.spans.size(), hipMemcpyHostToDevice));
+  if (!L.tile_vcf.empty()) HIPCHK(hipMemcpy(b->d_tile_vcf, L.tile_vcf.data(), 4 * L.tile_vcf.size(), hipMemcpyHostToDevice));
+  return QM_OK;
+}
+
+static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int32_t* truth_ids, int n_bins, qm_batch** out) {
+  qm_batch* b = new qm_batch();
+  b->ctx = c;
+  b->n_vcf = n_vcf;
+  b->n_bins = n_bins;
+  build_layout(n_records, truth_ids, n_vcf, b->L);
+  const Layout& L = b->L;
+  b->cap_spans = L.spans.size();
+  b->cap_tiles = L.tile_vcf.size();
+  const size_t np = (size_t)L.n_pad;
+  const size_t nt = std::max<size_t>(1, (size_t)c->truths.size());
+  int rc = QM_OK;
+#define A_(p, n) if (rc == QM_OK) { rc = dalloc(&(p), (n)); if (rc == QM_OK) b->dev_bytes += (int64_t)((n) * sizeof(*(p))); }
+  A_(b->pos, np) A_(b->ref, np) A_(b->alt, np) A_(b->qual, np) A_(b->flags, np)
+  A_(b->mask_pass, np / 64 + 64) A_(b->mask_tp, np / 64 + 64) A_(b->idx, np)
+  A_(b->tile_tp, b->cap_tiles) A_(b->tile_fp, b->cap_tiles) A_(b->tile_tp_off, b->cap_tiles) A_(b->tile_fp_off, b->cap_tiles)
+  A_(b->span_hist, b->cap_spans * 768) A_(b->span_scal, b->cap_spans * 8) A_(b->vcf_flags, (size_t)n_vcf)
+  A_(b->roc, (size_t)n_vcf * 3 * (size_t)n_bins) A_(b->global_acc, nt * 3 * (size_t)n_bins) A_(b->scalars, (size_t)n_vcf * 8)
+  A_(b->d_vcfs, (size_t)n_vcf) A_(b->d_spans, b->cap_spans) A_(b->d_tile_vcf, b->cap_tiles) A_(b->cls_scratch, (size_t)L.max_n)
+#undef A_
+  if (rc == QM_OK) rc = upload_layout(b);
+  if (rc == QM_OK) {
+    // padding lanes are masked in the kernels, but keep the columns defined
+    hipError_t e = hipMemset(b->flags, 0, np);
+    if (e == hipSuccess) e = hipMemset(b->pos, 0, np * 4);
+    if (e == hipSuccess) e = hipMemset(b->ref, 0, np * 4);
+    if (e == hipSuccess) e = hipMemset(b->alt, 0, np * 4);
+    if (e == hipSuccess) e = hipMemset(b->qual, 0, np * 4);
+    if (e != hipSuccess) rc = fail(QM_E_HIP, "hipMemset: %s", hipGetErrorString(e));
+  }
+  if (rc != QM_OK) { batch_free(b); return rc; }
+  *out = b;
+  return QM_OK;
+}
+
+extern "C" int qm_batch_create(qm_ctx* c, int n_vcf, const int64_t* n_records, const int32_t* truth_id_per_vcf, int n_bins,
+                               qm_batch** out) {
+  if (!c || !out || n_vcf <= 0 || !n_records || !truth_id_per_vcf) return fail(QM_E_INVAL, "qm_batch_create: bad arguments");
+  if (n_bins < 1 || n_bins > QM_MAX_BINS) return fail(QM_E_INVAL, "qm_batch_create: n_bins must be 1..256");
+  *out = nullptr;
+  for (int v = 0; v < n_vcf; ++v) {
+    if (n_records[v] < 0 || n_records[v] > 0x7fffff00ll) return fail(QM_E_INVAL, "qm_batch_create: VCF %d has %lld records", v, (long long)n_records[v]);
+    if (truth_id_per_vcf[v] < 0 || truth_id_per_vcf[v] >= (int)c->truths.size())
+      return fail(QM_E_INVAL, "qm_batch_create: VCF %d names truth set %d (have %zu)", v, truth_id_per_vcf[v], c->truths.size());
+  }
+  HIPCHK(hipSetDevice(c->dev));
+  return batch_alloc(c, n_vcf, n_records, truth_id_per_vcf, n_bins, out);
+}
+
+extern "C" void qm_batch_destroy(qm_batch* b) { batch_free(b); }
+extern "C" int64_t qm_batch_device_bytes(qm_batch* b) { return b ? b->dev_bytes : 0; }
+
+extern "C" int qm_batch_upload(qm_batch* b, int v, const int32_t* pos, const int32_t* ref, const int32_t* alt, const float* qual,
+                               const uint8_t* flags) {
+  if (!b || v < 0 || v >= b->n_vcf) return fail(QM_E_INVAL, "qm_batch_upload: bad arguments");
+  const VcfDesc& d = b->L.vcfs[(size_t)v];
+  if (d.n == 0) return QM_OK;
+  if (!pos || !ref || !alt || !qual || !flags) return fail(QM_E_INVAL, "qm_batch_upload: NULL column");
+  HIPCHK(hipSetDevice(b->ctx->dev));
+  const size_t n = (size_t)d.n;
+  HIPCHK(hipMemcpy(b->pos + d.off, pos, n * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->ref + d.off, ref, n * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->alt + d.off, alt, n * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->qual + d.off, qual, n * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(b->flags + d.off, flags, n, hipMemcpyHostToDevice));
+  b->ran = b->finished = false;
+  return QM_OK;
+}
+
+static uint64_t gcd64(uint64_t a, uint64_t b) { while (b) { uint64_t t = a % b; a = b; b = t; } return a; }
+
+extern "C" int qm_batch_synth(qm_batch* b, const qm_synth_cfg* cfg) {
+  if (!b || !cfg) return fail(QM_E_INVAL, "qm_batch_synth: bad arguments");
+  const Layout& L = b->L;
+  for (const VcfDesc& d : L.vcfs) {
+    if (d.n <= 0 || cfg->genome_len % d.n != 0) return fail(QM_E_INVAL, "qm_batch_synth: records per VCF must divide genome_len");
+    if ((cfg->genome_len / cfg->truth_n) % (cfg->genome_len / d.n) != 0)
+      return fail(QM_E_INVAL, "qm_batch_synth: VCF stratum width must divide the truth stratum width");
+  }
+  if (cfg->truth_n <= 0 || cfg->genome_len % cfg->truth_n != 0 || cfg->genome_len >= QM_POS_LIMIT)
+    return fail(QM_E_INVAL, "qm_batch_synth: need truth_n | genome_len < 2^28");
+  HIPCHK(hipSetDevice(b->ctx->dev));
+  SynthParams S;
+  S.vcfs = b->d_vcfs; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
+  S.genome_len = cfg->genome_len; S.truth_n = cfg->truth_n; S.truth_seed = cfg->truth_seed; S.seed = cfg->seed;
+  S.shuffled = cfg->shuffled;
+  // slot i holds generated record (i * a + b) mod n, a coprime to every n in the batch
+  uint64_t a = 2654435761ull;
+  for (;;) {
+    bool ok = true;
+    for (const VcfDesc& d : L.vcfs) if (gcd64(a, (uint64_t)d.n) != 1) { ok = false; break; }
+    if (ok) break;
+    a += 2;
+  }
+  S.perm_a = a; S.perm_b = 12345;
+  launch_synth(S, b->n_vcf, L.max_n, b->ctx->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(b->ctx->stream));
+  b->ran = b->finished = false;
+  return QM_OK;
+}
+
+static ClassifyParams classify_params(qm_batch* b) {
+  ClassifyParams P;
+  P.pos = b->pos; P.ref = b->ref; P.alt = b->alt; P.qual = b->qual; P.flags = b->flags;
+  P.spans = b->d_spans; P.vcfs = b->d_vcfs; P.truths = b->ctx->d_truths;
+  P.mask_pass = b->mask_pass; P.mask_tp = b->mask_tp; P.tile_tp = b->tile_tp; P.tile_fp = b->tile_fp;
+  P.span_hist = b->span_hist; P.span_scal = b->span_scal; P.n_bins = b->n_bins;
+  return P;
+}
+static FinalizeParams finalize_params(qm_batch* b, uint64_t* global) {
+  FinalizeParams F;
+  F.vcfs = b->d_vcfs; F.truths = b->ctx->d_truths; F.span_hist = b->span_hist; F.span_scal = b->span_scal;
+  F.tile_tp = b->tile_tp; F.tile_fp = b->tile_fp; F.tile_tp_off = b->tile_tp_off; F.tile_fp_off = b->tile_fp_off;
+  F.roc = b->roc; F.scalars = b->scalars; F.vcf_flags = b->vcf_flags; F.global_acc = global; F.n_bins = b->n_bins;
+  return F;
+}
+static CompactParams compact_params(qm_batch* b) {
+  CompactParams C;
+  C.vcfs = b->d_vcfs; C.tile_vcf = b->d_tile_vcf; C.mask_pass = b->mask_pass; C.mask_tp = b->mask_tp;
+  C.tile_fp = b->tile_fp; C.tile_tp_off = b->tile_tp_off; C.tile_fp_off = b->tile_fp_off; C.idx = b->idx;
+  return C;
+}
+
+extern "C" int qm_batch_set_timing(qm_batch* b, int on) {
+  if (!b) return fail(QM_E_INVAL, "qm_batch_set_timing: NULL batch");
+  HIPCHK(hipSetDevice(b->ctx->dev));
+  b->timing = on != 0;
+  b->n_timed = 0;   // averages restart
+  if (b->timing && !b->ev[0][0]) for (auto& r : b->ev) for (auto& e : r) HIPCHK(hipEventCreate(&e));
+  return QM_OK;
+}
+
+extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
+  if (!b) return fail(QM_E_INVAL, "qm_batch_run: NULL batch");
+  qm_ctx* c = b->ctx;
+  HIPCHK(hipSetDevice(c->dev));
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  uint64_t* g = global_dev ? (uint64_t*)global_dev : b->global_acc;
+  const size_t gbytes = std::max<size_t>(1, c->truths.size()) * 3 * (size_t)b->n_bins * 8;
+  HIPCHK(hipMemsetAsync(g, 0, gbytes, st));
+  hipEvent_t* ev = b->ev[b->n_timed % qm_batch::EV_RING];
+  if (b->timing) HIPCHK(hipEventRecord(ev[0], st));
+  launch_classify(classify_params(b), (int)b->L.spans.size(), st);
+  if (b->timing) HIPCHK(hipEventRecord(ev[1], st));
+  launch_finalize(finalize_params(b, g), b->n_vcf, st);
+  if (b->timing) HIPCHK(hipEventRecord(ev[2], st));
+  launch_compact(compact_params(b), (int)b->L.tile_vcf.size(), st);
+  if (b->timing) { HIPCHK(hipEventRecord(ev[3], st)); b->n_timed++; }
+  HIPCHK(hipGetLastError());
+  b->ran = true;
+  b->finished = false;
+  b->last_global = g;
+  return QM_OK;
+}
+
+extern "C" int qm_batch_timings(qm_batch* b, float* ms4) {
+  if (!b || !ms4 || !b->timing || b->n_timed == 0) return fail(QM_E_STATE, "qm_batch_timings: timing is off or nothing ran");
+  HIPCHK(hipSetDevice(b->ctx->dev));
+  const int n = (int)std::min<int64_t>(b->n_timed, qm_batch::EV_RING);
+  double acc[4] = {0, 0, 0, 0};
+  for (int i = 0; i < n; ++i) {   // averages over the latest runs since qm_batch_set_timing(1)
+    hipEvent_t* ev = b->ev[(b->n_timed - 1 - i) % qm_batch::EV_RING];
+    HIPCHK(hipEventSynchronize(ev[3]));
+    float t;
+    HIPCHK(hipEventElapsedTime(&t, ev[0], ev[1])); acc[0] += t;
+    HIPCHK(hipEventElapsedTime(&t, ev[1], ev[2])); acc[1] += t;
+    HIPCHK(hipEventElapsedTime(&t, ev[2], ev[3])); acc[2] += t;
+    HIPCHK(hipEventElapsedTime(&t, ev[0], ev[3])); acc[3] += t;
+  }
+  for (int k = 0; k < 4; ++k) ms4[k] = (float)(acc[k] / n);
+  return QM_OK;
+}
+
+// ---- sort path: one unsorted VCF at a time through a scratch sub-batch ------
+static int ensure_sort_scratch(qm_batch* b) {
+  if (b->sub) return QM_OK;
+  const int64_t n = b->L.max_n;
+  int32_t t0 = 0;
+  int rc = batch_alloc(b->ctx, 1, &n, &t0, b->n_bins, &b->sub);
+  if (rc != QM_OK) return rc;
+  b->dev_bytes += b->sub->dev_bytes;
+  const size_t ntiles = (size_t)((n + SORT_TILE - 1) / SORT_TILE);
+  for (int i = 0; i < 2; ++i) { DALLOC(b->sk[i], (size_t)n); DALLOC(b->sv[i], (size_t)n); }
+  DALLOC(b->shist, ntiles * 256);
+  b->dev_bytes += (int64_t)n * 16 + (int64_t)ntiles * 1024;
+  return QM_OK;
+}
+
+static int sort_one_vcf(qm_batch* b, int v, hipStream_t st, uint64_t* global) {
+  const VcfDesc d = b->L.vcfs[(size_t)v];
+  qm_batch* s = b->sub;
+  // 1. stable LSD radix sort of (pos, original index)
+  launch_sort_init(b->pos, d.off, d.n, b->sk[0], b->sv[0], st);
+  int cur = 0;
+  for (int shift = 0; shift < 32; shift += 8) {  // positions are < 2^28: four 8-bit digits
+    launch_sort_pass(b->sk[cur], b->sv[cur], d.n, shift, b->shist, b->sk[cur ^ 1], b->sv[cur ^ 1], st);
+    cur ^= 1;
+  }
+  const uint32_t* perm = b->sv[cur];
+  // 2. sorted copy of the VCF in the scratch batch, same truth set
+  int32_t tid = d.truth;
+  int64_t n = d.n;
+  build_layout(&n, &tid, 1, s->L);
+  int rc = upload_layout(s);
+  if (rc != QM_OK) return rc;
+  launch_sort_gather(b->pos, b->ref, b->alt, b->qual, b->flags, d.off, perm, d.n, s->pos, s->ref, s->alt, s->qual, s->flags, 0, st);
+  // 3. the normal path on the sorted copy; its ROC row is added to the caller's per-truth sums
+  launch_classify(classify_params(s), (int)s->L.spans.size(), st);
+  launch_finalize(finalize_params(s, global), 1, st);
+  // 4. results back under the original VCF: ROC + scalars rows, class bits in input order
+  HIPCHK(hipMemcpyAsync(b->roc + (size_t)v * 3 * b->n_bins, s->roc, (size_t)3 * b->n_bins * 8, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->scalars + (size_t)v * 8, s->scalars, 8 * 8, hipMemcpyDeviceToDevice, st));
+  launch_sort_scatter_cls(s->mask_pass, s->mask_tp, 0, perm, d.n, b->cls_scratch, st);
+  launch_cls_to_masks(b->cls_scratch, d.off, d.n, b->mask_pass, b->mask_tp, b->tile_tp, b->tile_fp, d.tile0, st);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  // the scratch run saw sorted data: record that the original was not
+  uint32_t sflags = 0;
+  HIPCHK(hipMemcpy(&sflags, s->vcf_flags, 4, hipMemcpyDeviceToHost));
+  if (sflags & SPANF_UNSORTED) return fail(QM_E_HIP, "internal: VCF %d still unsorted after the radix sort", v);
+  const int64_t zero = 0;
+  HIPCHK(hipMemcpy(b->scalars + (size_t)v * 8 + QM_S_SORTED, &zero, 8, hipMemcpyHostToDevice));
+  return QM_OK;
+}
+
+// re-derive tile offsets + compaction for every VCF (cheap: masks only)
+static int rescan_and_compact(qm_batch* b, hipStream_t st);
+
+extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
+  if (!b || !b->ran) return fail(QM_E_STATE, "qm_batch_finish: nothing was run");
+  qm_ctx* c = b->ctx;
+  HIPCHK(hipSetDevice(c->dev));
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  HIPCHK(hipStreamSynchronize(st));
+  if (b->finished) return QM_OK;
+  std::vector<uint32_t> fl((size_t)b->n_vcf);
+  HIPCHK(hipMemcpy(fl.data(), b->vcf_flags, 4 * fl.size(), hipMemcpyDeviceToHost));
+  std::vector<int> todo;
+  for (int v = 0; v < b->n_vcf; ++v) {
+    if (fl[(size_t)v] & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", v);
+    if (fl[(size_t)v] & SPANF_UNSORTED) todo.push_back(v);
+  }
+  if (!todo.empty()) {
+    int rc = ensure_sort_scratch(b);
+    if (rc != QM_OK) return rc;
+    for (int v : todo) {
+      rc = sort_one_vcf(b, v, st, b->last_global);
+      if (rc != QM_OK) return rc;
+    }
+    rc = rescan_and_compact(b, st);
+    if (rc != QM_OK) return rc;
+  }
+  b->finished = true;
+  return QM_OK;
+}
+
+// k_finalize recomputes the offsets of every tile; to keep ROC rows and per-truth
+// sums untouched it runs on a throw-away output set.
+static int rescan_and_compact(qm_batch* b, hipStream_t st) {
+  uint64_t* tmp_roc = nullptr;
+  int64_t* tmp_scal = nullptr;
+  uint32_t* tmp_flags = nullptr;
+  DALLOC(tmp_roc, (size_t)b->n_vcf * 3 * (size_t)b->n_bins);
+  DALLOC(tmp_scal, (size_t)b->n_vcf * 8);
+  DALLOC(tmp_flags, (size_t)b->n_vcf);
+  FinalizeParams F = finalize_params(b, nullptr);
+  F.roc = tmp_roc; F.scalars = tmp_scal; F.vcf_flags = tmp_flags;
+  launch_finalize(F, b->n_vcf, st);
+  launch_compact(compact_params(b), (int)b->L.tile_vcf.size(), st);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(tmp_roc); (void)hipFree(tmp_scal); (void)hipFree(tmp_flags);
+  if (e != hipSuccess) return fail(QM_E_HIP, "rescan/compact: %s", hipGetErrorString(e));
+  return QM_OK;
+}
+
+// ---- getters ------------------------------------------------------------------
+#define NEED_FINISHED(b, name) \
+  if (!(b) || !(b)->finished) return fail(QM_E_STATE, name ": call qm_batch_run + qm_batch_finish first")
+
+extern "C" int qm_batch_get_cls(qm_batch* b, int v, uint8_t* out) {
+  NEED_FINISHED(b, "qm_batch_get_cls");
+  if (v < 0 || v >= b->n_vcf || !out) return fail(QM_E_INVAL, "qm_batch_get_cls: bad arguments");
+  HIPCHK(hipSetDevice(b->ctx->dev));
+  const VcfDesc& d = b->L.vcfs[(size_t)v];
+  if (d.n == 0) return QM_OK;
+  launch_masks_to_cls(b->mask_pass, b->mask_tp, d.off, d.n, b->cls_scratch, b->ctx->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, b->cls_scratch, (size_t)d.n, hipMemcpyDeviceToHost, b->ctx->stream));
+  HIPCHK(hipStreamSynchronize(b->ctx->stream));
+  return QM_OK;
+}
+extern "C" int qm_batch_get_idx(qm_batch* b, int v, int32_t* out) {
+  NEED_FINISHED(b, "qm_batch_get_idx");
+  if (v < 0 || v >= b->n_vcf || !out) return fail(QM_E_INVAL, "qm_batch_get_idx: bad arguments");
+  HIPCHK(hipSetDevice(b->ctx->dev));
+  const VcfDesc& d = b->L.vcfs[(size_t)v];
+  if (d.n) HIPCHK(hipMemcpy(out, b->idx + d.off, (size_t)d.n * 4, hipMemcpyDeviceToHost));
+  return QM_OK;
+}
+extern "C" int qm_batch_get_roc(qm_batch* b, uint64_t* out) {
+  NEED_FINISHED(b, "qm_batch_get_roc");
+  HIPCHK(hipSetDevice(b->ctx->dev));
+  HIPCHK(hipMemcpy(out, b->roc, (size_t)b->n_vcf * 3 * (size_t)b->n_bins * 8, hipMemcpyDeviceToHost));
+  return QM_OK;
+}
+extern "C" int qm_batch_get_scalars(qm_batch* b, int64_t* out) {
+  NEED_FINISHED(b, "qm_batch_get_scalars");
+  HIPCHK(hipSetDevice(b->ctx->dev));
+  HIPCHK(hipMemcpy(out, b->scalars, (size_t)b->n_vcf * 8 * 8, hipMemcpyDeviceToHost));
+  return QM_OK;
+}
+extern "C" int qm_batch_get_global(qm_batch* b, uint64_t* out) {
+  NEED_FINISHED(b, "qm_batch_get_global");
+  HIPCHK(hipSetDevice(b->ctx->dev));
+  HIPCHK(hipMemcpy(out, b->last_global, b->ctx->truths.size() * 3 * (size_t)b->n_bins * 8, hipMemcpyDeviceToHost));
+  return QM_OK;
+}
+extern "C" int qm_batch_get_columns(qm_batch* b, int v, int32_t* pos, int32_t* ref, int32_t* alt, float* qual, uint8_t* flags) {
+  if (!b || v < 0 || v >= b->n_vcf) return fail(QM_E_INVAL, "qm_batch_get_columns: bad arguments");
+  HIPCHK(hipSetDevice(b->ctx->dev));
+  const VcfDesc& d = b->L.vcfs[(size_t)v];
+  const size_t n = (size_t)d.n;
+  if (!n) return QM_OK;
+  if (pos) HIPCHK(hipMemcpy(pos, b->pos + d.off, n * 4, hipMemcpyDeviceToHost));
+  if (ref) HIPCHK(hipMemcpy(ref, b->ref + d.off, n * 4, hipMemcpyDeviceToHost));
+  if (alt) HIPCHK(hipMemcpy(alt, b->alt + d.off, n * 4, hipMemcpyDeviceToHost));
+  if (qual) HIPCHK(hipMemcpy(qual, b->qual + d.off, n * 4, hipMemcpyDeviceToHost));
+  if (flags) HIPCHK(hipMemcpy(flags, b->flags + d.off, n, hipMemcpyDeviceToHost));
+  return QM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// one-shot host-buffer entry point
+// ---------------------------------------------------------------------------
+extern "C" int qm_classify_batch(qm_ctx* c, int n_vcf, const int64_t* rec_offsets, const int32_t* pos, const int32_t* ref,
+                                 const int32_t* alt, const float* qual, const uint8_t* flags, const int32_t* truth_id_per_vcf,
+                                 int n_bins, uint8_t* out_cls, uint64_t* out_roc, int64_t* out_scalars, int32_t* out_idx,
+                                 uint64_t* out_global) {
+  if (!c || n_vcf <= 0 || !rec_offsets || !truth_id_per_vcf) return fail(QM_E_INVAL, "qm_classify_batch: bad arguments");
+  std::vector<int64_t> n((size_t)n_vcf);
+  for (int v = 0; v < n_vcf; ++v) {
+    n[(size_t)v] = rec_offsets[v + 1] - rec_offsets[v];
+    if (n[(size_t)v] < 0) return fail(QM_E_INVAL, "qm_classify_batch: rec_offsets must be non-decreasing");
+  }
+  qm_batch* b = nullptr;
+  int rc = qm_batch_create(c, n_vcf, n.data(), truth_id_per_vcf, n_bins, &b);
+  if (rc != QM_OK) return rc;
+  for (int v = 0; v < n_vcf && rc == QM_OK; ++v) {
+    const int64_t o = rec_offsets[v];
+    rc = qm_batch_upload(b, v, pos + o, ref + o, alt + o, qual + o, flags + o);
+  }
+  if (rc == QM_OK) rc = qm_batch_run(b, nullptr, nullptr);
+  if (rc == QM_OK) rc = qm_batch_finish(b, nullptr);
+  for (int v = 0; v < n_vcf && rc == QM_OK; ++v) {
+    if (out_cls) rc = qm_batch_get_cls(b, v, out_cls + rec_offsets[v]);
+    if (rc == QM_OK && out_idx) rc = qm_batch_get_idx(b, v, out_idx + rec_offsets[v]);
+  }
+  if (rc == QM_OK && out_roc) rc = qm_batch_get_roc(b, out_roc);
+  if (rc == QM_OK && out_scalars) rc = qm_batch_get_scalars(b, out_scalars);
+  if (rc == QM_OK && out_global) rc = qm_batch_get_global(b, out_global);
+  std::string keep = g_err;
+  qm_batch_destroy(b);
+  g_err = keep;
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
+// FP overlap (A7)
+// ---------------------------------------------------------------------------
+extern "C" int qm_fp_overlap(qm_ctx* c, int n_sets, const int64_t* set_offsets, const int32_t* pos, const int32_t* ref,
+                             const int32_t* alt, int64_t* regions) {
+  if (!c || n_sets < 1 || n_sets > 5 || !set_offsets || !regions) return fail(QM_E_INVAL, "qm_fp_overlap: bad arguments");
+  HIPCHK(hipSetDevice(c->dev));
+  const int64_t n = set_offsets[n_sets] - set_offsets[0];
+  const int nreg = 1 << n_sets;
+  for (int i = 0; i < nreg; ++i) regions[i] = 0;
+  if (n <= 0) return QM_OK;
+  if (n > 0x7fffff00ll) return fail(QM_E_INVAL, "qm_fp_overlap: too many keys");
+  std::vector<int32_t> set_of((size_t)n);
+  for (int s = 0; s < n_sets; ++s)
+    for (int64_t i = set_offsets[s]; i < set_offsets[s + 1]; ++i) set_of[(size_t)(i - set_offsets[0])] = s;
+  const int64_t o = set_offsets[0];
+  int32_t *dp = nullptr, *dr = nullptr, *da = nullptr, *ds = nullptr;
+  uint32_t *k[2] = {nullptr, nullptr}, *v[2] = {nullptr, nullptr}, *hist = nullptr, *bad = nullptr;
+  unsigned long long* dreg = nullptr;
+  int rc = QM_OK;
+  auto cleanup = [&]() {
+    void* ps[] = {dp, dr, da, ds, k[0], k[1], v[0], v[1], hist, bad, dreg};
+    for (void* p : ps) (void)hipFree(p);
+  };
+#define A_(p, cnt) if (rc == QM_OK) rc = dalloc(&(p), (size_t)(cnt));
+  A_(dp, n) A_(dr, n) A_(da, n) A_(ds, n) A_(k[0], n) A_(k[1], n) A_(v[0], n) A_(v[1], n)
+  A_(hist, (size_t)((n + SORT_TILE - 1) / SORT_TILE) * 256) A_(bad, 1) A_(dreg, nreg)
+#undef A_
+  if (rc != QM_OK) { cleanup(); return rc; }
+  hipStream_t st = c->stream;
+  hipError_t e = hipMemcpy(dp, pos + o, (size_t)n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dr, ref + o, (size_t)n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(da, alt + o, (size_t)n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(ds, set_of.data(), (size_t)n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemsetAsync(bad, 0, 4, st);
+  if (e == hipSuccess) e = hipMemsetAsync(dreg, 0, sizeof(unsigned long long) * (size_t)nreg, st);
+  if (e != hipSuccess) { cleanup(); return fail(QM_E_HIP, "qm_fp_overlap: %s", hipGetErrorString(e)); }
+  launch_overlap_pack(dp, dr, da, ds, n, k[0], v[0], bad, st);
+  int cur = 0;
+  for (int shift = 0; shift < 32; shift += 8) {
+    launch_sort_pass(k[cur], v[cur], n, shift, hist, k[cur ^ 1], v[cur ^ 1], st);
+    cur ^= 1;
+  }
+  launch_overlap_count(k[cur], v[cur], n, dreg, st);
+  std::vector<unsigned long long> hreg((size_t)nreg);
+  uint32_t hbad = 0;
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e == hipSuccess) e = hipMemcpy(hreg.data(), dreg, sizeof(unsigned long long) * (size_t)nreg, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(&hbad, bad, 4, hipMemcpyDeviceToHost);
+  cleanup();
+  if (e != hipSuccess) return fail(QM_E_HIP, "qm_fp_overlap: %s", hipGetErrorString(e));
+  if (hbad) return fail(QM_E_INVAL, "qm_fp_overlap: a key is not a single-base variant with 0 <= pos < 2^28");
+  for (int i = 0; i < nreg; ++i) regions[i] = (int64_t)hreg[(size_t)i];
+  return QM_OK;
+}

@@ -1,0 +1,177 @@
+// qmvt_dev.h -- structures shared by the kernels (qmvt_kernels.hip) and the
+// C-ABI host side (qmvt_api.cpp).  Internal; the public surface is include/qmvt.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace qm {
+
+constexpr int K1_BLOCK = 256;
+constexpr int K1_WAVES = 4;
+constexpr int K1_ROUNDS = 2;                       // 4 consecutive records per lane per round
+constexpr int K1_TILE = K1_BLOCK * 4 * K1_ROUNDS;  // 2048 records
+constexpr int K1_SLICE = 2048;                     // truth keys staged in LDS per pass
+constexpr int SPAN_TILES = 8;                      // tiles per workgroup (one histogram flush per span)
+constexpr int VCF_ALIGN = 256;                     // device start of every VCF (records)
+constexpr int SORT_TILE = 2048;
+constexpr int QM_POS_LIMIT_DEV = 1 << 28;
+
+constexpr uint32_t QMF_PASS = 1u;
+constexpr uint32_t QMF_IDDOT = 2u;
+constexpr uint32_t SPANF_UNSORTED = 1u;
+constexpr uint32_t SPANF_BADPOS = 2u;
+
+struct TruthDev {
+  const uint32_t* keys;  // sorted distinct pos<<4 | ref<<2 | alt
+  const int32_t* tidx;   // tidx[b] = first key index with pos >= b << shift; nb + 2 entries
+  int32_t shift;
+  int32_t nb;
+  int64_t n;
+};
+
+struct VcfDesc {
+  int64_t off;  // first record (device index, multiple of VCF_ALIGN)
+  int64_t n;    // records
+  int32_t truth;
+  int32_t tile0, ntiles;
+  int32_t span0, nspans;
+  int32_t pad;
+};
+
+struct SpanDesc {
+  int64_t begin, end;  // device record indices, one VCF
+  int32_t vcf;
+  int32_t tile0;       // global index of the first tile
+};
+
+struct ClassifyParams {
+  const int32_t* pos;
+  const int32_t* ref;
+  const int32_t* alt;
+  const float* qual;
+  const uint8_t* flags;
+  const SpanDesc* spans;
+  const VcfDesc* vcfs;
+  const TruthDev* truths;
+  uint64_t* mask_pass;
+  uint64_t* mask_tp;
+  uint32_t* tile_tp;
+  uint32_t* tile_fp;
+  uint32_t* span_hist;  // [n_spans][3][256]
+  uint32_t* span_scal;  // [n_spans][8]
+  int32_t n_bins;
+};
+
+struct FinalizeParams {
+  const VcfDesc* vcfs;
+  const TruthDev* truths;
+  const uint32_t* span_hist;
+  const uint32_t* span_scal;
+  const uint32_t* tile_tp;
+  const uint32_t* tile_fp;
+  uint32_t* tile_tp_off;
+  uint32_t* tile_fp_off;
+  uint64_t* roc;      // [n_vcf][3][n_bins]
+  int64_t* scalars;   // [n_vcf][8]
+  uint32_t* vcf_flags;
+  uint64_t* global_acc;  // [n_truth][3][n_bins] or null
+  int32_t n_bins;
+};
+
+struct CompactParams {
+  const VcfDesc* vcfs;
+  const int32_t* tile_vcf;
+  const uint64_t* mask_pass;
+  const uint64_t* mask_tp;
+  const uint32_t* tile_fp;
+  const uint32_t* tile_tp_off;
+  const uint32_t* tile_fp_off;
+  int32_t* idx;
+};
+
+struct SynthParams {
+  const VcfDesc* vcfs;
+  int32_t* pos;
+  int32_t* ref;
+  int32_t* alt;
+  float* qual;
+  uint8_t* flags;
+  int64_t genome_len;
+  int64_t truth_n;
+  uint64_t truth_seed;
+  uint64_t seed;
+  uint64_t perm_a, perm_b;
+  int32_t shuffled;
+};
+
+// ---- synthetic workload: the same arithmetic on host and device -------------
+__host__ __device__ inline uint64_t mix64(uint64_t x) {  // splitmix64 finalizer
+  x += 0x9e3779b97f4a7c15ull;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+__host__ __device__ inline uint64_t hash3(uint64_t seed, uint64_t a, uint64_t b) {
+  return mix64(mix64(seed ^ 0x51ed270b7f3c9a11ull) + a * 0x9e3779b97f4a7c15ull + b * 0xc2b2ae3d27d4eb4full);
+}
+__host__ __device__ inline int32_t synth_refbase(int64_t p) { return (int32_t)(hash3(3, (uint64_t)p, 0) & 3u); }
+// truth entry j of T over genome L: one position per stratum of width L / T
+__host__ __device__ inline void synth_truth(int64_t L, int64_t T, uint64_t tseed, int64_t j, int32_t* p, int32_t* r,
+                                             int32_t* a) {
+  const int64_t wt = L / T;
+  const uint64_t h = hash3(tseed, (uint64_t)j, 1);
+  const int64_t pp = j * wt + 1 + (int64_t)(h % (uint64_t)wt);
+  const int32_t rr = synth_refbase(pp);
+  *p = (int32_t)pp;
+  *r = rr;
+  *a = (int32_t)((rr + 1 + (int32_t)((h >> 32) % 3u)) & 3);
+}
+// record i of a VCF with N records: one position per stratum of width L / N;
+// takes the truth entry that falls into its stratum with probability 0.8.
+__host__ __device__ inline void synth_record(int64_t L, int64_t N, int64_t T, uint64_t tseed, uint64_t seed, int64_t i,
+                                              int32_t* p, int32_t* r, int32_t* a, float* q, uint8_t* f) {
+  const int64_t w = L / N;
+  const int64_t wt = L / T;
+  const int64_t s0 = i * w + 1;  // stratum [s0, s0 + w)
+  const int64_t j = (s0 - 1) / wt;
+  int32_t tp = 0, tr = 0, ta = 0;
+  bool take = false;
+  if (j < T) {
+    synth_truth(L, T, tseed, j, &tp, &tr, &ta);
+    take = tp >= s0 && tp < s0 + w && (hash3(seed, (uint64_t)i, 10) % 10u) < 8u;
+  }
+  if (take) {
+    *p = tp; *r = tr; *a = ta;
+  } else {
+    const int64_t pp = s0 + (int64_t)(hash3(seed, (uint64_t)i, 11) % (uint64_t)w);
+    const int32_t rr = synth_refbase(pp);
+    *p = (int32_t)pp;
+    *r = rr;
+    *a = (int32_t)((rr + 1 + (int32_t)(hash3(seed, (uint64_t)i, 12) % 3u)) & 3);
+  }
+  const uint32_t qi = (uint32_t)(hash3(seed, (uint64_t)i, 13) & 255u);
+  *q = (float)qi;
+  *f = (uint8_t)(QMF_IDDOT | (qi >= 20u ? QMF_PASS : 0u));
+}
+
+// ---- launchers ---------------------------------------------------------------
+void launch_classify(const ClassifyParams& P, int n_spans, hipStream_t st);
+void launch_finalize(const FinalizeParams& P, int n_vcf, hipStream_t st);
+void launch_compact(const CompactParams& P, int n_tiles, hipStream_t st);
+void launch_masks_to_cls(const uint64_t* mp, const uint64_t* mt, int64_t off, int64_t n, uint8_t* cls, hipStream_t st);
+void launch_synth(const SynthParams& S, int n_vcf, int64_t max_n, hipStream_t st);
+void launch_sort_init(const int32_t* pos, int64_t off, int64_t n, uint32_t* keys, uint32_t* vals, hipStream_t st);
+void launch_sort_pass(const uint32_t* keys, const uint32_t* vals, int64_t n, int shift, uint32_t* hist, uint32_t* okeys,
+                      uint32_t* ovals, hipStream_t st);
+void launch_sort_gather(const int32_t* pos, const int32_t* ref, const int32_t* alt, const float* qual, const uint8_t* flags,
+                        int64_t src_off, const uint32_t* perm, int64_t n, int32_t* opos, int32_t* oref, int32_t* oalt,
+                        float* oqual, uint8_t* oflags, int64_t dst_off, hipStream_t st);
+void launch_sort_scatter_cls(const uint64_t* mp, const uint64_t* mt, int64_t src_off, const uint32_t* perm, int64_t n,
+                             uint8_t* cls, hipStream_t st);
+void launch_cls_to_masks(const uint8_t* cls, int64_t off, int64_t n, uint64_t* mp, uint64_t* mt, uint32_t* tile_tp,
+                         uint32_t* tile_fp, int tile0, hipStream_t st);
+void launch_overlap_pack(const int32_t* pos, const int32_t* ref, const int32_t* alt, const int32_t* set_of, int64_t n,
+                         uint32_t* keys, uint32_t* vals, uint32_t* bad, hipStream_t st);
+void launch_overlap_count(const uint32_t* keys, const uint32_t* vals, int64_t n, unsigned long long* regions, hipStream_t st);
+
+}  // namespace qm

@@ -1,0 +1,266 @@
+// qmvt_host.cpp -- host text side of libqmvt.so: VCF / truth tokenizer-packer
+// and the output writers.  No GPU code, no classification: this file turns
+// text into the packed columns of include/qmvt.h and class bits back into files.
+//
+// Replaces (file:line in /root/reference):
+//   awk -F"\t" '$4~/^[ACGT]$/&&$5~/^[ACGT]$/&&($6>=20||$6==".")'   program/extract_TP_FP_SNPs.py:24
+//   grep -E "^#"                                                    :27,50,52
+//   awk ... {print $2,".",$4,$5}  /  {print $1,".",$2,$3}           :47, :92
+//   shell `>` redirection of the selected lines                     :50-53
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <unistd.h>
+
+#include "../../include/qmvt.h"
+
+namespace {
+
+struct Span { const uint8_t* p; size_t n; };
+
+inline bool acgt1(Span f) { return f.n == 1 && (f.p[0] == 'A' || f.p[0] == 'C' || f.p[0] == 'G' || f.p[0] == 'T'); }
+inline int base_code(uint8_t c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; }
+inline bool is_dot(Span f) { return f.n == 1 && f.p[0] == '.'; }
+inline bool is_word(uint8_t c) { return (c >= '0' && c <= '9') || (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == '_'; }
+
+// canonical decimal POS: "0" or [1-9][0-9]*, value < 2^28
+inline bool canon_pos(Span f, int32_t* out) {
+  if (f.n == 0 || f.n > 9) return false;
+  if (f.n > 1 && f.p[0] == '0') return false;
+  uint32_t v = 0;
+  for (size_t i = 0; i < f.n; ++i) {
+    if (f.p[i] < '0' || f.p[i] > '9') return false;
+    v = v * 10 + (uint32_t)(f.p[i] - '0');
+  }
+  if (v >= (uint32_t)QM_POS_LIMIT) return false;
+  *out = (int32_t)v;
+  return true;
+}
+
+// mawk 1.3.4 numeric-string test (tests/golden/PROVENANCE.md): blanks stripped,
+// last char digit or '.', first char digit/+/-/., glibc strtod consumes all,
+// any ERANGE -> plain string.
+bool awk_strnum(Span f, double* d) {
+  const uint8_t* s = f.p;
+  const uint8_t* q = f.p + f.n;
+  while (s < q && (*s == ' ' || *s == '\t')) ++s;
+  if (s == q) return false;
+  while (q[-1] == ' ' || q[-1] == '\t') --q;
+  const uint8_t last = q[-1], first = *s;
+  if (!((last >= '0' && last <= '9') || last == '.')) return false;
+  if (!((first >= '0' && first <= '9') || first == '+' || first == '-' || first == '.')) return false;
+  const size_t m = (size_t)(q - s);
+  if (memchr(s, 0, m)) return false;
+  char tmp[256];
+  std::string heap;
+  char* z = tmp;
+  if (m + 1 > sizeof tmp) { heap.assign((const char*)s, m); z = &heap[0]; } else { memcpy(tmp, s, m); tmp[m] = 0; }
+  char* endp = nullptr;
+  errno = 0;
+  const double v = strtod(z, &endp);
+  if (endp != z + m || errno != 0) return false;
+  *d = v;
+  return true;
+}
+
+// Effective QUAL: floor(q) >= t  <=>  awk `$6>=t` for integer t, numeric fields;
+// other spellings collapse to +-inf by their answer at t = 20.
+float effective_qual(Span f, bool* ge20) {
+  double d;
+  if (awk_strnum(f, &d)) {
+    *ge20 = d >= 20.0;
+    float q = (float)d;
+    if ((double)q > d) q = nextafterf(q, -INFINITY);  // round toward -inf: never crosses an integer upward
+    return q;
+  }
+  if (is_dot(f)) { *ge20 = true; return INFINITY; }  // `||$6=="."`
+  const size_t m = f.n < 2 ? f.n : 2;
+  const int c = memcmp(f.p, "20", m);
+  const bool ge = c != 0 ? c > 0 : f.n >= 2;
+  *ge20 = ge;
+  return ge ? INFINITY : -INFINITY;
+}
+
+inline int split_tabs(const uint8_t* line, size_t n, Span* f, int maxf) {
+  if (n == 0) return 0;
+  int nf = 0;
+  const uint8_t* s = line;
+  const uint8_t* end = line + n;
+  for (;;) {
+    const uint8_t* t = (const uint8_t*)memchr(s, '\t', (size_t)(end - s));
+    if (nf < maxf) { f[nf].p = s; f[nf].n = (size_t)((t ? t : end) - s); }
+    ++nf;
+    if (!t) break;
+    s = t + 1;
+  }
+  return nf;
+}
+
+}  // namespace
+
+extern "C" int64_t qm_vcf_count_lines(const uint8_t* text, size_t len) {
+  int64_t c = 0;
+  const uint8_t* p = text;
+  const uint8_t* end = text + len;
+  while (p < end) {
+    const uint8_t* nl = (const uint8_t*)memchr(p, '\n', (size_t)(end - p));
+    ++c;
+    if (!nl) break;
+    p = nl + 1;
+  }
+  return c;
+}
+
+extern "C" int qm_vcf_scan(const uint8_t* text, size_t len, int64_t cap_lines, int64_t* line_off, uint8_t* line_kind,
+                           int32_t* pos, int32_t* ref, int32_t* alt, float* qual, uint8_t* flags, qm_vcf_cols* info) {
+  if ((!text && len) || !line_off || !line_kind || !info) return QM_E_INVAL;
+  int64_t nl = 0, nd = 0, nnc = 0, first_nc = 0;
+  size_t off = 0;
+  enum { MAXF = 64 };
+  Span f[MAXF];
+  while (off < len) {
+    const uint8_t* s = text + off;
+    const uint8_t* e = (const uint8_t*)memchr(s, '\n', len - off);
+    const size_t n = e ? (size_t)(e - s) : len - off;
+    if (nl >= cap_lines) return QM_E_INVAL;
+    line_off[nl] = (int64_t)off;
+    if (n && s[0] == '#') {
+      line_kind[nl] = 1;
+    } else {
+      uint8_t kind = 0;
+      int nf = split_tabs(s, n, f, MAXF);
+      const int nfc = nf < MAXF ? nf : MAXF;
+      const Span empty = {(const uint8_t*)"", 0};
+      const Span fpos = nf > 1 ? f[1] : empty, fid = nf > 2 ? f[2] : empty, fref = nf > 3 ? f[3] : empty,
+                 falt = nf > 4 ? f[4] : empty, fq = nf > 5 ? f[5] : empty;
+      const bool snp = acgt1(fref) && acgt1(falt);
+      bool ge20 = false;
+      const float q = effective_qual(fq, &ge20);
+      const bool pass = snp && ge20;
+      int32_t p = -1;
+      const bool cpos = canon_pos(fpos, &p);
+      if (!cpos) p = -1;
+      if (pass) {
+        bool nc = !cpos;  // fgrep compares POS as a string: only canonical spellings are safe
+        for (size_t i = 0; i < n && !nc; ++i) nc = s[i] == 0 || s[i] >= 0x80;  // locale-dependent in the reference
+        // pattern X\t.\tY\tZ found at later fields
+        for (int k = 6; k + 2 < nfc && !nc; ++k)
+          if (is_dot(f[k]) && f[k - 1].n && f[k - 1].p[f[k - 1].n - 1] >= '0' && f[k - 1].p[f[k - 1].n - 1] <= '9' &&
+              f[k + 1].n == 1 && f[k + 2].n >= 1 && (f[k + 2].n == 1 || !is_word(f[k + 2].p[1])))
+            nc = true;
+        if (nf > MAXF) nc = true;
+        if (nc) { kind = 2; ++nnc; if (!first_nc) first_nc = nl + 1; }
+      }
+      line_kind[nl] = kind;
+      if (pos) {
+        pos[nd] = p;
+        ref[nd] = fref.n == 1 ? base_code(fref.p[0]) : 4;
+        alt[nd] = falt.n == 1 ? base_code(falt.p[0]) : 4;
+        qual[nd] = q;
+        flags[nd] = (uint8_t)((pass ? QM_F_PASS : 0u) | (is_dot(fid) ? QM_F_IDDOT : 0u));
+      }
+      ++nd;
+    }
+    ++nl;
+    off += n + 1;
+  }
+  line_off[nl] = (int64_t)len;
+  info->n_lines = nl;
+  info->n_data = nd;
+  info->n_noncanon = nnc;
+  info->first_noncanon_line = first_nc;
+  return QM_OK;
+}
+
+extern "C" int64_t qm_truth_scan(const uint8_t* text, size_t len, int mode, int64_t cap, int32_t* pos, int32_t* ref, int32_t* alt,
+                                 int64_t* out_counts) {
+  if ((!text && len) || (mode != 0 && mode != 1)) return QM_E_INVAL;
+  int64_t genomediff = 0, nkeys = 0, never = 0, refused = 0;
+  size_t off = 0;
+  Span f[6];
+  const Span empty = {(const uint8_t*)"", 0};
+  while (off < len) {
+    const uint8_t* s = text + off;
+    const uint8_t* e = (const uint8_t*)memchr(s, '\n', len - off);
+    const size_t n = e ? (size_t)(e - s) : len - off;
+    off += n + 1;
+    const int nf = split_tabs(s, n, f, 6);
+    for (int i = nf < 6 ? nf : 6; i < 6; ++i) f[i] = empty;
+    const bool comment = n && s[0] == '#';
+    Span X, Y, Z;
+    bool pattern;
+    if (mode == 0) {  // extract_TP_FP_SNPs.py:47 ; R: caller_performance_compare.R:29-55
+      X = f[1]; Y = f[3]; Z = f[4];
+      pattern = acgt1(Y) && acgt1(Z);
+      if (pattern && !comment) ++genomediff;
+    } else {          // extract_TP_FP_SNPs.py:92 ; R: custom_snp_benchmark.R:23-27
+      X = f[0]; Y = f[1]; Z = f[2];
+      pattern = !is_dot(Y) && !is_dot(Z);
+      if (pattern && !comment && n) ++genomediff;
+    }
+    if (!pattern) continue;
+    if (comment) { ++refused; continue; }  // awk makes a pattern of it, R skips it: refuse to guess
+    bool ascii = true;
+    for (size_t i = 0; i < n && ascii; ++i) ascii = s[i] != 0 && s[i] < 0x80;
+    int32_t p;
+    if (!acgt1(Y) || !acgt1(Z)) { ++never; continue; }   // Y must equal a single-base REF field
+    if (!canon_pos(X, &p)) {
+      // digits with a non-canonical spelling or out of range could match a non-canonical line
+      ++never;
+      continue;
+    }
+    if (!ascii) { ++refused; continue; }
+    if (pos) {
+      if (nkeys >= cap) return QM_E_INVAL;
+      pos[nkeys] = p; ref[nkeys] = base_code(Y.p[0]); alt[nkeys] = base_code(Z.p[0]);
+    }
+    ++nkeys;
+  }
+  if (out_counts) { out_counts[0] = genomediff; out_counts[1] = nkeys; out_counts[2] = never; out_counts[3] = refused; }
+  return nkeys;
+}
+
+extern "C" int qm_vcf_write(const char* path, const uint8_t* text, size_t len, int64_t n_lines, const int64_t* line_off,
+                            const uint8_t* line_kind, const uint8_t* cls, int select) {
+  if (!path || !line_off || !line_kind || select < 0 || select > 2) return QM_E_INVAL;
+  const std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid());
+  FILE* fh = fopen(tmp.c_str(), "wb");
+  if (!fh) return QM_E_IO;
+  std::vector<char> buf;
+  buf.reserve(1 << 20);
+  auto flush = [&]() -> bool {
+    if (buf.empty()) return true;
+    const bool ok = fwrite(buf.data(), 1, buf.size(), fh) == buf.size();
+    buf.clear();
+    return ok;
+  };
+  auto put_line = [&](int64_t i) -> bool {
+    size_t b = (size_t)line_off[i], e = (size_t)line_off[i + 1];
+    if (e > len) e = len;
+    if (e > b && text[e - 1] == '\n') --e;
+    buf.insert(buf.end(), (const char*)text + b, (const char*)text + e);
+    buf.push_back('\n');
+    return buf.size() < (1u << 20) || flush();
+  };
+  bool ok = true;
+  for (int64_t i = 0; i < n_lines && ok; ++i)
+    if (line_kind[i] == 1) ok = put_line(i);
+  int64_t r = 0;
+  for (int64_t i = 0; i < n_lines && ok; ++i) {
+    if (line_kind[i] == 1) continue;
+    const uint8_t c = cls ? cls[r] : 0;
+    ++r;
+    const bool sel = select == 0 ? (c & QM_CLS_KEPT) : select == 1 ? ((c & 3u) == 3u) : ((c & 3u) == 1u);
+    if (sel) ok = put_line(i);
+  }
+  ok = ok && flush();
+  ok = (fclose(fh) == 0) && ok;
+  if (!ok) { remove(tmp.c_str()); return QM_E_IO; }
+  if (rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return QM_E_IO; }
+  return QM_OK;
+}

@@ -1,0 +1,202 @@
+"""Engine / Batch: thin object layer over the C ABI (include/qmvt.h)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import SCALAR_NAMES, QmvtError, SynthCfg, check
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+class Engine:
+    """One context per process and GPU (qm_init).  Raises QmvtError(QM_E_NODEVICE)
+    when no HIP device is usable -- there is no CPU path."""
+
+    def __init__(self, device=0):
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        check(self._L.qm_init(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.qm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- truth sets -----------------------------------------------------------
+    def truth_load(self, pos, ref, alt):
+        pos, ref, alt = _c(pos, np.int32), _c(ref, np.int32), _c(alt, np.int32)
+        tid = C.c_int(-1)
+        check(self._L.qm_truth_load(self._h, _p(pos), _p(ref), _p(alt), pos.shape[0], C.byref(tid)), self._h)
+        return tid.value
+
+    def truth_synth(self, genome_len, truth_n, truth_seed):
+        tid = C.c_int(-1)
+        check(self._L.qm_truth_synth(self._h, int(genome_len), int(truth_n), int(truth_seed), C.byref(tid)), self._h)
+        return tid.value
+
+    def truth_size(self, tid):
+        n = C.c_int64()
+        check(self._L.qm_truth_size(self._h, int(tid), C.byref(n)), self._h)
+        return n.value
+
+    @property
+    def n_truth(self):
+        return self._L.qm_truth_count(self._h)
+
+    # -- one-shot ---------------------------------------------------------------
+    def classify_batch(self, columns, truth_ids, n_bins=256):
+        """columns: list of (pos, ref, alt, qual, flags) per VCF.  Returns a dict of
+        per-VCF results; see qm_classify_batch in include/qmvt.h."""
+        n_vcf = len(columns)
+        sizes = [int(np.asarray(c[0]).shape[0]) for c in columns]
+        offs = np.zeros(n_vcf + 1, np.int64)
+        offs[1:] = np.cumsum(sizes)
+        N = int(offs[-1])
+        cat = lambda k, dt: _c(np.concatenate([np.asarray(c[k], dtype=dt) for c in columns]) if n_vcf else np.zeros(0, dt), dt)
+        pos, ref, alt = cat(0, np.int32), cat(1, np.int32), cat(2, np.int32)
+        qual, flags = cat(3, np.float32), cat(4, np.uint8)
+        tids = _c(truth_ids, np.int32)
+        cls = np.zeros(max(N, 1), np.uint8)
+        idx = np.zeros(max(N, 1), np.int32)
+        roc = np.zeros((n_vcf, 3, n_bins), np.uint64)
+        scal = np.zeros((n_vcf, _lib.QM_N_SCALARS), np.int64)
+        glob = np.zeros((max(self.n_truth, 1), 3, n_bins), np.uint64)
+        check(self._L.qm_classify_batch(self._h, n_vcf, _p(offs), _p(pos), _p(ref), _p(alt), _p(qual), _p(flags), _p(tids),
+                                        int(n_bins), _p(cls), _p(roc), _p(scal), _p(idx), _p(glob)), self._h)
+        out = []
+        for v in range(n_vcf):
+            a, b = int(offs[v]), int(offs[v + 1])
+            s = dict(zip(SCALAR_NAMES, scal[v].tolist()))
+            reg = idx[a:b]
+            out.append({"cls": cls[a:b].copy(), "roc": roc[v].copy(), "scalars": s,
+                        "tp_idx": reg[:s["tp_lines"]].copy(), "fp_idx": reg[(b - a) - s["fp_lines"]:].copy()})
+        return out, glob
+
+    def fp_overlap(self, key_sets):
+        """key_sets: list of (pos, ref, alt) arrays, one per caller.  Returns region
+        counts indexed by membership mask (snpcaller_fp_compare.R:36-47)."""
+        n = len(key_sets)
+        offs = np.zeros(n + 1, np.int64)
+        offs[1:] = np.cumsum([np.asarray(k[0]).shape[0] for k in key_sets])
+        cat = lambda j: _c(np.concatenate([np.asarray(k[j], np.int32) for k in key_sets]) if n else np.zeros(0, np.int32), np.int32)
+        pos, ref, alt = cat(0), cat(1), cat(2)
+        reg = np.zeros(1 << n, np.int64)
+        check(self._L.qm_fp_overlap(self._h, n, _p(offs), _p(pos), _p(ref), _p(alt), _p(reg)), self._h)
+        return reg
+
+    def batch(self, n_records, truth_ids, n_bins=256):
+        return Batch(self, n_records, truth_ids, n_bins)
+
+
+class Batch:
+    """Resident batch: columns stay in HBM across runs (qm_batch_*)."""
+
+    def __init__(self, engine, n_records, truth_ids, n_bins=256):
+        self.engine = engine
+        self._L = engine._L
+        self.n_records = _c(n_records, np.int64)
+        self.truth_ids = _c(truth_ids, np.int32)
+        self.n_vcf = int(self.n_records.shape[0])
+        self.n_bins = int(n_bins)
+        h = C.c_void_p()
+        check(self._L.qm_batch_create(engine._h, self.n_vcf, _p(self.n_records), _p(self.truth_ids), self.n_bins,
+                                      C.byref(h)), engine._h)
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.qm_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        return check(rc, self.engine._h)
+
+    def upload(self, v, pos, ref, alt, qual, flags):
+        a = (_c(pos, np.int32), _c(ref, np.int32), _c(alt, np.int32), _c(qual, np.float32), _c(flags, np.uint8))
+        if any(x.shape[0] != int(self.n_records[v]) for x in a):
+            raise ValueError("column length != n_records[%d]" % v)
+        self._ck(self._L.qm_batch_upload(self._h, int(v), *[_p(x) for x in a]))
+
+    def synth(self, genome_len, truth_n, truth_seed, seed, shuffled=False):
+        cfg = SynthCfg(int(genome_len), int(seed), int(truth_seed), int(truth_n), int(bool(shuffled)), 0)
+        self._ck(self._L.qm_batch_synth(self._h, C.byref(cfg)))
+
+    def set_timing(self, on=True):
+        self._ck(self._L.qm_batch_set_timing(self._h, int(on)))
+
+    def run(self, stream=None, global_dev=None):
+        """Enqueue classify -> finalize -> compact.  stream: raw hipStream_t (int) or None;
+        global_dev: device pointer (int) of a [n_truth][3][n_bins] uint64 buffer or None."""
+        self._ck(self._L.qm_batch_run(self._h, C.c_void_p(stream) if stream else None,
+                                      C.c_void_p(global_dev) if global_dev else None))
+
+    def finish(self, stream=None):
+        self._ck(self._L.qm_batch_finish(self._h, C.c_void_p(stream) if stream else None))
+
+    def timings(self):
+        ms = (C.c_float * 4)()
+        self._ck(self._L.qm_batch_timings(self._h, ms))
+        return {"classify_ms": ms[0], "finalize_ms": ms[1], "compact_ms": ms[2], "total_ms": ms[3]}
+
+    def cls(self, v):
+        out = np.zeros(max(int(self.n_records[v]), 1), np.uint8)
+        self._ck(self._L.qm_batch_get_cls(self._h, int(v), _p(out)))
+        return out[:int(self.n_records[v])]
+
+    def idx(self, v):
+        out = np.zeros(max(int(self.n_records[v]), 1), np.int32)
+        self._ck(self._L.qm_batch_get_idx(self._h, int(v), _p(out)))
+        return out[:int(self.n_records[v])]
+
+    def roc(self):
+        out = np.zeros((self.n_vcf, 3, self.n_bins), np.uint64)
+        self._ck(self._L.qm_batch_get_roc(self._h, _p(out)))
+        return out
+
+    def scalars(self):
+        out = np.zeros((self.n_vcf, _lib.QM_N_SCALARS), np.int64)
+        self._ck(self._L.qm_batch_get_scalars(self._h, _p(out)))
+        return out
+
+    def global_counts(self):
+        out = np.zeros((max(self.engine.n_truth, 1), 3, self.n_bins), np.uint64)
+        self._ck(self._L.qm_batch_get_global(self._h, _p(out)))
+        return out
+
+    def columns(self, v):
+        n = int(self.n_records[v])
+        pos, ref, alt = np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)
+        qual, flags = np.zeros(n, np.float32), np.zeros(n, np.uint8)
+        self._ck(self._L.qm_batch_get_columns(self._h, int(v), _p(pos), _p(ref), _p(alt), _p(qual), _p(flags)))
+        return pos, ref, alt, qual, flags
+
+    @property
+    def device_bytes(self):
+        return int(self._L.qm_batch_device_bytes(self._h))

@@ -1,0 +1,139 @@
+"""Host mirror of the reference worker program/extract_TP_FP_SNPs.py.
+
+Same function names and argument meaning as the reference
+(extract_tp_fp_snp :12, extract_tp_fp_custom_snp :60); the shell pipeline is
+replaced by one text scan on the host + the HIP engine.  `extract_many` is the
+batch form used by the rule bodies: every mixed-sample VCF of a run is
+classified in ONE qm_classify_batch call.
+
+Differences from the reference, all deliberate:
+  * errors raise (the CLI exits non-zero) instead of being ignored;
+  * outputs are written atomically and tp/ is complete before returning
+    (the reference does not wait for its tp writer, :55-57);
+  * fp/ and tp/ are created when missing (the reference relies on Snakemake for fp/).
+"""
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from ._lib import SCALAR_NAMES, QmvtError
+from .engine import Engine
+from .vcfio import scan_truth, scan_vcf
+
+
+def is_pure_strain(vcf_file):
+    """extract_TP_FP_SNPs.py:33 -- sample name ends in -1-0 / -0-1: no truth comparison."""
+    return os.path.basename(vcf_file).split(".")[0].endswith(("-1-0", "-0-1"))
+
+
+@dataclass
+class Job:
+    vcf_file: str
+    snp_file: str
+    mode: str = "hcmv"        # "hcmv" | "custom"
+    outdir: str = ""
+    caller: str = ""
+    # filled by extract_many
+    filtered_out: str = ""
+    tp_out: str = ""
+    fp_out: str = ""
+    stats: dict = field(default_factory=dict)
+
+
+def _paths(job):
+    """Output paths exactly as the reference derives them (:19-22,39-41 hcmv; :71-72,91 custom)."""
+    if job.mode == "hcmv":
+        dirname = os.path.dirname(job.vcf_file)
+        base = os.path.basename(job.vcf_file)[:-4]
+        job.filtered_out = job.vcf_file[:-4] + ".filtered.vcf"
+        job.fp_out = os.path.join(dirname, "fp", base + ".fp.vcf")
+        job.tp_out = os.path.join(dirname, "tp", base + ".tp.vcf")
+    elif job.mode == "custom":
+        job.filtered_out = os.path.join(job.outdir, job.caller + ".filtered.vcf")
+        job.fp_out = os.path.join(job.outdir, "fp", job.caller + ".fp.vcf")
+        job.tp_out = os.path.join(job.outdir, "tp", job.caller + ".tp.vcf")
+    else:
+        raise ValueError("data must be 'hcmv' or 'custom', got %r" % job.mode)
+
+
+def _strict_default():
+    return os.environ.get("QM_LENIENT", "0") in ("", "0")
+
+
+def extract_many(jobs, engine=None, strict=None, n_bins=256):
+    """Classify and write filtered / tp / fp VCFs for a list of Job.  Returns the jobs
+    with .stats filled (line counts, R-path counts, ROC rows)."""
+    strict = _strict_default() if strict is None else strict
+    own = engine is None
+    scanned, mixed = [], []
+    for j, job in enumerate(jobs):
+        _paths(job)
+        with open(job.vcf_file, "rb") as fh:
+            sv = scan_vcf(fh.read())
+        if sv.n_noncanon and strict:
+            raise QmvtError(-8, "%s line %d: the reference's answer for this kept line depends on locale or on "
+                                "non-canonical field alignment (non-ASCII bytes, POS not a plain decimal < 2^28, or a "
+                                "'.' column after QUAL); set QM_LENIENT=1 to classify by the canonical columns"
+                            % (job.vcf_file, sv.first_noncanon_line))
+        scanned.append(sv)
+        if not is_pure_strain(job.vcf_file):
+            mixed.append(j)
+    results = {}
+    if mixed:
+        if engine is None:
+            engine = Engine(int(os.environ.get("QM_DEVICE", "0")))
+        try:
+            truth_ids, truth_info = {}, {}
+            for j in mixed:
+                key = (os.path.abspath(jobs[j].snp_file), jobs[j].mode)
+                if key not in truth_ids:
+                    with open(jobs[j].snp_file, "rb") as fh:
+                        tk = scan_truth(fh.read(), custom=jobs[j].mode == "custom")
+                    if tk.n_refused and strict:
+                        raise QmvtError(-8, "%s: %d truth rows the engine refuses to guess about (comment rows with a "
+                                            "valid pattern or non-ASCII bytes)" % (jobs[j].snp_file, tk.n_refused))
+                    truth_ids[key] = engine.truth_load(tk.pos, tk.ref, tk.alt)
+                    truth_info[key] = tk
+            cols = [scanned[j].columns for j in mixed]
+            tids = [truth_ids[(os.path.abspath(jobs[j].snp_file), jobs[j].mode)] for j in mixed]
+            res, _ = engine.classify_batch(cols, tids, n_bins=n_bins)
+            for j, r in zip(mixed, res):
+                r["genomediff"] = truth_info[(os.path.abspath(jobs[j].snp_file), jobs[j].mode)].genomediff
+                results[j] = r
+        finally:
+            if own:
+                engine.close()
+    for j, job in enumerate(jobs):
+        sv = scanned[j]
+        os.makedirs(os.path.dirname(job.fp_out) or ".", exist_ok=True)
+        if j in results:
+            r = results[j]
+            cls = r["cls"]
+            os.makedirs(os.path.dirname(job.tp_out) or ".", exist_ok=True)
+            sv.write(job.filtered_out, cls, 0)
+            sv.write(job.tp_out, cls, 1)
+            sv.write(job.fp_out, cls, 2)
+            job.stats = dict(r["scalars"])
+            job.stats.update(pure_strain=False, genomediff=r["genomediff"], roc=r["roc"])
+        else:  # pure strain: fp is a copy of filtered, truth never read (:33-36)
+            cls = (sv.flags & 1).astype(np.uint8)
+            sv.write(job.filtered_out, cls, 0)
+            sv.write(job.fp_out, cls, 0)
+            job.tp_out = ""
+            npass = int(cls.sum())
+            job.stats = dict(zip(SCALAR_NAMES, (npass, 0, npass, 0, 0, 1, sv.n_records, 0)))
+            job.stats.update(pure_strain=True, genomediff=0, roc=None)
+    return jobs
+
+
+def extract_tp_fp_snp(vcf_file, snp_file, engine=None, strict=None):
+    """Extract the TP and FP SNPs of one caller VCF (hcmv mode).
+    @param vcf_file: caller VCF.  @param snp_file: truth VCF written by mummer2vcf.py.
+    Outputs next to the input: <x>.filtered.vcf, fp/<x>.fp.vcf, tp/<x>.tp.vcf (:19-22,39-41)."""
+    return extract_many([Job(vcf_file, snp_file, "hcmv")], engine=engine, strict=strict)[0]
+
+
+def extract_tp_fp_custom_snp(vcf_file, snp_file, outdir, caller, engine=None, strict=None):
+    """Custom (vareval) mode: truth is the show-snps TSV; outputs under outdir (:71-72,91)."""
+    return extract_many([Job(vcf_file, snp_file, "custom", outdir, caller)], engine=engine, strict=strict)[0]

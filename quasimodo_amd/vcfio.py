@@ -1,0 +1,90 @@
+"""Host text side: VCF / truth tokenizing into packed columns and the output writers.
+All heavy lifting is in libqmvt.so (quasimodo_amd/csrc/qmvt_host.cpp)."""
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import QmvtError, VcfCols, check
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+@dataclass
+class ScannedVcf:
+    """One VCF text scanned once (replaces the three awk passes + grep of
+    extract_TP_FP_SNPs.py:24-32,50,52)."""
+    text: bytes
+    n_lines: int
+    line_off: np.ndarray   # int64 [n_lines + 1]
+    line_kind: np.ndarray  # uint8 [n_lines]: 0 data, 1 header, 2 data (non-canonical, strict mode refuses)
+    pos: np.ndarray
+    ref: np.ndarray
+    alt: np.ndarray
+    qual: np.ndarray
+    flags: np.ndarray
+    n_noncanon: int
+    first_noncanon_line: int
+
+    @property
+    def n_records(self):
+        return int(self.pos.shape[0])
+
+    @property
+    def columns(self):
+        return self.pos, self.ref, self.alt, self.qual, self.flags
+
+    def write(self, path, cls, select):
+        """select: 0 = kept lines (filtered.vcf), 1 = TP lines, 2 = FP lines; header lines always first."""
+        cls = np.ascontiguousarray(cls, np.uint8)
+        if cls.shape[0] != self.n_records:
+            raise ValueError("cls length %d != records %d" % (cls.shape[0], self.n_records))
+        rc = _lib.lib().qm_vcf_write(os.fsencode(path), self.text, len(self.text), self.n_lines, _p(self.line_off),
+                                     _p(self.line_kind), _p(cls) if self.n_records else None, int(select))
+        if rc < 0:
+            raise QmvtError(rc, "cannot write %s" % path)
+
+
+def scan_vcf(text: bytes) -> ScannedVcf:
+    L = _lib.lib()
+    nl = int(L.qm_vcf_count_lines(text, len(text)))
+    cap = nl + 1
+    line_off = np.zeros(cap + 1, np.int64)
+    kind = np.zeros(cap, np.uint8)
+    pos, ref, alt = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    qual, flags = np.zeros(cap, np.float32), np.zeros(cap, np.uint8)
+    info = VcfCols()
+    rc = L.qm_vcf_scan(text, len(text), cap, _p(line_off), _p(kind), _p(pos), _p(ref), _p(alt), _p(qual), _p(flags),
+                       C.byref(info))
+    if rc < 0:
+        raise QmvtError(rc, "qm_vcf_scan failed")
+    n, d = int(info.n_lines), int(info.n_data)
+    return ScannedVcf(text, n, line_off[:n + 1].copy(), kind[:n].copy(), pos[:d].copy(), ref[:d].copy(), alt[:d].copy(),
+                      qual[:d].copy(), flags[:d].copy(), int(info.n_noncanon), int(info.first_noncanon_line))
+
+
+@dataclass
+class TruthKeys:
+    pos: np.ndarray
+    ref: np.ndarray
+    alt: np.ndarray
+    genomediff: int   # rows R counts as `genomediff` (caller_performance_compare.R:90)
+    n_never: int      # rows whose pattern can never match a canonical kept line
+    n_refused: int    # rows the engine refuses to guess about (strict mode)
+
+
+def scan_truth(text: bytes, custom: bool = False) -> TruthKeys:
+    """Truth text -> (pos, ref, alt) key columns.  custom=False: VCF written by
+    mummer2vcf.py (extract_TP_FP_SNPs.py:47); custom=True: show-snps TSV (:92)."""
+    L = _lib.lib()
+    cap = int(L.qm_vcf_count_lines(text, len(text))) + 1
+    pos, ref, alt = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    counts = np.zeros(4, np.int64)
+    n = int(L.qm_truth_scan(text, len(text), int(bool(custom)), cap, _p(pos), _p(ref), _p(alt), _p(counts)))
+    if n < 0:
+        raise QmvtError(n, "qm_truth_scan failed")
+    return TruthKeys(pos[:n].copy(), ref[:n].copy(), alt[:n].copy(), int(counts[0]), int(counts[2]), int(counts[3]))

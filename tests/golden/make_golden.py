@@ -201,8 +201,13 @@ QUAL_PROBES = ["20", "20.0", "2e1", "+20", " 20", "020", "20.", "19.999", "-1", 
                "0x1f", "00x14", "19.99999999999999999999e0", "99999999999999999999999999999999", "+5", "-0", "- 30"]
 
 
-def quirks_case():
-    """One line per quirk of SURVEY.md section 8a (Q1-Q11) plus the QUAL strnum probes."""
+NONCANON_MARKS = ("\t01000\t", "\t1-1000\t", "chrT\t999\t", "chrT\t998\t", "chrT\t996\t")
+
+
+def quirks_case(canonical_only=False):
+    """One line per quirk of SURVEY.md section 8a (Q1-Q11) plus the QUAL strnum probes.
+    canonical_only drops the lines whose fgrep match hangs on non-canonical field
+    alignment (Q10) or POS spelling -- the engine refuses those in strict mode."""
     truth = ["##fileformat=VCFv4.2", "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO",
              "chrT\t1000\t.\tA\tG\t30\tPASS\tDP=30;TYPE=SNV",
              "chrT\t1100\t.\tT\tC\t30\tPASS\tDP=30;TYPE=SNV",
@@ -243,6 +248,8 @@ def quirks_case():
          ]
     for i, q in enumerate(QUAL_PROBES):
         v.append("chrQ\t%d\t.\tA\tG\t%s\tPASS\tprobe%d" % (5000 + i, q, i))
+    if canonical_only:
+        v = [ln for ln in v if not any(m in ln for m in NONCANON_MARKS)]
     vt = ("\n".join(v)).encode("latin1")   # NO trailing newline (Q7)
     return vt, ("\n".join(truth) + "\n").encode()
 
@@ -335,7 +342,7 @@ def write(path, data):
 
 def gen_all():
     manifest = []
-    for fam in ("quirks", "hcmv", "config1", "custom", "edge"):
+    for fam in ("quirks", "quirks_canon", "hcmv", "config1", "custom", "edge"):
         shutil.rmtree(os.path.join(HERE, fam), ignore_errors=True)
     refs = {k: read_fasta(k) for k in FASTA}
 
@@ -352,6 +359,14 @@ def gen_all():
         write(os.path.join(w, "nucmer/r1_r2.maskrepeat.snps"), snps)
         write(os.path.join(w, "in/quirks.vcf"), v)
         store_case("quirks", manifest, w, "in/quirks.vcf", "nucmer/r1_r2.maskrepeat.snps", "custom", "callers", "quirks")
+    with tempfile.TemporaryDirectory() as w:
+        v, t = quirks_case(canonical_only=True)
+        write(os.path.join(w, "q/QC-1-10.R.q.vcf"), v)
+        write(os.path.join(w, "nucmer/QC.maskrepeat.variants.vcf"), t)
+        store_case("quirks_canon", manifest, w, "q/QC-1-10.R.q.vcf", "nucmer/QC.maskrepeat.variants.vcf", "hcmv", "q", "q")
+        write(os.path.join(w, "nucmer/r1_r2.maskrepeat.snps"), snps)
+        write(os.path.join(w, "in/quirks_canon.vcf"), v)
+        store_case("quirks_canon", manifest, w, "in/quirks_canon.vcf", "nucmer/r1_r2.maskrepeat.snps", "custom", "callers", "quirks_canon")
 
     # ---- config 1: TA-1-10 LoFreq vs TA truth ------------------
     with tempfile.TemporaryDirectory() as w:

@@ -1,0 +1,231 @@
+"""Parity tests proper: the HIP engine (through the C ABI) against the oracle on the same
+seeded inputs, and end to end against the reference's golden bytes.  Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import case_id, golden_cases, random_columns, random_truth, read_case
+
+pytestmark = pytest.mark.gpu
+CASES = golden_cases()
+
+
+def check_vcf(oracle, res, cols, truth, n_bins=256, expect_sorted=None):
+    cls, roc, sc = oracle.classify_columns(*cols, *truth, n_bins=n_bins)
+    assert np.array_equal(res["cls"], cls)
+    assert np.array_equal(res["roc"], roc)
+    s = res["scalars"]
+    for k in ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R", "truth_unique"):
+        assert s[k] == sc[k], (k, s[k], sc[k])
+    assert s["n_records"] == len(cols[0])
+    if expect_sorted is not None:
+        assert s["sorted"] == int(expect_sorted)
+    # compacted line-index lists: ascending, exactly the TP / FP lines
+    assert np.array_equal(res["tp_idx"], np.nonzero(cls == 3)[0])
+    assert np.array_equal(res["fp_idx"], np.nonzero(cls == 1)[0])
+    # pinned point of the ROC
+    if n_bins > 20:
+        assert int(res["roc"][0, 20]) == s["tp_lines"] and int(res["roc"][1, 20]) == s["fp_lines"]
+
+
+SIZES = [0, 1, 3, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 4096, 5000, 16384, 16385, 40000]
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_ragged_sorted_batch(engine, oracle, seed):
+    rng = np.random.default_rng(100 + seed)
+    L = 60000
+    truths = [random_truth(rng, 4000, L), random_truth(rng, 300, L)]
+    tids = [engine.truth_load(*t) for t in truths]
+    cols, which = [], []
+    for i, n in enumerate(SIZES):
+        w = i % 2
+        cols.append(random_columns(rng, n, L, truths[w], sorted_=True))
+        which.append(w)
+    res, glob = engine.classify_batch(cols, [tids[w] for w in which])
+    for r, c, w in zip(res, cols, which):
+        check_vcf(oracle, r, c, truths[w], expect_sorted=True)
+    # per-truth sums = sum of the ROC rows of the VCFs that use that truth set
+    for w in range(2):
+        want = sum((r["roc"] for r, ww in zip(res, which) if ww == w), np.zeros((3, 256), np.uint64))
+        assert np.array_equal(glob[tids[w]], want)
+
+
+def test_unsorted_vcfs_take_the_radix_sort_path(engine, oracle):
+    rng = np.random.default_rng(7)
+    L = 200000
+    truth = random_truth(rng, 5000, L)
+    tid = engine.truth_load(*truth)
+    cols = [random_columns(rng, n, L, truth, sorted_=s) for n, s in
+            ((3000, False), (10, False), (5000, True), (2, False), (70000, False), (2048, False), (1, False))]
+    res, glob = engine.classify_batch(cols, [tid] * len(cols))
+    for r, c in zip(res, cols):
+        srt = bool(np.all(np.diff(c[0].astype(np.int64)) >= 0))
+        check_vcf(oracle, r, c, truth, expect_sorted=srt)
+    want = sum((r["roc"] for r in res), np.zeros((3, 256), np.uint64))
+    assert np.array_equal(glob[tid], want)
+
+
+def test_long_equal_position_runs_across_tiles(engine, oracle):
+    """Runs of one position longer than a tile: ownership of the truth entries and the
+    R-path de-duplication must not double count across tile and span boundaries."""
+    rng = np.random.default_rng(11)
+    truth = (np.array([50, 50, 50, 77, 90], np.int32), np.array([0, 0, 1, 2, 3], np.int32), np.array([1, 2, 3, 3, 0], np.int32))
+    tid = engine.truth_load(*truth)
+    n = 9000
+    pos = np.concatenate([np.full(20, 10), np.full(n, 50), np.full(2048 * 9, 77), np.full(5, 90), np.full(3, 95)]).astype(np.int32)
+    N = len(pos)
+    ref = rng.integers(0, 4, N).astype(np.int32)
+    alt = rng.integers(0, 4, N).astype(np.int32)
+    qual = rng.integers(0, 260, N).astype(np.float32)
+    flags = (((qual >= 20).astype(np.uint8)) | ((rng.random(N) > 0.1).astype(np.uint8) << 1)).astype(np.uint8)
+    cols = (pos, ref, alt, qual, flags)
+    res, _ = engine.classify_batch([cols], [tid])
+    check_vcf(oracle, res[0], cols, truth, expect_sorted=True)
+
+
+def test_dense_truth_slices_are_chunked(engine, oracle):
+    """Truth slice of one tile larger than the LDS staging capacity (2048 keys)."""
+    rng = np.random.default_rng(13)
+    L = 40000
+    tp = np.repeat(np.arange(1, L + 1, dtype=np.int32), 3)
+    truth = (tp, rng.integers(0, 4, len(tp)).astype(np.int32), rng.integers(0, 4, len(tp)).astype(np.int32))
+    tid = engine.truth_load(*truth)
+    cols = [random_columns(rng, 500, L, truth, frac_truth=0.5), random_columns(rng, 6000, L, truth, frac_truth=0.5)]
+    res, _ = engine.classify_batch(cols, [tid, tid])
+    for r, c in zip(res, cols):
+        check_vcf(oracle, r, c, truth)
+
+
+def test_empty_truth_and_small_bins(engine, oracle):
+    rng = np.random.default_rng(17)
+    empty = (np.zeros(0, np.int32),) * 3
+    tid = engine.truth_load(*empty)
+    cols = random_columns(rng, 3000, 5000, empty)
+    for nb in (256, 64, 21):
+        res, _ = engine.classify_batch([cols], [tid], n_bins=nb)
+        check_vcf(oracle, res[0], cols, empty, n_bins=nb)
+        assert res[0]["scalars"]["tp_lines"] == 0
+
+
+def test_position_out_of_range_is_an_error(engine):
+    import quasimodo_amd as q
+    tid = engine.truth_load(np.array([5], np.int32), np.array([0], np.int32), np.array([1], np.int32))
+    cols = (np.array([1, 1 << 28], np.int32), np.zeros(2, np.int32), np.ones(2, np.int32), np.full(2, 50, np.float32),
+            np.full(2, 3, np.uint8))
+    with pytest.raises(q.QmvtError) as ei:
+        engine.classify_batch([cols], [tid])
+    assert ei.value.code == -5
+    with pytest.raises(q.QmvtError):
+        engine.truth_load(np.array([-1], np.int32), np.array([0], np.int32), np.array([1], np.int32))
+
+
+@pytest.mark.parametrize("shuffled", [False, True])
+def test_synthetic_batch_vs_oracle(engine, oracle, shuffled):
+    """The on-device generator of the bench workload, at a size the oracle finishes in seconds."""
+    L, N, T = 400000, 80000, 8000
+    tid = engine.truth_synth(L, T, 3)
+    b = engine.batch([N, N, N // 2], [tid] * 3)
+    b.synth(L, T, 3, 3000, shuffled=shuffled)
+    b.run()
+    b.finish()
+    roc, scal = b.roc(), b.scalars()
+    # the truth keys, regenerated through the engine's own columns: every record drawn from
+    # the truth is a hit, so recover T' from the scalars and the keys from a dense probe
+    tk = None
+    for v in range(3):
+        cols = b.columns(v)
+        if not shuffled:
+            assert np.all(np.diff(cols[0]) > 0)           # distinct, sorted positions
+        if tk is None:
+            from oracle.synth import synth_truth_keys
+            tk = synth_truth_keys(L, T, 3)
+        cls, oroc, sc = oracle.classify_columns(*cols, *tk)
+        assert np.array_equal(b.cls(v), cls)
+        assert np.array_equal(roc[v], oroc)
+        assert scal[v][0] == sc["n_pass"] and scal[v][3] == sc["TP_R"] and scal[v][4] == sc["FP_R"]
+        assert scal[v][5] == (0 if shuffled else 1)
+        hit_frac = sc["tp_lines"] / max(sc["n_pass"], 1)
+        assert 0.06 < hit_frac < 0.11                       # ~8 % of the kept records are truth hits
+        idx = b.idx(v)
+        n = len(cols[0])
+        assert np.array_equal(idx[:sc["tp_lines"]], np.nonzero(cls == 3)[0])
+        assert np.array_equal(idx[n - sc["fp_lines"]:], np.nonzero(cls == 1)[0])
+    b.close()
+
+
+def test_fp_overlap_vs_sets(engine):
+    rng = np.random.default_rng(23)
+    sets = []
+    for k in range(4):
+        n = 3000 + 500 * k
+        sets.append((rng.integers(1, 2000, n).astype(np.int32), rng.integers(0, 4, n).astype(np.int32),
+                     rng.integers(0, 4, n).astype(np.int32)))
+    reg = engine.fp_overlap(sets)
+    member = {}
+    for k, (p, r, a) in enumerate(sets):
+        for key in set(zip(p.tolist(), r.tolist(), a.tolist())):
+            member[key] = member.get(key, 0) | (1 << k)
+    want = np.zeros(16, np.int64)
+    for m in member.values():
+        want[m] += 1
+    assert np.array_equal(reg, want)
+
+
+def test_golden_end_to_end_bytes(engine, oracle, tmp_path):
+    """BASELINE config 1 + 2 (HCMV-shaped bundle stand-in): the drop-in worker writes exactly the
+    bytes the reference wrote, for every caller x sample VCF, in one batch call."""
+    import quasimodo_amd as q
+    from quasimodo_amd.extract import Job
+    jobs, exps = [], []
+    for e in CASES:
+        if e["family"] == "quirks":
+            continue
+        vcf, truth, exp = read_case(e)
+        root = tmp_path / e["family"] / e["mode"]
+        vp = root / e["vcf"][len("input/"):]
+        tp = root / e["truth"][len("input/"):]
+        vp.parent.mkdir(parents=True, exist_ok=True)
+        tp.parent.mkdir(parents=True, exist_ok=True)
+        vp.write_bytes(vcf)
+        tp.write_bytes(truth)
+        jobs.append(Job(str(vp), str(tp), e["mode"], str(root / e["outdir"]), e["caller"]))
+        exps.append((e, exp, truth))
+    q.extract_many(jobs, engine=engine)
+    for job, (e, exp, truth) in zip(jobs, exps):
+        assert open(job.filtered_out, "rb").read() == exp["filtered"], case_id(e)
+        assert open(job.fp_out, "rb").read() == exp["fp"], case_id(e)
+        if e["pure"]:
+            assert job.tp_out == ""
+            continue
+        assert open(job.tp_out, "rb").read() == exp["tp"], case_id(e)
+        # declared output paths (extract_TP.smk:6-11 / eval_variant_custom.smk:63-64)
+        if e["mode"] == "hcmv":
+            assert job.filtered_out.endswith(e["expected"]["filtered"][len("expected/"):])
+        rc = oracle.count_text(exp["filtered"], truth, custom=e["mode"] == "custom")
+        assert job.stats["n_pass"] == rc["calleridentify"] and job.stats["genomediff"] == rc["genomediff"]
+        assert job.stats["TP_R"] == rc["TP"] and job.stats["FP_R"] == rc["FP"]
+        assert job.stats["truth_unique"] - job.stats["TP_R"] <= rc["FN"]   # R's FN also counts never-matching rows
+
+
+def test_cli_dropin(engine, tmp_path):
+    """program/extract_TP_FP_SNPs.py: same argv as the reference, non-zero exit on error."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    e = [c for c in CASES if c["family"] == "config1"][0]
+    vcf, truth, exp = read_case(e)
+    d = tmp_path / "lofreq"
+    d.mkdir()
+    (d / "TA-1-10.AD169.lofreq.vcf").write_bytes(vcf)
+    (tmp_path / "TA.maskrepeat.variants.vcf").write_bytes(truth)
+    cli = os.path.join(ROOT, "program", "extract_TP_FP_SNPs.py")
+    r = subprocess.run([sys.executable, cli, str(d / "TA-1-10.AD169.lofreq.vcf"), str(tmp_path / "TA.maskrepeat.variants.vcf"),
+                        "hcmv", str(d), "lofreq"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (d / "TA-1-10.AD169.lofreq.filtered.vcf").read_bytes() == exp["filtered"]
+    assert (d / "tp" / "TA-1-10.AD169.lofreq.tp.vcf").read_bytes() == exp["tp"]
+    assert (d / "fp" / "TA-1-10.AD169.lofreq.fp.vcf").read_bytes() == exp["fp"]
+    r = subprocess.run([sys.executable, cli, str(d / "missing.vcf"), "x", "hcmv", str(d), "lofreq"], capture_output=True, text=True)
+    assert r.returncode != 0 and "extract_TP_FP_SNPs.py" in r.stderr

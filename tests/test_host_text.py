@@ -1,0 +1,156 @@
+"""Host text side of libqmvt.so (tokenizer / packer / writers) against the oracle and the
+golden bytes.  CPU only: no kernel is launched here; where a classification is needed to
+exercise the writers the ORACLE provides it (checker role only)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import case_id, golden_cases, read_case
+
+CASES = golden_cases()
+
+
+def _data_lines(text):
+    lines = text.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    return [ln for ln in lines if not ln.startswith(b"#")]
+
+
+@pytest.mark.parametrize("e", CASES, ids=case_id)
+def test_tokenizer_flags_match_awk_filter(qmlib, oracle, e):
+    from quasimodo_amd import scan_vcf
+    vcf, _, exp = read_case(e)
+    sv = scan_vcf(vcf)
+    lines = _data_lines(vcf)
+    assert sv.n_records == len(lines)
+    want = np.array([oracle.caller_filter(ln) for ln in lines], dtype=bool)
+    assert np.array_equal((sv.flags & 1).astype(bool), want)
+    # ID == "." bit
+    ids = np.array([(ln.split(b"\t") + [b"", b"", b""])[2] == b"." for ln in lines], dtype=bool)
+    assert np.array_equal(((sv.flags >> 1) & 1).astype(bool), ids)
+
+
+@pytest.mark.parametrize("e", CASES, ids=case_id)
+def test_filtered_writer_bytes(qmlib, tmp_path, e):
+    from quasimodo_amd import scan_vcf
+    vcf, _, exp = read_case(e)
+    sv = scan_vcf(vcf)
+    out = tmp_path / "f.vcf"
+    sv.write(str(out), (sv.flags & 1).astype(np.uint8), 0)
+    assert out.read_bytes() == exp["filtered"]
+
+
+@pytest.mark.parametrize("e", [c for c in CASES if not c["pure"] and c["family"] != "quirks"], ids=case_id)
+def test_pack_classify_write_roundtrip(qmlib, oracle, tmp_path, e):
+    """text -> columns (product tokenizer) -> classes (oracle as checker) -> files == reference bytes.
+    Pins the packing (POS/allele codes, effective QUAL, truth keys) to the golden vectors on CPU."""
+    from quasimodo_amd import scan_truth, scan_vcf
+    vcf, truth, exp = read_case(e)
+    sv = scan_vcf(vcf)
+    assert sv.n_noncanon == 0
+    tk = scan_truth(truth, custom=e["mode"] == "custom")
+    assert tk.n_refused == 0
+    cls, roc, sc = oracle.classify_columns(*sv.columns, tk.pos, tk.ref, tk.alt)
+    for sel, kind in ((0, "filtered"), (1, "tp"), (2, "fp")):
+        out = tmp_path / (kind + ".vcf")
+        sv.write(str(out), cls, sel)
+        assert out.read_bytes() == exp[kind], kind
+    # effective QUAL invariant: floor(qual) >= 20 <=> awk kept the record (given single-base alleles)
+    snp = (sv.ref < 4) & (sv.alt < 4)
+    assert np.array_equal(snp & (np.floor(sv.qual) >= 20), (sv.flags & 1).astype(bool))
+    assert int(roc[0, 20]) == sc["tp_lines"] and int(roc[1, 20]) == sc["fp_lines"]
+    # R-path counts (A6) from columns == R restatement on the text
+    rc = oracle.count_text(exp["filtered"], truth, custom=e["mode"] == "custom")
+    assert rc["calleridentify"] == sc["n_pass"]
+    assert rc["TP"] == sc["TP_R"] and rc["FP"] == sc["FP_R"]
+    assert rc["genomediff"] == tk.genomediff
+
+
+def test_noncanonical_lines_are_flagged(qmlib):
+    from quasimodo_amd import scan_vcf
+    e = [c for c in CASES if c["family"] == "quirks" and c["mode"] == "hcmv"][0]
+    vcf, _, _ = read_case(e)
+    sv = scan_vcf(vcf)
+    lines = vcf.split(b"\n")
+    flagged = [lines[i] for i in range(sv.n_lines) if sv.line_kind[i] == 2]
+    assert len(flagged) == 5 and sv.n_noncanon == 5
+    assert any(b"\t1-1000\t" in ln for ln in flagged) and any(b"\t01000\t" in ln for ln in flagged)
+    assert sv.first_noncanon_line == lines.index(flagged[0]) + 1
+
+
+def test_strict_mode_refuses_noncanonical(qmlib, tmp_path):
+    """extract_many raises before touching the GPU when a kept line is ambiguous."""
+    import quasimodo_amd as q
+    from quasimodo_amd.extract import Job
+    e = [c for c in CASES if c["family"] == "quirks" and c["mode"] == "hcmv"][0]
+    vcf, truth, _ = read_case(e)
+    d = tmp_path / "q"
+    d.mkdir()
+    (d / "QK-1-10.R.q.vcf").write_bytes(vcf)
+    (tmp_path / "t.vcf").write_bytes(truth)
+    with pytest.raises(q.QmvtError) as ei:
+        q.extract_many([Job(str(d / "QK-1-10.R.q.vcf"), str(tmp_path / "t.vcf"), "hcmv")], strict=True)
+    assert ei.value.code == -8
+
+
+def test_non_ascii_kept_line_flagged(qmlib, oracle):
+    from quasimodo_amd import scan_vcf
+    vcf = b"c\t5\t.\tA\tG\t50\tPASS\tname=\xc3\xa9\nc\t6\t.\tA\tG\t5\tPASS\tname=\xc3\xa9\n"
+    sv = scan_vcf(vcf)
+    assert list(sv.line_kind) == [2, 0]          # only KEPT lines matter
+    with pytest.raises(ValueError):
+        oracle.extract_text(vcf, b"", False, False)
+
+
+def test_pure_strain_paths_and_copy(qmlib, tmp_path):
+    """A5p: fp is a copy of filtered, no tp/, truth never opened (extract_TP_FP_SNPs.py:33-36)."""
+    import quasimodo_amd as q
+    e = [c for c in CASES if c["family"] == "edge" and c["vcf"].endswith("ED-1-0.R.e.vcf")][0]
+    vcf, _, exp = read_case(e)
+    d = tmp_path / "e"
+    d.mkdir()
+    p = d / "ED-1-0.R.e.vcf"
+    p.write_bytes(vcf)
+    job = q.extract_tp_fp_snp(str(p), str(tmp_path / "does-not-exist.vcf"))
+    assert open(job.filtered_out, "rb").read() == exp["filtered"]
+    assert open(job.fp_out, "rb").read() == exp["fp"]
+    assert job.filtered_out == str(d / "ED-1-0.R.e.filtered.vcf")
+    assert job.fp_out == str(d / "fp" / "ED-1-0.R.e.fp.vcf")
+    assert not (d / "tp").exists()
+    assert job.stats["pure_strain"] and job.stats["fp_lines"] == job.stats["n_pass"]
+
+
+def test_custom_mode_paths(qmlib):
+    from quasimodo_amd.extract import Job, _paths
+    j = Job("/x/in/a.vcf", "/x/t.snps", "custom", "/out/callers", "lab")
+    _paths(j)
+    assert (j.filtered_out, j.fp_out, j.tp_out) == ("/out/callers/lab.filtered.vcf", "/out/callers/fp/lab.fp.vcf",
+                                                     "/out/callers/tp/lab.tp.vcf")
+    h = Job("/x/lofreq/TA-1-10.AD169.lofreq.vcf", "/x/t.vcf", "hcmv", "ignored", "ignored")
+    _paths(h)
+    assert h.filtered_out == "/x/lofreq/TA-1-10.AD169.lofreq.filtered.vcf"
+    assert h.fp_out == "/x/lofreq/fp/TA-1-10.AD169.lofreq.fp.vcf"
+    assert h.tp_out == "/x/lofreq/tp/TA-1-10.AD169.lofreq.tp.vcf"
+
+
+def test_effective_qual_rounds_down(qmlib):
+    from quasimodo_amd import scan_vcf
+    sv = scan_vcf(b"c\t1\t.\tA\tG\t19.99999999\nc\t2\t.\tA\tG\t20.00000001\nc\t3\t.\tA\tG\t.\nc\t4\t.\tA\tG\tPASS\n"
+                  b"c\t5\t.\tA\tG\t1,2\nc\t6\t.\tA\tG\t16777217.5\n")
+    assert np.floor(sv.qual[0]) == 19 and np.floor(sv.qual[1]) == 20
+    assert np.isposinf(sv.qual[2]) and np.isposinf(sv.qual[3]) and np.isneginf(sv.qual[4])
+    assert sv.qual[5] <= 16777217.5
+    assert list(sv.flags & 1) == [0, 1, 1, 1, 0, 1]
+
+
+def test_truth_scan_modes(qmlib):
+    from quasimodo_amd import scan_truth
+    t = b"##x\n#CHROM\tPOS\tID\tREF\tALT\nc\t10\t.\tA\tG\nc\t11\t.\tA\tG,T\nc\t12\t.\tAC\tA\nc\t013\t.\tA\tC\nc\t14\t.\tc\tt\n"
+    tk = scan_truth(t)
+    assert list(tk.pos) == [10] and tk.genomediff == 2 and tk.n_never == 1 and tk.n_refused == 0
+    s = b"10\tA\tG\tx\n11\tN\tG\tx\n12\t.\tG\tx\n\n13\tC\tT\n"
+    tk = scan_truth(s, custom=True)
+    assert list(tk.pos) == [10, 13] and list(tk.ref) == [0, 1] and list(tk.alt) == [2, 3]
+    assert tk.genomediff == 3 and tk.n_never == 2     # 'N' row and the empty line's pattern
