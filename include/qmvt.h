@@ -21,6 +21,9 @@
  *                spellings are +inf, failing ones -inf
  *   flags uint8  bit0 QM_F_PASS  = line kept by the A2 filter (extract_TP_FP_SNPs.py:24)
  *                bit1 QM_F_IDDOT = ID column is exactly "."
+ *                bit2 QM_F_NOKEY = the line has no comparable key (POS is not a canonical
+ *                                  decimal): it can never be in the truth set; the packer
+ *                                  gives it the previous record's pos so order is kept
  */
 #ifndef QMVT_H
 #define QMVT_H
@@ -46,6 +49,7 @@ extern "C" {
 
 #define QM_F_PASS 1u
 #define QM_F_IDDOT 2u
+#define QM_F_NOKEY 4u
 
 #define QM_CLS_KEPT 1u /* out_cls bit0: line is in <x>.filtered.vcf */
 #define QM_CLS_TP 2u   /* out_cls bit1: line is in tp/<x>.tp.vcf (else, if kept, fp/) */

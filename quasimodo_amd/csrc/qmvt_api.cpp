@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -387,6 +388,8 @@ static ClassifyParams classify_params(qm_batch* b) {
   P.spans = b->d_spans; P.vcfs = b->d_vcfs; P.truths = b->ctx->d_truths;
   P.mask_pass = b->mask_pass; P.mask_tp = b->mask_tp; P.tile_tp = b->tile_tp; P.tile_fp = b->tile_fp;
   P.span_hist = b->span_hist; P.span_scal = b->span_scal; P.n_bins = b->n_bins;
+  const char* ab = getenv("QM_ABLATE");
+  P.ablate = ab ? atoi(ab) : 0;
   return P;
 }
 static FinalizeParams finalize_params(qm_batch* b, uint64_t* global) {

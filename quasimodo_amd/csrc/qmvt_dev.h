@@ -6,18 +6,17 @@
 
 namespace qm {
 
-constexpr int K1_BLOCK = 256;
-constexpr int K1_WAVES = 4;
-constexpr int K1_ROUNDS = 2;                       // 4 consecutive records per lane per round
-constexpr int K1_TILE = K1_BLOCK * 4 * K1_ROUNDS;  // 2048 records
-constexpr int K1_SLICE = 2048;                     // truth keys staged in LDS per pass
-constexpr int SPAN_TILES = 8;                      // tiles per workgroup (one histogram flush per span)
+constexpr int K1_ROUNDS = 4;                 // rounds of 256 records (4 consecutive per lane) per tile
+constexpr int K1_TILE = 256 * K1_ROUNDS;     // 1024 records: one LDS truth slice, one TP/FP line count
+constexpr int K1_SLICE = 512;                // truth keys per LDS slice buffer (two buffers per wave)
+constexpr int SPAN_TILES = 16;               // tiles per wave = per workgroup (one histogram flush per span)
 constexpr int VCF_ALIGN = 256;                     // device start of every VCF (records)
 constexpr int SORT_TILE = 2048;
 constexpr int QM_POS_LIMIT_DEV = 1 << 28;
 
 constexpr uint32_t QMF_PASS = 1u;
 constexpr uint32_t QMF_IDDOT = 2u;
+constexpr uint32_t QMF_NOKEY = 4u;
 constexpr uint32_t SPANF_UNSORTED = 1u;
 constexpr uint32_t SPANF_BADPOS = 2u;
 
@@ -60,6 +59,7 @@ struct ClassifyParams {
   uint32_t* span_hist;  // [n_spans][3][256]
   uint32_t* span_scal;  // [n_spans][8]
   int32_t n_bins;
+  int32_t ablate;  // debug only (QM_ABLATE): skip phases to price them; results are wrong when non-zero
 };
 
 struct FinalizeParams {

@@ -120,6 +120,7 @@ extern "C" int qm_vcf_scan(const uint8_t* text, size_t len, int64_t cap_lines, i
                            int32_t* pos, int32_t* ref, int32_t* alt, float* qual, uint8_t* flags, qm_vcf_cols* info) {
   if ((!text && len) || !line_off || !line_kind || !info) return QM_E_INVAL;
   int64_t nl = 0, nd = 0, nnc = 0, first_nc = 0;
+  int32_t last_pos = 0;  // carried onto records without a comparable POS
   size_t off = 0;
   enum { MAXF = 64 };
   Span f[MAXF];
@@ -144,7 +145,7 @@ extern "C" int qm_vcf_scan(const uint8_t* text, size_t len, int64_t cap_lines, i
       const bool pass = snp && ge20;
       int32_t p = -1;
       const bool cpos = canon_pos(fpos, &p);
-      if (!cpos) p = -1;
+      if (cpos) last_pos = p; else p = last_pos;
       if (pass) {
         bool nc = !cpos;  // fgrep compares POS as a string: only canonical spellings are safe
         for (size_t i = 0; i < n && !nc; ++i) nc = s[i] == 0 || s[i] >= 0x80;  // locale-dependent in the reference
@@ -162,7 +163,7 @@ extern "C" int qm_vcf_scan(const uint8_t* text, size_t len, int64_t cap_lines, i
         ref[nd] = fref.n == 1 ? base_code(fref.p[0]) : 4;
         alt[nd] = falt.n == 1 ? base_code(falt.p[0]) : 4;
         qual[nd] = q;
-        flags[nd] = (uint8_t)((pass ? QM_F_PASS : 0u) | (is_dot(fid) ? QM_F_IDDOT : 0u));
+        flags[nd] = (uint8_t)((pass ? QM_F_PASS : 0u) | (is_dot(fid) ? QM_F_IDDOT : 0u) | (cpos ? 0u : QM_F_NOKEY));
       }
       ++nd;
     }

@@ -2,16 +2,17 @@
 //
 // Pure integer / index work, HBM-bound: no MFMA.  wave = 64 lanes everywhere.
 //
-//   k_classify   one workgroup per SPAN (<= SPAN_TILES consecutive 2048-record
-//                tiles of one VCF).  Streams pos/ref/alt/qual (dwordx4 per lane)
-//                + flags (dword per lane), stages the tile's slice of the sorted
-//                truth keys in LDS and merge-joins by LDS binary search.  Emits
+//   k_classify   one wave per SPAN (<= SPAN_TILES consecutive 512-record tiles of
+//                one VCF), no barriers.  Streams pos/ref/alt/qual (dwordx4 per lane)
+//                + flags (dword per lane) with the next tile in flight, stages each
+//                tile's slice of the sorted truth keys in double-buffered LDS and
+//                merge-joins by LDS binary search.  Emits
 //                wave-ballot class masks (kept / TP, 1 bit per record each),
 //                per-tile TP/FP line counts, per-span QUAL-bin histograms
 //                (TP, FP, distinct truth keys) and scalar counters.
 //   k_finalize   one workgroup per VCF: span histograms -> ROC suffix sums,
 //                scalars, exclusive scan of tile counts, per-truth-set sums.
-//   k_compact    one workgroup per tile: expands the ballot masks into the
+//   k_compact    one wave per tile: expands the ballot masks into the
 //                compacted TP / FP line-index lists (mbcnt prefix ranks).
 //   k_sort_*     per-VCF LSD radix sort (wave multisplit) for unsorted VCFs.
 //   k_synth_*    on-device generator of the BASELINE.json config-3/4 workload.
@@ -59,7 +60,16 @@ __device__ __forceinline__ int lds_lower_bound(const uint32_t* __restrict__ k, i
 }
 
 // ---------------------------------------------------------------------------
-// k_classify
+// k_classify -- wave-autonomous streaming merge-join.
+//
+// One workgroup = ONE wave (64 lanes) = one span of up to SPAN_TILES consecutive
+// tiles of one VCF; no workgroup barriers.  Units:
+//   round = 256 records, register resident (4 consecutive records per lane:
+//           dwordx4 per column + one dword of flags).  The next round's loads are
+//           issued before the current round is touched (register double buffer).
+//   tile  = K1_ROUNDS rounds = the unit that owns a slice of the sorted truth keys
+//           in LDS (double buffered: tile t+1's slice is staged while t finishes),
+//           the per-truth-entry state for U(t)/TP_R, and one TP/FP line count.
 // ---------------------------------------------------------------------------
 struct Rec4 {
   int p[4], r[4], a[4];
@@ -79,28 +89,116 @@ __device__ __forceinline__ void load_rec4(const ClassifyParams& P, int64_t idx, 
   R.q[0] = qv.x; R.q[1] = qv.y; R.q[2] = qv.z; R.q[3] = qv.w;
 }
 
-// Was a kept record with the same (pos, ref, alt) seen earlier in this VCF?
-// Only walks the run of equal positions; the number of distinct single-base
-// keys per position (<= 16) bounds the total work per run to O(run length).
-__device__ __noinline__ bool seen_before(const ClassifyParams& P, int64_t i, int64_t vbegin, int p, int r, int a) {
-  for (int64_t j = i - 1; j >= vbegin; --j) {
-    if (P.pos[j] != p) break;
-    if (P.ref[j] == r && P.alt[j] == a && (P.flags[j] & QMF_PASS)) return true;
-  }
-  return false;
+struct TileBounds {
+  int a, b;          // first / last position of the tile
+  int prevp, nextp;  // position just before / after it (INT32_MIN at the VCF edge)
+};
+
+__device__ __forceinline__ TileBounds tile_bounds(const ClassifyParams& P, int64_t tb, int64_t te, int64_t vbegin, int64_t vend) {
+  TileBounds t;
+  t.a = P.pos[tb];
+  t.b = P.pos[te - 1];
+  t.prevp = (tb > vbegin) ? P.pos[tb - 1] : INT32_MIN;
+  t.nextp = (te < vend) ? P.pos[te] : INT32_MIN;
+  return t;
 }
 
-__global__ __launch_bounds__(K1_BLOCK) void k_classify(ClassifyParams P) {
-  __shared__ uint32_t s_keys[K1_SLICE];
-  __shared__ uint32_t s_max[K1_SLICE];
-  __shared__ uint32_t s_rf[K1_SLICE / 32];
-  __shared__ uint32_t s_hist[3 * 256];
-  __shared__ uint32_t s_cnt[8];   // 0 n_pass 1 tp_lines 2 fp_lines 3 tpR 4 fpR 5 flags 6 tile_tp 7 tile_fp
-  __shared__ int s_flag;
+// truth slice [lo, hi) covering positions a..b, from the coarse position index
+__device__ __forceinline__ void slice_range(const TruthDev& tr, int a, int b, int& lo, int& hi) {
+  uint32_t ba = (uint32_t)a >> tr.shift;
+  uint32_t bb = ((uint32_t)b >> tr.shift) + 1u;
+  const uint32_t lim = (uint32_t)tr.nb + 1u;
+  ba = ba < lim ? ba : lim;
+  bb = bb < lim ? bb : lim;
+  lo = tr.tidx[ba];
+  hi = tr.tidx[bb];
+  if (hi < lo) hi = lo;  // only on unsorted input (results discarded)
+}
 
-  const int tid = (int)threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
+struct Slice {
+  uint32_t* keys;
+  uint32_t* smax;  // per key: max(bin + 1) over '.'-ID single-base matches (U histogram)
+  uint32_t* srf;   // per key: matched by a kept record (TP_R), one bit each
+  int m;           // keys staged
+  int top;         // largest power of two <= m
+};
+
+__device__ __forceinline__ void stage_slice(const TruthDev& tr, int c0, Slice& S, int lane) {
+  for (int j = lane; j < S.m; j += 64) { S.keys[j] = tr.keys[c0 + j]; S.smax[j] = 0; }
+  if (lane < K1_SLICE / 32) S.srf[lane] = 0;
+  S.top = S.m > 0 ? 1 << (31 - __clz(S.m)) : 0;
+}
+
+__device__ __forceinline__ void slice_update(const Slice& S, int j, uint32_t fl, float q, int nb) {
+  const int bin = qual_bin(q, nb);
+  if ((fl & QMF_IDDOT) && bin >= 0) atomicMax(&S.smax[j], (uint32_t)(bin + 1));
+  if (fl & QMF_PASS) atomicOr(&S.srf[j >> 5], 1u << (j & 31));
+}
+
+// search the 4 records of a round in the slice; returns the hit nibble.  `own_a` is
+// INT32_MIN when the tile owns the run at its first position, else that position
+// (the run started in an earlier tile, which owns its truth entries).
+__device__ __forceinline__ uint32_t search_round(const Slice& S, const Rec4& R, int64_t i0, int64_t te, int own_a, int nb) {
+  uint32_t hits = 0;
+  if (S.m <= 0) return 0;
+  uint32_t key[4];
+  int fnd[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) key[k] = pack_key(R.p[k], R.r[k], R.a[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) fnd[k] = lds_lower_bound(S.keys, S.m, S.top, key[k]);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t fl = (R.f >> (8 * k)) & 0xffu;
+    const bool ok = (i0 + k < te) && (uint32_t)R.p[k] < (uint32_t)QM_POS_LIMIT_DEV && is_snp(R.r[k], R.a[k]) && !(fl & QMF_NOKEY);
+    const int j = fnd[k];
+    if (ok && j < S.m && S.keys[j] == key[k]) {
+      hits |= 1u << k;
+      if (R.p[k] != own_a) slice_update(S, j, fl, R.q[k], nb);
+    }
+  }
+  return hits;
+}
+
+// records of later tiles that continue this tile's last run of equal positions
+__device__ __forceinline__ void continue_run(const ClassifyParams& P, const Slice& S, int64_t te, int64_t vend, int bpos, int nb, int lane) {
+  for (int64_t base = te; base < vend; base += 64) {
+    const int64_t i = base + lane;
+    bool cont = false;
+    if (i < vend) {
+      const int p = P.pos[i];
+      cont = (p == bpos);
+      if (cont && S.m > 0) {
+        const int r_ = P.ref[i], a_ = P.alt[i];
+        const uint32_t fl = P.flags[i];
+        if (is_snp(r_, a_) && (uint32_t)p < (uint32_t)QM_POS_LIMIT_DEV && !(fl & QMF_NOKEY)) {
+          const uint32_t key = pack_key(p, r_, a_);
+          const int j = lds_lower_bound(S.keys, S.m, S.top, key);
+          if (j < S.m && S.keys[j] == key) slice_update(S, j, fl, P.qual[i], nb);
+        }
+      }
+    }
+    if (ballot64(cont) != ~0ull) break;
+  }
+}
+
+__device__ __forceinline__ uint32_t flush_slice(const Slice& S, uint32_t* s_hist, int lane) {
+  uint32_t tpr = 0;
+  for (int j = lane; j < S.m; j += 64) {
+    const uint32_t mx = S.smax[j];
+    if (mx) atomicAdd(&s_hist[512 + mx - 1], 1u);
+    tpr += (S.srf[j >> 5] >> (j & 31)) & 1u;
+  }
+  return tpr;
+}
+
+__global__ __launch_bounds__(64) void k_classify(ClassifyParams P) {
+  __shared__ uint32_t s_keys[2][K1_SLICE];
+  __shared__ uint32_t s_max[2][K1_SLICE];
+  __shared__ uint32_t s_rf[2][K1_SLICE / 32];
+  __shared__ uint32_t s_hist[3 * 256];
+
+  const int lane = (int)threadIdx.x;
   const SpanDesc sp = P.spans[blockIdx.x];
   const VcfDesc vd = P.vcfs[sp.vcf];
   const TruthDev tr = P.truths[vd.truth];
@@ -108,234 +206,200 @@ __global__ __launch_bounds__(K1_BLOCK) void k_classify(ClassifyParams P) {
   const int64_t vend = vd.off + vd.n;
   const int nb = P.n_bins;
 
-  for (int i = tid; i < 3 * 256; i += K1_BLOCK) s_hist[i] = 0;
-  if (tid < 8) s_cnt[tid] = 0;
+  for (int i = lane; i < 3 * 256; i += 64) s_hist[i] = 0;
   uint32_t span_flags = 0;
+  uint32_t acc_pass = 0, acc_tp = 0;  // wave-uniform
+  uint32_t acc_tpr = 0, acc_fpr = 0;  // per lane, reduced at the end
+
+  // ---- prologue: first round in flight, first tile's bounds and slice -------------
+  int64_t tb = sp.begin;
+  int64_t te = (tb + K1_TILE < sp.end) ? tb + K1_TILE : sp.end;
+  Rec4 N;
+  load_rec4(P, tb + lane * 4, N);
+  TileBounds B = tile_bounds(P, tb, te, vbegin, vend);
+  int lo, hi;
+  slice_range(tr, B.a, B.b, lo, hi);
+  int buf = 0;
+  Slice S;
+  S.keys = s_keys[0]; S.smax = s_max[0]; S.srf = s_rf[0];
+  S.m = (hi - lo) < K1_SLICE ? (hi - lo) : K1_SLICE;
+  stage_slice(tr, lo, S, lane);
   __syncthreads();
 
   int tile = sp.tile0;
-  for (int64_t tb = sp.begin; tb < sp.end; tb += K1_TILE, ++tile) {
-    const int64_t te = (tb + K1_TILE < sp.end) ? tb + K1_TILE : sp.end;  // valid end (device index)
+  for (;;) {
+    const bool has_next_tile = te < sp.end;
+    const int64_t ntb = tb + K1_TILE;
+    const int64_t nte = (ntb + K1_TILE < sp.end) ? ntb + K1_TILE : sp.end;
+    const bool started_before = (tb > vbegin) && (B.prevp == B.a);
+    const int own_a = started_before ? B.a : INT32_MIN;
+    const bool owns_b = !(started_before && B.a == B.b);
+    const int nrounds = (int)((te - tb + 255) >> 8);
 
-    // ---- stream the tile: 2 rounds x 4 consecutive records per lane ----------
-    Rec4 R[K1_ROUNDS];
-    int64_t ridx[K1_ROUNDS];
-#pragma unroll
-    for (int r = 0; r < K1_ROUNDS; ++r) {
-      ridx[r] = tb + (int64_t)((r * K1_WAVES + wave) * 256 + lane * 4);
-      load_rec4(P, ridx[r], R[r]);  // padded allocation: always in bounds
-    }
-    const int a_pos = P.pos[tb];
-    const int b_pos = P.pos[te - 1];
-    const int prev_tile_pos = (tb > vbegin) ? P.pos[tb - 1] : INT32_MIN;
-    const int next_pos = (te < vend) ? P.pos[te] : INT32_MIN;
-    const bool started_before = (tb > vbegin) && (prev_tile_pos == a_pos);
-
-    // ---- truth slice [lo, hi) from the coarse position index ----------------
-    int lo, hi;
-    {
-      uint32_t ba = (uint32_t)a_pos >> tr.shift;
-      uint32_t bb = ((uint32_t)b_pos >> tr.shift) + 1u;
-      uint32_t lim = (uint32_t)tr.nb + 1u;
-      ba = ba < lim ? ba : lim;
-      bb = bb < lim ? bb : lim;
-      lo = tr.tidx[ba];
-      hi = tr.tidx[bb];
-      if (hi < lo) hi = lo;  // only on unsorted input (results discarded)
-    }
-
-    // per-record derived values
-    uint32_t hitmask = 0;  // bit (r*4+k)
-    bool validk[K1_ROUNDS][4];
-    uint32_t keyk[K1_ROUNDS][4];
-    bool snpk[K1_ROUNDS][4];
-#pragma unroll
-    for (int r = 0; r < K1_ROUNDS; ++r)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int64_t i = ridx[r] + k;
-        validk[r][k] = i < te;
-        const bool okpos = (uint32_t)R[r].p[k] < (uint32_t)QM_POS_LIMIT_DEV;
-        if (validk[r][k] && !okpos) span_flags |= SPANF_BADPOS;
-        snpk[r][k] = validk[r][k] && okpos && is_snp(R[r].r[k], R[r].a[k]);
-        keyk[r][k] = pack_key(R[r].p[k], R[r].r[k], R[r].a[k]);
-      }
-
-    // ---- merge-join against the LDS-staged slice (chunked if it is large) ----
-    for (int c0 = lo;; c0 += K1_SLICE) {
-      const int m = (hi - c0) < K1_SLICE ? (hi - c0) : K1_SLICE;
-      __syncthreads();  // previous chunk / tile fully flushed
-      for (int j = tid; j < m; j += K1_BLOCK) { s_keys[j] = tr.keys[c0 + j]; s_max[j] = 0; }
-      for (int j = tid; j < (m + 31) / 32; j += K1_BLOCK) s_rf[j] = 0;
-      __syncthreads();
-      if (m > 0) {
-        const int top = 1 << (31 - __clz(m));
-        int fnd[K1_ROUNDS][4];
-#pragma unroll
-        for (int r = 0; r < K1_ROUNDS; ++r)
-#pragma unroll
-          for (int k = 0; k < 4; ++k) fnd[r][k] = lds_lower_bound(s_keys, m, top, keyk[r][k]);
-#pragma unroll
-        for (int r = 0; r < K1_ROUNDS; ++r)
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int j = fnd[r][k];
-            const bool hit = snpk[r][k] && j < m && s_keys[j < m ? j : 0] == keyk[r][k];
-            if (hit) {
-              hitmask |= 1u << (r * 4 + k);
-              const uint32_t fl = (R[r].f >> (8 * k)) & 0xffu;
-              // the tile in which a run of equal positions starts owns its truth entries
-              const bool owner = !(started_before && R[r].p[k] == a_pos);
-              if (owner) {
-                const int bin = qual_bin(R[r].q[k], nb);
-                if ((fl & QMF_IDDOT) && bin >= 0) atomicMax(&s_max[j], (uint32_t)(bin + 1));
-                if (fl & QMF_PASS) atomicOr(&s_rf[j >> 5], 1u << (j & 31));
-              }
-            }
-          }
-        // records of later tiles that continue this tile's last run
-        if (next_pos == b_pos && !(started_before && a_pos == b_pos)) {
-          for (int64_t base = te; base < vend; base += K1_BLOCK) {
-            const int64_t i = base + tid;
-            bool cont = false;
-            if (i < vend) {
-              const int p = P.pos[i];
-              cont = (p == b_pos);
-              if (cont) {
-                const int r_ = P.ref[i], a_ = P.alt[i];
-                if (is_snp(r_, a_) && (uint32_t)p < (uint32_t)QM_POS_LIMIT_DEV) {
-                  const uint32_t key = pack_key(p, r_, a_);
-                  const int j = lds_lower_bound(s_keys, m, top, key);
-                  if (j < m && s_keys[j] == key) {
-                    const uint32_t fl = P.flags[i];
-                    const int bin = qual_bin(P.qual[i], nb);
-                    if ((fl & QMF_IDDOT) && bin >= 0) atomicMax(&s_max[j], (uint32_t)(bin + 1));
-                    if (fl & QMF_PASS) atomicOr(&s_rf[j >> 5], 1u << (j & 31));
-                  }
-                }
-              }
-            }
-            if (!__syncthreads_and(cont ? 1 : 0)) break;
-          }
-        }
+    // ---- dense truth / sparse VCF: the keys beyond the staged chunk, as a pre-pass ----
+    uint32_t prehit = 0;
+    if (hi - lo > K1_SLICE && !(P.ablate & 1)) {
+      for (int c0 = lo + K1_SLICE; c0 < hi; c0 += K1_SLICE) {
         __syncthreads();
-        // flush the chunk's per-truth-entry state into the span histogram
-        uint32_t tpr = 0;
-        for (int j = tid; j < m; j += K1_BLOCK) {
-          const uint32_t mx = s_max[j];
-          if (mx) atomicAdd(&s_hist[512 + mx - 1], 1u);
-          tpr += (s_rf[j >> 5] >> (j & 31)) & 1u;
+        S.m = (hi - c0) < K1_SLICE ? (hi - c0) : K1_SLICE;
+        stage_slice(tr, c0, S, lane);
+        __syncthreads();
+        for (int r = 0; r < nrounds; ++r) {
+          Rec4 T;
+          const int64_t i0 = tb + r * 256 + lane * 4;
+          load_rec4(P, i0, T);
+          prehit |= search_round(S, T, i0, te, own_a, nb) << (4 * r);
         }
-        if (tpr) atomicAdd(&s_cnt[3], tpr);
+        if (B.nextp == B.b && owns_b) continue_run(P, S, te, vend, B.b, nb, lane);
+        __syncthreads();
+        acc_tpr += flush_slice(S, s_hist, lane);
       }
-      if (c0 + K1_SLICE >= hi) break;
+      __syncthreads();
+      S.m = K1_SLICE;
+      stage_slice(tr, lo, S, lane);
+      __syncthreads();
     }
 
-    // ---- per record: class bits, histograms, order check, R-path FP dedupe ---
-#pragma unroll
-    for (int r = 0; r < K1_ROUNDS; ++r) {
-      // previous record's position for slot 0
-      int prevp = __shfl_up(R[r].p[3], 1);
-      if (lane == 0) prevp = (ridx[r] > vbegin) ? P.pos[ridx[r] - 1] : INT32_MIN;
+    // ---- the tile's rounds: next round's loads first, then search + per-record work ----
+    TileBounds NB = B;
+    uint32_t tile_np = 0, tile_nt = 0;
+    for (int r = 0; r < nrounds; ++r) {
+      const Rec4 R = N;
+      const int64_t rbase = tb + r * 256;
+      const int64_t i0 = rbase + lane * 4;
+      if (r + 1 < nrounds) {
+        load_rec4(P, i0 + 256, N);
+      } else if (has_next_tile) {
+        load_rec4(P, ntb + lane * 4, N);
+        NB = tile_bounds(P, ntb, nte, vbegin, vend);
+      }
+      uint32_t hits = (prehit >> (4 * r)) & 15u;
+      if (!(P.ablate & 1)) hits |= search_round(S, R, i0, te, own_a, nb);
+
+      int prevp = __shfl_up(R.p[3], 1);
+      if (lane == 0) prevp = (r == 0) ? B.prevp : P.pos[rbase - 1];
       uint32_t nib_pass = 0, nib_tp = 0;
-      uint32_t fpr = 0;
       bool unsorted = false;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const bool valid = validk[r][k];
-        const uint32_t fl = (R[r].f >> (8 * k)) & 0xffu;
-        const bool hit = (hitmask >> (r * 4 + k)) & 1u;
-        const bool snp = snpk[r][k];
-        const bool pass = valid && snp && (fl & QMF_PASS);
+        const int64_t i = i0 + k;
+        const bool valid = i < te;
+        const uint32_t fl = (R.f >> (8 * k)) & 0xffu;
+        const int p = R.p[k];
+        const bool okpos = (uint32_t)p < (uint32_t)QM_POS_LIMIT_DEV;
+        if (valid && !okpos) span_flags |= SPANF_BADPOS;
+        const bool snp = valid && okpos && is_snp(R.r[k], R.a[k]);
+        const bool hit = (hits >> k) & 1u;
+        const bool pass = snp && (fl & QMF_PASS);
         const bool tpkey = hit && (fl & QMF_IDDOT);
-        const bool tp = pass && tpkey;
         nib_pass |= (pass ? 1u : 0u) << k;
-        nib_tp |= (tp ? 1u : 0u) << k;
-        const int p = R[r].p[k];
-        const int pp = (k == 0) ? prevp : R[r].p[k - 1];
+        nib_tp |= ((pass && tpkey) ? 1u : 0u) << k;
+        const int pp = (k == 0) ? prevp : R.p[k - 1];
         if (valid && p < pp) unsorted = true;
         // ROC histograms: one count per single-base record with a bin
-        const int bin = qual_bin(R[r].q[k], nb);
-        const bool counted = valid && snp && bin >= 0;
-        const bool sat = counted && bin == nb - 1;  // real data piles up in the top bin
-        const uint64_t sat_tp = ballot64(sat && tpkey);
-        const uint64_t sat_fp = ballot64(sat && !tpkey);
-        if (lane == 0) {
-          if (sat_tp) atomicAdd(&s_hist[nb - 1], (uint32_t)popc64(sat_tp));
-          if (sat_fp) atomicAdd(&s_hist[256 + nb - 1], (uint32_t)popc64(sat_fp));
+        const int bin = qual_bin(R.q[k], nb);
+        const bool counted = snp && bin >= 0;
+        if (!(P.ablate & 2)) {
+          const bool sat = counted && bin == nb - 1;  // real data piles up in the top bin
+          const uint64_t sat_tp = ballot64(sat && tpkey);
+          const uint64_t sat_fp = ballot64(sat && !tpkey);
+          if (lane == 0) {
+            if (sat_tp) atomicAdd(&s_hist[nb - 1], (uint32_t)popc64(sat_tp));
+            if (sat_fp) atomicAdd(&s_hist[256 + nb - 1], (uint32_t)popc64(sat_fp));
+          }
+          if (counted && !sat) atomicAdd(&s_hist[(tpkey ? 0 : 256) + bin], 1u);
         }
-        if (counted && !sat) atomicAdd(&s_hist[(tpkey ? 0 : 256) + bin], 1u);
-        // R path: distinct kept keys outside the truth set
-        if (pass && !hit) {
+        // R path: distinct kept keys outside the truth set.  Only a record whose
+        // predecessor has the same position can be a repeat; walk that run backwards
+        // (<= 16 distinct single-base keys per position bound the total walk per run).
+        if (pass && !hit && !(P.ablate & 8)) {
           bool first = true;
-          if (valid && p == pp) first = !seen_before(P, ridx[r] + k, vbegin, p, R[r].r[k], R[r].a[k]);
-          fpr += first ? 1u : 0u;
+          if (p == pp) {
+            const uint32_t nk = fl & QMF_NOKEY;
+            for (int64_t j = i - 1; j >= vbegin; --j) {
+              if (P.pos[j] != p) break;
+              const uint32_t fj = P.flags[j];
+              if ((fj & QMF_PASS) && (fj & QMF_NOKEY) == nk && P.ref[j] == R.r[k] && P.alt[j] == R.a[k]) { first = false; break; }
+            }
+          }
+          acc_fpr += first ? 1u : 0u;
         }
       }
       if (unsorted) span_flags |= SPANF_UNSORTED;
-      if (fpr) atomicAdd(&s_cnt[4], fpr);
 
-      // ---- wave ballots -> natural-order 64-bit mask words ---------------------
-      const int sel = lane & 3;
-      const int sh = lane >> 2;
-      uint64_t wp[4], wt[4];
-      {
-        const uint64_t b0 = ballot64(nib_pass & 1u), b1 = ballot64(nib_pass & 2u);
-        const uint64_t b2 = ballot64(nib_pass & 4u), b3 = ballot64(nib_pass & 8u);
-        const uint64_t mine = sel == 0 ? b0 : sel == 1 ? b1 : sel == 2 ? b2 : b3;
+      // ---- wave ballots -> natural-order 64-bit mask words ---------------------------
+      if (!(P.ablate & 4)) {
+        const int sel = lane & 3;
+        const int sh = lane >> 2;
+        uint64_t wp[4], wt[4];
+        {
+          const uint64_t b0 = ballot64(nib_pass & 1u), b1 = ballot64(nib_pass & 2u);
+          const uint64_t b2 = ballot64(nib_pass & 4u), b3 = ballot64(nib_pass & 8u);
+          const uint64_t mine = sel == 0 ? b0 : sel == 1 ? b1 : sel == 2 ? b2 : b3;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) wp[w] = ballot64((mine >> (16 * w + sh)) & 1ull);
-      }
-      {
-        const uint64_t b0 = ballot64(nib_tp & 1u), b1 = ballot64(nib_tp & 2u);
-        const uint64_t b2 = ballot64(nib_tp & 4u), b3 = ballot64(nib_tp & 8u);
-        const uint64_t mine = sel == 0 ? b0 : sel == 1 ? b1 : sel == 2 ? b2 : b3;
+          for (int w = 0; w < 4; ++w) wp[w] = ballot64((mine >> (16 * w + sh)) & 1ull);
+        }
+        {
+          const uint64_t b0 = ballot64(nib_tp & 1u), b1 = ballot64(nib_tp & 2u);
+          const uint64_t b2 = ballot64(nib_tp & 4u), b3 = ballot64(nib_tp & 8u);
+          const uint64_t mine = sel == 0 ? b0 : sel == 1 ? b1 : sel == 2 ? b2 : b3;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) wt[w] = ballot64((mine >> (16 * w + sh)) & 1ull);
-      }
-      const int64_t round_base = tb + (int64_t)((r * K1_WAVES + wave) * 256);
-      if (round_base < te) {  // wave-uniform
+          for (int w = 0; w < 4; ++w) wt[w] = ballot64((mine >> (16 * w + sh)) & 1ull);
+        }
         if (lane < 4) {
           const uint64_t vp = lane == 0 ? wp[0] : lane == 1 ? wp[1] : lane == 2 ? wp[2] : wp[3];
           const uint64_t vt = lane == 0 ? wt[0] : lane == 1 ? wt[1] : lane == 2 ? wt[2] : wt[3];
-          P.mask_pass[(round_base >> 6) + lane] = vp;
-          P.mask_tp[(round_base >> 6) + lane] = vt;
+          P.mask_pass[(rbase >> 6) + lane] = vp;
+          P.mask_tp[(rbase >> 6) + lane] = vt;
         }
-        if (lane == 0) {
-          const uint32_t np = (uint32_t)(popc64(wp[0]) + popc64(wp[1]) + popc64(wp[2]) + popc64(wp[3]));
-          const uint32_t nt = (uint32_t)(popc64(wt[0]) + popc64(wt[1]) + popc64(wt[2]) + popc64(wt[3]));
-          atomicAdd(&s_cnt[6], nt);
-          atomicAdd(&s_cnt[7], np - nt);
-        }
+        tile_np += (uint32_t)(popc64(wp[0]) + popc64(wp[1]) + popc64(wp[2]) + popc64(wp[3]));
+        tile_nt += (uint32_t)(popc64(wt[0]) + popc64(wt[1]) + popc64(wt[2]) + popc64(wt[3]));
       }
     }
-    __syncthreads();
-    if (tid == 0) {
-      const uint32_t nt = s_cnt[6], nf = s_cnt[7];
-      P.tile_tp[tile] = nt;
-      P.tile_fp[tile] = nf;
-      s_cnt[0] += nt + nf;
-      s_cnt[1] += nt;
-      s_cnt[2] += nf;
-      s_cnt[6] = 0;
-      s_cnt[7] = 0;
+
+    // ---- tile epilogue: run continuation, per-truth-entry state -> histogram, counts ----
+    if (!(P.ablate & 1)) {
+      if (B.nextp == B.b && owns_b) continue_run(P, S, te, vend, B.b, nb, lane);
+      __syncthreads();
+      acc_tpr += flush_slice(S, s_hist, lane);
     }
+    if (lane == 0) {
+      P.tile_tp[tile] = tile_nt;
+      P.tile_fp[tile] = tile_np - tile_nt;
+    }
+    acc_pass += tile_np;
+    acc_tp += tile_nt;
+
+    if (!has_next_tile) break;
+    // ---- stage the next tile's slice into the other LDS half ----------------------------
+    B = NB;
+    tb = ntb;
+    te = nte;
+    ++tile;
+    slice_range(tr, B.a, B.b, lo, hi);
+    buf ^= 1;
+    S.keys = s_keys[buf]; S.smax = s_max[buf]; S.srf = s_rf[buf];
+    S.m = (hi - lo) < K1_SLICE ? (hi - lo) : K1_SLICE;
+    stage_slice(tr, lo, S, lane);
+    __syncthreads();
   }
 
-  // ---- span epilogue ----------------------------------------------------------
-  {
-    const uint64_t any_uns = ballot64(span_flags & SPANF_UNSORTED);
-    const uint64_t any_bad = ballot64(span_flags & SPANF_BADPOS);
-    if (lane == 0) {
-      uint32_t f = (any_uns ? SPANF_UNSORTED : 0u) | (any_bad ? SPANF_BADPOS : 0u);
-      if (f) atomicOr(&s_cnt[5], f);
-    }
+  // ---- span epilogue -------------------------------------------------------------------
+  for (int o = 32; o > 0; o >>= 1) {
+    acc_tpr += __shfl_xor(acc_tpr, o);
+    acc_fpr += __shfl_xor(acc_fpr, o);
   }
+  const uint64_t any_uns = ballot64(span_flags & SPANF_UNSORTED);
+  const uint64_t any_bad = ballot64(span_flags & SPANF_BADPOS);
   __syncthreads();
   uint32_t* oh = P.span_hist + (size_t)blockIdx.x * (3 * 256);
-  for (int i = tid; i < 3 * 256; i += K1_BLOCK) oh[i] = s_hist[i];
-  if (tid < 8) P.span_scal[(size_t)blockIdx.x * 8 + tid] = s_cnt[tid];
-  (void)s_flag;
+  for (int i = lane; i < 3 * 256; i += 64) oh[i] = s_hist[i];
+  if (lane == 0) {
+    uint32_t* sc = P.span_scal + (size_t)blockIdx.x * 8;
+    sc[0] = acc_pass; sc[1] = acc_tp; sc[2] = acc_pass - acc_tp; sc[3] = acc_tpr; sc[4] = acc_fpr;
+    sc[5] = (any_uns ? SPANF_UNSORTED : 0u) | (any_bad ? SPANF_BADPOS : 0u);
+    sc[6] = 0; sc[7] = 0;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -414,15 +478,14 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
 }
 
 // ---------------------------------------------------------------------------
-// k_compact: ballot masks -> compacted line-index lists.  One workgroup per tile.
-// idx region of VCF v (vd.n entries at vd.off): TP ascending from the front,
-// FP ascending, ending at the back.
+// k_compact: ballot masks -> compacted line-index lists.  One wave per 512-record
+// tile (4 tiles per workgroup).  idx region of VCF v (vd.n entries at vd.off):
+// TP line indices ascending from the front, FP ascending, ending at the back.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_compact(CompactParams P) {
-  const int tile = (int)blockIdx.x;
-  const int tid = (int)threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
+__global__ __launch_bounds__(256) void k_compact(CompactParams P, int n_tiles) {
+  const int lane = (int)(threadIdx.x & 63);
+  const int tile = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  if (tile >= n_tiles) return;
   const int v = P.tile_vcf[tile];
   const VcfDesc vd = P.vcfs[v];
   const int64_t tb = vd.off + (int64_t)(tile - vd.tile0) * K1_TILE;
@@ -435,27 +498,20 @@ __global__ __launch_bounds__(256) void k_compact(CompactParams P) {
   const int lastt = vd.tile0 + vd.ntiles - 1;
   const int64_t fp_total = (int64_t)P.tile_fp_off[lastt] + P.tile_fp[lastt];
   int32_t* out = P.idx + vd.off;
-  int64_t tp_base = P.tile_tp_off[tile];
-  int64_t fp_base = (vd.n - fp_total) + P.tile_fp_off[tile];
-
-  // each wave handles words wave, wave+4, ...; needs the counts of earlier words
-  __shared__ uint32_t s_tp[32], s_fp[32];
-  if (tid < 32) {
-    uint64_t a = 0, b = 0;
-    if (tid < nwords) { a = mt[tid]; b = mp[tid] & ~a; }
-    s_tp[tid] = (uint32_t)__popcll(a);
-    s_fp[tid] = (uint32_t)__popcll(b);
-  }
-  __syncthreads();
-  for (int w = wave; w < nwords; w += 4) {
-    uint32_t ptp = 0, pfp = 0;
-    for (int j = 0; j < w; ++j) { ptp += s_tp[j]; pfp += s_fp[j]; }
-    const uint64_t wt = mt[w];
-    const uint64_t wf = mp[w] & ~wt;
-    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
-    const int32_t rel = (int32_t)(tb - vd.off) + w * 64 + lane;
-    if ((wt >> lane) & 1ull) out[tp_base + ptp + __popcll(wt & below)] = rel;
-    if ((wf >> lane) & 1ull) out[fp_base + pfp + __popcll(wf & below)] = rel;
+  int64_t tp_at = P.tile_tp_off[tile];
+  int64_t fp_at = (vd.n - fp_total) + P.tile_fp_off[tile];
+  const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+  const int32_t rel0 = (int32_t)(tb - vd.off) + lane;
+#pragma unroll
+  for (int w = 0; w < K1_TILE / 64; ++w) {
+    if (w < nwords) {  // wave-uniform
+      const uint64_t wt = mt[w];
+      const uint64_t wf = mp[w] & ~wt;
+      if ((wt >> lane) & 1ull) out[tp_at + __popcll(wt & below)] = rel0 + w * 64;
+      if ((wf >> lane) & 1ull) out[fp_at + __popcll(wf & below)] = rel0 + w * 64;
+      tp_at += __popcll(wt);
+      fp_at += __popcll(wf);
+    }
   }
 }
 
@@ -671,13 +727,13 @@ __global__ void k_overlap_count(const uint32_t* keys, const uint32_t* vals, int6
 // launchers (called from qmvt_api.cpp through qmvt_dev.h)
 // ---------------------------------------------------------------------------
 void launch_classify(const ClassifyParams& P, int n_spans, hipStream_t st) {
-  if (n_spans > 0) hipLaunchKernelGGL(k_classify, dim3(n_spans), dim3(K1_BLOCK), 0, st, P);
+  if (n_spans > 0) hipLaunchKernelGGL(k_classify, dim3(n_spans), dim3(64), 0, st, P);
 }
 void launch_finalize(const FinalizeParams& P, int n_vcf, hipStream_t st) {
   if (n_vcf > 0) hipLaunchKernelGGL(k_finalize, dim3(n_vcf), dim3(256), 0, st, P);
 }
 void launch_compact(const CompactParams& P, int n_tiles, hipStream_t st) {
-  if (n_tiles > 0) hipLaunchKernelGGL(k_compact, dim3(n_tiles), dim3(256), 0, st, P);
+  if (n_tiles > 0) hipLaunchKernelGGL(k_compact, dim3((n_tiles + 3) / 4), dim3(256), 0, st, P, n_tiles);
 }
 void launch_masks_to_cls(const uint64_t* mp, const uint64_t* mt, int64_t off, int64_t n, uint8_t* cls, hipStream_t st) {
   if (n > 0) hipLaunchKernelGGL(k_masks_to_cls, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mp, mt, off, n, cls);

@@ -89,7 +89,8 @@ def random_columns(rng, n, genome_len, truth, frac_truth=0.3, sorted_=True, dup_
     snp = (ref >= 0) & (ref < 4) & (alt >= 0) & (alt < 4)
     passed = snp & (np.floor(qual) >= 20)
     iddot = rng.random(n) > (0.05 if weird else 0.0)
-    flags = (passed.astype(np.uint8)) | (iddot.astype(np.uint8) << 1)
+    nokey = (rng.random(n) < 0.02) if weird else np.zeros(n, bool)
+    flags = (passed.astype(np.uint8)) | (iddot.astype(np.uint8) << 1) | (nokey.astype(np.uint8) << 2)
     if sorted_ and n:
         o = np.argsort(pos, kind="stable")
         pos, ref, alt, qual, flags = pos[o], ref[o], alt[o], qual[o], flags[o]

@@ -89,12 +89,12 @@ def _python_restatement(pos, ref, alt, qual, flags, truth, n_bins):
     for i in range(n):
         k = (int(pos[i]), int(ref[i]), int(alt[i]))
         snp = 0 <= k[1] < 4 and 0 <= k[2] < 4
-        hit = snp and k in tset
+        hit = snp and k in tset and not (flags[i] & 4)
         iddot = bool(flags[i] & 2)
         passed = bool(flags[i] & 1) and snp
         if passed:
             cls[i] = 3 if (hit and iddot) else 1
-            (tr_keys if hit else fp_keys).add(k)
+            (tr_keys if hit else fp_keys).add(k + (bool(flags[i] & 4),))   # keyless records are keys of their own
         q = float(qual[i])
         b = -1 if (q != q or q < 0) else int(min(np.floor(q), n_bins - 1))
         if snp and b >= 0:
