@@ -8,7 +8,7 @@ namespace qm {
 
 constexpr int K1_ROUNDS = 4;                 // rounds of 256 records (4 consecutive per lane) per tile
 constexpr int K1_TILE = 256 * K1_ROUNDS;     // 1024 records: one LDS truth slice, one TP/FP line count
-constexpr int K1_SLICE = 512;                // truth keys per LDS slice buffer (two buffers per wave)
+constexpr int K1_SLICE = 256;                // truth keys per LDS slice buffer (two buffers per wave)
 constexpr int SPAN_TILES = 16;               // tiles per wave = per workgroup (one histogram flush per span)
 constexpr int VCF_ALIGN = 256;                     // device start of every VCF (records)
 constexpr int SORT_TILE = 2048;

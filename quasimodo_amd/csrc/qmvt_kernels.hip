@@ -64,12 +64,17 @@ __device__ __forceinline__ int lds_lower_bound(const uint32_t* __restrict__ k, i
 //
 // One workgroup = ONE wave (64 lanes) = one span of up to SPAN_TILES consecutive
 // tiles of one VCF; no workgroup barriers.  Units:
-//   round = 256 records, register resident (4 consecutive records per lane:
-//           dwordx4 per column + one dword of flags).  The next round's loads are
-//           issued before the current round is touched (register double buffer).
+//   round = 256 records.  Loaded 4 consecutive records per lane (dwordx4 per column
+//           + one dword of flags) with the NEXT round's loads already in flight,
+//           packed to (key, info) words and staged in LDS.  The join then runs from
+//           the sparse side: every truth key of the round's position range (one per
+//           lane) binary-searches the 256 staged record keys and marks its matches.
+//           The per-record pass re-reads the round in lane-major order (record
+//           l + 64k), so one wave ballot per slot is a natural-order mask word.
 //   tile  = K1_ROUNDS rounds = the unit that owns a slice of the sorted truth keys
 //           in LDS (double buffered: tile t+1's slice is staged while t finishes),
 //           the per-truth-entry state for U(t)/TP_R, and one TP/FP line count.
+// All record indices are 32-bit and relative to the VCF (n < 2^31).
 // ---------------------------------------------------------------------------
 struct Rec4 {
   int p[4], r[4], a[4];
@@ -77,30 +82,60 @@ struct Rec4 {
   uint32_t f;  // 4 flag bytes
 };
 
-__device__ __forceinline__ void load_rec4(const ClassifyParams& P, int64_t idx, Rec4& R) {
-  const int4 pv = *reinterpret_cast<const int4*>(P.pos + idx);
-  const int4 rv = *reinterpret_cast<const int4*>(P.ref + idx);
-  const int4 av = *reinterpret_cast<const int4*>(P.alt + idx);
-  const float4 qv = *reinterpret_cast<const float4*>(P.qual + idx);
-  R.f = *reinterpret_cast<const uint32_t*>(P.flags + idx);
+struct Cols {  // column bases of one VCF
+  const int32_t* pos;
+  const int32_t* ref;
+  const int32_t* alt;
+  const float* qual;
+  const uint8_t* flags;
+};
+
+__device__ __forceinline__ void load_rec4(const Cols& C, int idx, Rec4& R) {
+  const int4 pv = *reinterpret_cast<const int4*>(C.pos + idx);
+  const int4 rv = *reinterpret_cast<const int4*>(C.ref + idx);
+  const int4 av = *reinterpret_cast<const int4*>(C.alt + idx);
+  const float4 qv = *reinterpret_cast<const float4*>(C.qual + idx);
+  R.f = *reinterpret_cast<const uint32_t*>(C.flags + idx);
   R.p[0] = pv.x; R.p[1] = pv.y; R.p[2] = pv.z; R.p[3] = pv.w;
   R.r[0] = rv.x; R.r[1] = rv.y; R.r[2] = rv.z; R.r[3] = rv.w;
   R.a[0] = av.x; R.a[1] = av.y; R.a[2] = av.z; R.a[3] = av.w;
   R.q[0] = qv.x; R.q[1] = qv.y; R.q[2] = qv.z; R.q[3] = qv.w;
 }
 
-struct TileBounds {
-  int a, b;          // first / last position of the tile
-  int prevp, nextp;  // position just before / after it (INT32_MIN at the VCF edge)
+// info word of a staged record
+constexpr uint32_t I_BIN1 = 0x1ffu;      // bin + 1 (0 = passes no threshold)
+constexpr uint32_t I_PASS = 1u << 9;     // flags bit0
+constexpr uint32_t I_IDDOT = 1u << 10;   // flags bit1
+constexpr uint32_t I_NOKEY = 1u << 11;   // flags bit2
+constexpr uint32_t I_LIVE = 1u << 12;    // in range, single-base alleles: takes part in matching and ROC
+constexpr uint32_t I_VALID = 1u << 13;   // inside the tile
+constexpr uint32_t I_BADPOS = 1u << 14;  // valid and position outside [0, 2^28)
+constexpr uint32_t I_HIT = 1u << 16;     // set by the truth key that matches it
+
+// LDS layout of the wave (dword offsets into one array, so every access is a ds_ op)
+constexpr int L_HIST = 0;                               // [3][256] TP / FP / distinct-truth-key histograms
+constexpr int L_KEYS = 768;                             // [2][K1_SLICE] staged truth keys
+constexpr int L_SMAX = L_KEYS + 2 * K1_SLICE;           // [2][K1_SLICE] per key: max(bin + 1) of '.'-ID matches
+constexpr int L_SRF = L_SMAX + 2 * K1_SLICE;            // [2][K1_SLICE / 32] per key: matched by a kept record
+constexpr int L_RKEY = L_SRF + 2 * (K1_SLICE / 32);     // [256] record keys of the round (16-byte aligned)
+constexpr int L_RINF = L_RKEY + 256;                    // [256] record info words
+constexpr int L_TOTAL = L_RINF + 256;
+static_assert(L_RKEY % 4 == 0, "b128 LDS stores need 16-byte alignment");
+
+struct Slice {
+  int keys, smax, srf;  // dword offsets of the active buffer
+  int m;                // keys staged
 };
 
-__device__ __forceinline__ TileBounds tile_bounds(const ClassifyParams& P, int64_t tb, int64_t te, int64_t vbegin, int64_t vend) {
-  TileBounds t;
-  t.a = P.pos[tb];
-  t.b = P.pos[te - 1];
-  t.prevp = (tb > vbegin) ? P.pos[tb - 1] : INT32_MIN;
-  t.nextp = (te < vend) ? P.pos[te] : INT32_MIN;
-  return t;
+__device__ __forceinline__ void slice_select(Slice& S, int buf) {
+  S.keys = L_KEYS + buf * K1_SLICE;
+  S.smax = L_SMAX + buf * K1_SLICE;
+  S.srf = L_SRF + buf * (K1_SLICE / 32);
+}
+
+__device__ __forceinline__ void stage_slice(uint32_t* lds, const TruthDev& tr, int c0, const Slice& S, int lane) {
+  for (int j = lane; j < S.m; j += 64) { lds[S.keys + j] = tr.keys[c0 + j]; lds[S.smax + j] = 0; }
+  if (lane < K1_SLICE / 32) lds[S.srf + lane] = 0;
 }
 
 // truth slice [lo, hi) covering positions a..b, from the coarse position index
@@ -115,66 +150,117 @@ __device__ __forceinline__ void slice_range(const TruthDev& tr, int a, int b, in
   if (hi < lo) hi = lo;  // only on unsorted input (results discarded)
 }
 
-struct Slice {
-  uint32_t* keys;
-  uint32_t* smax;  // per key: max(bin + 1) over '.'-ID single-base matches (U histogram)
-  uint32_t* srf;   // per key: matched by a kept record (TP_R), one bit each
-  int m;           // keys staged
-  int top;         // largest power of two <= m
+struct SegBounds {   // a run of records that owns truth-entry state (a tile, or a round on the slow path)
+  int a, b;          // first / last position
+  int prevp, nextp;  // position just before / after it (INT32_MIN at the VCF edge)
 };
 
-__device__ __forceinline__ void stage_slice(const TruthDev& tr, int c0, Slice& S, int lane) {
-  for (int j = lane; j < S.m; j += 64) { S.keys[j] = tr.keys[c0 + j]; S.smax[j] = 0; }
-  if (lane < K1_SLICE / 32) S.srf[lane] = 0;
-  S.top = S.m > 0 ? 1 << (31 - __clz(S.m)) : 0;
+__device__ __forceinline__ SegBounds seg_bounds(const int32_t* pos, int sb, int se, int vn) {
+  SegBounds t;
+  t.a = pos[sb];
+  t.b = pos[se - 1];
+  t.prevp = (sb > 0) ? pos[sb - 1] : INT32_MIN;
+  t.nextp = (se < vn) ? pos[se] : INT32_MIN;
+  return t;
 }
 
-__device__ __forceinline__ void slice_update(const Slice& S, int j, uint32_t fl, float q, int nb) {
-  const int bin = qual_bin(q, nb);
-  if ((fl & QMF_IDDOT) && bin >= 0) atomicMax(&S.smax[j], (uint32_t)(bin + 1));
-  if (fl & QMF_PASS) atomicOr(&S.srf[j >> 5], 1u << (j & 31));
-}
-
-// search the 4 records of a round in the slice; returns the hit nibble.  `own_a` is
-// INT32_MIN when the tile owns the run at its first position, else that position
-// (the run started in an earlier tile, which owns its truth entries).
-__device__ __forceinline__ uint32_t search_round(const Slice& S, const Rec4& R, int64_t i0, int64_t te, int own_a, int nb) {
-  uint32_t hits = 0;
-  if (S.m <= 0) return 0;
-  uint32_t key[4];
-  int fnd[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) key[k] = pack_key(R.p[k], R.r[k], R.a[k]);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) fnd[k] = lds_lower_bound(S.keys, S.m, S.top, key[k]);
+// ---- phase A: pack the round (4 consecutive records per lane) into LDS ----------------
+__device__ __forceinline__ void stage_round(uint32_t* lds, const Rec4& R, int i0, int te, int nb, int lane) {
+  uint4 kv, iv;
+  uint32_t key[4], inf[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const uint32_t fl = (R.f >> (8 * k)) & 0xffu;
-    const bool ok = (i0 + k < te) && (uint32_t)R.p[k] < (uint32_t)QM_POS_LIMIT_DEV && is_snp(R.r[k], R.a[k]) && !(fl & QMF_NOKEY);
-    const int j = fnd[k];
-    if (ok && j < S.m && S.keys[j] == key[k]) {
-      hits |= 1u << k;
-      if (R.p[k] != own_a) slice_update(S, j, fl, R.q[k], nb);
-    }
+    const uint32_t fl = (R.f >> (8 * k)) & 7u;
+    const bool valid = i0 + k < te;
+    const bool okpos = (uint32_t)R.p[k] < (uint32_t)QM_POS_LIMIT_DEV;
+    const bool live = valid & okpos & is_snp(R.r[k], R.a[k]);
+    const int bin = qual_bin(R.q[k], nb);
+    key[k] = valid ? (((uint32_t)R.p[k] << 4) | (live ? ((uint32_t)R.r[k] << 2) | (uint32_t)R.a[k] : 0u)) : 0xffffffffu;
+    inf[k] = (uint32_t)(bin + 1) | (fl << 9) | (live ? I_LIVE : 0u) | (valid ? I_VALID : 0u) | ((valid & !okpos) ? I_BADPOS : 0u);
   }
-  return hits;
+  kv.x = key[0]; kv.y = key[1]; kv.z = key[2]; kv.w = key[3];
+  iv.x = inf[0]; iv.y = inf[1]; iv.z = inf[2]; iv.w = inf[3];
+  *reinterpret_cast<uint4*>(&lds[L_RKEY + lane * 4]) = kv;
+  *reinterpret_cast<uint4*>(&lds[L_RINF + lane * 4]) = iv;
 }
 
-// records of later tiles that continue this tile's last run of equal positions
-__device__ __forceinline__ void continue_run(const ClassifyParams& P, const Slice& S, int64_t te, int64_t vend, int bpos, int nb, int lane) {
-  for (int64_t base = te; base < vend; base += 64) {
-    const int64_t i = base + lane;
+// ---- phase B: the truth keys of the round's position range search the staged records ----
+// own_a: INT32_MIN when the segment owns the run at its first position, else that position
+// (the run started in an earlier segment, which owns its truth entries).
+__device__ __forceinline__ void join_round(uint32_t* lds, const Slice& S, int nrec, int own_a, int lane) {
+  if (S.m <= 0 || nrec <= 0) return;
+  const uint32_t first_pos = lds[L_RKEY] >> 4;
+  const uint32_t last_pos = lds[L_RKEY + nrec - 1] >> 4;
+  // keys of the slice inside [first_pos, last_pos]: counted with ballots
+  int rlo = 0, rhi = 0;
+  for (int base = 0; base < S.m; base += 64) {
+    const int j = base + lane;
+    const uint32_t kp = j < S.m ? lds[S.keys + j] >> 4 : 0xffffffffu;
+    rlo += popc64(ballot64(kp < first_pos));
+    rhi += popc64(ballot64(kp <= last_pos));
+  }
+  for (int base = rlo; base < rhi; base += 64) {
+    const int j = base + lane;
+    if (j < rhi) {
+      const uint32_t kkey = lds[S.keys + j];
+      const uint32_t kpos = kkey >> 4;
+      // first staged record with position >= kpos
+      int s = 0;
+#pragma unroll
+      for (int step = 128; step > 0; step >>= 1) {
+        const int idx = s + step;
+        if ((lds[L_RKEY + idx - 1] >> 4) < kpos) s = idx;   // idx - 1 <= 254
+      }
+      if (s < 256 && (lds[L_RKEY + s] >> 4) < kpos) s += 1;   // s == 255 still below
+      uint32_t mx = 0, rf = 0;
+      for (; s < nrec; ++s) {   // the run of records at this position
+        const uint32_t rk = lds[L_RKEY + s];
+        if ((rk >> 4) != kpos) break;
+        if (rk != kkey) continue;
+        const uint32_t inf = lds[L_RINF + s];
+        if ((inf & (I_LIVE | I_NOKEY)) != I_LIVE) continue;
+        atomicOr(&lds[L_RINF + s], I_HIT);
+        if ((int)kpos != own_a) {
+          const uint32_t b1 = inf & I_BIN1;
+          if ((inf & I_IDDOT) && b1 > mx) mx = b1;
+          rf |= (inf & I_PASS) ? 1u : 0u;
+        }
+      }
+      if (mx) atomicMax(&lds[S.smax + j], mx);
+      if (rf) atomicOr(&lds[S.srf + (j >> 5)], 1u << (j & 31));
+    }
+  }
+}
+
+// number of staged slice keys < key (records of later tiles look themselves up: rare path)
+__device__ __forceinline__ int slice_lower_bound(const uint32_t* lds, const Slice& S, uint32_t key) {
+  int lo = 0, n = S.m;
+  while (n > 0) {
+    const int h = n >> 1;
+    if (lds[S.keys + lo + h] < key) { lo += h + 1; n -= h + 1; } else n = h;
+  }
+  return lo;
+}
+
+// records after the segment that continue its last run of equal positions
+__device__ __noinline__ void continue_run(const Cols& C, uint32_t* lds, const Slice& S, int se, int vn, int bpos, int nb, int lane) {
+  for (int base = se; base < vn; base += 64) {
+    const int i = base + lane;
     bool cont = false;
-    if (i < vend) {
-      const int p = P.pos[i];
+    if (i < vn) {
+      const int p = C.pos[i];
       cont = (p == bpos);
       if (cont && S.m > 0) {
-        const int r_ = P.ref[i], a_ = P.alt[i];
-        const uint32_t fl = P.flags[i];
+        const int r_ = C.ref[i], a_ = C.alt[i];
+        const uint32_t fl = C.flags[i];
         if (is_snp(r_, a_) && (uint32_t)p < (uint32_t)QM_POS_LIMIT_DEV && !(fl & QMF_NOKEY)) {
           const uint32_t key = pack_key(p, r_, a_);
-          const int j = lds_lower_bound(S.keys, S.m, S.top, key);
-          if (j < S.m && S.keys[j] == key) slice_update(S, j, fl, P.qual[i], nb);
+          const int j = slice_lower_bound(lds, S, key);
+          if (j < S.m && lds[S.keys + j] == key) {
+            const int bin = qual_bin(C.qual[i], nb);
+            if ((fl & QMF_IDDOT) && bin >= 0) atomicMax(&lds[S.smax + j], (uint32_t)(bin + 1));
+            if (fl & QMF_PASS) atomicOr(&lds[S.srf + (j >> 5)], 1u << (j & 31));
+          }
         }
       }
     }
@@ -182,186 +268,176 @@ __device__ __forceinline__ void continue_run(const ClassifyParams& P, const Slic
   }
 }
 
-__device__ __forceinline__ uint32_t flush_slice(const Slice& S, uint32_t* s_hist, int lane) {
+__device__ __forceinline__ uint32_t flush_slice(uint32_t* lds, const Slice& S, int lane) {
   uint32_t tpr = 0;
   for (int j = lane; j < S.m; j += 64) {
-    const uint32_t mx = S.smax[j];
-    if (mx) atomicAdd(&s_hist[512 + mx - 1], 1u);
-    tpr += (S.srf[j >> 5] >> (j & 31)) & 1u;
+    const uint32_t mx = lds[S.smax + j];
+    if (mx) atomicAdd(&lds[L_HIST + 512 + mx - 1], 1u);
+    tpr += (lds[S.srf + (j >> 5)] >> (j & 31)) & 1u;
   }
   return tpr;
 }
 
+// Has a kept record with this (pos, ref, alt) been seen earlier in the VCF?  Only called
+// when the predecessor has the same position; walks that run of equal positions
+// backwards.  <= 16 distinct single-base keys per position bound the walk per run.
+__device__ __noinline__ uint32_t repeated_key(const Cols& C, int i, int p, int ra, uint32_t nokey) {
+  for (int j = i - 1; j >= 0; --j) {
+    if (C.pos[j] != p) break;
+    const uint32_t fj = C.flags[j];
+    const int rj = C.ref[j], aj = C.alt[j];
+    if ((fj & QMF_PASS) && (fj & QMF_NOKEY) == nokey && is_snp(rj, aj) && ((rj << 2) | aj) == ra) return 1u;
+  }
+  return 0u;
+}
+
+struct Acc {
+  uint32_t bad;              // per lane: bit0 order violated, bit1 position out of range
+  uint32_t fpr;              // per lane: distinct kept keys outside the truth set
+  uint32_t top_tp, top_fp;   // per lane: counts of the saturated top bin (real QUALs pile up there)
+};
+
+// ---- phase C: per-record pass in lane-major order (record 64 k + lane) ------------------
+__device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, int rbase, int prev_pos, int nb, int ablate,
+                                               uint64_t* mpass, uint64_t* mtp, Acc& A, uint32_t& n_pass, uint32_t& n_tp, int lane) {
+  uint64_t wp[4], wt[4];
+  int carry = prev_pos;  // position of the record before slot k's lane 0
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t key = lds[L_RKEY + 64 * k + lane];
+    const uint32_t inf = lds[L_RINF + 64 * k + lane];
+    const int p = (int)(key >> 4);
+    int pp = __shfl_up(p, 1);
+    if (lane == 0) pp = carry;
+    carry = __shfl(p, 63);
+    const bool valid = (inf & I_VALID) != 0;
+    const bool live = (inf & I_LIVE) != 0;
+    const bool hit = (inf & I_HIT) != 0;
+    const bool pass = live & ((inf & I_PASS) != 0);
+    const bool tpkey = hit & ((inf & I_IDDOT) != 0);
+    A.bad |= ((valid & (p < pp)) ? 1u : 0u) | ((inf & I_BADPOS) ? 2u : 0u);
+    wp[k] = ballot64(pass);
+    wt[k] = ballot64(pass & tpkey);
+    // ROC histograms: one count per live record with a bin
+    const int bin = (int)(inf & I_BIN1) - 1;
+    const bool counted = live & (bin >= 0);
+    const bool sat = counted & (bin == nb - 1);
+    A.top_tp += (sat & tpkey) ? 1u : 0u;
+    A.top_fp += (sat & !tpkey) ? 1u : 0u;
+    if (counted && !sat && !(ablate & 2)) atomicAdd(&lds[L_HIST + (tpkey ? 0 : 256) + bin], 1u);
+    // R path: distinct kept keys outside the truth set
+    const bool fpkey = pass & !hit;
+    A.fpr += fpkey ? 1u : 0u;
+    if (fpkey && p == pp && !(ablate & 8)) A.fpr -= repeated_key(C, rbase + 64 * k + lane, p, (int)(key & 15u), (inf & I_NOKEY) ? QMF_NOKEY : 0u);
+  }
+  if (lane < 4) {
+    const uint64_t vp = lane == 0 ? wp[0] : lane == 1 ? wp[1] : lane == 2 ? wp[2] : wp[3];
+    const uint64_t vt = lane == 0 ? wt[0] : lane == 1 ? wt[1] : lane == 2 ? wt[2] : wt[3];
+    mpass[(rbase >> 6) + lane] = vp;
+    mtp[(rbase >> 6) + lane] = vt;
+  }
+  n_pass += (uint32_t)(popc64(wp[0]) + popc64(wp[1]) + popc64(wp[2]) + popc64(wp[3]));
+  n_tp += (uint32_t)(popc64(wt[0]) + popc64(wt[1]) + popc64(wt[2]) + popc64(wt[3]));
+}
+
 __global__ __launch_bounds__(64) void k_classify(ClassifyParams P) {
-  __shared__ uint32_t s_keys[2][K1_SLICE];
-  __shared__ uint32_t s_max[2][K1_SLICE];
-  __shared__ uint32_t s_rf[2][K1_SLICE / 32];
-  __shared__ uint32_t s_hist[3 * 256];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[L_TOTAL];
 
   const int lane = (int)threadIdx.x;
   const SpanDesc sp = P.spans[blockIdx.x];
   const VcfDesc vd = P.vcfs[sp.vcf];
   const TruthDev tr = P.truths[vd.truth];
-  const int64_t vbegin = vd.off;
-  const int64_t vend = vd.off + vd.n;
+  Cols C;
+  C.pos = P.pos + vd.off; C.ref = P.ref + vd.off; C.alt = P.alt + vd.off; C.qual = P.qual + vd.off; C.flags = P.flags + vd.off;
+  uint64_t* const mpass = P.mask_pass + (vd.off >> 6);
+  uint64_t* const mtp = P.mask_tp + (vd.off >> 6);
+  const int vn = (int)vd.n;
+  const int sp_end = (int)(sp.end - vd.off);
   const int nb = P.n_bins;
+  const int ablate = P.ablate;
 
-  for (int i = lane; i < 3 * 256; i += 64) s_hist[i] = 0;
-  uint32_t span_flags = 0;
+  for (int i = lane; i < 3 * 256; i += 64) lds[L_HIST + i] = 0;
+  Acc A = {0u, 0u, 0u, 0u};
   uint32_t acc_pass = 0, acc_tp = 0;  // wave-uniform
-  uint32_t acc_tpr = 0, acc_fpr = 0;  // per lane, reduced at the end
+  uint32_t acc_tpr = 0;               // per lane, reduced at the end
 
   // ---- prologue: first round in flight, first tile's bounds and slice -------------
-  int64_t tb = sp.begin;
-  int64_t te = (tb + K1_TILE < sp.end) ? tb + K1_TILE : sp.end;
+  int tb = (int)(sp.begin - vd.off);
+  int te = (tb + K1_TILE < sp_end) ? tb + K1_TILE : sp_end;
   Rec4 N;
-  load_rec4(P, tb + lane * 4, N);
-  TileBounds B = tile_bounds(P, tb, te, vbegin, vend);
+  load_rec4(C, tb + lane * 4, N);
+  SegBounds B = seg_bounds(C.pos, tb, te, vn);
   int lo, hi;
   slice_range(tr, B.a, B.b, lo, hi);
   int buf = 0;
   Slice S;
-  S.keys = s_keys[0]; S.smax = s_max[0]; S.srf = s_rf[0];
-  S.m = (hi - lo) < K1_SLICE ? (hi - lo) : K1_SLICE;
-  stage_slice(tr, lo, S, lane);
+  slice_select(S, 0);
+  S.m = (hi - lo) <= K1_SLICE ? (hi - lo) : 0;   // an oversize slice is handled round by round
+  stage_slice(lds, tr, lo, S, lane);
   __syncthreads();
 
   int tile = sp.tile0;
   for (;;) {
-    const bool has_next_tile = te < sp.end;
-    const int64_t ntb = tb + K1_TILE;
-    const int64_t nte = (ntb + K1_TILE < sp.end) ? ntb + K1_TILE : sp.end;
-    const bool started_before = (tb > vbegin) && (B.prevp == B.a);
+    const bool has_next_tile = te < sp_end;
+    const int ntb = tb + K1_TILE;
+    const int nte = (ntb + K1_TILE < sp_end) ? ntb + K1_TILE : sp_end;
+    const bool oversize = (hi - lo) > K1_SLICE;
+    const bool started_before = (tb > 0) && (B.prevp == B.a);
     const int own_a = started_before ? B.a : INT32_MIN;
     const bool owns_b = !(started_before && B.a == B.b);
-    const int nrounds = (int)((te - tb + 255) >> 8);
+    const int nrounds = (te - tb + 255) >> 8;
 
-    // ---- dense truth / sparse VCF: the keys beyond the staged chunk, as a pre-pass ----
-    uint32_t prehit = 0;
-    if (hi - lo > K1_SLICE && !(P.ablate & 1)) {
-      for (int c0 = lo + K1_SLICE; c0 < hi; c0 += K1_SLICE) {
-        __syncthreads();
-        S.m = (hi - c0) < K1_SLICE ? (hi - c0) : K1_SLICE;
-        stage_slice(tr, c0, S, lane);
-        __syncthreads();
-        for (int r = 0; r < nrounds; ++r) {
-          Rec4 T;
-          const int64_t i0 = tb + r * 256 + lane * 4;
-          load_rec4(P, i0, T);
-          prehit |= search_round(S, T, i0, te, own_a, nb) << (4 * r);
-        }
-        if (B.nextp == B.b && owns_b) continue_run(P, S, te, vend, B.b, nb, lane);
-        __syncthreads();
-        acc_tpr += flush_slice(S, s_hist, lane);
-      }
-      __syncthreads();
-      S.m = K1_SLICE;
-      stage_slice(tr, lo, S, lane);
-      __syncthreads();
-    }
-
-    // ---- the tile's rounds: next round's loads first, then search + per-record work ----
-    TileBounds NB = B;
+    SegBounds NB = B;
     uint32_t tile_np = 0, tile_nt = 0;
+    int prev_pos = B.prevp;
     for (int r = 0; r < nrounds; ++r) {
       const Rec4 R = N;
-      const int64_t rbase = tb + r * 256;
-      const int64_t i0 = rbase + lane * 4;
+      const int rbase = tb + r * 256;
+      const int rend = rbase + 256 < te ? rbase + 256 : te;
+      // next round's records into flight first
       if (r + 1 < nrounds) {
-        load_rec4(P, i0 + 256, N);
+        load_rec4(C, rbase + 256 + lane * 4, N);
       } else if (has_next_tile) {
-        load_rec4(P, ntb + lane * 4, N);
-        NB = tile_bounds(P, ntb, nte, vbegin, vend);
+        load_rec4(C, ntb + lane * 4, N);
+        NB = seg_bounds(C.pos, ntb, nte, vn);
       }
-      uint32_t hits = (prehit >> (4 * r)) & 15u;
-      if (!(P.ablate & 1)) hits |= search_round(S, R, i0, te, own_a, nb);
-
-      int prevp = __shfl_up(R.p[3], 1);
-      if (lane == 0) prevp = (r == 0) ? B.prevp : P.pos[rbase - 1];
-      uint32_t nib_pass = 0, nib_tp = 0;
-      bool unsorted = false;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int64_t i = i0 + k;
-        const bool valid = i < te;
-        const uint32_t fl = (R.f >> (8 * k)) & 0xffu;
-        const int p = R.p[k];
-        const bool okpos = (uint32_t)p < (uint32_t)QM_POS_LIMIT_DEV;
-        if (valid && !okpos) span_flags |= SPANF_BADPOS;
-        const bool snp = valid && okpos && is_snp(R.r[k], R.a[k]);
-        const bool hit = (hits >> k) & 1u;
-        const bool pass = snp && (fl & QMF_PASS);
-        const bool tpkey = hit && (fl & QMF_IDDOT);
-        nib_pass |= (pass ? 1u : 0u) << k;
-        nib_tp |= ((pass && tpkey) ? 1u : 0u) << k;
-        const int pp = (k == 0) ? prevp : R.p[k - 1];
-        if (valid && p < pp) unsorted = true;
-        // ROC histograms: one count per single-base record with a bin
-        const int bin = qual_bin(R.q[k], nb);
-        const bool counted = snp && bin >= 0;
-        if (!(P.ablate & 2)) {
-          const bool sat = counted && bin == nb - 1;  // real data piles up in the top bin
-          const uint64_t sat_tp = ballot64(sat && tpkey);
-          const uint64_t sat_fp = ballot64(sat && !tpkey);
-          if (lane == 0) {
-            if (sat_tp) atomicAdd(&s_hist[nb - 1], (uint32_t)popc64(sat_tp));
-            if (sat_fp) atomicAdd(&s_hist[256 + nb - 1], (uint32_t)popc64(sat_fp));
+      stage_round(lds, R, rbase + lane * 4, te, nb, lane);
+      __syncthreads();
+      if (!(ablate & 1)) {
+        if (!oversize) {
+          join_round(lds, S, rend - rbase, own_a, lane);
+        } else {
+          // dense truth against a sparse VCF: this round is its own owner of truth state,
+          // and its slice is walked in chunks staged on the spot
+          const SegBounds RB = seg_bounds(C.pos, rbase, rend, vn);
+          const bool r_started = (rbase > 0) && (RB.prevp == RB.a);
+          const int r_own_a = r_started ? RB.a : INT32_MIN;
+          int rlo, rhi;
+          slice_range(tr, RB.a, RB.b, rlo, rhi);
+          for (int c0 = rlo; c0 < rhi; c0 += K1_SLICE) {
+            S.m = (rhi - c0) < K1_SLICE ? (rhi - c0) : K1_SLICE;
+            stage_slice(lds, tr, c0, S, lane);
+            __syncthreads();
+            join_round(lds, S, rend - rbase, r_own_a, lane);
+            if (RB.nextp == RB.b && !(r_started && RB.a == RB.b)) continue_run(C, lds, S, rend, vn, RB.b, nb, lane);
+            __syncthreads();
+            acc_tpr += flush_slice(lds, S, lane);
+            __syncthreads();
           }
-          if (counted && !sat) atomicAdd(&s_hist[(tpkey ? 0 : 256) + bin], 1u);
-        }
-        // R path: distinct kept keys outside the truth set.  Only a record whose
-        // predecessor has the same position can be a repeat; walk that run backwards
-        // (<= 16 distinct single-base keys per position bound the total walk per run).
-        if (pass && !hit && !(P.ablate & 8)) {
-          bool first = true;
-          if (p == pp) {
-            const uint32_t nk = fl & QMF_NOKEY;
-            for (int64_t j = i - 1; j >= vbegin; --j) {
-              if (P.pos[j] != p) break;
-              const uint32_t fj = P.flags[j];
-              if ((fj & QMF_PASS) && (fj & QMF_NOKEY) == nk && P.ref[j] == R.r[k] && P.alt[j] == R.a[k]) { first = false; break; }
-            }
-          }
-          acc_fpr += first ? 1u : 0u;
+          S.m = 0;
         }
       }
-      if (unsorted) span_flags |= SPANF_UNSORTED;
-
-      // ---- wave ballots -> natural-order 64-bit mask words ---------------------------
-      if (!(P.ablate & 4)) {
-        const int sel = lane & 3;
-        const int sh = lane >> 2;
-        uint64_t wp[4], wt[4];
-        {
-          const uint64_t b0 = ballot64(nib_pass & 1u), b1 = ballot64(nib_pass & 2u);
-          const uint64_t b2 = ballot64(nib_pass & 4u), b3 = ballot64(nib_pass & 8u);
-          const uint64_t mine = sel == 0 ? b0 : sel == 1 ? b1 : sel == 2 ? b2 : b3;
-#pragma unroll
-          for (int w = 0; w < 4; ++w) wp[w] = ballot64((mine >> (16 * w + sh)) & 1ull);
-        }
-        {
-          const uint64_t b0 = ballot64(nib_tp & 1u), b1 = ballot64(nib_tp & 2u);
-          const uint64_t b2 = ballot64(nib_tp & 4u), b3 = ballot64(nib_tp & 8u);
-          const uint64_t mine = sel == 0 ? b0 : sel == 1 ? b1 : sel == 2 ? b2 : b3;
-#pragma unroll
-          for (int w = 0; w < 4; ++w) wt[w] = ballot64((mine >> (16 * w + sh)) & 1ull);
-        }
-        if (lane < 4) {
-          const uint64_t vp = lane == 0 ? wp[0] : lane == 1 ? wp[1] : lane == 2 ? wp[2] : wp[3];
-          const uint64_t vt = lane == 0 ? wt[0] : lane == 1 ? wt[1] : lane == 2 ? wt[2] : wt[3];
-          P.mask_pass[(rbase >> 6) + lane] = vp;
-          P.mask_tp[(rbase >> 6) + lane] = vt;
-        }
-        tile_np += (uint32_t)(popc64(wp[0]) + popc64(wp[1]) + popc64(wp[2]) + popc64(wp[3]));
-        tile_nt += (uint32_t)(popc64(wt[0]) + popc64(wt[1]) + popc64(wt[2]) + popc64(wt[3]));
-      }
+      __syncthreads();
+      classify_round(lds, C, rbase, prev_pos, nb, ablate, mpass, mtp, A, tile_np, tile_nt, lane);
+      prev_pos = (int)(lds[L_RKEY + 255] >> 4);
+      __syncthreads();
     }
 
     // ---- tile epilogue: run continuation, per-truth-entry state -> histogram, counts ----
-    if (!(P.ablate & 1)) {
-      if (B.nextp == B.b && owns_b) continue_run(P, S, te, vend, B.b, nb, lane);
+    if (!(ablate & 1) && !oversize) {
+      if (B.nextp == B.b && owns_b) continue_run(C, lds, S, te, vn, B.b, nb, lane);
       __syncthreads();
-      acc_tpr += flush_slice(S, s_hist, lane);
+      acc_tpr += flush_slice(lds, S, lane);
     }
     if (lane == 0) {
       P.tile_tp[tile] = tile_nt;
@@ -378,25 +454,32 @@ __global__ __launch_bounds__(64) void k_classify(ClassifyParams P) {
     ++tile;
     slice_range(tr, B.a, B.b, lo, hi);
     buf ^= 1;
-    S.keys = s_keys[buf]; S.smax = s_max[buf]; S.srf = s_rf[buf];
-    S.m = (hi - lo) < K1_SLICE ? (hi - lo) : K1_SLICE;
-    stage_slice(tr, lo, S, lane);
+    slice_select(S, buf);
+    S.m = (hi - lo) <= K1_SLICE ? (hi - lo) : 0;
+    stage_slice(lds, tr, lo, S, lane);
     __syncthreads();
   }
 
   // ---- span epilogue -------------------------------------------------------------------
   for (int o = 32; o > 0; o >>= 1) {
     acc_tpr += __shfl_xor(acc_tpr, o);
-    acc_fpr += __shfl_xor(acc_fpr, o);
+    A.fpr += __shfl_xor(A.fpr, o);
+    A.top_tp += __shfl_xor(A.top_tp, o);
+    A.top_fp += __shfl_xor(A.top_fp, o);
   }
-  const uint64_t any_uns = ballot64(span_flags & SPANF_UNSORTED);
-  const uint64_t any_bad = ballot64(span_flags & SPANF_BADPOS);
+  const uint64_t any_uns = ballot64(A.bad & 1u);
+  const uint64_t any_bad = ballot64(A.bad & 2u);
   __syncthreads();
   uint32_t* oh = P.span_hist + (size_t)blockIdx.x * (3 * 256);
-  for (int i = lane; i < 3 * 256; i += 64) oh[i] = s_hist[i];
+  for (int i = lane; i < 3 * 256; i += 64) {
+    uint32_t v = lds[L_HIST + i];
+    if (i == nb - 1) v += A.top_tp;
+    if (i == 256 + nb - 1) v += A.top_fp;
+    oh[i] = v;
+  }
   if (lane == 0) {
     uint32_t* sc = P.span_scal + (size_t)blockIdx.x * 8;
-    sc[0] = acc_pass; sc[1] = acc_tp; sc[2] = acc_pass - acc_tp; sc[3] = acc_tpr; sc[4] = acc_fpr;
+    sc[0] = acc_pass; sc[1] = acc_tp; sc[2] = acc_pass - acc_tp; sc[3] = acc_tpr; sc[4] = A.fpr;
     sc[5] = (any_uns ? SPANF_UNSORTED : 0u) | (any_bad ? SPANF_BADPOS : 0u);
     sc[6] = 0; sc[7] = 0;
   }

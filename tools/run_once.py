@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Minimal driver for profiling: build one synthetic batch, run the path a few times.
+usage: python3 tools/run_once.py [n_vcf] [runs] [shuffled]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import quasimodo_amd as q
+
+nv = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+runs = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+shuffled = len(sys.argv) > 3 and sys.argv[3] == "1"
+eng = q.Engine(0)
+tid = eng.truth_synth(5_000_000, 100_000, 3)
+b = eng.batch([1_000_000] * nv, [tid] * nv)
+b.synth(5_000_000, 100_000, 3, 3000, shuffled=shuffled)
+b.set_timing(True)
+for _ in range(runs):
+    b.run()
+    b.finish()
+t = b.timings()
+byts = nv * (17e6 + 1.2e6)
+print("n_vcf=%d classify %.3f ms (%.0f GB/s algorithmic) finalize %.3f compact %.3f total %.3f" %
+      (nv, t["classify_ms"], byts / t["classify_ms"] / 1e6, t["finalize_ms"], t["compact_ms"], t["total_ms"]))
