@@ -112,6 +112,19 @@ constexpr uint32_t I_VALID = 1u << 13;   // inside the tile
 constexpr uint32_t I_BADPOS = 1u << 14;  // valid and position outside [0, 2^28)
 constexpr uint32_t I_HIT = 1u << 16;     // set by the truth key that matches it
 
+typedef const __attribute__((address_space(1))) uint32_t* gu32p;
+typedef const __attribute__((address_space(1))) int32_t* gi32p;
+struct TruthG {   // TruthDev with global-address-space pointers: its loads are global_load, never flat_load
+  gu32p keys;
+  gi32p tidx;
+  int32_t shift, nb;
+};
+__device__ __forceinline__ TruthG truth_global(const TruthDev& t) {
+  TruthG g;
+  g.keys = (gu32p)t.keys; g.tidx = (gi32p)t.tidx; g.shift = t.shift; g.nb = t.nb;
+  return g;
+}
+
 // LDS layout of the wave (dword offsets into one array, so every access is a ds_ op)
 constexpr int L_HIST = 0;                               // [3][256] TP / FP / distinct-truth-key histograms
 constexpr int L_KEYS = 768;                             // [2][K1_SLICE] staged truth keys
@@ -133,13 +146,13 @@ __device__ __forceinline__ void slice_select(Slice& S, int buf) {
   S.srf = L_SRF + buf * (K1_SLICE / 32);
 }
 
-__device__ __forceinline__ void stage_slice(uint32_t* lds, const TruthDev& tr, int c0, const Slice& S, int lane) {
+__device__ __forceinline__ void stage_slice(uint32_t* lds, const TruthG& tr, int c0, const Slice& S, int lane) {
   for (int j = lane; j < S.m; j += 64) { lds[S.keys + j] = tr.keys[c0 + j]; lds[S.smax + j] = 0; }
   if (lane < K1_SLICE / 32) lds[S.srf + lane] = 0;
 }
 
 // truth slice [lo, hi) covering positions a..b, from the coarse position index
-__device__ __forceinline__ void slice_range(const TruthDev& tr, int a, int b, int& lo, int& hi) {
+__device__ __forceinline__ void slice_range(const TruthG& tr, int a, int b, int& lo, int& hi) {
   uint32_t ba = (uint32_t)a >> tr.shift;
   uint32_t bb = ((uint32_t)b >> tr.shift) + 1u;
   const uint32_t lim = (uint32_t)tr.nb + 1u;
@@ -243,7 +256,7 @@ __device__ __forceinline__ int slice_lower_bound(const uint32_t* lds, const Slic
 }
 
 // records after the segment that continue its last run of equal positions
-__device__ __noinline__ void continue_run(const Cols& C, uint32_t* lds, const Slice& S, int se, int vn, int bpos, int nb, int lane) {
+__device__ __forceinline__ void continue_run(const Cols& C, uint32_t* lds, const Slice& S, int se, int vn, int bpos, int nb, int lane) {
   for (int base = se; base < vn; base += 64) {
     const int i = base + lane;
     bool cont = false;
@@ -281,7 +294,7 @@ __device__ __forceinline__ uint32_t flush_slice(uint32_t* lds, const Slice& S, i
 // Has a kept record with this (pos, ref, alt) been seen earlier in the VCF?  Only called
 // when the predecessor has the same position; walks that run of equal positions
 // backwards.  <= 16 distinct single-base keys per position bound the walk per run.
-__device__ __noinline__ uint32_t repeated_key(const Cols& C, int i, int p, int ra, uint32_t nokey) {
+__device__ __forceinline__ uint32_t repeated_key(const Cols& C, int i, int p, int ra, uint32_t nokey) {
   for (int j = i - 1; j >= 0; --j) {
     if (C.pos[j] != p) break;
     const uint32_t fj = C.flags[j];
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(64) void k_classify(ClassifyParams P) {
   const int lane = (int)threadIdx.x;
   const SpanDesc sp = P.spans[blockIdx.x];
   const VcfDesc vd = P.vcfs[sp.vcf];
-  const TruthDev tr = P.truths[vd.truth];
+  const TruthG tr = truth_global(P.truths[vd.truth]);
   Cols C;
   C.pos = P.pos + vd.off; C.ref = P.ref + vd.off; C.alt = P.alt + vd.off; C.qual = P.qual + vd.off; C.flags = P.flags + vd.off;
   uint64_t* const mpass = P.mask_pass + (vd.off >> 6);
