@@ -302,12 +302,14 @@ static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int
 #undef A_
   if (rc == QM_OK) rc = upload_layout(b);
   if (rc == QM_OK) {
-    // padding lanes are masked in the kernels, but keep the columns defined
-    hipError_t e = hipMemset(b->flags, 0, np);
-    if (e == hipSuccess) e = hipMemset(b->pos, 0, np * 4);
-    if (e == hipSuccess) e = hipMemset(b->ref, 0, np * 4);
-    if (e == hipSuccess) e = hipMemset(b->alt, 0, np * 4);
-    if (e == hipSuccess) e = hipMemset(b->qual, 0, np * 4);
+    // padding lanes are masked in the kernels, but keep the columns defined.  On the context's
+    // stream (hipMemset on the null stream would not be ordered before work on a non-blocking stream).
+    hipError_t e = hipMemsetAsync(b->flags, 0, np, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b->pos, 0, np * 4, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b->ref, 0, np * 4, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b->alt, 0, np * 4, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(b->qual, 0, np * 4, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) rc = fail(QM_E_HIP, "hipMemset: %s", hipGetErrorString(e));
   }
   if (rc != QM_OK) { batch_free(b); return rc; }
