@@ -15,4 +15,6 @@ from .extract import (  # noqa: F401
     is_pure_strain,
 )
 
+from . import tables, workflow  # noqa: F401,E402
+
 __version__ = "0.1.0"

@@ -1,0 +1,93 @@
+"""R-free writers of the path's tables.
+
+  final_tables/caller_performance.tsv   scripts/caller_performance_compare.R:57-143
+  final_tables/snpcall_benchmark.txt    scripts/custom_snp_benchmark.R:30-95
+  final_tables/snpcaller_fp_snp_compare.txt   region sizes of the Venn diagrams drawn by
+                                        scripts/snpcaller_fp_compare.R (the PDF itself is out of scope)
+
+The counts come from the engine (Job.stats); only the three ratios are computed here, with R's
+round(x, 3) (R 3.5.1: x * 10^3 in long double, nearbyint, / 10^3).  Raw counts are written next to
+the rounded columns so that a tie-rounding difference between R versions is visible."""
+import math
+
+import numpy as np
+
+CALLER_MAP = {"bcftools": "BCFtools", "clc": "CLC", "freebayes": "FreeBayes", "gatk": "GATK", "lofreq": "LoFreq",
+              "varscan": "VarScan2"}  # caller_performance_compare.R:24-27
+
+
+def r_div(a, b):
+    """R's a / b on doubles: x/0 is Inf, 0/0 is NaN."""
+    a, b = float(a), float(b)
+    if b == 0.0:
+        return float("nan") if a == 0.0 else math.copysign(float("inf"), a)
+    return a / b
+
+
+def r_round3(x):
+    if x is None or math.isnan(x) or math.isinf(x):
+        return x
+    return float(np.rint(np.longdouble(x) * np.longdouble(1000.0)) / np.longdouble(1000.0))
+
+
+def r_str(x):
+    """write.table(quote = FALSE) formatting of one cell."""
+    if x is None:
+        return "NA"
+    if isinstance(x, str):
+        return x
+    if isinstance(x, (int, np.integer)):
+        return str(int(x))
+    if math.isnan(x):
+        return "NaN"
+    if math.isinf(x):
+        return "Inf" if x > 0 else "-Inf"
+    return "%.15g" % x
+
+
+def performance_row(stats):
+    """One VCF -> (genomediff, calleridentify, TP, FP, precision, recall, f1) as R computes them
+    (caller_performance_compare.R:84-128).  None = NA."""
+    n = int(stats["n_pass"])
+    if stats.get("pure_strain"):
+        return 0, n, 0, n, 0.0, None, None                       # :121-128
+    gd = int(stats["genomediff"])
+    if n == 0:
+        return gd, 0, 0, 0, None, None, None                      # :101-108
+    tp, fp = int(stats["TP_R"]), int(stats["FP_R"])
+    p = r_round3(r_div(tp, n))
+    r = r_round3(r_div(tp, gd))
+    f1 = r_round3(r_div(2 * (p * r), p + r))
+    return gd, n, tp, fp, p, r, f1
+
+
+def write_caller_performance(path, rows):
+    """rows: iterable of (caller_lower, sample, stats)."""
+    with open(path, "w") as fh:
+        fh.write("\t".join(["caller", "mixture", "genomediff", "calleridentify", "TP", "FP", "Precision", "Recall", "F1"]) + "\n")
+        for caller, sample, stats in rows:
+            vals = performance_row(stats)
+            fh.write("\t".join([CALLER_MAP.get(caller, caller), sample] + [r_str(v) for v in vals]) + "\n")
+
+
+def write_snpcall_benchmark(path, rows):
+    """rows: iterable of (label, stats).  custom_snp_benchmark.R:30-95."""
+    with open(path, "w") as fh:
+        fh.write("\t".join(["caller", "genomediff", "calleridentify", "TP", "FP", "precision", "recall", "f1"]) + "\n")
+        for label, stats in rows:
+            st = dict(stats)
+            st["pure_strain"] = False     # the custom script has no pure-strain branch
+            vals = performance_row(st)
+            fh.write("\t".join([label] + [r_str(v) for v in vals]) + "\n")
+
+
+def write_fp_overlap(path, per_sample, callers):
+    """per_sample: {sample: region counts indexed by membership mask (bit i = callers[i])}."""
+    n = len(callers)
+    with open(path, "w") as fh:
+        fh.write("\t".join(["sample", "callers", "count"]) + "\n")
+        for sample in sorted(per_sample):
+            reg = per_sample[sample]
+            for m in range(1, 1 << n):
+                names = "&".join(CALLER_MAP.get(callers[i], callers[i]) for i in range(n) if m >> i & 1)
+                fh.write("%s\t%s\t%d\n" % (sample, names, int(reg[m])))

@@ -1,0 +1,119 @@
+"""The path's slice of the two Snakemake workflows, without Snakemake.
+
+  hcmv -e variantcall (bundled-VCF mode): eval_variantcall.smk cp_vcf / cp_genome_diff (:62-93) ->
+      rules/extract_TP.smk -> rules/vis_eval_vcf.smk snp_evaluate (table only) -> rules/compare_FP.smk
+  vareval: eval_variant_custom.smk extract_TP (:58-74) -> snp_benchmark (table only, :76-92)
+
+Everything upstream (reads -> VCF, nucmer) and every figure is out of scope:
+the inputs must already exist.  Every mixed-sample VCF of a run goes through ONE engine batch."""
+import glob
+import os
+import shutil
+
+from .engine import Engine
+from .extract import Job, extract_many, is_pure_strain
+from .tables import write_caller_performance, write_fp_overlap, write_snpcall_benchmark
+from .vcfio import scan_vcf
+
+SAMPLE_REF = {  # rules/load_config.smk:20-23
+    "TM-0-1": "Merlin", "TM-1-1": "Merlin", "TM-1-10": "Merlin", "TM-1-50": "Merlin", "TM-1-0": "TB40E",
+    "TA-1-0": "TB40E", "TA-1-1": "AD169", "TA-1-10": "AD169", "TA-1-50": "AD169", "TA-0-1": "AD169"}
+SNPCALLERS = ["lofreq", "varscan", "clc", "bcftools", "freebayes", "gatk"]   # eval_variantcall.smk:10
+FP_COMPARED = ["lofreq", "clc", "varscan", "freebayes"]                       # rules/compare_FP.smk:1
+
+
+class WorkflowError(RuntimeError):
+    pass
+
+
+def _fp_keys(path):
+    """snpcaller_fp_compare.R:36-47: pos/ref/alt of the data rows with single-base alleles."""
+    with open(path, "rb") as fh:
+        sv = scan_vcf(fh.read())
+    keep = (sv.ref < 4) & (sv.alt < 4) & ((sv.flags & 4) == 0)
+    return sv.pos[keep], sv.ref[keep], sv.alt[keep]
+
+
+def fp_overlap_tables(engine, fp_files_by_sample, callers):
+    out = {}
+    for sample, files in fp_files_by_sample.items():
+        sets = [_fp_keys(files[c]) for c in callers]
+        out[sample] = engine.fp_overlap(sets)
+    return out
+
+
+def run_hcmv_variantcall(data_dir, outpath, callers=None, engine=None, dryrun=False):
+    """data_dir: the unpacked bundle (data/snp): vcf/{caller}/{sample}.{ref}.{caller}.vcf and
+    nucmer/{TM,TA}.maskrepeat.variants.vcf (rules/load_config.smk:28-36)."""
+    callers = list(callers or SNPCALLERS)
+    results = os.path.join(outpath.rstrip("/"), "results")
+    snp_dir = os.path.join(results, "snp")
+    call_dir = os.path.join(snp_dir, "callers")
+    samples = sorted(s for s in (os.path.basename(p).split(".")[0] for p in glob.glob(os.path.join(data_dir, "vcf", "clc", "*.clc.vcf")))
+                     if s in SAMPLE_REF)
+    if not samples:
+        raise WorkflowError("no bundled VCFs under %s/vcf/clc (data/snp.tar.gz not unpacked?)" % data_dir)
+    plan = []
+    for s in samples:
+        for c in callers:
+            src = os.path.join(data_dir, "vcf", c, "%s.%s.%s.vcf" % (s, SAMPLE_REF[s], c))
+            if not os.path.exists(src):
+                raise WorkflowError("missing input %s" % src)
+            plan.append((s, c, src))
+    if dryrun:
+        for s, c, src in plan:
+            print("extractTP\t%s\t%s" % (c, src))
+        return None
+    os.makedirs(os.path.join(snp_dir, "nucmer"), exist_ok=True)
+    for mix in ("TM", "TA"):                                           # cp_genome_diff
+        src = os.path.join(data_dir, "nucmer", "%s.maskrepeat.variants.vcf" % mix)
+        if os.path.exists(src):
+            shutil.copyfile(src, os.path.join(snp_dir, "nucmer", os.path.basename(src)))
+    jobs, meta = [], []
+    for s, c, src in plan:                                              # cp_vcf
+        d = os.path.join(call_dir, c)
+        os.makedirs(os.path.join(d, "fp"), exist_ok=True)
+        dst = os.path.join(d, os.path.basename(src))
+        shutil.copyfile(src, dst)
+        jobs.append(Job(dst, os.path.join(snp_dir, "nucmer", "%s.maskrepeat.variants.vcf" % s[:2]), "hcmv", d, c))
+        meta.append((c, s))
+    own = engine is None
+    if own:
+        engine = Engine(int(os.environ.get("QM_DEVICE", "0")))
+    try:
+        extract_many(jobs, engine=engine)                                # extractTP, one batch
+        os.makedirs(os.path.join(results, "final_tables"), exist_ok=True)
+        write_caller_performance(os.path.join(results, "final_tables", "caller_performance.tsv"),
+                                 [(c, s, j.stats) for (c, s), j in zip(meta, jobs)])
+        mixed = [s for s in samples if not s.endswith(("-1-0", "-0-1"))]
+        cmp_callers = [c for c in FP_COMPARED if c in callers]
+        if mixed and len(cmp_callers) >= 2:                              # compareFP (counts only)
+            files = {s: {c: j.fp_out for (c, ss), j in zip(meta, jobs) if ss == s and c in cmp_callers} for s in mixed}
+            reg = fp_overlap_tables(engine, files, cmp_callers)
+            write_fp_overlap(os.path.join(results, "final_tables", "snpcaller_fp_snp_compare.txt"), reg, cmp_callers)
+    finally:
+        if own:
+            engine.close()
+    return jobs
+
+
+def run_vareval(vcfs, snps_file, outpath, labels=None, engine=None, dryrun=False):
+    """eval_variant_custom.smk with the genome difference (show-snps -CTHIlr TSV) already computed."""
+    results = os.path.join(outpath.rstrip("/"), "results")
+    call_dir = os.path.join(results, "snp", "callers")
+    labels = list(labels) if labels else [os.path.splitext(os.path.basename(v))[0] for v in vcfs]
+    if len(labels) != len(vcfs):
+        raise WorkflowError("labels and vcfs differ in length")
+    if dryrun:
+        for lab, v in zip(labels, vcfs):
+            print("extract_TP\t%s\t%s" % (lab, v))
+        return None
+    if not os.path.exists(snps_file) or os.path.getsize(snps_file) == 0:
+        raise WorkflowError("No difference between two genomes!")       # custom_snp_benchmark.R:19-21
+    os.makedirs(os.path.join(call_dir, "fp"), exist_ok=True)
+    jobs = [Job(v, snps_file, "custom", call_dir, lab) for lab, v in zip(labels, vcfs)]
+    extract_many(jobs, engine=engine)
+    os.makedirs(os.path.join(results, "final_tables"), exist_ok=True)
+    write_snpcall_benchmark(os.path.join(results, "final_tables", "snpcall_benchmark.txt"),
+                            [(lab, j.stats) for lab, j in zip(labels, jobs)])
+    return jobs

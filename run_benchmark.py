@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""run_benchmark.py -- the reference's CLI surface (run_benchmark.py:62-192) for the commands
+that sit on the accelerated path.
+
+  hcmv    -e variantcall   TP/FP extraction + caller_performance.tsv + FP overlap counts on the bundled VCFs
+  vareval                  the same for user VCFs against a precomputed genome difference
+
+Everything that is not this path (read mapping, variant calling, nucmer, assembly evaluation,
+figures) is out of scope and reported as such; `asmeval` and `-e assembly` exit with status 2."""
+import os
+import sys
+
+import click
+
+wd = os.path.dirname(os.path.realpath(__file__))
+sys.path.insert(0, wd)
+VERSION = "0.4.2"
+cd = os.getcwd()
+
+
+def print_version(ctx, param, value):
+    if not value or ctx.resilient_parsing:
+        return
+    click.echo("Version {}".format(VERSION))
+    ctx.exit()
+
+
+@click.group()
+@click.option("--version", is_flag=True, callback=print_version, expose_value=False, is_eager=True, help="Print the version.")
+def cli():
+    pass
+
+
+def common_options(f):
+    for opt in reversed([
+        click.option("-d", "--dryrun", is_flag=True, default=False, show_default=True, help="Print the details without run the pipeline."),
+        click.option("-t", "--threads", type=int, default=2, show_default=True, help="The number of threads to use."),
+        click.option("-c", "--conda_prefix", type=click.Path(exists=True), default=None, help="Accepted for compatibility; unused."),
+        click.option("-o", "--outpath", type=click.Path(), default=None, help="The directory where to put the results."),
+    ]):
+        f = opt(f)
+    return f
+
+
+def _fail(e):
+    from datetime import datetime
+    print("ERROR")
+    print("{}\t{}\n".format(datetime.now().isoformat(" ", timespec="minutes"), e))
+    raise RuntimeError(e)
+
+
+@cli.command(help="Benchmarking for HCMV dataset")
+@common_options
+@click.option("-e", "--evaluation", required=True, type=click.Choice(["all", "variantcall", "assembly"]), help="The evaluation to run.")
+@click.option("-s", "--slow", is_flag=True, default=False, show_default=True, help="Run the evaluation based on reads (not supported by this build).")
+@click.option("--data", type=click.Path(), default=None, help="Unpacked bundle directory (default: <repo>/data/snp).")
+def hcmv(evaluation, dryrun=False, conda_prefix=None, slow=False, outpath=None, threads=2, data=None):
+    if slow:
+        click.echo("--slow (reads -> VCF) is outside the accelerated path; not supported", err=True)
+        sys.exit(2)
+    if evaluation == "assembly":
+        click.echo("assembly evaluation is outside the accelerated path; not supported", err=True)
+        sys.exit(2)
+    from quasimodo_amd import workflow
+    out = os.path.join(cd, outpath) if outpath else os.path.join(cd, "..", "revision_output_1")   # config/config.yaml outpath
+    try:
+        workflow.run_hcmv_variantcall(data or os.path.join(wd, "data", "snp"), out, dryrun=dryrun)
+    except Exception as e:
+        _fail(e)
+    if evaluation == "all":
+        click.echo("assembly evaluation skipped: outside the accelerated path", err=True)
+
+
+@cli.command(help="Variants benchmark for customized dataset")
+@common_options
+@click.option("-v", "--vcfs", type=str, help="Comma-separated list of VCF files.")
+@click.option("-l", "--labels", help="Comma-separated list of labels of VCF.", default=None)
+@click.option("-r", "--refs", type=str, help="Comma-separated list of reference genome files (used to name the genome difference).")
+@click.option("--novenn", is_flag=True, help="Accepted for compatibility; no figure is drawn.")
+@click.option("--snps", type=click.Path(), default=None,
+              help="show-snps -CTHIlr table of the two references; default <outpath>/results/snp/nucmer/<g1>_<g2>.maskrepeat.snps")
+def vareval(dryrun=False, conda_prefix=None, vcfs=None, labels=None, refs=None, novenn=False, outpath=None, threads=2, snps=None):
+    if not vcfs or not outpath:
+        _fail("The VCF files from SNP calling or the output directory are not specified.")
+    vlist = [os.path.join(cd, v.strip()) for v in vcfs.split(",")]
+    out = os.path.join(cd, outpath)
+    if snps is None:
+        if not refs:
+            _fail("The reference genome files are not specified.")
+        g = [os.path.splitext(os.path.basename(r.strip()))[0] for r in refs.split(",")]
+        snps = os.path.join(out, "results", "snp", "nucmer", "%s_%s.maskrepeat.snps" % (g[0], g[1]))   # eval_variant_custom.smk:14-17,40
+    from quasimodo_amd import workflow
+    try:
+        workflow.run_vareval(vlist, snps, out, labels=labels.split(",") if labels else None, dryrun=dryrun)
+    except Exception as e:
+        _fail(e)
+
+
+@cli.command(help="Assembly benchmark for customized dataset (not on the accelerated path)")
+@common_options
+@click.option("-s", "--scaffolds", type=str)
+@click.option("-r", "--refs", type=str)
+def asmeval(**kwargs):
+    click.echo("asmeval is outside the accelerated path; not supported", err=True)
+    sys.exit(2)
+
+
+if __name__ == "__main__":
+    cli()
