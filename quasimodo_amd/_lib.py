@@ -5,7 +5,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
-_SO = os.path.join(_CSRC, "libqmvt.so")
+_SO = os.environ.get("QM_LIBQMVT") or os.path.join(_CSRC, "libqmvt.so")   # override only for A/B builds of the kernels
 
 QM_N_SCALARS = 8
 SCALAR_NAMES = ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R", "sorted", "n_records", "truth_unique")

@@ -403,7 +403,7 @@ static FinalizeParams finalize_params(qm_batch* b, uint64_t* global) {
 }
 static CompactParams compact_params(qm_batch* b) {
   CompactParams C;
-  C.vcfs = b->d_vcfs; C.tile_vcf = b->d_tile_vcf; C.mask_pass = b->mask_pass; C.mask_tp = b->mask_tp;
+  C.vcfs = b->d_vcfs; C.spans = b->d_spans; C.mask_pass = b->mask_pass; C.mask_tp = b->mask_tp;
   C.tile_fp = b->tile_fp; C.tile_tp_off = b->tile_tp_off; C.tile_fp_off = b->tile_fp_off; C.idx = b->idx;
   return C;
 }
@@ -431,7 +431,7 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
   if (b->timing) HIPCHK(hipEventRecord(ev[1], st));
   launch_finalize(finalize_params(b, g), b->n_vcf, st);
   if (b->timing) HIPCHK(hipEventRecord(ev[2], st));
-  launch_compact(compact_params(b), (int)b->L.tile_vcf.size(), st);
+  launch_compact(compact_params(b), (int)b->L.spans.size(), st);
   if (b->timing) { HIPCHK(hipEventRecord(ev[3], st)); b->n_timed++; }
   HIPCHK(hipGetLastError());
   b->ran = true;
@@ -553,7 +553,7 @@ static int rescan_and_compact(qm_batch* b, hipStream_t st) {
   FinalizeParams F = finalize_params(b, nullptr);
   F.roc = tmp_roc; F.scalars = tmp_scal; F.vcf_flags = tmp_flags;
   launch_finalize(F, b->n_vcf, st);
-  launch_compact(compact_params(b), (int)b->L.tile_vcf.size(), st);
+  launch_compact(compact_params(b), (int)b->L.spans.size(), st);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   (void)hipFree(tmp_roc); (void)hipFree(tmp_scal); (void)hipFree(tmp_flags);

@@ -80,7 +80,7 @@ struct FinalizeParams {
 
 struct CompactParams {
   const VcfDesc* vcfs;
-  const int32_t* tile_vcf;
+  const SpanDesc* spans;
   const uint64_t* mask_pass;
   const uint64_t* mask_tp;
   const uint32_t* tile_fp;
@@ -157,7 +157,7 @@ __host__ __device__ inline void synth_record(int64_t L, int64_t N, int64_t T, ui
 // ---- launchers ---------------------------------------------------------------
 void launch_classify(const ClassifyParams& P, int n_spans, hipStream_t st);
 void launch_finalize(const FinalizeParams& P, int n_vcf, hipStream_t st);
-void launch_compact(const CompactParams& P, int n_tiles, hipStream_t st);
+void launch_compact(const CompactParams& P, int n_spans, hipStream_t st);
 void launch_masks_to_cls(const uint64_t* mp, const uint64_t* mt, int64_t off, int64_t n, uint8_t* cls, hipStream_t st);
 void launch_synth(const SynthParams& S, int n_vcf, int64_t max_n, hipStream_t st);
 void launch_sort_init(const int32_t* pos, int64_t off, int64_t n, uint32_t* keys, uint32_t* vals, hipStream_t st);

@@ -354,7 +354,10 @@ __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, int
 }
 
 __global__ __launch_bounds__(64) void k_classify(ClassifyParams P) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds[L_TOTAL];
+#ifndef K1_LDS_PAD
+#define K1_LDS_PAD 0
+#endif
+  __shared__ __attribute__((aligned(16))) uint32_t lds[L_TOTAL + K1_LDS_PAD];
 
   const int lane = (int)threadIdx.x;
   const SpanDesc sp = P.spans[blockIdx.x];
@@ -574,39 +577,53 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
 }
 
 // ---------------------------------------------------------------------------
-// k_compact: ballot masks -> compacted line-index lists.  One wave per 512-record
-// tile (4 tiles per workgroup).  idx region of VCF v (vd.n entries at vd.off):
-// TP line indices ascending from the front, FP ascending, ending at the back.
+// k_compact: ballot masks -> compacted line-index lists (prefix-sum compaction).
+// One wave per span (the same spans as k_classify: <= SPAN_TILES tiles of one VCF).
+// The span's mask words are fetched with a few coalesced vector loads (lane l holds
+// words l, l + 64, ...) and broadcast from registers; per word a lane tests its bit,
+// ranks itself with popc(word & lanemask_lt) on top of a running offset and stores
+// its VCF-relative line index.  idx region of VCF v (vd.n entries at vd.off): TP line
+// indices ascending from the front, FP ascending, ending at the back.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_compact(CompactParams P, int n_tiles) {
-  const int lane = (int)(threadIdx.x & 63);
-  const int tile = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
-  if (tile >= n_tiles) return;
-  const int v = P.tile_vcf[tile];
-  const VcfDesc vd = P.vcfs[v];
-  const int64_t tb = vd.off + (int64_t)(tile - vd.tile0) * K1_TILE;
-  const int64_t vend = vd.off + vd.n;
-  const int64_t te = tb + K1_TILE < vend ? tb + K1_TILE : vend;
-  const int nwords = (int)((te - tb + 63) >> 6);
-  const uint64_t* mp = P.mask_pass + (tb >> 6);
-  const uint64_t* mt = P.mask_tp + (tb >> 6);
+constexpr int K3_WORDS = SPAN_TILES * K1_TILE / 64;   // mask words per span
+constexpr int K3_REGS = (K3_WORDS + 63) / 64;
+
+__global__ __launch_bounds__(64) void k_compact(CompactParams P) {
+  const int lane = (int)threadIdx.x;
+  const SpanDesc sp = P.spans[blockIdx.x];
+  const VcfDesc vd = P.vcfs[sp.vcf];
+  const int sb = (int)(sp.begin - vd.off);
+  const int se = (int)(sp.end - vd.off);
+  const int nwords = (se - sb + 63) >> 6;
+  const uint64_t* mp = P.mask_pass + ((vd.off + sb) >> 6);
+  const uint64_t* mt = P.mask_tp + ((vd.off + sb) >> 6);
+  uint64_t rp[K3_REGS], rt[K3_REGS];
+#pragma unroll
+  for (int i = 0; i < K3_REGS; ++i) {
+    const int w = i * 64 + lane;
+    rp[i] = w < nwords ? mp[w] : 0ull;
+    rt[i] = w < nwords ? mt[w] : 0ull;
+  }
   // total FP lines of the VCF = offset of its last tile + that tile's count
   const int lastt = vd.tile0 + vd.ntiles - 1;
-  const int64_t fp_total = (int64_t)P.tile_fp_off[lastt] + P.tile_fp[lastt];
+  const uint32_t fp_total = P.tile_fp_off[lastt] + P.tile_fp[lastt];
   int32_t* out = P.idx + vd.off;
-  int64_t tp_at = P.tile_tp_off[tile];
-  int64_t fp_at = (vd.n - fp_total) + P.tile_fp_off[tile];
+  uint32_t tp_at = P.tile_tp_off[sp.tile0];
+  uint32_t fp_at = ((uint32_t)vd.n - fp_total) + P.tile_fp_off[sp.tile0];
   const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
-  const int32_t rel0 = (int32_t)(tb - vd.off) + lane;
 #pragma unroll
-  for (int w = 0; w < K1_TILE / 64; ++w) {
-    if (w < nwords) {  // wave-uniform
-      const uint64_t wt = mt[w];
-      const uint64_t wf = mp[w] & ~wt;
-      if ((wt >> lane) & 1ull) out[tp_at + __popcll(wt & below)] = rel0 + w * 64;
-      if ((wf >> lane) & 1ull) out[fp_at + __popcll(wf & below)] = rel0 + w * 64;
-      tp_at += __popcll(wt);
-      fp_at += __popcll(wf);
+  for (int i = 0; i < K3_REGS; ++i) {
+    const int wn = nwords - i * 64 < 64 ? nwords - i * 64 : 64;
+    for (int j = 0; j < wn; ++j) {
+      const uint32_t plo = __builtin_amdgcn_readlane((uint32_t)rp[i], j), phi = __builtin_amdgcn_readlane((uint32_t)(rp[i] >> 32), j);
+      const uint32_t tlo = __builtin_amdgcn_readlane((uint32_t)rt[i], j), thi = __builtin_amdgcn_readlane((uint32_t)(rt[i] >> 32), j);
+      const uint64_t wt = ((uint64_t)thi << 32) | tlo;
+      const uint64_t wf = (((uint64_t)phi << 32) | plo) & ~wt;
+      const int32_t rel = sb + (i * 64 + j) * 64 + lane;
+      if ((wt >> lane) & 1ull) out[tp_at + (uint32_t)__popcll(wt & below)] = rel;
+      if ((wf >> lane) & 1ull) out[fp_at + (uint32_t)__popcll(wf & below)] = rel;
+      tp_at += (uint32_t)__popcll(wt);
+      fp_at += (uint32_t)__popcll(wf);
     }
   }
 }
@@ -828,8 +845,8 @@ void launch_classify(const ClassifyParams& P, int n_spans, hipStream_t st) {
 void launch_finalize(const FinalizeParams& P, int n_vcf, hipStream_t st) {
   if (n_vcf > 0) hipLaunchKernelGGL(k_finalize, dim3(n_vcf), dim3(256), 0, st, P);
 }
-void launch_compact(const CompactParams& P, int n_tiles, hipStream_t st) {
-  if (n_tiles > 0) hipLaunchKernelGGL(k_compact, dim3((n_tiles + 3) / 4), dim3(256), 0, st, P, n_tiles);
+void launch_compact(const CompactParams& P, int n_spans, hipStream_t st) {
+  if (n_spans > 0) hipLaunchKernelGGL(k_compact, dim3(n_spans), dim3(64), 0, st, P);
 }
 void launch_masks_to_cls(const uint64_t* mp, const uint64_t* mt, int64_t off, int64_t n, uint8_t* cls, hipStream_t st) {
   if (n > 0) hipLaunchKernelGGL(k_masks_to_cls, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mp, mt, off, n, cls);
