@@ -6,10 +6,19 @@
 
 namespace qm {
 
-constexpr int K1_ROUNDS = 4;                 // rounds of 256 records (4 consecutive per lane) per tile
+#ifndef QM_K1_ROUNDS
+#define QM_K1_ROUNDS 4
+#endif
+#ifndef QM_K1_SLICE
+#define QM_K1_SLICE 256
+#endif
+#ifndef QM_SPAN_TILES
+#define QM_SPAN_TILES 16
+#endif
+constexpr int K1_ROUNDS = QM_K1_ROUNDS;      // rounds of 256 records (4 consecutive per lane) per tile
 constexpr int K1_TILE = 256 * K1_ROUNDS;     // 1024 records: one LDS truth slice, one TP/FP line count
-constexpr int K1_SLICE = 256;                // truth keys per LDS slice buffer (two buffers per wave)
-constexpr int SPAN_TILES = 16;               // tiles per wave = per workgroup (one histogram flush per span)
+constexpr int K1_SLICE = QM_K1_SLICE;        // truth keys per LDS slice buffer (two buffers per wave)
+constexpr int SPAN_TILES = QM_SPAN_TILES;    // tiles per wave = per workgroup (one histogram flush per span)
 constexpr int VCF_ALIGN = 256;                     // device start of every VCF (records)
 constexpr int SORT_TILE = 2048;
 constexpr int QM_POS_LIMIT_DEV = 1 << 28;
