@@ -102,15 +102,12 @@ __device__ __forceinline__ void load_rec4(const Cols& C, int idx, Rec4& R) {
   R.q[0] = qv.x; R.q[1] = qv.y; R.q[2] = qv.z; R.q[3] = qv.w;
 }
 
-// info word of a staged record
+// 16-bit info of a staged record (what a matching truth key needs to know about it)
 constexpr uint32_t I_BIN1 = 0x1ffu;      // bin + 1 (0 = passes no threshold)
 constexpr uint32_t I_PASS = 1u << 9;     // flags bit0
 constexpr uint32_t I_IDDOT = 1u << 10;   // flags bit1
 constexpr uint32_t I_NOKEY = 1u << 11;   // flags bit2
-constexpr uint32_t I_LIVE = 1u << 12;    // in range, single-base alleles: takes part in matching and ROC
-constexpr uint32_t I_VALID = 1u << 13;   // inside the tile
-constexpr uint32_t I_BADPOS = 1u << 14;  // valid and position outside [0, 2^28)
-constexpr uint32_t I_HIT = 1u << 16;     // set by the truth key that matches it
+constexpr uint32_t I_LIVE = 1u << 12;    // inside the tile, position in range, single-base alleles
 
 typedef const __attribute__((address_space(1))) uint32_t* gu32p;
 typedef const __attribute__((address_space(1))) int32_t* gi32p;
@@ -126,14 +123,20 @@ __device__ __forceinline__ TruthG truth_global(const TruthDev& t) {
 }
 
 // LDS layout of the wave (dword offsets into one array, so every access is a ds_ op)
-constexpr int L_HIST = 0;                               // [3][256] TP / FP / distinct-truth-key histograms
-constexpr int L_KEYS = 768;                             // [2][K1_SLICE] staged truth keys
+constexpr int L_HIST = 0;                               // [3][128] TP / FP / distinct-truth-key histograms, two u16 bins per dword
+constexpr int L_KEYS = 384;                             // [2][K1_SLICE] staged truth keys
 constexpr int L_SMAX = L_KEYS + 2 * K1_SLICE;           // [2][K1_SLICE] per key: max(bin + 1) of '.'-ID matches
 constexpr int L_SRF = L_SMAX + 2 * K1_SLICE;            // [2][K1_SLICE / 32] per key: matched by a kept record
 constexpr int L_RKEY = L_SRF + 2 * (K1_SLICE / 32);     // [256] record keys of the round (16-byte aligned)
-constexpr int L_RINF = L_RKEY + 256;                    // [256] record info words
-constexpr int L_TOTAL = L_RINF + 256;
-static_assert(L_RKEY % 4 == 0, "b128 LDS stores need 16-byte alignment");
+constexpr int L_RINF = L_RKEY + 256;                    // [128] record infos, u16 each
+constexpr int L_HITS = L_RINF + 128;                    // [8] one bit per record of the round: matched a truth key
+constexpr int L_TOTAL = L_HITS + 8;
+static_assert(L_RKEY % 4 == 0 && L_RINF % 2 == 0, "b128 / b64 LDS stores need natural alignment");
+static_assert(SPAN_TILES * K1_TILE < 65536, "u16 histogram bins hold at most one span");
+
+__device__ __forceinline__ void hist_add(uint32_t* lds, int which, int bin) {
+  atomicAdd(&lds[L_HIST + which * 128 + (bin >> 1)], 1u << (16 * (bin & 1)));
+}
 
 struct Slice {
   int keys, smax, srf;  // dword offsets of the active buffer
@@ -177,24 +180,39 @@ __device__ __forceinline__ SegBounds seg_bounds(const int32_t* pos, int sb, int 
   return t;
 }
 
+// per-lane view of a staged round: one bit per record of the lane (4 consecutive records)
+struct Nib {
+  uint32_t live, pass, iddot, nokey;  // pass = live & PASS
+  int bin1[4];                        // bin + 1
+};
+
 // ---- phase A: pack the round (4 consecutive records per lane) into LDS ----------------
-__device__ __forceinline__ void stage_round(uint32_t* lds, const Rec4& R, int i0, int te, int nb, int lane) {
-  uint4 kv, iv;
+__device__ __forceinline__ void stage_round(uint32_t* lds, const Rec4& R, int i0, int te, int nb, int lane, Nib& X, uint32_t& bad) {
   uint32_t key[4], inf[4];
+  X.live = X.pass = X.iddot = X.nokey = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const uint32_t fl = (R.f >> (8 * k)) & 7u;
     const bool valid = i0 + k < te;
     const bool okpos = (uint32_t)R.p[k] < (uint32_t)QM_POS_LIMIT_DEV;
-    const bool live = valid & okpos & is_snp(R.r[k], R.a[k]);
-    const int bin = qual_bin(R.q[k], nb);
+    const bool live = valid & okpos & ((uint32_t)(R.r[k] | R.a[k]) < 4u);
+    const int b1 = qual_bin(R.q[k], nb) + 1;
+    X.bin1[k] = b1;
+    X.live |= (live ? 1u : 0u) << k;
+    X.pass |= ((live & ((fl & QMF_PASS) != 0)) ? 1u : 0u) << k;
+    X.iddot |= ((fl & QMF_IDDOT) ? 1u : 0u) << k;
+    X.nokey |= ((fl & QMF_NOKEY) ? 1u : 0u) << k;
+    bad |= (valid & !okpos) ? 2u : 0u;
     key[k] = valid ? (((uint32_t)R.p[k] << 4) | (live ? ((uint32_t)R.r[k] << 2) | (uint32_t)R.a[k] : 0u)) : 0xffffffffu;
-    inf[k] = (uint32_t)(bin + 1) | (fl << 9) | (live ? I_LIVE : 0u) | (valid ? I_VALID : 0u) | ((valid & !okpos) ? I_BADPOS : 0u);
+    inf[k] = (uint32_t)b1 | (fl << 9) | (live ? I_LIVE : 0u);
   }
+  uint4 kv;
   kv.x = key[0]; kv.y = key[1]; kv.z = key[2]; kv.w = key[3];
-  iv.x = inf[0]; iv.y = inf[1]; iv.z = inf[2]; iv.w = inf[3];
+  uint2 iv;
+  iv.x = inf[0] | (inf[1] << 16); iv.y = inf[2] | (inf[3] << 16);
   *reinterpret_cast<uint4*>(&lds[L_RKEY + lane * 4]) = kv;
-  *reinterpret_cast<uint4*>(&lds[L_RINF + lane * 4]) = iv;
+  *reinterpret_cast<uint2*>(&lds[L_RINF + lane * 2]) = iv;
+  if (lane < 8) lds[L_HITS + lane] = 0;
 }
 
 // ---- phase B: the truth keys of the round's position range search the staged records ----
@@ -230,9 +248,9 @@ __device__ __forceinline__ void join_round(uint32_t* lds, const Slice& S, int nr
         const uint32_t rk = lds[L_RKEY + s];
         if ((rk >> 4) != kpos) break;
         if (rk != kkey) continue;
-        const uint32_t inf = lds[L_RINF + s];
+        const uint32_t inf = (lds[L_RINF + (s >> 1)] >> (16 * (s & 1))) & 0xffffu;
         if ((inf & (I_LIVE | I_NOKEY)) != I_LIVE) continue;
-        atomicOr(&lds[L_RINF + s], I_HIT);
+        atomicOr(&lds[L_HITS + (s >> 5)], 1u << (s & 31));
         if ((int)kpos != own_a) {
           const uint32_t b1 = inf & I_BIN1;
           if ((inf & I_IDDOT) && b1 > mx) mx = b1;
@@ -285,7 +303,7 @@ __device__ __forceinline__ uint32_t flush_slice(uint32_t* lds, const Slice& S, i
   uint32_t tpr = 0;
   for (int j = lane; j < S.m; j += 64) {
     const uint32_t mx = lds[S.smax + j];
-    if (mx) atomicAdd(&lds[L_HIST + 512 + mx - 1], 1u);
+    if (mx) hist_add(lds, 2, (int)mx - 1);
     tpr += (lds[S.srf + (j >> 5)] >> (j & 31)) & 1u;
   }
   return tpr;
@@ -308,55 +326,74 @@ struct Acc {
   uint32_t bad;              // per lane: bit0 order violated, bit1 position out of range
   uint32_t fpr;              // per lane: distinct kept keys outside the truth set
   uint32_t top_tp, top_fp;   // per lane: counts of the saturated top bin (real QUALs pile up there)
+  uint32_t n_pass, n_tp;     // per lane: kept / TP lines of the current tile
 };
 
-// ---- phase C: per-record pass in lane-major order (record 64 k + lane) ------------------
-__device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, int rbase, int prev_pos, int nb, int ablate,
-                                               uint64_t* mpass, uint64_t* mtp, Acc& A, uint32_t& n_pass, uint32_t& n_tp, int lane) {
-  uint64_t wp[4], wt[4];
-  int carry = prev_pos;  // position of the record before slot k's lane 0
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const uint32_t key = lds[L_RKEY + 64 * k + lane];
-    const uint32_t inf = lds[L_RINF + 64 * k + lane];
-    const int p = (int)(key >> 4);
-    int pp = __shfl_up(p, 1);
-    if (lane == 0) pp = carry;
-    carry = __shfl(p, 63);
-    const bool valid = (inf & I_VALID) != 0;
-    const bool live = (inf & I_LIVE) != 0;
-    const bool hit = (inf & I_HIT) != 0;
-    const bool pass = live & ((inf & I_PASS) != 0);
-    const bool tpkey = hit & ((inf & I_IDDOT) != 0);
-    A.bad |= ((valid & (p < pp)) ? 1u : 0u) | ((inf & I_BADPOS) ? 2u : 0u);
-    wp[k] = ballot64(pass);
-    wt[k] = ballot64(pass & tpkey);
-    // ROC histograms: one count per live record with a bin
-    const int bin = (int)(inf & I_BIN1) - 1;
-    const bool counted = live & (bin >= 0);
-    const bool sat = counted & (bin == nb - 1);
-    A.top_tp += (sat & tpkey) ? 1u : 0u;
-    A.top_fp += (sat & !tpkey) ? 1u : 0u;
-    if (counted && !sat && !(ablate & 2)) atomicAdd(&lds[L_HIST + (tpkey ? 0 : 256) + bin], 1u);
-    // R path: distinct kept keys outside the truth set
-    const bool fpkey = pass & !hit;
-    A.fpr += fpkey ? 1u : 0u;
-    if (fpkey && p == pp && !(ablate & 8)) A.fpr -= repeated_key(C, rbase + 64 * k + lane, p, (int)(key & 15u), (inf & I_NOKEY) ? QMF_NOKEY : 0u);
-  }
-  if (lane < 4) {
-    const uint64_t vp = lane == 0 ? wp[0] : lane == 1 ? wp[1] : lane == 2 ? wp[2] : wp[3];
-    const uint64_t vt = lane == 0 ? wt[0] : lane == 1 ? wt[1] : lane == 2 ? wt[2] : wt[3];
-    mpass[(rbase >> 6) + lane] = vp;
-    mtp[(rbase >> 6) + lane] = vt;
-  }
-  n_pass += (uint32_t)(popc64(wp[0]) + popc64(wp[1]) + popc64(wp[2]) + popc64(wp[3]));
-  n_tp += (uint32_t)(popc64(wt[0]) + popc64(wt[1]) + popc64(wt[2]) + popc64(wt[3]));
+// inclusive OR over each group of 8 lanes, valid in lanes 8g+7 (DPP row_shr 1,2,4; rows are 16 lanes)
+__device__ __forceinline__ uint32_t or_reduce8(uint32_t v) {
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+  return v;
 }
 
-__global__ __launch_bounds__(64) void k_classify(ClassifyParams P) {
+// ---- phase C: per-record work on the registers of the round ------------------------------
+// prev_last = position of the record before the round (INT32_MIN at the VCF start).
+__device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, const Rec4& R, const Nib& X, int rbase, int te, int prev_last,
+                                               int nb, int ablate, uint32_t* mpass32, uint32_t* mtp32, Acc& A, int lane) {
+  const uint32_t hit = (lds[L_HITS + (lane >> 3)] >> (4 * (lane & 7))) & 15u;
+  const uint32_t tpkey = hit & X.iddot;
+  const uint32_t tp = X.pass & tpkey;
+  const uint32_t fpkey = X.pass & ~hit;
+  A.n_pass += (uint32_t)__popc(X.pass);
+  A.n_tp += (uint32_t)__popc(tp);
+  A.fpr += (uint32_t)__popc(fpkey);
+  // natural-order mask words: 8 lanes x 4 records = one 32-bit word
+  if (!(ablate & 4)) {
+    const uint32_t sh = 4u * (uint32_t)(lane & 7);
+    const uint32_t wp = or_reduce8(X.pass << sh);
+    const uint32_t wt = or_reduce8(tp << sh);
+    if ((lane & 7) == 7) {
+      mpass32[(rbase >> 5) + (lane >> 3)] = wp;
+      mtp32[(rbase >> 5) + (lane >> 3)] = wt;
+    }
+  }
+  int pp = __shfl_up(R.p[3], 1);
+  if (lane == 0) pp = prev_last;
+  const int i0 = rbase + lane * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int p = R.p[k];
+    const bool valid = i0 + k < te;
+    A.bad |= (valid & (p < pp)) ? 1u : 0u;
+    // ROC histograms: one count per live record with a bin
+    const int bin = X.bin1[k] - 1;
+    const bool counted = ((X.live >> k) & 1u) & (bin >= 0);
+    const bool is_tp = (tpkey >> k) & 1u;
+    const bool sat = counted & (bin == nb - 1);
+    A.top_tp += (sat & is_tp) ? 1u : 0u;
+    A.top_fp += (sat & !is_tp) ? 1u : 0u;
+    if (counted && !sat && !(ablate & 2)) hist_add(lds, is_tp ? 0 : 1, bin);
+    // R path: a kept key outside the truth set counts once per VCF
+    if (((fpkey >> k) & 1u) && p == pp && !(ablate & 8))
+      A.fpr -= repeated_key(C, i0 + k, p, (R.r[k] << 2) | R.a[k], ((X.nokey >> k) & 1u) ? QMF_NOKEY : 0u);
+    pp = p;
+  }
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
 #ifndef K1_LDS_PAD
 #define K1_LDS_PAD 0
 #endif
+#ifndef K1_WAVES_PER_EU
+#define K1_WAVES_PER_EU 4
+#endif
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER_EU, 8))) void k_classify(ClassifyParams P) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[L_TOTAL + K1_LDS_PAD];
 
   const int lane = (int)threadIdx.x;
@@ -365,15 +402,15 @@ __global__ __launch_bounds__(64) void k_classify(ClassifyParams P) {
   const TruthG tr = truth_global(P.truths[vd.truth]);
   Cols C;
   C.pos = P.pos + vd.off; C.ref = P.ref + vd.off; C.alt = P.alt + vd.off; C.qual = P.qual + vd.off; C.flags = P.flags + vd.off;
-  uint64_t* const mpass = P.mask_pass + (vd.off >> 6);
-  uint64_t* const mtp = P.mask_tp + (vd.off >> 6);
+  uint32_t* const mpass32 = reinterpret_cast<uint32_t*>(P.mask_pass + (vd.off >> 6));
+  uint32_t* const mtp32 = reinterpret_cast<uint32_t*>(P.mask_tp + (vd.off >> 6));
   const int vn = (int)vd.n;
   const int sp_end = (int)(sp.end - vd.off);
   const int nb = P.n_bins;
   const int ablate = P.ablate;
 
-  for (int i = lane; i < 3 * 256; i += 64) lds[L_HIST + i] = 0;
-  Acc A = {0u, 0u, 0u, 0u};
+  for (int i = lane; i < 3 * 128; i += 64) lds[L_HIST + i] = 0;
+  Acc A = {0u, 0u, 0u, 0u, 0u, 0u};
   uint32_t acc_pass = 0, acc_tp = 0;  // wave-uniform
   uint32_t acc_tpr = 0;               // per lane, reduced at the end
 
@@ -404,8 +441,7 @@ __global__ __launch_bounds__(64) void k_classify(ClassifyParams P) {
     const int nrounds = (te - tb + 255) >> 8;
 
     SegBounds NB = B;
-    uint32_t tile_np = 0, tile_nt = 0;
-    int prev_pos = B.prevp;
+    int prev_last = B.prevp;
     for (int r = 0; r < nrounds; ++r) {
       const Rec4 R = N;
       const int rbase = tb + r * 256;
@@ -417,7 +453,8 @@ __global__ __launch_bounds__(64) void k_classify(ClassifyParams P) {
         load_rec4(C, ntb + lane * 4, N);
         NB = seg_bounds(C.pos, ntb, nte, vn);
       }
-      stage_round(lds, R, rbase + lane * 4, te, nb, lane);
+      Nib X;
+      stage_round(lds, R, rbase + lane * 4, te, nb, lane, X, A.bad);
       __syncthreads();
       if (!(ablate & 1)) {
         if (!oversize) {
@@ -444,8 +481,8 @@ __global__ __launch_bounds__(64) void k_classify(ClassifyParams P) {
         }
       }
       __syncthreads();
-      classify_round(lds, C, rbase, prev_pos, nb, ablate, mpass, mtp, A, tile_np, tile_nt, lane);
-      prev_pos = (int)(lds[L_RKEY + 255] >> 4);
+      classify_round(lds, C, R, X, rbase, te, prev_last, nb, ablate, mpass32, mtp32, A, lane);
+      prev_last = (int)(lds[L_RKEY + 255] >> 4);
       __syncthreads();
     }
 
@@ -455,12 +492,16 @@ __global__ __launch_bounds__(64) void k_classify(ClassifyParams P) {
       __syncthreads();
       acc_tpr += flush_slice(lds, S, lane);
     }
-    if (lane == 0) {
-      P.tile_tp[tile] = tile_nt;
-      P.tile_fp[tile] = tile_np - tile_nt;
+    {
+      const uint32_t tile_np = wave_sum(A.n_pass), tile_nt = wave_sum(A.n_tp);
+      A.n_pass = 0; A.n_tp = 0;
+      if (lane == 0) {
+        P.tile_tp[tile] = tile_nt;
+        P.tile_fp[tile] = tile_np - tile_nt;
+      }
+      acc_pass += tile_np;
+      acc_tp += tile_nt;
     }
-    acc_pass += tile_np;
-    acc_tp += tile_nt;
 
     if (!has_next_tile) break;
     // ---- stage the next tile's slice into the other LDS half ----------------------------
@@ -477,18 +518,16 @@ __global__ __launch_bounds__(64) void k_classify(ClassifyParams P) {
   }
 
   // ---- span epilogue -------------------------------------------------------------------
-  for (int o = 32; o > 0; o >>= 1) {
-    acc_tpr += __shfl_xor(acc_tpr, o);
-    A.fpr += __shfl_xor(A.fpr, o);
-    A.top_tp += __shfl_xor(A.top_tp, o);
-    A.top_fp += __shfl_xor(A.top_fp, o);
-  }
+  acc_tpr = wave_sum(acc_tpr);
+  A.fpr = wave_sum(A.fpr);
+  A.top_tp = wave_sum(A.top_tp);
+  A.top_fp = wave_sum(A.top_fp);
   const uint64_t any_uns = ballot64(A.bad & 1u);
   const uint64_t any_bad = ballot64(A.bad & 2u);
   __syncthreads();
   uint32_t* oh = P.span_hist + (size_t)blockIdx.x * (3 * 256);
   for (int i = lane; i < 3 * 256; i += 64) {
-    uint32_t v = lds[L_HIST + i];
+    uint32_t v = (lds[L_HIST + (i >> 8) * 128 + ((i & 255) >> 1)] >> (16 * (i & 1))) & 0xffffu;
     if (i == nb - 1) v += A.top_tp;
     if (i == 256 + nb - 1) v += A.top_fp;
     oh[i] = v;
