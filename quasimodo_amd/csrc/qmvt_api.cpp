@@ -247,9 +247,15 @@ struct qm_batch {
   int32_t* d_tile_vcf = nullptr;
   uint8_t* cls_scratch = nullptr;  // max_n bytes
   int64_t dev_bytes = 0;
-  // sort path scratch (lazy)
-  qm_batch* sub = nullptr;
-  uint32_t *sk[2] = {nullptr, nullptr}, *sv[2] = {nullptr, nullptr}, *shist = nullptr;
+  // sort path scratch (lazy): one chunk of unsorted VCFs at a time
+  qm_batch* sub = nullptr;               // sorted copies of the chunk's VCFs
+  std::vector<int64_t> sub_sig;          // record counts the scratch batch was built for
+  uint32_t *sk[2] = {nullptr, nullptr}, *sv[2] = {nullptr, nullptr}, *shist = nullptr, *sorbits = nullptr;
+  uint8_t* scls = nullptr;
+  SortSeg* d_segs = nullptr;
+  int32_t *d_tile_seg = nullptr, *d_ktile_seg = nullptr, *d_ktile_local = nullptr;
+  int64_t cap_sort_n = 0, cap_sort_hist = 0;
+  int cap_segs = 0, cap_stiles = 0, cap_ktiles = 0;
   // timing
   bool timing = false;
   static constexpr int EV_RING = 32;   // per-kernel events of the latest runs
@@ -266,7 +272,7 @@ static void batch_free(qm_batch* b) {
   void* ptrs[] = {b->pos, b->ref, b->alt, b->qual, b->flags, b->mask_pass, b->mask_tp, b->idx, b->tile_tp, b->tile_fp,
                   b->tile_tp_off, b->tile_fp_off, b->span_hist, b->span_scal, b->vcf_flags, b->roc, b->global_acc,
                   b->scalars, b->d_vcfs, b->d_spans, b->d_tile_vcf, b->cls_scratch, b->sk[0], b->sk[1], b->sv[0],
-                  b->sv[1], b->shist};
+                  b->sv[1], b->shist, b->sorbits, b->scls, b->d_segs, b->d_tile_seg, b->d_ktile_seg, b->d_ktile_local};
   for (void* p : ptrs) (void)hipFree(p);
   for (auto& r : b->ev) for (auto& e : r) if (e) (void)hipEventDestroy(e);
   delete b;
@@ -458,55 +464,106 @@ extern "C" int qm_batch_timings(qm_batch* b, float* ms4) {
   return QM_OK;
 }
 
-// ---- sort path: one unsorted VCF at a time through a scratch sub-batch ------
-static int ensure_sort_scratch(qm_batch* b) {
-  if (b->sub) return QM_OK;
-  const int64_t n = b->L.max_n;
-  int32_t t0 = 0;
-  int rc = batch_alloc(b->ctx, 1, &n, &t0, b->n_bins, &b->sub);
+// ---- sort path: unsorted VCFs are redone in chunks; every step of a chunk is one launch ----
+constexpr int64_t SORT_CHUNK_RECORDS = 1ll << 28;
+
+template <typename T>
+static int regrow(T** p, int64_t* cap, int64_t need, int64_t* bytes) {
+  if (need <= *cap) return QM_OK;
+  (void)hipFree(*p);
+  *p = nullptr;
+  *cap = 0;
+  int rc = dalloc(p, (size_t)need);
   if (rc != QM_OK) return rc;
-  b->dev_bytes += b->sub->dev_bytes;
-  const size_t ntiles = (size_t)((n + SORT_TILE - 1) / SORT_TILE);
-  for (int i = 0; i < 2; ++i) { DALLOC(b->sk[i], (size_t)n); DALLOC(b->sv[i], (size_t)n); }
-  DALLOC(b->shist, ntiles * 256);
-  b->dev_bytes += (int64_t)n * 16 + (int64_t)ntiles * 1024;
+  *bytes += (need - *cap) * (int64_t)sizeof(T);
+  *cap = need;
   return QM_OK;
 }
 
-static int sort_one_vcf(qm_batch* b, int v, hipStream_t st, uint64_t* global) {
-  const VcfDesc d = b->L.vcfs[(size_t)v];
+static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global) {
+  const int nseg = (int)vs.size();
+  // --- scratch batch holding the sorted copies (rebuilt only when the chunk's shape changes)
+  std::vector<int64_t> sig((size_t)nseg);
+  std::vector<int32_t> tids((size_t)nseg);
+  for (int i = 0; i < nseg; ++i) { sig[(size_t)i] = b->L.vcfs[(size_t)vs[(size_t)i]].n; tids[(size_t)i] = b->L.vcfs[(size_t)vs[(size_t)i]].truth; }
+  if (!b->sub || b->sub_sig != sig) {
+    if (b->sub) { b->dev_bytes -= b->sub->dev_bytes; batch_free(b->sub); b->sub = nullptr; }
+    int rc = batch_alloc(b->ctx, nseg, sig.data(), tids.data(), b->n_bins, &b->sub);
+    if (rc != QM_OK) return rc;
+    b->dev_bytes += b->sub->dev_bytes;
+    b->sub_sig = sig;
+  } else {
+    for (int i = 0; i < nseg; ++i) b->sub->L.vcfs[(size_t)i].truth = tids[(size_t)i];
+    int rc = upload_layout(b->sub);
+    if (rc != QM_OK) return rc;
+  }
   qm_batch* s = b->sub;
-  // 1. stable LSD radix sort of (pos, original index)
-  launch_sort_init(b->pos, d.off, d.n, b->sk[0], b->sv[0], st);
+  // --- segment table and tile maps
+  std::vector<SortSeg> segs((size_t)nseg);
+  std::vector<int32_t> tile_seg, ktile_seg, ktile_local;
+  int64_t koff = 0, hoff = 0;
+  for (int i = 0; i < nseg; ++i) {
+    const VcfDesc& d = b->L.vcfs[(size_t)vs[(size_t)i]];
+    SortSeg& g = segs[(size_t)i];
+    g.src_off = d.off; g.dst_off = s->L.vcfs[(size_t)i].off; g.koff = koff; g.hoff = hoff; g.n = d.n;
+    g.tile0 = (int32_t)tile_seg.size(); g.ntiles = (int32_t)((d.n + SORT_TILE - 1) / SORT_TILE);
+    g.main_vcf = vs[(size_t)i]; g.sub_vcf = i; g.main_tile0 = d.tile0; g.pad = 0;
+    for (int t = 0; t < g.ntiles; ++t) tile_seg.push_back(i);
+    for (int t = 0; t < d.ntiles; ++t) { ktile_seg.push_back(i); ktile_local.push_back(t); }
+    koff += (d.n + 63) / 64 * 64;
+    hoff += (int64_t)g.ntiles * 256;
+  }
+  const int nst = (int)tile_seg.size(), nkt = (int)ktile_seg.size();
+  int rc = QM_OK;
+  int64_t cap;
+  for (int i = 0; i < 2 && rc == QM_OK; ++i) {
+    cap = b->cap_sort_n; rc = regrow(&b->sk[i], &cap, koff, &b->dev_bytes);
+    if (rc == QM_OK) { cap = b->cap_sort_n; rc = regrow(&b->sv[i], &cap, koff, &b->dev_bytes); }
+  }
+  if (rc == QM_OK) { cap = b->cap_sort_n; rc = regrow(&b->scls, &cap, koff, &b->dev_bytes); }
+  if (rc == QM_OK) b->cap_sort_n = std::max(b->cap_sort_n, koff);
+  if (rc == QM_OK) rc = regrow(&b->shist, &b->cap_sort_hist, hoff, &b->dev_bytes);
+  if (rc == QM_OK) { cap = b->cap_segs; rc = regrow(&b->d_segs, &cap, (int64_t)nseg, &b->dev_bytes); b->cap_segs = (int)cap; }
+  if (rc == QM_OK) { cap = b->cap_stiles; rc = regrow(&b->d_tile_seg, &cap, (int64_t)nst, &b->dev_bytes); b->cap_stiles = (int)cap; }
+  if (rc == QM_OK) {
+    cap = b->cap_ktiles; rc = regrow(&b->d_ktile_seg, &cap, (int64_t)nkt, &b->dev_bytes);
+    if (rc == QM_OK) { cap = b->cap_ktiles; rc = regrow(&b->d_ktile_local, &cap, (int64_t)nkt, &b->dev_bytes); }
+    if (rc == QM_OK) b->cap_ktiles = std::max(b->cap_ktiles, nkt);
+  }
+  if (rc == QM_OK && !b->sorbits) rc = dalloc(&b->sorbits, 1);
+  if (rc != QM_OK) return rc;
+  HIPCHK(hipMemcpyAsync(b->d_segs, segs.data(), sizeof(SortSeg) * segs.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->d_tile_seg, tile_seg.data(), 4 * tile_seg.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->d_ktile_seg, ktile_seg.data(), 4 * ktile_seg.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->d_ktile_local, ktile_local.data(), 4 * ktile_local.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemsetAsync(b->sorbits, 0, 4, st));
+  // --- 1. stable LSD radix sort of (pos, original index); only the digits that are in use
+  launch_sort_init(b->d_segs, b->d_tile_seg, nst, b->pos, b->sk[0], b->sv[0], b->sorbits, st);
+  uint32_t orbits = 0;
+  HIPCHK(hipMemcpyAsync(&orbits, b->sorbits, 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));   // also makes the host tables above safe to free
   int cur = 0;
-  for (int shift = 0; shift < 32; shift += 8) {  // positions are < 2^28: four 8-bit digits
-    launch_sort_pass(b->sk[cur], b->sv[cur], d.n, shift, b->shist, b->sk[cur ^ 1], b->sv[cur ^ 1], st);
+  for (int shift = 0; shift < 32 && (orbits >> shift) != 0; shift += 8) {
+    launch_sort_pass(b->d_segs, b->d_tile_seg, nseg, nst, b->sk[cur], b->sv[cur], shift, b->shist, b->sk[cur ^ 1], b->sv[cur ^ 1], st);
     cur ^= 1;
   }
   const uint32_t* perm = b->sv[cur];
-  // 2. sorted copy of the VCF in the scratch batch, same truth set
-  int32_t tid = d.truth;
-  int64_t n = d.n;
-  build_layout(&n, &tid, 1, s->L);
-  int rc = upload_layout(s);
-  if (rc != QM_OK) return rc;
-  launch_sort_gather(b->pos, b->ref, b->alt, b->qual, b->flags, d.off, perm, d.n, s->pos, s->ref, s->alt, s->qual, s->flags, 0, st);
-  // 3. the normal path on the sorted copy; its ROC row is added to the caller's per-truth sums
+  // --- 2. sorted copies, 3. the normal path on them (their ROC rows go into the caller's per-truth sums)
+  SortCols src = {b->pos, b->ref, b->alt, b->qual, b->flags};
+  SortColsOut dst = {s->pos, s->ref, s->alt, s->qual, s->flags};
+  launch_sort_gather(b->d_segs, b->d_tile_seg, nst, perm, src, dst, st);
   launch_classify(classify_params(s), (int)s->L.spans.size(), st);
-  launch_finalize(finalize_params(s, global), 1, st);
-  // 4. results back under the original VCF: ROC + scalars rows, class bits in input order
-  HIPCHK(hipMemcpyAsync(b->roc + (size_t)v * 3 * b->n_bins, s->roc, (size_t)3 * b->n_bins * 8, hipMemcpyDeviceToDevice, st));
-  HIPCHK(hipMemcpyAsync(b->scalars + (size_t)v * 8, s->scalars, 8 * 8, hipMemcpyDeviceToDevice, st));
-  launch_sort_scatter_cls(s->mask_pass, s->mask_tp, 0, perm, d.n, b->cls_scratch, st);
-  launch_cls_to_masks(b->cls_scratch, d.off, d.n, b->mask_pass, b->mask_tp, b->tile_tp, b->tile_fp, d.tile0, st);
+  launch_finalize(finalize_params(s, global), nseg, st);
+  // --- 4. results back under the original VCFs: ROC + scalar rows, class bits in input order
+  launch_sort_copy_rows(b->d_segs, nseg, s->roc, s->scalars, b->roc, b->scalars, b->n_bins, st);
+  launch_sort_scatter_cls(b->d_segs, b->d_tile_seg, nst, s->mask_pass, s->mask_tp, perm, b->scls, st);
+  launch_cls_to_masks(b->d_segs, b->d_ktile_seg, b->d_ktile_local, nkt, b->scls, b->mask_pass, b->mask_tp, b->tile_tp, b->tile_fp, st);
   HIPCHK(hipGetLastError());
+  std::vector<uint32_t> sfl((size_t)nseg);
+  HIPCHK(hipMemcpyAsync(sfl.data(), s->vcf_flags, 4 * sfl.size(), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  // the scratch run saw sorted data: record that the original was not
-  uint32_t sflags = 0;
-  HIPCHK(hipMemcpy(&sflags, s->vcf_flags, 4, hipMemcpyDeviceToHost));
-  if (sflags & SPANF_UNSORTED) return fail(QM_E_HIP, "internal: VCF %d still unsorted after the radix sort", v);
-  const int64_t zero = 0;
-  HIPCHK(hipMemcpy(b->scalars + (size_t)v * 8 + QM_S_SORTED, &zero, 8, hipMemcpyHostToDevice));
+  for (int i = 0; i < nseg; ++i)
+    if (sfl[(size_t)i] & SPANF_UNSORTED) return fail(QM_E_HIP, "internal: VCF %d still unsorted after the radix sort", vs[(size_t)i]);
   return QM_OK;
 }
 
@@ -528,13 +585,19 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
     if (fl[(size_t)v] & SPANF_UNSORTED) todo.push_back(v);
   }
   if (!todo.empty()) {
-    int rc = ensure_sort_scratch(b);
-    if (rc != QM_OK) return rc;
-    for (int v : todo) {
-      rc = sort_one_vcf(b, v, st, b->last_global);
-      if (rc != QM_OK) return rc;
+    std::vector<int> chunk;
+    int64_t chunk_n = 0;
+    for (size_t i = 0; i <= todo.size(); ++i) {
+      const bool flush = i == todo.size() || (!chunk.empty() && chunk_n + b->L.vcfs[(size_t)todo[i]].n > SORT_CHUNK_RECORDS);
+      if (flush && !chunk.empty()) {
+        int rc = sort_chunk(b, chunk, st, b->last_global);
+        if (rc != QM_OK) return rc;
+        chunk.clear();
+        chunk_n = 0;
+      }
+      if (i < todo.size()) { chunk.push_back(todo[i]); chunk_n += b->L.vcfs[(size_t)todo[i]].n; }
     }
-    rc = rescan_and_compact(b, st);
+    int rc = rescan_and_compact(b, st);
     if (rc != QM_OK) return rc;
   }
   b->finished = true;
@@ -671,14 +734,17 @@ extern "C" int qm_fp_overlap(qm_ctx* c, int n_sets, const int64_t* set_offsets, 
   int32_t *dp = nullptr, *dr = nullptr, *da = nullptr, *ds = nullptr;
   uint32_t *k[2] = {nullptr, nullptr}, *v[2] = {nullptr, nullptr}, *hist = nullptr, *bad = nullptr;
   unsigned long long* dreg = nullptr;
+  SortSeg* dseg = nullptr;
+  int32_t* dts = nullptr;
   int rc = QM_OK;
   auto cleanup = [&]() {
-    void* ps[] = {dp, dr, da, ds, k[0], k[1], v[0], v[1], hist, bad, dreg};
+    void* ps[] = {dp, dr, da, ds, k[0], k[1], v[0], v[1], hist, bad, dreg, dseg, dts};
     for (void* p : ps) (void)hipFree(p);
   };
 #define A_(p, cnt) if (rc == QM_OK) rc = dalloc(&(p), (size_t)(cnt));
   A_(dp, n) A_(dr, n) A_(da, n) A_(ds, n) A_(k[0], n) A_(k[1], n) A_(v[0], n) A_(v[1], n)
-  A_(hist, (size_t)((n + SORT_TILE - 1) / SORT_TILE) * 256) A_(bad, 1) A_(dreg, nreg)
+  A_(hist, (size_t)((n + SORT_TILE - 1) / SORT_TILE) * 256) A_(bad, 1) A_(dreg, nreg) A_(dseg, 1)
+  A_(dts, (n + SORT_TILE - 1) / SORT_TILE)
 #undef A_
   if (rc != QM_OK) { cleanup(); return rc; }
   hipStream_t st = c->stream;
@@ -690,9 +756,18 @@ extern "C" int qm_fp_overlap(qm_ctx* c, int n_sets, const int64_t* set_offsets, 
   if (e == hipSuccess) e = hipMemsetAsync(dreg, 0, sizeof(unsigned long long) * (size_t)nreg, st);
   if (e != hipSuccess) { cleanup(); return fail(QM_E_HIP, "qm_fp_overlap: %s", hipGetErrorString(e)); }
   launch_overlap_pack(dp, dr, da, ds, n, k[0], v[0], bad, st);
+  {
+    SortSeg g;
+    memset(&g, 0, sizeof g);
+    g.n = n; g.ntiles = (int32_t)((n + SORT_TILE - 1) / SORT_TILE);
+    std::vector<int32_t> ts((size_t)g.ntiles, 0);
+    e = hipMemcpy(dseg, &g, sizeof g, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dts, ts.data(), 4 * ts.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { cleanup(); return fail(QM_E_HIP, "qm_fp_overlap: %s", hipGetErrorString(e)); }
+  }
   int cur = 0;
   for (int shift = 0; shift < 32; shift += 8) {
-    launch_sort_pass(k[cur], v[cur], n, shift, hist, k[cur ^ 1], v[cur ^ 1], st);
+    launch_sort_pass(dseg, dts, 1, (int)((n + SORT_TILE - 1) / SORT_TILE), k[cur], v[cur], shift, hist, k[cur ^ 1], v[cur ^ 1], st);
     cur ^= 1;
   }
   launch_overlap_count(k[cur], v[cur], n, dreg, st);

@@ -98,6 +98,20 @@ struct CompactParams {
   int32_t* idx;
 };
 
+// one unsorted VCF inside a sort chunk
+struct SortSeg {
+  int64_t src_off;   // first record of the VCF in the main batch (device index)
+  int64_t dst_off;   // first record of its sorted copy in the scratch batch
+  int64_t koff;      // offset of the segment in the chunk's key / payload / class arrays
+  int64_t hoff;      // offset of the segment's [256][ntiles] digit histogram
+  int64_t n;
+  int32_t tile0, ntiles;     // sort tiles (SORT_TILE records), numbered over the chunk
+  int32_t main_vcf, sub_vcf;
+  int32_t main_tile0, pad;   // first K1 tile of the VCF in the main batch
+};
+struct SortCols { const int32_t* pos; const int32_t* ref; const int32_t* alt; const float* qual; const uint8_t* flags; };
+struct SortColsOut { int32_t* pos; int32_t* ref; int32_t* alt; float* qual; uint8_t* flags; };
+
 struct SynthParams {
   const VcfDesc* vcfs;
   int32_t* pos;
@@ -169,16 +183,18 @@ void launch_finalize(const FinalizeParams& P, int n_vcf, hipStream_t st);
 void launch_compact(const CompactParams& P, int n_spans, hipStream_t st);
 void launch_masks_to_cls(const uint64_t* mp, const uint64_t* mt, int64_t off, int64_t n, uint8_t* cls, hipStream_t st);
 void launch_synth(const SynthParams& S, int n_vcf, int64_t max_n, hipStream_t st);
-void launch_sort_init(const int32_t* pos, int64_t off, int64_t n, uint32_t* keys, uint32_t* vals, hipStream_t st);
-void launch_sort_pass(const uint32_t* keys, const uint32_t* vals, int64_t n, int shift, uint32_t* hist, uint32_t* okeys,
-                      uint32_t* ovals, hipStream_t st);
-void launch_sort_gather(const int32_t* pos, const int32_t* ref, const int32_t* alt, const float* qual, const uint8_t* flags,
-                        int64_t src_off, const uint32_t* perm, int64_t n, int32_t* opos, int32_t* oref, int32_t* oalt,
-                        float* oqual, uint8_t* oflags, int64_t dst_off, hipStream_t st);
-void launch_sort_scatter_cls(const uint64_t* mp, const uint64_t* mt, int64_t src_off, const uint32_t* perm, int64_t n,
-                             uint8_t* cls, hipStream_t st);
-void launch_cls_to_masks(const uint8_t* cls, int64_t off, int64_t n, uint64_t* mp, uint64_t* mt, uint32_t* tile_tp,
-                         uint32_t* tile_fp, int tile0, hipStream_t st);
+void launch_sort_init(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const int32_t* pos, uint32_t* keys, uint32_t* vals,
+                      uint32_t* orbits, hipStream_t st);
+void launch_sort_pass(const SortSeg* segs, const int32_t* tile_seg, int nseg, int ntiles, const uint32_t* keys, const uint32_t* vals,
+                      int shift, uint32_t* hist, uint32_t* okeys, uint32_t* ovals, hipStream_t st);
+void launch_sort_gather(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const uint32_t* perm, const SortCols& src,
+                        const SortColsOut& dst, hipStream_t st);
+void launch_sort_scatter_cls(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const uint64_t* mp, const uint64_t* mt,
+                             const uint32_t* perm, uint8_t* cls, hipStream_t st);
+void launch_cls_to_masks(const SortSeg* segs, const int32_t* ktile_seg, const int32_t* ktile_local, int nktiles, const uint8_t* cls,
+                         uint64_t* mp, uint64_t* mt, uint32_t* tile_tp, uint32_t* tile_fp, hipStream_t st);
+void launch_sort_copy_rows(const SortSeg* segs, int nseg, const uint64_t* sub_roc, const int64_t* sub_scal, uint64_t* roc,
+                           int64_t* scal, int n_bins, hipStream_t st);
 void launch_overlap_pack(const int32_t* pos, const int32_t* ref, const int32_t* alt, const int32_t* set_of, int64_t n,
                          uint32_t* keys, uint32_t* vals, uint32_t* bad, hipStream_t st);
 void launch_overlap_count(const uint32_t* keys, const uint32_t* vals, int64_t n, unsigned long long* regions, hipStream_t st);

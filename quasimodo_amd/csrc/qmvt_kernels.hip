@@ -459,6 +459,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
       if (!(ablate & 1)) {
         if (!oversize) {
           join_round(lds, S, rend - rbase, own_a, lane);
+        } else if (ballot64((lane * 4 < rend - rbase) && R.p[0] < __shfl_up(R.p[3], 1) && lane > 0) != 0ull ||
+                   ballot64((R.p[1] < R.p[0] && lane * 4 + 1 < rend - rbase) || (R.p[2] < R.p[1] && lane * 4 + 2 < rend - rbase) ||
+                            (R.p[3] < R.p[2] && lane * 4 + 3 < rend - rbase)) != 0ull) {
+          // the round is out of order: the VCF is redone through the radix sort, nothing to join here
+          A.bad |= 1u;
         } else {
           // dense truth against a sparse VCF: this round is its own owner of truth state,
           // and its slice is walked in chunks staged on the spot
@@ -699,35 +704,55 @@ __global__ void k_synth(SynthParams S) {
 }
 
 // ---------------------------------------------------------------------------
-// radix sort path (unsorted VCFs): stable LSD passes over 8-bit digits of
-// key = pos (28 bits), payload = original record index.
+// radix sort path (unsorted VCFs), batched over segments: every unsorted VCF of a chunk is
+// one segment; one launch per step serves all of them.  Stable LSD passes over 8-bit digits
+// of key = pos, payload = original record index.  Sort tiles are numbered over the chunk;
+// tile_seg maps a tile to its segment.
 // ---------------------------------------------------------------------------
-__global__ void k_sort_init(const int32_t* pos, int64_t off, int64_t n, uint32_t* keys, uint32_t* vals) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  keys[i] = (uint32_t)pos[off + i];
-  vals[i] = (uint32_t)i;
+__global__ __launch_bounds__(256) void k_sort_init(const SortSeg* segs, const int32_t* tile_seg, const int32_t* pos,
+                                                   uint32_t* keys, uint32_t* vals, uint32_t* orbits) {
+  const SortSeg sg = segs[tile_seg[blockIdx.x]];
+  const int64_t base = (int64_t)((int)blockIdx.x - sg.tile0) * SORT_TILE;
+  uint32_t acc = 0;
+  for (int k = 0; k < SORT_TILE / 256; ++k) {
+    const int64_t i = base + k * 256 + threadIdx.x;
+    if (i < sg.n) {
+      const uint32_t key = (uint32_t)pos[sg.src_off + i];
+      keys[sg.koff + i] = key;
+      vals[sg.koff + i] = (uint32_t)i;
+      acc |= key;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) acc |= __shfl_xor(acc, o);
+  // the OR saturates after a few tiles: only waves that still add a bit touch the shared word
+  if ((threadIdx.x & 63) == 0 && (acc & ~__hip_atomic_load(orbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u) atomicOr(orbits, acc);
 }
 
-// per-tile digit histogram: hist[digit * ntiles + tile]
-__global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* keys, int64_t n, int shift, uint32_t* hist, int ntiles) {
+// per-tile digit histogram of a segment: hist[hoff + digit * ntiles + tile]
+__global__ __launch_bounds__(256) void k_sort_hist(const SortSeg* segs, const int32_t* tile_seg, const uint32_t* keys, int shift,
+                                                   uint32_t* hist) {
   __shared__ uint32_t s[256];
+  const SortSeg sg = segs[tile_seg[blockIdx.x]];
+  const int t = (int)blockIdx.x - sg.tile0;
   const int tid = (int)threadIdx.x;
   s[tid] = 0;
   __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * SORT_TILE;
+  const int64_t base = (int64_t)t * SORT_TILE;
   for (int k = 0; k < SORT_TILE / 256; ++k) {
     const int64_t i = base + k * 256 + tid;
-    if (i < n) atomicAdd(&s[(keys[i] >> shift) & 255u], 1u);
+    if (i < sg.n) atomicAdd(&s[(keys[sg.koff + i] >> shift) & 255u], 1u);
   }
   __syncthreads();
-  hist[(size_t)tid * ntiles + blockIdx.x] = s[tid];
+  hist[sg.hoff + (size_t)tid * sg.ntiles + t] = s[tid];
 }
 
-// exclusive scan over the digit-major histogram (single workgroup, sequential chunks)
-__global__ __launch_bounds__(256) void k_sort_scan(uint32_t* hist, int64_t total) {
+// exclusive scan over each segment's digit-major histogram (one workgroup per segment)
+__global__ __launch_bounds__(256) void k_sort_scan(const SortSeg* segs, uint32_t* hist_all) {
   __shared__ uint32_t s_scan[256];
   __shared__ uint32_t s_carry;
+  const SortSeg sg = segs[blockIdx.x];
+  uint32_t* hist = hist_all + sg.hoff;
+  const int64_t total = (int64_t)sg.ntiles * 256;
   const int tid = (int)threadIdx.x;
   if (tid == 0) s_carry = 0;
   __syncthreads();
@@ -753,25 +778,27 @@ __global__ __launch_bounds__(256) void k_sort_scan(uint32_t* hist, int64_t total
 
 // stable scatter: wave w of the tile owns SORT_TILE/4 consecutive keys and walks
 // them 64 at a time; rank inside a wave step by an 8-ballot multisplit.
-__global__ __launch_bounds__(256) void k_sort_scatter(const uint32_t* keys, const uint32_t* vals, int64_t n, int shift,
-                                                      const uint32_t* hist, int ntiles, uint32_t* okeys, uint32_t* ovals) {
+__global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const int32_t* tile_seg, const uint32_t* keys,
+                                                      const uint32_t* vals, int shift, const uint32_t* hist, uint32_t* okeys,
+                                                      uint32_t* ovals) {
   __shared__ uint32_t s_cnt[4][256];   // running count of digit d in wave w
   __shared__ uint32_t s_base[4][256];  // start of wave w's digit-d block in the output
+  const SortSeg sg = segs[tile_seg[blockIdx.x]];
+  const int t = (int)blockIdx.x - sg.tile0;
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   for (int i = tid; i < 4 * 256; i += 256) (&s_cnt[0][0])[i] = 0;
   __syncthreads();
-  const int64_t wbase = (int64_t)blockIdx.x * SORT_TILE + (int64_t)wave * (SORT_TILE / 4);
+  const int64_t wbase = (int64_t)t * SORT_TILE + (int64_t)wave * (SORT_TILE / 4);
   constexpr int STEPS = SORT_TILE / 4 / 64;
   uint32_t kk[STEPS], vv[STEPS], rk[STEPS];
-  // pass 1: ranks within the wave's chunk
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) {
     const int64_t i = wbase + s * 64 + lane;
-    const bool valid = i < n;
-    kk[s] = valid ? keys[i] : 0xffffffffu;
-    vv[s] = valid ? vals[i] : 0u;
+    const bool valid = i < sg.n;
+    kk[s] = valid ? keys[sg.koff + i] : 0xffffffffu;
+    vv[s] = valid ? vals[sg.koff + i] : 0u;
     const uint32_t d = (kk[s] >> shift) & 255u;
     uint64_t peers = ballot64(valid);
 #pragma unroll
@@ -782,14 +809,14 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint32_t* keys, cons
     const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
     const uint32_t r = (uint32_t)__popcll(peers & below);
     uint32_t basec = 0;
-    if (valid) basec = s_cnt[wave][d];   // every peer reads before the leader writes (same wave, lockstep)
+    if (valid) basec = s_cnt[wave][d];   // every peer reads before the leader writes (same wave, in order)
     rk[s] = basec + r;
     if (valid && r == 0) s_cnt[wave][d] = basec + (uint32_t)__popcll(peers);
   }
   __syncthreads();
   // digit d (thread d): global offset of this tile + exclusive scan over the 4 waves
   {
-    const uint32_t g = hist[(size_t)tid * ntiles + blockIdx.x];
+    const uint32_t g = hist[sg.hoff + (size_t)tid * sg.ntiles + t];
     uint32_t run = g;
 #pragma unroll
     for (int w = 0; w < 4; ++w) { s_base[w][tid] = run; run += s_cnt[w][tid]; }
@@ -798,59 +825,86 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint32_t* keys, cons
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) {
     const int64_t i = wbase + s * 64 + lane;
-    if (i < n) {
+    if (i < sg.n) {
       const uint32_t d = (kk[s] >> shift) & 255u;
       const uint32_t o = s_base[wave][d] + rk[s];
-      okeys[o] = kk[s];
-      ovals[o] = vv[s];
+      okeys[sg.koff + o] = kk[s];
+      ovals[sg.koff + o] = vv[s];
     }
   }
 }
 
-// gather the columns of one VCF through the sorted permutation into a scratch VCF
-__global__ void k_sort_gather(const int32_t* pos, const int32_t* ref, const int32_t* alt, const float* qual,
-                              const uint8_t* flags, int64_t src_off, const uint32_t* perm, int64_t n, int32_t* opos,
-                              int32_t* oref, int32_t* oalt, float* oqual, uint8_t* oflags, int64_t dst_off) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int64_t s = src_off + perm[i];
-  opos[dst_off + i] = pos[s]; oref[dst_off + i] = ref[s]; oalt[dst_off + i] = alt[s];
-  oqual[dst_off + i] = qual[s]; oflags[dst_off + i] = flags[s];
+// gather the columns of every segment through its sorted permutation into the scratch batch
+__global__ __launch_bounds__(256) void k_sort_gather(const SortSeg* segs, const int32_t* tile_seg, const uint32_t* perm, SortCols src,
+                                                     SortColsOut dst) {
+  const SortSeg sg = segs[tile_seg[blockIdx.x]];
+  const int64_t base = (int64_t)((int)blockIdx.x - sg.tile0) * SORT_TILE;
+  for (int k = 0; k < SORT_TILE / 256; ++k) {
+    const int64_t i = base + k * 256 + threadIdx.x;
+    if (i < sg.n) {
+      const int64_t s = sg.src_off + perm[sg.koff + i];
+      const int64_t d = sg.dst_off + i;
+      dst.pos[d] = src.pos[s]; dst.ref[d] = src.ref[s]; dst.alt[d] = src.alt[s];
+      dst.qual[d] = src.qual[s]; dst.flags[d] = src.flags[s];
+    }
+  }
 }
 
-// scatter class bits of the sorted scratch VCF back to input order (byte per record)
-__global__ void k_sort_scatter_cls(const uint64_t* mp, const uint64_t* mt, int64_t src_off, const uint32_t* perm, int64_t n,
-                                   uint8_t* cls) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int64_t g = src_off + i;
-  const uint32_t p = (uint32_t)((mp[g >> 6] >> (g & 63)) & 1ull);
-  const uint32_t t = (uint32_t)((mt[g >> 6] >> (g & 63)) & 1ull);
-  cls[perm[i]] = (uint8_t)(p | (t << 1));
+// class bits of the sorted scratch VCFs back to input order (one byte per record, chunk-relative)
+__global__ __launch_bounds__(256) void k_sort_scatter_cls(const SortSeg* segs, const int32_t* tile_seg, const uint64_t* mp,
+                                                          const uint64_t* mt, const uint32_t* perm, uint8_t* cls) {
+  const SortSeg sg = segs[tile_seg[blockIdx.x]];
+  const int64_t base = (int64_t)((int)blockIdx.x - sg.tile0) * SORT_TILE;
+  for (int k = 0; k < SORT_TILE / 256; ++k) {
+    const int64_t i = base + k * 256 + threadIdx.x;
+    if (i < sg.n) {
+      const int64_t g = sg.dst_off + i;
+      const uint32_t p = (uint32_t)((mp[g >> 6] >> (g & 63)) & 1ull);
+      const uint32_t t = (uint32_t)((mt[g >> 6] >> (g & 63)) & 1ull);
+      cls[sg.koff + perm[sg.koff + i]] = (uint8_t)(p | (t << 1));
+    }
+  }
 }
 
-// byte-per-record classes -> mask words + per-tile counts (input order), one wave per 64 records
-__global__ __launch_bounds__(256) void k_cls_to_masks(const uint8_t* cls, int64_t off, int64_t n, uint64_t* mp, uint64_t* mt,
-                                                      uint32_t* tile_tp, uint32_t* tile_fp, int tile0) {
+// byte-per-record classes -> mask words + per-tile counts of the main batch (input order).
+// One workgroup per K1 tile of an unsorted VCF; ktile_seg maps it to its segment.
+__global__ __launch_bounds__(256) void k_cls_to_masks(const SortSeg* segs, const int32_t* ktile_seg, const int32_t* ktile_local,
+                                                      const uint8_t* cls, uint64_t* mp, uint64_t* mt, uint32_t* tile_tp,
+                                                      uint32_t* tile_fp) {
   __shared__ uint32_t s_c[2];
+  const SortSeg sg = segs[ktile_seg[blockIdx.x]];
+  const int t = ktile_local[blockIdx.x];
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
   if (tid < 2) s_c[tid] = 0;
   __syncthreads();
-  const int64_t tb = (int64_t)blockIdx.x * K1_TILE;
+  const int64_t tb = (int64_t)t * K1_TILE;
   for (int w = tid >> 6; w < K1_TILE / 64; w += 4) {
     const int64_t i = tb + w * 64 + lane;
-    const uint8_t c = i < n ? cls[i] : 0;
+    const uint8_t c = i < sg.n ? cls[sg.koff + i] : 0;
     const uint64_t bp = ballot64(c & 1u), bt = ballot64(c & 2u);
-    if (tb + w * 64 < n && lane == 0) {
-      mp[((off + tb) >> 6) + w] = bp;
-      mt[((off + tb) >> 6) + w] = bt;
+    if (tb + w * 64 < sg.n && lane == 0) {
+      mp[((sg.src_off + tb) >> 6) + w] = bp;
+      mt[((sg.src_off + tb) >> 6) + w] = bt;
       atomicAdd(&s_c[0], (uint32_t)__popcll(bt));
       atomicAdd(&s_c[1], (uint32_t)__popcll(bp & ~bt));
     }
   }
   __syncthreads();
-  if (tid == 0) { tile_tp[tile0 + blockIdx.x] = s_c[0]; tile_fp[tile0 + blockIdx.x] = s_c[1]; }
+  if (tid == 0) { tile_tp[sg.main_tile0 + t] = s_c[0]; tile_fp[sg.main_tile0 + t] = s_c[1]; }
+}
+
+// ROC rows and scalars of the sorted scratch VCFs back under the original VCFs
+__global__ __launch_bounds__(256) void k_sort_copy_rows(const SortSeg* segs, const uint64_t* sub_roc, const int64_t* sub_scal,
+                                                        uint64_t* roc, int64_t* scal, int n_bins) {
+  const SortSeg sg = segs[blockIdx.x];
+  const int n = 3 * n_bins;
+  for (int i = (int)threadIdx.x; i < n; i += 256) roc[(size_t)sg.main_vcf * n + i] = sub_roc[(size_t)sg.sub_vcf * n + i];
+  if (threadIdx.x < 8) {
+    int64_t v = sub_scal[(size_t)sg.sub_vcf * 8 + threadIdx.x];
+    if (threadIdx.x == 5) v = 0;   // QM_S_SORTED: the original was not
+    scal[(size_t)sg.main_vcf * 8 + threadIdx.x] = v;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -894,31 +948,33 @@ void launch_synth(const SynthParams& S, int n_vcf, int64_t max_n, hipStream_t st
   if (n_vcf > 0 && max_n > 0)
     hipLaunchKernelGGL(k_synth, dim3((unsigned)((max_n + 255) / 256), (unsigned)n_vcf), dim3(256), 0, st, S);
 }
-void launch_sort_init(const int32_t* pos, int64_t off, int64_t n, uint32_t* keys, uint32_t* vals, hipStream_t st) {
-  hipLaunchKernelGGL(k_sort_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pos, off, n, keys, vals);
+void launch_sort_init(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const int32_t* pos, uint32_t* keys, uint32_t* vals,
+                      uint32_t* orbits, hipStream_t st) {
+  if (ntiles > 0) hipLaunchKernelGGL(k_sort_init, dim3(ntiles), dim3(256), 0, st, segs, tile_seg, pos, keys, vals, orbits);
 }
-void launch_sort_pass(const uint32_t* keys, const uint32_t* vals, int64_t n, int shift, uint32_t* hist, uint32_t* okeys,
-                      uint32_t* ovals, hipStream_t st) {
-  const int ntiles = (int)((n + SORT_TILE - 1) / SORT_TILE);
-  hipLaunchKernelGGL(k_sort_hist, dim3(ntiles), dim3(256), 0, st, keys, n, shift, hist, ntiles);
-  hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(256), 0, st, hist, (int64_t)ntiles * 256);
-  hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(256), 0, st, keys, vals, n, shift, hist, ntiles, okeys, ovals);
+void launch_sort_pass(const SortSeg* segs, const int32_t* tile_seg, int nseg, int ntiles, const uint32_t* keys, const uint32_t* vals,
+                      int shift, uint32_t* hist, uint32_t* okeys, uint32_t* ovals, hipStream_t st) {
+  if (ntiles <= 0) return;
+  hipLaunchKernelGGL(k_sort_hist, dim3(ntiles), dim3(256), 0, st, segs, tile_seg, keys, shift, hist);
+  hipLaunchKernelGGL(k_sort_scan, dim3(nseg), dim3(256), 0, st, segs, hist);
+  hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(256), 0, st, segs, tile_seg, keys, vals, shift, hist, okeys, ovals);
 }
-void launch_sort_gather(const int32_t* pos, const int32_t* ref, const int32_t* alt, const float* qual, const uint8_t* flags,
-                        int64_t src_off, const uint32_t* perm, int64_t n, int32_t* opos, int32_t* oref, int32_t* oalt,
-                        float* oqual, uint8_t* oflags, int64_t dst_off, hipStream_t st) {
-  hipLaunchKernelGGL(k_sort_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pos, ref, alt, qual, flags, src_off,
-                     perm, n, opos, oref, oalt, oqual, oflags, dst_off);
+void launch_sort_gather(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const uint32_t* perm, const SortCols& src,
+                        const SortColsOut& dst, hipStream_t st) {
+  if (ntiles > 0) hipLaunchKernelGGL(k_sort_gather, dim3(ntiles), dim3(256), 0, st, segs, tile_seg, perm, src, dst);
 }
-void launch_sort_scatter_cls(const uint64_t* mp, const uint64_t* mt, int64_t src_off, const uint32_t* perm, int64_t n,
-                             uint8_t* cls, hipStream_t st) {
-  hipLaunchKernelGGL(k_sort_scatter_cls, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mp, mt, src_off, perm, n, cls);
+void launch_sort_scatter_cls(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const uint64_t* mp, const uint64_t* mt,
+                             const uint32_t* perm, uint8_t* cls, hipStream_t st) {
+  if (ntiles > 0) hipLaunchKernelGGL(k_sort_scatter_cls, dim3(ntiles), dim3(256), 0, st, segs, tile_seg, mp, mt, perm, cls);
 }
-void launch_cls_to_masks(const uint8_t* cls, int64_t off, int64_t n, uint64_t* mp, uint64_t* mt, uint32_t* tile_tp,
-                         uint32_t* tile_fp, int tile0, hipStream_t st) {
-  const int ntiles = (int)((n + K1_TILE - 1) / K1_TILE);
-  if (ntiles > 0)
-    hipLaunchKernelGGL(k_cls_to_masks, dim3(ntiles), dim3(256), 0, st, cls, off, n, mp, mt, tile_tp, tile_fp, tile0);
+void launch_cls_to_masks(const SortSeg* segs, const int32_t* ktile_seg, const int32_t* ktile_local, int nktiles, const uint8_t* cls,
+                         uint64_t* mp, uint64_t* mt, uint32_t* tile_tp, uint32_t* tile_fp, hipStream_t st) {
+  if (nktiles > 0)
+    hipLaunchKernelGGL(k_cls_to_masks, dim3(nktiles), dim3(256), 0, st, segs, ktile_seg, ktile_local, cls, mp, mt, tile_tp, tile_fp);
+}
+void launch_sort_copy_rows(const SortSeg* segs, int nseg, const uint64_t* sub_roc, const int64_t* sub_scal, uint64_t* roc,
+                           int64_t* scal, int n_bins, hipStream_t st) {
+  if (nseg > 0) hipLaunchKernelGGL(k_sort_copy_rows, dim3(nseg), dim3(256), 0, st, segs, sub_roc, sub_scal, roc, scal, n_bins);
 }
 void launch_overlap_pack(const int32_t* pos, const int32_t* ref, const int32_t* alt, const int32_t* set_of, int64_t n,
                          uint32_t* keys, uint32_t* vals, uint32_t* bad, hipStream_t st) {
