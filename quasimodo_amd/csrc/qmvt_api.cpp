@@ -231,7 +231,8 @@ struct qm_batch {
   int n_vcf = 0, n_bins = 256;
   Layout L;
   size_t cap_spans = 0, cap_tiles = 0;
-  // columns
+  // columns (or, for the radix-sort scratch batch, the packed key / info pairs)
+  uint32_t *pkey = nullptr, *pinf = nullptr;
   int32_t *pos = nullptr, *ref = nullptr, *alt = nullptr;
   float* qual = nullptr;
   uint8_t* flags = nullptr;
@@ -393,6 +394,7 @@ extern "C" int qm_batch_synth(qm_batch* b, const qm_synth_cfg* cfg) {
 static ClassifyParams classify_params(qm_batch* b) {
   ClassifyParams P;
   P.pos = b->pos; P.ref = b->ref; P.alt = b->alt; P.qual = b->qual; P.flags = b->flags;
+  P.pkey = b->pkey; P.pinf = b->pinf;
   P.spans = b->d_spans; P.vcfs = b->d_vcfs; P.truths = b->ctx->d_truths;
   P.mask_pass = b->mask_pass; P.mask_tp = b->mask_tp; P.tile_tp = b->tile_tp; P.tile_fp = b->tile_fp;
   P.span_hist = b->span_hist; P.span_scal = b->span_scal; P.n_bins = b->n_bins;

@@ -58,6 +58,8 @@ struct ClassifyParams {
   const int32_t* alt;
   const float* qual;
   const uint8_t* flags;
+  const uint32_t* pkey;   // packed input (radix-sort path): key / info pairs instead of the five columns
+  const uint32_t* pinf;
   const SpanDesc* spans;
   const VcfDesc* vcfs;
   const TruthDev* truths;

@@ -64,50 +64,87 @@ __device__ __forceinline__ int lds_lower_bound(const uint32_t* __restrict__ k, i
 //
 // One workgroup = ONE wave (64 lanes) = one span of up to SPAN_TILES consecutive
 // tiles of one VCF; no workgroup barriers.  Units:
-//   round = 256 records.  Loaded 4 consecutive records per lane (dwordx4 per column
-//           + one dword of flags) with the NEXT round's loads already in flight,
-//           packed to (key, info) words and staged in LDS.  The join then runs from
-//           the sparse side: every truth key of the round's position range (one per
-//           lane) binary-searches the 256 staged record keys and marks its matches.
-//           The per-record pass re-reads the round in lane-major order (record
-//           l + 64k), so one wave ballot per slot is a natural-order mask word.
+//   round = 256 records, 4 consecutive records per lane.  The NEXT round's loads are
+//           issued before the current round is touched (register double buffer).
+//           Each record is packed to a 32-bit key (pos << 4 | ref << 2 | alt) and a
+//           16-bit info (bin + 1, flags, live) and staged in LDS.  The join then runs
+//           from the sparse side: every truth key of the round's position range (one
+//           per lane) binary-searches the 256 staged record keys, marks its matches
+//           in a 256-bit hit set and folds them into its per-truth-entry state.
+//           The per-record pass works on 4-bit nibbles in registers (kept, TP, ...);
+//           a three-step DPP OR turns 8 lanes' nibbles into a natural-order mask word.
 //   tile  = K1_ROUNDS rounds = the unit that owns a slice of the sorted truth keys
 //           in LDS (double buffered: tile t+1's slice is staged while t finishes),
 //           the per-truth-entry state for U(t)/TP_R, and one TP/FP line count.
+// Two input formats: the five SoA columns of include/qmvt.h (PACKED = false), and the
+// (key, info) pairs the radix-sort path produces for unsorted VCFs (PACKED = true).
 // All record indices are 32-bit and relative to the VCF (n < 2^31).
 // ---------------------------------------------------------------------------
-struct Rec4 {
-  int p[4], r[4], a[4];
-  float q[4];
-  uint32_t f;  // 4 flag bytes
-};
 
-struct Cols {  // column bases of one VCF
+// 16-bit info of a record (what a matching truth key and the per-record pass need)
+constexpr uint32_t I_BIN1 = 0x1ffu;      // bin + 1 (0 = passes no threshold)
+constexpr uint32_t I_PASS = 1u << 9;     // flags bit0
+constexpr uint32_t I_IDDOT = 1u << 10;   // flags bit1
+constexpr uint32_t I_NOKEY = 1u << 11;   // flags bit2
+constexpr uint32_t I_LIVE = 1u << 12;    // position in range, single-base alleles
+constexpr uint32_t I_BADPOS = 1u << 13;  // position outside [0, 2^28)
+
+// key and info of one record from its columns (qmvt_dev.h: the radix-sort path uses the same)
+__device__ __forceinline__ void pack_record(int p, int r, int a, float q, uint32_t fl, int nb, uint32_t& key, uint32_t& inf) {
+  const bool okpos = (uint32_t)p < (uint32_t)QM_POS_LIMIT_DEV;
+  const bool live = okpos & ((uint32_t)(r | a) < 4u);
+  key = ((uint32_t)p << 4) | (live ? ((uint32_t)r << 2) | (uint32_t)a : 0u);
+  inf = (uint32_t)(qual_bin(q, nb) + 1) | ((fl & 7u) << 9) | (live ? I_LIVE : 0u) | (okpos ? 0u : I_BADPOS);
+}
+
+struct Cols {  // bases of one VCF: the five columns, or the packed pair
   const int32_t* pos;
   const int32_t* ref;
   const int32_t* alt;
   const float* qual;
   const uint8_t* flags;
+  const uint32_t* pkey;
+  const uint32_t* pinf;
 };
 
-__device__ __forceinline__ void load_rec4(const Cols& C, int idx, Rec4& R) {
-  const int4 pv = *reinterpret_cast<const int4*>(C.pos + idx);
-  const int4 rv = *reinterpret_cast<const int4*>(C.ref + idx);
-  const int4 av = *reinterpret_cast<const int4*>(C.alt + idx);
-  const float4 qv = *reinterpret_cast<const float4*>(C.qual + idx);
+template <bool PACKED> struct Raw4;   // one round's loads, still in flight
+template <> struct Raw4<false> { int4 p, r, a; float4 q; uint32_t f; };
+template <> struct Raw4<true> { uint4 k, i; };
+
+__device__ __forceinline__ void load_raw(const Cols& C, int idx, Raw4<false>& R) {
+  R.p = *reinterpret_cast<const int4*>(C.pos + idx);
+  R.r = *reinterpret_cast<const int4*>(C.ref + idx);
+  R.a = *reinterpret_cast<const int4*>(C.alt + idx);
+  R.q = *reinterpret_cast<const float4*>(C.qual + idx);
   R.f = *reinterpret_cast<const uint32_t*>(C.flags + idx);
-  R.p[0] = pv.x; R.p[1] = pv.y; R.p[2] = pv.z; R.p[3] = pv.w;
-  R.r[0] = rv.x; R.r[1] = rv.y; R.r[2] = rv.z; R.r[3] = rv.w;
-  R.a[0] = av.x; R.a[1] = av.y; R.a[2] = av.z; R.a[3] = av.w;
-  R.q[0] = qv.x; R.q[1] = qv.y; R.q[2] = qv.z; R.q[3] = qv.w;
+}
+__device__ __forceinline__ void load_raw(const Cols& C, int idx, Raw4<true>& R) {
+  R.k = *reinterpret_cast<const uint4*>(C.pkey + idx);
+  R.i = *reinterpret_cast<const uint4*>(C.pinf + idx);
 }
 
-// 16-bit info of a staged record (what a matching truth key needs to know about it)
-constexpr uint32_t I_BIN1 = 0x1ffu;      // bin + 1 (0 = passes no threshold)
-constexpr uint32_t I_PASS = 1u << 9;     // flags bit0
-constexpr uint32_t I_IDDOT = 1u << 10;   // flags bit1
-constexpr uint32_t I_NOKEY = 1u << 11;   // flags bit2
-constexpr uint32_t I_LIVE = 1u << 12;    // inside the tile, position in range, single-base alleles
+struct In4 { uint32_t key[4], inf[4]; };   // the lane's 4 records of the round, packed
+
+__device__ __forceinline__ void unpack_raw(const Raw4<false>& R, int nb, In4& X) {
+  pack_record(R.p.x, R.r.x, R.a.x, R.q.x, R.f, nb, X.key[0], X.inf[0]);
+  pack_record(R.p.y, R.r.y, R.a.y, R.q.y, R.f >> 8, nb, X.key[1], X.inf[1]);
+  pack_record(R.p.z, R.r.z, R.a.z, R.q.z, R.f >> 16, nb, X.key[2], X.inf[2]);
+  pack_record(R.p.w, R.r.w, R.a.w, R.q.w, R.f >> 24, nb, X.key[3], X.inf[3]);
+}
+__device__ __forceinline__ void unpack_raw(const Raw4<true>& R, int, In4& X) {
+  X.key[0] = R.k.x; X.key[1] = R.k.y; X.key[2] = R.k.z; X.key[3] = R.k.w;
+  X.inf[0] = R.i.x; X.inf[1] = R.i.y; X.inf[2] = R.i.z; X.inf[3] = R.i.w;
+}
+
+// single-record accessors for the rare paths (run continuation, repeated keys, segment bounds)
+template <bool PACKED> __device__ __forceinline__ int rec_pos(const Cols& C, int i) {
+  if (PACKED) return (int)(C.pkey[i] >> 4);
+  return C.pos[i];
+}
+template <bool PACKED> __device__ __forceinline__ void rec_packed(const Cols& C, int i, int nb, uint32_t& key, uint32_t& inf) {
+  if (PACKED) { key = C.pkey[i]; inf = C.pinf[i]; return; }
+  pack_record(C.pos[i], C.ref[i], C.alt[i], C.qual[i], C.flags[i], nb, key, inf);
+}
 
 typedef const __attribute__((address_space(1))) uint32_t* gu32p;
 typedef const __attribute__((address_space(1))) int32_t* gi32p;
@@ -124,7 +161,8 @@ __device__ __forceinline__ TruthG truth_global(const TruthDev& t) {
 
 // LDS layout of the wave (dword offsets into one array, so every access is a ds_ op)
 constexpr int L_HIST = 0;                               // [3][128] TP / FP / distinct-truth-key histograms, two u16 bins per dword
-constexpr int L_KEYS = 384;                             // [2][K1_SLICE] staged truth keys
+constexpr int L_TRASH = 384;                            // [4] sink for predicated-off histogram adds
+constexpr int L_KEYS = 388;                             // [2][K1_SLICE] staged truth keys
 constexpr int L_SMAX = L_KEYS + 2 * K1_SLICE;           // [2][K1_SLICE] per key: max(bin + 1) of '.'-ID matches
 constexpr int L_SRF = L_SMAX + 2 * K1_SLICE;            // [2][K1_SLICE / 32] per key: matched by a kept record
 constexpr int L_RKEY = L_SRF + 2 * (K1_SLICE / 32);     // [256] record keys of the round (16-byte aligned)
@@ -133,10 +171,6 @@ constexpr int L_HITS = L_RINF + 128;                    // [8] one bit per recor
 constexpr int L_TOTAL = L_HITS + 8;
 static_assert(L_RKEY % 4 == 0 && L_RINF % 2 == 0, "b128 / b64 LDS stores need natural alignment");
 static_assert(SPAN_TILES * K1_TILE < 65536, "u16 histogram bins hold at most one span");
-
-__device__ __forceinline__ void hist_add(uint32_t* lds, int which, int bin) {
-  atomicAdd(&lds[L_HIST + which * 128 + (bin >> 1)], 1u << (16 * (bin & 1)));
-}
 
 struct Slice {
   int keys, smax, srf;  // dword offsets of the active buffer
@@ -171,45 +205,25 @@ struct SegBounds {   // a run of records that owns truth-entry state (a tile, or
   int prevp, nextp;  // position just before / after it (INT32_MIN at the VCF edge)
 };
 
-__device__ __forceinline__ SegBounds seg_bounds(const int32_t* pos, int sb, int se, int vn) {
+template <bool PACKED> __device__ __forceinline__ SegBounds seg_bounds(const Cols& C, int sb, int se, int vn) {
   SegBounds t;
-  t.a = pos[sb];
-  t.b = pos[se - 1];
-  t.prevp = (sb > 0) ? pos[sb - 1] : INT32_MIN;
-  t.nextp = (se < vn) ? pos[se] : INT32_MIN;
+  t.a = rec_pos<PACKED>(C, sb);
+  t.b = rec_pos<PACKED>(C, se - 1);
+  t.prevp = (sb > 0) ? rec_pos<PACKED>(C, sb - 1) : INT32_MIN;
+  t.nextp = (se < vn) ? rec_pos<PACKED>(C, se) : INT32_MIN;
   return t;
 }
 
-// per-lane view of a staged round: one bit per record of the lane (4 consecutive records)
-struct Nib {
-  uint32_t live, pass, iddot, nokey;  // pass = live & PASS
-  int bin1[4];                        // bin + 1
-};
-
-// ---- phase A: pack the round (4 consecutive records per lane) into LDS ----------------
-__device__ __forceinline__ void stage_round(uint32_t* lds, const Rec4& R, int i0, int te, int nb, int lane, Nib& X, uint32_t& bad) {
-  uint32_t key[4], inf[4];
-  X.live = X.pass = X.iddot = X.nokey = 0;
+// ---- phase A: stage the round's keys and infos in LDS ------------------------------------
+// records at or beyond `te` become key 0xffffffff (sorts last, matches nothing), info 0.
+__device__ __forceinline__ void stage_round(uint32_t* lds, In4& X, int i0, int te, int lane) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const uint32_t fl = (R.f >> (8 * k)) & 7u;
-    const bool valid = i0 + k < te;
-    const bool okpos = (uint32_t)R.p[k] < (uint32_t)QM_POS_LIMIT_DEV;
-    const bool live = valid & okpos & ((uint32_t)(R.r[k] | R.a[k]) < 4u);
-    const int b1 = qual_bin(R.q[k], nb) + 1;
-    X.bin1[k] = b1;
-    X.live |= (live ? 1u : 0u) << k;
-    X.pass |= ((live & ((fl & QMF_PASS) != 0)) ? 1u : 0u) << k;
-    X.iddot |= ((fl & QMF_IDDOT) ? 1u : 0u) << k;
-    X.nokey |= ((fl & QMF_NOKEY) ? 1u : 0u) << k;
-    bad |= (valid & !okpos) ? 2u : 0u;
-    key[k] = valid ? (((uint32_t)R.p[k] << 4) | (live ? ((uint32_t)R.r[k] << 2) | (uint32_t)R.a[k] : 0u)) : 0xffffffffu;
-    inf[k] = (uint32_t)b1 | (fl << 9) | (live ? I_LIVE : 0u);
-  }
+  for (int k = 0; k < 4; ++k)
+    if (i0 + k >= te) { X.key[k] = 0xffffffffu; X.inf[k] = 0u; }
   uint4 kv;
-  kv.x = key[0]; kv.y = key[1]; kv.z = key[2]; kv.w = key[3];
+  kv.x = X.key[0]; kv.y = X.key[1]; kv.z = X.key[2]; kv.w = X.key[3];
   uint2 iv;
-  iv.x = inf[0] | (inf[1] << 16); iv.y = inf[2] | (inf[3] << 16);
+  iv.x = (X.inf[0] & 0xffffu) | (X.inf[1] << 16); iv.y = (X.inf[2] & 0xffffu) | (X.inf[3] << 16);
   *reinterpret_cast<uint4*>(&lds[L_RKEY + lane * 4]) = kv;
   *reinterpret_cast<uint2*>(&lds[L_RINF + lane * 2]) = iv;
   if (lane < 8) lds[L_HITS + lane] = 0;
@@ -274,29 +288,31 @@ __device__ __forceinline__ int slice_lower_bound(const uint32_t* lds, const Slic
 }
 
 // records after the segment that continue its last run of equal positions
+template <bool PACKED>
 __device__ __forceinline__ void continue_run(const Cols& C, uint32_t* lds, const Slice& S, int se, int vn, int bpos, int nb, int lane) {
   for (int base = se; base < vn; base += 64) {
     const int i = base + lane;
     bool cont = false;
     if (i < vn) {
-      const int p = C.pos[i];
-      cont = (p == bpos);
+      cont = (rec_pos<PACKED>(C, i) == bpos);
       if (cont && S.m > 0) {
-        const int r_ = C.ref[i], a_ = C.alt[i];
-        const uint32_t fl = C.flags[i];
-        if (is_snp(r_, a_) && (uint32_t)p < (uint32_t)QM_POS_LIMIT_DEV && !(fl & QMF_NOKEY)) {
-          const uint32_t key = pack_key(p, r_, a_);
+        uint32_t key, inf;
+        rec_packed<PACKED>(C, i, nb, key, inf);
+        if ((inf & (I_LIVE | I_NOKEY)) == I_LIVE) {
           const int j = slice_lower_bound(lds, S, key);
           if (j < S.m && lds[S.keys + j] == key) {
-            const int bin = qual_bin(C.qual[i], nb);
-            if ((fl & QMF_IDDOT) && bin >= 0) atomicMax(&lds[S.smax + j], (uint32_t)(bin + 1));
-            if (fl & QMF_PASS) atomicOr(&lds[S.srf + (j >> 5)], 1u << (j & 31));
+            if (inf & I_IDDOT) atomicMax(&lds[S.smax + j], inf & I_BIN1);
+            if (inf & I_PASS) atomicOr(&lds[S.srf + (j >> 5)], 1u << (j & 31));
           }
         }
       }
     }
     if (ballot64(cont) != ~0ull) break;
   }
+}
+
+__device__ __forceinline__ void hist_add(uint32_t* lds, int which, int bin) {
+  atomicAdd(&lds[L_HIST + which * 128 + (bin >> 1)], 1u << (16 * (bin & 1)));
 }
 
 __device__ __forceinline__ uint32_t flush_slice(uint32_t* lds, const Slice& S, int lane) {
@@ -309,15 +325,16 @@ __device__ __forceinline__ uint32_t flush_slice(uint32_t* lds, const Slice& S, i
   return tpr;
 }
 
-// Has a kept record with this (pos, ref, alt) been seen earlier in the VCF?  Only called
-// when the predecessor has the same position; walks that run of equal positions
-// backwards.  <= 16 distinct single-base keys per position bound the walk per run.
-__device__ __forceinline__ uint32_t repeated_key(const Cols& C, int i, int p, int ra, uint32_t nokey) {
+// Has a kept record with this key been seen earlier in the VCF?  Only called when the
+// predecessor has the same position; walks that run of equal positions backwards.
+// <= 16 distinct single-base keys per position bound the total walk per run.
+template <bool PACKED>
+__device__ __forceinline__ uint32_t repeated_key(const Cols& C, int i, uint32_t key, uint32_t nokey, int nb) {
   for (int j = i - 1; j >= 0; --j) {
-    if (C.pos[j] != p) break;
-    const uint32_t fj = C.flags[j];
-    const int rj = C.ref[j], aj = C.alt[j];
-    if ((fj & QMF_PASS) && (fj & QMF_NOKEY) == nokey && is_snp(rj, aj) && ((rj << 2) | aj) == ra) return 1u;
+    if (rec_pos<PACKED>(C, j) != (int)(key >> 4)) break;
+    uint32_t kj, ij;
+    rec_packed<PACKED>(C, j, nb, kj, ij);
+    if (kj == key && (ij & (I_LIVE | I_PASS)) == (I_LIVE | I_PASS) && (ij & I_NOKEY) == nokey) return 1u;
   }
   return 0u;
 }
@@ -337,47 +354,66 @@ __device__ __forceinline__ uint32_t or_reduce8(uint32_t v) {
   return v;
 }
 
-// ---- phase C: per-record work on the registers of the round ------------------------------
+// ---- phase C: per-record work on the packed registers of the round -----------------------
 // prev_last = position of the record before the round (INT32_MIN at the VCF start).
-__device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, const Rec4& R, const Nib& X, int rbase, int te, int prev_last,
-                                               int nb, int ablate, uint32_t* mpass32, uint32_t* mtp32, Acc& A, int lane) {
+template <bool PACKED>
+__device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, const In4& X, int rbase, int te, int prev_last, int nb,
+                                               int ablate, uint32_t* mpass32, uint32_t* mtp32, Acc& A, int lane) {
   const uint32_t hit = (lds[L_HITS + (lane >> 3)] >> (4 * (lane & 7))) & 15u;
-  const uint32_t tpkey = hit & X.iddot;
-  const uint32_t tp = X.pass & tpkey;
-  const uint32_t fpkey = X.pass & ~hit;
-  A.n_pass += (uint32_t)__popc(X.pass);
+  uint32_t live = 0, pass = 0, iddot = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    live |= ((X.inf[k] >> 12) & 1u) << k;
+    pass |= (((X.inf[k] & (I_LIVE | I_PASS)) == (I_LIVE | I_PASS)) ? 1u : 0u) << k;
+    iddot |= ((X.inf[k] >> 10) & 1u) << k;
+    A.bad |= (X.inf[k] & I_BADPOS) ? 2u : 0u;
+  }
+  const uint32_t tpkey = hit & iddot;
+  const uint32_t tp = pass & tpkey;
+  const uint32_t fpkey = pass & ~hit;
+  A.n_pass += (uint32_t)__popc(pass);
   A.n_tp += (uint32_t)__popc(tp);
   A.fpr += (uint32_t)__popc(fpkey);
   // natural-order mask words: 8 lanes x 4 records = one 32-bit word
   if (!(ablate & 4)) {
     const uint32_t sh = 4u * (uint32_t)(lane & 7);
-    const uint32_t wp = or_reduce8(X.pass << sh);
+    const uint32_t wp = or_reduce8(pass << sh);
     const uint32_t wt = or_reduce8(tp << sh);
     if ((lane & 7) == 7) {
       mpass32[(rbase >> 5) + (lane >> 3)] = wp;
       mtp32[(rbase >> 5) + (lane >> 3)] = wt;
     }
   }
-  int pp = __shfl_up(R.p[3], 1);
+  int pp = __shfl_up((int)(X.key[3] >> 4), 1);
   if (lane == 0) pp = prev_last;
   const int i0 = rbase + lane * 4;
+  uint32_t cand = 0;   // kept keys outside the truth set whose predecessor has the same position
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int p = R.p[k];
+    const int p = (int)(X.key[k] >> 4);
     const bool valid = i0 + k < te;
     A.bad |= (valid & (p < pp)) ? 1u : 0u;
-    // ROC histograms: one count per live record with a bin
-    const int bin = X.bin1[k] - 1;
-    const bool counted = ((X.live >> k) & 1u) & (bin >= 0);
+    cand |= ((valid & (p == pp)) ? 1u : 0u) << k;
+    // ROC histograms: one count per live record with a bin; predicated-off lanes add into a sink
+    const int bin = (int)(X.inf[k] & I_BIN1) - 1;
+    const bool counted = ((live >> k) & 1u) & (bin >= 0);
     const bool is_tp = (tpkey >> k) & 1u;
     const bool sat = counted & (bin == nb - 1);
     A.top_tp += (sat & is_tp) ? 1u : 0u;
     A.top_fp += (sat & !is_tp) ? 1u : 0u;
-    if (counted && !sat && !(ablate & 2)) hist_add(lds, is_tp ? 0 : 1, bin);
-    // R path: a kept key outside the truth set counts once per VCF
-    if (((fpkey >> k) & 1u) && p == pp && !(ablate & 8))
-      A.fpr -= repeated_key(C, i0 + k, p, (R.r[k] << 2) | R.a[k], ((X.nokey >> k) & 1u) ? QMF_NOKEY : 0u);
+    if (!(ablate & 2)) {
+      const bool add = counted & !sat;
+      const int slot = add ? L_HIST + (is_tp ? 0 : 128) + (bin >> 1) : L_TRASH + (lane & 3);
+      atomicAdd(&lds[slot], add ? 1u << (16 * (bin & 1)) : 0u);
+    }
     pp = p;
+  }
+  // R path: a kept key outside the truth set counts once per VCF
+  cand &= fpkey;
+  if (cand && !(ablate & 8)) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if ((cand >> k) & 1u) A.fpr -= repeated_key<PACKED>(C, i0 + k, X.key[k], X.inf[k] & I_NOKEY, nb);
   }
 }
 
@@ -393,6 +429,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #define K1_WAVES_PER_EU 4
 #endif
 
+template <bool PACKED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER_EU, 8))) void k_classify(ClassifyParams P) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[L_TOTAL + K1_LDS_PAD];
 
@@ -402,6 +439,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
   const TruthG tr = truth_global(P.truths[vd.truth]);
   Cols C;
   C.pos = P.pos + vd.off; C.ref = P.ref + vd.off; C.alt = P.alt + vd.off; C.qual = P.qual + vd.off; C.flags = P.flags + vd.off;
+  C.pkey = P.pkey + vd.off; C.pinf = P.pinf + vd.off;
   uint32_t* const mpass32 = reinterpret_cast<uint32_t*>(P.mask_pass + (vd.off >> 6));
   uint32_t* const mtp32 = reinterpret_cast<uint32_t*>(P.mask_tp + (vd.off >> 6));
   const int vn = (int)vd.n;
@@ -409,7 +447,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
   const int nb = P.n_bins;
   const int ablate = P.ablate;
 
-  for (int i = lane; i < 3 * 128; i += 64) lds[L_HIST + i] = 0;
+  for (int i = lane; i < L_KEYS; i += 64) lds[i] = 0;   // histograms + sink
   Acc A = {0u, 0u, 0u, 0u, 0u, 0u};
   uint32_t acc_pass = 0, acc_tp = 0;  // wave-uniform
   uint32_t acc_tpr = 0;               // per lane, reduced at the end
@@ -417,9 +455,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
   // ---- prologue: first round in flight, first tile's bounds and slice -------------
   int tb = (int)(sp.begin - vd.off);
   int te = (tb + K1_TILE < sp_end) ? tb + K1_TILE : sp_end;
-  Rec4 N;
-  load_rec4(C, tb + lane * 4, N);
-  SegBounds B = seg_bounds(C.pos, tb, te, vn);
+  Raw4<PACKED> N;
+  load_raw(C, tb + lane * 4, N);
+  SegBounds B = seg_bounds<PACKED>(C, tb, te, vn);
   int lo, hi;
   slice_range(tr, B.a, B.b, lo, hi);
   int buf = 0;
@@ -443,57 +481,60 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
     SegBounds NB = B;
     int prev_last = B.prevp;
     for (int r = 0; r < nrounds; ++r) {
-      const Rec4 R = N;
+      In4 X;
+      unpack_raw(N, nb, X);
       const int rbase = tb + r * 256;
       const int rend = rbase + 256 < te ? rbase + 256 : te;
       // next round's records into flight first
       if (r + 1 < nrounds) {
-        load_rec4(C, rbase + 256 + lane * 4, N);
+        load_raw(C, rbase + 256 + lane * 4, N);
       } else if (has_next_tile) {
-        load_rec4(C, ntb + lane * 4, N);
-        NB = seg_bounds(C.pos, ntb, nte, vn);
+        load_raw(C, ntb + lane * 4, N);
+        NB = seg_bounds<PACKED>(C, ntb, nte, vn);
       }
-      Nib X;
-      stage_round(lds, R, rbase + lane * 4, te, nb, lane, X, A.bad);
+      stage_round(lds, X, rbase + lane * 4, te, lane);
       __syncthreads();
       if (!(ablate & 1)) {
         if (!oversize) {
           join_round(lds, S, rend - rbase, own_a, lane);
-        } else if (ballot64((lane * 4 < rend - rbase) && R.p[0] < __shfl_up(R.p[3], 1) && lane > 0) != 0ull ||
-                   ballot64((R.p[1] < R.p[0] && lane * 4 + 1 < rend - rbase) || (R.p[2] < R.p[1] && lane * 4 + 2 < rend - rbase) ||
-                            (R.p[3] < R.p[2] && lane * 4 + 3 < rend - rbase)) != 0ull) {
-          // the round is out of order: the VCF is redone through the radix sort, nothing to join here
-          A.bad |= 1u;
         } else {
-          // dense truth against a sparse VCF: this round is its own owner of truth state,
-          // and its slice is walked in chunks staged on the spot
-          const SegBounds RB = seg_bounds(C.pos, rbase, rend, vn);
-          const bool r_started = (rbase > 0) && (RB.prevp == RB.a);
-          const int r_own_a = r_started ? RB.a : INT32_MIN;
-          int rlo, rhi;
-          slice_range(tr, RB.a, RB.b, rlo, rhi);
-          for (int c0 = rlo; c0 < rhi; c0 += K1_SLICE) {
-            S.m = (rhi - c0) < K1_SLICE ? (rhi - c0) : K1_SLICE;
-            stage_slice(lds, tr, c0, S, lane);
-            __syncthreads();
-            join_round(lds, S, rend - rbase, r_own_a, lane);
-            if (RB.nextp == RB.b && !(r_started && RB.a == RB.b)) continue_run(C, lds, S, rend, vn, RB.b, nb, lane);
-            __syncthreads();
-            acc_tpr += flush_slice(lds, S, lane);
-            __syncthreads();
+          // dense truth against a sparse VCF -- or an out-of-order round, whose VCF is redone
+          // through the radix sort anyway: then there is nothing to join here
+          const int pl = __shfl_up((int)(X.key[3] >> 4), 1);
+          const bool ooo = (lane > 0 && X.key[0] != 0xffffffffu && (int)(X.key[0] >> 4) < pl) ||
+                           (X.key[1] < (X.key[0] & ~15u)) || (X.key[2] < (X.key[1] & ~15u)) || (X.key[3] < (X.key[2] & ~15u));
+          if (ballot64(ooo) != 0ull) {
+            A.bad |= 1u;
+          } else {
+            // this round is its own owner of truth state; its slice is walked in chunks staged on the spot
+            const SegBounds RB = seg_bounds<PACKED>(C, rbase, rend, vn);
+            const bool r_started = (rbase > 0) && (RB.prevp == RB.a);
+            const int r_own_a = r_started ? RB.a : INT32_MIN;
+            int rlo, rhi;
+            slice_range(tr, RB.a, RB.b, rlo, rhi);
+            for (int c0 = rlo; c0 < rhi; c0 += K1_SLICE) {
+              S.m = (rhi - c0) < K1_SLICE ? (rhi - c0) : K1_SLICE;
+              stage_slice(lds, tr, c0, S, lane);
+              __syncthreads();
+              join_round(lds, S, rend - rbase, r_own_a, lane);
+              if (RB.nextp == RB.b && !(r_started && RB.a == RB.b)) continue_run<PACKED>(C, lds, S, rend, vn, RB.b, nb, lane);
+              __syncthreads();
+              acc_tpr += flush_slice(lds, S, lane);
+              __syncthreads();
+            }
+            S.m = 0;
           }
-          S.m = 0;
         }
       }
       __syncthreads();
-      classify_round(lds, C, R, X, rbase, te, prev_last, nb, ablate, mpass32, mtp32, A, lane);
+      classify_round<PACKED>(lds, C, X, rbase, te, prev_last, nb, ablate, mpass32, mtp32, A, lane);
       prev_last = (int)(lds[L_RKEY + 255] >> 4);
       __syncthreads();
     }
 
     // ---- tile epilogue: run continuation, per-truth-entry state -> histogram, counts ----
     if (!(ablate & 1) && !oversize) {
-      if (B.nextp == B.b && owns_b) continue_run(C, lds, S, te, vn, B.b, nb, lane);
+      if (B.nextp == B.b && owns_b) continue_run<PACKED>(C, lds, S, te, vn, B.b, nb, lane);
       __syncthreads();
       acc_tpr += flush_slice(lds, S, lane);
     }
@@ -933,7 +974,9 @@ __global__ void k_overlap_count(const uint32_t* keys, const uint32_t* vals, int6
 // launchers (called from qmvt_api.cpp through qmvt_dev.h)
 // ---------------------------------------------------------------------------
 void launch_classify(const ClassifyParams& P, int n_spans, hipStream_t st) {
-  if (n_spans > 0) hipLaunchKernelGGL(k_classify, dim3(n_spans), dim3(64), 0, st, P);
+  if (n_spans <= 0) return;
+  if (P.pkey) hipLaunchKernelGGL(k_classify<true>, dim3(n_spans), dim3(64), 0, st, P);
+  else hipLaunchKernelGGL(k_classify<false>, dim3(n_spans), dim3(64), 0, st, P);
 }
 void launch_finalize(const FinalizeParams& P, int n_vcf, hipStream_t st) {
   if (n_vcf > 0) hipLaunchKernelGGL(k_finalize, dim3(n_vcf), dim3(256), 0, st, P);
