@@ -251,7 +251,7 @@ struct qm_batch {
   // sort path scratch (lazy): one chunk of unsorted VCFs at a time
   qm_batch* sub = nullptr;               // sorted copies of the chunk's VCFs
   std::vector<int64_t> sub_sig;          // record counts the scratch batch was built for
-  uint32_t *sk[2] = {nullptr, nullptr}, *sv[2] = {nullptr, nullptr}, *shist = nullptr, *sorbits = nullptr;
+  uint32_t *sk[2] = {nullptr, nullptr}, *sv[2] = {nullptr, nullptr}, *si[2] = {nullptr, nullptr}, *shist = nullptr, *sorbits = nullptr;
   uint8_t* scls = nullptr;
   SortSeg* d_segs = nullptr;
   int32_t *d_tile_seg = nullptr, *d_ktile_seg = nullptr, *d_ktile_local = nullptr;
@@ -270,10 +270,10 @@ static void batch_free(qm_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->ctx->dev);
   if (b->sub) { batch_free(b->sub); b->sub = nullptr; }
-  void* ptrs[] = {b->pos, b->ref, b->alt, b->qual, b->flags, b->mask_pass, b->mask_tp, b->idx, b->tile_tp, b->tile_fp,
+  void* ptrs[] = {b->pkey, b->pinf, b->pos, b->ref, b->alt, b->qual, b->flags, b->mask_pass, b->mask_tp, b->idx, b->tile_tp, b->tile_fp,
                   b->tile_tp_off, b->tile_fp_off, b->span_hist, b->span_scal, b->vcf_flags, b->roc, b->global_acc,
                   b->scalars, b->d_vcfs, b->d_spans, b->d_tile_vcf, b->cls_scratch, b->sk[0], b->sk[1], b->sv[0],
-                  b->sv[1], b->shist, b->sorbits, b->scls, b->d_segs, b->d_tile_seg, b->d_ktile_seg, b->d_ktile_local};
+                  b->sv[1], b->si[0], b->si[1], b->shist, b->sorbits, b->scls, b->d_segs, b->d_tile_seg, b->d_ktile_seg, b->d_ktile_local};
   for (void* p : ptrs) (void)hipFree(p);
   for (auto& r : b->ev) for (auto& e : r) if (e) (void)hipEventDestroy(e);
   delete b;
@@ -287,7 +287,8 @@ static int upload_layout(qm_batch* b) {
   return QM_OK;
 }
 
-static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int32_t* truth_ids, int n_bins, qm_batch** out) {
+static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int32_t* truth_ids, int n_bins, qm_batch** out,
+                       bool packed = false) {
   qm_batch* b = new qm_batch();
   b->ctx = c;
   b->n_vcf = n_vcf;
@@ -300,7 +301,8 @@ static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int
   const size_t nt = std::max<size_t>(1, (size_t)c->truths.size());
   int rc = QM_OK;
 #define A_(p, n) if (rc == QM_OK) { rc = dalloc(&(p), (n)); if (rc == QM_OK) b->dev_bytes += (int64_t)((n) * sizeof(*(p))); }
-  A_(b->pos, np) A_(b->ref, np) A_(b->alt, np) A_(b->qual, np) A_(b->flags, np)
+  if (packed) { A_(b->pkey, np) A_(b->pinf, np) }
+  else { A_(b->pos, np) A_(b->ref, np) A_(b->alt, np) A_(b->qual, np) A_(b->flags, np) }
   A_(b->mask_pass, np / 64 + 64) A_(b->mask_tp, np / 64 + 64) A_(b->idx, np)
   A_(b->tile_tp, b->cap_tiles) A_(b->tile_fp, b->cap_tiles) A_(b->tile_tp_off, b->cap_tiles) A_(b->tile_fp_off, b->cap_tiles)
   A_(b->span_hist, b->cap_spans * 768) A_(b->span_scal, b->cap_spans * 8) A_(b->vcf_flags, (size_t)n_vcf)
@@ -308,7 +310,7 @@ static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int
   A_(b->d_vcfs, (size_t)n_vcf) A_(b->d_spans, b->cap_spans) A_(b->d_tile_vcf, b->cap_tiles) A_(b->cls_scratch, (size_t)L.max_n)
 #undef A_
   if (rc == QM_OK) rc = upload_layout(b);
-  if (rc == QM_OK) {
+  if (rc == QM_OK && !packed) {
     // padding lanes are masked in the kernels, but keep the columns defined.  On the context's
     // stream (hipMemset on the null stream would not be ordered before work on a non-blocking stream).
     hipError_t e = hipMemsetAsync(b->flags, 0, np, c->stream);
@@ -490,7 +492,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   for (int i = 0; i < nseg; ++i) { sig[(size_t)i] = b->L.vcfs[(size_t)vs[(size_t)i]].n; tids[(size_t)i] = b->L.vcfs[(size_t)vs[(size_t)i]].truth; }
   if (!b->sub || b->sub_sig != sig) {
     if (b->sub) { b->dev_bytes -= b->sub->dev_bytes; batch_free(b->sub); b->sub = nullptr; }
-    int rc = batch_alloc(b->ctx, nseg, sig.data(), tids.data(), b->n_bins, &b->sub);
+    int rc = batch_alloc(b->ctx, nseg, sig.data(), tids.data(), b->n_bins, &b->sub, true);
     if (rc != QM_OK) return rc;
     b->dev_bytes += b->sub->dev_bytes;
     b->sub_sig = sig;
@@ -521,6 +523,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   for (int i = 0; i < 2 && rc == QM_OK; ++i) {
     cap = b->cap_sort_n; rc = regrow(&b->sk[i], &cap, koff, &b->dev_bytes);
     if (rc == QM_OK) { cap = b->cap_sort_n; rc = regrow(&b->sv[i], &cap, koff, &b->dev_bytes); }
+    if (rc == QM_OK) { cap = b->cap_sort_n; rc = regrow(&b->si[i], &cap, koff, &b->dev_bytes); }
   }
   if (rc == QM_OK) { cap = b->cap_sort_n; rc = regrow(&b->scls, &cap, koff, &b->dev_bytes); }
   if (rc == QM_OK) b->cap_sort_n = std::max(b->cap_sort_n, koff);
@@ -539,21 +542,24 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   HIPCHK(hipMemcpyAsync(b->d_ktile_seg, ktile_seg.data(), 4 * ktile_seg.size(), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->d_ktile_local, ktile_local.data(), 4 * ktile_local.size(), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemsetAsync(b->sorbits, 0, 4, st));
-  // --- 1. stable LSD radix sort of (pos, original index); only the digits that are in use
-  launch_sort_init(b->d_segs, b->d_tile_seg, nst, b->pos, b->sk[0], b->sv[0], b->sorbits, st);
+  // --- 1. records packed to (key, info, original index), 2. stable LSD radix sort by position (key bits 4..31),
+  //        only the digits in use; the last pass drops keys and infos straight into the scratch batch
+  SortCols src = {b->pos, b->ref, b->alt, b->qual, b->flags};
+  launch_sort_init(b->d_segs, b->d_tile_seg, nst, src, b->n_bins, b->sk[0], b->si[0], b->sv[0], b->sorbits, st);
   uint32_t orbits = 0;
   HIPCHK(hipMemcpyAsync(&orbits, b->sorbits, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));   // also makes the host tables above safe to free
+  int npass = 1;
+  while (4 + 8 * npass < 32 && (orbits >> (4 + 8 * npass)) != 0) ++npass;
   int cur = 0;
-  for (int shift = 0; shift < 32 && (orbits >> shift) != 0; shift += 8) {
-    launch_sort_pass(b->d_segs, b->d_tile_seg, nseg, nst, b->sk[cur], b->sv[cur], shift, b->shist, b->sk[cur ^ 1], b->sv[cur ^ 1], st);
+  for (int ps = 0; ps < npass; ++ps) {
+    const bool last = ps == npass - 1;
+    launch_sort_pass(b->d_segs, b->d_tile_seg, nseg, nst, b->sk[cur], b->si[cur], b->sv[cur], 4 + 8 * ps, b->shist,
+                     last ? s->pkey : b->sk[cur ^ 1], last ? s->pinf : b->si[cur ^ 1], b->sv[cur ^ 1], last ? 1 : 0, st);
     cur ^= 1;
   }
   const uint32_t* perm = b->sv[cur];
-  // --- 2. sorted copies, 3. the normal path on them (their ROC rows go into the caller's per-truth sums)
-  SortCols src = {b->pos, b->ref, b->alt, b->qual, b->flags};
-  SortColsOut dst = {s->pos, s->ref, s->alt, s->qual, s->flags};
-  launch_sort_gather(b->d_segs, b->d_tile_seg, nst, perm, src, dst, st);
+  // --- 3. the normal path on the sorted copies (their ROC rows go into the caller's per-truth sums)
   launch_classify(classify_params(s), (int)s->L.spans.size(), st);
   launch_finalize(finalize_params(s, global), nseg, st);
   // --- 4. results back under the original VCFs: ROC + scalar rows, class bits in input order
@@ -769,7 +775,7 @@ extern "C" int qm_fp_overlap(qm_ctx* c, int n_sets, const int64_t* set_offsets, 
   }
   int cur = 0;
   for (int shift = 0; shift < 32; shift += 8) {
-    launch_sort_pass(dseg, dts, 1, (int)((n + SORT_TILE - 1) / SORT_TILE), k[cur], v[cur], shift, hist, k[cur ^ 1], v[cur ^ 1], st);
+    launch_sort_pass(dseg, dts, 1, (int)((n + SORT_TILE - 1) / SORT_TILE), k[cur], nullptr, v[cur], shift, hist, k[cur ^ 1], nullptr, v[cur ^ 1], 0, st);
     cur ^= 1;
   }
   launch_overlap_count(k[cur], v[cur], n, dreg, st);

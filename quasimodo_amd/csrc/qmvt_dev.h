@@ -112,7 +112,6 @@ struct SortSeg {
   int32_t main_tile0, pad;   // first K1 tile of the VCF in the main batch
 };
 struct SortCols { const int32_t* pos; const int32_t* ref; const int32_t* alt; const float* qual; const uint8_t* flags; };
-struct SortColsOut { int32_t* pos; int32_t* ref; int32_t* alt; float* qual; uint8_t* flags; };
 
 struct SynthParams {
   const VcfDesc* vcfs;
@@ -185,12 +184,11 @@ void launch_finalize(const FinalizeParams& P, int n_vcf, hipStream_t st);
 void launch_compact(const CompactParams& P, int n_spans, hipStream_t st);
 void launch_masks_to_cls(const uint64_t* mp, const uint64_t* mt, int64_t off, int64_t n, uint8_t* cls, hipStream_t st);
 void launch_synth(const SynthParams& S, int n_vcf, int64_t max_n, hipStream_t st);
-void launch_sort_init(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const int32_t* pos, uint32_t* keys, uint32_t* vals,
-                      uint32_t* orbits, hipStream_t st);
-void launch_sort_pass(const SortSeg* segs, const int32_t* tile_seg, int nseg, int ntiles, const uint32_t* keys, const uint32_t* vals,
-                      int shift, uint32_t* hist, uint32_t* okeys, uint32_t* ovals, hipStream_t st);
-void launch_sort_gather(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const uint32_t* perm, const SortCols& src,
-                        const SortColsOut& dst, hipStream_t st);
+void launch_sort_init(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const SortCols& src, int n_bins, uint32_t* keys,
+                      uint32_t* infs, uint32_t* vals, uint32_t* orbits, hipStream_t st);
+void launch_sort_pass(const SortSeg* segs, const int32_t* tile_seg, int nseg, int ntiles, const uint32_t* keys, const uint32_t* infs,
+                      const uint32_t* vals, int shift, uint32_t* hist, uint32_t* okeys, uint32_t* oinfs, uint32_t* ovals, int final_dst,
+                      hipStream_t st);
 void launch_sort_scatter_cls(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const uint64_t* mp, const uint64_t* mt,
                              const uint32_t* perm, uint8_t* cls, hipStream_t st);
 void launch_cls_to_masks(const SortSeg* segs, const int32_t* ktile_seg, const int32_t* ktile_local, int nktiles, const uint8_t* cls,

@@ -750,16 +750,19 @@ __global__ void k_synth(SynthParams S) {
 // of key = pos, payload = original record index.  Sort tiles are numbered over the chunk;
 // tile_seg maps a tile to its segment.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sort_init(const SortSeg* segs, const int32_t* tile_seg, const int32_t* pos,
-                                                   uint32_t* keys, uint32_t* vals, uint32_t* orbits) {
+__global__ __launch_bounds__(256) void k_sort_init(const SortSeg* segs, const int32_t* tile_seg, SortCols src, int n_bins,
+                                                   uint32_t* keys, uint32_t* infs, uint32_t* vals, uint32_t* orbits) {
   const SortSeg sg = segs[tile_seg[blockIdx.x]];
   const int64_t base = (int64_t)((int)blockIdx.x - sg.tile0) * SORT_TILE;
   uint32_t acc = 0;
   for (int k = 0; k < SORT_TILE / 256; ++k) {
     const int64_t i = base + k * 256 + threadIdx.x;
     if (i < sg.n) {
-      const uint32_t key = (uint32_t)pos[sg.src_off + i];
+      const int64_t g = sg.src_off + i;
+      uint32_t key, inf;
+      pack_record(src.pos[g], src.ref[g], src.alt[g], src.qual[g], src.flags[g], n_bins, key, inf);
       keys[sg.koff + i] = key;
+      infs[sg.koff + i] = inf;
       vals[sg.koff + i] = (uint32_t)i;
       acc |= key;
     }
@@ -819,9 +822,11 @@ __global__ __launch_bounds__(256) void k_sort_scan(const SortSeg* segs, uint32_t
 
 // stable scatter: wave w of the tile owns SORT_TILE/4 consecutive keys and walks
 // them 64 at a time; rank inside a wave step by an 8-ballot multisplit.
+// `infs` (second payload) may be null; with `final_dst` the keys and infos of the last pass land at the
+// segment's place in the scratch batch (dst_off) instead of the chunk arrays (koff).
 __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const int32_t* tile_seg, const uint32_t* keys,
-                                                      const uint32_t* vals, int shift, const uint32_t* hist, uint32_t* okeys,
-                                                      uint32_t* ovals) {
+                                                      const uint32_t* infs, const uint32_t* vals, int shift, const uint32_t* hist,
+                                                      uint32_t* okeys, uint32_t* oinfs, uint32_t* ovals, int final_dst) {
   __shared__ uint32_t s_cnt[4][256];   // running count of digit d in wave w
   __shared__ uint32_t s_base[4][256];  // start of wave w's digit-d block in the output
   const SortSeg sg = segs[tile_seg[blockIdx.x]];
@@ -833,13 +838,14 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
   __syncthreads();
   const int64_t wbase = (int64_t)t * SORT_TILE + (int64_t)wave * (SORT_TILE / 4);
   constexpr int STEPS = SORT_TILE / 4 / 64;
-  uint32_t kk[STEPS], vv[STEPS], rk[STEPS];
+  uint32_t kk[STEPS], vv[STEPS], ii[STEPS], rk[STEPS];
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) {
     const int64_t i = wbase + s * 64 + lane;
     const bool valid = i < sg.n;
     kk[s] = valid ? keys[sg.koff + i] : 0xffffffffu;
     vv[s] = valid ? vals[sg.koff + i] : 0u;
+    ii[s] = (valid && infs) ? infs[sg.koff + i] : 0u;
     const uint32_t d = (kk[s] >> shift) & 255u;
     uint64_t peers = ballot64(valid);
 #pragma unroll
@@ -869,24 +875,10 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
     if (i < sg.n) {
       const uint32_t d = (kk[s] >> shift) & 255u;
       const uint32_t o = s_base[wave][d] + rk[s];
-      okeys[sg.koff + o] = kk[s];
+      const int64_t ko = (final_dst ? sg.dst_off : sg.koff) + o;
+      okeys[ko] = kk[s];
+      if (infs) oinfs[ko] = ii[s];
       ovals[sg.koff + o] = vv[s];
-    }
-  }
-}
-
-// gather the columns of every segment through its sorted permutation into the scratch batch
-__global__ __launch_bounds__(256) void k_sort_gather(const SortSeg* segs, const int32_t* tile_seg, const uint32_t* perm, SortCols src,
-                                                     SortColsOut dst) {
-  const SortSeg sg = segs[tile_seg[blockIdx.x]];
-  const int64_t base = (int64_t)((int)blockIdx.x - sg.tile0) * SORT_TILE;
-  for (int k = 0; k < SORT_TILE / 256; ++k) {
-    const int64_t i = base + k * 256 + threadIdx.x;
-    if (i < sg.n) {
-      const int64_t s = sg.src_off + perm[sg.koff + i];
-      const int64_t d = sg.dst_off + i;
-      dst.pos[d] = src.pos[s]; dst.ref[d] = src.ref[s]; dst.alt[d] = src.alt[s];
-      dst.qual[d] = src.qual[s]; dst.flags[d] = src.flags[s];
     }
   }
 }
@@ -991,20 +983,18 @@ void launch_synth(const SynthParams& S, int n_vcf, int64_t max_n, hipStream_t st
   if (n_vcf > 0 && max_n > 0)
     hipLaunchKernelGGL(k_synth, dim3((unsigned)((max_n + 255) / 256), (unsigned)n_vcf), dim3(256), 0, st, S);
 }
-void launch_sort_init(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const int32_t* pos, uint32_t* keys, uint32_t* vals,
-                      uint32_t* orbits, hipStream_t st) {
-  if (ntiles > 0) hipLaunchKernelGGL(k_sort_init, dim3(ntiles), dim3(256), 0, st, segs, tile_seg, pos, keys, vals, orbits);
+void launch_sort_init(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const SortCols& src, int n_bins, uint32_t* keys,
+                      uint32_t* infs, uint32_t* vals, uint32_t* orbits, hipStream_t st) {
+  if (ntiles > 0) hipLaunchKernelGGL(k_sort_init, dim3(ntiles), dim3(256), 0, st, segs, tile_seg, src, n_bins, keys, infs, vals, orbits);
 }
-void launch_sort_pass(const SortSeg* segs, const int32_t* tile_seg, int nseg, int ntiles, const uint32_t* keys, const uint32_t* vals,
-                      int shift, uint32_t* hist, uint32_t* okeys, uint32_t* ovals, hipStream_t st) {
+void launch_sort_pass(const SortSeg* segs, const int32_t* tile_seg, int nseg, int ntiles, const uint32_t* keys, const uint32_t* infs,
+                      const uint32_t* vals, int shift, uint32_t* hist, uint32_t* okeys, uint32_t* oinfs, uint32_t* ovals, int final_dst,
+                      hipStream_t st) {
   if (ntiles <= 0) return;
   hipLaunchKernelGGL(k_sort_hist, dim3(ntiles), dim3(256), 0, st, segs, tile_seg, keys, shift, hist);
   hipLaunchKernelGGL(k_sort_scan, dim3(nseg), dim3(256), 0, st, segs, hist);
-  hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(256), 0, st, segs, tile_seg, keys, vals, shift, hist, okeys, ovals);
-}
-void launch_sort_gather(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const uint32_t* perm, const SortCols& src,
-                        const SortColsOut& dst, hipStream_t st) {
-  if (ntiles > 0) hipLaunchKernelGGL(k_sort_gather, dim3(ntiles), dim3(256), 0, st, segs, tile_seg, perm, src, dst);
+  hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(256), 0, st, segs, tile_seg, keys, infs, vals, shift, hist, okeys, oinfs, ovals,
+                     final_dst);
 }
 void launch_sort_scatter_cls(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const uint64_t* mp, const uint64_t* mt,
                              const uint32_t* perm, uint8_t* cls, hipStream_t st) {
