@@ -820,15 +820,20 @@ __global__ __launch_bounds__(256) void k_sort_scan(const SortSeg* segs, uint32_t
   }
 }
 
-// stable scatter: wave w of the tile owns SORT_TILE/4 consecutive keys and walks
-// them 64 at a time; rank inside a wave step by an 8-ballot multisplit.
+// stable scatter: wave w of the tile owns SORT_TILE/4 consecutive keys and walks them 64 at a
+// time; the rank inside a wave step comes from an 8-ballot multisplit (peers = lanes with the
+// same digit).  The tile is then reordered by digit in LDS so that each digit's run leaves as
+// ONE contiguous, coalesced write per array instead of dribbling out 4 bytes at a time.
 // `infs` (second payload) may be null; with `final_dst` the keys and infos of the last pass land at the
 // segment's place in the scratch batch (dst_off) instead of the chunk arrays (koff).
 __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const int32_t* tile_seg, const uint32_t* keys,
                                                       const uint32_t* infs, const uint32_t* vals, int shift, const uint32_t* hist,
                                                       uint32_t* okeys, uint32_t* oinfs, uint32_t* ovals, int final_dst) {
-  __shared__ uint32_t s_cnt[4][256];   // running count of digit d in wave w
-  __shared__ uint32_t s_base[4][256];  // start of wave w's digit-d block in the output
+  __shared__ uint32_t s_cnt[4][256];   // count of digit d in wave w's chunk (running during the ranking)
+  __shared__ uint32_t s_loc[256];      // tile-local start of digit d's run
+  __shared__ uint32_t s_glob[256];     // global start of this tile's digit-d run, minus s_loc[d]
+  __shared__ uint32_t s_scan[256];
+  __shared__ uint32_t s_k[SORT_TILE], s_i[SORT_TILE], s_v[SORT_TILE];
   const SortSeg sg = segs[tile_seg[blockIdx.x]];
   const int t = (int)blockIdx.x - sg.tile0;
   const int tid = (int)threadIdx.x;
@@ -836,7 +841,8 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
   const int wave = tid >> 6;
   for (int i = tid; i < 4 * 256; i += 256) (&s_cnt[0][0])[i] = 0;
   __syncthreads();
-  const int64_t wbase = (int64_t)t * SORT_TILE + (int64_t)wave * (SORT_TILE / 4);
+  const int64_t tbase = (int64_t)t * SORT_TILE;
+  const int64_t wbase = tbase + (int64_t)wave * (SORT_TILE / 4);
   constexpr int STEPS = SORT_TILE / 4 / 64;
   uint32_t kk[STEPS], vv[STEPS], ii[STEPS], rk[STEPS];
 #pragma unroll
@@ -861,25 +867,41 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
     if (valid && r == 0) s_cnt[wave][d] = basec + (uint32_t)__popcll(peers);
   }
   __syncthreads();
-  // digit d (thread d): global offset of this tile + exclusive scan over the 4 waves
-  {
-    const uint32_t g = hist[sg.hoff + (size_t)tid * sg.ntiles + t];
-    uint32_t run = g;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) { s_base[w][tid] = run; run += s_cnt[w][tid]; }
+  // thread d: digit d's count over the 4 waves -> exclusive scan over digits = tile-local run starts
+  uint32_t c0 = s_cnt[0][tid], c1 = s_cnt[1][tid], c2 = s_cnt[2][tid], c3 = s_cnt[3][tid];
+  const uint32_t tot = c0 + c1 + c2 + c3;
+  s_scan[tid] = tot;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const uint32_t y = tid >= d ? s_scan[tid - d] : 0u;
+    __syncthreads();
+    s_scan[tid] += y;
+    __syncthreads();
   }
+  const uint32_t loc = s_scan[tid] - tot;
+  s_loc[tid] = loc;
+  s_glob[tid] = hist[sg.hoff + (size_t)tid * sg.ntiles + t] - loc;
+  // wave w's block inside digit d's run
+  s_cnt[0][tid] = loc; s_cnt[1][tid] = loc + c0; s_cnt[2][tid] = loc + c0 + c1; s_cnt[3][tid] = loc + c0 + c1 + c2;
   __syncthreads();
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) {
     const int64_t i = wbase + s * 64 + lane;
     if (i < sg.n) {
       const uint32_t d = (kk[s] >> shift) & 255u;
-      const uint32_t o = s_base[wave][d] + rk[s];
-      const int64_t ko = (final_dst ? sg.dst_off : sg.koff) + o;
-      okeys[ko] = kk[s];
-      if (infs) oinfs[ko] = ii[s];
-      ovals[sg.koff + o] = vv[s];
+      const uint32_t lp = s_cnt[wave][d] + rk[s];
+      s_k[lp] = kk[s]; s_i[lp] = ii[s]; s_v[lp] = vv[s];
     }
+  }
+  __syncthreads();
+  const int nvalid = (int)((sg.n - tbase) < SORT_TILE ? (sg.n - tbase) : SORT_TILE);
+  const int64_t kbase = final_dst ? sg.dst_off : sg.koff;
+  for (int idx = tid; idx < nvalid; idx += 256) {
+    const uint32_t k = s_k[idx];
+    const uint32_t g = s_glob[(k >> shift) & 255u] + (uint32_t)idx;
+    okeys[kbase + g] = k;
+    if (infs) oinfs[kbase + g] = s_i[idx];
+    ovals[sg.koff + g] = s_v[idx];
   }
 }
 
