@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("QM_BENCH_CPU_VCFS", "100")),
                     help="VCFs timed through the CPU oracle on rank 0 (N=1 only); 0 disables")
     ap.add_argument("--shuffled", action="store_true", help="records permuted: every VCF takes the radix-sort path")
+    ap.add_argument("--shuffled-vcfs", type=int, default=int(os.environ.get("QM_BENCH_SHUFFLED_VCFS", "128")),
+                    help="also time the shuffled variant (radix-sort path) on this many VCFs at N=1; 0 disables")
     args = ap.parse_args()
 
     import numpy as np
@@ -159,12 +161,39 @@ def main():
 
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(batch, args, min(args.cpu_sample, n_vcf), args.genome, args.truth, tseed)
+    if rank == 0 and world == 1 and not args.shuffled and args.shuffled_vcfs > 0:
+        out["shuffled_variant"] = shuffled_variant(eng, tid, args, min(args.shuffled_vcfs, n_vcf), tseed, roc)
     if rank == 0:
         print(json.dumps(out))
     batch.close()
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def shuffled_variant(eng, tid, args, nv, tseed, sorted_roc):
+    """Config 3's second variant: the same VCFs with their records permuted, so every VCF takes the
+    optimistic pass, is found out of order and goes through the batched radix-sort path.  A side
+    measurement on a subset; its counters must equal those of the sorted VCFs."""
+    import numpy as np
+    import torch
+    b = eng.batch([args.records] * nv, [tid] * nv, n_bins=args.bins)
+    b.synth(args.genome, args.truth, tseed, 3000, shuffled=True)
+    for _ in range(1):
+        b.run()
+        b.finish()
+    torch.cuda.synchronize()
+    steps = 3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b.run()
+        b.finish()
+    dt = time.perf_counter() - t0
+    ok = bool(np.array_equal(b.roc(), sorted_roc[:nv])) and int(b.scalars()[:, 5].sum()) == 0
+    b.close()
+    return {"value": nv * float(args.records) * steps / dt, "unit": "classifications/s", "vcfs": nv, "steps": steps,
+            "ms_per_step": dt / steps * 1e3, "roc_equals_sorted_variant": ok,
+            "note": "records permuted: optimistic pass + batched LSD radix sort (8-bit digits) + packed k_classify + scatter back"}
 
 
 def cpu_baseline(batch, args, n_sample, L, T, tseed):

@@ -20,7 +20,10 @@ constexpr int K1_TILE = 256 * K1_ROUNDS;     // 1024 records: one LDS truth slic
 constexpr int K1_SLICE = QM_K1_SLICE;        // truth keys per LDS slice buffer (two buffers per wave)
 constexpr int SPAN_TILES = QM_SPAN_TILES;    // tiles per wave = per workgroup (one histogram flush per span)
 constexpr int VCF_ALIGN = 256;                     // device start of every VCF (records)
-constexpr int SORT_TILE = 2048;
+#ifndef QM_SORT_TILE
+#define QM_SORT_TILE 2048
+#endif
+constexpr int SORT_TILE = QM_SORT_TILE;      // keys per radix-sort workgroup
 constexpr int QM_POS_LIMIT_DEV = 1 << 28;
 
 constexpr uint32_t QMF_PASS = 1u;
