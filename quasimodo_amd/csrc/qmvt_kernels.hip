@@ -161,8 +161,7 @@ __device__ __forceinline__ TruthG truth_global(const TruthDev& t) {
 
 // LDS layout of the wave (dword offsets into one array, so every access is a ds_ op)
 constexpr int L_HIST = 0;                               // [3][128] TP / FP / distinct-truth-key histograms, two u16 bins per dword
-constexpr int L_TRASH = 384;                            // [4] sink for predicated-off histogram adds
-constexpr int L_KEYS = 388;                             // [2][K1_SLICE] staged truth keys
+constexpr int L_KEYS = 384;                             // [2][K1_SLICE] staged truth keys
 constexpr int L_SMAX = L_KEYS + 2 * K1_SLICE;           // [2][K1_SLICE] per key: max(bin + 1) of '.'-ID matches
 constexpr int L_SRF = L_SMAX + 2 * K1_SLICE;            // [2][K1_SLICE / 32] per key: matched by a kept record
 constexpr int L_RKEY = L_SRF + 2 * (K1_SLICE / 32);     // [256] record keys of the round (16-byte aligned)
@@ -401,11 +400,7 @@ __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, con
     const bool sat = counted & (bin == nb - 1);
     A.top_tp += (sat & is_tp) ? 1u : 0u;
     A.top_fp += (sat & !is_tp) ? 1u : 0u;
-    if (!(ablate & 2)) {
-      const bool add = counted & !sat;
-      const int slot = add ? L_HIST + (is_tp ? 0 : 128) + (bin >> 1) : L_TRASH + (lane & 3);
-      atomicAdd(&lds[slot], add ? 1u << (16 * (bin & 1)) : 0u);
-    }
+    if (counted && !sat && !(ablate & 2)) hist_add(lds, is_tp ? 0 : 1, bin);   // skipped wave-wide when QUALs saturate
     pp = p;
   }
   // R path: a kept key outside the truth set counts once per VCF
@@ -447,7 +442,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
   const int nb = P.n_bins;
   const int ablate = P.ablate;
 
-  for (int i = lane; i < L_KEYS; i += 64) lds[i] = 0;   // histograms + sink
+  for (int i = lane; i < L_KEYS; i += 64) lds[i] = 0;   // histograms
   Acc A = {0u, 0u, 0u, 0u, 0u, 0u};
   uint32_t acc_pass = 0, acc_tp = 0;  // wave-uniform
   uint32_t acc_tpr = 0;               // per lane, reduced at the end

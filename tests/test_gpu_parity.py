@@ -156,6 +156,31 @@ def test_synthetic_batch_vs_oracle(engine, oracle, shuffled):
     b.close()
 
 
+def test_config4_shape_ten_million_record_vcfs(engine, oracle):
+    """BASELINE configs[3] shape per VCF: 10 M records on a 50 Mb reference, 1 M truth keys (611 spans,
+    9 766 tiles per VCF), sorted and shuffled, against the oracle."""
+    from oracle.synth import synth_truth_keys
+    L, N, T = 50_000_000, 10_000_000, 1_000_000
+    tid = engine.truth_synth(L, T, 4)
+    tk = synth_truth_keys(L, T, 4)
+    for shuffled in (False, True):
+        b = engine.batch([N, N // 2], [tid, tid])
+        b.synth(L, T, 4, 4000, shuffled=shuffled)
+        b.run()
+        b.finish()
+        roc, scal = b.roc(), b.scalars()
+        for v in range(2):
+            cols = b.columns(v)
+            cls, oroc, sc = oracle.classify_columns(*cols, *tk)
+            assert np.array_equal(b.cls(v), cls)
+            assert np.array_equal(roc[v], oroc)
+            assert [int(x) for x in scal[v][:5]] == [sc[k] for k in ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R")]
+            idx = b.idx(v)
+            assert np.array_equal(idx[:sc["tp_lines"]], np.nonzero(cls == 3)[0])
+            assert np.array_equal(idx[len(cls) - sc["fp_lines"]:], np.nonzero(cls == 1)[0])
+        b.close()
+
+
 def test_fp_overlap_vs_sets(engine):
     rng = np.random.default_rng(23)
     sets = []
