@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--bins", type=int, default=256)
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("QM_BENCH_CPU_VCFS", "100")),
                     help="VCFs timed through the CPU oracle on rank 0 (N=1 only); 0 disables")
+    ap.add_argument("--shell-sample", type=int, default=int(os.environ.get("QM_BENCH_SHELL_VCFS", "3")),
+                    help="VCFs timed through the reference's own mechanism (awk + fgrep pipeline) on rank 0 (N=1 only); 0 disables")
     ap.add_argument("--shuffled", action="store_true", help="records permuted: every VCF takes the radix-sort path")
     ap.add_argument("--shuffled-vcfs", type=int, default=int(os.environ.get("QM_BENCH_SHUFFLED_VCFS", "128")),
                     help="also time the shuffled variant (radix-sort path) on this many VCFs at N=1; 0 disables")
@@ -161,6 +163,11 @@ def main():
 
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(batch, args, min(args.cpu_sample, n_vcf), args.genome, args.truth, tseed)
+    if rank == 0 and world == 1 and args.shell_sample > 0:
+        try:
+            out["cpu_baseline_shell"] = shell_baseline(batch, args, min(args.shell_sample, n_vcf), tseed)
+        except Exception as e:   # awk / GNU grep missing on the box: a reported extra, never fatal
+            out["cpu_baseline_shell"] = {"error": str(e)[:200]}
     if rank == 0 and world == 1 and not args.shuffled and args.shuffled_vcfs > 0:
         out["shuffled_variant"] = shuffled_variant(eng, tid, args, min(args.shuffled_vcfs, n_vcf), tseed, roc)
     if rank == 0:
@@ -194,6 +201,65 @@ def shuffled_variant(eng, tid, args, nv, tseed, sorted_roc):
     return {"value": nv * float(args.records) * steps / dt, "unit": "classifications/s", "vcfs": nv, "steps": steps,
             "ms_per_step": dt / steps * 1e3, "roc_equals_sorted_variant": ok,
             "note": "records permuted: optimistic pass + batched LSD radix sort (8-bit digits) + packed k_classify + scatter back"}
+
+
+def shell_baseline(batch, args, n_sample, tseed):
+    """The reference's mechanism on this box's host: the same five shell commands per VCF that
+    program/extract_TP_FP_SNPs.py:24-57 issues (awk filter, grep header, fgrep -wf / -wvf with
+    process substitution), authored here (the reference file itself does not travel), on text
+    renderings of the first n_sample VCFs of the batch, one VCF at a time as rules/extract_TP.smk:17
+    serialises them.  Line counts are checked against the GPU's."""
+    import shutil
+    import subprocess
+    import tempfile
+    import numpy as np
+    from oracle.synth import synth_truth_keys
+    for tool in ("awk", "grep", "bash"):
+        if not shutil.which(tool):
+            raise RuntimeError("%s not found" % tool)
+    awkv = subprocess.run("awk -W version 2>&1 | head -1 || awk --version | head -1", shell=True, capture_output=True, text=True).stdout.strip()
+    bases = np.array([b"A", b"C", b"G", b"T"])
+    tp, tr, ta = synth_truth_keys(args.genome, args.truth, tseed)
+    scal = batch.scalars()
+    hdr = b"##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n"
+
+    def render(pos, ref, alt, qual):
+        cols = [np.full(len(pos), b"chrS"), pos.astype("S"), np.full(len(pos), b"."), bases[ref], bases[alt], qual.astype(np.int64).astype("S"),
+                np.full(len(pos), b"PASS"), np.full(len(pos), b"DP=30")]
+        line = cols[0]
+        for c in cols[1:]:
+            line = np.char.add(np.char.add(line, b"\t"), c)
+        return hdr + b"\n".join(line.tolist()) + b"\n"
+
+    with tempfile.TemporaryDirectory() as w:
+        truth = os.path.join(w, "truth.vcf")
+        open(truth, "wb").write(render(tp, tr, ta, np.full(len(tp), 30.0)))
+        paths = []
+        for v in range(n_sample):
+            pos, ref, alt, qual, _ = batch.columns(v)
+            p = os.path.join(w, "S-1-10.R%d.c.vcf" % v)
+            open(p, "wb").write(render(pos, ref, alt, qual))
+            paths.append(p)
+        flt = r'''awk -F"\t" '$4~/^[ACGT]$/&&$5~/^[ACGT]$/&&($6>=20||$6==".")' %s'''
+        gs = r'''awk -F"\t" '$4~/^[ACGT]$/&&$5~/^[ACGT]$/{print $2, ".", $4, $5}' OFS="\t" %s''' % truth
+        t0 = time.perf_counter()
+        for p in paths:
+            f = flt % p
+            subprocess.run(["bash", "-c", '(grep -E "^#" %s;%s) > %s.filtered' % (p, f, p)], check=True)
+            a = subprocess.Popen(["bash", "-c", '(grep -E "^#" %s;grep -F -wf <(%s) <(%s)) > %s.tp' % (p, gs, f, p)])
+            b = subprocess.Popen(["bash", "-c", '(grep -E "^#" %s;grep -F -wvf <(%s) <(%s)) > %s.fp' % (p, gs, f, p)])
+            a.wait(); b.wait()
+        dt = time.perf_counter() - t0
+        mb = os.path.getsize(paths[0]) / 1e6
+        for v, p in enumerate(paths):
+            nl = lambda q: sum(1 for ln in open(q, "rb") if not ln.startswith(b"#"))
+            assert nl(p + ".filtered") == scal[v][0] and nl(p + ".tp") == scal[v][1] and nl(p + ".fp") == scal[v][2], \
+                "shell pipeline and GPU disagree on VCF %d" % v
+    n = float(n_sample) * args.records
+    return {"value": n / dt, "unit": "classifications/s", "cores": 3, "kind": "reference-mechanism",
+            "sample": "first %d VCFs as text (%.0f MB each), awk filter + fgrep -wf/-wvf as extract_TP_FP_SNPs.py:24-57, VCFs serial, "
+                      "<= 3 concurrent pipelines per VCF, %.1f s; line counts equal the GPU's" % (n_sample, mb, dt),
+            "awk": awkv}
 
 
 def cpu_baseline(batch, args, n_sample, L, T, tseed):
