@@ -170,6 +170,7 @@ constexpr int L_HITS = L_RINF + 128;                    // [8] one bit per recor
 constexpr int L_TOTAL = L_HITS + 8;
 static_assert(L_RKEY % 4 == 0 && L_RINF % 2 == 0, "b128 / b64 LDS stores need natural alignment");
 static_assert(SPAN_TILES * K1_TILE < 65536, "u16 histogram bins hold at most one span");
+static_assert(K1_ROUNDS >= 3 && K1_SLICE % 64 == 0, "the next tile's slice is fetched over rounds 0..2 of the current one");
 
 struct Slice {
   int keys, smax, srf;  // dword offsets of the active buffer
@@ -420,6 +421,9 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #ifndef K1_LDS_PAD
 #define K1_LDS_PAD 0
 #endif
+#ifndef K1_PREFETCH
+#define K1_PREFETCH 1
+#endif
 #ifndef K1_WAVES_PER_EU
 #define K1_WAVES_PER_EU 4
 #endif
@@ -452,6 +456,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
   int te = (tb + K1_TILE < sp_end) ? tb + K1_TILE : sp_end;
   Raw4<PACKED> N;
   load_raw(C, tb + lane * 4, N);
+#if K1_PREFETCH == 2
+  Raw4<PACKED> N2 = N;
+  if (tb + 256 < sp_end) load_raw(C, tb + 256 + lane * 4, N2);
+#endif
   SegBounds B = seg_bounds<PACKED>(C, tb, te, vn);
   int lo, hi;
   slice_range(tr, B.a, B.b, lo, hi);
@@ -474,18 +482,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
     const int nrounds = (te - tb + 255) >> 8;
 
     SegBounds NB = B;
+    int nlo = 0, nhi = 0;
+    uint32_t nkeys[K1_SLICE / 64];
+#pragma unroll
+    for (int q = 0; q < K1_SLICE / 64; ++q) nkeys[q] = 0u;
     int prev_last = B.prevp;
     for (int r = 0; r < nrounds; ++r) {
       In4 X;
       unpack_raw(N, nb, X);
       const int rbase = tb + r * 256;
       const int rend = rbase + 256 < te ? rbase + 256 : te;
-      // next round's records into flight first
-      if (r + 1 < nrounds) {
-        load_raw(C, rbase + 256 + lane * 4, N);
-      } else if (has_next_tile) {
-        load_raw(C, ntb + lane * 4, N);
-        NB = seg_bounds<PACKED>(C, ntb, nte, vn);
+      // the following rounds' records into flight first (rounds are contiguous across the span's tiles)
+#if K1_PREFETCH == 2
+      N = N2;
+      if (rbase + 512 < sp_end) load_raw(C, rbase + 512 + lane * 4, N2);
+#else
+      if (rbase + 256 < sp_end) load_raw(C, rbase + 256 + lane * 4, N);
+#endif
+      // the next tile's slice is fetched as a side chain spread over this tile's rounds, so none of
+      // its three dependent global round trips (bounds -> position index -> keys) is exposed
+      if (has_next_tile) {
+        if (r == 0) {
+          NB = seg_bounds<PACKED>(C, ntb, nte, vn);
+        } else if (r == 1) {
+          slice_range(tr, NB.a, NB.b, nlo, nhi);
+        } else if (r == 2) {
+          const int nm = (nhi - nlo) <= K1_SLICE ? (nhi - nlo) : 0;
+#pragma unroll
+          for (int q = 0; q < K1_SLICE / 64; ++q) nkeys[q] = (q * 64 + lane < nm) ? tr.keys[nlo + q * 64 + lane] : 0u;
+        }
       }
       stage_round(lds, X, rbase + lane * 4, te, lane);
       __syncthreads();
@@ -546,15 +571,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
 
     if (!has_next_tile) break;
     // ---- stage the next tile's slice into the other LDS half ----------------------------
+    // (a full tile has K1_ROUNDS >= 3 rounds, so the side chain above has run to its end)
     B = NB;
     tb = ntb;
     te = nte;
     ++tile;
-    slice_range(tr, B.a, B.b, lo, hi);
+    lo = nlo;
+    hi = nhi;
     buf ^= 1;
     slice_select(S, buf);
     S.m = (hi - lo) <= K1_SLICE ? (hi - lo) : 0;
-    stage_slice(lds, tr, lo, S, lane);
+#pragma unroll
+    for (int q = 0; q < K1_SLICE / 64; ++q) {
+      const int j = q * 64 + lane;
+      if (j < S.m) { lds[S.keys + j] = nkeys[q]; lds[S.smax + j] = 0; }
+    }
+    if (lane < K1_SLICE / 32) lds[S.srf + lane] = 0;
     __syncthreads();
   }
 
