@@ -81,8 +81,12 @@ def main():
     batch = eng.batch([args.records] * n_vcf, [tid] * n_vcf, n_bins=args.bins)
     # VCF v of rank r is global VCF r * n_vcf + v: seed 3000 + that
     batch.synth(args.genome, args.truth, tseed, 3000 + rank * n_vcf, shuffled=args.shuffled)
-    stream = torch.cuda.current_stream()
+    # One explicit (non-default) stream carries the engine's kernels AND the collective, so the all-reduce is
+    # ordered after the counters it sums.  (A NULL handle would make the engine use its own private stream.)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     glob = torch.zeros((eng.n_truth, 3, args.bins), dtype=torch.int64, device=dev)
+    assert stream.cuda_stream != 0
 
     def step():
         batch.run(stream=stream.cuda_stream, global_dev=glob.data_ptr())
@@ -125,7 +129,9 @@ def main():
     else:
         ref = torch.from_numpy(local_sum).to(dev)
         dist.all_reduce(ref, op=dist.ReduceOp.SUM)
-        assert np.array_equal(got, ref.cpu().numpy()), "all-reduced counters != sum over ranks of the per-VCF ROC rows"
+        if not np.array_equal(got, ref.cpu().numpy()):
+            raise AssertionError("all-reduced counters != sum over ranks of the per-VCF ROC rows: rank %d got %d, local %d, summed %d"
+                                 % (rank, int(got.sum()), int(local_sum.sum()), int(ref.sum().item())))
 
     total_records = float(n_vcf) * args.records * world
     value = total_records * args.steps / dt
