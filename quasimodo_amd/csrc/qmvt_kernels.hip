@@ -136,7 +136,20 @@ __device__ __forceinline__ void unpack_raw(const Raw4<true>& R, int, In4& X) {
   X.inf[0] = R.i.x; X.inf[1] = R.i.y; X.inf[2] = R.i.z; X.inf[3] = R.i.w;
 }
 
-// single-record accessors for the rare paths (run continuation, repeated keys, segment bounds)
+// Wave-uniform single values (tile bounds, position-index entries) go through the scalar cache:
+// constant-address-space loads become s_load_dword, which count on lgkmcnt and therefore never
+// make the wave drain its in-flight vector prefetch (vmcnt is in-order).  The columns and the
+// truth set are read-only for the whole launch, so the non-coherent scalar cache is safe.
+typedef const __attribute__((address_space(4))) int32_t* ci32p;
+typedef const __attribute__((address_space(4))) uint32_t* cu32p;
+__device__ __forceinline__ int uload(const int32_t* p, int i) { return ((ci32p)(uintptr_t)p)[i]; }
+__device__ __forceinline__ uint32_t uload(const uint32_t* p, int i) { return ((cu32p)(uintptr_t)p)[i]; }
+template <bool PACKED> __device__ __forceinline__ int rec_pos_uniform(const Cols& C, int i) {
+  if (PACKED) return (int)(uload(C.pkey, i) >> 4);
+  return uload(C.pos, i);
+}
+
+// single-record accessors for the rare paths (run continuation, repeated keys)
 template <bool PACKED> __device__ __forceinline__ int rec_pos(const Cols& C, int i) {
   if (PACKED) return (int)(C.pkey[i] >> 4);
   return C.pos[i];
@@ -195,8 +208,8 @@ __device__ __forceinline__ void slice_range(const TruthG& tr, int a, int b, int&
   const uint32_t lim = (uint32_t)tr.nb + 1u;
   ba = ba < lim ? ba : lim;
   bb = bb < lim ? bb : lim;
-  lo = tr.tidx[ba];
-  hi = tr.tidx[bb];
+  lo = uload((const int32_t*)(uintptr_t)tr.tidx, (int)ba);
+  hi = uload((const int32_t*)(uintptr_t)tr.tidx, (int)bb);
   if (hi < lo) hi = lo;  // only on unsorted input (results discarded)
 }
 
@@ -207,10 +220,10 @@ struct SegBounds {   // a run of records that owns truth-entry state (a tile, or
 
 template <bool PACKED> __device__ __forceinline__ SegBounds seg_bounds(const Cols& C, int sb, int se, int vn) {
   SegBounds t;
-  t.a = rec_pos<PACKED>(C, sb);
-  t.b = rec_pos<PACKED>(C, se - 1);
-  t.prevp = (sb > 0) ? rec_pos<PACKED>(C, sb - 1) : INT32_MIN;
-  t.nextp = (se < vn) ? rec_pos<PACKED>(C, se) : INT32_MIN;
+  t.a = rec_pos_uniform<PACKED>(C, sb);
+  t.b = rec_pos_uniform<PACKED>(C, se - 1);
+  t.prevp = (sb > 0) ? rec_pos_uniform<PACKED>(C, sb - 1) : INT32_MIN;
+  t.nextp = (se < vn) ? rec_pos_uniform<PACKED>(C, se) : INT32_MIN;
   return t;
 }
 
@@ -492,13 +505,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
       unpack_raw(N, nb, X);
       const int rbase = tb + r * 256;
       const int rend = rbase + 256 < te ? rbase + 256 : te;
-      // the following rounds' records into flight first (rounds are contiguous across the span's tiles)
-#if K1_PREFETCH == 2
-      N = N2;
-      if (rbase + 512 < sp_end) load_raw(C, rbase + 512 + lane * 4, N2);
-#else
-      if (rbase + 256 < sp_end) load_raw(C, rbase + 256 + lane * 4, N);
-#endif
       // the next tile's slice is fetched as a side chain spread over this tile's rounds, so none of
       // its three dependent global round trips (bounds -> position index -> keys) is exposed
       if (has_next_tile) {
@@ -512,6 +518,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
           for (int q = 0; q < K1_SLICE / 64; ++q) nkeys[q] = (q * 64 + lane < nm) ? tr.keys[nlo + q * 64 + lane] : 0u;
         }
       }
+      // then the following rounds' records into flight (rounds are contiguous across the span's tiles)
+#if K1_PREFETCH == 2
+      N = N2;
+      if (rbase + 512 < sp_end) load_raw(C, rbase + 512 + lane * 4, N2);
+#else
+      if (rbase + 256 < sp_end) load_raw(C, rbase + 256 + lane * 4, N);
+#endif
       stage_round(lds, X, rbase + lane * 4, te, lane);
       __syncthreads();
       if (!(ablate & 1)) {
