@@ -82,19 +82,21 @@ __device__ __forceinline__ int lds_lower_bound(const uint32_t* __restrict__ k, i
 // ---------------------------------------------------------------------------
 
 // 16-bit info of a record (what a matching truth key and the per-record pass need)
-constexpr uint32_t I_BIN1 = 0x1ffu;      // bin + 1 (0 = passes no threshold)
+constexpr uint32_t I_BIN1 = 0x1ffu;      // bin + 1; 0 = passes no threshold or is not a live (single-base, in-range) record
 constexpr uint32_t I_PASS = 1u << 9;     // flags bit0
 constexpr uint32_t I_IDDOT = 1u << 10;   // flags bit1
 constexpr uint32_t I_NOKEY = 1u << 11;   // flags bit2
 constexpr uint32_t I_LIVE = 1u << 12;    // position in range, single-base alleles
 constexpr uint32_t I_BADPOS = 1u << 13;  // position outside [0, 2^28)
+constexpr uint32_t I_KEPT = 1u << 14;    // live and PASS: the line is in <x>.filtered.vcf
 
 // key and info of one record from its columns (qmvt_dev.h: the radix-sort path uses the same)
 __device__ __forceinline__ void pack_record(int p, int r, int a, float q, uint32_t fl, int nb, uint32_t& key, uint32_t& inf) {
   const bool okpos = (uint32_t)p < (uint32_t)QM_POS_LIMIT_DEV;
   const bool live = okpos & ((uint32_t)(r | a) < 4u);
   key = ((uint32_t)p << 4) | (live ? ((uint32_t)r << 2) | (uint32_t)a : 0u);
-  inf = (uint32_t)(qual_bin(q, nb) + 1) | ((fl & 7u) << 9) | (live ? I_LIVE : 0u) | (okpos ? 0u : I_BADPOS);
+  inf = (live ? (uint32_t)(qual_bin(q, nb) + 1) : 0u) | ((fl & 7u) << 9) | (live ? I_LIVE : 0u) | (okpos ? 0u : I_BADPOS) |
+        ((live && (fl & QMF_PASS)) ? I_KEPT : 0u);
 }
 
 struct Cols {  // bases of one VCF: the five columns, or the packed pair
@@ -173,8 +175,11 @@ __device__ __forceinline__ TruthG truth_global(const TruthDev& t) {
 }
 
 // LDS layout of the wave (dword offsets into one array, so every access is a ds_ op)
-constexpr int L_HIST = 0;                               // [3][128] TP / FP / distinct-truth-key histograms, two u16 bins per dword
-constexpr int L_KEYS = 384;                             // [2][K1_SLICE] staged truth keys
+constexpr int L_HTP = 0;                                // [257] TP histogram indexed by bin + 1; slot 0 swallows the uncounted records
+constexpr int L_HFP = 257;                              // [257] FP histogram, same indexing
+constexpr int L_HU = 514;                               // [256] distinct-truth-key histogram indexed by bin
+constexpr int L_TOP = 770;                              // [2][64] per-lane counters of the saturated top bin (TP, FP): real QUALs pile up there
+constexpr int L_KEYS = 900;                             // [2][K1_SLICE] staged truth keys
 constexpr int L_SMAX = L_KEYS + 2 * K1_SLICE;           // [2][K1_SLICE] per key: max(bin + 1) of '.'-ID matches
 constexpr int L_SRF = L_SMAX + 2 * K1_SLICE;            // [2][K1_SLICE / 32] per key: matched by a kept record
 constexpr int L_RKEY = L_SRF + 2 * (K1_SLICE / 32);     // [256] record keys of the round (16-byte aligned)
@@ -182,7 +187,6 @@ constexpr int L_RINF = L_RKEY + 256;                    // [128] record infos, u
 constexpr int L_HITS = L_RINF + 128;                    // [8] one bit per record of the round: matched a truth key
 constexpr int L_TOTAL = L_HITS + 8;
 static_assert(L_RKEY % 4 == 0 && L_RINF % 2 == 0, "b128 / b64 LDS stores need natural alignment");
-static_assert(SPAN_TILES * K1_TILE < 65536, "u16 histogram bins hold at most one span");
 static_assert(K1_ROUNDS >= 3 && K1_SLICE % 64 == 0, "the next tile's slice is fetched over rounds 0..2 of the current one");
 
 struct Slice {
@@ -230,9 +234,11 @@ template <bool PACKED> __device__ __forceinline__ SegBounds seg_bounds(const Col
 // ---- phase A: stage the round's keys and infos in LDS ------------------------------------
 // records at or beyond `te` become key 0xffffffff (sorts last, matches nothing), info 0.
 __device__ __forceinline__ void stage_round(uint32_t* lds, In4& X, int i0, int te, int lane) {
+  if (i0 - lane * 4 + 256 > te) {   // wave-uniform: only the last round of a span can be partial
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (i0 + k >= te) { X.key[k] = 0xffffffffu; X.inf[k] = 0u; }
+    for (int k = 0; k < 4; ++k)
+      if (i0 + k >= te) { X.key[k] = 0xffffffffu; X.inf[k] = 0u; }
+  }
   uint4 kv;
   kv.x = X.key[0]; kv.y = X.key[1]; kv.z = X.key[2]; kv.w = X.key[3];
   uint2 iv;
@@ -324,15 +330,11 @@ __device__ __forceinline__ void continue_run(const Cols& C, uint32_t* lds, const
   }
 }
 
-__device__ __forceinline__ void hist_add(uint32_t* lds, int which, int bin) {
-  atomicAdd(&lds[L_HIST + which * 128 + (bin >> 1)], 1u << (16 * (bin & 1)));
-}
-
 __device__ __forceinline__ uint32_t flush_slice(uint32_t* lds, const Slice& S, int lane) {
   uint32_t tpr = 0;
   for (int j = lane; j < S.m; j += 64) {
     const uint32_t mx = lds[S.smax + j];
-    if (mx) hist_add(lds, 2, (int)mx - 1);
+    if (mx) atomicAdd(&lds[L_HU + mx - 1], 1u);
     tpr += (lds[S.srf + (j >> 5)] >> (j & 31)) & 1u;
   }
   return tpr;
@@ -355,7 +357,6 @@ __device__ __forceinline__ uint32_t repeated_key(const Cols& C, int i, uint32_t 
 struct Acc {
   uint32_t bad;              // per lane: bit0 order violated, bit1 position out of range
   uint32_t fpr;              // per lane: distinct kept keys outside the truth set
-  uint32_t top_tp, top_fp;   // per lane: counts of the saturated top bin (real QUALs pile up there)
   uint32_t n_pass, n_tp;     // per lane: kept / TP lines of the current tile
 };
 
@@ -373,14 +374,14 @@ template <bool PACKED>
 __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, const In4& X, int rbase, int te, int prev_last, int nb,
                                                int ablate, uint32_t* mpass32, uint32_t* mtp32, Acc& A, int lane) {
   const uint32_t hit = (lds[L_HITS + (lane >> 3)] >> (4 * (lane & 7))) & 15u;
-  uint32_t live = 0, pass = 0, iddot = 0;
+  uint32_t pass = 0, iddot = 0, anyinf = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    live |= ((X.inf[k] >> 12) & 1u) << k;
-    pass |= (((X.inf[k] & (I_LIVE | I_PASS)) == (I_LIVE | I_PASS)) ? 1u : 0u) << k;
+    pass |= ((X.inf[k] >> 14) & 1u) << k;
     iddot |= ((X.inf[k] >> 10) & 1u) << k;
-    A.bad |= (X.inf[k] & I_BADPOS) ? 2u : 0u;
+    anyinf |= X.inf[k];
   }
+  A.bad |= (anyinf & I_BADPOS) ? 2u : 0u;
   const uint32_t tpkey = hit & iddot;
   const uint32_t tp = pass & tpkey;
   const uint32_t fpkey = pass & ~hit;
@@ -407,14 +408,15 @@ __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, con
     const bool valid = i0 + k < te;
     A.bad |= (valid & (p < pp)) ? 1u : 0u;
     cand |= ((valid & (p == pp)) ? 1u : 0u) << k;
-    // ROC histograms: one count per live record with a bin; predicated-off lanes add into a sink
-    const int bin = (int)(X.inf[k] & I_BIN1) - 1;
-    const bool counted = ((live >> k) & 1u) & (bin >= 0);
-    const bool is_tp = (tpkey >> k) & 1u;
-    const bool sat = counted & (bin == nb - 1);
-    A.top_tp += (sat & is_tp) ? 1u : 0u;
-    A.top_fp += (sat & !is_tp) ? 1u : 0u;
-    if (counted && !sat && !(ablate & 2)) hist_add(lds, is_tp ? 0 : 1, bin);   // skipped wave-wide when QUALs saturate
+    // ROC histograms, branch-free: slot = bin + 1 in the TP or FP table (slot 0 swallows records without
+    // a bin); the saturated top bin goes to a per-lane counter so that real, saturated QUALs do not
+    // serialise on one LDS address
+    if (!(ablate & 2)) {
+      const uint32_t b1 = X.inf[k] & I_BIN1;
+      const uint32_t notp = ((~tpkey) >> k) & 1u;
+      const uint32_t slot = (b1 == (uint32_t)nb) ? (uint32_t)(L_TOP + lane) + notp * 64u : (uint32_t)L_HTP + notp * 257u + b1;
+      atomicAdd(&lds[slot], 1u);
+    }
     pp = p;
   }
   // R path: a kept key outside the truth set counts once per VCF
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
   const int ablate = P.ablate;
 
   for (int i = lane; i < L_KEYS; i += 64) lds[i] = 0;   // histograms
-  Acc A = {0u, 0u, 0u, 0u, 0u, 0u};
+  Acc A = {0u, 0u, 0u, 0u};
   uint32_t acc_pass = 0, acc_tp = 0;  // wave-uniform
   uint32_t acc_tpr = 0;               // per lane, reduced at the end
 
@@ -606,17 +608,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
   // ---- span epilogue -------------------------------------------------------------------
   acc_tpr = wave_sum(acc_tpr);
   A.fpr = wave_sum(A.fpr);
-  A.top_tp = wave_sum(A.top_tp);
-  A.top_fp = wave_sum(A.top_fp);
   const uint64_t any_uns = ballot64(A.bad & 1u);
   const uint64_t any_bad = ballot64(A.bad & 2u);
   __syncthreads();
+  const uint32_t top_tp = wave_sum(lds[L_TOP + lane]), top_fp = wave_sum(lds[L_TOP + 64 + lane]);
   uint32_t* oh = P.span_hist + (size_t)blockIdx.x * (3 * 256);
-  for (int i = lane; i < 3 * 256; i += 64) {
-    uint32_t v = (lds[L_HIST + (i >> 8) * 128 + ((i & 255) >> 1)] >> (16 * (i & 1))) & 0xffffu;
-    if (i == nb - 1) v += A.top_tp;
-    if (i == 256 + nb - 1) v += A.top_fp;
-    oh[i] = v;
+  for (int i = lane; i < 256; i += 64) {
+    oh[i] = lds[L_HTP + 1 + i] + (i == nb - 1 ? top_tp : 0u);
+    oh[256 + i] = lds[L_HFP + 1 + i] + (i == nb - 1 ? top_fp : 0u);
+    oh[512 + i] = lds[L_HU + i];
   }
   if (lane == 0) {
     uint32_t* sc = P.span_scal + (size_t)blockIdx.x * 8;
