@@ -404,10 +404,9 @@ __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, con
   uint32_t cand = 0;   // kept keys outside the truth set whose predecessor has the same position
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int p = (int)(X.key[k] >> 4);
-    const bool valid = i0 + k < te;
-    A.bad |= (valid & (p < pp)) ? 1u : 0u;
-    cand |= ((valid & (p == pp)) ? 1u : 0u) << k;
+    const int p = (int)(X.key[k] >> 4);   // records beyond the span carry the maximal key: never below, never kept
+    A.bad |= (p < pp) ? 1u : 0u;
+    cand |= ((p == pp) ? 1u : 0u) << k;
     // ROC histograms, branch-free: slot = bin + 1 in the TP or FP table (slot 0 swallows records without
     // a bin); the saturated top bin goes to a per-lane counter so that real, saturated QUALs do not
     // serialise on one LDS address
