@@ -701,18 +701,47 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
 }
 
 // ---------------------------------------------------------------------------
-// k_compact: ballot masks -> compacted line-index lists (prefix-sum compaction).
+// k_compact: class masks -> compacted line-index lists (prefix-sum compaction).
 // One wave per span (the same spans as k_classify: <= SPAN_TILES tiles of one VCF).
 // The span's mask words are fetched with a few coalesced vector loads (lane l holds
 // words l, l + 64, ...) and broadcast from registers; per word a lane tests its bit,
-// ranks itself with popc(word & lanemask_lt) on top of a running offset and stores
-// its VCF-relative line index.  idx region of VCF v (vd.n entries at vd.off): TP line
-// indices ascending from the front, FP ascending, ending at the back.
+// ranks itself with popc(word & lanemask_lt) on top of a running offset and appends
+// its VCF-relative line index to a ring in LDS.  Whenever 256 entries are ready the
+// wave drains them with ONE 16-byte-per-lane store, aligned to 1 KiB of the output --
+// dword stores are issue-bound on gfx950, dwordx4 stores are not.  Only the ragged head
+// and tail of a span's run fall back to masked dword stores.
+// idx region of VCF v (vd.n entries at vd.off): TP line indices ascending from the
+// front, FP ascending, ending at the back.
 // ---------------------------------------------------------------------------
 constexpr int K3_WORDS = SPAN_TILES * K1_TILE / 64;   // mask words per span
 constexpr int K3_REGS = (K3_WORDS + 63) / 64;
+constexpr int K3_RING = 512;                          // entries per ring (two rings per wave)
+
+struct Ring {
+  uint32_t* buf;    // LDS, K3_RING entries; slot of global output index g is g & (K3_RING - 1)
+  int32_t* out;     // the VCF's index region
+  uint32_t first;   // first output index this span owns
+  uint32_t drained; // next output index to drain (multiple of 256 once past the head)
+  uint32_t end;     // output index after the last appended entry
+};
+
+__device__ __forceinline__ void ring_drain_full(Ring& R, int lane) {
+  // R.drained is a multiple of 256 here: the 256 entries sit contiguously in the ring
+  const uint4 v = *reinterpret_cast<const uint4*>(&R.buf[(R.drained & (K3_RING - 1)) + 4 * lane]);
+  *reinterpret_cast<uint4*>(&R.out[R.drained + 4 * lane]) = v;
+  R.drained += 256;
+}
+// entries [lo, hi) of the 256-chunk starting at `chunk` (the ragged head or tail of the span's run)
+__device__ __forceinline__ void ring_drain_part(Ring& R, uint32_t chunk, uint32_t lo, uint32_t hi, int lane) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t g = chunk + 64u * k + lane;
+    if (g >= lo && g < hi) R.out[g] = (int32_t)R.buf[g & (K3_RING - 1)];
+  }
+}
 
 __global__ __launch_bounds__(64) void k_compact(CompactParams P) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_ring[2][K3_RING];
   const int lane = (int)threadIdx.x;
   const SpanDesc sp = P.spans[blockIdx.x];
   const VcfDesc vd = P.vcfs[sp.vcf];
@@ -731,9 +760,13 @@ __global__ __launch_bounds__(64) void k_compact(CompactParams P) {
   // total FP lines of the VCF = offset of its last tile + that tile's count
   const int lastt = vd.tile0 + vd.ntiles - 1;
   const uint32_t fp_total = P.tile_fp_off[lastt] + P.tile_fp[lastt];
-  int32_t* out = P.idx + vd.off;
-  uint32_t tp_at = P.tile_tp_off[sp.tile0];
-  uint32_t fp_at = ((uint32_t)vd.n - fp_total) + P.tile_fp_off[sp.tile0];
+  Ring T, F;
+  T.buf = s_ring[0]; F.buf = s_ring[1];
+  T.out = F.out = P.idx + vd.off;
+  T.first = T.end = P.tile_tp_off[sp.tile0];
+  F.first = F.end = ((uint32_t)vd.n - fp_total) + P.tile_fp_off[sp.tile0];
+  T.drained = T.first & ~255u;
+  F.drained = F.first & ~255u;
   const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
 #pragma unroll
   for (int i = 0; i < K3_REGS; ++i) {
@@ -743,13 +776,30 @@ __global__ __launch_bounds__(64) void k_compact(CompactParams P) {
       const uint32_t tlo = __builtin_amdgcn_readlane((uint32_t)rt[i], j), thi = __builtin_amdgcn_readlane((uint32_t)(rt[i] >> 32), j);
       const uint64_t wt = ((uint64_t)thi << 32) | tlo;
       const uint64_t wf = (((uint64_t)phi << 32) | plo) & ~wt;
-      const int32_t rel = sb + (i * 64 + j) * 64 + lane;
-      if ((wt >> lane) & 1ull) out[tp_at + (uint32_t)__popcll(wt & below)] = rel;
-      if ((wf >> lane) & 1ull) out[fp_at + (uint32_t)__popcll(wf & below)] = rel;
-      tp_at += (uint32_t)__popcll(wt);
-      fp_at += (uint32_t)__popcll(wf);
+      const uint32_t rel = (uint32_t)(sb + (i * 64 + j) * 64 + lane);
+      if ((wt >> lane) & 1ull) T.buf[(T.end + (uint32_t)__popcll(wt & below)) & (K3_RING - 1)] = rel;
+      if ((wf >> lane) & 1ull) F.buf[(F.end + (uint32_t)__popcll(wf & below)) & (K3_RING - 1)] = rel;
+      T.end += (uint32_t)__popcll(wt);
+      F.end += (uint32_t)__popcll(wf);
+      // drain complete 256-entry chunks (wave-uniform conditions)
+      if (F.end - F.drained >= 256u) {
+        __syncthreads();
+        if (F.drained < F.first) { ring_drain_part(F, F.drained, F.first, F.drained + 256u, lane); F.drained += 256u; }
+        else ring_drain_full(F, lane);
+        __syncthreads();
+      }
+      if (T.end - T.drained >= 256u) {
+        __syncthreads();
+        if (T.drained < T.first) { ring_drain_part(T, T.drained, T.first, T.drained + 256u, lane); T.drained += 256u; }
+        else ring_drain_full(T, lane);
+        __syncthreads();
+      }
     }
   }
+  __syncthreads();
+  // ragged tails (fewer than 256 entries left in each ring)
+  if (F.end > F.drained) ring_drain_part(F, F.drained, F.first > F.drained ? F.first : F.drained, F.end, lane);
+  if (T.end > T.drained) ring_drain_part(T, T.drained, T.first > T.drained ? T.first : T.drained, T.end, lane);
 }
 
 // ---------------------------------------------------------------------------
