@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <unistd.h>
@@ -68,11 +69,43 @@ bool awk_strnum(Span f, double* d) {
   return true;
 }
 
+// Plain decimals -- optional sign, <= 15 significant digits, optional fraction of <= 15 digits, no
+// exponent -- convert exactly with one correctly rounded division (Clinger's fast path), which is
+// what strtod returns for them; everything else goes through awk_strnum / strtod.
+static const double kPow10[16] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15};
+inline bool fast_decimal(Span f, double* d) {
+  const uint8_t* s = f.p;
+  const uint8_t* q = f.p + f.n;
+  if (s == q) return false;
+  bool neg = false;
+  if (*s == '+' || *s == '-') { neg = *s == '-'; ++s; }
+  uint64_t mant = 0;
+  int digits = 0, frac = 0;
+  bool seen_dot = false, any = false;
+  for (; s < q; ++s) {
+    if (*s >= '0' && *s <= '9') {
+      if (digits >= 15) return false;
+      mant = mant * 10 + (uint64_t)(*s - '0');
+      digits += (mant != 0 || digits != 0) ? 1 : 0;
+      frac += seen_dot ? 1 : 0;
+      any = true;
+    } else if (*s == '.' && !seen_dot) {
+      seen_dot = true;
+    } else {
+      return false;
+    }
+  }
+  if (!any || frac > 15) return false;
+  const double v = (double)mant / kPow10[frac];
+  *d = neg ? -v : v;
+  return true;
+}
+
 // Effective QUAL: floor(q) >= t  <=>  awk `$6>=t` for integer t, numeric fields;
 // other spellings collapse to +-inf by their answer at t = 20.
 float effective_qual(Span f, bool* ge20) {
   double d;
-  if (awk_strnum(f, &d)) {
+  if (fast_decimal(f, &d) || awk_strnum(f, &d)) {
     *ge20 = d >= 20.0;
     float q = (float)d;
     if ((double)q > d) q = nextafterf(q, -INFINITY);  // round toward -inf: never crosses an integer upward
@@ -116,59 +149,130 @@ extern "C" int64_t qm_vcf_count_lines(const uint8_t* text, size_t len) {
   return c;
 }
 
-extern "C" int qm_vcf_scan(const uint8_t* text, size_t len, int64_t cap_lines, int64_t* line_off, uint8_t* line_kind,
-                           int32_t* pos, int32_t* ref, int32_t* alt, float* qual, uint8_t* flags, qm_vcf_cols* info) {
-  if ((!text && len) || !line_off || !line_kind || !info) return QM_E_INVAL;
-  int64_t nl = 0, nd = 0, nnc = 0, first_nc = 0;
-  int32_t last_pos = 0;  // carried onto records without a comparable POS
-  size_t off = 0;
+// One chunk of the text (whole lines).  count_only: just the number of lines / data lines.
+struct ScanChunk {
+  size_t begin = 0, end = 0;       // byte range
+  int64_t nl = 0, nd = 0;          // lines / data lines in the chunk
+  int64_t l0 = 0, d0 = 0;          // global index of its first line / data line
+  int64_t nnc = 0, first_nc = 0;   // non-canonical kept lines; 1-based global line of the first
+  int32_t last_pos = 0;            // last canonical POS seen in the chunk (0 if none)
+  int64_t lead_nokey = 0;          // data lines before the chunk's first canonical POS
+  bool any_pos = false;
+};
+
+static void scan_chunk(const uint8_t* text, ScanChunk& c, bool count_only, int64_t* line_off, uint8_t* line_kind, int32_t* pos,
+                       int32_t* ref, int32_t* alt, float* qual, uint8_t* flags) {
+  int64_t nl = 0, nd = 0;
+  int32_t last_pos = 0;
+  bool any_pos = false;
+  size_t off = c.begin;
   enum { MAXF = 64 };
   Span f[MAXF];
-  while (off < len) {
+  while (off < c.end) {
     const uint8_t* s = text + off;
-    const uint8_t* e = (const uint8_t*)memchr(s, '\n', len - off);
-    const size_t n = e ? (size_t)(e - s) : len - off;
-    if (nl >= cap_lines) return QM_E_INVAL;
-    line_off[nl] = (int64_t)off;
-    if (n && s[0] == '#') {
-      line_kind[nl] = 1;
+    const uint8_t* e = (const uint8_t*)memchr(s, '\n', c.end - off);
+    const size_t n = e ? (size_t)(e - s) : c.end - off;
+    const bool header = n && s[0] == '#';
+    if (count_only) {
+      nd += header ? 0 : 1;
     } else {
-      uint8_t kind = 0;
-      int nf = split_tabs(s, n, f, MAXF);
-      const int nfc = nf < MAXF ? nf : MAXF;
-      const Span empty = {(const uint8_t*)"", 0};
-      const Span fpos = nf > 1 ? f[1] : empty, fid = nf > 2 ? f[2] : empty, fref = nf > 3 ? f[3] : empty,
-                 falt = nf > 4 ? f[4] : empty, fq = nf > 5 ? f[5] : empty;
-      const bool snp = acgt1(fref) && acgt1(falt);
-      bool ge20 = false;
-      const float q = effective_qual(fq, &ge20);
-      const bool pass = snp && ge20;
-      int32_t p = -1;
-      const bool cpos = canon_pos(fpos, &p);
-      if (cpos) last_pos = p; else p = last_pos;
-      if (pass) {
-        bool nc = !cpos;  // fgrep compares POS as a string: only canonical spellings are safe
-        for (size_t i = 0; i < n && !nc; ++i) nc = s[i] == 0 || s[i] >= 0x80;  // locale-dependent in the reference
-        // pattern X\t.\tY\tZ found at later fields
-        for (int k = 6; k + 2 < nfc && !nc; ++k)
-          if (is_dot(f[k]) && f[k - 1].n && f[k - 1].p[f[k - 1].n - 1] >= '0' && f[k - 1].p[f[k - 1].n - 1] <= '9' &&
-              f[k + 1].n == 1 && f[k + 2].n >= 1 && (f[k + 2].n == 1 || !is_word(f[k + 2].p[1])))
-            nc = true;
-        if (nf > MAXF) nc = true;
-        if (nc) { kind = 2; ++nnc; if (!first_nc) first_nc = nl + 1; }
+      const int64_t gl = c.l0 + nl, gd = c.d0 + nd;
+      line_off[gl] = (int64_t)off;
+      if (header) {
+        line_kind[gl] = 1;
+      } else {
+        uint8_t kind = 0;
+        int nf = split_tabs(s, n, f, MAXF);
+        const int nfc = nf < MAXF ? nf : MAXF;
+        const Span empty = {(const uint8_t*)"", 0};
+        const Span fpos = nf > 1 ? f[1] : empty, fid = nf > 2 ? f[2] : empty, fref = nf > 3 ? f[3] : empty,
+                   falt = nf > 4 ? f[4] : empty, fq = nf > 5 ? f[5] : empty;
+        const bool snp = acgt1(fref) && acgt1(falt);
+        bool ge20 = false;
+        const float q = effective_qual(fq, &ge20);
+        const bool pass = snp && ge20;
+        int32_t p = -1;
+        const bool cpos = canon_pos(fpos, &p);
+        if (cpos) { last_pos = p; any_pos = true; } else { p = last_pos; if (!any_pos) c.lead_nokey++; }
+        if (pass) {
+          bool nc = !cpos;  // fgrep compares POS as a string: only canonical spellings are safe
+          for (size_t i = 0; i < n && !nc; ++i) nc = s[i] == 0 || s[i] >= 0x80;  // locale-dependent in the reference
+          // pattern X\t.\tY\tZ found at later fields
+          for (int k = 6; k + 2 < nfc && !nc; ++k)
+            if (is_dot(f[k]) && f[k - 1].n && f[k - 1].p[f[k - 1].n - 1] >= '0' && f[k - 1].p[f[k - 1].n - 1] <= '9' &&
+                f[k + 1].n == 1 && f[k + 2].n >= 1 && (f[k + 2].n == 1 || !is_word(f[k + 2].p[1])))
+              nc = true;
+          if (nf > MAXF) nc = true;
+          if (nc) { kind = 2; ++c.nnc; if (!c.first_nc) c.first_nc = gl + 1; }
+        }
+        line_kind[gl] = kind;
+        if (pos) {
+          pos[gd] = p;
+          ref[gd] = fref.n == 1 ? base_code(fref.p[0]) : 4;
+          alt[gd] = falt.n == 1 ? base_code(falt.p[0]) : 4;
+          qual[gd] = q;
+          flags[gd] = (uint8_t)((pass ? QM_F_PASS : 0u) | (is_dot(fid) ? QM_F_IDDOT : 0u) | (cpos ? 0u : QM_F_NOKEY));
+        }
       }
-      line_kind[nl] = kind;
-      if (pos) {
-        pos[nd] = p;
-        ref[nd] = fref.n == 1 ? base_code(fref.p[0]) : 4;
-        alt[nd] = falt.n == 1 ? base_code(falt.p[0]) : 4;
-        qual[nd] = q;
-        flags[nd] = (uint8_t)((pass ? QM_F_PASS : 0u) | (is_dot(fid) ? QM_F_IDDOT : 0u) | (cpos ? 0u : QM_F_NOKEY));
-      }
-      ++nd;
+      if (!header) ++nd;
     }
     ++nl;
     off += n + 1;
+  }
+  c.nl = nl;
+  c.nd = nd;
+  c.last_pos = last_pos;
+  c.any_pos = any_pos;
+}
+
+static int host_threads() {
+  const char* e = getenv("QM_HOST_THREADS");
+  int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+  if (n < 1) n = 1;
+  return n > 32 ? 32 : n;
+}
+
+// Two passes over whole-line chunks, each pass with one thread per chunk: count, then fill at
+// known offsets.  The only cross-chunk state, the position carried onto records without a
+// comparable POS, is patched for the (few) records that precede a chunk's first canonical POS.
+extern "C" int qm_vcf_scan(const uint8_t* text, size_t len, int64_t cap_lines, int64_t* line_off, uint8_t* line_kind,
+                           int32_t* pos, int32_t* ref, int32_t* alt, float* qual, uint8_t* flags, qm_vcf_cols* info) {
+  if ((!text && len) || !line_off || !line_kind || !info) return QM_E_INVAL;
+  int nt = host_threads();
+  if (len < (size_t)(1 << 20)) nt = 1;
+  std::vector<ScanChunk> ch((size_t)nt);
+  size_t b = 0;
+  for (int t = 0; t < nt; ++t) {
+    size_t e = t == nt - 1 ? len : len * (size_t)(t + 1) / (size_t)nt;
+    if (e < b) e = b;
+    if (e < len) {   // extend to the end of the line
+      const uint8_t* nlp = (const uint8_t*)memchr(text + e, '\n', len - e);
+      e = nlp ? (size_t)(nlp - text) + 1 : len;
+    }
+    ch[(size_t)t].begin = b;
+    ch[(size_t)t].end = e;
+    b = e;
+  }
+  auto run = [&](bool count_only) {
+    if (nt == 1) { scan_chunk(text, ch[0], count_only, line_off, line_kind, pos, ref, alt, qual, flags); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t)
+      th.emplace_back([&, t]() { scan_chunk(text, ch[(size_t)t], count_only, line_off, line_kind, pos, ref, alt, qual, flags); });
+    for (auto& x : th) x.join();
+  };
+  run(true);
+  int64_t nl = 0, nd = 0;
+  for (auto& c : ch) { c.l0 = nl; c.d0 = nd; nl += c.nl; nd += c.nd; }
+  if (nl > cap_lines) return QM_E_INVAL;
+  run(false);
+  int64_t nnc = 0, first_nc = 0;
+  int32_t carry = 0;
+  for (auto& c : ch) {
+    if (pos && carry != 0)
+      for (int64_t i = 0; i < c.lead_nokey; ++i) pos[c.d0 + i] = carry;   // leading records had no position of their own
+    if (c.any_pos) carry = c.last_pos;
+    nnc += c.nnc;
+    if (!first_nc && c.first_nc) first_nc = c.first_nc;
   }
   line_off[nl] = (int64_t)len;
   info->n_lines = nl;
