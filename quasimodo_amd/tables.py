@@ -91,3 +91,30 @@ def write_fp_overlap(path, per_sample, callers):
             for m in range(1, 1 << n):
                 names = "&".join(CALLER_MAP.get(callers[i], callers[i]) for i in range(n) if m >> i & 1)
                 fh.write("%s\t%s\t%d\n" % (sample, names, int(reg[m])))
+
+
+def write_weighted_roc(path, roc, truth_unique):
+    """The engine's exact-match ROC sweep in the column layout the reference's plotting code reads from
+    `rtg vcfeval` (scripts/caller_performance_compare.R:329-340: score, TP_baseline, FP, TP_call, FN,
+    Precision, Recall, F1; '#' comment lines; gzip when the path ends in .gz).  The VALUES are a
+    build-defined quantity -- exact (pos, ref, alt) matching, not RTG's haplotype-aware matching -- and
+    equal the reference's own tp/fp split at score 20 only."""
+    import gzip
+    n_bins = roc.shape[1]
+    lines = ["#Version qmvt exact-match ROC (not rtg vcfeval), baseline = distinct single-base truth keys",
+             "#total baseline variants: %d" % int(truth_unique),
+             "#score field: QUAL",
+             "#score\ttrue_positives_baseline\tfalse_positives\ttrue_positives_call\tfalse_negatives\tprecision\tsensitivity\tf_measure"]
+    for t in range(n_bins - 1, -1, -1):
+        tp_call, fp, tp_base = int(roc[0, t]), int(roc[1, t]), int(roc[2, t])
+        if tp_call + fp == 0:
+            continue
+        fn = int(truth_unique) - tp_base
+        prec = tp_call / (tp_call + fp)
+        sens = tp_base / truth_unique if truth_unique else 0.0
+        f1 = 2 * prec * sens / (prec + sens) if prec + sens > 0 else 0.0
+        lines.append("%d\t%d\t%d\t%d\t%d\t%.4f\t%.4f\t%.4f" % (t, tp_base, fp, tp_call, fn, prec, sens, f1))
+    data = ("\n".join(lines) + "\n").encode()
+    opener = gzip.open if str(path).endswith(".gz") else open
+    with opener(path, "wb") as fh:
+        fh.write(data)

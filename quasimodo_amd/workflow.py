@@ -12,7 +12,7 @@ import shutil
 
 from .engine import Engine
 from .extract import Job, extract_many, is_pure_strain
-from .tables import write_caller_performance, write_fp_overlap, write_snpcall_benchmark
+from .tables import write_caller_performance, write_fp_overlap, write_snpcall_benchmark, write_weighted_roc
 from .vcfio import scan_vcf
 
 SAMPLE_REF = {  # rules/load_config.smk:20-23
@@ -85,6 +85,11 @@ def run_hcmv_variantcall(data_dir, outpath, callers=None, engine=None, dryrun=Fa
         os.makedirs(os.path.join(results, "final_tables"), exist_ok=True)
         write_caller_performance(os.path.join(results, "final_tables", "caller_performance.tsv"),
                                  [(c, s, j.stats) for (c, s), j in zip(meta, jobs)])
+        for (c, smp), j in zip(meta, jobs):                              # exact-match ROC where rules/vis_eval_vcf.smk puts RTG's
+            if not j.stats.get("pure_strain") and j.stats.get("roc") is not None:
+                d = os.path.join(snp_dir, "rtg", c, "%s.%s.xsnp" % (smp, SAMPLE_REF[smp]))
+                os.makedirs(d, exist_ok=True)
+                write_weighted_roc(os.path.join(d, "weighted_roc.tsv.gz"), j.stats["roc"], j.stats["truth_unique"])
         mixed = [s for s in samples if not s.endswith(("-1-0", "-0-1"))]
         cmp_callers = [c for c in FP_COMPARED if c in callers]
         if mixed and len(cmp_callers) >= 2:                              # compareFP (counts only)

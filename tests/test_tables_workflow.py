@@ -39,6 +39,19 @@ def test_table_files(qmlib, tmp_path):
     assert p3.read_text().splitlines()[1:] == ["TA-1-1\tLoFreq\t3", "TA-1-1\tCLC\t2", "TA-1-1\tLoFreq&CLC\t1"]
 
 
+def test_weighted_roc_layout(qmlib, tmp_path):
+    import gzip
+    from quasimodo_amd.tables import write_weighted_roc
+    roc = np.zeros((3, 256), np.uint64)
+    roc[0, :31] = 4; roc[1, :31] = 6; roc[2, :31] = 3        # 4 TP lines, 6 FP lines, 3 distinct truth keys, all with QUAL 30
+    roc[0, :11] = 5; roc[1, :11] = 9; roc[2, :11] = 4        # below 11: one more of each
+    p = tmp_path / "weighted_roc.tsv.gz"
+    write_weighted_roc(str(p), roc, 8)
+    rows = [ln.split("\t") for ln in gzip.open(p, "rt").read().splitlines() if not ln.startswith("#")]
+    assert rows[0] == ["30", "3", "6", "4", "5", "0.4000", "0.3750", "0.3871"]
+    assert rows[-1][:5] == ["0", "4", "9", "5", "4"] and len(rows) == 31
+
+
 def test_lpt_shards(qmlib):
     from quasimodo_amd.sharding import lpt_shards
     n = [10, 1, 1, 1, 9, 8, 2, 2]
@@ -93,6 +106,14 @@ def test_hcmv_variantcall_workflow(engine, oracle, tmp_path):
             assert row[2:6] == ["0", str(rc["calleridentify"]), "0", str(rc["calleridentify"])] and row[6:] == ["0", "NA", "NA"]
         else:
             assert row[2:6] == [str(rc["genomediff"]), str(rc["calleridentify"]), str(rc["TP"]), str(rc["FP"])]
+    # the exact-match ROC in RTG's file layout: its score-20 row is the reference's tp/fp split
+    import gzip
+    e = cases["TA-1-10.AD169.lofreq.vcf"]
+    _, _, exp = read_case(e)
+    rocf = results / "snp" / "rtg" / "lofreq" / "TA-1-10.AD169.xsnp" / "weighted_roc.tsv.gz"
+    r20 = [ln.split("\t") for ln in gzip.open(rocf, "rt").read().splitlines() if ln.startswith("20\t")][0]
+    nd = lambda b: sum(1 for ln in b.split(b"\n") if ln and not ln.startswith(b"#"))
+    assert int(r20[3]) == nd(exp["tp"]) and int(r20[2]) == nd(exp["fp"])
     # FP overlap regions against the oracle's restatement of snpcaller_fp_compare.R
     table = (results / "final_tables" / "snpcaller_fp_snp_compare.txt").read_text().splitlines()[1:]
     got = {}
