@@ -181,6 +181,35 @@ def test_config4_shape_ten_million_record_vcfs(engine, oracle):
         b.close()
 
 
+def test_config5_shape_mixed_snp_indel_three_truth_sets(engine, oracle):
+    """BASELINE configs[4] under the reference's semantics: 70 % SNP / 30 % indel records, three truth sets
+    (VCF v uses truth v mod 3).  The reference drops every indel at the A2 filter
+    (extract_TP_FP_SNPs.py:24), so records whose alleles are not single bases are neither kept nor matched;
+    matching variable-length alleles would be a build-defined extension and is not built."""
+    rng = np.random.default_rng(55)
+    L = 300000
+    truths = [random_truth(rng, 6000, L) for _ in range(3)]
+    tids = [engine.truth_load(*t) for t in truths]
+    cols, which = [], []
+    for v in range(9):
+        w = v % 3
+        c = list(random_columns(rng, 20000 + 3000 * v, L, truths[w], weird=False))
+        indel = rng.random(len(c[0])) < 0.3
+        c[2] = np.where(indel, rng.integers(4, 1 << 20, len(c[0])), c[2]).astype(np.int32)   # allele-pool style codes
+        c[1] = np.where(indel & (rng.random(len(c[0])) < 0.5), rng.integers(4, 1 << 20, len(c[0])), c[1]).astype(np.int32)
+        snp = (c[1] < 4) & (c[2] < 4)
+        c[4] = ((snp & (np.floor(c[3]) >= 20)).astype(np.uint8) | 2).astype(np.uint8)
+        cols.append(tuple(c))
+        which.append(w)
+    res, glob = engine.classify_batch(cols, [tids[w] for w in which])
+    for r, c, w in zip(res, cols, which):
+        check_vcf(oracle, r, c, truths[w], expect_sorted=True)
+        assert not np.any(r["cls"][(c[1] >= 4) | (c[2] >= 4)])            # indel rows are in no output file
+    for w in range(3):
+        want = sum((r["roc"] for r, ww in zip(res, which) if ww == w), np.zeros((3, 256), np.uint64))
+        assert np.array_equal(glob[tids[w]], want)
+
+
 def test_fp_overlap_vs_sets(engine):
     rng = np.random.default_rng(23)
     sets = []
