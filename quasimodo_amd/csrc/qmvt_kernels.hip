@@ -185,8 +185,10 @@ constexpr int L_SRF = L_SMAX + 2 * K1_SLICE;            // [2][K1_SLICE / 32] pe
 constexpr int L_RKEY = L_SRF + 2 * (K1_SLICE / 32);     // [256] record keys of the round (16-byte aligned)
 constexpr int L_RINF = L_RKEY + 256;                    // [128] record infos, u16 each
 constexpr int L_HITS = L_RINF + 128;                    // [8] one bit per record of the round: matched a truth key
-constexpr int L_TOTAL = L_HITS + 8;
+constexpr int L_MASK = L_HITS + 8;                        // [2][32] the tile's kept / TP mask words, stored once per tile
+constexpr int L_TOTAL = L_MASK + 64;
 static_assert(L_RKEY % 4 == 0 && L_RINF % 2 == 0, "b128 / b64 LDS stores need natural alignment");
+static_assert(K1_ROUNDS == 4, "one store covers the 32 + 32 mask words of a four-round tile");
 static_assert(K1_ROUNDS >= 3 && K1_SLICE % 64 == 0, "the next tile's slice is fetched over rounds 0..2 of the current one");
 
 struct Slice {
@@ -372,7 +374,7 @@ __device__ __forceinline__ uint32_t or_reduce8(uint32_t v) {
 // prev_last = position of the record before the round (INT32_MIN at the VCF start).
 template <bool PACKED>
 __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, const In4& X, int rbase, int te, int prev_last, int nb,
-                                               int ablate, uint32_t* mpass32, uint32_t* mtp32, Acc& A, int lane) {
+                                               int ablate, int mslot, Acc& A, int lane) {
   const uint32_t hit = (lds[L_HITS + (lane >> 3)] >> (4 * (lane & 7))) & 15u;
   uint32_t pass = 0, iddot = 0, anyinf = 0;
 #pragma unroll
@@ -388,14 +390,14 @@ __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, con
   A.n_pass += (uint32_t)__popc(pass);
   A.n_tp += (uint32_t)__popc(tp);
   A.fpr += (uint32_t)__popc(fpkey);
-  // natural-order mask words: 8 lanes x 4 records = one 32-bit word
+  // natural-order mask words: 8 lanes x 4 records = one 32-bit word; parked in LDS, the tile stores them at once
   if (!(ablate & 4)) {
     const uint32_t sh = 4u * (uint32_t)(lane & 7);
     const uint32_t wp = or_reduce8(pass << sh);
     const uint32_t wt = or_reduce8(tp << sh);
     if ((lane & 7) == 7) {
-      mpass32[(rbase >> 5) + (lane >> 3)] = wp;
-      mtp32[(rbase >> 5) + (lane >> 3)] = wt;
+      lds[L_MASK + mslot + (lane >> 3)] = wp;
+      lds[L_MASK + 32 + mslot + (lane >> 3)] = wt;
     }
   }
   int pp = __shfl_up((int)(X.key[3] >> 4), 1);
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
         }
       }
       __syncthreads();
-      classify_round<PACKED>(lds, C, X, rbase, te, prev_last, nb, ablate, mpass32, mtp32, A, lane);
+      classify_round<PACKED>(lds, C, X, rbase, te, prev_last, nb, ablate, 8 * r, A, lane);
       prev_last = (int)(lds[L_RKEY + 255] >> 4);
       __syncthreads();
     }
@@ -571,6 +573,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
       if (B.nextp == B.b && owns_b) continue_run<PACKED>(C, lds, S, te, vn, B.b, nb, lane);
       __syncthreads();
       acc_tpr += flush_slice(lds, S, lane);
+    }
+    if (!(ablate & 4)) {   // the tile's 32 + 32 mask words leave with one store: lanes 0..31 kept, 32..63 TP
+      const int w = lane & 31;
+      if (w < 8 * nrounds) {
+        uint32_t* dst = (lane < 32 ? mpass32 : mtp32) + (tb >> 5) + w;
+        *dst = lds[L_MASK + lane];
+      }
     }
     {
       const uint32_t tile_np = wave_sum(A.n_pass), tile_nt = wave_sum(A.n_tp);
