@@ -164,7 +164,8 @@ int qm_fp_overlap(qm_ctx* ctx, int n_sets, const int64_t* set_offsets, const int
  * every line of the text (header lines included), its byte offset; for data
  * lines the packed columns.  Returns the number of lines, or a negative code.
  * line_kind: 0 = data, 1 = header ('#'), 2 = data line the engine refuses in
- * strict mode (QM_E_NONCANON reasons).                        */
+ * strict mode (QM_E_NONCANON reasons), 3 = header line that also
+ * satisfies the A2 filter (awk would emit it as data too; refused in strict mode). */
 typedef struct qm_vcf_cols {
   int64_t n_lines;      /* all lines */
   int64_t n_data;       /* data lines = records */

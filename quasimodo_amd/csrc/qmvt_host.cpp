@@ -179,7 +179,17 @@ static void scan_chunk(const uint8_t* text, ScanChunk& c, bool count_only, int64
       const int64_t gl = c.l0 + nl, gd = c.d0 + nd;
       line_off[gl] = (int64_t)off;
       if (header) {
-        line_kind[gl] = 1;
+        // awk does not skip '#': a header line that also satisfies the A2 filter is emitted twice by the
+        // reference (once by grep, once by awk) while R's read.table ignores it -- refuse to guess (kind 3)
+        uint8_t kind = 1;
+        const int nf = split_tabs(s, n, f, MAXF);
+        if (nf >= 5 && acgt1(f[3]) && acgt1(f[4])) {
+          bool ge20 = false;
+          const Span empty = {(const uint8_t*)"", 0};
+          (void)effective_qual(nf > 5 ? f[5] : empty, &ge20);
+          if (ge20) { kind = 3; ++c.nnc; if (!c.first_nc) c.first_nc = gl + 1; }
+        }
+        line_kind[gl] = kind;
       } else {
         uint8_t kind = 0;
         int nf = split_tabs(s, n, f, MAXF);
@@ -354,10 +364,10 @@ extern "C" int qm_vcf_write(const char* path, const uint8_t* text, size_t len, i
   };
   bool ok = true;
   for (int64_t i = 0; i < n_lines && ok; ++i)
-    if (line_kind[i] == 1) ok = put_line(i);
+    if (line_kind[i] == 1 || line_kind[i] == 3) ok = put_line(i);
   int64_t r = 0;
   for (int64_t i = 0; i < n_lines && ok; ++i) {
-    if (line_kind[i] == 1) continue;
+    if (line_kind[i] == 1 || line_kind[i] == 3) continue;
     const uint8_t c = cls ? cls[r] : 0;
     ++r;
     const bool sel = select == 0 ? (c & QM_CLS_KEPT) : select == 1 ? ((c & 3u) == 3u) : ((c & 3u) == 1u);

@@ -21,7 +21,7 @@ class ScannedVcf:
     text: bytes
     n_lines: int
     line_off: np.ndarray   # int64 [n_lines + 1]
-    line_kind: np.ndarray  # uint8 [n_lines]: 0 data, 1 header, 2 data (non-canonical, strict mode refuses)
+    line_kind: np.ndarray  # uint8 [n_lines]: 0 data, 1 header, 2 data (non-canonical), 3 header that also passes the A2 filter (2 and 3: strict mode refuses)
     pos: np.ndarray
     ref: np.ndarray
     alt: np.ndarray

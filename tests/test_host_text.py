@@ -154,3 +154,66 @@ def test_truth_scan_modes(qmlib):
     tk = scan_truth(s, custom=True)
     assert list(tk.pos) == [10, 13] and list(tk.ref) == [0, 1] and list(tk.alt) == [2, 3]
     assert tk.genomediff == 3 and tk.n_never == 2     # 'N' row and the empty line's pattern
+
+
+def _random_case(rng):
+    """Hostile but ASCII VCF / truth texts (same generator family as make_golden.py --fuzz)."""
+    fields = ["A", "C", "G", "T", ".", "N", "a", "AC", "A,C", "", "PASS", "20", "19", "30", "5", "1e2", "0x14", "rs1", "-",
+              "5_", "x.y", " 20", "20 ", "2e-400", "7\r", "100", "10", "1", "19.9999999", "20.0000001", "1e400", "+20", "nan"]
+    npos = int(rng.integers(1, 40))
+
+    def line(ncol_max=10):
+        nc = int(rng.integers(1, ncol_max + 1))
+        cols = []
+        for c in range(nc):
+            u = rng.random()
+            if c == 1 and u < 0.985:
+                cols.append(str(int(rng.integers(1, npos + 1))))
+            elif c == 2 and u < 0.7:
+                cols.append(".")
+            elif c in (3, 4) and u < 0.85:
+                cols.append("ACGT"[int(rng.integers(0, 4))])
+            elif c == 5 and u < 0.6:
+                cols.append(str(int(rng.integers(0, 60))))
+            else:
+                cols.append(fields[int(rng.integers(0, len(fields)))])
+        return "\t".join(cols)
+
+    v = [("##" + line()) if rng.random() < 0.1 else line() for _ in range(int(rng.integers(0, 80)))]
+    vtxt = "\n".join(v) + ("\n" if rng.random() < 0.8 else "")
+    custom = bool(rng.random() < 0.4)
+    t = []
+    for _ in range(int(rng.integers(0, 30))):
+        if custom:
+            t.append("\t".join([str(int(rng.integers(1, npos + 1))), "ACGT.N"[int(rng.integers(0, 6))], "ACGT.N"[int(rng.integers(0, 6))]] + ["x"] * 9))
+        else:
+            t.append(line(8))
+    ttxt = "\n".join(t) + ("\n" if t else "")
+    return vtxt.encode("latin1"), ttxt.encode("latin1"), custom
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_columns_equal_text_semantics_on_random_inputs(qmlib, oracle, tmp_path, seed):
+    """Property: for every input the engine accepts in strict mode, packing to columns, classifying the
+    columns (oracle as checker) and writing back gives exactly the text-level result, which is pinned to
+    the reference by the golden vectors and the live fuzz of make_golden.py."""
+    from quasimodo_amd import scan_truth, scan_vcf
+    rng = np.random.default_rng(9000 + seed)
+    checked = 0
+    for _ in range(60):
+        vcf, truth, custom = _random_case(rng)
+        sv = scan_vcf(vcf)
+        tk = scan_truth(truth, custom=custom)
+        f, tp, fp, _ = oracle.extract_text(vcf, truth, custom=custom, pure_strain=False)
+        out = tmp_path / "o.vcf"
+        if sv.n_noncanon or tk.n_refused:
+            continue                                        # refused in strict mode: nothing is claimed
+        sv.write(str(out), (sv.flags & 1).astype(np.uint8), 0)
+        assert out.read_bytes() == f
+        cls, _, _ = oracle.classify_columns(*sv.columns, tk.pos, tk.ref, tk.alt)
+        sv.write(str(out), cls, 1)
+        assert out.read_bytes() == tp
+        sv.write(str(out), cls, 2)
+        assert out.read_bytes() == fp
+        checked += 1
+    assert checked >= 20
