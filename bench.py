@@ -73,6 +73,17 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    # The HIP library is built in-tree and travels with the snapshot; if it is missing (fresh checkout)
+    # local rank 0 compiles it with hipcc and the others wait for it.  No other implementation exists.
+    if not os.path.exists(q.library_path()):
+        if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+            q.build_library()
+        else:
+            for _ in range(600):
+                if os.path.exists(q.library_path()):
+                    break
+                time.sleep(0.5)
+            time.sleep(1.0)
     eng = q.Engine(local_rank)
     tseed = 3
     tid = eng.truth_synth(args.genome, args.truth, tseed)
