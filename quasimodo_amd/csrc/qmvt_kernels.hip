@@ -270,18 +270,19 @@ __device__ __forceinline__ void join_round(uint32_t* lds, const Slice& S, int nr
     if (j < rhi) {
       const uint32_t kkey = lds[S.keys + j];
       const uint32_t kpos = kkey >> 4;
+      const uint32_t kfloor = kkey & ~15u;   // smallest key at this position: (rk >> 4) < kpos  <=>  rk < kfloor
       // first staged record with position >= kpos
       int s = 0;
 #pragma unroll
       for (int step = 128; step > 0; step >>= 1) {
         const int idx = s + step;
-        if ((lds[L_RKEY + idx - 1] >> 4) < kpos) s = idx;   // idx - 1 <= 254
+        if (lds[L_RKEY + idx - 1] < kfloor) s = idx;   // idx - 1 <= 254
       }
-      if (s < 256 && (lds[L_RKEY + s] >> 4) < kpos) s += 1;   // s == 255 still below
+      if (s < 256 && lds[L_RKEY + s] < kfloor) s += 1;   // s == 255 still below
       uint32_t mx = 0, rf = 0;
       for (; s < nrec; ++s) {   // the run of records at this position
         const uint32_t rk = lds[L_RKEY + s];
-        if ((rk >> 4) != kpos) break;
+        if ((rk & ~15u) != kfloor) break;
         if (rk != kkey) continue;
         const uint32_t inf = (lds[L_RINF + (s >> 1)] >> (16 * (s & 1))) & 0xffffu;
         if ((inf & (I_LIVE | I_NOKEY)) != I_LIVE) continue;
