@@ -186,6 +186,12 @@ int64_t qm_truth_scan(const uint8_t* text, size_t len, int mode, int64_t cap, in
  * (SURVEY Q7).  select: 0 = kept (filtered.vcf), 1 = TP, 2 = FP. */
 int qm_vcf_write(const char* path, const uint8_t* text, size_t len, int64_t n_lines, const int64_t* line_off,
                  const uint8_t* line_kind, const uint8_t* cls /*per data line*/, int select);
+/* SNP / indel splitters of rules/vis_eval_vcf.smk:35,50,66,81 (`extract_snp`, `extract_indel`,
+ * `extract_nucmer_snp`, `extract_nucmer_indel`): every '#' line, plus every line whose REF/ALT
+ * satisfy the rule's awk pattern, in input order ('#' lines that also satisfy it appear twice,
+ * as awk prints them).  mode 0 = xsnp, 1 = xindel.  flavour 0 reads `{2,}` as a POSIX interval
+ * (gawk), flavour 1 as literal text (mawk 1.3.4 20200120).  Atomic (temp file + rename). */
+int qm_vcf_split_write(const char* path, const uint8_t* text, size_t len, int mode, int flavour, int64_t* n_written);
 
 #ifdef __cplusplus
 }

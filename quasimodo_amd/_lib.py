@@ -18,7 +18,7 @@ EXPORTS = (
     "qm_classify_batch", "qm_batch_create", "qm_batch_destroy", "qm_batch_upload", "qm_truth_synth", "qm_batch_synth",
     "qm_batch_run", "qm_batch_finish", "qm_batch_set_timing", "qm_batch_timings", "qm_batch_get_cls", "qm_batch_get_idx",
     "qm_batch_get_roc", "qm_batch_get_scalars", "qm_batch_get_global", "qm_batch_get_columns", "qm_batch_device_bytes",
-    "qm_fp_overlap", "qm_vcf_count_lines", "qm_vcf_scan", "qm_truth_scan", "qm_vcf_write",
+    "qm_fp_overlap", "qm_vcf_count_lines", "qm_vcf_scan", "qm_truth_scan", "qm_vcf_write", "qm_vcf_split_write",
 )
 
 
@@ -100,6 +100,7 @@ def lib():
     L.qm_truth_scan.argtypes = [C.c_char_p, C.c_size_t, i32, i64, vp, vp, vp, vp]
     L.qm_truth_scan.restype = i64
     L.qm_vcf_write.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, i64, vp, vp, vp, i32]
+    L.qm_vcf_split_write.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, i32, i32, C.POINTER(C.c_int64)]
     _lib = L
     return L
 

@@ -379,3 +379,63 @@ extern "C" int qm_vcf_write(const char* path, const uint8_t* text, size_t len, i
   if (rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return QM_E_IO; }
   return QM_OK;
 }
+
+// ---------------------------------------------------------------------------
+// SNP / indel splitters (rules/vis_eval_vcf.smk:35,50,66,81): awk programs with two rules,
+//   /^#.*/{print}   and   <allele pattern>     (no `next`, so a '#' line that also satisfies
+// the allele pattern is printed twice), output in input order.
+//   mode 0 (xsnp):   $4 ~ /^[actgACTG]$/ && $5 ~ /^[actgACTG]$/
+//   mode 1 (xindel): $4 ~ /^[actgACTG]{2,}/ || $5 ~ /^[actgACTG]{2,}/
+// flavour 0: `{2,}` is a POSIX interval (gawk, mawk >= 1.3.4-2020xxxx built with repetitions);
+// flavour 1: `{2,}` is the literal text (mawk 1.3.4 20200120, the awk of the build image).
+// ---------------------------------------------------------------------------
+static inline bool base8(uint8_t c) {
+  switch (c) { case 'a': case 'c': case 't': case 'g': case 'A': case 'C': case 'T': case 'G': return true; default: return false; }
+}
+static inline bool indel_field(const uint8_t* f, size_t n, int flavour) {
+  if (flavour == 0) return n >= 2 && base8(f[0]) && base8(f[1]);
+  return n >= 5 && base8(f[0]) && f[1] == '{' && f[2] == '2' && f[3] == ',' && f[4] == '}';
+}
+
+extern "C" int qm_vcf_split_write(const char* path, const uint8_t* text, size_t len, int mode, int flavour, int64_t* n_written) {
+  if (!path || (!text && len) || mode < 0 || mode > 1 || flavour < 0 || flavour > 1) return QM_E_INVAL;
+  const std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid());
+  FILE* fh = fopen(tmp.c_str(), "wb");
+  if (!fh) return QM_E_IO;
+  std::vector<char> buf;
+  buf.reserve(1 << 20);
+  bool ok = true;
+  int64_t nw = 0;
+  size_t b = 0;
+  while (b < len && ok) {
+    const uint8_t* nl = (const uint8_t*)memchr(text + b, '\n', len - b);
+    const size_t e = nl ? (size_t)(nl - text) : len;
+    // fields 4 and 5 of the tab-split record
+    const uint8_t* f[2] = {nullptr, nullptr};
+    size_t fl[2] = {0, 0};
+    size_t q = b;
+    for (int k = 1; k <= 5 && q <= e; ++k) {
+      const uint8_t* t = (q < e) ? (const uint8_t*)memchr(text + q, '\t', e - q) : nullptr;
+      const size_t fe = t ? (size_t)(t - text) : e;
+      if (k >= 4) { f[k - 4] = text + q; fl[k - 4] = fe - q; }
+      if (!t) break;
+      q = fe + 1;
+    }
+    int times = (e > b && text[b] == '#') ? 1 : 0;
+    if (mode == 0) times += (fl[0] == 1 && base8(f[0][0]) && fl[1] == 1 && base8(f[1][0])) ? 1 : 0;
+    else times += ((f[0] && indel_field(f[0], fl[0], flavour)) || (f[1] && indel_field(f[1], fl[1], flavour))) ? 1 : 0;
+    for (int t = 0; t < times; ++t) {
+      buf.insert(buf.end(), (const char*)text + b, (const char*)text + e);
+      buf.push_back('\n');
+      ++nw;
+    }
+    if (buf.size() >= (1u << 20)) { ok = fwrite(buf.data(), 1, buf.size(), fh) == buf.size(); buf.clear(); }
+    b = e + 1;
+  }
+  if (ok && !buf.empty()) ok = fwrite(buf.data(), 1, buf.size(), fh) == buf.size();
+  ok = (fclose(fh) == 0) && ok;
+  if (!ok) { remove(tmp.c_str()); return QM_E_IO; }
+  if (rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return QM_E_IO; }
+  if (n_written) *n_written = nw;
+  return QM_OK;
+}

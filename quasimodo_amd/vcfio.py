@@ -88,3 +88,30 @@ def scan_truth(text: bytes, custom: bool = False) -> TruthKeys:
     if n < 0:
         raise QmvtError(n, "qm_truth_scan failed")
     return TruthKeys(pos[:n].copy(), ref[:n].copy(), alt[:n].copy(), int(counts[0]), int(counts[2]), int(counts[3]))
+
+
+AWK_POSIX, AWK_MAWK_LITERAL = 0, 1
+
+
+def awk_flavour_default() -> int:
+    """`{2,}` in the xindel rule: POSIX interval unless QM_AWK_FLAVOUR=mawk-literal
+    (mawk 1.3.4 20200120 reads the braces as text)."""
+    v = os.environ.get("QM_AWK_FLAVOUR", "posix")
+    if v not in ("posix", "mawk-literal"):
+        raise ValueError("QM_AWK_FLAVOUR must be posix or mawk-literal, not %r" % v)
+    return AWK_MAWK_LITERAL if v == "mawk-literal" else AWK_POSIX
+
+
+def split_variants(vcf_path, out_path, kind, flavour=None) -> int:
+    """`extract_snp` / `extract_indel` / `extract_nucmer_*` (rules/vis_eval_vcf.smk:25-86) without
+    awk: kind "xsnp" or "xindel"; returns the number of lines written."""
+    if kind not in ("xsnp", "xindel"):
+        raise ValueError("kind must be xsnp or xindel")
+    with open(vcf_path, "rb") as fh:
+        text = fh.read()
+    n = C.c_int64(0)
+    rc = _lib.lib().qm_vcf_split_write(os.fsencode(out_path), text, len(text), 0 if kind == "xsnp" else 1,
+                                       awk_flavour_default() if flavour is None else int(flavour), C.byref(n))
+    if rc < 0:
+        raise QmvtError(rc, "cannot write %s" % out_path)
+    return int(n.value)

@@ -77,6 +77,14 @@ def run_hcmv_variantcall(data_dir, outpath, callers=None, engine=None, dryrun=Fa
         shutil.copyfile(src, dst)
         jobs.append(Job(dst, os.path.join(snp_dir, "nucmer", "%s.maskrepeat.variants.vcf" % s[:2]), "hcmv", d, c))
         meta.append((c, s))
+    from .vcfio import split_variants
+    for kind in ("xsnp", "xindel"):                                      # extract_snp / extract_indel / extract_nucmer_*
+        for j in jobs:
+            split_variants(j.vcf_file, j.vcf_file[:-4] + ".%s.vcf" % kind, kind)
+        for mix in ("TM", "TA"):
+            t = os.path.join(snp_dir, "nucmer", "%s.maskrepeat.variants.vcf" % mix)
+            if os.path.exists(t):
+                split_variants(t, os.path.join(snp_dir, "nucmer", "%s.maskrepeat.%s.vcf" % (mix, kind)), kind)
     own = engine is None
     if own:
         engine = Engine(int(os.environ.get("QM_DEVICE", "0")))

@@ -217,3 +217,41 @@ def test_columns_equal_text_semantics_on_random_inputs(qmlib, oracle, tmp_path, 
         assert out.read_bytes() == fp
         checked += 1
     assert checked >= 20
+
+
+# ---- SNP / indel splitters (rules/vis_eval_vcf.smk:25-86) ------------------------------------
+def _split_cases():
+    import json
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    return [(g, c) for c in json.load(open(os.path.join(g, "split", "manifest.json")))["cases"]]
+
+
+@pytest.mark.parametrize("g,c", _split_cases(), ids=lambda x: x["expected"].split("/")[-1] if isinstance(x, dict) else "")
+def test_splitter_equals_awk_output(qmlib, tmp_path, g, c):
+    """golden = this image's awk (mawk 1.3.4: `{2,}` literal) run with the rule's program"""
+    from quasimodo_amd import vcfio
+    out = tmp_path / "o.vcf"
+    n = vcfio.split_variants(os.path.join(g, c["input"]), str(out), c["kind"], flavour=vcfio.AWK_MAWK_LITERAL)
+    exp = open(os.path.join(g, c["expected"]), "rb").read()
+    assert out.read_bytes() == exp
+    assert n == exp.count(b"\n")
+
+
+def test_splitter_posix_interval_flavour(qmlib, tmp_path):
+    """`{2,}` as an interval: REF or ALT *starting* with two bases (the pattern has no `$`), '#' lines
+    always, and twice when they satisfy the pattern themselves.  Hand-derived from the awk program."""
+    from quasimodo_amd import vcfio
+    g = os.path.join(os.path.dirname(__file__), "golden", "split", "input", "probe.vcf")
+    out = tmp_path / "o.vcf"
+    vcfio.split_variants(g, str(out), "xindel", flavour=vcfio.AWK_POSIX)
+    got = out.read_bytes().split(b"\n")
+    assert got[-1] == b""
+    pos = [ln.split(b"\t")[1] for ln in got[:-1] if not ln.startswith(b"#")]
+    assert pos == [b"12", b"13", b"18"]          # AC>G, A>GT, AC,G>T ; G,T / A{2,} / c{2,}TT do not start with two bases
+    assert [ln.split(b"\t")[0] for ln in got[:-1] if ln.startswith(b"#")] == [b"##fileformat=VCFv4.2", b"#CHROM", b"#mid", b"#mid2"]
+    # default flavour comes from QM_AWK_FLAVOUR and is POSIX
+    out2 = tmp_path / "o2.vcf"
+    vcfio.split_variants(g, str(out2), "xindel")
+    assert out2.read_bytes() == out.read_bytes()
+    with pytest.raises(ValueError):
+        vcfio.split_variants(g, str(out2), "snp")

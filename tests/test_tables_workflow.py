@@ -114,6 +114,12 @@ def test_hcmv_variantcall_workflow(engine, oracle, tmp_path):
     r20 = [ln.split("\t") for ln in gzip.open(rocf, "rt").read().splitlines() if ln.startswith("20\t")][0]
     nd = lambda b: sum(1 for ln in b.split(b"\n") if ln and not ln.startswith(b"#"))
     assert int(r20[3]) == nd(exp["tp"]) and int(r20[2]) == nd(exp["fp"])
+    # extract_snp / extract_indel / extract_nucmer_* outputs sit where rules/vis_eval_vcf.smk:25-86 put them
+    cdir = results / "snp" / "callers" / "lofreq"
+    xs = (cdir / "TA-1-10.AD169.lofreq.xsnp.vcf").read_bytes().split(b"\n")
+    assert all(ln.startswith(b"#") or (len(ln.split(b"\t")[3]) == 1 and len(ln.split(b"\t")[4]) == 1) for ln in xs if ln)
+    assert (cdir / "TA-1-10.AD169.lofreq.xindel.vcf").exists()
+    assert (results / "snp" / "nucmer" / "TA.maskrepeat.xsnp.vcf").exists() and (results / "snp" / "nucmer" / "TA.maskrepeat.xindel.vcf").exists()
     # FP overlap regions against the oracle's restatement of snpcaller_fp_compare.R
     table = (results / "final_tables" / "snpcaller_fp_snp_compare.txt").read_text().splitlines()[1:]
     got = {}
