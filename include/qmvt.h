@@ -46,6 +46,25 @@ extern "C" {
 #define QM_E_STATE (-6)     /* call order violated */
 #define QM_E_IO (-7)
 #define QM_E_NONCANON (-8)  /* text input the engine refuses to guess about (strict mode) */
+#define QM_E_UNSORTED (-9)  /* allele-extended batch: a VCF is not position sorted */
+#define QM_E_LIMIT (-10)    /* allele-extended batch: too many records at one position */
+
+/* ---- allele-extended mode (QM_BATCH_ALLELES) ---------------------------------------------
+ * BASELINE.json configs[4] (mixed SNP + indel, variable-length alleles).  The reference drops
+ * every non-single-base record at its A2 filter, so this mode is a build-defined widening and is
+ * OFF by default: `$4~/^[ACGT]$/&&$5~/^[ACGT]$/` becomes `$4~/^[ACGT]+$/&&$5~/^[ACGT]+$/`, in the
+ * caller filter and in the truth pattern list alike; everything else (ID == ".", QUAL clause,
+ * line / unique-key counts, ROC) is unchanged, and records with single-base alleles are
+ * classified exactly as without the mode.
+ * Allele codes (ref / alt columns, int32): two alleles are the same string iff their codes are equal.
+ *   0..3                          one base A,C,G,T
+ *   len << 26 | bases             2..13 bases inline: base k (0-based, A=0 C=1 G=2 T=3) in bits 2k+1..2k
+ *   0x40000000 | id               longer alleles: id from a qm_dict (interned strings)
+ *   negative, or 4..0x07ffffff    not an allele that takes part (as without the mode) */
+#define QM_BATCH_ALLELES 1u
+#define QM_ALLELE_NONE (-1)
+#define QM_ALLELE_INLINE_MAX 13
+#define QM_ALLELE_DICT 0x40000000
 
 #define QM_F_PASS 1u
 #define QM_F_IDDOT 2u
@@ -90,6 +109,8 @@ const char* qm_last_error(qm_ctx* ctx);
 int qm_truth_load(qm_ctx* ctx, const int32_t* pos, const int32_t* ref, const int32_t* alt, int64_t n,
                   int* truth_id);
 int qm_truth_size(qm_ctx* ctx, int truth_id, int64_t* n_unique);
+/* distinct valid (pos, ref, alt) entries of any allele length: T' of allele-extended batches */
+int qm_truth_size_ext(qm_ctx* ctx, int truth_id, int64_t* n_unique);
 int qm_truth_count(qm_ctx* ctx);
 
 /* ---- one-shot, host buffers -------------------------------------------------
@@ -107,10 +128,18 @@ int qm_classify_batch(qm_ctx* ctx, int n_vcf, const int64_t* rec_offsets, const 
                       const int32_t* ref, const int32_t* alt, const float* qual, const uint8_t* flags,
                       const int32_t* truth_id_per_vcf, int n_bins, uint8_t* out_cls, uint64_t* out_roc,
                       int64_t* out_scalars, int32_t* out_idx, uint64_t* out_global);
+/* The same with a batch mode (0 or QM_BATCH_ALLELES).  Allele-extended batches take position-sorted
+ * VCFs only (QM_E_UNSORTED otherwise). */
+int qm_classify_batch_ext(qm_ctx* ctx, int n_vcf, const int64_t* rec_offsets, const int32_t* pos,
+                          const int32_t* ref, const int32_t* alt, const float* qual, const uint8_t* flags,
+                          const int32_t* truth_id_per_vcf, int n_bins, unsigned mode, uint8_t* out_cls,
+                          uint64_t* out_roc, int64_t* out_scalars, int32_t* out_idx, uint64_t* out_global);
 
 /* ---- resident batches (columns live in HBM across runs) -------------------- */
 int qm_batch_create(qm_ctx* ctx, int n_vcf, const int64_t* n_records, const int32_t* truth_id_per_vcf,
                     int n_bins, qm_batch** out);
+int qm_batch_create_ext(qm_ctx* ctx, int n_vcf, const int64_t* n_records, const int32_t* truth_id_per_vcf,
+                        int n_bins, unsigned mode, qm_batch** out);
 void qm_batch_destroy(qm_batch* b);
 int qm_batch_upload(qm_batch* b, int vcf, const int32_t* pos, const int32_t* ref, const int32_t* alt,
                     const float* qual, const uint8_t* flags);
@@ -121,11 +150,14 @@ typedef struct qm_synth_cfg {
   uint64_t truth_seed;  /* must equal the seed passed to qm_truth_synth        */
   int64_t truth_n;      /* T of that truth set                                  */
   int32_t shuffled;     /* 0 = position sorted, 1 = records permuted            */
-  int32_t reserved;
+  int32_t indel_pct;    /* 0 = single-base records only (configs 3/4); > 0: that share of the
+                           generated records / truth entries carries longer alleles (config 5;
+                           allele-extended batches only; must equal qm_truth_synth_ext's) */
 } qm_synth_cfg;
 /* Synthetic workload of BASELINE.json configs 3/4, generated on the device
  * (DESIGN.md "Synthetic generator").  Every VCF of the batch is filled. */
 int qm_truth_synth(qm_ctx* ctx, int64_t genome_len, int64_t truth_n, uint64_t truth_seed, int* truth_id);
+int qm_truth_synth_ext(qm_ctx* ctx, int64_t genome_len, int64_t truth_n, uint64_t truth_seed, int indel_pct, int* truth_id);
 int qm_batch_synth(qm_batch* b, const qm_synth_cfg* cfg);
 
 /* Enqueue the whole path on `stream` (a hipStream_t; NULL = the context's own

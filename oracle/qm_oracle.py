@@ -44,6 +44,7 @@ def lib():
         L.qmo_qual_bin.argtypes = [C.c_float, C.c_int]
         vp = C.c_void_p
         L.qmo_classify_columns.argtypes = [C.c_int64, vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, C.c_int, vp, vp, vp]
+        L.qmo_classify_columns_ext.argtypes = L.qmo_classify_columns.argtypes
         _lib = L
     return _lib
 
@@ -97,7 +98,8 @@ def caller_filter(line: bytes):
     return bool(lib().qmo_caller_filter(line, len(line)))
 
 
-def classify_columns(pos, ref, alt, qual, flags, tpos, tref, talt, n_bins=256):
+def classify_columns(pos, ref, alt, qual, flags, tpos, tref, talt, n_bins=256, ext=False):
+    """ext: allele-extended mode (any valid allele code takes part, not only 0..3)."""
     L = lib()
     pos = np.ascontiguousarray(pos, np.int32); ref = np.ascontiguousarray(ref, np.int32)
     alt = np.ascontiguousarray(alt, np.int32); qual = np.ascontiguousarray(qual, np.float32)
@@ -109,7 +111,7 @@ def classify_columns(pos, ref, alt, qual, flags, tpos, tref, talt, n_bins=256):
     roc = np.zeros((3, n_bins), np.uint64)
     sc = np.zeros(8, np.int64)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    rc = L.qmo_classify_columns(n, p(pos), p(ref), p(alt), p(qual), p(flags), tpos.shape[0], p(tpos), p(tref), p(talt),
+    rc = (L.qmo_classify_columns_ext if ext else L.qmo_classify_columns)(n, p(pos), p(ref), p(alt), p(qual), p(flags), tpos.shape[0], p(tpos), p(tref), p(talt),
                                 n_bins, p(cls), p(roc), p(sc))
     if rc:
         raise ValueError("qmo_classify_columns rc=%d" % rc)

@@ -18,7 +18,30 @@ def hash3(seed, a, b):
     return mix64((s + a * np.uint64(0x9e3779b97f4a7c15) + b * np.uint64(0xc2b2ae3d27d4eb4f)) & _M)
 
 
-def synth_truth_keys(L, T, tseed):
+SYNTH_POOL = 1 << 20
+
+
+def synth_allele(h, minlen):
+    """qmvt_dev.h synth_allele: length minlen + Geom(0.5) capped at 32; <= 13 bases inline
+    (len << 26 | 2-bit bases), longer ones an id of the synthetic dictionary."""
+    with np.errstate(over="ignore"):
+        h = np.asarray(h, np.uint64)
+        ln = np.full(h.shape, minlen, np.int64)
+        g = h.copy()
+        alive = np.ones(h.shape, bool)
+        for _ in range(32):
+            alive &= (ln < 32) & ((g & np.uint64(1)) == np.uint64(1))
+            ln += alive
+            g = np.where(alive, g >> np.uint64(1), g)
+        bits = mix64(h ^ np.uint64(0xa11e1e5))
+        sh = np.minimum(2 * ln, 62).astype(np.uint64)
+        inline = (ln.astype(np.uint64) << np.uint64(26)) | (bits & ((np.uint64(1) << sh) - np.uint64(1)))
+        pool = np.uint64(0x40000000) | (bits % np.uint64(SYNTH_POOL))
+        out = np.where(ln == 1, bits & np.uint64(3), np.where(ln <= 13, inline, pool))
+    return out.astype(np.int64).astype(np.int32)
+
+
+def synth_truth_keys(L, T, tseed, indel_pct=0):
     with np.errstate(over="ignore"):
         j = np.arange(T, dtype=np.uint64)
         wt = np.uint64(L // T)
@@ -26,4 +49,27 @@ def synth_truth_keys(L, T, tseed):
         p = j * wt + np.uint64(1) + h % wt
         r = hash3(3, p, np.uint64(0)) & np.uint64(3)
         a = (r + np.uint64(1) + (h >> np.uint64(32)) % np.uint64(3)) & np.uint64(3)
+        r, a = r.astype(np.int32), a.astype(np.int32)
+        if indel_pct > 0:
+            ind = (hash3(tseed, j, np.uint64(2)) % np.uint64(100)).astype(np.int64) < indel_pct
+            r = np.where(ind, synth_allele(hash3(tseed, j, np.uint64(3)), 1), r)
+            a = np.where(ind, synth_allele(hash3(tseed, j, np.uint64(4)), 2), a)
     return p.astype(np.int32), r.astype(np.int32), a.astype(np.int32)
+
+
+def allele_string(code):
+    """Spelling of an allele code (include/qmvt.h).  Dictionary ids are spelled as the synthetic
+    dictionary defines them (14..32 bases from the id) -- only meaningful for generated data."""
+    code = int(code)
+    if 0 <= code < 4:
+        return "ACGT"[code]
+    if 0x08000000 <= code < 0x40000000:
+        ln = code >> 26
+        return "".join("ACGT"[(code >> (2 * k)) & 3] for k in range(ln))
+    if code >= 0x40000000:
+        i = code & 0x3fffffff
+        ln = 14 + i % 19
+        with np.errstate(over="ignore"):
+            w = [int(mix64(np.uint64(i * 2 + k))) for k in range(2)]
+        return "".join("ACGT"[(w[k // 32] >> (2 * (k % 32))) & 3] for k in range(ln))
+    raise ValueError("not an allele code: %d" % code)

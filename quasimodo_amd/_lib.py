@@ -10,7 +10,8 @@ _SO = os.environ.get("QM_LIBQMVT") or os.path.join(_CSRC, "libqmvt.so")   # over
 QM_N_SCALARS = 8
 SCALAR_NAMES = ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R", "sorted", "n_records", "truth_unique")
 ERRORS = {-1: "QM_E_INVAL", -2: "QM_E_NODEVICE", -3: "QM_E_HIP", -4: "QM_E_NOMEM", -5: "QM_E_RANGE",
-          -6: "QM_E_STATE", -7: "QM_E_IO", -8: "QM_E_NONCANON"}
+          -6: "QM_E_STATE", -7: "QM_E_IO", -8: "QM_E_NONCANON", -9: "QM_E_UNSORTED", -10: "QM_E_LIMIT"}
+QM_BATCH_ALLELES = 1
 
 # every symbol include/qmvt.h declares
 EXPORTS = (
@@ -19,6 +20,7 @@ EXPORTS = (
     "qm_batch_run", "qm_batch_finish", "qm_batch_set_timing", "qm_batch_timings", "qm_batch_get_cls", "qm_batch_get_idx",
     "qm_batch_get_roc", "qm_batch_get_scalars", "qm_batch_get_global", "qm_batch_get_columns", "qm_batch_device_bytes",
     "qm_fp_overlap", "qm_vcf_count_lines", "qm_vcf_scan", "qm_truth_scan", "qm_vcf_write", "qm_vcf_split_write",
+    "qm_truth_size_ext", "qm_truth_synth_ext", "qm_batch_create_ext", "qm_classify_batch_ext",
 )
 
 
@@ -30,7 +32,7 @@ class QmvtError(RuntimeError):
 
 class SynthCfg(C.Structure):
     _fields_ = [("genome_len", C.c_int64), ("seed", C.c_uint64), ("truth_seed", C.c_uint64), ("truth_n", C.c_int64),
-                ("shuffled", C.c_int32), ("reserved", C.c_int32)]
+                ("shuffled", C.c_int32), ("indel_pct", C.c_int32)]
 
 
 class VcfCols(C.Structure):
@@ -74,6 +76,10 @@ def lib():
     L.qm_truth_load.argtypes = [vp, vp, vp, vp, i64, C.POINTER(i32)]
     L.qm_truth_synth.argtypes = [vp, i64, i64, C.c_uint64, C.POINTER(i32)]
     L.qm_truth_size.argtypes = [vp, i32, C.POINTER(i64)]
+    L.qm_truth_size_ext.argtypes = [vp, i32, C.POINTER(i64)]
+    L.qm_truth_synth_ext.argtypes = [vp, i64, i64, C.c_uint64, i32, C.POINTER(i32)]
+    L.qm_batch_create_ext.argtypes = [vp, i32, vp, vp, i32, C.c_uint, C.POINTER(vp)]
+    L.qm_classify_batch_ext.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, C.c_uint, vp, vp, vp, vp, vp]
     L.qm_truth_count.argtypes = [vp]
     L.qm_classify_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     L.qm_batch_create.argtypes = [vp, i32, vp, vp, i32, C.POINTER(vp)]

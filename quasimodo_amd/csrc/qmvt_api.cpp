@@ -42,6 +42,11 @@ struct Truth {
   int32_t* d_tidx = nullptr;
   int32_t shift = 0, nb = 0;
   int64_t n = 0;
+  // allele-extended table (every valid entry, single-base ones included)
+  uint32_t* d_xkeys = nullptr;
+  int32_t *d_xref = nullptr, *d_xalt = nullptr, *d_xtidx = nullptr;
+  int32_t xshift = 0, xnb = 0;
+  int64_t xn = 0;
 };
 
 struct qm_ctx {
@@ -90,7 +95,10 @@ extern "C" int qm_init(int device_id, qm_ctx** out) {
 extern "C" void qm_destroy(qm_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->dev);
-  for (auto& t : c->truths) { (void)hipFree(t.d_keys); (void)hipFree(t.d_tidx); }
+  for (auto& t : c->truths) {
+    (void)hipFree(t.d_keys); (void)hipFree(t.d_tidx);
+    (void)hipFree(t.d_xkeys); (void)hipFree(t.d_xref); (void)hipFree(t.d_xalt); (void)hipFree(t.d_xtidx);
+  }
   (void)hipFree(c->d_truths);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -110,35 +118,70 @@ static int upload_truth_table(qm_ctx* c) {
   for (int i = 0; i < n; ++i) {
     h[i].keys = c->truths[i].d_keys; h[i].tidx = c->truths[i].d_tidx;
     h[i].shift = c->truths[i].shift; h[i].nb = c->truths[i].nb; h[i].n = c->truths[i].n;
+    h[i].xkeys = c->truths[i].d_xkeys; h[i].xref = c->truths[i].d_xref; h[i].xalt = c->truths[i].d_xalt;
+    h[i].xtidx = c->truths[i].d_xtidx; h[i].xshift = c->truths[i].xshift; h[i].xnb = c->truths[i].xnb; h[i].xn = c->truths[i].xn;
   }
   HIPCHK(hipMemcpy(c->d_truths, h.data(), sizeof(TruthDev) * (size_t)n, hipMemcpyHostToDevice));
   return QM_OK;
 }
 
-static int truth_from_keys(qm_ctx* c, std::vector<uint32_t>& keys, int* truth_id) {
+// coarse position index over sorted keys (pos << 4 | nibble): tidx[b] = first key with pos >= b << shift
+static void coarse_index(const std::vector<uint32_t>& keys, int32_t* shift_out, int32_t* nb_out, std::vector<int32_t>& tidx) {
+  const uint32_t maxpos = keys.empty() ? 0u : (keys.back() >> 4);
+  int shift = 0;
+  while ((maxpos >> shift) >= (1u << 16)) ++shift;  // <= 65536 buckets
+  const int32_t nb = (int32_t)(maxpos >> shift);
+  tidx.assign((size_t)nb + 2, 0);
+  size_t j = 0;
+  for (int32_t b = 0; b <= nb + 1; ++b) {
+    const uint64_t lim = ((uint64_t)b << shift) << 4;
+    while (j < keys.size() && (uint64_t)keys[j] < lim) ++j;
+    tidx[(size_t)b] = (int32_t)j;
+  }
+  tidx[(size_t)nb + 1] = (int32_t)keys.size();
+  *shift_out = shift;
+  *nb_out = nb;
+}
+
+struct XEntry { uint32_t key; int32_t ref, alt; };
+
+// keys: single-base entries; xe: every valid entry (allele-extended batches join against these)
+static int truth_from_keys(qm_ctx* c, std::vector<uint32_t>& keys, std::vector<XEntry>& xe, int* truth_id) {
   std::sort(keys.begin(), keys.end());
   keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
   Truth t;
   t.n = (int64_t)keys.size();
-  const uint32_t maxpos = keys.empty() ? 0u : (keys.back() >> 4);
-  int shift = 0;
-  while ((maxpos >> shift) >= (1u << 16)) ++shift;  // <= 65536 buckets
-  t.shift = shift;
-  t.nb = (int32_t)(maxpos >> shift);
-  std::vector<int32_t> tidx((size_t)t.nb + 2);
-  {
-    size_t j = 0;
-    for (int32_t b = 0; b <= t.nb + 1; ++b) {
-      const uint64_t lim = ((uint64_t)b << shift) << 4;  // first key with pos >= b << shift
-      while (j < keys.size() && (uint64_t)keys[j] < lim) ++j;
-      tidx[(size_t)b] = (int32_t)j;
-    }
-    tidx[(size_t)t.nb + 1] = (int32_t)keys.size();
-  }
+  std::vector<int32_t> tidx;
+  coarse_index(keys, &t.shift, &t.nb, tidx);
   DALLOC(t.d_keys, keys.size());
   DALLOC(t.d_tidx, tidx.size());
   if (!keys.empty()) HIPCHK(hipMemcpy(t.d_keys, keys.data(), keys.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(t.d_tidx, tidx.data(), tidx.size() * 4, hipMemcpyHostToDevice));
+  {
+    auto lt = [](const XEntry& a, const XEntry& b) {
+      if (a.key != b.key) return a.key < b.key;
+      if (a.ref != b.ref) return a.ref < b.ref;
+      return a.alt < b.alt;
+    };
+    auto eq = [](const XEntry& a, const XEntry& b) { return a.key == b.key && a.ref == b.ref && a.alt == b.alt; };
+    std::sort(xe.begin(), xe.end(), lt);
+    xe.erase(std::unique(xe.begin(), xe.end(), eq), xe.end());
+    t.xn = (int64_t)xe.size();
+    std::vector<uint32_t> xk(xe.size());
+    std::vector<int32_t> xr(xe.size()), xa(xe.size()), xtidx;
+    for (size_t i = 0; i < xe.size(); ++i) { xk[i] = xe[i].key; xr[i] = xe[i].ref; xa[i] = xe[i].alt; }
+    coarse_index(xk, &t.xshift, &t.xnb, xtidx);
+    DALLOC(t.d_xkeys, xk.size());
+    DALLOC(t.d_xref, xk.size());
+    DALLOC(t.d_xalt, xk.size());
+    DALLOC(t.d_xtidx, xtidx.size());
+    if (!xk.empty()) {
+      HIPCHK(hipMemcpy(t.d_xkeys, xk.data(), xk.size() * 4, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(t.d_xref, xr.data(), xr.size() * 4, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(t.d_xalt, xa.data(), xa.size() * 4, hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemcpy(t.d_xtidx, xtidx.data(), xtidx.size() * 4, hipMemcpyHostToDevice));
+  }
   c->truths.push_back(t);
   int rc = upload_truth_table(c);
   if (rc != QM_OK) return rc;
@@ -151,32 +194,49 @@ extern "C" int qm_truth_load(qm_ctx* c, const int32_t* pos, const int32_t* ref, 
   if (n < 0 || (n > 0 && (!pos || !ref || !alt))) return fail(QM_E_INVAL, "qm_truth_load: bad arguments");
   HIPCHK(hipSetDevice(c->dev));
   std::vector<uint32_t> keys;
+  std::vector<XEntry> xe;
   keys.reserve((size_t)n);
+  xe.reserve((size_t)n);
   for (int64_t i = 0; i < n; ++i) {
-    if ((uint32_t)ref[i] >= 4u || (uint32_t)alt[i] >= 4u) continue;  // can never match a kept line
+    if (!allele_valid(ref[i]) || !allele_valid(alt[i])) continue;  // can never match a kept line
     if ((uint32_t)pos[i] >= (uint32_t)QM_POS_LIMIT)
       return fail(QM_E_RANGE, "qm_truth_load: position %d of row %lld outside [0, 2^28)", pos[i], (long long)i);
-    keys.push_back(((uint32_t)pos[i] << 4) | ((uint32_t)ref[i] << 2) | (uint32_t)alt[i]);
+    const uint32_t key = ((uint32_t)pos[i] << 4) | allele_nib(ref[i], alt[i]);
+    xe.push_back(XEntry{key, ref[i], alt[i]});
+    if ((uint32_t)(ref[i] | alt[i]) < 4u) keys.push_back(key);   // single-base: what the reference's pattern list holds
   }
-  return truth_from_keys(c, keys, truth_id);
+  return truth_from_keys(c, keys, xe, truth_id);
 }
 
-extern "C" int qm_truth_synth(qm_ctx* c, int64_t L, int64_t T, uint64_t tseed, int* truth_id) {
+extern "C" int qm_truth_synth_ext(qm_ctx* c, int64_t L, int64_t T, uint64_t tseed, int indel_pct, int* truth_id) {
   if (!c) return fail(QM_E_INVAL, "qm_truth_synth: ctx is NULL");
   if (T <= 0 || L <= 0 || L % T != 0 || L >= QM_POS_LIMIT) return fail(QM_E_INVAL, "qm_truth_synth: need T | L and L < 2^28");
+  if (indel_pct < 0 || indel_pct > 100) return fail(QM_E_INVAL, "qm_truth_synth: indel_pct must be 0..100");
   HIPCHK(hipSetDevice(c->dev));
-  std::vector<uint32_t> keys((size_t)T);
+  std::vector<uint32_t> keys;
+  std::vector<XEntry> xe((size_t)T);
+  keys.reserve((size_t)T);
   for (int64_t j = 0; j < T; ++j) {
     int32_t p, r, a;
-    synth_truth(L, T, tseed, j, &p, &r, &a);
-    keys[(size_t)j] = ((uint32_t)p << 4) | ((uint32_t)r << 2) | (uint32_t)a;
+    synth_truth(L, T, tseed, j, &p, &r, &a, indel_pct);
+    const uint32_t key = ((uint32_t)p << 4) | allele_nib(r, a);
+    xe[(size_t)j] = XEntry{key, r, a};
+    if ((uint32_t)(r | a) < 4u) keys.push_back(key);
   }
-  return truth_from_keys(c, keys, truth_id);
+  return truth_from_keys(c, keys, xe, truth_id);
+}
+extern "C" int qm_truth_synth(qm_ctx* c, int64_t L, int64_t T, uint64_t tseed, int* truth_id) {
+  return qm_truth_synth_ext(c, L, T, tseed, 0, truth_id);
 }
 
 extern "C" int qm_truth_size(qm_ctx* c, int truth_id, int64_t* n_unique) {
   if (!c || truth_id < 0 || truth_id >= (int)c->truths.size() || !n_unique) return fail(QM_E_INVAL, "qm_truth_size: bad arguments");
   *n_unique = c->truths[(size_t)truth_id].n;
+  return QM_OK;
+}
+extern "C" int qm_truth_size_ext(qm_ctx* c, int truth_id, int64_t* n_unique) {
+  if (!c || truth_id < 0 || truth_id >= (int)c->truths.size() || !n_unique) return fail(QM_E_INVAL, "qm_truth_size_ext: bad arguments");
+  *n_unique = c->truths[(size_t)truth_id].xn;
   return QM_OK;
 }
 extern "C" int qm_truth_count(qm_ctx* c) { return c ? (int)c->truths.size() : 0; }
@@ -263,6 +323,7 @@ struct qm_batch {
   hipEvent_t ev[EV_RING][4] = {};
   int64_t n_timed = 0;
   bool ran = false, finished = false;
+  bool ext = false;   // allele-extended: any valid allele code takes part (build-defined widening, config 5)
   uint64_t* last_global = nullptr;
 };
 
@@ -326,9 +387,10 @@ static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int
   return QM_OK;
 }
 
-extern "C" int qm_batch_create(qm_ctx* c, int n_vcf, const int64_t* n_records, const int32_t* truth_id_per_vcf, int n_bins,
-                               qm_batch** out) {
+extern "C" int qm_batch_create_ext(qm_ctx* c, int n_vcf, const int64_t* n_records, const int32_t* truth_id_per_vcf, int n_bins,
+                                   unsigned mode, qm_batch** out) {
   if (!c || !out || n_vcf <= 0 || !n_records || !truth_id_per_vcf) return fail(QM_E_INVAL, "qm_batch_create: bad arguments");
+  if (mode & ~(unsigned)QM_BATCH_ALLELES) return fail(QM_E_INVAL, "qm_batch_create_ext: unknown mode bits 0x%x", mode);
   if (n_bins < 1 || n_bins > QM_MAX_BINS) return fail(QM_E_INVAL, "qm_batch_create: n_bins must be 1..256");
   *out = nullptr;
   for (int v = 0; v < n_vcf; ++v) {
@@ -337,7 +399,13 @@ extern "C" int qm_batch_create(qm_ctx* c, int n_vcf, const int64_t* n_records, c
       return fail(QM_E_INVAL, "qm_batch_create: VCF %d names truth set %d (have %zu)", v, truth_id_per_vcf[v], c->truths.size());
   }
   HIPCHK(hipSetDevice(c->dev));
-  return batch_alloc(c, n_vcf, n_records, truth_id_per_vcf, n_bins, out);
+  int rc = batch_alloc(c, n_vcf, n_records, truth_id_per_vcf, n_bins, out);
+  if (rc == QM_OK) (*out)->ext = (mode & QM_BATCH_ALLELES) != 0;
+  return rc;
+}
+extern "C" int qm_batch_create(qm_ctx* c, int n_vcf, const int64_t* n_records, const int32_t* truth_id_per_vcf, int n_bins,
+                               qm_batch** out) {
+  return qm_batch_create_ext(c, n_vcf, n_records, truth_id_per_vcf, n_bins, 0u, out);
 }
 
 extern "C" void qm_batch_destroy(qm_batch* b) { batch_free(b); }
@@ -377,6 +445,9 @@ extern "C" int qm_batch_synth(qm_batch* b, const qm_synth_cfg* cfg) {
   S.vcfs = b->d_vcfs; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
   S.genome_len = cfg->genome_len; S.truth_n = cfg->truth_n; S.truth_seed = cfg->truth_seed; S.seed = cfg->seed;
   S.shuffled = cfg->shuffled;
+  S.indel_pct = cfg->indel_pct;
+  if (cfg->indel_pct < 0 || cfg->indel_pct > 100) return fail(QM_E_INVAL, "qm_batch_synth: indel_pct must be 0..100");
+  if (cfg->indel_pct > 0 && !b->ext) return fail(QM_E_INVAL, "qm_batch_synth: indel_pct > 0 needs an allele-extended batch");
   // slot i holds generated record (i * a + b) mod n, a coprime to every n in the batch
   uint64_t a = 2654435761ull;
   for (;;) {
@@ -402,13 +473,14 @@ static ClassifyParams classify_params(qm_batch* b) {
   P.span_hist = b->span_hist; P.span_scal = b->span_scal; P.n_bins = b->n_bins;
   const char* ab = getenv("QM_ABLATE");
   P.ablate = ab ? atoi(ab) : 0;
+  P.ext = b->ext ? 1 : 0;
   return P;
 }
 static FinalizeParams finalize_params(qm_batch* b, uint64_t* global) {
   FinalizeParams F;
   F.vcfs = b->d_vcfs; F.truths = b->ctx->d_truths; F.span_hist = b->span_hist; F.span_scal = b->span_scal;
   F.tile_tp = b->tile_tp; F.tile_fp = b->tile_fp; F.tile_tp_off = b->tile_tp_off; F.tile_fp_off = b->tile_fp_off;
-  F.roc = b->roc; F.scalars = b->scalars; F.vcf_flags = b->vcf_flags; F.global_acc = global; F.n_bins = b->n_bins;
+  F.roc = b->roc; F.scalars = b->scalars; F.vcf_flags = b->vcf_flags; F.global_acc = global; F.n_bins = b->n_bins; F.ext = b->ext ? 1 : 0;
   return F;
 }
 static CompactParams compact_params(qm_batch* b) {
@@ -590,6 +662,10 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
   std::vector<int> todo;
   for (int v = 0; v < b->n_vcf; ++v) {
     if (fl[(size_t)v] & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", v);
+    if (b->ext && (fl[(size_t)v] & SPANF_UNSORTED))
+      return fail(QM_E_UNSORTED, "VCF %d is not position sorted: allele-extended batches take sorted VCFs only", v);
+    if (fl[(size_t)v] & SPANF_RUNLIMIT)
+      return fail(QM_E_LIMIT, "VCF %d repeats one position more than %d times between equal alleles (allele-extended de-duplication limit)", v, 1 << 14);
     if (fl[(size_t)v] & SPANF_UNSORTED) todo.push_back(v);
   }
   if (!todo.empty()) {
@@ -695,6 +771,14 @@ extern "C" int qm_classify_batch(qm_ctx* c, int n_vcf, const int64_t* rec_offset
                                  const int32_t* alt, const float* qual, const uint8_t* flags, const int32_t* truth_id_per_vcf,
                                  int n_bins, uint8_t* out_cls, uint64_t* out_roc, int64_t* out_scalars, int32_t* out_idx,
                                  uint64_t* out_global) {
+  return qm_classify_batch_ext(c, n_vcf, rec_offsets, pos, ref, alt, qual, flags, truth_id_per_vcf, n_bins, 0u, out_cls, out_roc,
+                               out_scalars, out_idx, out_global);
+}
+
+extern "C" int qm_classify_batch_ext(qm_ctx* c, int n_vcf, const int64_t* rec_offsets, const int32_t* pos, const int32_t* ref,
+                                     const int32_t* alt, const float* qual, const uint8_t* flags, const int32_t* truth_id_per_vcf,
+                                     int n_bins, unsigned mode, uint8_t* out_cls, uint64_t* out_roc, int64_t* out_scalars,
+                                     int32_t* out_idx, uint64_t* out_global) {
   if (!c || n_vcf <= 0 || !rec_offsets || !truth_id_per_vcf) return fail(QM_E_INVAL, "qm_classify_batch: bad arguments");
   std::vector<int64_t> n((size_t)n_vcf);
   for (int v = 0; v < n_vcf; ++v) {
@@ -702,7 +786,7 @@ extern "C" int qm_classify_batch(qm_ctx* c, int n_vcf, const int64_t* rec_offset
     if (n[(size_t)v] < 0) return fail(QM_E_INVAL, "qm_classify_batch: rec_offsets must be non-decreasing");
   }
   qm_batch* b = nullptr;
-  int rc = qm_batch_create(c, n_vcf, n.data(), truth_id_per_vcf, n_bins, &b);
+  int rc = qm_batch_create_ext(c, n_vcf, n.data(), truth_id_per_vcf, n_bins, mode, &b);
   if (rc != QM_OK) return rc;
   for (int v = 0; v < n_vcf && rc == QM_OK; ++v) {
     const int64_t o = rec_offsets[v];

@@ -31,6 +31,20 @@ constexpr uint32_t QMF_IDDOT = 2u;
 constexpr uint32_t QMF_NOKEY = 4u;
 constexpr uint32_t SPANF_UNSORTED = 1u;
 constexpr uint32_t SPANF_BADPOS = 2u;
+constexpr uint32_t SPANF_RUNLIMIT = 4u;   // allele-extended batch: more records at one position than the dedupe walk allows
+
+// ---- allele codes (include/qmvt.h): 0..3 single base, >= QM_ALLELE_EXT_MIN and non-negative = an
+// inline-packed (2..13 bases) or dictionary-interned longer allele; everything else takes no part.
+constexpr uint32_t ALLELE_EXT_MIN = 0x08000000u;
+__host__ __device__ inline bool allele_valid(int32_t c) {
+  const uint32_t u = (uint32_t)c;
+  return u < 4u || (u - ALLELE_EXT_MIN) < (0x80000000u - ALLELE_EXT_MIN);
+}
+// low nibble of the 32-bit key: exact for single-base pairs, a hash for the others
+__host__ __device__ inline uint32_t allele_nib(int32_t r, int32_t a) {
+  if ((uint32_t)(r | a) < 4u) return ((uint32_t)r << 2) | (uint32_t)a;
+  return ((((uint32_t)r * 0x9e3779b1u) ^ ((uint32_t)a * 0x85ebca6bu)) * 0xc2b2ae35u) >> 28;
+}
 
 struct TruthDev {
   const uint32_t* keys;  // sorted distinct pos<<4 | ref<<2 | alt
@@ -38,6 +52,15 @@ struct TruthDev {
   int32_t shift;
   int32_t nb;
   int64_t n;
+  // allele-extended table: every entry (single-base ones included), distinct (pos, ref, alt),
+  // sorted by (pos << 4 | allele_nib, ref, alt); same coarse index
+  const uint32_t* xkeys;
+  const int32_t* xref;
+  const int32_t* xalt;
+  const int32_t* xtidx;
+  int32_t xshift;
+  int32_t xnb;
+  int64_t xn;
 };
 
 struct VcfDesc {
@@ -74,6 +97,7 @@ struct ClassifyParams {
   uint32_t* span_scal;  // [n_spans][8]
   int32_t n_bins;
   int32_t ablate;  // debug only (QM_ABLATE): skip phases to price them; results are wrong when non-zero
+  int32_t ext;     // allele-extended batch: k_classify<false, true> against the truth sets' extended tables
 };
 
 struct FinalizeParams {
@@ -90,6 +114,7 @@ struct FinalizeParams {
   uint32_t* vcf_flags;
   uint64_t* global_acc;  // [n_truth][3][n_bins] or null
   int32_t n_bins;
+  int32_t ext;           // allele-extended batch: T' is the size of the extended truth table
 };
 
 struct CompactParams {
@@ -129,6 +154,7 @@ struct SynthParams {
   uint64_t seed;
   uint64_t perm_a, perm_b;
   int32_t shuffled;
+  int32_t indel_pct;
 };
 
 // ---- synthetic workload: the same arithmetic on host and device -------------
@@ -142,9 +168,23 @@ __host__ __device__ inline uint64_t hash3(uint64_t seed, uint64_t a, uint64_t b)
   return mix64(mix64(seed ^ 0x51ed270b7f3c9a11ull) + a * 0x9e3779b97f4a7c15ull + b * 0xc2b2ae3d27d4eb4full);
 }
 __host__ __device__ inline int32_t synth_refbase(int64_t p) { return (int32_t)(hash3(3, (uint64_t)p, 0) & 3u); }
-// truth entry j of T over genome L: one position per stratum of width L / T
+// A synthetic allele (config 5, mixed SNP + indel): length minlen + Geom(0.5) capped at 32.  Up to
+// 13 bases it is the inline code (len << 26 | 2-bit bases); longer ones are an id of the synthetic
+// dictionary (SYNTH_POOL strings of 14..32 bases, spelled from the id alone, tests/ restate the spelling).
+constexpr uint32_t SYNTH_POOL = 1u << 20;
+__host__ __device__ inline int32_t synth_allele(uint64_t h, int minlen) {
+  int len = minlen;
+  uint64_t g = h;
+  while (len < 32 && (g & 1u)) { ++len; g >>= 1; }
+  const uint64_t bits = mix64(h ^ 0xa11e1e5ull);
+  if (len == 1) return (int32_t)(bits & 3u);
+  if (len <= 13) return (int32_t)(((uint32_t)len << 26) | (uint32_t)(bits & ((1ull << (2 * len)) - 1ull)));
+  return (int32_t)(0x40000000u | (uint32_t)(bits % SYNTH_POOL));
+}
+// truth entry j of T over genome L: one position per stratum of width L / T; indel_pct % of the
+// entries carry longer alleles (0 = the single-base workload of configs 3 / 4)
 __host__ __device__ inline void synth_truth(int64_t L, int64_t T, uint64_t tseed, int64_t j, int32_t* p, int32_t* r,
-                                             int32_t* a) {
+                                             int32_t* a, int indel_pct = 0) {
   const int64_t wt = L / T;
   const uint64_t h = hash3(tseed, (uint64_t)j, 1);
   const int64_t pp = j * wt + 1 + (int64_t)(h % (uint64_t)wt);
@@ -152,11 +192,15 @@ __host__ __device__ inline void synth_truth(int64_t L, int64_t T, uint64_t tseed
   *p = (int32_t)pp;
   *r = rr;
   *a = (int32_t)((rr + 1 + (int32_t)((h >> 32) % 3u)) & 3);
+  if (indel_pct > 0 && (int)(hash3(tseed, (uint64_t)j, 2) % 100u) < indel_pct) {
+    *r = synth_allele(hash3(tseed, (uint64_t)j, 3), 1);
+    *a = synth_allele(hash3(tseed, (uint64_t)j, 4), 2);
+  }
 }
 // record i of a VCF with N records: one position per stratum of width L / N;
 // takes the truth entry that falls into its stratum with probability 0.8.
 __host__ __device__ inline void synth_record(int64_t L, int64_t N, int64_t T, uint64_t tseed, uint64_t seed, int64_t i,
-                                              int32_t* p, int32_t* r, int32_t* a, float* q, uint8_t* f) {
+                                              int32_t* p, int32_t* r, int32_t* a, float* q, uint8_t* f, int indel_pct = 0) {
   const int64_t w = L / N;
   const int64_t wt = L / T;
   const int64_t s0 = i * w + 1;  // stratum [s0, s0 + w)
@@ -164,7 +208,7 @@ __host__ __device__ inline void synth_record(int64_t L, int64_t N, int64_t T, ui
   int32_t tp = 0, tr = 0, ta = 0;
   bool take = false;
   if (j < T) {
-    synth_truth(L, T, tseed, j, &tp, &tr, &ta);
+    synth_truth(L, T, tseed, j, &tp, &tr, &ta, indel_pct);
     take = tp >= s0 && tp < s0 + w && (hash3(seed, (uint64_t)i, 10) % 10u) < 8u;
   }
   if (take) {
@@ -175,6 +219,10 @@ __host__ __device__ inline void synth_record(int64_t L, int64_t N, int64_t T, ui
     *p = (int32_t)pp;
     *r = rr;
     *a = (int32_t)((rr + 1 + (int32_t)(hash3(seed, (uint64_t)i, 12) % 3u)) & 3);
+    if (indel_pct > 0 && (int)(hash3(seed, (uint64_t)i, 14) % 100u) < indel_pct) {
+      *r = synth_allele(hash3(seed, (uint64_t)i, 15), 1);
+      *a = synth_allele(hash3(seed, (uint64_t)i, 16), 2);
+    }
   }
   const uint32_t qi = (uint32_t)(hash3(seed, (uint64_t)i, 13) & 255u);
   *q = (float)qi;

@@ -91,10 +91,22 @@ constexpr uint32_t I_BADPOS = 1u << 13;  // position outside [0, 2^28)
 constexpr uint32_t I_KEPT = 1u << 14;    // live and PASS: the line is in <x>.filtered.vcf
 
 // key and info of one record from its columns (qmvt_dev.h: the radix-sort path uses the same)
+// EXT (allele-extended batches, include/qmvt.h "allele codes"): any valid allele code is live; the
+// key's nibble is ref << 2 | alt for single bases and a hash of the two codes otherwise, so key
+// equality is necessary and (key, ref, alt) equality is the match.
+template <bool EXT = false>
 __device__ __forceinline__ void pack_record(int p, int r, int a, float q, uint32_t fl, int nb, uint32_t& key, uint32_t& inf) {
   const bool okpos = (uint32_t)p < (uint32_t)QM_POS_LIMIT_DEV;
-  const bool live = okpos & ((uint32_t)(r | a) < 4u);
-  key = ((uint32_t)p << 4) | (live ? ((uint32_t)r << 2) | (uint32_t)a : 0u);
+  bool live;
+  uint32_t nib;
+  if (EXT) {
+    live = okpos && allele_valid(r) && allele_valid(a);
+    nib = allele_nib(r, a);
+  } else {
+    live = okpos & ((uint32_t)(r | a) < 4u);
+    nib = ((uint32_t)r << 2) | (uint32_t)a;
+  }
+  key = ((uint32_t)p << 4) | (live ? nib : 0u);
   inf = (live ? (uint32_t)(qual_bin(q, nb) + 1) : 0u) | ((fl & 7u) << 9) | (live ? I_LIVE : 0u) | (okpos ? 0u : I_BADPOS) |
         ((live && (fl & QMF_PASS)) ? I_KEPT : 0u);
 }
@@ -125,15 +137,25 @@ __device__ __forceinline__ void load_raw(const Cols& C, int idx, Raw4<true>& R) 
   R.i = *reinterpret_cast<const uint4*>(C.pinf + idx);
 }
 
-struct In4 { uint32_t key[4], inf[4]; };   // the lane's 4 records of the round, packed
+struct In4 {   // the lane's 4 records of the round, packed
+  uint32_t key[4], inf[4];
+  int32_t r[4], a[4];   // EXT only: the allele codes behind the key's nibble
+};
 
+template <bool EXT>
 __device__ __forceinline__ void unpack_raw(const Raw4<false>& R, int nb, In4& X) {
-  pack_record(R.p.x, R.r.x, R.a.x, R.q.x, R.f, nb, X.key[0], X.inf[0]);
-  pack_record(R.p.y, R.r.y, R.a.y, R.q.y, R.f >> 8, nb, X.key[1], X.inf[1]);
-  pack_record(R.p.z, R.r.z, R.a.z, R.q.z, R.f >> 16, nb, X.key[2], X.inf[2]);
-  pack_record(R.p.w, R.r.w, R.a.w, R.q.w, R.f >> 24, nb, X.key[3], X.inf[3]);
+  pack_record<EXT>(R.p.x, R.r.x, R.a.x, R.q.x, R.f, nb, X.key[0], X.inf[0]);
+  pack_record<EXT>(R.p.y, R.r.y, R.a.y, R.q.y, R.f >> 8, nb, X.key[1], X.inf[1]);
+  pack_record<EXT>(R.p.z, R.r.z, R.a.z, R.q.z, R.f >> 16, nb, X.key[2], X.inf[2]);
+  pack_record<EXT>(R.p.w, R.r.w, R.a.w, R.q.w, R.f >> 24, nb, X.key[3], X.inf[3]);
+  if (EXT) {
+    X.r[0] = R.r.x; X.r[1] = R.r.y; X.r[2] = R.r.z; X.r[3] = R.r.w;
+    X.a[0] = R.a.x; X.a[1] = R.a.y; X.a[2] = R.a.z; X.a[3] = R.a.w;
+  }
 }
+template <bool EXT>
 __device__ __forceinline__ void unpack_raw(const Raw4<true>& R, int, In4& X) {
+  static_assert(!EXT, "allele-extended batches take the column format only");
   X.key[0] = R.k.x; X.key[1] = R.k.y; X.key[2] = R.k.z; X.key[3] = R.k.w;
   X.inf[0] = R.i.x; X.inf[1] = R.i.y; X.inf[2] = R.i.z; X.inf[3] = R.i.w;
 }
@@ -156,9 +178,10 @@ template <bool PACKED> __device__ __forceinline__ int rec_pos(const Cols& C, int
   if (PACKED) return (int)(C.pkey[i] >> 4);
   return C.pos[i];
 }
-template <bool PACKED> __device__ __forceinline__ void rec_packed(const Cols& C, int i, int nb, uint32_t& key, uint32_t& inf) {
+template <bool PACKED, bool EXT = false>
+__device__ __forceinline__ void rec_packed(const Cols& C, int i, int nb, uint32_t& key, uint32_t& inf) {
   if (PACKED) { key = C.pkey[i]; inf = C.pinf[i]; return; }
-  pack_record(C.pos[i], C.ref[i], C.alt[i], C.qual[i], C.flags[i], nb, key, inf);
+  pack_record<EXT>(C.pos[i], C.ref[i], C.alt[i], C.qual[i], C.flags[i], nb, key, inf);
 }
 
 typedef const __attribute__((address_space(1))) uint32_t* gu32p;
@@ -166,11 +189,17 @@ typedef const __attribute__((address_space(1))) int32_t* gi32p;
 struct TruthG {   // TruthDev with global-address-space pointers: its loads are global_load, never flat_load
   gu32p keys;
   gi32p tidx;
+  gi32p ref, alt;   // EXT only
   int32_t shift, nb;
 };
+template <bool EXT>
 __device__ __forceinline__ TruthG truth_global(const TruthDev& t) {
   TruthG g;
-  g.keys = (gu32p)t.keys; g.tidx = (gi32p)t.tidx; g.shift = t.shift; g.nb = t.nb;
+  if (EXT) {
+    g.keys = (gu32p)t.xkeys; g.tidx = (gi32p)t.xtidx; g.ref = (gi32p)t.xref; g.alt = (gi32p)t.xalt; g.shift = t.xshift; g.nb = t.xnb;
+  } else {
+    g.keys = (gu32p)t.keys; g.tidx = (gi32p)t.tidx; g.ref = nullptr; g.alt = nullptr; g.shift = t.shift; g.nb = t.nb;
+  }
   return g;
 }
 
@@ -187,12 +216,20 @@ constexpr int L_RINF = L_RKEY + 256;                    // [128] record infos, u
 constexpr int L_HITS = L_RINF + 128;                    // [8] one bit per record of the round: matched a truth key
 constexpr int L_MASK = L_HITS + 8;                        // [2][32] the tile's kept / TP mask words, stored once per tile
 constexpr int L_TOTAL = L_MASK + 64;
+// allele-extended instantiation only: the allele codes behind the staged keys
+constexpr int L_XRREF = L_TOTAL;                        // [256] record REF codes of the round
+constexpr int L_XRALT = L_XRREF + 256;                  // [256] record ALT codes
+constexpr int L_XSREF = L_XRALT + 256;                  // [2][K1_SLICE] REF codes of the staged truth entries
+constexpr int L_XSALT = L_XSREF + 2 * K1_SLICE;         // [2][K1_SLICE] ALT codes
+constexpr int L_TOTAL_X = L_XSALT + 2 * K1_SLICE;
+static_assert(L_XRREF % 4 == 0, "b128 LDS stores need natural alignment");
 static_assert(L_RKEY % 4 == 0 && L_RINF % 2 == 0, "b128 / b64 LDS stores need natural alignment");
 static_assert(K1_ROUNDS == 4, "one store covers the 32 + 32 mask words of a four-round tile");
 static_assert(K1_ROUNDS >= 3 && K1_SLICE % 64 == 0, "the next tile's slice is fetched over rounds 0..2 of the current one");
 
 struct Slice {
   int keys, smax, srf;  // dword offsets of the active buffer
+  int ref, alt;         // EXT only
   int m;                // keys staged
 };
 
@@ -200,10 +237,17 @@ __device__ __forceinline__ void slice_select(Slice& S, int buf) {
   S.keys = L_KEYS + buf * K1_SLICE;
   S.smax = L_SMAX + buf * K1_SLICE;
   S.srf = L_SRF + buf * (K1_SLICE / 32);
+  S.ref = L_XSREF + buf * K1_SLICE;
+  S.alt = L_XSALT + buf * K1_SLICE;
 }
 
+template <bool EXT>
 __device__ __forceinline__ void stage_slice(uint32_t* lds, const TruthG& tr, int c0, const Slice& S, int lane) {
-  for (int j = lane; j < S.m; j += 64) { lds[S.keys + j] = tr.keys[c0 + j]; lds[S.smax + j] = 0; }
+  for (int j = lane; j < S.m; j += 64) {
+    lds[S.keys + j] = tr.keys[c0 + j];
+    lds[S.smax + j] = 0;
+    if (EXT) { lds[S.ref + j] = (uint32_t)tr.ref[c0 + j]; lds[S.alt + j] = (uint32_t)tr.alt[c0 + j]; }
+  }
   if (lane < K1_SLICE / 32) lds[S.srf + lane] = 0;
 }
 
@@ -235,6 +279,7 @@ template <bool PACKED> __device__ __forceinline__ SegBounds seg_bounds(const Col
 
 // ---- phase A: stage the round's keys and infos in LDS ------------------------------------
 // records at or beyond `te` become key 0xffffffff (sorts last, matches nothing), info 0.
+template <bool EXT>
 __device__ __forceinline__ void stage_round(uint32_t* lds, In4& X, int i0, int te, int lane) {
   if (i0 - lane * 4 + 256 > te) {   // wave-uniform: only the last round of a span can be partial
 #pragma unroll
@@ -247,12 +292,20 @@ __device__ __forceinline__ void stage_round(uint32_t* lds, In4& X, int i0, int t
   iv.x = (X.inf[0] & 0xffffu) | (X.inf[1] << 16); iv.y = (X.inf[2] & 0xffffu) | (X.inf[3] << 16);
   *reinterpret_cast<uint4*>(&lds[L_RKEY + lane * 4]) = kv;
   *reinterpret_cast<uint2*>(&lds[L_RINF + lane * 2]) = iv;
+  if (EXT) {   // records beyond `te` keep whatever codes they loaded: their key matches nothing
+    uint4 rv, av;
+    rv.x = (uint32_t)X.r[0]; rv.y = (uint32_t)X.r[1]; rv.z = (uint32_t)X.r[2]; rv.w = (uint32_t)X.r[3];
+    av.x = (uint32_t)X.a[0]; av.y = (uint32_t)X.a[1]; av.z = (uint32_t)X.a[2]; av.w = (uint32_t)X.a[3];
+    *reinterpret_cast<uint4*>(&lds[L_XRREF + lane * 4]) = rv;
+    *reinterpret_cast<uint4*>(&lds[L_XRALT + lane * 4]) = av;
+  }
   if (lane < 8) lds[L_HITS + lane] = 0;
 }
 
 // ---- phase B: the truth keys of the round's position range search the staged records ----
 // own_a: INT32_MIN when the segment owns the run at its first position, else that position
 // (the run started in an earlier segment, which owns its truth entries).
+template <bool EXT>
 __device__ __forceinline__ void join_round(uint32_t* lds, const Slice& S, int nrec, int own_a, int lane) {
   if (S.m <= 0 || nrec <= 0) return;
   const uint32_t first_pos = lds[L_RKEY] >> 4;
@@ -284,6 +337,9 @@ __device__ __forceinline__ void join_round(uint32_t* lds, const Slice& S, int nr
         const uint32_t rk = lds[L_RKEY + s];
         if ((rk & ~15u) != kfloor) break;
         if (rk != kkey) continue;
+        if (EXT) {   // the nibble of an extended key is a hash: the allele codes decide
+          if (lds[L_XRREF + s] != lds[S.ref + j] || lds[L_XRALT + s] != lds[S.alt + j]) continue;
+        }
         const uint32_t inf = (lds[L_RINF + (s >> 1)] >> (16 * (s & 1))) & 0xffffu;
         if ((inf & (I_LIVE | I_NOKEY)) != I_LIVE) continue;
         atomicOr(&lds[L_HITS + (s >> 5)], 1u << (s & 31));
@@ -310,7 +366,7 @@ __device__ __forceinline__ int slice_lower_bound(const uint32_t* lds, const Slic
 }
 
 // records after the segment that continue its last run of equal positions
-template <bool PACKED>
+template <bool PACKED, bool EXT>
 __device__ __forceinline__ void continue_run(const Cols& C, uint32_t* lds, const Slice& S, int se, int vn, int bpos, int nb, int lane) {
   for (int base = se; base < vn; base += 64) {
     const int i = base + lane;
@@ -319,9 +375,13 @@ __device__ __forceinline__ void continue_run(const Cols& C, uint32_t* lds, const
       cont = (rec_pos<PACKED>(C, i) == bpos);
       if (cont && S.m > 0) {
         uint32_t key, inf;
-        rec_packed<PACKED>(C, i, nb, key, inf);
+        rec_packed<PACKED, EXT>(C, i, nb, key, inf);
         if ((inf & (I_LIVE | I_NOKEY)) == I_LIVE) {
-          const int j = slice_lower_bound(lds, S, key);
+          int j = slice_lower_bound(lds, S, key);
+          if (EXT) {   // several truth entries may share the 32-bit key: find the one with these alleles
+            const uint32_t rr = (uint32_t)C.ref[i], aa = (uint32_t)C.alt[i];
+            while (j < S.m && lds[S.keys + j] == key && (lds[S.ref + j] != rr || lds[S.alt + j] != aa)) ++j;
+          }
           if (j < S.m && lds[S.keys + j] == key) {
             if (inf & I_IDDOT) atomicMax(&lds[S.smax + j], inf & I_BIN1);
             if (inf & I_PASS) atomicOr(&lds[S.srf + (j >> 5)], 1u << (j & 31));
@@ -346,19 +406,26 @@ __device__ __forceinline__ uint32_t flush_slice(uint32_t* lds, const Slice& S, i
 // Has a kept record with this key been seen earlier in the VCF?  Only called when the
 // predecessor has the same position; walks that run of equal positions backwards.
 // <= 16 distinct single-base keys per position bound the total walk per run.
-template <bool PACKED>
-__device__ __forceinline__ uint32_t repeated_key(const Cols& C, int i, uint32_t key, uint32_t nokey, int nb) {
+// EXT: the number of distinct keys per position is unbounded, so the walk has a budget; a record
+// that exhausts it flags the VCF (SPANF_RUNLIMIT) instead of stalling the wave.
+constexpr int X_WALK_LIMIT = 1 << 14;
+template <bool PACKED, bool EXT>
+__device__ __forceinline__ uint32_t repeated_key(const Cols& C, int i, uint32_t key, uint32_t nokey, int nb, int32_t r, int32_t a,
+                                                 uint32_t& bad) {
   for (int j = i - 1; j >= 0; --j) {
+    if (EXT && i - j > X_WALK_LIMIT) { bad |= 4u; break; }
     if (rec_pos<PACKED>(C, j) != (int)(key >> 4)) break;
     uint32_t kj, ij;
-    rec_packed<PACKED>(C, j, nb, kj, ij);
-    if (kj == key && (ij & (I_LIVE | I_PASS)) == (I_LIVE | I_PASS) && (ij & I_NOKEY) == nokey) return 1u;
+    rec_packed<PACKED, EXT>(C, j, nb, kj, ij);
+    if (kj == key && (ij & (I_LIVE | I_PASS)) == (I_LIVE | I_PASS) && (ij & I_NOKEY) == nokey) {
+      if (!EXT || (C.ref[j] == r && C.alt[j] == a)) return 1u;
+    }
   }
   return 0u;
 }
 
 struct Acc {
-  uint32_t bad;              // per lane: bit0 order violated, bit1 position out of range
+  uint32_t bad;              // per lane: bit0 order violated, bit1 position out of range, bit2 EXT walk budget exhausted
   uint32_t fpr;              // per lane: distinct kept keys outside the truth set
   uint32_t n_pass, n_tp;     // per lane: kept / TP lines of the current tile
 };
@@ -373,7 +440,7 @@ __device__ __forceinline__ uint32_t or_reduce8(uint32_t v) {
 
 // ---- phase C: per-record work on the packed registers of the round -----------------------
 // prev_last = position of the record before the round (INT32_MIN at the VCF start).
-template <bool PACKED>
+template <bool PACKED, bool EXT>
 __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, const In4& X, int rbase, int te, int prev_last, int nb,
                                                int ablate, int mslot, Acc& A, int lane) {
   const uint32_t hit = (lds[L_HITS + (lane >> 3)] >> (4 * (lane & 7))) & 15u;
@@ -426,7 +493,7 @@ __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, con
   if (cand && !(ablate & 8)) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if ((cand >> k) & 1u) A.fpr -= repeated_key<PACKED>(C, i0 + k, X.key[k], X.inf[k] & I_NOKEY, nb);
+      if ((cand >> k) & 1u) A.fpr -= repeated_key<PACKED, EXT>(C, i0 + k, X.key[k], X.inf[k] & I_NOKEY, nb, X.r[k], X.a[k], A.bad);
   }
 }
 
@@ -445,14 +512,14 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #define K1_WAVES_PER_EU 4
 #endif
 
-template <bool PACKED>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER_EU, 8))) void k_classify(ClassifyParams P) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds[L_TOTAL + K1_LDS_PAD];
+template <bool PACKED, bool EXT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? 2 : K1_WAVES_PER_EU, 8))) void k_classify(ClassifyParams P) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[(EXT ? L_TOTAL_X : L_TOTAL) + K1_LDS_PAD];
 
   const int lane = (int)threadIdx.x;
   const SpanDesc sp = P.spans[blockIdx.x];
   const VcfDesc vd = P.vcfs[sp.vcf];
-  const TruthG tr = truth_global(P.truths[vd.truth]);
+  const TruthG tr = truth_global<EXT>(P.truths[vd.truth]);
   Cols C;
   C.pos = P.pos + vd.off; C.ref = P.ref + vd.off; C.alt = P.alt + vd.off; C.qual = P.qual + vd.off; C.flags = P.flags + vd.off;
   C.pkey = P.pkey + vd.off; C.pinf = P.pinf + vd.off;
@@ -484,7 +551,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
   Slice S;
   slice_select(S, 0);
   S.m = (hi - lo) <= K1_SLICE ? (hi - lo) : 0;   // an oversize slice is handled round by round
-  stage_slice(lds, tr, lo, S, lane);
+  stage_slice<EXT>(lds, tr, lo, S, lane);
   __syncthreads();
 
   int tile = sp.tile0;
@@ -500,13 +567,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
 
     SegBounds NB = B;
     int nlo = 0, nhi = 0;
-    uint32_t nkeys[K1_SLICE / 64];
+    uint32_t nkeys[K1_SLICE / 64], nref[K1_SLICE / 64], nalt[K1_SLICE / 64];   // nref / nalt: EXT only
 #pragma unroll
-    for (int q = 0; q < K1_SLICE / 64; ++q) nkeys[q] = 0u;
+    for (int q = 0; q < K1_SLICE / 64; ++q) { nkeys[q] = 0u; nref[q] = 0u; nalt[q] = 0u; }
     int prev_last = B.prevp;
     for (int r = 0; r < nrounds; ++r) {
       In4 X;
-      unpack_raw(N, nb, X);
+      unpack_raw<EXT>(N, nb, X);
       const int rbase = tb + r * 256;
       const int rend = rbase + 256 < te ? rbase + 256 : te;
       // the next tile's slice is fetched as a side chain spread over this tile's rounds, so none of
@@ -519,7 +586,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
         } else if (r == 2) {
           const int nm = (nhi - nlo) <= K1_SLICE ? (nhi - nlo) : 0;
 #pragma unroll
-          for (int q = 0; q < K1_SLICE / 64; ++q) nkeys[q] = (q * 64 + lane < nm) ? tr.keys[nlo + q * 64 + lane] : 0u;
+          for (int q = 0; q < K1_SLICE / 64; ++q) {
+            const bool in = q * 64 + lane < nm;
+            nkeys[q] = in ? tr.keys[nlo + q * 64 + lane] : 0u;
+            if (EXT) { nref[q] = in ? (uint32_t)tr.ref[nlo + q * 64 + lane] : 0u; nalt[q] = in ? (uint32_t)tr.alt[nlo + q * 64 + lane] : 0u; }
+          }
         }
       }
       // then the following rounds' records into flight (rounds are contiguous across the span's tiles)
@@ -529,11 +600,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
 #else
       if (rbase + 256 < sp_end) load_raw(C, rbase + 256 + lane * 4, N);
 #endif
-      stage_round(lds, X, rbase + lane * 4, te, lane);
+      stage_round<EXT>(lds, X, rbase + lane * 4, te, lane);
       __syncthreads();
       if (!(ablate & 1)) {
         if (!oversize) {
-          join_round(lds, S, rend - rbase, own_a, lane);
+          join_round<EXT>(lds, S, rend - rbase, own_a, lane);
         } else {
           // dense truth against a sparse VCF -- or an out-of-order round, whose VCF is redone
           // through the radix sort anyway: then there is nothing to join here
@@ -551,10 +622,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
             slice_range(tr, RB.a, RB.b, rlo, rhi);
             for (int c0 = rlo; c0 < rhi; c0 += K1_SLICE) {
               S.m = (rhi - c0) < K1_SLICE ? (rhi - c0) : K1_SLICE;
-              stage_slice(lds, tr, c0, S, lane);
+              stage_slice<EXT>(lds, tr, c0, S, lane);
               __syncthreads();
-              join_round(lds, S, rend - rbase, r_own_a, lane);
-              if (RB.nextp == RB.b && !(r_started && RB.a == RB.b)) continue_run<PACKED>(C, lds, S, rend, vn, RB.b, nb, lane);
+              join_round<EXT>(lds, S, rend - rbase, r_own_a, lane);
+              if (RB.nextp == RB.b && !(r_started && RB.a == RB.b)) continue_run<PACKED, EXT>(C, lds, S, rend, vn, RB.b, nb, lane);
               __syncthreads();
               acc_tpr += flush_slice(lds, S, lane);
               __syncthreads();
@@ -564,14 +635,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
         }
       }
       __syncthreads();
-      classify_round<PACKED>(lds, C, X, rbase, te, prev_last, nb, ablate, 8 * r, A, lane);
+      classify_round<PACKED, EXT>(lds, C, X, rbase, te, prev_last, nb, ablate, 8 * r, A, lane);
       prev_last = (int)(lds[L_RKEY + 255] >> 4);
       __syncthreads();
     }
 
     // ---- tile epilogue: run continuation, per-truth-entry state -> histogram, counts ----
     if (!(ablate & 1) && !oversize) {
-      if (B.nextp == B.b && owns_b) continue_run<PACKED>(C, lds, S, te, vn, B.b, nb, lane);
+      if (B.nextp == B.b && owns_b) continue_run<PACKED, EXT>(C, lds, S, te, vn, B.b, nb, lane);
       __syncthreads();
       acc_tpr += flush_slice(lds, S, lane);
     }
@@ -608,7 +679,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
 #pragma unroll
     for (int q = 0; q < K1_SLICE / 64; ++q) {
       const int j = q * 64 + lane;
-      if (j < S.m) { lds[S.keys + j] = nkeys[q]; lds[S.smax + j] = 0; }
+      if (j < S.m) {
+        lds[S.keys + j] = nkeys[q]; lds[S.smax + j] = 0;
+        if (EXT) { lds[S.ref + j] = nref[q]; lds[S.alt + j] = nalt[q]; }
+      }
     }
     if (lane < K1_SLICE / 32) lds[S.srf + lane] = 0;
     __syncthreads();
@@ -619,6 +693,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
   A.fpr = wave_sum(A.fpr);
   const uint64_t any_uns = ballot64(A.bad & 1u);
   const uint64_t any_bad = ballot64(A.bad & 2u);
+  const uint64_t any_lim = ballot64(A.bad & 4u);
   __syncthreads();
   const uint32_t top_tp = wave_sum(lds[L_TOP + lane]), top_fp = wave_sum(lds[L_TOP + 64 + lane]);
   uint32_t* oh = P.span_hist + (size_t)blockIdx.x * (3 * 256);
@@ -630,7 +705,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(K1_WAVES_PER
   if (lane == 0) {
     uint32_t* sc = P.span_scal + (size_t)blockIdx.x * 8;
     sc[0] = acc_pass; sc[1] = acc_tp; sc[2] = acc_pass - acc_tp; sc[3] = acc_tpr; sc[4] = A.fpr;
-    sc[5] = (any_uns ? SPANF_UNSORTED : 0u) | (any_bad ? SPANF_BADPOS : 0u);
+    sc[5] = (any_uns ? SPANF_UNSORTED : 0u) | (any_bad ? SPANF_BADPOS : 0u) | (any_lim ? SPANF_RUNLIMIT : 0u);
     sc[6] = 0; sc[7] = 0;
   }
 }
@@ -652,6 +727,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
   for (int s = tid; s < vd.nspans; s += 256) fl |= P.span_scal[(size_t)(vd.span0 + s) * 8 + 5];
   const bool unsorted = __syncthreads_or((int)(fl & SPANF_UNSORTED)) != 0;
   const bool badpos = __syncthreads_or((int)(fl & SPANF_BADPOS)) != 0;
+  const bool runlim = __syncthreads_or((int)(fl & SPANF_RUNLIMIT)) != 0;
 
   // sum span histograms (thread = bin)
   uint32_t h0 = 0, h1 = 0, h2 = 0;
@@ -679,9 +755,9 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
     for (int s = 0; s < vd.nspans; ++s) acc += P.span_scal[(size_t)(vd.span0 + s) * 8 + tid];
     int64_t* sc = P.scalars + (size_t)v * 8;
     if (tid < 5) sc[tid] = (int64_t)acc;
-    else if (tid == 5) { sc[5] = unsorted ? 0 : 1; P.vcf_flags[v] = (unsorted ? SPANF_UNSORTED : 0u) | (badpos ? SPANF_BADPOS : 0u); }
+    else if (tid == 5) { sc[5] = unsorted ? 0 : 1; P.vcf_flags[v] = (unsorted ? SPANF_UNSORTED : 0u) | (badpos ? SPANF_BADPOS : 0u) | (runlim ? SPANF_RUNLIMIT : 0u); }
     else if (tid == 6) sc[6] = vd.n;
-    else sc[7] = P.truths[vd.truth].n;
+    else sc[7] = P.ext ? P.truths[vd.truth].xn : P.truths[vd.truth].n;
   }
   // exclusive scan of the tile counts (TP then FP) over the VCF's tiles
   for (int which = 0; which < 2; ++which) {
@@ -838,7 +914,7 @@ __global__ void k_synth(SynthParams S) {
   int32_t p, r, a;
   float q;
   uint8_t f;
-  synth_record(S.genome_len, vd.n, S.truth_n, S.truth_seed, seed, src, &p, &r, &a, &q, &f);
+  synth_record(S.genome_len, vd.n, S.truth_n, S.truth_seed, seed, src, &p, &r, &a, &q, &f, S.indel_pct);
   const int64_t g = vd.off + i;
   S.pos[g] = p; S.ref[g] = r; S.alt[g] = a; S.qual[g] = q; S.flags[g] = f;
 }
@@ -1088,8 +1164,9 @@ __global__ void k_overlap_count(const uint32_t* keys, const uint32_t* vals, int6
 // ---------------------------------------------------------------------------
 void launch_classify(const ClassifyParams& P, int n_spans, hipStream_t st) {
   if (n_spans <= 0) return;
-  if (P.pkey) hipLaunchKernelGGL(k_classify<true>, dim3(n_spans), dim3(64), 0, st, P);
-  else hipLaunchKernelGGL(k_classify<false>, dim3(n_spans), dim3(64), 0, st, P);
+  if (P.pkey) hipLaunchKernelGGL((k_classify<true, false>), dim3(n_spans), dim3(64), 0, st, P);
+  else if (P.ext) hipLaunchKernelGGL((k_classify<false, true>), dim3(n_spans), dim3(64), 0, st, P);
+  else hipLaunchKernelGGL((k_classify<false, false>), dim3(n_spans), dim3(64), 0, st, P);
 }
 void launch_finalize(const FinalizeParams& P, int n_vcf, hipStream_t st) {
   if (n_vcf > 0) hipLaunchKernelGGL(k_finalize, dim3(n_vcf), dim3(256), 0, st, P);

@@ -50,14 +50,15 @@ class Engine:
         check(self._L.qm_truth_load(self._h, _p(pos), _p(ref), _p(alt), pos.shape[0], C.byref(tid)), self._h)
         return tid.value
 
-    def truth_synth(self, genome_len, truth_n, truth_seed):
+    def truth_synth(self, genome_len, truth_n, truth_seed, indel_pct=0):
         tid = C.c_int(-1)
-        check(self._L.qm_truth_synth(self._h, int(genome_len), int(truth_n), int(truth_seed), C.byref(tid)), self._h)
+        check(self._L.qm_truth_synth_ext(self._h, int(genome_len), int(truth_n), int(truth_seed), int(indel_pct), C.byref(tid)), self._h)
         return tid.value
 
-    def truth_size(self, tid):
+    def truth_size(self, tid, alleles=False):
+        """distinct single-base keys; alleles=True: distinct valid keys of any allele length"""
         n = C.c_int64()
-        check(self._L.qm_truth_size(self._h, int(tid), C.byref(n)), self._h)
+        check((self._L.qm_truth_size_ext if alleles else self._L.qm_truth_size)(self._h, int(tid), C.byref(n)), self._h)
         return n.value
 
     @property
@@ -65,9 +66,10 @@ class Engine:
         return self._L.qm_truth_count(self._h)
 
     # -- one-shot ---------------------------------------------------------------
-    def classify_batch(self, columns, truth_ids, n_bins=256):
+    def classify_batch(self, columns, truth_ids, n_bins=256, alleles=False):
         """columns: list of (pos, ref, alt, qual, flags) per VCF.  Returns a dict of
-        per-VCF results; see qm_classify_batch in include/qmvt.h."""
+        per-VCF results; see qm_classify_batch in include/qmvt.h.  alleles=True: the
+        allele-extended mode (QM_BATCH_ALLELES), position-sorted VCFs only."""
         n_vcf = len(columns)
         sizes = [int(np.asarray(c[0]).shape[0]) for c in columns]
         offs = np.zeros(n_vcf + 1, np.int64)
@@ -82,8 +84,9 @@ class Engine:
         roc = np.zeros((n_vcf, 3, n_bins), np.uint64)
         scal = np.zeros((n_vcf, _lib.QM_N_SCALARS), np.int64)
         glob = np.zeros((max(self.n_truth, 1), 3, n_bins), np.uint64)
-        check(self._L.qm_classify_batch(self._h, n_vcf, _p(offs), _p(pos), _p(ref), _p(alt), _p(qual), _p(flags), _p(tids),
-                                        int(n_bins), _p(cls), _p(roc), _p(scal), _p(idx), _p(glob)), self._h)
+        check(self._L.qm_classify_batch_ext(self._h, n_vcf, _p(offs), _p(pos), _p(ref), _p(alt), _p(qual), _p(flags), _p(tids),
+                                            int(n_bins), _lib.QM_BATCH_ALLELES if alleles else 0, _p(cls), _p(roc), _p(scal),
+                                            _p(idx), _p(glob)), self._h)
         out = []
         for v in range(n_vcf):
             a, b = int(offs[v]), int(offs[v + 1])
@@ -105,14 +108,14 @@ class Engine:
         check(self._L.qm_fp_overlap(self._h, n, _p(offs), _p(pos), _p(ref), _p(alt), _p(reg)), self._h)
         return reg
 
-    def batch(self, n_records, truth_ids, n_bins=256):
-        return Batch(self, n_records, truth_ids, n_bins)
+    def batch(self, n_records, truth_ids, n_bins=256, alleles=False):
+        return Batch(self, n_records, truth_ids, n_bins, alleles)
 
 
 class Batch:
     """Resident batch: columns stay in HBM across runs (qm_batch_*)."""
 
-    def __init__(self, engine, n_records, truth_ids, n_bins=256):
+    def __init__(self, engine, n_records, truth_ids, n_bins=256, alleles=False):
         self.engine = engine
         self._L = engine._L
         self.n_records = _c(n_records, np.int64)
@@ -120,8 +123,9 @@ class Batch:
         self.n_vcf = int(self.n_records.shape[0])
         self.n_bins = int(n_bins)
         h = C.c_void_p()
-        check(self._L.qm_batch_create(engine._h, self.n_vcf, _p(self.n_records), _p(self.truth_ids), self.n_bins,
-                                      C.byref(h)), engine._h)
+        self.alleles = bool(alleles)
+        check(self._L.qm_batch_create_ext(engine._h, self.n_vcf, _p(self.n_records), _p(self.truth_ids), self.n_bins,
+                                          _lib.QM_BATCH_ALLELES if alleles else 0, C.byref(h)), engine._h)
         self._h = h
 
     def close(self):
@@ -144,8 +148,8 @@ class Batch:
             raise ValueError("column length != n_records[%d]" % v)
         self._ck(self._L.qm_batch_upload(self._h, int(v), *[_p(x) for x in a]))
 
-    def synth(self, genome_len, truth_n, truth_seed, seed, shuffled=False):
-        cfg = SynthCfg(int(genome_len), int(seed), int(truth_seed), int(truth_n), int(bool(shuffled)), 0)
+    def synth(self, genome_len, truth_n, truth_seed, seed, shuffled=False, indel_pct=0):
+        cfg = SynthCfg(int(genome_len), int(seed), int(truth_seed), int(truth_n), int(bool(shuffled)), int(indel_pct))
         self._ck(self._L.qm_batch_synth(self._h, C.byref(cfg)))
 
     def set_timing(self, on=True):
