@@ -204,6 +204,7 @@ typedef struct qm_vcf_cols {
   int64_t n_noncanon;   /* kept lines with locale-dependent / non-canonical matching */
   int64_t first_noncanon_line; /* 1-based, 0 = none */
 } qm_vcf_cols;
+typedef struct qm_dict qm_dict;
 int64_t qm_vcf_count_lines(const uint8_t* text, size_t len);
 int qm_vcf_scan(const uint8_t* text, size_t len, int64_t cap_lines, int64_t* line_off /*cap+1*/,
                 uint8_t* line_kind, int32_t* pos, int32_t* ref, int32_t* alt, float* qual, uint8_t* flags,
@@ -214,6 +215,22 @@ int qm_vcf_scan(const uint8_t* text, size_t len, int64_t cap_lines, int64_t* lin
  * [2] = rows with a pattern that can never match canonical lines, [3] = rows refused. */
 int64_t qm_truth_scan(const uint8_t* text, size_t len, int mode, int64_t cap, int32_t* pos, int32_t* ref,
                       int32_t* alt, int64_t* out_counts);
+/* Allele-extended tokenising (QM_BATCH_ALLELES): the filter's `^[ACGT]$` becomes `^[ACGT]+$`, ref / alt
+ * carry allele codes, alleles longer than QM_ALLELE_INLINE_MAX bases are interned in `dict`, which the
+ * truth set and every VCF of a batch must share.  dict == NULL is qm_vcf_scan / qm_truth_scan.
+ * qm_truth_scan_ext takes mode 0 (VCF) only.  qm_dict is thread safe. */
+qm_dict* qm_dict_create(void);
+void qm_dict_destroy(qm_dict* d);
+int64_t qm_dict_size(qm_dict* d);
+/* code of an allele string; QM_ALLELE_NONE unless it is [ACGT]+ (and, beyond 13 bases, d != NULL) */
+int32_t qm_allele_code(qm_dict* d, const uint8_t* s, size_t n);
+/* spelling of a code into out[cap]; returns its length, -1 if the code is no allele / does not fit */
+int64_t qm_allele_spell(qm_dict* d, int32_t code, uint8_t* out, size_t cap);
+int qm_vcf_scan_ext(const uint8_t* text, size_t len, int64_t cap_lines, int64_t* line_off, uint8_t* line_kind,
+                    int32_t* pos, int32_t* ref, int32_t* alt, float* qual, uint8_t* flags, qm_vcf_cols* info,
+                    qm_dict* dict);
+int64_t qm_truth_scan_ext(const uint8_t* text, size_t len, int mode, int64_t cap, int32_t* pos, int32_t* ref,
+                          int32_t* alt, int64_t* out_counts, qm_dict* dict);
 /* Writes header lines + selected data lines, verbatim, newline-terminated
  * (SURVEY Q7).  select: 0 = kept (filtered.vcf), 1 = TP, 2 = FP. */
 int qm_vcf_write(const char* path, const uint8_t* text, size_t len, int64_t n_lines, const int64_t* line_off,

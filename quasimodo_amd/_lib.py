@@ -21,6 +21,7 @@ EXPORTS = (
     "qm_batch_get_roc", "qm_batch_get_scalars", "qm_batch_get_global", "qm_batch_get_columns", "qm_batch_device_bytes",
     "qm_fp_overlap", "qm_vcf_count_lines", "qm_vcf_scan", "qm_truth_scan", "qm_vcf_write", "qm_vcf_split_write",
     "qm_truth_size_ext", "qm_truth_synth_ext", "qm_batch_create_ext", "qm_classify_batch_ext",
+    "qm_dict_create", "qm_dict_destroy", "qm_dict_size", "qm_allele_code", "qm_allele_spell", "qm_vcf_scan_ext", "qm_truth_scan_ext",
 )
 
 
@@ -105,6 +106,19 @@ def lib():
     L.qm_vcf_scan.argtypes = [C.c_char_p, C.c_size_t, i64, vp, vp, vp, vp, vp, vp, vp, C.POINTER(VcfCols)]
     L.qm_truth_scan.argtypes = [C.c_char_p, C.c_size_t, i32, i64, vp, vp, vp, vp]
     L.qm_truth_scan.restype = i64
+    L.qm_vcf_scan_ext.argtypes = [C.c_char_p, C.c_size_t, i64, vp, vp, vp, vp, vp, vp, vp, C.POINTER(VcfCols), vp]
+    L.qm_truth_scan_ext.argtypes = [C.c_char_p, C.c_size_t, i32, i64, vp, vp, vp, vp, vp]
+    L.qm_truth_scan_ext.restype = i64
+    L.qm_dict_create.argtypes = []
+    L.qm_dict_create.restype = vp
+    L.qm_dict_destroy.argtypes = [vp]
+    L.qm_dict_destroy.restype = None
+    L.qm_dict_size.argtypes = [vp]
+    L.qm_dict_size.restype = i64
+    L.qm_allele_code.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.qm_allele_code.restype = i32
+    L.qm_allele_spell.argtypes = [vp, i32, C.c_char_p, C.c_size_t]
+    L.qm_allele_spell.restype = i64
     L.qm_vcf_write.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, i64, vp, vp, vp, i32]
     L.qm_vcf_split_write.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, i32, i32, C.POINTER(C.c_int64)]
     _lib = L

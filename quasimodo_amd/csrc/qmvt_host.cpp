@@ -12,13 +12,22 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include <unistd.h>
 
 #include "../../include/qmvt.h"
+
+// Interned long alleles of the allele-extended mode (include/qmvt.h): id <-> string, thread safe.
+struct qm_dict {
+  std::mutex mu;
+  std::unordered_map<std::string, int32_t> ids;
+  std::vector<std::string> strings;
+};
 
 namespace {
 
@@ -27,7 +36,38 @@ struct Span { const uint8_t* p; size_t n; };
 inline bool acgt1(Span f) { return f.n == 1 && (f.p[0] == 'A' || f.p[0] == 'C' || f.p[0] == 'G' || f.p[0] == 'T'); }
 inline int base_code(uint8_t c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4; }
 inline bool is_dot(Span f) { return f.n == 1 && f.p[0] == '.'; }
+inline bool acgt_all(Span f) {
+  if (f.n == 0) return false;
+  for (size_t i = 0; i < f.n; ++i)
+    if (base_code(f.p[i]) > 3) return false;
+  return true;
+}
+// allele code of an [ACGT]+ field (caller checked): one base, 2..13 inline, longer ones interned
+int32_t allele_code(qm_dict* d, Span f) {
+  if (f.n == 1) return base_code(f.p[0]);
+  if (f.n <= (size_t)QM_ALLELE_INLINE_MAX) {
+    uint32_t c = (uint32_t)f.n << 26;
+    for (size_t k = 0; k < f.n; ++k) c |= (uint32_t)base_code(f.p[k]) << (2 * k);
+    return (int32_t)c;
+  }
+  if (!d) return QM_ALLELE_NONE;
+  std::string key((const char*)f.p, f.n);
+  std::lock_guard<std::mutex> g(d->mu);
+  auto it = d->ids.find(key);
+  if (it != d->ids.end()) return (int32_t)(QM_ALLELE_DICT | it->second);
+  if (d->strings.size() >= (size_t)0x3fffffff) return QM_ALLELE_NONE;
+  const int32_t id = (int32_t)d->strings.size();
+  d->strings.push_back(key);
+  d->ids.emplace(std::move(key), id);
+  return (int32_t)(QM_ALLELE_DICT | id);
+}
 inline bool is_word(uint8_t c) { return (c >= '0' && c <= '9') || (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == '_'; }
+// begins with [ACGT]+ that ends at the field's end or before a non-word character (what `grep -w` needs)
+inline bool acgt_prefix_word(Span f) {
+  size_t k = 0;
+  while (k < f.n && base_code(f.p[k]) <= 3) ++k;
+  return k > 0 && (k == f.n || !is_word(f.p[k]));
+}
 
 // canonical decimal POS: "0" or [1-9][0-9]*, value < 2^28
 inline bool canon_pos(Span f, int32_t* out) {
@@ -160,8 +200,10 @@ struct ScanChunk {
   bool any_pos = false;
 };
 
+// dict != nullptr: allele-extended tokenising -- the filter's `^[ACGT]$` becomes `^[ACGT]+$`
 static void scan_chunk(const uint8_t* text, ScanChunk& c, bool count_only, int64_t* line_off, uint8_t* line_kind, int32_t* pos,
-                       int32_t* ref, int32_t* alt, float* qual, uint8_t* flags) {
+                       int32_t* ref, int32_t* alt, float* qual, uint8_t* flags, qm_dict* dict) {
+  auto allele_ok = [dict](Span f) { return dict ? acgt_all(f) : acgt1(f); };
   int64_t nl = 0, nd = 0;
   int32_t last_pos = 0;
   bool any_pos = false;
@@ -183,7 +225,7 @@ static void scan_chunk(const uint8_t* text, ScanChunk& c, bool count_only, int64
         // reference (once by grep, once by awk) while R's read.table ignores it -- refuse to guess (kind 3)
         uint8_t kind = 1;
         const int nf = split_tabs(s, n, f, MAXF);
-        if (nf >= 5 && acgt1(f[3]) && acgt1(f[4])) {
+        if (nf >= 5 && allele_ok(f[3]) && allele_ok(f[4])) {
           bool ge20 = false;
           const Span empty = {(const uint8_t*)"", 0};
           (void)effective_qual(nf > 5 ? f[5] : empty, &ge20);
@@ -197,7 +239,7 @@ static void scan_chunk(const uint8_t* text, ScanChunk& c, bool count_only, int64
         const Span empty = {(const uint8_t*)"", 0};
         const Span fpos = nf > 1 ? f[1] : empty, fid = nf > 2 ? f[2] : empty, fref = nf > 3 ? f[3] : empty,
                    falt = nf > 4 ? f[4] : empty, fq = nf > 5 ? f[5] : empty;
-        const bool snp = acgt1(fref) && acgt1(falt);
+        const bool snp = allele_ok(fref) && allele_ok(falt);
         bool ge20 = false;
         const float q = effective_qual(fq, &ge20);
         const bool pass = snp && ge20;
@@ -210,7 +252,8 @@ static void scan_chunk(const uint8_t* text, ScanChunk& c, bool count_only, int64
           // pattern X\t.\tY\tZ found at later fields
           for (int k = 6; k + 2 < nfc && !nc; ++k)
             if (is_dot(f[k]) && f[k - 1].n && f[k - 1].p[f[k - 1].n - 1] >= '0' && f[k - 1].p[f[k - 1].n - 1] <= '9' &&
-                f[k + 1].n == 1 && f[k + 2].n >= 1 && (f[k + 2].n == 1 || !is_word(f[k + 2].p[1])))
+                (dict ? acgt_all(f[k + 1]) && acgt_prefix_word(f[k + 2])
+                      : f[k + 1].n == 1 && f[k + 2].n >= 1 && (f[k + 2].n == 1 || !is_word(f[k + 2].p[1]))))
               nc = true;
           if (nf > MAXF) nc = true;
           if (nc) { kind = 2; ++c.nnc; if (!c.first_nc) c.first_nc = gl + 1; }
@@ -218,8 +261,13 @@ static void scan_chunk(const uint8_t* text, ScanChunk& c, bool count_only, int64
         line_kind[gl] = kind;
         if (pos) {
           pos[gd] = p;
-          ref[gd] = fref.n == 1 ? base_code(fref.p[0]) : 4;
-          alt[gd] = falt.n == 1 ? base_code(falt.p[0]) : 4;
+          if (dict) {
+            ref[gd] = acgt_all(fref) ? allele_code(dict, fref) : QM_ALLELE_NONE;
+            alt[gd] = acgt_all(falt) ? allele_code(dict, falt) : QM_ALLELE_NONE;
+          } else {
+            ref[gd] = fref.n == 1 ? base_code(fref.p[0]) : 4;
+            alt[gd] = falt.n == 1 ? base_code(falt.p[0]) : 4;
+          }
           qual[gd] = q;
           flags[gd] = (uint8_t)((pass ? QM_F_PASS : 0u) | (is_dot(fid) ? QM_F_IDDOT : 0u) | (cpos ? 0u : QM_F_NOKEY));
         }
@@ -245,8 +293,9 @@ static int host_threads() {
 // Two passes over whole-line chunks, each pass with one thread per chunk: count, then fill at
 // known offsets.  The only cross-chunk state, the position carried onto records without a
 // comparable POS, is patched for the (few) records that precede a chunk's first canonical POS.
-extern "C" int qm_vcf_scan(const uint8_t* text, size_t len, int64_t cap_lines, int64_t* line_off, uint8_t* line_kind,
-                           int32_t* pos, int32_t* ref, int32_t* alt, float* qual, uint8_t* flags, qm_vcf_cols* info) {
+extern "C" int qm_vcf_scan_ext(const uint8_t* text, size_t len, int64_t cap_lines, int64_t* line_off, uint8_t* line_kind,
+                               int32_t* pos, int32_t* ref, int32_t* alt, float* qual, uint8_t* flags, qm_vcf_cols* info,
+                               qm_dict* dict) {
   if ((!text && len) || !line_off || !line_kind || !info) return QM_E_INVAL;
   int nt = host_threads();
   if (len < (size_t)(1 << 20)) nt = 1;
@@ -264,10 +313,10 @@ extern "C" int qm_vcf_scan(const uint8_t* text, size_t len, int64_t cap_lines, i
     b = e;
   }
   auto run = [&](bool count_only) {
-    if (nt == 1) { scan_chunk(text, ch[0], count_only, line_off, line_kind, pos, ref, alt, qual, flags); return; }
+    if (nt == 1) { scan_chunk(text, ch[0], count_only, line_off, line_kind, pos, ref, alt, qual, flags, dict); return; }
     std::vector<std::thread> th;
     for (int t = 0; t < nt; ++t)
-      th.emplace_back([&, t]() { scan_chunk(text, ch[(size_t)t], count_only, line_off, line_kind, pos, ref, alt, qual, flags); });
+      th.emplace_back([&, t]() { scan_chunk(text, ch[(size_t)t], count_only, line_off, line_kind, pos, ref, alt, qual, flags, dict); });
     for (auto& x : th) x.join();
   };
   run(true);
@@ -292,9 +341,57 @@ extern "C" int qm_vcf_scan(const uint8_t* text, size_t len, int64_t cap_lines, i
   return QM_OK;
 }
 
+extern "C" int qm_vcf_scan(const uint8_t* text, size_t len, int64_t cap_lines, int64_t* line_off, uint8_t* line_kind,
+                           int32_t* pos, int32_t* ref, int32_t* alt, float* qual, uint8_t* flags, qm_vcf_cols* info) {
+  return qm_vcf_scan_ext(text, len, cap_lines, line_off, line_kind, pos, ref, alt, qual, flags, info, nullptr);
+}
+
+extern "C" qm_dict* qm_dict_create(void) { return new qm_dict(); }
+extern "C" void qm_dict_destroy(qm_dict* d) { delete d; }
+extern "C" int64_t qm_dict_size(qm_dict* d) {
+  if (!d) return 0;
+  std::lock_guard<std::mutex> g(d->mu);
+  return (int64_t)d->strings.size();
+}
+extern "C" int32_t qm_allele_code(qm_dict* d, const uint8_t* s, size_t n) {
+  const Span f = {s, n};
+  if (!s || !acgt_all(f)) return QM_ALLELE_NONE;
+  return allele_code(d, f);
+}
+extern "C" int64_t qm_allele_spell(qm_dict* d, int32_t code, uint8_t* out, size_t cap) {
+  static const char B[] = "ACGT";
+  const uint32_t u = (uint32_t)code;
+  if (u < 4u) {
+    if (cap < 1) return -1;
+    out[0] = (uint8_t)B[u];
+    return 1;
+  }
+  if (u >= 0x08000000u && u < (uint32_t)QM_ALLELE_DICT) {
+    const size_t n = u >> 26;
+    if (n < 2 || n > (size_t)QM_ALLELE_INLINE_MAX || cap < n) return -1;
+    for (size_t k = 0; k < n; ++k) out[k] = (uint8_t)B[(u >> (2 * k)) & 3u];
+    return (int64_t)n;
+  }
+  if (u >= (uint32_t)QM_ALLELE_DICT && u < 0x80000000u && d) {
+    std::lock_guard<std::mutex> g(d->mu);
+    const size_t id = u & 0x3fffffffu;
+    if (id >= d->strings.size() || cap < d->strings[id].size()) return -1;
+    memcpy(out, d->strings[id].data(), d->strings[id].size());
+    return (int64_t)d->strings[id].size();
+  }
+  return -1;
+}
+
 extern "C" int64_t qm_truth_scan(const uint8_t* text, size_t len, int mode, int64_t cap, int32_t* pos, int32_t* ref, int32_t* alt,
                                  int64_t* out_counts) {
+  return qm_truth_scan_ext(text, len, mode, cap, pos, ref, alt, out_counts, nullptr);
+}
+
+extern "C" int64_t qm_truth_scan_ext(const uint8_t* text, size_t len, int mode, int64_t cap, int32_t* pos, int32_t* ref, int32_t* alt,
+                                     int64_t* out_counts, qm_dict* dict) {
   if ((!text && len) || (mode != 0 && mode != 1)) return QM_E_INVAL;
+  if (dict && mode != 0) return QM_E_INVAL;   // show-snps tables spell gaps as '.', not as VCF alleles
+  auto allele_ok = [dict](Span f) { return dict ? acgt_all(f) : acgt1(f); };
   int64_t genomediff = 0, nkeys = 0, never = 0, refused = 0;
   size_t off = 0;
   Span f[6];
@@ -311,7 +408,7 @@ extern "C" int64_t qm_truth_scan(const uint8_t* text, size_t len, int mode, int6
     bool pattern;
     if (mode == 0) {  // extract_TP_FP_SNPs.py:47 ; R: caller_performance_compare.R:29-55
       X = f[1]; Y = f[3]; Z = f[4];
-      pattern = acgt1(Y) && acgt1(Z);
+      pattern = allele_ok(Y) && allele_ok(Z);
       if (pattern && !comment) ++genomediff;
     } else {          // extract_TP_FP_SNPs.py:92 ; R: custom_snp_benchmark.R:23-27
       X = f[0]; Y = f[1]; Z = f[2];
@@ -323,7 +420,7 @@ extern "C" int64_t qm_truth_scan(const uint8_t* text, size_t len, int mode, int6
     bool ascii = true;
     for (size_t i = 0; i < n && ascii; ++i) ascii = s[i] != 0 && s[i] < 0x80;
     int32_t p;
-    if (!acgt1(Y) || !acgt1(Z)) { ++never; continue; }   // Y must equal a single-base REF field
+    if (!allele_ok(Y) || !allele_ok(Z)) { ++never; continue; }   // Y must equal a single-base REF field
     if (!canon_pos(X, &p)) {
       // digits with a non-canonical spelling or out of range could match a non-canonical line
       ++never;
@@ -332,7 +429,9 @@ extern "C" int64_t qm_truth_scan(const uint8_t* text, size_t len, int mode, int6
     if (!ascii) { ++refused; continue; }
     if (pos) {
       if (nkeys >= cap) return QM_E_INVAL;
-      pos[nkeys] = p; ref[nkeys] = base_code(Y.p[0]); alt[nkeys] = base_code(Z.p[0]);
+      pos[nkeys] = p;
+      ref[nkeys] = dict ? allele_code(dict, Y) : base_code(Y.p[0]);
+      alt[nkeys] = dict ? allele_code(dict, Z) : base_code(Z.p[0]);
     }
     ++nkeys;
   }

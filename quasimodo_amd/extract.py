@@ -19,7 +19,7 @@ import numpy as np
 
 from ._lib import SCALAR_NAMES, QmvtError
 from .engine import Engine
-from .vcfio import scan_truth, scan_vcf
+from .vcfio import AlleleDict, scan_truth, scan_vcf
 
 
 def is_pure_strain(vcf_file):
@@ -61,16 +61,27 @@ def _strict_default():
     return os.environ.get("QM_LENIENT", "0") in ("", "0")
 
 
-def extract_many(jobs, engine=None, strict=None, n_bins=256):
+def _alleles_default():
+    return os.environ.get("QM_ALLELES", "0") not in ("", "0")
+
+
+def extract_many(jobs, engine=None, strict=None, n_bins=256, alleles=None):
     """Classify and write filtered / tp / fp VCFs for a list of Job.  Returns the jobs
-    with .stats filled (line counts, R-path counts, ROC rows)."""
+    with .stats filled (line counts, R-path counts, ROC rows).
+    alleles=True (or QM_ALLELES=1): the allele-extended mode -- every record whose REF and ALT are
+    [ACGT]+ takes part, not only single bases (a build-defined widening of the reference's filter,
+    include/qmvt.h; hcmv mode and position-sorted VCFs only)."""
     strict = _strict_default() if strict is None else strict
+    alleles = _alleles_default() if alleles is None else bool(alleles)
+    if alleles and any(j.mode != "hcmv" for j in jobs):
+        raise ValueError("the allele-extended mode needs VCF truth sets (hcmv mode)")
+    adict = AlleleDict() if alleles else None
     own = engine is None
     scanned, mixed = [], []
     for j, job in enumerate(jobs):
         _paths(job)
         with open(job.vcf_file, "rb") as fh:
-            sv = scan_vcf(fh.read())
+            sv = scan_vcf(fh.read(), alleles=adict)
         if sv.n_noncanon and strict:
             raise QmvtError(-8, "%s line %d: the reference's answer for this kept line depends on locale or on "
                                 "non-canonical field alignment (non-ASCII bytes, POS not a plain decimal < 2^28, or a "
@@ -89,7 +100,7 @@ def extract_many(jobs, engine=None, strict=None, n_bins=256):
                 key = (os.path.abspath(jobs[j].snp_file), jobs[j].mode)
                 if key not in truth_ids:
                     with open(jobs[j].snp_file, "rb") as fh:
-                        tk = scan_truth(fh.read(), custom=jobs[j].mode == "custom")
+                        tk = scan_truth(fh.read(), custom=jobs[j].mode == "custom", alleles=adict)
                     if tk.n_refused and strict:
                         raise QmvtError(-8, "%s: %d truth rows the engine refuses to guess about (comment rows with a "
                                             "valid pattern or non-ASCII bytes)" % (jobs[j].snp_file, tk.n_refused))
@@ -97,7 +108,7 @@ def extract_many(jobs, engine=None, strict=None, n_bins=256):
                     truth_info[key] = tk
             cols = [scanned[j].columns for j in mixed]
             tids = [truth_ids[(os.path.abspath(jobs[j].snp_file), jobs[j].mode)] for j in mixed]
-            res, _ = engine.classify_batch(cols, tids, n_bins=n_bins)
+            res, _ = engine.classify_batch(cols, tids, n_bins=n_bins, alleles=alleles)
             for j, r in zip(mixed, res):
                 r["genomediff"] = truth_info[(os.path.abspath(jobs[j].snp_file), jobs[j].mode)].genomediff
                 results[j] = r

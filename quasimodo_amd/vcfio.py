@@ -49,7 +49,41 @@ class ScannedVcf:
             raise QmvtError(rc, "cannot write %s" % path)
 
 
-def scan_vcf(text: bytes) -> ScannedVcf:
+class AlleleDict:
+    """Interned long alleles of the allele-extended mode (qm_dict): one per engine run, shared by
+    the truth sets and every VCF classified against them."""
+
+    def __init__(self):
+        self._L = _lib.lib()
+        self._h = self._L.qm_dict_create()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.qm_dict_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(self._L.qm_dict_size(self._h))
+
+    def code(self, allele: bytes) -> int:
+        return int(self._L.qm_allele_code(self._h, allele, len(allele)))
+
+    def spell(self, code: int) -> bytes:
+        buf = C.create_string_buffer(1 << 16)
+        n = int(self._L.qm_allele_spell(self._h, int(code), buf, len(buf)))
+        if n < 0:
+            raise ValueError("not an allele code: %d" % code)
+        return buf.raw[:n]
+
+
+def scan_vcf(text: bytes, alleles: "AlleleDict | None" = None) -> ScannedVcf:
+    """alleles: an AlleleDict switches to allele-extended tokenising (any [ACGT]+ REF / ALT takes part)."""
     L = _lib.lib()
     nl = int(L.qm_vcf_count_lines(text, len(text)))
     cap = nl + 1
@@ -58,8 +92,8 @@ def scan_vcf(text: bytes) -> ScannedVcf:
     pos, ref, alt = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.int32)
     qual, flags = np.zeros(cap, np.float32), np.zeros(cap, np.uint8)
     info = VcfCols()
-    rc = L.qm_vcf_scan(text, len(text), cap, _p(line_off), _p(kind), _p(pos), _p(ref), _p(alt), _p(qual), _p(flags),
-                       C.byref(info))
+    rc = L.qm_vcf_scan_ext(text, len(text), cap, _p(line_off), _p(kind), _p(pos), _p(ref), _p(alt), _p(qual), _p(flags),
+                           C.byref(info), alleles._h if alleles is not None else None)
     if rc < 0:
         raise QmvtError(rc, "qm_vcf_scan failed")
     n, d = int(info.n_lines), int(info.n_data)
@@ -77,14 +111,18 @@ class TruthKeys:
     n_refused: int    # rows the engine refuses to guess about (strict mode)
 
 
-def scan_truth(text: bytes, custom: bool = False) -> TruthKeys:
+def scan_truth(text: bytes, custom: bool = False, alleles: "AlleleDict | None" = None) -> TruthKeys:
     """Truth text -> (pos, ref, alt) key columns.  custom=False: VCF written by
-    mummer2vcf.py (extract_TP_FP_SNPs.py:47); custom=True: show-snps TSV (:92)."""
+    mummer2vcf.py (extract_TP_FP_SNPs.py:47); custom=True: show-snps TSV (:92).
+    alleles: allele-extended keys (VCF truth only)."""
+    if alleles is not None and custom:
+        raise ValueError("allele-extended truth sets come from VCF truth files (show-snps tables spell gaps as '.')")
     L = _lib.lib()
     cap = int(L.qm_vcf_count_lines(text, len(text))) + 1
     pos, ref, alt = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.int32)
     counts = np.zeros(4, np.int64)
-    n = int(L.qm_truth_scan(text, len(text), int(bool(custom)), cap, _p(pos), _p(ref), _p(alt), _p(counts)))
+    n = int(L.qm_truth_scan_ext(text, len(text), int(bool(custom)), cap, _p(pos), _p(ref), _p(alt), _p(counts),
+                                alleles._h if alleles is not None else None))
     if n < 0:
         raise QmvtError(n, "qm_truth_scan failed")
     return TruthKeys(pos[:n].copy(), ref[:n].copy(), alt[:n].copy(), int(counts[0]), int(counts[2]), int(counts[3]))
