@@ -67,9 +67,33 @@ class Engine:
 
     # -- one-shot ---------------------------------------------------------------
     def classify_batch(self, columns, truth_ids, n_bins=256, alleles=False):
-        """columns: list of (pos, ref, alt, qual, flags) per VCF.  Returns a dict of
-        per-VCF results; see qm_classify_batch in include/qmvt.h.  alleles=True: the
-        allele-extended mode (QM_BATCH_ALLELES), position-sorted VCFs only."""
+        """columns: list of (pos, ref, alt, qual, flags) per VCF.  Returns (per-VCF result dicts,
+        per-truth sums): what qm_classify_batch computes (include/qmvt.h), through the resident-batch
+        entry points so that each VCF's arrays are uploaded from where they are (no concatenation).
+        alleles=True: the allele-extended mode (QM_BATCH_ALLELES), position-sorted VCFs only."""
+        n_vcf = len(columns)
+        if n_vcf == 0:
+            return [], np.zeros((max(self.n_truth, 1), 3, n_bins), np.uint64)
+        sizes = [int(np.asarray(c[0]).shape[0]) for c in columns]
+        b = Batch(self, sizes, truth_ids, n_bins, alleles)
+        try:
+            for v, c in enumerate(columns):
+                b.upload(v, *c)
+            b.run()
+            b.finish()
+            roc, scal, glob = b.roc(), b.scalars(), b.global_counts()
+            out = []
+            for v in range(n_vcf):
+                s = dict(zip(SCALAR_NAMES, scal[v].tolist()))
+                reg = b.idx(v)
+                out.append({"cls": b.cls(v), "roc": roc[v].copy(), "scalars": s,
+                            "tp_idx": reg[:s["tp_lines"]].copy(), "fp_idx": reg[sizes[v] - s["fp_lines"]:].copy()})
+        finally:
+            b.close()
+        return out, glob
+
+    def classify_batch_oneshot(self, columns, truth_ids, n_bins=256, alleles=False):
+        """The same through the single C call qm_classify_batch(_ext) on concatenated host buffers."""
         n_vcf = len(columns)
         sizes = [int(np.asarray(c[0]).shape[0]) for c in columns]
         offs = np.zeros(n_vcf + 1, np.int64)

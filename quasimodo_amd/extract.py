@@ -13,6 +13,7 @@ Differences from the reference, all deliberate:
   * fp/ and tp/ are created when missing (the reference relies on Snakemake for fp/).
 """
 import os
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -61,6 +62,14 @@ def _strict_default():
     return os.environ.get("QM_LENIENT", "0") in ("", "0")
 
 
+def _io_threads():
+    try:
+        n = int(os.environ.get("QM_IO_THREADS", "0"))
+    except ValueError:
+        n = 0
+    return n if n > 0 else min(16, os.cpu_count() or 1)
+
+
 def _alleles_default():
     return os.environ.get("QM_ALLELES", "0") not in ("", "0")
 
@@ -78,11 +87,25 @@ def extract_many(jobs, engine=None, strict=None, n_bins=256, alleles=None):
     adict = AlleleDict() if alleles else None
     own = engine is None
     scanned, mixed = [], []
-    for j, job in enumerate(jobs):
+    for job in jobs:
         _paths(job)
+
+    def _scan(job):
         with open(job.vcf_file, "rb") as fh:
-            sv = scan_vcf(fh.read(), alleles=adict)
+            return scan_vcf(fh.read(), alleles=adict)
+
+    # files are read, tokenized and (below) written by a small pool: the library drops the GIL, and
+    # one VCF's scan is itself multi-threaded only when the file is large
+    pool = ThreadPoolExecutor(max(1, min(len(jobs), _io_threads())))
+    try:
+        all_scanned = list(pool.map(_scan, jobs))
+    except BaseException:
+        pool.shutdown()
+        raise
+    for j, job in enumerate(jobs):
+        sv = all_scanned[j]
         if sv.n_noncanon and strict:
+            pool.shutdown()
             raise QmvtError(-8, "%s line %d: the reference's answer for this kept line depends on locale or on "
                                 "non-canonical field alignment (non-ASCII bytes, POS not a plain decimal < 2^28, or a "
                                 "'.' column after QUAL); set QM_LENIENT=1 to classify by the canonical columns"
@@ -112,9 +135,13 @@ def extract_many(jobs, engine=None, strict=None, n_bins=256, alleles=None):
             for j, r in zip(mixed, res):
                 r["genomediff"] = truth_info[(os.path.abspath(jobs[j].snp_file), jobs[j].mode)].genomediff
                 results[j] = r
+        except BaseException:
+            pool.shutdown()
+            raise
         finally:
             if own:
                 engine.close()
+    writes = []
     for j, job in enumerate(jobs):
         sv = scanned[j]
         os.makedirs(os.path.dirname(job.fp_out) or ".", exist_ok=True)
@@ -122,19 +149,22 @@ def extract_many(jobs, engine=None, strict=None, n_bins=256, alleles=None):
             r = results[j]
             cls = r["cls"]
             os.makedirs(os.path.dirname(job.tp_out) or ".", exist_ok=True)
-            sv.write(job.filtered_out, cls, 0)
-            sv.write(job.tp_out, cls, 1)
-            sv.write(job.fp_out, cls, 2)
+            writes += [pool.submit(sv.write, job.filtered_out, cls, 0), pool.submit(sv.write, job.tp_out, cls, 1),
+                       pool.submit(sv.write, job.fp_out, cls, 2)]
             job.stats = dict(r["scalars"])
             job.stats.update(pure_strain=False, genomediff=r["genomediff"], roc=r["roc"])
         else:  # pure strain: fp is a copy of filtered, truth never read (:33-36)
             cls = (sv.flags & 1).astype(np.uint8)
-            sv.write(job.filtered_out, cls, 0)
-            sv.write(job.fp_out, cls, 0)
+            writes += [pool.submit(sv.write, job.filtered_out, cls, 0), pool.submit(sv.write, job.fp_out, cls, 0)]
             job.tp_out = ""
             npass = int(cls.sum())
             job.stats = dict(zip(SCALAR_NAMES, (npass, 0, npass, 0, 0, 1, sv.n_records, 0)))
             job.stats.update(pure_strain=True, genomediff=0, roc=None)
+    try:
+        for w in writes:
+            w.result()          # the first writer error surfaces here
+    finally:
+        pool.shutdown()
     return jobs
 
 

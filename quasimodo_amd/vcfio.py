@@ -87,18 +87,19 @@ def scan_vcf(text: bytes, alleles: "AlleleDict | None" = None) -> ScannedVcf:
     L = _lib.lib()
     nl = int(L.qm_vcf_count_lines(text, len(text)))
     cap = nl + 1
-    line_off = np.zeros(cap + 1, np.int64)
-    kind = np.zeros(cap, np.uint8)
-    pos, ref, alt = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.int32)
-    qual, flags = np.zeros(cap, np.float32), np.zeros(cap, np.uint8)
+    line_off = np.empty(cap + 1, np.int64)
+    kind = np.empty(cap, np.uint8)
+    pos, ref, alt = np.empty(cap, np.int32), np.empty(cap, np.int32), np.empty(cap, np.int32)
+    qual, flags = np.empty(cap, np.float32), np.empty(cap, np.uint8)
     info = VcfCols()
     rc = L.qm_vcf_scan_ext(text, len(text), cap, _p(line_off), _p(kind), _p(pos), _p(ref), _p(alt), _p(qual), _p(flags),
                            C.byref(info), alleles._h if alleles is not None else None)
     if rc < 0:
         raise QmvtError(rc, "qm_vcf_scan failed")
     n, d = int(info.n_lines), int(info.n_data)
-    return ScannedVcf(text, n, line_off[:n + 1].copy(), kind[:n].copy(), pos[:d].copy(), ref[:d].copy(), alt[:d].copy(),
-                      qual[:d].copy(), flags[:d].copy(), int(info.n_noncanon), int(info.first_noncanon_line))
+    # views, not copies: the spare tail of each buffer is a line or two
+    return ScannedVcf(text, n, line_off[:n + 1], kind[:n], pos[:d], ref[:d], alt[:d], qual[:d], flags[:d],
+                      int(info.n_noncanon), int(info.first_noncanon_line))
 
 
 @dataclass

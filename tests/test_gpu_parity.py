@@ -46,6 +46,11 @@ def test_ragged_sorted_batch(engine, oracle, seed):
     res, glob = engine.classify_batch(cols, [tids[w] for w in which])
     for r, c, w in zip(res, cols, which):
         check_vcf(oracle, r, c, truths[w], expect_sorted=True)
+    # the single-call entry point (qm_classify_batch on concatenated host buffers) agrees
+    res1, glob1 = engine.classify_batch_oneshot(cols, [tids[w] for w in which])
+    assert np.array_equal(glob, glob1)
+    for a, b in zip(res, res1):
+        assert a["scalars"] == b["scalars"] and all(np.array_equal(a[k], b[k]) for k in ("cls", "roc", "tp_idx", "fp_idx"))
     # per-truth sums = sum of the ROC rows of the VCFs that use that truth set
     for w in range(2):
         want = sum((r["roc"] for r, ww in zip(res, which) if ww == w), np.zeros((3, 256), np.uint64))

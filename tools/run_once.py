@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Minimal driver for profiling: build one synthetic batch, run the path a few times.
-usage: python3 tools/run_once.py [n_vcf] [runs] [shuffled]"""
+usage: python3 tools/run_once.py [n_vcf] [runs] [shuffled] [indel_pct]
+indel_pct > 0: allele-extended batch of config 5's shape (mixed SNP + indel)"""
 import os
 import sys
 
@@ -10,10 +11,13 @@ import quasimodo_amd as q
 nv = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 shuffled = len(sys.argv) > 3 and sys.argv[3] == "1"
+pct = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+ext = pct != 0          # negative: allele-extended kernel on single-base data
+pct = max(pct, 0)
 eng = q.Engine(0)
-tid = eng.truth_synth(5_000_000, 100_000, 3)
-b = eng.batch([1_000_000] * nv, [tid] * nv)
-b.synth(5_000_000, 100_000, 3, 3000, shuffled=shuffled)
+tid = eng.truth_synth(5_000_000, 100_000, 3, indel_pct=pct)
+b = eng.batch([1_000_000] * nv, [tid] * nv, alleles=ext)
+b.synth(5_000_000, 100_000, 3, 3000, shuffled=shuffled, indel_pct=pct)
 b.set_timing(True)
 for _ in range(runs):
     b.run()
