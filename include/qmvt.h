@@ -46,8 +46,7 @@ extern "C" {
 #define QM_E_STATE (-6)     /* call order violated */
 #define QM_E_IO (-7)
 #define QM_E_NONCANON (-8)  /* text input the engine refuses to guess about (strict mode) */
-#define QM_E_UNSORTED (-9)  /* allele-extended batch: a VCF is not position sorted */
-#define QM_E_LIMIT (-10)    /* allele-extended batch: too many records at one position */
+#define QM_E_LIMIT (-9)     /* allele-extended batch: too many records at one position */
 
 /* ---- allele-extended mode (QM_BATCH_ALLELES) ---------------------------------------------
  * BASELINE.json configs[4] (mixed SNP + indel, variable-length alleles).  The reference drops
@@ -128,8 +127,7 @@ int qm_classify_batch(qm_ctx* ctx, int n_vcf, const int64_t* rec_offsets, const 
                       const int32_t* ref, const int32_t* alt, const float* qual, const uint8_t* flags,
                       const int32_t* truth_id_per_vcf, int n_bins, uint8_t* out_cls, uint64_t* out_roc,
                       int64_t* out_scalars, int32_t* out_idx, uint64_t* out_global);
-/* The same with a batch mode (0 or QM_BATCH_ALLELES).  Allele-extended batches take position-sorted
- * VCFs only (QM_E_UNSORTED otherwise). */
+/* The same with a batch mode (0 or QM_BATCH_ALLELES). */
 int qm_classify_batch_ext(qm_ctx* ctx, int n_vcf, const int64_t* rec_offsets, const int32_t* pos,
                           const int32_t* ref, const int32_t* alt, const float* qual, const uint8_t* flags,
                           const int32_t* truth_id_per_vcf, int n_bins, unsigned mode, uint8_t* out_cls,

@@ -10,7 +10,7 @@ _SO = os.environ.get("QM_LIBQMVT") or os.path.join(_CSRC, "libqmvt.so")   # over
 QM_N_SCALARS = 8
 SCALAR_NAMES = ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R", "sorted", "n_records", "truth_unique")
 ERRORS = {-1: "QM_E_INVAL", -2: "QM_E_NODEVICE", -3: "QM_E_HIP", -4: "QM_E_NOMEM", -5: "QM_E_RANGE",
-          -6: "QM_E_STATE", -7: "QM_E_IO", -8: "QM_E_NONCANON", -9: "QM_E_UNSORTED", -10: "QM_E_LIMIT"}
+          -6: "QM_E_STATE", -7: "QM_E_IO", -8: "QM_E_NONCANON", -9: "QM_E_LIMIT"}
 QM_BATCH_ALLELES = 1
 
 # every symbol include/qmvt.h declares

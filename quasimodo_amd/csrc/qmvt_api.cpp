@@ -349,7 +349,7 @@ static int upload_layout(qm_batch* b) {
 }
 
 static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int32_t* truth_ids, int n_bins, qm_batch** out,
-                       bool packed = false) {
+                       bool packed = false, bool packed_alleles = false) {
   qm_batch* b = new qm_batch();
   b->ctx = c;
   b->n_vcf = n_vcf;
@@ -362,7 +362,10 @@ static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int
   const size_t nt = std::max<size_t>(1, (size_t)c->truths.size());
   int rc = QM_OK;
 #define A_(p, n) if (rc == QM_OK) { rc = dalloc(&(p), (n)); if (rc == QM_OK) b->dev_bytes += (int64_t)((n) * sizeof(*(p))); }
-  if (packed) { A_(b->pkey, np) A_(b->pinf, np) }
+  if (packed) {
+    A_(b->pkey, np) A_(b->pinf, np)
+    if (packed_alleles) { A_(b->ref, np) A_(b->alt, np) }   // sorted copies of the allele codes
+  }
   else { A_(b->pos, np) A_(b->ref, np) A_(b->alt, np) A_(b->qual, np) A_(b->flags, np) }
   A_(b->mask_pass, np / 64 + 64) A_(b->mask_tp, np / 64 + 64) A_(b->idx, np)
   A_(b->tile_tp, b->cap_tiles) A_(b->tile_fp, b->cap_tiles) A_(b->tile_tp_off, b->cap_tiles) A_(b->tile_fp_off, b->cap_tiles)
@@ -564,8 +567,9 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   for (int i = 0; i < nseg; ++i) { sig[(size_t)i] = b->L.vcfs[(size_t)vs[(size_t)i]].n; tids[(size_t)i] = b->L.vcfs[(size_t)vs[(size_t)i]].truth; }
   if (!b->sub || b->sub_sig != sig) {
     if (b->sub) { b->dev_bytes -= b->sub->dev_bytes; batch_free(b->sub); b->sub = nullptr; }
-    int rc = batch_alloc(b->ctx, nseg, sig.data(), tids.data(), b->n_bins, &b->sub, true);
+    int rc = batch_alloc(b->ctx, nseg, sig.data(), tids.data(), b->n_bins, &b->sub, true, b->ext);
     if (rc != QM_OK) return rc;
+    b->sub->ext = b->ext;
     b->dev_bytes += b->sub->dev_bytes;
     b->sub_sig = sig;
   } else {
@@ -617,7 +621,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   // --- 1. records packed to (key, info, original index), 2. stable LSD radix sort by position (key bits 4..31),
   //        only the digits in use; the last pass drops keys and infos straight into the scratch batch
   SortCols src = {b->pos, b->ref, b->alt, b->qual, b->flags};
-  launch_sort_init(b->d_segs, b->d_tile_seg, nst, src, b->n_bins, b->sk[0], b->si[0], b->sv[0], b->sorbits, st);
+  launch_sort_init(b->d_segs, b->d_tile_seg, nst, src, b->n_bins, b->ext ? 1 : 0, b->sk[0], b->si[0], b->sv[0], b->sorbits, st);
   uint32_t orbits = 0;
   HIPCHK(hipMemcpyAsync(&orbits, b->sorbits, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));   // also makes the host tables above safe to free
@@ -631,6 +635,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     cur ^= 1;
   }
   const uint32_t* perm = b->sv[cur];
+  if (b->ext) launch_sort_gather_alleles(b->d_segs, b->d_tile_seg, nst, perm, b->ref, b->alt, s->ref, s->alt, st);
   // --- 3. the normal path on the sorted copies (their ROC rows go into the caller's per-truth sums)
   launch_classify(classify_params(s), (int)s->L.spans.size(), st);
   launch_finalize(finalize_params(s, global), nseg, st);
@@ -662,8 +667,6 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
   std::vector<int> todo;
   for (int v = 0; v < b->n_vcf; ++v) {
     if (fl[(size_t)v] & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", v);
-    if (b->ext && (fl[(size_t)v] & SPANF_UNSORTED))
-      return fail(QM_E_UNSORTED, "VCF %d is not position sorted: allele-extended batches take sorted VCFs only", v);
     if (fl[(size_t)v] & SPANF_RUNLIMIT)
       return fail(QM_E_LIMIT, "VCF %d repeats one position more than %d times between equal alleles (allele-extended de-duplication limit)", v, 1 << 14);
     if (fl[(size_t)v] & SPANF_UNSORTED) todo.push_back(v);

@@ -123,8 +123,9 @@ struct Cols {  // bases of one VCF: the five columns, or the packed pair
 
 template <bool PACKED> struct Raw4;   // one round's loads, still in flight
 template <> struct Raw4<false> { int4 p, r, a; float4 q; uint32_t f; };
-template <> struct Raw4<true> { uint4 k, i; };
+template <> struct Raw4<true> { uint4 k, i; int4 r, a; };   // r / a: allele-extended batches only
 
+template <bool EXT>
 __device__ __forceinline__ void load_raw(const Cols& C, int idx, Raw4<false>& R) {
   R.p = *reinterpret_cast<const int4*>(C.pos + idx);
   R.r = *reinterpret_cast<const int4*>(C.ref + idx);
@@ -132,9 +133,14 @@ __device__ __forceinline__ void load_raw(const Cols& C, int idx, Raw4<false>& R)
   R.q = *reinterpret_cast<const float4*>(C.qual + idx);
   R.f = *reinterpret_cast<const uint32_t*>(C.flags + idx);
 }
+template <bool EXT>
 __device__ __forceinline__ void load_raw(const Cols& C, int idx, Raw4<true>& R) {
   R.k = *reinterpret_cast<const uint4*>(C.pkey + idx);
   R.i = *reinterpret_cast<const uint4*>(C.pinf + idx);
+  if (EXT) {   // the sorted copies of the allele columns (k_sort_gather_alleles)
+    R.r = *reinterpret_cast<const int4*>(C.ref + idx);
+    R.a = *reinterpret_cast<const int4*>(C.alt + idx);
+  }
 }
 
 struct In4 {   // the lane's 4 records of the round, packed
@@ -155,7 +161,10 @@ __device__ __forceinline__ void unpack_raw(const Raw4<false>& R, int nb, In4& X)
 }
 template <bool EXT>
 __device__ __forceinline__ void unpack_raw(const Raw4<true>& R, int, In4& X) {
-  static_assert(!EXT, "allele-extended batches take the column format only");
+  if (EXT) {
+    X.r[0] = R.r.x; X.r[1] = R.r.y; X.r[2] = R.r.z; X.r[3] = R.r.w;
+    X.a[0] = R.a.x; X.a[1] = R.a.y; X.a[2] = R.a.z; X.a[3] = R.a.w;
+  }
   X.key[0] = R.k.x; X.key[1] = R.k.y; X.key[2] = R.k.z; X.key[3] = R.k.w;
   X.inf[0] = R.i.x; X.inf[1] = R.i.y; X.inf[2] = R.i.z; X.inf[3] = R.i.w;
 }
@@ -539,10 +548,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? 2 : K1
   int tb = (int)(sp.begin - vd.off);
   int te = (tb + K1_TILE < sp_end) ? tb + K1_TILE : sp_end;
   Raw4<PACKED> N;
-  load_raw(C, tb + lane * 4, N);
+  load_raw<EXT>(C, tb + lane * 4, N);
 #if K1_PREFETCH == 2
   Raw4<PACKED> N2 = N;
-  if (tb + 256 < sp_end) load_raw(C, tb + 256 + lane * 4, N2);
+  if (tb + 256 < sp_end) load_raw<EXT>(C, tb + 256 + lane * 4, N2);
 #endif
   SegBounds B = seg_bounds<PACKED>(C, tb, te, vn);
   int lo, hi;
@@ -596,9 +605,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? 2 : K1
       // then the following rounds' records into flight (rounds are contiguous across the span's tiles)
 #if K1_PREFETCH == 2
       N = N2;
-      if (rbase + 512 < sp_end) load_raw(C, rbase + 512 + lane * 4, N2);
+      if (rbase + 512 < sp_end) load_raw<EXT>(C, rbase + 512 + lane * 4, N2);
 #else
-      if (rbase + 256 < sp_end) load_raw(C, rbase + 256 + lane * 4, N);
+      if (rbase + 256 < sp_end) load_raw<EXT>(C, rbase + 256 + lane * 4, N);
 #endif
       stage_round<EXT>(lds, X, rbase + lane * 4, te, lane);
       __syncthreads();
@@ -925,7 +934,7 @@ __global__ void k_synth(SynthParams S) {
 // of key = pos, payload = original record index.  Sort tiles are numbered over the chunk;
 // tile_seg maps a tile to its segment.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sort_init(const SortSeg* segs, const int32_t* tile_seg, SortCols src, int n_bins,
+__global__ __launch_bounds__(256) void k_sort_init(const SortSeg* segs, const int32_t* tile_seg, SortCols src, int n_bins, int ext,
                                                    uint32_t* keys, uint32_t* infs, uint32_t* vals, uint32_t* orbits) {
   const SortSeg sg = segs[tile_seg[blockIdx.x]];
   const int64_t base = (int64_t)((int)blockIdx.x - sg.tile0) * SORT_TILE;
@@ -935,7 +944,8 @@ __global__ __launch_bounds__(256) void k_sort_init(const SortSeg* segs, const in
     if (i < sg.n) {
       const int64_t g = sg.src_off + i;
       uint32_t key, inf;
-      pack_record(src.pos[g], src.ref[g], src.alt[g], src.qual[g], src.flags[g], n_bins, key, inf);
+      if (ext) pack_record<true>(src.pos[g], src.ref[g], src.alt[g], src.qual[g], src.flags[g], n_bins, key, inf);
+      else pack_record<false>(src.pos[g], src.ref[g], src.alt[g], src.qual[g], src.flags[g], n_bins, key, inf);
       keys[sg.koff + i] = key;
       infs[sg.koff + i] = inf;
       vals[sg.koff + i] = (uint32_t)i;
@@ -945,6 +955,22 @@ __global__ __launch_bounds__(256) void k_sort_init(const SortSeg* segs, const in
   for (int o = 32; o > 0; o >>= 1) acc |= __shfl_xor(acc, o);
   // the OR saturates after a few tiles: only waves that still add a bit touch the shared word
   if ((threadIdx.x & 63) == 0 && (acc & ~__hip_atomic_load(orbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u) atomicOr(orbits, acc);
+}
+
+// allele-extended batches: the sorted copies also need the allele codes behind the keys
+__global__ __launch_bounds__(256) void k_sort_gather_alleles(const SortSeg* segs, const int32_t* tile_seg, const uint32_t* perm,
+                                                             const int32_t* src_ref, const int32_t* src_alt, int32_t* dst_ref,
+                                                             int32_t* dst_alt) {
+  const SortSeg sg = segs[tile_seg[blockIdx.x]];
+  const int64_t base = (int64_t)((int)blockIdx.x - sg.tile0) * SORT_TILE;
+  for (int k = 0; k < SORT_TILE / 256; ++k) {
+    const int64_t i = base + k * 256 + threadIdx.x;
+    if (i < sg.n) {
+      const int64_t g = sg.src_off + (int64_t)perm[sg.koff + i];
+      dst_ref[sg.dst_off + i] = src_ref[g];
+      dst_alt[sg.dst_off + i] = src_alt[g];
+    }
+  }
 }
 
 // per-tile digit histogram of a segment: hist[hoff + digit * ntiles + tile]
@@ -1164,7 +1190,8 @@ __global__ void k_overlap_count(const uint32_t* keys, const uint32_t* vals, int6
 // ---------------------------------------------------------------------------
 void launch_classify(const ClassifyParams& P, int n_spans, hipStream_t st) {
   if (n_spans <= 0) return;
-  if (P.pkey) hipLaunchKernelGGL((k_classify<true, false>), dim3(n_spans), dim3(64), 0, st, P);
+  if (P.pkey && P.ext) hipLaunchKernelGGL((k_classify<true, true>), dim3(n_spans), dim3(64), 0, st, P);
+  else if (P.pkey) hipLaunchKernelGGL((k_classify<true, false>), dim3(n_spans), dim3(64), 0, st, P);
   else if (P.ext) hipLaunchKernelGGL((k_classify<false, true>), dim3(n_spans), dim3(64), 0, st, P);
   else hipLaunchKernelGGL((k_classify<false, false>), dim3(n_spans), dim3(64), 0, st, P);
 }
@@ -1181,9 +1208,14 @@ void launch_synth(const SynthParams& S, int n_vcf, int64_t max_n, hipStream_t st
   if (n_vcf > 0 && max_n > 0)
     hipLaunchKernelGGL(k_synth, dim3((unsigned)((max_n + 255) / 256), (unsigned)n_vcf), dim3(256), 0, st, S);
 }
-void launch_sort_init(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const SortCols& src, int n_bins, uint32_t* keys,
+void launch_sort_init(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const SortCols& src, int n_bins, int ext, uint32_t* keys,
                       uint32_t* infs, uint32_t* vals, uint32_t* orbits, hipStream_t st) {
-  if (ntiles > 0) hipLaunchKernelGGL(k_sort_init, dim3(ntiles), dim3(256), 0, st, segs, tile_seg, src, n_bins, keys, infs, vals, orbits);
+  if (ntiles > 0) hipLaunchKernelGGL(k_sort_init, dim3(ntiles), dim3(256), 0, st, segs, tile_seg, src, n_bins, ext, keys, infs, vals, orbits);
+}
+void launch_sort_gather_alleles(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const uint32_t* perm, const int32_t* src_ref,
+                                const int32_t* src_alt, int32_t* dst_ref, int32_t* dst_alt, hipStream_t st) {
+  if (ntiles > 0)
+    hipLaunchKernelGGL(k_sort_gather_alleles, dim3(ntiles), dim3(256), 0, st, segs, tile_seg, perm, src_ref, src_alt, dst_ref, dst_alt);
 }
 void launch_sort_pass(const SortSeg* segs, const int32_t* tile_seg, int nseg, int ntiles, const uint32_t* keys, const uint32_t* infs,
                       const uint32_t* vals, int shift, uint32_t* hist, uint32_t* okeys, uint32_t* oinfs, uint32_t* ovals, int final_dst,

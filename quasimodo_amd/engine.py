@@ -70,7 +70,7 @@ class Engine:
         """columns: list of (pos, ref, alt, qual, flags) per VCF.  Returns (per-VCF result dicts,
         per-truth sums): what qm_classify_batch computes (include/qmvt.h), through the resident-batch
         entry points so that each VCF's arrays are uploaded from where they are (no concatenation).
-        alleles=True: the allele-extended mode (QM_BATCH_ALLELES), position-sorted VCFs only."""
+        alleles=True: the allele-extended mode (QM_BATCH_ALLELES)."""
         n_vcf = len(columns)
         if n_vcf == 0:
             return [], np.zeros((max(self.n_truth, 1), 3, n_bins), np.uint64)

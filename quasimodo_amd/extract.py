@@ -79,7 +79,7 @@ def extract_many(jobs, engine=None, strict=None, n_bins=256, alleles=None):
     with .stats filled (line counts, R-path counts, ROC rows).
     alleles=True (or QM_ALLELES=1): the allele-extended mode -- every record whose REF and ALT are
     [ACGT]+ takes part, not only single bases (a build-defined widening of the reference's filter,
-    include/qmvt.h; hcmv mode and position-sorted VCFs only)."""
+    include/qmvt.h; hcmv mode only)."""
     strict = _strict_default() if strict is None else strict
     alleles = _alleles_default() if alleles is None else bool(alleles)
     if alleles and any(j.mode != "hcmv" for j in jobs):

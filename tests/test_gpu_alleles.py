@@ -154,26 +154,37 @@ def test_config5_shape_generated_on_device(engine, oracle):
         b.close()
 
 
-def test_alleles_mode_refuses_unsorted_and_overlong_runs(engine):
+def test_alleles_mode_unsorted_vcfs_take_the_radix_sort_path(engine, oracle):
+    rng = np.random.default_rng(11)
+    L = 40000
+    truth = ext_truth(rng, 3000, L)
+    tid = engine.truth_load(*truth)
+    cols = []
+    for n in (1, 300, 5000, 70001):
+        c = ext_columns(rng, n, L, truth)
+        o = rng.permutation(n)
+        cols.append(tuple(np.ascontiguousarray(a[o]) for a in c))
+    cols.append(ext_columns(rng, 9000, L, truth))            # one sorted VCF in the same batch
+    res, _ = engine.classify_batch(cols, [tid] * len(cols), alleles=True)
+    for i, (r, c) in enumerate(zip(res, cols)):
+        cls, roc, sc = oracle.classify_columns(*c, *truth, ext=True)
+        assert np.array_equal(r["cls"], cls) and np.array_equal(r["roc"], roc)
+        for k in ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R", "truth_unique"):
+            assert r["scalars"][k] == sc[k], (i, k)
+        assert r["scalars"]["sorted"] == sc["sorted"]
+        assert np.array_equal(r["tp_idx"], np.nonzero(cls == 3)[0]) and np.array_equal(r["fp_idx"], np.nonzero(cls == 1)[0])
+
+
+def test_alleles_mode_gives_up_on_overlong_runs(engine):
     from quasimodo_amd import QmvtError
-    rng = np.random.default_rng(9)
     tid = engine.truth_load(np.array([10], np.int32), np.array([0], np.int32), np.array([inline_code("AC")], np.int32))
-    n = 5000
-    pos = rng.integers(1, 100000, size=n).astype(np.int32)       # unsorted
-    ref = np.zeros(n, np.int32)
-    alt = np.full(n, inline_code("ACG"), np.int32)
-    qual = np.full(n, 50, np.float32)
-    flags = np.full(n, 3, np.uint8)
-    with pytest.raises(QmvtError) as e:
-        engine.classify_batch([(pos, ref, alt, qual, flags)], [tid], alleles=True)
-    assert e.value.code == -9
     # 40 000 kept records at one position, all alleles different: the de-duplication walk gives up
     n = 40000
     pos = np.full(n, 77, np.int32)
     alt = ((13 << 26) | np.arange(n)).astype(np.int32)
     with pytest.raises(QmvtError) as e:
         engine.classify_batch([(pos, np.zeros(n, np.int32), alt, np.full(n, 50, np.float32), np.full(n, 3, np.uint8))], [tid], alleles=True)
-    assert e.value.code == -10
+    assert e.value.code == -9
     # the same run with a handful of alleles is fine (walks stay short)
     alt = ((13 << 26) | (np.arange(n) % 7)).astype(np.int32)
     res, _ = engine.classify_batch([(pos, np.zeros(n, np.int32), alt, np.full(n, 50, np.float32), np.full(n, 3, np.uint8))], [tid], alleles=True)
