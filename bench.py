@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--shuffled", action="store_true", help="records permuted: every VCF takes the radix-sort path")
     ap.add_argument("--shuffled-vcfs", type=int, default=int(os.environ.get("QM_BENCH_SHUFFLED_VCFS", "128")),
                     help="also time the shuffled variant (radix-sort path) on this many VCFs at N=1; 0 disables")
+    ap.add_argument("--alleles-vcfs", type=int, default=int(os.environ.get("QM_BENCH_ALLELES_VCFS", "128")),
+                    help="also time the allele-extended variant (config 5 shape: 30 %% indels) on this many VCFs at N=1; 0 disables")
     args = ap.parse_args()
 
     import numpy as np
@@ -193,6 +195,8 @@ def main():
             out["cpu_baseline_shell"] = {"error": str(e)[:200]}
     if rank == 0 and world == 1 and not args.shuffled and args.shuffled_vcfs > 0:
         out["shuffled_variant"] = shuffled_variant(eng, tid, args, min(args.shuffled_vcfs, n_vcf), tseed, roc)
+    if rank == 0 and world == 1 and not args.shuffled and args.alleles_vcfs > 0:
+        out["alleles_variant"] = alleles_variant(eng, args, min(args.alleles_vcfs, n_vcf))
     if rank == 0:
         print(json.dumps(out))
     batch.close()
@@ -224,6 +228,38 @@ def shuffled_variant(eng, tid, args, nv, tseed, sorted_roc):
     return {"value": nv * float(args.records) * steps / dt, "unit": "classifications/s", "vcfs": nv, "steps": steps,
             "ms_per_step": dt / steps * 1e3, "roc_equals_sorted_variant": ok,
             "note": "records permuted: optimistic pass + batched LSD radix sort (8-bit digits) + packed k_classify + scatter back"}
+
+
+def alleles_variant(eng, args, nv):
+    """BASELINE configs[4]'s shape on one GPU: mixed SNP + indel records (30 %) with variable-length
+    alleles, matched exactly in the allele-extended mode (a build-defined widening of the reference's
+    single-base filter).  A side measurement on a subset; VCF 0 is checked against the oracle."""
+    import numpy as np
+    from oracle import qm_oracle as O
+    from oracle.synth import synth_truth_keys
+    pct, tseed = 30, 5
+    tid = eng.truth_synth(args.genome, args.truth, tseed, indel_pct=pct)
+    b = eng.batch([args.records] * nv, [tid] * nv, n_bins=args.bins, alleles=True)
+    b.synth(args.genome, args.truth, tseed, 5000, indel_pct=pct)
+    b.run(); b.finish()
+    b.set_timing(True)
+    steps = 5
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b.run()
+    b.finish()
+    dt = time.perf_counter() - t0
+    tm = b.timings()
+    cols = b.columns(0)
+    cls, roc, sc = O.classify_columns(*cols, *synth_truth_keys(args.genome, args.truth, tseed, pct), n_bins=args.bins, ext=True)
+    ok = bool(np.array_equal(b.cls(0), cls) and np.array_equal(b.roc()[0], roc))
+    t_ext = eng.truth_size(tid, alleles=True)
+    b.close()
+    alg = nv * (17.0 * args.records + 12.0 * t_ext)
+    return {"value": nv * float(args.records) * steps / dt, "unit": "classifications/s", "vcfs": nv, "steps": steps,
+            "ms_per_step": dt / steps * 1e3, "classify_ms": tm["classify_ms"], "classify_GBps": alg / tm["classify_ms"] / 1e6,
+            "indel_pct": pct, "equals_oracle_on_vcf0": ok,
+            "note": "k_classify<false,true>: allele codes staged in LDS beside the keys, (key, ref, alt) equality"}
 
 
 def shell_baseline(batch, args, n_sample, tseed):
@@ -307,6 +343,7 @@ def cpu_baseline(batch, args, n_sample, L, T, tseed):
     # the same sample with one oracle call in flight per host core (ctypes drops the GIL during the call)
     from concurrent.futures import ThreadPoolExecutor
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, len(cols)))   # one VCF per thread: more threads than VCFs would idle
     with ThreadPoolExecutor(cores) as ex:
         t0 = time.perf_counter()
         res2 = list(ex.map(lambda c: O.classify_columns(*c, *truth, n_bins=args.bins), cols))
