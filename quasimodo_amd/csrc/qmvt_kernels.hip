@@ -983,40 +983,66 @@ __global__ __launch_bounds__(256) void k_sort_hist(const SortSeg* segs, const in
   s[tid] = 0;
   __syncthreads();
   const int64_t base = (int64_t)t * SORT_TILE;
-  for (int k = 0; k < SORT_TILE / 256; ++k) {
-    const int64_t i = base + k * 256 + tid;
-    if (i < sg.n) atomicAdd(&s[(keys[sg.koff + i] >> shift) & 255u], 1u);
+  // koff is a multiple of 64 and the chunk arrays are padded to it: whole uint4 loads, tail masked
+  for (int k = 0; k < SORT_TILE / 1024; ++k) {
+    const int64_t i = base + (int64_t)k * 1024 + tid * 4;
+    if (i < sg.n) {
+      const uint4 v = *reinterpret_cast<const uint4*>(keys + sg.koff + i);
+      atomicAdd(&s[(v.x >> shift) & 255u], 1u);
+      if (i + 1 < sg.n) atomicAdd(&s[(v.y >> shift) & 255u], 1u);
+      if (i + 2 < sg.n) atomicAdd(&s[(v.z >> shift) & 255u], 1u);
+      if (i + 3 < sg.n) atomicAdd(&s[(v.w >> shift) & 255u], 1u);
+    }
   }
   __syncthreads();
   hist[sg.hoff + (size_t)tid * sg.ntiles + t] = s[tid];
 }
 
-// exclusive scan over each segment's digit-major histogram (one workgroup per segment)
+// exclusive scan over each segment's digit-major histogram (one workgroup per segment): every
+// thread scans 16 consecutive counters in registers, the 256 thread totals are scanned with wave
+// shuffles, so one round of 4096 counters costs two barriers
 __global__ __launch_bounds__(256) void k_sort_scan(const SortSeg* segs, uint32_t* hist_all) {
-  __shared__ uint32_t s_scan[256];
-  __shared__ uint32_t s_carry;
+  constexpr int PER = 16;
+  __shared__ uint32_t s_wave[4];
   const SortSeg sg = segs[blockIdx.x];
   uint32_t* hist = hist_all + sg.hoff;
-  const int64_t total = (int64_t)sg.ntiles * 256;
+  const int64_t total = (int64_t)sg.ntiles * 256;   // multiple of 256, hoff too: 16-counter runs are whole and 16-byte aligned
   const int tid = (int)threadIdx.x;
-  if (tid == 0) s_carry = 0;
-  __syncthreads();
-  for (int64_t base = 0; base < total; base += 256) {
-    const int64_t t = base + tid;
-    const uint32_t x = t < total ? hist[t] : 0u;
-    s_scan[tid] = x;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {
-      const uint32_t y = tid >= d ? s_scan[tid - d] : 0u;
-      __syncthreads();
-      s_scan[tid] += y;
-      __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  uint32_t carry = 0;
+  for (int64_t base = 0; base < total; base += 256 * PER) {
+    const int64_t i0 = base + (int64_t)tid * PER;
+    const bool in = i0 < total;
+    uint32_t x[PER];
+#pragma unroll
+    for (int q = 0; q < PER / 4; ++q) {
+      uint4 v = in ? *reinterpret_cast<const uint4*>(hist + i0 + 4 * q) : make_uint4(0u, 0u, 0u, 0u);
+      x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
     }
-    const uint32_t incl = s_scan[tid];
-    const uint32_t carry = s_carry;
-    if (t < total) hist[t] = carry + incl - x;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) { const uint32_t t = x[k]; x[k] = sum; sum += t; }   // exclusive inside the run
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_up(incl, o);
+      if (lane >= o) incl += y;
+    }
+    if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
-    if (tid == 255) s_carry = carry + incl;
+    uint32_t woff = 0, btot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const uint32_t t = s_wave[w]; woff += w < wave ? t : 0u; btot += t; }
+    const uint32_t ex = carry + woff + incl - sum;
+    if (in) {
+#pragma unroll
+      for (int q = 0; q < PER / 4; ++q) {
+        uint4 v;
+        v.x = ex + x[4 * q]; v.y = ex + x[4 * q + 1]; v.z = ex + x[4 * q + 2]; v.w = ex + x[4 * q + 3];
+        *reinterpret_cast<uint4*>(hist + i0 + 4 * q) = v;
+      }
+    }
+    carry += btot;
     __syncthreads();
   }
 }
