@@ -217,10 +217,10 @@ constexpr int L_HTP = 0;                                // [257] TP histogram in
 constexpr int L_HFP = 257;                              // [257] FP histogram, same indexing
 constexpr int L_HU = 514;                               // [256] distinct-truth-key histogram indexed by bin
 constexpr int L_TOP = 770;                              // [2][64] per-lane counters of the saturated top bin (TP, FP): real QUALs pile up there
-constexpr int L_KEYS = 900;                             // [2][K1_SLICE] staged truth keys
-constexpr int L_SMAX = L_KEYS + 2 * K1_SLICE;           // [2][K1_SLICE] per key: max(bin + 1) of '.'-ID matches
-constexpr int L_SRF = L_SMAX + 2 * K1_SLICE;            // [2][K1_SLICE / 32] per key: matched by a kept record
-constexpr int L_RKEY = L_SRF + 2 * (K1_SLICE / 32);     // [256] record keys of the round (16-byte aligned)
+constexpr int L_KEYS = 900;                             // [K1_SLICE] staged truth keys of the tile
+constexpr int L_SMAX = L_KEYS + K1_SLICE;               // [K1_SLICE] per key: max(bin + 1) of '.'-ID matches
+constexpr int L_SRF = L_SMAX + K1_SLICE;                // [K1_SLICE / 32] per key: matched by a kept record
+constexpr int L_RKEY = (L_SRF + K1_SLICE / 32 + 3) & ~3;  // [256] record keys of the round (16-byte aligned)
 constexpr int L_RINF = L_RKEY + 256;                    // [128] record infos, u16 each
 constexpr int L_HITS = L_RINF + 128;                    // [8] one bit per record of the round: matched a truth key
 constexpr int L_MASK = L_HITS + 8;                        // [2][32] the tile's kept / TP mask words, stored once per tile
@@ -228,9 +228,9 @@ constexpr int L_TOTAL = L_MASK + 64;
 // allele-extended instantiation only: the allele codes behind the staged keys
 constexpr int L_XRREF = L_TOTAL;                        // [256] record REF codes of the round
 constexpr int L_XRALT = L_XRREF + 256;                  // [256] record ALT codes
-constexpr int L_XSREF = L_XRALT + 256;                  // [2][K1_SLICE] REF codes of the staged truth entries
-constexpr int L_XSALT = L_XSREF + 2 * K1_SLICE;         // [2][K1_SLICE] ALT codes
-constexpr int L_TOTAL_X = L_XSALT + 2 * K1_SLICE;
+constexpr int L_XSREF = L_XRALT + 256;                  // [K1_SLICE] REF codes of the staged truth entries
+constexpr int L_XSALT = L_XSREF + K1_SLICE;             // [K1_SLICE] ALT codes
+constexpr int L_TOTAL_X = L_XSALT + K1_SLICE;
 static_assert(L_XRREF % 4 == 0, "b128 LDS stores need natural alignment");
 static_assert(L_RKEY % 4 == 0 && L_RINF % 2 == 0, "b128 / b64 LDS stores need natural alignment");
 static_assert(K1_ROUNDS == 4, "one store covers the 32 + 32 mask words of a four-round tile");
@@ -242,12 +242,14 @@ struct Slice {
   int m;                // keys staged
 };
 
-__device__ __forceinline__ void slice_select(Slice& S, int buf) {
-  S.keys = L_KEYS + buf * K1_SLICE;
-  S.smax = L_SMAX + buf * K1_SLICE;
-  S.srf = L_SRF + buf * (K1_SLICE / 32);
-  S.ref = L_XSREF + buf * K1_SLICE;
-  S.alt = L_XSALT + buf * K1_SLICE;
+// One slice buffer is enough: the next tile's keys wait in registers (side chain) until the
+// current tile's per-entry state has been flushed.
+__device__ __forceinline__ void slice_select(Slice& S) {
+  S.keys = L_KEYS;
+  S.smax = L_SMAX;
+  S.srf = L_SRF;
+  S.ref = L_XSREF;
+  S.alt = L_XSALT;
 }
 
 template <bool EXT>
@@ -520,9 +522,12 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #ifndef K1_WAVES_PER_EU
 #define K1_WAVES_PER_EU 4
 #endif
+#ifndef K1_WAVES_MAX
+#define K1_WAVES_MAX 4
+#endif
 
 template <bool PACKED, bool EXT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? 2 : K1_WAVES_PER_EU, 8))) void k_classify(ClassifyParams P) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? 2 : K1_WAVES_PER_EU, K1_WAVES_MAX))) void k_classify(ClassifyParams P) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[(EXT ? L_TOTAL_X : L_TOTAL) + K1_LDS_PAD];
 
   const int lane = (int)threadIdx.x;
@@ -556,9 +561,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? 2 : K1
   SegBounds B = seg_bounds<PACKED>(C, tb, te, vn);
   int lo, hi;
   slice_range(tr, B.a, B.b, lo, hi);
-  int buf = 0;
   Slice S;
-  slice_select(S, 0);
+  slice_select(S);
   S.m = (hi - lo) <= K1_SLICE ? (hi - lo) : 0;   // an oversize slice is handled round by round
   stage_slice<EXT>(lds, tr, lo, S, lane);
   __syncthreads();
@@ -682,8 +686,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? 2 : K1
     ++tile;
     lo = nlo;
     hi = nhi;
-    buf ^= 1;
-    slice_select(S, buf);
     S.m = (hi - lo) <= K1_SLICE ? (hi - lo) : 0;
 #pragma unroll
     for (int q = 0; q < K1_SLICE / 64; ++q) {
