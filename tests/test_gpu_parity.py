@@ -289,3 +289,45 @@ def test_cli_dropin(engine, tmp_path):
     assert (d / "fp" / "TA-1-10.AD169.lofreq.fp.vcf").read_bytes() == exp["fp"]
     r = subprocess.run([sys.executable, cli, str(d / "missing.vcf"), "x", "hcmv", str(d), "lofreq"], capture_output=True, text=True)
     assert r.returncode != 0 and "extract_TP_FP_SNPs.py" in r.stderr
+
+
+@pytest.mark.parametrize("shuffled", [False, True], ids=["sorted", "shuffled"])
+def test_maximum_sizes_one_vcf_of_133_million_records_up_to_the_position_limit(engine, shuffled):
+    """Edge of the encoding: positions up to 2^28 - 2^21 (the key uses all 32 bits), one VCF of 1.3e8
+    records (130 048 tiles, 8 128 spans), 2 M truth keys.  Checked with size-independent numpy
+    arithmetic on the device's own columns instead of the (slow) oracle."""
+    from oracle.synth import synth_truth_keys
+    N = (1 << 27) - (1 << 20)
+    L, T = 2 * N, N // 64
+    assert L < (1 << 28)
+    tid = engine.truth_synth(L, T, 9)
+    b = engine.batch([N], [tid])
+    b.synth(L, T, 9, 9000, shuffled=shuffled)
+    b.run()
+    b.finish()
+    pos, ref, alt, qual, flags = b.columns(0)
+    assert int(pos.max()) > (1 << 28) - (1 << 22) and bool((np.diff(pos) > 0).all()) != shuffled
+    tp_, tr_, ta_ = synth_truth_keys(L, T, 9)
+    tkeys = np.sort((tp_.astype(np.uint32) << 4) | (tr_.astype(np.uint32) << 2) | ta_.astype(np.uint32))
+    keys = (pos.astype(np.uint32) << 4) | (ref.astype(np.uint32) << 2) | alt.astype(np.uint32)
+    bitmap = np.zeros(1 << 29, np.uint8)            # one bit per possible key: a vectorised gather also when shuffled
+    np.bitwise_or.at(bitmap, tkeys >> 3, (1 << (tkeys & 7)).astype(np.uint8))
+    hit = ((bitmap[keys >> 3] >> (keys & 7).astype(np.uint8)) & 1).astype(bool)
+    del bitmap
+    kept = (flags & 1).astype(bool)
+    cls = kept.astype(np.uint8) | ((kept & hit).astype(np.uint8) << 1)          # all IDs are '.', all alleles single bases
+    got = b.cls(0)
+    assert np.array_equal(got, cls)
+    sc = dict(zip(("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R", "sorted", "n", "T"), b.scalars()[0].tolist()))
+    assert sc["n_pass"] == int(kept.sum()) and sc["tp_lines"] == int((kept & hit).sum()) and sc["fp_lines"] == int((kept & ~hit).sum())
+    assert sc["TP_R"] == sc["tp_lines"] and sc["FP_R"] == sc["fp_lines"]          # positions are distinct: every key is unique
+    assert sc["sorted"] == int(not shuffled) and sc["n"] == N and sc["T"] == T
+    roc = b.roc()[0]
+    bins = np.clip(qual, 0, 255).astype(np.int64)
+    for t in (0, 20, 100, 255):
+        assert int(roc[0, t]) == int((hit & (bins >= t)).sum()) and int(roc[1, t]) == int((~hit & (bins >= t)).sum())
+        assert int(roc[2, t]) == int(roc[0, t])                                    # one record per truth key at most
+    idx = b.idx(0)
+    assert np.array_equal(idx[:sc["tp_lines"]], np.nonzero(cls == 3)[0].astype(np.int32))
+    assert np.array_equal(idx[N - sc["fp_lines"]:], np.nonzero(cls == 1)[0].astype(np.int32))
+    b.close()
