@@ -331,3 +331,39 @@ def test_maximum_sizes_one_vcf_of_133_million_records_up_to_the_position_limit(e
     assert np.array_equal(idx[:sc["tp_lines"]], np.nonzero(cls == 3)[0].astype(np.int32))
     assert np.array_equal(idx[N - sc["fp_lines"]:], np.nonzero(cls == 1)[0].astype(np.int32))
     b.close()
+
+
+def test_config3_full_size_properties(engine, oracle):
+    """BASELINE configs[2] at its full size on one GPU (1 000 VCFs x 1 M records, 21 GB resident):
+    size-independent properties over all VCFs, the oracle on three of them, idempotence, and order
+    independence of every counter (the same VCFs shuffled, on a subset)."""
+    from oracle.synth import synth_truth_keys
+    L, T, N, NV = 5_000_000, 100_000, 1_000_000, 1000
+    tid = engine.truth_synth(L, T, 3)
+    b = engine.batch([N] * NV, [tid] * NV)
+    b.synth(L, T, 3, 3000)
+    b.run(); b.finish()
+    roc, scal, glob = b.roc(), b.scalars(), b.global_counts()
+    assert (scal[:, 6] == N).all() and (scal[:, 5] == 1).all() and (scal[:, 7] == engine.truth_size(tid)).all()
+    assert np.array_equal(roc[:, 0, 20].astype(np.int64), scal[:, 1]) and np.array_equal(roc[:, 1, 20].astype(np.int64), scal[:, 2])
+    assert (scal[:, 0] == scal[:, 1] + scal[:, 2]).all()
+    assert (np.diff(roc.astype(np.int64), axis=2) <= 0).all()                       # cumulative from the top: non-increasing in t
+    assert (roc[:, 0, 0] + roc[:, 1, 0] == N).all()                                  # every record has a QUAL >= 0 here
+    assert (roc[:, 2, :] <= roc[:, 0, :]).all() and (roc[:, 2, 20].astype(np.int64) == scal[:, 3]).all()   # distinct keys <= TP lines; U(20) = TP_R (all IDs '.')
+    assert np.array_equal(glob[tid], roc.sum(axis=0))
+    truth = synth_truth_keys(L, T, 3)
+    for v in (0, 499, 999):
+        cls, oroc, sc = oracle.classify_columns(*b.columns(v), *truth)
+        assert np.array_equal(b.cls(v), cls) and np.array_equal(roc[v], oroc)
+        assert [int(x) for x in scal[v][:5]] == [sc[k] for k in ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R")]
+    b.run(); b.finish()                                                                # idempotent
+    assert np.array_equal(b.roc(), roc) and np.array_equal(b.scalars(), scal) and np.array_equal(b.global_counts(), glob)
+    b.close()
+    ns = 64
+    s = engine.batch([N] * ns, [tid] * ns)
+    s.synth(L, T, 3, 3000, shuffled=True)
+    s.run(); s.finish()
+    assert np.array_equal(s.roc(), roc[:ns])
+    sc2 = s.scalars()
+    assert np.array_equal(sc2[:, :5], scal[:ns, :5]) and (sc2[:, 5] == 0).all()
+    s.close()
