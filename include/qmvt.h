@@ -158,6 +158,21 @@ int qm_truth_synth(qm_ctx* ctx, int64_t genome_len, int64_t truth_n, uint64_t tr
 int qm_truth_synth_ext(qm_ctx* ctx, int64_t genome_len, int64_t truth_n, uint64_t truth_seed, int indel_pct, int* truth_id);
 int qm_batch_synth(qm_batch* b, const qm_synth_cfg* cfg);
 
+/* One self-contained synthetic run for harnesses that are not Python: truth set +
+ * batch of n_vcf x records_per_vcf generated on the device, one warm-up, `steps` timed runs of the
+ * whole path on the context's stream (wall clock around them; per-kernel times from HIP events). */
+typedef struct qm_bench_result {
+  int64_t records;               /* per step */
+  double seconds_per_step;
+  double classifications_per_s;
+  float classify_ms, finalize_ms, compact_ms;
+  int32_t reserved;
+  int64_t kept, tp_lines, fp_lines;   /* sums over the batch (same every step) */
+  int64_t device_bytes;
+} qm_bench_result;
+int qm_bench_synth(qm_ctx* ctx, const qm_synth_cfg* cfg, int n_vcf, int64_t records_per_vcf, int n_bins, int steps,
+                   qm_bench_result* out);
+
 /* Enqueue the whole path on `stream` (a hipStream_t; NULL = the context's own
  * stream): classify -> finalize (ROC suffix sums, tile offsets, per-truth sums)
  * -> compaction of TP/FP line indices.  Asynchronous.  If global_dev is not

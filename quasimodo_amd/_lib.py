@@ -22,7 +22,14 @@ EXPORTS = (
     "qm_fp_overlap", "qm_vcf_count_lines", "qm_vcf_scan", "qm_truth_scan", "qm_vcf_write", "qm_vcf_split_write",
     "qm_truth_size_ext", "qm_truth_synth_ext", "qm_batch_create_ext", "qm_classify_batch_ext",
     "qm_dict_create", "qm_dict_destroy", "qm_dict_size", "qm_allele_code", "qm_allele_spell", "qm_vcf_scan_ext", "qm_truth_scan_ext",
+    "qm_bench_synth",
 )
+
+
+class BenchResult(C.Structure):
+    _fields_ = [("records", C.c_int64), ("seconds_per_step", C.c_double), ("classifications_per_s", C.c_double),
+                ("classify_ms", C.c_float), ("finalize_ms", C.c_float), ("compact_ms", C.c_float), ("reserved", C.c_int32),
+                ("kept", C.c_int64), ("tp_lines", C.c_int64), ("fp_lines", C.c_int64), ("device_bytes", C.c_int64)]
 
 
 class QmvtError(RuntimeError):
@@ -88,6 +95,7 @@ def lib():
     L.qm_batch_destroy.restype = None
     L.qm_batch_upload.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     L.qm_batch_synth.argtypes = [vp, C.POINTER(SynthCfg)]
+    L.qm_bench_synth.argtypes = [vp, C.POINTER(SynthCfg), i32, i64, i32, i32, C.POINTER(BenchResult)]
     L.qm_batch_run.argtypes = [vp, vp, vp]
     L.qm_batch_finish.argtypes = [vp, vp]
     L.qm_batch_set_timing.argtypes = [vp, i32]

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -804,6 +805,54 @@ extern "C" int qm_classify_batch_ext(qm_ctx* c, int n_vcf, const int64_t* rec_of
   if (rc == QM_OK && out_roc) rc = qm_batch_get_roc(b, out_roc);
   if (rc == QM_OK && out_scalars) rc = qm_batch_get_scalars(b, out_scalars);
   if (rc == QM_OK && out_global) rc = qm_batch_get_global(b, out_global);
+  std::string keep = g_err;
+  qm_batch_destroy(b);
+  g_err = keep;
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
+// self-contained synthetic run (for harnesses that are not Python)
+// ---------------------------------------------------------------------------
+extern "C" int qm_bench_synth(qm_ctx* c, const qm_synth_cfg* cfg, int n_vcf, int64_t records_per_vcf, int n_bins, int steps,
+                              qm_bench_result* out) {
+  if (!c || !cfg || !out || n_vcf <= 0 || records_per_vcf <= 0 || steps <= 0) return fail(QM_E_INVAL, "qm_bench_synth: bad arguments");
+  int tid = -1;
+  int rc = qm_truth_synth_ext(c, cfg->genome_len, cfg->truth_n, cfg->truth_seed, cfg->indel_pct, &tid);
+  if (rc != QM_OK) return rc;
+  std::vector<int64_t> n((size_t)n_vcf, records_per_vcf);
+  std::vector<int32_t> tids((size_t)n_vcf, tid);
+  qm_batch* b = nullptr;
+  rc = qm_batch_create_ext(c, n_vcf, n.data(), tids.data(), n_bins, cfg->indel_pct > 0 ? QM_BATCH_ALLELES : 0u, &b);
+  if (rc != QM_OK) return rc;
+  rc = qm_batch_synth(b, cfg);
+  if (rc == QM_OK) rc = qm_batch_run(b, nullptr, nullptr);      // warm-up, also sorts what needs sorting once
+  if (rc == QM_OK) rc = qm_batch_finish(b, nullptr);
+  if (rc == QM_OK) rc = qm_batch_set_timing(b, 1);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < steps && rc == QM_OK; ++i) {
+    rc = qm_batch_run(b, nullptr, nullptr);
+    if (rc == QM_OK && cfg->shuffled) rc = qm_batch_finish(b, nullptr);
+  }
+  if (rc == QM_OK) rc = qm_batch_finish(b, nullptr);
+  const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  float ms[4] = {0, 0, 0, 0};
+  if (rc == QM_OK) rc = qm_batch_timings(b, ms);
+  if (rc == QM_OK) {
+    std::vector<int64_t> sc((size_t)n_vcf * QM_N_SCALARS);
+    rc = qm_batch_get_scalars(b, sc.data());
+    memset(out, 0, sizeof *out);
+    out->records = (int64_t)n_vcf * records_per_vcf;
+    out->seconds_per_step = sec / steps;
+    out->classifications_per_s = (double)out->records * steps / sec;
+    out->classify_ms = ms[0]; out->finalize_ms = ms[1]; out->compact_ms = ms[2];
+    for (int v = 0; v < n_vcf; ++v) {
+      out->kept += sc[(size_t)v * QM_N_SCALARS + QM_S_NPASS];
+      out->tp_lines += sc[(size_t)v * QM_N_SCALARS + QM_S_TP_LINES];
+      out->fp_lines += sc[(size_t)v * QM_N_SCALARS + QM_S_FP_LINES];
+    }
+    out->device_bytes = qm_batch_device_bytes(b);
+  }
   std::string keep = g_err;
   qm_batch_destroy(b);
   g_err = keep;

@@ -120,6 +120,13 @@ class Engine:
                         "tp_idx": reg[:s["tp_lines"]].copy(), "fp_idx": reg[(b - a) - s["fp_lines"]:].copy()})
         return out, glob
 
+    def bench_synth(self, n_vcf, records, genome_len, truth_n, truth_seed=3, seed=3000, n_bins=256, steps=5, shuffled=False, indel_pct=0):
+        """qm_bench_synth: one self-contained synthetic run inside the library."""
+        cfg = SynthCfg(int(genome_len), int(seed), int(truth_seed), int(truth_n), int(bool(shuffled)), int(indel_pct))
+        r = _lib.BenchResult()
+        check(self._L.qm_bench_synth(self._h, C.byref(cfg), int(n_vcf), int(records), int(n_bins), int(steps), C.byref(r)), self._h)
+        return {k: getattr(r, k) for k, _ in r._fields_ if k != "reserved"}
+
     def fp_overlap(self, key_sets):
         """key_sets: list of (pos, ref, alt) arrays, one per caller.  Returns region
         counts indexed by membership mask (snpcaller_fp_compare.R:36-47)."""

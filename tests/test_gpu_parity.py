@@ -367,3 +367,21 @@ def test_config3_full_size_properties(engine, oracle):
     sc2 = s.scalars()
     assert np.array_equal(sc2[:, :5], scal[:ns, :5]) and (sc2[:, 5] == 0).all()
     s.close()
+
+
+def test_bench_synth_entry_point(engine):
+    """qm_bench_synth (the harness entry point SURVEY.md 8b lists) agrees with the batch API on the same workload"""
+    L, T, N, NV = 5_000_000, 100_000, 1_000_000, 8
+    r = engine.bench_synth(NV, N, L, T, steps=3)
+    tid = engine.truth_synth(L, T, 3)
+    b = engine.batch([N] * NV, [tid] * NV)
+    b.synth(L, T, 3, 3000)
+    b.run(); b.finish()
+    sc = b.scalars()
+    assert (r["kept"], r["tp_lines"], r["fp_lines"]) == (int(sc[:, 0].sum()), int(sc[:, 1].sum()), int(sc[:, 2].sum()))
+    assert r["records"] == NV * N and r["classifications_per_s"] > 1e9 and r["classify_ms"] > 0
+    b.close()
+    rs = engine.bench_synth(4, N, L, T, steps=2, shuffled=True)
+    assert (rs["kept"], rs["tp_lines"]) == (int(sc[:4, 0].sum()), int(sc[:4, 1].sum()))   # VCFs 0..3 of the same seeds, order independent
+    ra = engine.bench_synth(4, N, L, T, steps=2, indel_pct=30, truth_seed=5, seed=5000)
+    assert ra["kept"] > 0 and ra["tp_lines"] > 0
