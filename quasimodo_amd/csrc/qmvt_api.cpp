@@ -147,10 +147,15 @@ static void coarse_index(const std::vector<uint32_t>& keys, int32_t* shift_out, 
 struct XEntry { uint32_t key; int32_t ref, alt; };
 
 // keys: single-base entries; xe: every valid entry (allele-extended batches join against these)
-static int truth_from_keys(qm_ctx* c, std::vector<uint32_t>& keys, std::vector<XEntry>& xe, int* truth_id) {
+static void truth_free(Truth& t) {
+  (void)hipFree(t.d_keys); (void)hipFree(t.d_tidx);
+  (void)hipFree(t.d_xkeys); (void)hipFree(t.d_xref); (void)hipFree(t.d_xalt); (void)hipFree(t.d_xtidx);
+  t = Truth();
+}
+
+static int truth_build(std::vector<uint32_t>& keys, std::vector<XEntry>& xe, Truth& t) {
   std::sort(keys.begin(), keys.end());
   keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
-  Truth t;
   t.n = (int64_t)keys.size();
   std::vector<int32_t> tidx;
   coarse_index(keys, &t.shift, &t.nb, tidx);
@@ -183,9 +188,16 @@ static int truth_from_keys(qm_ctx* c, std::vector<uint32_t>& keys, std::vector<X
     }
     HIPCHK(hipMemcpy(t.d_xtidx, xtidx.data(), xtidx.size() * 4, hipMemcpyHostToDevice));
   }
+  return QM_OK;
+}
+
+static int truth_from_keys(qm_ctx* c, std::vector<uint32_t>& keys, std::vector<XEntry>& xe, int* truth_id) {
+  Truth t;
+  int rc = truth_build(keys, xe, t);
+  if (rc != QM_OK) { truth_free(t); return rc; }   // nothing half-built stays behind
   c->truths.push_back(t);
-  int rc = upload_truth_table(c);
-  if (rc != QM_OK) return rc;
+  rc = upload_truth_table(c);
+  if (rc != QM_OK) { truth_free(c->truths.back()); c->truths.pop_back(); return rc; }
   if (truth_id) *truth_id = (int)c->truths.size() - 1;
   return QM_OK;
 }

@@ -1,5 +1,6 @@
 """Engine / Batch: thin object layer over the C ABI (include/qmvt.h)."""
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -25,9 +26,12 @@ class Engine:
         check(self._L.qm_init(int(device), C.byref(h)))
         self._h = h
         self.device = int(device)
+        self._batches = weakref.WeakSet()   # a batch must not outlive its context (qm_batch_destroy uses it)
 
     def close(self):
         if getattr(self, "_h", None):
+            for b in list(self._batches):
+                b.close()
             self._L.qm_destroy(self._h)
             self._h = None
 
@@ -158,6 +162,7 @@ class Batch:
         check(self._L.qm_batch_create_ext(engine._h, self.n_vcf, _p(self.n_records), _p(self.truth_ids), self.n_bins,
                                           _lib.QM_BATCH_ALLELES if alleles else 0, C.byref(h)), engine._h)
         self._h = h
+        engine._batches.add(self)
 
     def close(self):
         if getattr(self, "_h", None):
