@@ -216,8 +216,7 @@ __device__ __forceinline__ TruthG truth_global(const TruthDev& t) {
 constexpr int L_HTP = 0;                                // [257] TP histogram indexed by bin + 1; slot 0 swallows the uncounted records
 constexpr int L_HFP = 257;                              // [257] FP histogram, same indexing
 constexpr int L_HU = 514;                               // [256] distinct-truth-key histogram indexed by bin
-constexpr int L_TOP = 770;                              // [2][64] per-lane counters of the saturated top bin (TP, FP): real QUALs pile up there
-constexpr int L_KEYS = 900;                             // [K1_SLICE] staged truth keys of the tile
+constexpr int L_KEYS = 772;                             // [K1_SLICE] staged truth keys of the tile
 constexpr int L_SMAX = L_KEYS + K1_SLICE;               // [K1_SLICE] per key: max(bin + 1) of '.'-ID matches
 constexpr int L_SRF = L_SMAX + K1_SLICE;                // [K1_SLICE / 32] per key: matched by a kept record
 constexpr int L_RKEY = (L_SRF + K1_SLICE / 32 + 3) & ~3;  // [256] record keys of the round (16-byte aligned)
@@ -439,6 +438,7 @@ struct Acc {
   uint32_t bad;              // per lane: bit0 order violated, bit1 position out of range, bit2 EXT walk budget exhausted
   uint32_t fpr;              // per lane: distinct kept keys outside the truth set
   uint32_t n_pass, n_tp;     // per lane: kept / TP lines of the current tile
+  uint32_t top_tp, top_fp;   // wave-uniform: records of the saturated top bin (TP, FP)
 };
 
 // inclusive OR over each group of 8 lanes, valid in lanes 8g+7 (DPP row_shr 1,2,4; rows are 16 lanes)
@@ -488,14 +488,20 @@ __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, con
     const int p = (int)(X.key[k] >> 4);   // records beyond the span carry the maximal key: never below, never kept
     A.bad |= (p < pp) ? 1u : 0u;
     cand |= ((p == pp) ? 1u : 0u) << k;
-    // ROC histograms, branch-free: slot = bin + 1 in the TP or FP table (slot 0 swallows records without
-    // a bin); the saturated top bin goes to a per-lane counter so that real, saturated QUALs do not
-    // serialise on one LDS address
+    // ROC histograms: slot = bin + 1 in the TP or FP table (slot 0 swallows records without a bin).
+    // The saturated top bin, where real QUALs pile up, is counted with wave ballots into scalar
+    // registers instead: those lanes sit out the LDS add, so they never serialise on one address.
     if (!(ablate & 2)) {
       const uint32_t b1 = X.inf[k] & I_BIN1;
       const uint32_t notp = ((~tpkey) >> k) & 1u;
-      const uint32_t slot = (b1 == (uint32_t)nb) ? (uint32_t)(L_TOP + lane) + notp * 64u : (uint32_t)L_HTP + notp * 257u + b1;
-      atomicAdd(&lds[slot], 1u);
+      const bool top = b1 == (uint32_t)nb;
+      const uint64_t mtop = ballot64(top);
+      if (mtop) {   // wave-uniform
+        const uint32_t ntp = (uint32_t)popc64(ballot64(top && !notp));
+        A.top_tp += ntp;
+        A.top_fp += (uint32_t)popc64(mtop) - ntp;
+      }
+      if (!top) atomicAdd(&lds[(uint32_t)L_HTP + notp * 257u + b1], 1u);
     }
     pp = p;
   }
@@ -545,7 +551,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? 2 : K1
   const int ablate = P.ablate;
 
   for (int i = lane; i < L_KEYS; i += 64) lds[i] = 0;   // histograms
-  Acc A = {0u, 0u, 0u, 0u};
+  Acc A = {0u, 0u, 0u, 0u, 0u, 0u};
   uint32_t acc_pass = 0, acc_tp = 0;  // wave-uniform
   uint32_t acc_tpr = 0;               // per lane, reduced at the end
 
@@ -706,7 +712,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? 2 : K1
   const uint64_t any_bad = ballot64(A.bad & 2u);
   const uint64_t any_lim = ballot64(A.bad & 4u);
   __syncthreads();
-  const uint32_t top_tp = wave_sum(lds[L_TOP + lane]), top_fp = wave_sum(lds[L_TOP + 64 + lane]);
+  const uint32_t top_tp = A.top_tp, top_fp = A.top_fp;
   uint32_t* oh = P.span_hist + (size_t)blockIdx.x * (3 * 256);
   for (int i = lane; i < 256; i += 64) {
     oh[i] = lds[L_HTP + 1 + i] + (i == nb - 1 ? top_tp : 0u);
