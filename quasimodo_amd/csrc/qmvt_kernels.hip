@@ -158,8 +158,11 @@ __device__ __forceinline__ void load_raw(const Cols& C, int idx, Raw4<false>& R)
 }
 template <bool EXT>
 __device__ __forceinline__ void load_raw(const Cols& C, int idx, Raw4<true>& R) {
-  R.k = *reinterpret_cast<const uint4*>(C.pkey + idx);
-  R.i = *reinterpret_cast<const uint4*>(C.pinf + idx);
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  const v4u vk = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(C.pkey + idx));
+  const v4u vi = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(C.pinf + idx));
+  R.k = make_uint4(vk.x, vk.y, vk.z, vk.w);
+  R.i = make_uint4(vi.x, vi.y, vi.z, vi.w);
   if (EXT) {   // the sorted copies of the allele columns (k_sort_gather_alleles)
     R.r = *reinterpret_cast<const int4*>(C.ref + idx);
     R.a = *reinterpret_cast<const int4*>(C.alt + idx);
@@ -883,7 +886,7 @@ __global__ __launch_bounds__(64) void k_compact(CompactParams P) {
 #pragma unroll
   for (int i = 0; i < K3_REGS; ++i) {
     const int w = i * 64 + lane;
-    rp[i] = w < nwords ? mp[w] : 0ull;
+    rp[i] = w < nwords ? mp[w] : 0ull;   // cached on purpose: non-temporal mask accesses measured slightly slower
     rt[i] = w < nwords ? mt[w] : 0ull;
   }
   // total FP lines of the VCF = offset of its last tile + that tile's count
