@@ -173,6 +173,37 @@ inline int split_tabs(const uint8_t* line, size_t n, Span* f, int maxf) {
   }
   return nf;
 }
+// the first maxf fields only (the tokenizer needs CHROM..QUAL); returns how many it found
+inline int split_head(const uint8_t* line, size_t n, Span* f, int maxf) {
+  if (n == 0) return 0;
+  int nf = 0;
+  const uint8_t* s = line;
+  const uint8_t* end = line + n;
+  while (nf < maxf) {
+    const uint8_t* t = (const uint8_t*)memchr(s, '\t', (size_t)(end - s));
+    f[nf].p = s; f[nf].n = (size_t)((t ? t : end) - s);
+    ++nf;
+    if (!t) break;
+    s = t + 1;
+  }
+  return nf;
+}
+// could a truth pattern X\t.\tY\tZ also be found at later columns?  Walks the fields from QUAL
+// (field 5) to the end of the line with a window of four: (ends in a digit, ".", Y-like, Z-like then non-word).
+bool pattern_at_later_fields(const uint8_t* s, const uint8_t* end, bool ext) {
+  Span w[4] = {{s, 0}, {s, 0}, {s, 0}, {s, 0}};
+  int have = 0;
+  for (;;) {
+    const uint8_t* t = (const uint8_t*)memchr(s, '\t', (size_t)(end - s));
+    w[0] = w[1]; w[1] = w[2]; w[2] = w[3];
+    w[3].p = s; w[3].n = (size_t)((t ? t : end) - s);
+    if (++have >= 4 && is_dot(w[1]) && w[0].n && w[0].p[w[0].n - 1] >= '0' && w[0].p[w[0].n - 1] <= '9' &&
+        (ext ? acgt_all(w[2]) && acgt_prefix_word(w[3]) : w[2].n == 1 && w[3].n >= 1 && (w[3].n == 1 || !is_word(w[3].p[1]))))
+      return true;
+    if (!t) return false;
+    s = t + 1;
+  }
+}
 
 }  // namespace
 
@@ -208,7 +239,7 @@ static void scan_chunk(const uint8_t* text, ScanChunk& c, bool count_only, int64
   int32_t last_pos = 0;
   bool any_pos = false;
   size_t off = c.begin;
-  enum { MAXF = 64 };
+  enum { MAXF = 6 };   // CHROM POS ID REF ALT QUAL
   Span f[MAXF];
   while (off < c.end) {
     const uint8_t* s = text + off;
@@ -224,7 +255,7 @@ static void scan_chunk(const uint8_t* text, ScanChunk& c, bool count_only, int64
         // awk does not skip '#': a header line that also satisfies the A2 filter is emitted twice by the
         // reference (once by grep, once by awk) while R's read.table ignores it -- refuse to guess (kind 3)
         uint8_t kind = 1;
-        const int nf = split_tabs(s, n, f, MAXF);
+        const int nf = split_head(s, n, f, MAXF);
         if (nf >= 5 && allele_ok(f[3]) && allele_ok(f[4])) {
           bool ge20 = false;
           const Span empty = {(const uint8_t*)"", 0};
@@ -234,8 +265,7 @@ static void scan_chunk(const uint8_t* text, ScanChunk& c, bool count_only, int64
         line_kind[gl] = kind;
       } else {
         uint8_t kind = 0;
-        int nf = split_tabs(s, n, f, MAXF);
-        const int nfc = nf < MAXF ? nf : MAXF;
+        const int nf = split_head(s, n, f, MAXF);
         const Span empty = {(const uint8_t*)"", 0};
         const Span fpos = nf > 1 ? f[1] : empty, fid = nf > 2 ? f[2] : empty, fref = nf > 3 ? f[3] : empty,
                    falt = nf > 4 ? f[4] : empty, fq = nf > 5 ? f[5] : empty;
@@ -249,13 +279,7 @@ static void scan_chunk(const uint8_t* text, ScanChunk& c, bool count_only, int64
         if (pass) {
           bool nc = !cpos;  // fgrep compares POS as a string: only canonical spellings are safe
           for (size_t i = 0; i < n && !nc; ++i) nc = s[i] == 0 || s[i] >= 0x80;  // locale-dependent in the reference
-          // pattern X\t.\tY\tZ found at later fields
-          for (int k = 6; k + 2 < nfc && !nc; ++k)
-            if (is_dot(f[k]) && f[k - 1].n && f[k - 1].p[f[k - 1].n - 1] >= '0' && f[k - 1].p[f[k - 1].n - 1] <= '9' &&
-                (dict ? acgt_all(f[k + 1]) && acgt_prefix_word(f[k + 2])
-                      : f[k + 1].n == 1 && f[k + 2].n >= 1 && (f[k + 2].n == 1 || !is_word(f[k + 2].p[1]))))
-              nc = true;
-          if (nf > MAXF) nc = true;
+          if (!nc && nf > 5) nc = pattern_at_later_fields(f[5].p, s + n, dict != nullptr);
           if (nc) { kind = 2; ++c.nnc; if (!c.first_nc) c.first_nc = gl + 1; }
         }
         line_kind[gl] = kind;

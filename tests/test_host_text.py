@@ -255,3 +255,18 @@ def test_splitter_posix_interval_flavour(qmlib, tmp_path):
     assert out2.read_bytes() == out.read_bytes()
     with pytest.raises(ValueError):
         vcfio.split_variants(g, str(out2), "snp")
+
+
+def test_many_sample_columns_are_tokenised_without_a_field_limit(qmlib, oracle):
+    """a 200-sample VCF line is canonical; the same line with a pattern-shaped run of fields (digits, '.', Y, Z)
+    far to the right is the reference's fgrep hazard and is flagged"""
+    from quasimodo_amd import vcfio
+    samples = "\t".join("0/1:%d" % (10 + i) for i in range(200))
+    ok = "c\t100\t.\tA\tG\t50\tPASS\tDP=9\tGT:DP\t" + samples
+    hazard = "c\t200\t.\tA\tG\t50\tPASS\tDP=9\tGT:DP\t" + samples + "\t77\t.\tC\tT\tend"
+    text = ("##x\n#CHROM\n" + ok + "\n" + hazard + "\n").encode()
+    sv = vcfio.scan_vcf(text)
+    assert sv.n_records == 2 and sv.line_kind.tolist() == [1, 1, 0, 2] and sv.n_noncanon == 1 and sv.first_noncanon_line == 4
+    # and the reference mechanism agrees that the hazard is real: truth 77 . C T matches line 2 by its tail
+    f, tp, fp, st = oracle.extract_text(text, b"c\t77\t.\tC\tT\t30\tPASS\tX\n")
+    assert st["tp_lines"] == 1 and tp.count(b"\t200\t") == 1
