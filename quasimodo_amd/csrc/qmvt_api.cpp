@@ -382,7 +382,7 @@ static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int
   else { A_(b->pos, np) A_(b->ref, np) A_(b->alt, np) A_(b->qual, np) A_(b->flags, np) }
   A_(b->mask_pass, np / 64 + 64) A_(b->mask_tp, np / 64 + 64) A_(b->idx, np)
   A_(b->tile_tp, b->cap_tiles) A_(b->tile_fp, b->cap_tiles) A_(b->tile_tp_off, b->cap_tiles) A_(b->tile_fp_off, b->cap_tiles)
-  A_(b->span_hist, b->cap_spans * 768) A_(b->span_scal, b->cap_spans * 8) A_(b->vcf_flags, (size_t)n_vcf)
+  A_(b->span_hist, b->cap_spans * SPAN_HIST_WORDS) A_(b->span_scal, b->cap_spans * 8) A_(b->vcf_flags, (size_t)n_vcf)
   A_(b->roc, (size_t)n_vcf * 3 * (size_t)n_bins) A_(b->global_acc, nt * 3 * (size_t)n_bins) A_(b->scalars, (size_t)n_vcf * 8)
   A_(b->d_vcfs, (size_t)n_vcf) A_(b->d_spans, b->cap_spans) A_(b->d_tile_vcf, b->cap_tiles) A_(b->cls_scratch, (size_t)L.max_n)
 #undef A_

@@ -19,6 +19,8 @@ constexpr int K1_ROUNDS = QM_K1_ROUNDS;      // rounds of 256 records (4 consecu
 constexpr int K1_TILE = 256 * K1_ROUNDS;     // 1024 records: one LDS truth slice, one TP/FP line count
 constexpr int K1_SLICE = QM_K1_SLICE;        // truth keys per LDS slice buffer (two buffers per wave)
 constexpr int SPAN_TILES = QM_SPAN_TILES;    // tiles per wave = per workgroup (one histogram flush per span)
+constexpr int SPAN_HIST_WORDS = 3 * 128;            // per-span TP / FP / U histograms, two u16 bins per dword
+static_assert(QM_SPAN_TILES * 256 * QM_K1_ROUNDS < 65536, "span histograms are u16");
 constexpr int VCF_ALIGN = 256;                     // device start of every VCF (records)
 #ifndef QM_SORT_TILE
 #define QM_SORT_TILE 2048
@@ -93,7 +95,7 @@ struct ClassifyParams {
   uint64_t* mask_tp;
   uint32_t* tile_tp;
   uint32_t* tile_fp;
-  uint32_t* span_hist;  // [n_spans][3][256]
+  uint32_t* span_hist;  // [n_spans][SPAN_HIST_WORDS]
   uint32_t* span_scal;  // [n_spans][8]
   int32_t n_bins;
   int32_t ablate;  // debug only (QM_ABLATE): skip phases to price them; results are wrong when non-zero

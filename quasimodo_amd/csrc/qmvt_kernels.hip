@@ -739,11 +739,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? 2 : K1
   const uint64_t any_lim = ballot64(A.bad & 4u);
   __syncthreads();
   const uint32_t top_tp = A.top_tp, top_fp = A.top_fp;
-  uint32_t* oh = P.span_hist + (size_t)blockIdx.x * (3 * 256);
-  for (int i = lane; i < 256; i += 64) {
-    oh[i] = lds[L_HTP + 1 + i] + (i == nb - 1 ? top_tp : 0u);
-    oh[256 + i] = lds[L_HFP + 1 + i] + (i == nb - 1 ? top_fp : 0u);
-    oh[512 + i] = lds[L_HU + i];
+  // a span holds at most SPAN_TILES * K1_TILE < 65 536 records: two bins per dword (bin 2i low, 2i + 1 high)
+  uint32_t* oh = P.span_hist + (size_t)blockIdx.x * SPAN_HIST_WORDS;
+  for (int i = lane; i < 128; i += 64) {
+    const int b0 = 2 * i, b1 = 2 * i + 1;
+    oh[i] = (lds[L_HTP + 1 + b0] + (b0 == nb - 1 ? top_tp : 0u)) | ((lds[L_HTP + 1 + b1] + (b1 == nb - 1 ? top_tp : 0u)) << 16);
+    oh[128 + i] = (lds[L_HFP + 1 + b0] + (b0 == nb - 1 ? top_fp : 0u)) | ((lds[L_HFP + 1 + b1] + (b1 == nb - 1 ? top_fp : 0u)) << 16);
+    oh[256 + i] = lds[L_HU + b0] | (lds[L_HU + b1] << 16);
   }
   if (lane == 0) {
     uint32_t* sc = P.span_scal + (size_t)blockIdx.x * 8;
@@ -759,7 +761,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? 2 : K1
 __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
   __shared__ uint32_t s_h[3][256];
   __shared__ uint32_t s_scan[256];
-  __shared__ uint32_t s_carry[2];
   const int v = (int)blockIdx.x;
   const int tid = (int)threadIdx.x;
   const VcfDesc vd = P.vcfs[v];
@@ -774,9 +775,10 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
 
   // sum span histograms (thread = bin)
   uint32_t h0 = 0, h1 = 0, h2 = 0;
+  const int hw = tid >> 1, hs = 16 * (tid & 1);   // two u16 bins per dword
   for (int s = 0; s < vd.nspans; ++s) {
-    const uint32_t* sh = P.span_hist + (size_t)(vd.span0 + s) * (3 * 256);
-    h0 += sh[tid]; h1 += sh[256 + tid]; h2 += sh[512 + tid];
+    const uint32_t* sh = P.span_hist + (size_t)(vd.span0 + s) * SPAN_HIST_WORDS;
+    h0 += (sh[hw] >> hs) & 0xffffu; h1 += (sh[128 + hw] >> hs) & 0xffffu; h2 += (sh[256 + hw] >> hs) & 0xffffu;
   }
   s_h[0][tid] = h0; s_h[1][tid] = h1; s_h[2][tid] = h2;
   __syncthreads();
@@ -802,28 +804,43 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
     else if (tid == 6) sc[6] = vd.n;
     else sc[7] = P.ext ? P.truths[vd.truth].xn : P.truths[vd.truth].n;
   }
-  // exclusive scan of the tile counts (TP then FP) over the VCF's tiles
-  for (int which = 0; which < 2; ++which) {
-    const uint32_t* in = which ? P.tile_fp : P.tile_tp;
-    uint32_t* out = which ? P.tile_fp_off : P.tile_tp_off;
-    if (tid == 0) s_carry[which] = 0;
-    __syncthreads();
-    for (int base = 0; base < vd.ntiles; base += 256) {
-      const int t = base + tid;
-      const uint32_t x = t < vd.ntiles ? in[vd.tile0 + t] : 0u;
-      s_scan[tid] = x;
-      __syncthreads();
-      for (int d = 1; d < 256; d <<= 1) {
-        const uint32_t y = tid >= d ? s_scan[tid - d] : 0u;
-        __syncthreads();
-        s_scan[tid] += y;
-        __syncthreads();
+  // exclusive scan of the tile counts (TP and FP together) over the VCF's tiles: four consecutive tiles
+  // per thread in registers, the 256 thread totals with wave shuffles -- two barriers per 1 024 tiles
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t carry_t = 0, carry_f = 0;
+    for (int base = 0; base < vd.ntiles; base += 1024) {
+      const int t0 = base + tid * 4;
+      uint32_t xt[4], xf[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool in = t0 + k < vd.ntiles;
+        xt[k] = in ? P.tile_tp[vd.tile0 + t0 + k] : 0u;
+        xf[k] = in ? P.tile_fp[vd.tile0 + t0 + k] : 0u;
       }
-      const uint32_t incl = s_scan[tid];
-      const uint32_t carry = s_carry[which];
-      if (t < vd.ntiles) out[vd.tile0 + t] = carry + incl - x;
+      const uint32_t st = xt[0] + xt[1] + xt[2] + xt[3], sf = xf[0] + xf[1] + xf[2] + xf[3];
+      uint32_t it = st, jf = sf;   // inclusive over the wave
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t yt = __shfl_up(it, o), yf = __shfl_up(jf, o);
+        if (lane >= o) { it += yt; jf += yf; }
+      }
+      if (lane == 63) { s_scan[wave] = it; s_scan[4 + wave] = jf; }
       __syncthreads();
-      if (tid == 255) s_carry[which] = carry + incl;
+      uint32_t wt = 0, wf = 0, bt = 0, bf = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const uint32_t a = s_scan[w], c = s_scan[4 + w];
+        wt += w < wave ? a : 0u; wf += w < wave ? c : 0u;
+        bt += a; bf += c;
+      }
+      uint32_t et = carry_t + wt + it - st, ef = carry_f + wf + jf - sf;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (t0 + k < vd.ntiles) { P.tile_tp_off[vd.tile0 + t0 + k] = et; P.tile_fp_off[vd.tile0 + t0 + k] = ef; }
+        et += xt[k]; ef += xf[k];
+      }
+      carry_t += bt; carry_f += bf;
       __syncthreads();
     }
   }
