@@ -290,6 +290,7 @@ static void build_layout(const int64_t* n_records, const int32_t* truth_ids, int
       sd.tile0 = d.tile0 + s * SPAN_TILES;
       sd.begin = d.off + (int64_t)s * SPAN_TILES * K1_TILE;
       sd.end = std::min(d.off + d.n, sd.begin + (int64_t)SPAN_TILES * K1_TILE);
+      sd.voff = d.off; sd.vn = (int32_t)d.n; sd.truth = d.truth;
       L.spans.push_back(sd);
     }
     off += (d.n + VCF_ALIGN - 1) / VCF_ALIGN * VCF_ALIGN;
@@ -587,6 +588,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     b->sub_sig = sig;
   } else {
     for (int i = 0; i < nseg; ++i) b->sub->L.vcfs[(size_t)i].truth = tids[(size_t)i];
+    for (SpanDesc& sd : b->sub->L.spans) sd.truth = b->sub->L.vcfs[(size_t)sd.vcf].truth;
     int rc = upload_layout(b->sub);
     if (rc != QM_OK) return rc;
   }

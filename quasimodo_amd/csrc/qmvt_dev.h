@@ -78,6 +78,10 @@ struct SpanDesc {
   int64_t begin, end;  // device record indices, one VCF
   int32_t vcf;
   int32_t tile0;       // global index of the first tile
+  // copies of the VCF's off / n / truth: k_classify starts streaming after ONE descriptor load
+  int64_t voff;
+  int32_t vn;
+  int32_t truth;
 };
 
 struct ClassifyParams {

@@ -564,15 +564,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? 2 : K1
 
   const int lane = (int)threadIdx.x;
   const SpanDesc sp = P.spans[blockIdx.x];
-  const VcfDesc vd = P.vcfs[sp.vcf];
-  const TruthG tr = truth_global<EXT>(P.truths[vd.truth]);
+  const TruthG tr = truth_global<EXT>(P.truths[sp.truth]);
   Cols C;
-  C.pos = P.pos + vd.off; C.ref = P.ref + vd.off; C.alt = P.alt + vd.off; C.qual = P.qual + vd.off; C.flags = P.flags + vd.off;
-  C.pkey = P.pkey + vd.off; C.pinf = P.pinf + vd.off;
-  uint32_t* const mpass32 = reinterpret_cast<uint32_t*>(P.mask_pass + (vd.off >> 6));
-  uint32_t* const mtp32 = reinterpret_cast<uint32_t*>(P.mask_tp + (vd.off >> 6));
-  const int vn = (int)vd.n;
-  const int sp_end = (int)(sp.end - vd.off);
+  C.pos = P.pos + sp.voff; C.ref = P.ref + sp.voff; C.alt = P.alt + sp.voff; C.qual = P.qual + sp.voff; C.flags = P.flags + sp.voff;
+  C.pkey = P.pkey + sp.voff; C.pinf = P.pinf + sp.voff;
+  uint32_t* const mpass32 = reinterpret_cast<uint32_t*>(P.mask_pass + (sp.voff >> 6));
+  uint32_t* const mtp32 = reinterpret_cast<uint32_t*>(P.mask_tp + (sp.voff >> 6));
+  const int vn = sp.vn;
+  const int sp_end = (int)(sp.end - sp.voff);
   const int nb = P.n_bins;
   const int ablate = P.ablate;
 
@@ -582,7 +581,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? 2 : K1
   uint32_t acc_tpr = 0;               // per lane, reduced at the end
 
   // ---- prologue: first round in flight, first tile's bounds and slice -------------
-  int tb = (int)(sp.begin - vd.off);
+  int tb = (int)(sp.begin - sp.voff);
   int te = (tb + K1_TILE < sp_end) ? tb + K1_TILE : sp_end;
   Raw4<PACKED> N;
   load_raw<EXT>(C, tb + lane * 4, N);
