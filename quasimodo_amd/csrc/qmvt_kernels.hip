@@ -540,9 +540,18 @@ __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, con
   }
 }
 
+// sum over the 64 lanes, returned to all of them.  DPP only (no LDS crossbar round trips): xor 1, xor 2
+// within quads, half-row and row mirrors, then the gfx9 row broadcasts carry the row sums to lane 63.
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+#define QM_DPP_ADD(ctrl, rmask) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false)
+  QM_DPP_ADD(0xb1, 0xf);    // quad_perm [1,0,3,2]
+  QM_DPP_ADD(0x4e, 0xf);    // quad_perm [2,3,0,1]
+  QM_DPP_ADD(0x141, 0xf);   // row_half_mirror
+  QM_DPP_ADD(0x140, 0xf);   // row_mirror: every lane holds its row's sum
+  QM_DPP_ADD(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+  QM_DPP_ADD(0x143, 0xc);   // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's sum
+#undef QM_DPP_ADD
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 #ifndef K1_LDS_PAD
