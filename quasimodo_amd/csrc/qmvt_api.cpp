@@ -662,8 +662,12 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   std::vector<uint32_t> sfl((size_t)nseg);
   HIPCHK(hipMemcpyAsync(sfl.data(), s->vcf_flags, 4 * sfl.size(), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
-  for (int i = 0; i < nseg; ++i)
+  for (int i = 0; i < nseg; ++i) {
     if (sfl[(size_t)i] & SPANF_UNSORTED) return fail(QM_E_HIP, "internal: VCF %d still unsorted after the radix sort", vs[(size_t)i]);
+    if (sfl[(size_t)i] & SPANF_RUNLIMIT)
+      return fail(QM_E_LIMIT, "VCF %d repeats one position more than %d times between equal alleles (allele-extended de-duplication limit)",
+                  vs[(size_t)i], 1 << 14);
+  }
   return QM_OK;
 }
 

@@ -185,6 +185,12 @@ def test_alleles_mode_gives_up_on_overlong_runs(engine):
     with pytest.raises(QmvtError) as e:
         engine.classify_batch([(pos, np.zeros(n, np.int32), alt, np.full(n, 50, np.float32), np.full(n, 3, np.uint8))], [tid], alleles=True)
     assert e.value.code == -9
+    # the limit is reported from the radix-sort path too (found by tools/gpu_fuzz.py: it used to be swallowed there)
+    o = np.random.default_rng(3).permutation(n)
+    pos2 = np.where(np.arange(n) % 2 == 0, 77, 5).astype(np.int32)[o]
+    with pytest.raises(QmvtError) as e:
+        engine.classify_batch([(pos2, np.zeros(n, np.int32), alt[o], np.full(n, 50, np.float32), np.full(n, 3, np.uint8))], [tid], alleles=True)
+    assert e.value.code == -9
     # the same run with a handful of alleles is fine (walks stay short)
     alt = ((13 << 26) | (np.arange(n) % 7)).astype(np.int32)
     res, _ = engine.classify_batch([(pos, np.zeros(n, np.int32), alt, np.full(n, 50, np.float32), np.full(n, 3, np.uint8))], [tid], alleles=True)
