@@ -385,3 +385,13 @@ def test_bench_synth_entry_point(engine):
     assert (rs["kept"], rs["tp_lines"]) == (int(sc[:4, 0].sum()), int(sc[:4, 1].sum()))   # VCFs 0..3 of the same seeds, order independent
     ra = engine.bench_synth(4, N, L, T, steps=2, indel_pct=30, truth_seed=5, seed=5000)
     assert ra["kept"] > 0 and ra["tp_lines"] > 0
+
+
+def test_randomised_adversarial_batches(engine):
+    """a short fixed-seed run of tools/gpu_fuzz.py (the long runs are a development tool): runs of equal
+    positions across rounds / tiles / spans, oversize truth slices, unsorted VCFs, few bins, both modes"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gpu_fuzz", os.path.join(os.path.dirname(__file__), "..", "tools", "gpu_fuzz.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.run(60, 5, eng=engine) == 0
