@@ -504,6 +504,7 @@ static CompactParams compact_params(qm_batch* b) {
   CompactParams C;
   C.vcfs = b->d_vcfs; C.spans = b->d_spans; C.mask_pass = b->mask_pass; C.mask_tp = b->mask_tp;
   C.tile_fp = b->tile_fp; C.tile_tp_off = b->tile_tp_off; C.tile_fp_off = b->tile_fp_off; C.idx = b->idx;
+  C.vcf_flags = b->vcf_flags; C.skip_unsorted = 1;
   return C;
 }
 
@@ -722,7 +723,9 @@ static int rescan_and_compact(qm_batch* b, hipStream_t st) {
   FinalizeParams F = finalize_params(b, nullptr);
   F.roc = tmp_roc; F.scalars = tmp_scal; F.vcf_flags = tmp_flags;
   launch_finalize(F, b->n_vcf, st);
-  launch_compact(compact_params(b), (int)b->L.spans.size(), st);
+  CompactParams CP = compact_params(b);
+  CP.skip_unsorted = 0;   // the flags still say 'unsorted' for the VCFs just redone: compact them too
+  launch_compact(CP, (int)b->L.spans.size(), st);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   (void)hipFree(tmp_roc); (void)hipFree(tmp_scal); (void)hipFree(tmp_flags);

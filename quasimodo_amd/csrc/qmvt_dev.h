@@ -132,6 +132,8 @@ struct CompactParams {
   const uint32_t* tile_tp_off;
   const uint32_t* tile_fp_off;
   int32_t* idx;
+  const uint32_t* vcf_flags;   // written by k_finalize of the same run
+  int32_t skip_unsorted;       // 1: leave VCFs flagged unsorted alone (they are redone); 0: compact everything
 };
 
 // one unsorted VCF inside a sort chunk

@@ -718,6 +718,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? 2 : K1
     }
 
     if (!has_next_tile) break;
+    // Out of order: the VCF will be redone through the radix sort and nothing computed here is used
+    // (k_compact skips it, the sort path rewrites its masks, counts and rows) -- stop streaming it.
+    if (!PACKED && ballot64(A.bad & 1u) != 0ull) break;
     // ---- stage the next tile's slice into the other LDS half ----------------------------
     // (a full tile has K1_ROUNDS >= 3 rounds, so the side chain above has run to its end)
     B = NB;
@@ -901,6 +904,8 @@ __global__ __launch_bounds__(64) void k_compact(CompactParams P) {
   __shared__ __attribute__((aligned(16))) uint32_t s_ring[2][K3_RING];
   const int lane = (int)threadIdx.x;
   const SpanDesc sp = P.spans[blockIdx.x];
+  // VCFs found out of order by this run are redone by the sort path: their masks and counts are not meaningful yet
+  if (P.skip_unsorted && (P.vcf_flags[sp.vcf] & SPANF_UNSORTED)) return;
   const VcfDesc vd = P.vcfs[sp.vcf];
   const int sb = (int)(sp.begin - vd.off);
   const int se = (int)(sp.end - vd.off);
