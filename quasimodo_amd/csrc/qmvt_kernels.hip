@@ -1142,6 +1142,8 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
   const int64_t wbase = tbase + (int64_t)wave * (SORT_TILE / 4);
   constexpr int STEPS = SORT_TILE / 4 / 64;
   uint32_t kk[STEPS], vv[STEPS], ii[STEPS], rk[STEPS];
+  // (loads stay inside the ranking loop on purpose: issued all at once up front the kernel was 10 % slower --
+  // the five workgroups of a CU then move in lockstep between a memory phase and a compute phase)
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) {
     const int64_t i = wbase + s * 64 + lane;
@@ -1167,15 +1169,18 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
   // thread d: digit d's count over the 4 waves -> exclusive scan over digits = tile-local run starts
   uint32_t c0 = s_cnt[0][tid], c1 = s_cnt[1][tid], c2 = s_cnt[2][tid], c3 = s_cnt[3][tid];
   const uint32_t tot = c0 + c1 + c2 + c3;
-  s_scan[tid] = tot;
-  __syncthreads();
-  for (int d = 1; d < 256; d <<= 1) {
-    const uint32_t y = tid >= d ? s_scan[tid - d] : 0u;
-    __syncthreads();
-    s_scan[tid] += y;
-    __syncthreads();
+  uint32_t incl = tot;   // inclusive scan over the 256 digits: shuffles inside the wave, one LDS hop across the four
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(incl, o);
+    if (lane >= o) incl += y;
   }
-  const uint32_t loc = s_scan[tid] - tot;
+  if (lane == 63) s_scan[wave] = incl;
+  __syncthreads();
+  uint32_t woff = 0;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) woff += w < wave ? s_scan[w] : 0u;
+  const uint32_t loc = woff + incl - tot;
   s_loc[tid] = loc;
   s_glob[tid] = hist[sg.hoff + (size_t)tid * sg.ntiles + t] - loc;
   // wave w's block inside digit d's run
