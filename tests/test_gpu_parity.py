@@ -395,3 +395,33 @@ def test_randomised_adversarial_batches(engine):
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     assert m.run(60, 5, eng=engine) == 0
+
+
+def test_two_contexts_in_two_threads(oracle):
+    """the ABI promises re-entrancy across distinct contexts: two engines on the same GPU, one thread each"""
+    import threading
+    import quasimodo_amd as q
+    out, errs = {}, []
+
+    def work(k):
+        try:
+            rng = np.random.default_rng(900 + k)
+            eng = q.Engine(0)
+            truth = random_truth(rng, 3000, 100000)
+            tid = eng.truth_load(*truth)
+            for rep in range(4):
+                cols = [random_columns(rng, n, 100000, truth, sorted_=(rep % 2 == 0)) for n in (5000, 20000, 300)]
+                res, _ = eng.classify_batch(cols, [tid] * 3)
+                for r, c in zip(res, cols):
+                    cls, roc, sc = oracle.classify_columns(*c, *truth)
+                    assert np.array_equal(r["cls"], cls) and np.array_equal(r["roc"], roc) and r["scalars"]["FP_R"] == sc["FP_R"]
+            eng.close()
+            out[k] = True
+        except BaseException as e:   # surfaced in the main thread
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    assert out == {0: True, 1: True}
