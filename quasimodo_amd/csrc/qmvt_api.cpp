@@ -326,7 +326,6 @@ struct qm_batch {
   qm_batch* sub = nullptr;               // sorted copies of the chunk's VCFs
   std::vector<int64_t> sub_sig;          // record counts the scratch batch was built for
   uint32_t *sk[2] = {nullptr, nullptr}, *sv[2] = {nullptr, nullptr}, *si[2] = {nullptr, nullptr}, *shist = nullptr, *sorbits = nullptr;
-  uint8_t* scls = nullptr;
   SortSeg* d_segs = nullptr;
   int32_t *d_tile_seg = nullptr, *d_ktile_seg = nullptr, *d_ktile_local = nullptr;
   int64_t cap_sort_n = 0, cap_sort_hist = 0;
@@ -348,7 +347,7 @@ static void batch_free(qm_batch* b) {
   void* ptrs[] = {b->pkey, b->pinf, b->pos, b->ref, b->alt, b->qual, b->flags, b->mask_pass, b->mask_tp, b->idx, b->tile_tp, b->tile_fp,
                   b->tile_tp_off, b->tile_fp_off, b->span_hist, b->span_scal, b->vcf_flags, b->roc, b->global_acc,
                   b->scalars, b->d_vcfs, b->d_spans, b->d_tile_vcf, b->cls_scratch, b->sk[0], b->sk[1], b->sv[0],
-                  b->sv[1], b->si[0], b->si[1], b->shist, b->sorbits, b->scls, b->d_segs, b->d_tile_seg, b->d_ktile_seg, b->d_ktile_local};
+                  b->sv[1], b->si[0], b->si[1], b->shist, b->sorbits, b->d_segs, b->d_tile_seg, b->d_ktile_seg, b->d_ktile_local};
   for (void* p : ptrs) (void)hipFree(p);
   for (auto& r : b->ev) for (auto& e : r) if (e) (void)hipEventDestroy(e);
   delete b;
@@ -617,7 +616,6 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     if (rc == QM_OK) { cap = b->cap_sort_n; rc = regrow(&b->sv[i], &cap, koff, &b->dev_bytes); }
     if (rc == QM_OK) { cap = b->cap_sort_n; rc = regrow(&b->si[i], &cap, koff, &b->dev_bytes); }
   }
-  if (rc == QM_OK) { cap = b->cap_sort_n; rc = regrow(&b->scls, &cap, koff, &b->dev_bytes); }
   if (rc == QM_OK) b->cap_sort_n = std::max(b->cap_sort_n, koff);
   if (rc == QM_OK) rc = regrow(&b->shist, &b->cap_sort_hist, hoff, &b->dev_bytes);
   if (rc == QM_OK) { cap = b->cap_segs; rc = regrow(&b->d_segs, &cap, (int64_t)nseg, &b->dev_bytes); b->cap_segs = (int)cap; }
@@ -637,7 +635,8 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   // --- 1. records packed to (key, info, original index), 2. stable LSD radix sort by position (key bits 4..31),
   //        only the digits in use; the last pass drops keys and infos straight into the scratch batch
   SortCols src = {b->pos, b->ref, b->alt, b->qual, b->flags};
-  launch_sort_init(b->d_segs, b->d_tile_seg, nst, src, b->n_bins, b->ext ? 1 : 0, b->sk[0], b->si[0], b->sv[0], b->sorbits, st);
+  launch_sort_init(b->d_segs, b->d_tile_seg, nst, src, b->n_bins, b->ext ? 1 : 0, b->sk[0], b->si[0], b->sv[0], b->sorbits, b->mask_pass,
+                   b->mask_tp, st);
   uint32_t orbits = 0;
   HIPCHK(hipMemcpyAsync(&orbits, b->sorbits, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));   // also makes the host tables above safe to free
@@ -657,8 +656,8 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   launch_finalize(finalize_params(s, global), nseg, st);
   // --- 4. results back under the original VCFs: ROC + scalar rows, class bits in input order
   launch_sort_copy_rows(b->d_segs, nseg, s->roc, s->scalars, b->roc, b->scalars, b->n_bins, st);
-  launch_sort_scatter_cls(b->d_segs, b->d_tile_seg, nst, s->mask_pass, s->mask_tp, perm, b->scls, st);
-  launch_cls_to_masks(b->d_segs, b->d_ktile_seg, b->d_ktile_local, nkt, b->scls, b->mask_pass, b->mask_tp, b->tile_tp, b->tile_fp, st);
+  launch_sort_scatter_tp(b->d_segs, b->d_tile_seg, nst, s->mask_tp, perm, b->mask_tp, st);
+  launch_tile_counts(b->d_segs, b->d_ktile_seg, b->d_ktile_local, nkt, b->mask_pass, b->mask_tp, b->tile_tp, b->tile_fp, st);
   HIPCHK(hipGetLastError());
   std::vector<uint32_t> sfl((size_t)nseg);
   HIPCHK(hipMemcpyAsync(sfl.data(), s->vcf_flags, 4 * sfl.size(), hipMemcpyDeviceToHost, st));

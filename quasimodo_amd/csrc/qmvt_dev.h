@@ -244,16 +244,16 @@ void launch_compact(const CompactParams& P, int n_spans, hipStream_t st);
 void launch_masks_to_cls(const uint64_t* mp, const uint64_t* mt, int64_t off, int64_t n, uint8_t* cls, hipStream_t st);
 void launch_synth(const SynthParams& S, int n_vcf, int64_t max_n, hipStream_t st);
 void launch_sort_init(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const SortCols& src, int n_bins, int ext, uint32_t* keys,
-                      uint32_t* infs, uint32_t* vals, uint32_t* orbits, hipStream_t st);
+                      uint32_t* infs, uint32_t* vals, uint32_t* orbits, uint64_t* mask_pass, uint64_t* mask_tp, hipStream_t st);
 void launch_sort_gather_alleles(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const uint32_t* perm, const int32_t* src_ref,
                                 const int32_t* src_alt, int32_t* dst_ref, int32_t* dst_alt, hipStream_t st);
 void launch_sort_pass(const SortSeg* segs, const int32_t* tile_seg, int nseg, int ntiles, const uint32_t* keys, const uint32_t* infs,
                       const uint32_t* vals, int shift, uint32_t* hist, uint32_t* okeys, uint32_t* oinfs, uint32_t* ovals, int final_dst,
                       hipStream_t st);
-void launch_sort_scatter_cls(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const uint64_t* mp, const uint64_t* mt,
-                             const uint32_t* perm, uint8_t* cls, hipStream_t st);
-void launch_cls_to_masks(const SortSeg* segs, const int32_t* ktile_seg, const int32_t* ktile_local, int nktiles, const uint8_t* cls,
-                         uint64_t* mp, uint64_t* mt, uint32_t* tile_tp, uint32_t* tile_fp, hipStream_t st);
+void launch_sort_scatter_tp(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const uint64_t* sub_mt, const uint32_t* perm,
+                            uint64_t* mask_tp, hipStream_t st);
+void launch_tile_counts(const SortSeg* segs, const int32_t* ktile_seg, const int32_t* ktile_local, int nktiles, const uint64_t* mp,
+                        const uint64_t* mt, uint32_t* tile_tp, uint32_t* tile_fp, hipStream_t st);
 void launch_sort_copy_rows(const SortSeg* segs, int nseg, const uint64_t* sub_roc, const int64_t* sub_scal, uint64_t* roc,
                            int64_t* scal, int n_bins, hipStream_t st);
 void launch_overlap_pack(const int32_t* pos, const int32_t* ref, const int32_t* alt, const int32_t* set_of, int64_t n,

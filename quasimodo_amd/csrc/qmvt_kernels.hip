@@ -1001,13 +1001,17 @@ __global__ void k_synth(SynthParams S) {
 // of key = pos, payload = original record index.  Sort tiles are numbered over the chunk;
 // tile_seg maps a tile to its segment.
 // ---------------------------------------------------------------------------
+// Also writes the VCF's kept mask in INPUT order (kept = live and PASS needs no truth set) and clears its TP mask:
+// after the join only the TP bits (a few per cent of the records) have to find their way back (k_sort_scatter_tp).
 __global__ __launch_bounds__(256) void k_sort_init(const SortSeg* segs, const int32_t* tile_seg, SortCols src, int n_bins, int ext,
-                                                   uint32_t* keys, uint32_t* infs, uint32_t* vals, uint32_t* orbits) {
+                                                   uint32_t* keys, uint32_t* infs, uint32_t* vals, uint32_t* orbits,
+                                                   uint64_t* mask_pass, uint64_t* mask_tp) {
   const SortSeg sg = segs[tile_seg[blockIdx.x]];
   const int64_t base = (int64_t)((int)blockIdx.x - sg.tile0) * SORT_TILE;
   uint32_t acc = 0;
   for (int k = 0; k < SORT_TILE / 256; ++k) {
     const int64_t i = base + k * 256 + threadIdx.x;
+    bool kept = false;
     if (i < sg.n) {
       const int64_t g = sg.src_off + i;
       uint32_t key, inf;
@@ -1020,6 +1024,13 @@ __global__ __launch_bounds__(256) void k_sort_init(const SortSeg* segs, const in
       nts(infs + sg.koff + i, inf);
       nts(vals + sg.koff + i, (uint32_t)i);
       acc |= key;
+      kept = (inf & I_KEPT) != 0u;
+    }
+    const uint64_t bp = ballot64(kept);
+    const int64_t i0 = i - (int64_t)(threadIdx.x & 63);   // the wave's 64 consecutive records start at a multiple of 64
+    if ((threadIdx.x & 63) == 0 && i0 < sg.n) {
+      mask_pass[(sg.src_off + i0) >> 6] = bp;
+      mask_tp[(sg.src_off + i0) >> 6] = 0ull;
     }
   }
   for (int o = 32; o > 0; o >>= 1) acc |= __shfl_xor(acc, o);
@@ -1207,48 +1218,43 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
   }
 }
 
-// class bits of the sorted scratch VCFs back to input order (one byte per record, chunk-relative)
-__global__ __launch_bounds__(256) void k_sort_scatter_cls(const SortSeg* segs, const int32_t* tile_seg, const uint64_t* mp,
-                                                          const uint64_t* mt, const uint32_t* perm, uint8_t* cls) {
+// TP bits of the sorted scratch VCFs back to input order: only the records that ARE true positives
+// (a few per cent) take the random trip, one 64-bit atomic OR each.
+__global__ __launch_bounds__(256) void k_sort_scatter_tp(const SortSeg* segs, const int32_t* tile_seg, const uint64_t* sub_mt,
+                                                         const uint32_t* perm, uint64_t* mask_tp) {
   const SortSeg sg = segs[tile_seg[blockIdx.x]];
   const int64_t base = (int64_t)((int)blockIdx.x - sg.tile0) * SORT_TILE;
   for (int k = 0; k < SORT_TILE / 256; ++k) {
     const int64_t i = base + k * 256 + threadIdx.x;
     if (i < sg.n) {
       const int64_t g = sg.dst_off + i;
-      const uint32_t p = (uint32_t)((mp[g >> 6] >> (g & 63)) & 1ull);
-      const uint32_t t = (uint32_t)((mt[g >> 6] >> (g & 63)) & 1ull);
-      cls[sg.koff + perm[sg.koff + i]] = (uint8_t)(p | (t << 1));
+      if ((sub_mt[g >> 6] >> (g & 63)) & 1ull) {
+        const int64_t o = sg.src_off + (int64_t)perm[sg.koff + i];
+        atomicOr(reinterpret_cast<unsigned long long*>(mask_tp) + (o >> 6), 1ull << (o & 63));
+      }
     }
   }
 }
 
-// byte-per-record classes -> mask words + per-tile counts of the main batch (input order).
-// One workgroup per K1 tile of an unsorted VCF; ktile_seg maps it to its segment.
-__global__ __launch_bounds__(256) void k_cls_to_masks(const SortSeg* segs, const int32_t* ktile_seg, const int32_t* ktile_local,
-                                                      const uint8_t* cls, uint64_t* mp, uint64_t* mt, uint32_t* tile_tp,
-                                                      uint32_t* tile_fp) {
-  __shared__ uint32_t s_c[2];
-  const SortSeg sg = segs[ktile_seg[blockIdx.x]];
-  const int t = ktile_local[blockIdx.x];
-  const int tid = (int)threadIdx.x;
-  const int lane = tid & 63;
-  if (tid < 2) s_c[tid] = 0;
-  __syncthreads();
+// per-tile TP / FP line counts of the redone VCFs from their rebuilt masks (one thread per K1 tile)
+__global__ __launch_bounds__(256) void k_tile_counts(const SortSeg* segs, const int32_t* ktile_seg, const int32_t* ktile_local, int nktiles,
+                                                     const uint64_t* mp, const uint64_t* mt, uint32_t* tile_tp, uint32_t* tile_fp) {
+  const int kt = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (kt >= nktiles) return;
+  const SortSeg sg = segs[ktile_seg[kt]];
+  const int t = ktile_local[kt];
   const int64_t tb = (int64_t)t * K1_TILE;
-  for (int w = tid >> 6; w < K1_TILE / 64; w += 4) {
-    const int64_t i = tb + w * 64 + lane;
-    const uint8_t c = i < sg.n ? cls[sg.koff + i] : 0;
-    const uint64_t bp = ballot64(c & 1u), bt = ballot64(c & 2u);
-    if (tb + w * 64 < sg.n && lane == 0) {
-      mp[((sg.src_off + tb) >> 6) + w] = bp;
-      mt[((sg.src_off + tb) >> 6) + w] = bt;
-      atomicAdd(&s_c[0], (uint32_t)__popcll(bt));
-      atomicAdd(&s_c[1], (uint32_t)__popcll(bp & ~bt));
+  const int64_t w0 = (sg.src_off + tb) >> 6;
+  uint32_t ntp = 0, nfp = 0;
+  for (int w = 0; w < K1_TILE / 64; ++w) {
+    if (tb + (int64_t)w * 64 < sg.n) {
+      const uint64_t bp = mp[w0 + w], bt = mt[w0 + w];
+      ntp += (uint32_t)__popcll(bt);
+      nfp += (uint32_t)__popcll(bp & ~bt);
     }
   }
-  __syncthreads();
-  if (tid == 0) { tile_tp[sg.main_tile0 + t] = s_c[0]; tile_fp[sg.main_tile0 + t] = s_c[1]; }
+  tile_tp[sg.main_tile0 + t] = ntp;
+  tile_fp[sg.main_tile0 + t] = nfp;
 }
 
 // ROC rows and scalars of the sorted scratch VCFs back under the original VCFs
@@ -1310,8 +1316,10 @@ void launch_synth(const SynthParams& S, int n_vcf, int64_t max_n, hipStream_t st
     hipLaunchKernelGGL(k_synth, dim3((unsigned)((max_n + 255) / 256), (unsigned)n_vcf), dim3(256), 0, st, S);
 }
 void launch_sort_init(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const SortCols& src, int n_bins, int ext, uint32_t* keys,
-                      uint32_t* infs, uint32_t* vals, uint32_t* orbits, hipStream_t st) {
-  if (ntiles > 0) hipLaunchKernelGGL(k_sort_init, dim3(ntiles), dim3(256), 0, st, segs, tile_seg, src, n_bins, ext, keys, infs, vals, orbits);
+                      uint32_t* infs, uint32_t* vals, uint32_t* orbits, uint64_t* mask_pass, uint64_t* mask_tp, hipStream_t st) {
+  if (ntiles > 0)
+    hipLaunchKernelGGL(k_sort_init, dim3(ntiles), dim3(256), 0, st, segs, tile_seg, src, n_bins, ext, keys, infs, vals, orbits, mask_pass,
+                       mask_tp);
 }
 void launch_sort_gather_alleles(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const uint32_t* perm, const int32_t* src_ref,
                                 const int32_t* src_alt, int32_t* dst_ref, int32_t* dst_alt, hipStream_t st) {
@@ -1327,14 +1335,15 @@ void launch_sort_pass(const SortSeg* segs, const int32_t* tile_seg, int nseg, in
   hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(256), 0, st, segs, tile_seg, keys, infs, vals, shift, hist, okeys, oinfs, ovals,
                      final_dst);
 }
-void launch_sort_scatter_cls(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const uint64_t* mp, const uint64_t* mt,
-                             const uint32_t* perm, uint8_t* cls, hipStream_t st) {
-  if (ntiles > 0) hipLaunchKernelGGL(k_sort_scatter_cls, dim3(ntiles), dim3(256), 0, st, segs, tile_seg, mp, mt, perm, cls);
+void launch_sort_scatter_tp(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const uint64_t* sub_mt, const uint32_t* perm,
+                            uint64_t* mask_tp, hipStream_t st) {
+  if (ntiles > 0) hipLaunchKernelGGL(k_sort_scatter_tp, dim3(ntiles), dim3(256), 0, st, segs, tile_seg, sub_mt, perm, mask_tp);
 }
-void launch_cls_to_masks(const SortSeg* segs, const int32_t* ktile_seg, const int32_t* ktile_local, int nktiles, const uint8_t* cls,
-                         uint64_t* mp, uint64_t* mt, uint32_t* tile_tp, uint32_t* tile_fp, hipStream_t st) {
+void launch_tile_counts(const SortSeg* segs, const int32_t* ktile_seg, const int32_t* ktile_local, int nktiles, const uint64_t* mp,
+                        const uint64_t* mt, uint32_t* tile_tp, uint32_t* tile_fp, hipStream_t st) {
   if (nktiles > 0)
-    hipLaunchKernelGGL(k_cls_to_masks, dim3(nktiles), dim3(256), 0, st, segs, ktile_seg, ktile_local, cls, mp, mt, tile_tp, tile_fp);
+    hipLaunchKernelGGL(k_tile_counts, dim3((unsigned)((nktiles + 255) / 256)), dim3(256), 0, st, segs, ktile_seg, ktile_local, nktiles, mp, mt,
+                       tile_tp, tile_fp);
 }
 void launch_sort_copy_rows(const SortSeg* segs, int nseg, const uint64_t* sub_roc, const int64_t* sub_scal, uint64_t* roc,
                            int64_t* scal, int n_bins, hipStream_t st) {
