@@ -632,18 +632,23 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   HIPCHK(hipMemcpyAsync(b->d_ktile_seg, ktile_seg.data(), 4 * ktile_seg.size(), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->d_ktile_local, ktile_local.data(), 4 * ktile_local.size(), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemsetAsync(b->sorbits, 0, 4, st));
-  // --- 1. records packed to (key, info, original index), 2. stable LSD radix sort by position (key bits 4..31),
-  //        only the digits in use; the last pass drops keys and infos straight into the scratch batch
+  // --- 1. + 2. stable LSD radix sort by position (key bits 4..31), only the digits in use.  The first pass packs the
+  //        records to (key, info, original index) on the fly; the last pass drops keys and infos straight into the
+  //        scratch batch.
   SortCols src = {b->pos, b->ref, b->alt, b->qual, b->flags};
-  launch_sort_init(b->d_segs, b->d_tile_seg, nst, src, b->n_bins, b->ext ? 1 : 0, b->sk[0], b->si[0], b->sv[0], b->sorbits, b->mask_pass,
-                   b->mask_tp, st);
+  launch_sort_first_hist(b->d_segs, b->d_tile_seg, nst, b->pos, b->shist, b->sorbits, st);
   uint32_t orbits = 0;
   HIPCHK(hipMemcpyAsync(&orbits, b->sorbits, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));   // also makes the host tables above safe to free
   int npass = 1;
   while (4 + 8 * npass < 32 && (orbits >> (4 + 8 * npass)) != 0) ++npass;
   int cur = 0;
-  for (int ps = 0; ps < npass; ++ps) {
+  {
+    const bool last = npass == 1;
+    launch_sort_first_scatter(b->d_segs, b->d_tile_seg, nseg, nst, src, b->n_bins, b->ext ? 1 : 0, b->shist, last ? s->pkey : b->sk[0],
+                              last ? s->pinf : b->si[0], b->sv[0], last ? 1 : 0, b->mask_pass, b->mask_tp, st);
+  }
+  for (int ps = 1; ps < npass; ++ps) {
     const bool last = ps == npass - 1;
     launch_sort_pass(b->d_segs, b->d_tile_seg, nseg, nst, b->sk[cur], b->si[cur], b->sv[cur], 4 + 8 * ps, b->shist,
                      last ? s->pkey : b->sk[cur ^ 1], last ? s->pinf : b->si[cur ^ 1], b->sv[cur ^ 1], last ? 1 : 0, st);

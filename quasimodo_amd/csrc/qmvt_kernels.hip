@@ -1001,43 +1001,6 @@ __global__ void k_synth(SynthParams S) {
 // of key = pos, payload = original record index.  Sort tiles are numbered over the chunk;
 // tile_seg maps a tile to its segment.
 // ---------------------------------------------------------------------------
-// Also writes the VCF's kept mask in INPUT order (kept = live and PASS needs no truth set) and clears its TP mask:
-// after the join only the TP bits (a few per cent of the records) have to find their way back (k_sort_scatter_tp).
-__global__ __launch_bounds__(256) void k_sort_init(const SortSeg* segs, const int32_t* tile_seg, SortCols src, int n_bins, int ext,
-                                                   uint32_t* keys, uint32_t* infs, uint32_t* vals, uint32_t* orbits,
-                                                   uint64_t* mask_pass, uint64_t* mask_tp) {
-  const SortSeg sg = segs[tile_seg[blockIdx.x]];
-  const int64_t base = (int64_t)((int)blockIdx.x - sg.tile0) * SORT_TILE;
-  uint32_t acc = 0;
-  for (int k = 0; k < SORT_TILE / 256; ++k) {
-    const int64_t i = base + k * 256 + threadIdx.x;
-    bool kept = false;
-    if (i < sg.n) {
-      const int64_t g = sg.src_off + i;
-      uint32_t key, inf;
-      const int32_t p = ntl(src.pos + g), r = ntl(src.ref + g), a = ntl(src.alt + g);
-      const float q = ntl(src.qual + g);
-      const uint32_t f = ntl(src.flags + g);
-      if (ext) pack_record<true>(p, r, a, q, f, n_bins, key, inf);
-      else pack_record<false>(p, r, a, q, f, n_bins, key, inf);
-      nts(keys + sg.koff + i, key);
-      nts(infs + sg.koff + i, inf);
-      nts(vals + sg.koff + i, (uint32_t)i);
-      acc |= key;
-      kept = (inf & I_KEPT) != 0u;
-    }
-    const uint64_t bp = ballot64(kept);
-    const int64_t i0 = i - (int64_t)(threadIdx.x & 63);   // the wave's 64 consecutive records start at a multiple of 64
-    if ((threadIdx.x & 63) == 0 && i0 < sg.n) {
-      mask_pass[(sg.src_off + i0) >> 6] = bp;
-      mask_tp[(sg.src_off + i0) >> 6] = 0ull;
-    }
-  }
-  for (int o = 32; o > 0; o >>= 1) acc |= __shfl_xor(acc, o);
-  // the OR saturates after a few tiles: only waves that still add a bit touch the shared word
-  if ((threadIdx.x & 63) == 0 && (acc & ~__hip_atomic_load(orbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u) atomicOr(orbits, acc);
-}
-
 // allele-extended batches: the sorted copies also need the allele codes behind the keys
 __global__ __launch_bounds__(256) void k_sort_gather_alleles(const SortSeg* segs, const int32_t* tile_seg, const uint32_t* perm,
                                                              const int32_t* src_ref, const int32_t* src_alt, int32_t* dst_ref,
@@ -1055,20 +1018,31 @@ __global__ __launch_bounds__(256) void k_sort_gather_alleles(const SortSeg* segs
 }
 
 // per-tile digit histogram of a segment: hist[hoff + digit * ntiles + tile]
+// FIRST: the first pass reads the position column itself (key bits >= 4 are the position) and also collects the OR of
+// all keys, which tells the host how many digits are in use.
+template <bool FIRST>
 __global__ __launch_bounds__(256) void k_sort_hist(const SortSeg* segs, const int32_t* tile_seg, const uint32_t* keys, int shift,
-                                                   uint32_t* hist) {
+                                                   uint32_t* hist, const int32_t* pos_col, uint32_t* orbits) {
   __shared__ uint32_t s[256];
   const SortSeg sg = segs[tile_seg[blockIdx.x]];
   const int t = (int)blockIdx.x - sg.tile0;
   const int tid = (int)threadIdx.x;
   s[tid] = 0;
+  uint32_t acc = 0;
   __syncthreads();
   const int64_t base = (int64_t)t * SORT_TILE;
   // koff is a multiple of 64 and the chunk arrays are padded to it: whole uint4 loads, tail masked
   for (int k = 0; k < SORT_TILE / 1024; ++k) {
     const int64_t i = base + (int64_t)k * 1024 + tid * 4;
     if (i < sg.n) {
-      const uint4 v = *reinterpret_cast<const uint4*>(keys + sg.koff + i);
+      uint4 v;
+      if (FIRST) {   // every VCF starts on a 256-record boundary of the padded columns: whole uint4 loads here too
+        v = *reinterpret_cast<const uint4*>(pos_col + sg.src_off + i);
+        v.x <<= 4; v.y <<= 4; v.z <<= 4; v.w <<= 4;
+        acc |= v.x | (i + 1 < sg.n ? v.y : 0u) | (i + 2 < sg.n ? v.z : 0u) | (i + 3 < sg.n ? v.w : 0u);
+      } else {
+        v = *reinterpret_cast<const uint4*>(keys + sg.koff + i);
+      }
       atomicAdd(&s[(v.x >> shift) & 255u], 1u);
       if (i + 1 < sg.n) atomicAdd(&s[(v.y >> shift) & 255u], 1u);
       if (i + 2 < sg.n) atomicAdd(&s[(v.z >> shift) & 255u], 1u);
@@ -1077,6 +1051,11 @@ __global__ __launch_bounds__(256) void k_sort_hist(const SortSeg* segs, const in
   }
   __syncthreads();
   hist[sg.hoff + (size_t)tid * sg.ntiles + t] = s[tid];
+  if (FIRST) {
+    for (int o = 32; o > 0; o >>= 1) acc |= __shfl_xor(acc, o);
+    // the OR saturates after a few tiles: only waves that still add a bit touch the shared word
+    if ((tid & 63) == 0 && (acc & ~__hip_atomic_load(orbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u) atomicOr(orbits, acc);
+  }
 }
 
 // exclusive scan over each segment's digit-major histogram (one workgroup per segment): every
@@ -1134,9 +1113,14 @@ __global__ __launch_bounds__(256) void k_sort_scan(const SortSeg* segs, uint32_t
 // ONE contiguous, coalesced write per array instead of dribbling out 4 bytes at a time.
 // `infs` (second payload) may be null; with `final_dst` the keys and infos of the last pass land at the
 // segment's place in the scratch batch (dst_off) instead of the chunk arrays (koff).
+// FIRST: the first pass packs its (key, info, index) triples straight from the columns -- there is no separate
+// packing pass -- and, having every record's info in hand in INPUT order, writes the VCF's kept mask (kept = live
+// and PASS needs no truth set) and clears its TP mask: after the join only the TP bits travel back.
+template <bool FIRST>
 __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const int32_t* tile_seg, const uint32_t* keys,
                                                       const uint32_t* infs, const uint32_t* vals, int shift, const uint32_t* hist,
-                                                      uint32_t* okeys, uint32_t* oinfs, uint32_t* ovals, int final_dst) {
+                                                      uint32_t* okeys, uint32_t* oinfs, uint32_t* ovals, int final_dst, SortCols src,
+                                                      int n_bins, int ext, uint64_t* mask_pass, uint64_t* mask_tp) {
   __shared__ uint32_t s_cnt[4][256];   // count of digit d in wave w's chunk (running during the ranking)
   __shared__ uint32_t s_loc[256];      // tile-local start of digit d's run
   __shared__ uint32_t s_glob[256];     // global start of this tile's digit-d run, minus s_loc[d]
@@ -1159,9 +1143,28 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
   for (int s = 0; s < STEPS; ++s) {
     const int64_t i = wbase + s * 64 + lane;
     const bool valid = i < sg.n;
-    kk[s] = valid ? ntl(keys + sg.koff + i) : 0xffffffffu;
-    vv[s] = valid ? ntl(vals + sg.koff + i) : 0u;
-    ii[s] = (valid && infs) ? ntl(infs + sg.koff + i) : 0u;
+    if (FIRST) {
+      kk[s] = 0xffffffffu; vv[s] = 0u; ii[s] = 0u;
+      if (valid) {
+        const int64_t g = sg.src_off + i;
+        const int32_t p = ntl(src.pos + g), r = ntl(src.ref + g), a = ntl(src.alt + g);
+        const float q = ntl(src.qual + g);
+        const uint32_t f = ntl(src.flags + g);
+        if (ext) pack_record<true>(p, r, a, q, f, n_bins, kk[s], ii[s]);
+        else pack_record<false>(p, r, a, q, f, n_bins, kk[s], ii[s]);
+        vv[s] = (uint32_t)i;
+      }
+      const uint64_t bp = ballot64(valid && (ii[s] & I_KEPT) != 0u);
+      const int64_t i0 = i - lane;   // the wave's 64 consecutive records start at a multiple of 64
+      if (lane == 0 && i0 < sg.n) {
+        mask_pass[(sg.src_off + i0) >> 6] = bp;
+        mask_tp[(sg.src_off + i0) >> 6] = 0ull;
+      }
+    } else {
+      kk[s] = valid ? ntl(keys + sg.koff + i) : 0xffffffffu;
+      vv[s] = valid ? ntl(vals + sg.koff + i) : 0u;
+      ii[s] = (valid && infs) ? ntl(infs + sg.koff + i) : 0u;
+    }
     const uint32_t d = (kk[s] >> shift) & 255u;
     uint64_t peers = ballot64(valid);
 #pragma unroll
@@ -1213,7 +1216,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
     const uint32_t k = s_k[idx];
     const uint32_t g = s_glob[(k >> shift) & 255u] + (uint32_t)idx;
     okeys[kbase + g] = k;
-    if (infs) oinfs[kbase + g] = s_i[idx];
+    if (FIRST || infs) oinfs[kbase + g] = s_i[idx];
     ovals[sg.koff + g] = s_v[idx];
   }
 }
@@ -1315,11 +1318,19 @@ void launch_synth(const SynthParams& S, int n_vcf, int64_t max_n, hipStream_t st
   if (n_vcf > 0 && max_n > 0)
     hipLaunchKernelGGL(k_synth, dim3((unsigned)((max_n + 255) / 256), (unsigned)n_vcf), dim3(256), 0, st, S);
 }
-void launch_sort_init(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const SortCols& src, int n_bins, int ext, uint32_t* keys,
-                      uint32_t* infs, uint32_t* vals, uint32_t* orbits, uint64_t* mask_pass, uint64_t* mask_tp, hipStream_t st) {
+// first pass of the batch's sort, in two steps because the host needs the OR of the keys in between
+void launch_sort_first_hist(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const int32_t* pos_col, uint32_t* hist, uint32_t* orbits,
+                            hipStream_t st) {
   if (ntiles > 0)
-    hipLaunchKernelGGL(k_sort_init, dim3(ntiles), dim3(256), 0, st, segs, tile_seg, src, n_bins, ext, keys, infs, vals, orbits, mask_pass,
-                       mask_tp);
+    hipLaunchKernelGGL((k_sort_hist<true>), dim3(ntiles), dim3(256), 0, st, segs, tile_seg, (const uint32_t*)nullptr, 4, hist, pos_col, orbits);
+}
+void launch_sort_first_scatter(const SortSeg* segs, const int32_t* tile_seg, int nseg, int ntiles, const SortCols& src, int n_bins, int ext,
+                               uint32_t* hist, uint32_t* okeys, uint32_t* oinfs, uint32_t* ovals, int final_dst, uint64_t* mask_pass,
+                               uint64_t* mask_tp, hipStream_t st) {
+  if (ntiles <= 0) return;
+  hipLaunchKernelGGL(k_sort_scan, dim3(nseg), dim3(256), 0, st, segs, hist);
+  hipLaunchKernelGGL((k_sort_scatter<true>), dim3(ntiles), dim3(256), 0, st, segs, tile_seg, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
+                     (const uint32_t*)nullptr, 4, hist, okeys, oinfs, ovals, final_dst, src, n_bins, ext, mask_pass, mask_tp);
 }
 void launch_sort_gather_alleles(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const uint32_t* perm, const int32_t* src_ref,
                                 const int32_t* src_alt, int32_t* dst_ref, int32_t* dst_alt, hipStream_t st) {
@@ -1330,10 +1341,12 @@ void launch_sort_pass(const SortSeg* segs, const int32_t* tile_seg, int nseg, in
                       const uint32_t* vals, int shift, uint32_t* hist, uint32_t* okeys, uint32_t* oinfs, uint32_t* ovals, int final_dst,
                       hipStream_t st) {
   if (ntiles <= 0) return;
-  hipLaunchKernelGGL(k_sort_hist, dim3(ntiles), dim3(256), 0, st, segs, tile_seg, keys, shift, hist);
+  hipLaunchKernelGGL((k_sort_hist<false>), dim3(ntiles), dim3(256), 0, st, segs, tile_seg, keys, shift, hist, (const int32_t*)nullptr,
+                     (uint32_t*)nullptr);
   hipLaunchKernelGGL(k_sort_scan, dim3(nseg), dim3(256), 0, st, segs, hist);
-  hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(256), 0, st, segs, tile_seg, keys, infs, vals, shift, hist, okeys, oinfs, ovals,
-                     final_dst);
+  const SortCols none = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL((k_sort_scatter<false>), dim3(ntiles), dim3(256), 0, st, segs, tile_seg, keys, infs, vals, shift, hist, okeys, oinfs, ovals,
+                     final_dst, none, 0, 0, (uint64_t*)nullptr, (uint64_t*)nullptr);
 }
 void launch_sort_scatter_tp(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const uint64_t* sub_mt, const uint32_t* perm,
                             uint64_t* mask_tp, hipStream_t st) {
