@@ -1017,6 +1017,19 @@ __global__ __launch_bounds__(256) void k_sort_gather_alleles(const SortSeg* segs
   }
 }
 
+// XCD-aware tile order for kernels whose neighbouring tiles write neighbouring pieces of the same cache lines:
+// workgroups go round-robin to the 8 XCDs, each with its own L2; giving each XCD a CONTIGUOUS range of tiles lets
+// one L2 merge the pieces into whole lines before they leave for HBM.
+__device__ __forceinline__ int xcd_contiguous_block() {
+#ifndef QM_SORT_NO_XCD_MAP
+  const int nblk = (int)gridDim.x, xcd = (int)blockIdx.x & 7, jx = (int)blockIdx.x >> 3;
+  const int per = nblk >> 3, rem = nblk & 7;
+  return xcd * per + (xcd < rem ? xcd : rem) + jx;
+#else
+  return (int)blockIdx.x;
+#endif
+}
+
 // per-tile digit histogram of a segment: hist[hoff + digit * ntiles + tile]
 // FIRST: the first pass reads the position column itself (key bits >= 4 are the position) and also collects the OR of
 // all keys, which tells the host how many digits are in use.
@@ -1024,8 +1037,9 @@ template <bool FIRST>
 __global__ __launch_bounds__(256) void k_sort_hist(const SortSeg* segs, const int32_t* tile_seg, const uint32_t* keys, int shift,
                                                    uint32_t* hist, const int32_t* pos_col, uint32_t* orbits) {
   __shared__ uint32_t s[256];
-  const SortSeg sg = segs[tile_seg[blockIdx.x]];
-  const int t = (int)blockIdx.x - sg.tile0;
+  const int bid = xcd_contiguous_block();   // neighbouring tiles write neighbouring 4-byte counters of every digit's row
+  const SortSeg sg = segs[tile_seg[bid]];
+  const int t = bid - sg.tile0;
   const int tid = (int)threadIdx.x;
   s[tid] = 0;
   uint32_t acc = 0;
@@ -1126,8 +1140,9 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
   __shared__ uint32_t s_glob[256];     // global start of this tile's digit-d run, minus s_loc[d]
   __shared__ uint32_t s_scan[256];
   __shared__ uint32_t s_k[SORT_TILE], s_i[SORT_TILE], s_v[SORT_TILE];
-  const SortSeg sg = segs[tile_seg[blockIdx.x]];
-  const int t = (int)blockIdx.x - sg.tile0;
+  const int bid = xcd_contiguous_block();   // neighbouring tiles write neighbouring 32-byte pieces of every digit's run
+  const SortSeg sg = segs[tile_seg[bid]];
+  const int t = bid - sg.tile0;
   const int tid = (int)threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -1227,13 +1242,20 @@ __global__ __launch_bounds__(256) void k_sort_scatter_tp(const SortSeg* segs, co
                                                          const uint32_t* perm, uint64_t* mask_tp) {
   const SortSeg sg = segs[tile_seg[blockIdx.x]];
   const int64_t base = (int64_t)((int)blockIdx.x - sg.tile0) * SORT_TILE;
-  for (int k = 0; k < SORT_TILE / 256; ++k) {
-    const int64_t i = base + k * 256 + threadIdx.x;
-    if (i < sg.n) {
-      const int64_t g = sg.dst_off + i;
-      if ((sub_mt[g >> 6] >> (g & 63)) & 1ull) {
-        const int64_t o = sg.src_off + (int64_t)perm[sg.koff + i];
-        atomicOr(reinterpret_cast<unsigned long long*>(mask_tp) + (o >> 6), 1ull << (o & 63));
+  // one thread per 64-record word of the sorted TP mask (the sorted copies start on 256-record boundaries)
+  const int w = (int)threadIdx.x;
+  if (w < SORT_TILE / 64) {
+    const int64_t i0 = base + (int64_t)w * 64;
+    if (i0 < sg.n) {
+      uint64_t m = sub_mt[(sg.dst_off + i0) >> 6];
+      while (m) {
+        const int bit = __builtin_ctzll(m);
+        m &= m - 1;
+        const int64_t i = i0 + bit;
+        if (i < sg.n) {
+          const int64_t o = sg.src_off + (int64_t)perm[sg.koff + i];
+          atomicOr(reinterpret_cast<unsigned long long*>(mask_tp) + (o >> 6), 1ull << (o & 63));
+        }
       }
     }
   }
