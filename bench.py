@@ -227,7 +227,7 @@ def shuffled_variant(eng, tid, args, nv, tseed, sorted_roc):
     b.close()
     return {"value": nv * float(args.records) * steps / dt, "unit": "classifications/s", "vcfs": nv, "steps": steps,
             "ms_per_step": dt / steps * 1e3, "roc_equals_sorted_variant": ok,
-            "note": "records permuted: optimistic pass + batched LSD radix sort (8-bit digits) + packed k_classify + scatter back"}
+            "note": "records permuted: optimistic pass (stops early) + batched LSD radix sort (8-bit digits, XCD-aware tile order) + packed k_classify + TP bits scattered back"}
 
 
 def alleles_variant(eng, args, nv):
