@@ -253,9 +253,11 @@ constexpr int L_TOTAL = L_MASK + 64;
 // allele-extended instantiation only: the allele codes behind the staged keys
 constexpr int L_XRREF = L_TOTAL;                        // [256] record REF codes of the round
 constexpr int L_XRALT = L_XRREF + 256;                  // [256] record ALT codes
-constexpr int L_XSREF = L_XRALT + 256;                  // [K1_SLICE] REF codes of the staged truth entries
-constexpr int L_XSALT = L_XSREF + K1_SLICE;             // [K1_SLICE] ALT codes
-constexpr int L_TOTAL_X = L_XSALT + K1_SLICE;
+constexpr int L_TOTAL_X = L_XRALT + 256;
+// The allele-extended instantiation stages at most SLICE_CAP_X truth entries per tile and keeps their REF / ALT codes
+// in the upper halves of the key and state arrays: no extra LDS for the truth side, 16 waves per CU again.
+constexpr int SLICE_CAP_X = K1_SLICE / 2;
+template <bool EXT> __device__ __forceinline__ constexpr int slice_cap() { return EXT ? SLICE_CAP_X : K1_SLICE; }
 static_assert(L_XRREF % 4 == 0, "b128 LDS stores need natural alignment");
 static_assert(L_RKEY % 4 == 0 && L_RINF % 2 == 0, "b128 / b64 LDS stores need natural alignment");
 static_assert(K1_ROUNDS == 4, "one store covers the 32 + 32 mask words of a four-round tile");
@@ -273,8 +275,8 @@ __device__ __forceinline__ void slice_select(Slice& S) {
   S.keys = L_KEYS;
   S.smax = L_SMAX;
   S.srf = L_SRF;
-  S.ref = L_XSREF;
-  S.alt = L_XSALT;
+  S.ref = L_KEYS + SLICE_CAP_X;    // EXT only: upper halves of the key / state arrays
+  S.alt = L_SMAX + SLICE_CAP_X;
 }
 
 template <bool EXT>
@@ -603,7 +605,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? 2 : K1
   slice_range(tr, B.a, B.b, lo, hi);
   Slice S;
   slice_select(S);
-  S.m = (hi - lo) <= K1_SLICE ? (hi - lo) : 0;   // an oversize slice is handled round by round
+  S.m = (hi - lo) <= slice_cap<EXT>() ? (hi - lo) : 0;   // an oversize slice is handled round by round
   stage_slice<EXT>(lds, tr, lo, S, lane);
   __syncthreads();
 
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? 2 : K1
     const bool has_next_tile = te < sp_end;
     const int ntb = tb + K1_TILE;
     const int nte = (ntb + K1_TILE < sp_end) ? ntb + K1_TILE : sp_end;
-    const bool oversize = (hi - lo) > K1_SLICE;
+    const bool oversize = (hi - lo) > slice_cap<EXT>();
     const bool started_before = (tb > 0) && (B.prevp == B.a);
     const int own_a = started_before ? B.a : INT32_MIN;
     const bool owns_b = !(started_before && B.a == B.b);
@@ -637,7 +639,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? 2 : K1
         } else if (r == 1) {
           slice_range(tr, NB.a, NB.b, nlo, nhi);
         } else if (r == 2) {
-          const int nm = (nhi - nlo) <= K1_SLICE ? (nhi - nlo) : 0;
+          const int nm = (nhi - nlo) <= slice_cap<EXT>() ? (nhi - nlo) : 0;
 #pragma unroll
           for (int q = 0; q < K1_SLICE / 64; ++q) {
             const bool in = q * 64 + lane < nm;
@@ -673,8 +675,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? 2 : K1
             const int r_own_a = r_started ? RB.a : INT32_MIN;
             int rlo, rhi;
             slice_range(tr, RB.a, RB.b, rlo, rhi);
-            for (int c0 = rlo; c0 < rhi; c0 += K1_SLICE) {
-              S.m = (rhi - c0) < K1_SLICE ? (rhi - c0) : K1_SLICE;
+            for (int c0 = rlo; c0 < rhi; c0 += slice_cap<EXT>()) {
+              S.m = (rhi - c0) < slice_cap<EXT>() ? (rhi - c0) : slice_cap<EXT>();
               stage_slice<EXT>(lds, tr, c0, S, lane);
               __syncthreads();
               join_round<EXT>(lds, S, rend - rbase, r_own_a, lane);
@@ -729,7 +731,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? 2 : K1
     ++tile;
     lo = nlo;
     hi = nhi;
-    S.m = (hi - lo) <= K1_SLICE ? (hi - lo) : 0;
+    S.m = (hi - lo) <= slice_cap<EXT>() ? (hi - lo) : 0;
 #pragma unroll
     for (int q = 0; q < K1_SLICE / 64; ++q) {
       const int j = q * 64 + lane;
