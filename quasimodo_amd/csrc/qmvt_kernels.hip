@@ -566,7 +566,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #define K1_WAVES_PER_EU 4
 #endif
 #ifndef K1_WAVES_MAX
-#define K1_WAVES_MAX 4
+#define K1_WAVES_MAX 5
 #endif
 
 template <bool PACKED, bool EXT>
