@@ -2,20 +2,24 @@
 //
 // Pure integer / index work, HBM-bound: no MFMA.  wave = 64 lanes everywhere.
 //
-//   k_classify   one wave per SPAN (<= SPAN_TILES consecutive 512-record tiles of
-//                one VCF), no barriers.  Streams pos/ref/alt/qual (dwordx4 per lane)
-//                + flags (dword per lane) with the next tile in flight, stages each
-//                tile's slice of the sorted truth keys in double-buffered LDS and
-//                merge-joins by LDS binary search.  Emits
-//                wave-ballot class masks (kept / TP, 1 bit per record each),
-//                per-tile TP/FP line counts, per-span QUAL-bin histograms
-//                (TP, FP, distinct truth keys) and scalar counters.
-//   k_finalize   one workgroup per VCF: span histograms -> ROC suffix sums,
-//                scalars, exclusive scan of tile counts, per-truth-set sums.
-//   k_compact    one wave per tile: expands the ballot masks into the
-//                compacted TP / FP line-index lists (mbcnt prefix ranks).
-//   k_sort_*     per-VCF LSD radix sort (wave multisplit) for unsorted VCFs.
-//   k_synth_*    on-device generator of the BASELINE.json config-3/4 workload.
+//   k_classify   one wave per SPAN (<= SPAN_TILES consecutive 1024-record tiles of one VCF),
+//                no barriers.  Streams pos/ref/alt/qual (non-temporal dwordx4 per lane) +
+//                flags (dword per lane) one round of 256 records ahead, stages each tile's
+//                slice of the sorted truth keys in LDS (the next tile's slice waits in
+//                registers) and merge-joins from the sparse side: truth keys bisect the
+//                staged record keys.  Emits natural-order class masks (kept / TP, 1 bit per
+//                record each; DPP OR over 8 lanes x 4 records), per-tile TP/FP line counts,
+//                per-span QUAL-bin histograms (TP, FP, distinct truth keys; u16 pairs) and
+//                scalar counters.  Instantiations: <PACKED> for the sorted (key, info)
+//                pairs of the radix-sort path, <EXT> for the allele-extended mode.
+//   k_finalize   one workgroup per VCF: span histograms -> ROC suffix sums, scalars,
+//                exclusive scan of the tile counts, per-truth-set sums.
+//   k_compact    one wave per span: expands the masks into the compacted TP / FP
+//                line-index lists (popc prefix ranks, LDS rings, 16-byte NT stores).
+//   k_sort_*     batched, segmented LSD radix sort (wave multisplit, XCD-aware tile order)
+//                for unsorted VCFs; the first pass packs straight from the columns and
+//                writes the kept mask in input order; only TP bits travel back.
+//   k_synth      on-device generator of the BASELINE.json config-3/4/5 workloads.
 //
 // Reference stages replaced (file:line in /root/reference):
 //   fgrep -wf / -wvf            program/extract_TP_FP_SNPs.py:50-57
