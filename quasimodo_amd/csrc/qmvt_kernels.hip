@@ -93,7 +93,7 @@ __device__ __forceinline__ int lds_lower_bound(const uint32_t* __restrict__ k, i
 //           The per-record pass works on 4-bit nibbles in registers (kept, TP, ...);
 //           a three-step DPP OR turns 8 lanes' nibbles into a natural-order mask word.
 //   tile  = K1_ROUNDS rounds = the unit that owns a slice of the sorted truth keys
-//           in LDS (double buffered: tile t+1's slice is staged while t finishes),
+//           in LDS (tile t+1's slice is fetched into registers while t runs and staged once t's state is flushed),
 //           the per-truth-entry state for U(t)/TP_R, and one TP/FP line count.
 // Two input formats: the five SoA columns of include/qmvt.h (PACKED = false), and the
 // (key, info) pairs the radix-sort path produces for unsorted VCFs (PACKED = true).
