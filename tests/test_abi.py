@@ -58,3 +58,38 @@ def test_null_arguments_are_rejected(qmlib):
     assert qmlib.qm_truth_load(None, None, None, None, 0, None) == -1
     assert qmlib.qm_batch_run(None, None, None) == -1
     assert b"NULL" in qmlib.qm_last_error(None)
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "qm_bench")
+    libdir = os.path.join(root, "quasimodo_amd", "csrc")
+    subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), "-o", exe,
+                    os.path.join(root, "examples", "qm_bench.c"), "-L" + libdir, "-lqmvt", "-Wl,-rpath," + libdir], check=True)
+    return exe
+
+
+def test_c_program_links_against_the_abi_and_fails_loudly_without_a_gpu(qmlib, tmp_path):
+    """include/qmvt.h is usable from plain C; without a HIP device the engine refuses (no CPU path)"""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by the gpu test")
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "no CPU fallback" in r.stderr and r.stdout == ""
+
+
+@pytest.mark.gpu
+def test_c_program_runs_the_synthetic_workload(qmlib, tmp_path):
+    import json
+    import subprocess
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([exe, "8", "1000000", "3"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout)
+    assert d["vcfs"] == 8 and d["kept"] == d["tp_lines"] + d["fp_lines"] and d["tp_lines"] > 0 and d["classifications_per_s"] > 1e9
+    r2 = subprocess.run([exe, "4", "1000000", "2", "1"], capture_output=True, text=True)      # shuffled: the radix-sort path
+    d2 = json.loads(r2.stdout)
+    assert r2.returncode == 0 and d2["kept"] > 0
