@@ -911,7 +911,7 @@ extern "C" int qm_fp_overlap(qm_ctx* c, int n_sets, const int64_t* set_offsets, 
     for (void* p : ps) (void)hipFree(p);
   };
 #define A_(p, cnt) if (rc == QM_OK) rc = dalloc(&(p), (size_t)(cnt));
-  A_(dp, n) A_(dr, n) A_(da, n) A_(ds, n) A_(k[0], n) A_(k[1], n) A_(v[0], n) A_(v[1], n)
+  A_(dp, n) A_(dr, n) A_(da, n) A_(ds, n) A_(k[0], n + 64) A_(k[1], n + 64) A_(v[0], n + 64) A_(v[1], n + 64)   /* the sort kernels read whole 16-byte pieces */
   A_(hist, (size_t)((n + SORT_TILE - 1) / SORT_TILE) * 256) A_(bad, 1) A_(dreg, nreg) A_(dseg, 1)
   A_(dts, (n + SORT_TILE - 1) / SORT_TILE)
 #undef A_

@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
   __shared__ uint32_t s_loc[256];      // tile-local start of digit d's run
   __shared__ uint32_t s_glob[256];     // global start of this tile's digit-d run, minus s_loc[d]
   __shared__ uint32_t s_scan[256];
-  __shared__ uint32_t s_k[SORT_TILE], s_i[SORT_TILE], s_v[SORT_TILE];
+  __shared__ __attribute__((aligned(16))) uint32_t s_k[SORT_TILE], s_i[SORT_TILE], s_v[SORT_TILE];
   const int bid = xcd_contiguous_block();   // neighbouring tiles write neighbouring 32-byte pieces of every digit's run
   const SortSeg sg = segs[tile_seg[bid]];
   const int t = bid - sg.tile0;
@@ -1158,23 +1158,69 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
   const int64_t wbase = tbase + (int64_t)wave * (SORT_TILE / 4);
   constexpr int STEPS = SORT_TILE / 4 / 64;
   uint32_t kk[STEPS], vv[STEPS], ii[STEPS], rk[STEPS];
-  // (loads stay inside the ranking loop on purpose: issued all at once up front the kernel was 10 % slower --
-  // the five workgroups of a CU then move in lockstep between a memory phase and a compute phase)
+  uint32_t* const stK = s_k + wave * (SORT_TILE / 4);
+  uint32_t* const stI = s_i + wave * (SORT_TILE / 4);
+  uint32_t* const stV = s_v + wave * (SORT_TILE / 4);
+  // Dword loads are bound by the rate of memory instructions, not by bytes: fetch the wave's 512 entries with
+  // 16-byte loads (4 consecutive entries per lane), park them in the LDS area the reorder uses later, and take
+  // them back one per lane in step order (the stable ranking needs lane = consecutive entry).
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  if (FIRST) {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    typedef float v4f __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int j = 0; j < SORT_TILE / 4 / 256; ++j) {
+      const int64_t i4 = wbase + j * 256 + lane * 4;
+      v4u k4 = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, f4 = {0u, 0u, 0u, 0u};
+      if (i4 < sg.n) {   // whole 16-byte pieces: the columns are padded past every VCF
+        const int64_t g = sg.src_off + i4;
+        const v4i p = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(src.pos + g));
+        const v4i r = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(src.ref + g));
+        const v4i a = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(src.alt + g));
+        const v4f q = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src.qual + g));
+        const uint32_t f = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(src.flags + g));
+        uint32_t kx[4], ix[4];
+        if (ext) {
+          pack_record<true>(p.x, r.x, a.x, q.x, f, n_bins, kx[0], ix[0]);
+          pack_record<true>(p.y, r.y, a.y, q.y, f >> 8, n_bins, kx[1], ix[1]);
+          pack_record<true>(p.z, r.z, a.z, q.z, f >> 16, n_bins, kx[2], ix[2]);
+          pack_record<true>(p.w, r.w, a.w, q.w, f >> 24, n_bins, kx[3], ix[3]);
+        } else {
+          pack_record<false>(p.x, r.x, a.x, q.x, f, n_bins, kx[0], ix[0]);
+          pack_record<false>(p.y, r.y, a.y, q.y, f >> 8, n_bins, kx[1], ix[1]);
+          pack_record<false>(p.z, r.z, a.z, q.z, f >> 16, n_bins, kx[2], ix[2]);
+          pack_record<false>(p.w, r.w, a.w, q.w, f >> 24, n_bins, kx[3], ix[3]);
+        }
+        k4.x = kx[0]; k4.y = kx[1]; k4.z = kx[2]; k4.w = kx[3];
+        f4.x = ix[0]; f4.y = ix[1]; f4.z = ix[2]; f4.w = ix[3];
+      }
+      *reinterpret_cast<v4u*>(&stK[j * 256 + lane * 4]) = k4;
+      *reinterpret_cast<v4u*>(&stI[j * 256 + lane * 4]) = f4;
+    }
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int j = 0; j < SORT_TILE / 4 / 256; ++j) {
+      const int64_t i4 = wbase + j * 256 + lane * 4;
+      v4u k4 = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, v4 = {0u, 0u, 0u, 0u}, f4 = {0u, 0u, 0u, 0u};
+      if (i4 < sg.n) {   // whole 16-byte pieces: every segment of the chunk arrays is padded to 64 entries
+        k4 = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(keys + sg.koff + i4));
+        v4 = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(vals + sg.koff + i4));
+        if (infs) f4 = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(infs + sg.koff + i4));
+      }
+      *reinterpret_cast<v4u*>(&stK[j * 256 + lane * 4]) = k4;
+      *reinterpret_cast<v4u*>(&stV[j * 256 + lane * 4]) = v4;
+      *reinterpret_cast<v4u*>(&stI[j * 256 + lane * 4]) = f4;
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int s = 0; s < STEPS; ++s) {
     const int64_t i = wbase + s * 64 + lane;
     const bool valid = i < sg.n;
     if (FIRST) {
       kk[s] = 0xffffffffu; vv[s] = 0u; ii[s] = 0u;
-      if (valid) {
-        const int64_t g = sg.src_off + i;
-        const int32_t p = ntl(src.pos + g), r = ntl(src.ref + g), a = ntl(src.alt + g);
-        const float q = ntl(src.qual + g);
-        const uint32_t f = ntl(src.flags + g);
-        if (ext) pack_record<true>(p, r, a, q, f, n_bins, kk[s], ii[s]);
-        else pack_record<false>(p, r, a, q, f, n_bins, kk[s], ii[s]);
-        vv[s] = (uint32_t)i;
-      }
+      if (valid) { kk[s] = stK[s * 64 + lane]; ii[s] = stI[s * 64 + lane]; vv[s] = (uint32_t)i; }
       const uint64_t bp = ballot64(valid && (ii[s] & I_KEPT) != 0u);
       const int64_t i0 = i - lane;   // the wave's 64 consecutive records start at a multiple of 64
       if (lane == 0 && i0 < sg.n) {
@@ -1182,9 +1228,9 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
         mask_tp[(sg.src_off + i0) >> 6] = 0ull;
       }
     } else {
-      kk[s] = valid ? ntl(keys + sg.koff + i) : 0xffffffffu;
-      vv[s] = valid ? ntl(vals + sg.koff + i) : 0u;
-      ii[s] = (valid && infs) ? ntl(infs + sg.koff + i) : 0u;
+      kk[s] = valid ? stK[s * 64 + lane] : 0xffffffffu;
+      vv[s] = valid ? stV[s * 64 + lane] : 0u;
+      ii[s] = valid ? stI[s * 64 + lane] : 0u;
     }
     const uint32_t d = (kk[s] >> shift) & 255u;
     uint64_t peers = ballot64(valid);
