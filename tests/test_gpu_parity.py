@@ -425,3 +425,25 @@ def test_two_contexts_in_two_threads(oracle):
     [t.join() for t in th]
     assert not errs, errs
     assert out == {0: True, 1: True}
+
+
+def test_integration_md_ctypes_stub_runs_as_written(tmp_path):
+    """the stand-alone ctypes binding shown in INTEGRATION.md is executed verbatim on a golden case"""
+    root = os.path.join(os.path.dirname(__file__), "..")
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = md[md.index("## The binding itself"):]
+    code = sec[sec.index("```python") + len("```python"):]
+    code = code[:code.index("```")]
+    e = [c for c in CASES if c["family"] == "config1"][0]
+    g = os.path.join(os.path.dirname(__file__), "golden", "config1")
+    outs = {k: str(tmp_path / (k + ".vcf")) for k in ("filtered", "tp", "fp")}
+    env = {"vcf_path": os.path.join(g, e["vcf"]), "truth_path": os.path.join(g, e["truth"]),
+           "filtered_out": outs["filtered"], "tp_out": outs["tp"], "fp_out": outs["fp"]}
+    cwd = os.getcwd()
+    os.chdir(root)                     # the stub loads quasimodo_amd/csrc/libqmvt.so by relative path
+    try:
+        exec(compile(code, "INTEGRATION.md", "exec"), env)
+    finally:
+        os.chdir(cwd)
+    for k in ("filtered", "tp", "fp"):
+        assert open(outs[k], "rb").read() == open(os.path.join(g, e["expected"][k]), "rb").read(), k
