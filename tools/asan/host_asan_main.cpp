@@ -1,0 +1,87 @@
+// Sanitizer harness for the host text side (qmvt_host.cpp): every host entry point of include/qmvt.h on the files
+// given on the command line, plus truncations and byte flips of them.  Build + run: bash tools/asan/run.sh
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/qmvt.h"
+
+static std::vector<uint8_t> slurp(const char* p) {
+  std::vector<uint8_t> v;
+  FILE* f = fopen(p, "rb");
+  if (!f) return v;
+  uint8_t buf[1 << 16];
+  size_t n;
+  while ((n = fread(buf, 1, sizeof buf, f)) > 0) v.insert(v.end(), buf, buf + n);
+  fclose(f);
+  return v;
+}
+
+static long g_calls = 0;
+
+static void exercise(const std::vector<uint8_t>& t, qm_dict* dict, const char* outdir) {
+  // exact-size heap copy: any read past the end trips the sanitizer
+  uint8_t* text = (uint8_t*)malloc(t.size() ? t.size() : 1);
+  if (t.size()) memcpy(text, t.data(), t.size());
+  const size_t len = t.size();
+  const int64_t cap = qm_vcf_count_lines(text, len) + 1;
+  std::vector<int64_t> off((size_t)cap + 1);
+  std::vector<uint8_t> kind((size_t)cap), flags((size_t)cap), cls((size_t)cap, 3);
+  std::vector<int32_t> pos((size_t)cap), ref((size_t)cap), alt((size_t)cap);
+  std::vector<float> qual((size_t)cap);
+  for (int ext = 0; ext < 2; ++ext) {
+    qm_vcf_cols info;
+    int rc = qm_vcf_scan_ext(text, len, cap, off.data(), kind.data(), pos.data(), ref.data(), alt.data(), qual.data(), flags.data(), &info,
+                             ext ? dict : nullptr);
+    if (rc != QM_OK) { fprintf(stderr, "scan rc=%d\n", rc); exit(1); }
+    for (int sel = 0; sel < 3; ++sel) {
+      const std::string o = std::string(outdir) + "/w.vcf";
+      qm_vcf_write(o.c_str(), text, len, info.n_lines, off.data(), kind.data(), cls.data(), sel);
+    }
+    int64_t counts[4];
+    for (int mode = 0; mode < 2; ++mode) {
+      if (ext && mode == 1) continue;
+      qm_truth_scan_ext(text, len, mode, cap, pos.data(), ref.data(), alt.data(), counts, ext ? dict : nullptr);
+    }
+    g_calls += 6;
+  }
+  for (int mode = 0; mode < 2; ++mode)
+    for (int fl = 0; fl < 2; ++fl) {
+      int64_t n = 0;
+      const std::string o = std::string(outdir) + "/s.vcf";
+      qm_vcf_split_write(o.c_str(), text, len, mode, fl, &n);
+      ++g_calls;
+    }
+  free(text);
+}
+
+int main(int argc, char** argv) {
+  if (argc < 3) { fprintf(stderr, "usage: host_asan <outdir> <file>...\n"); return 2; }
+  qm_dict* dict = qm_dict_create();
+  unsigned rng = 12345;
+  for (int a = 2; a < argc; ++a) {
+    std::vector<uint8_t> t = slurp(argv[a]);
+    if (t.size() > (4u << 20)) t.resize(4u << 20);
+    exercise(t, dict, argv[1]);
+    // truncations at awkward places and random byte flips
+    for (int k = 0; k < 24 && !t.empty(); ++k) {
+      rng = rng * 1664525u + 1013904223u;
+      std::vector<uint8_t> u(t.begin(), t.begin() + (rng % (t.size() + 1)));
+      exercise(u, dict, argv[1]);
+      std::vector<uint8_t> w = t;
+      for (int j = 0; j < 16; ++j) {
+        rng = rng * 1664525u + 1013904223u;
+        static const uint8_t alphabet[] = {'\t', '\n', '\r', 0, 0xff, '.', 'A', '9', '#', ',', ' ', 'e', '-', '+'};
+        w[(rng >> 8) % w.size()] = alphabet[rng % sizeof alphabet];
+      }
+      exercise(w, dict, argv[1]);
+    }
+  }
+  uint8_t buf[64];
+  for (int32_t c : {0, 3, 4, -1, (2 << 26) | 5, 0x40000000, 0x40000001, 0x7fffffff, (int32_t)0x80000000}) qm_allele_spell(dict, c, buf, sizeof buf);
+  printf("host sanitizer run: %ld calls, dictionary %lld entries, clean\n", g_calls, (long long)qm_dict_size(dict));
+  qm_dict_destroy(dict);
+  return 0;
+}
