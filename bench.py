@@ -175,8 +175,8 @@ def main():
         "vs_baseline": None,
         "dtype": "int32",
         "data": "synthetic (generated on device; seeds 3000+v, truth seed 3)",
-        "config": {"workload": "BASELINE configs[2]: %d VCFs x %d SNPs per GPU, %d bp reference, %d truth keys, %d-threshold ROC%s"
-                               % (n_vcf, args.records, args.genome, t_unique, args.bins, ", records shuffled (radix-sort path)" if args.shuffled else ", position sorted"),
+        "config": {"workload": "%s: %d VCFs x %d SNPs per GPU, %d bp reference, %d truth keys, %d-threshold ROC%s"
+                               % (workload_name(args), n_vcf, args.records, args.genome, t_unique, args.bins, ", records shuffled (radix-sort path)" if args.shuffled else ", position sorted"),
                    "vcfs_per_gpu": n_vcf, "records_per_vcf": args.records, "parallelism": "vcf-shard x%d" % world,
                    "collective": "1 all-reduce of [%d x 3 x %d] int64 per step" % (eng.n_truth, args.bins) if world > 1 else "none"},
         "roofline": {"bound": "hbm", "kernel": "k_classify", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -203,6 +203,15 @@ def main():
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def workload_name(args):
+    """which BASELINE.json configuration the arguments describe (the default is configs[2])"""
+    if (args.records, args.genome, args.truth) == (1_000_000, 5_000_000, 100_000):
+        return "BASELINE configs[2]"
+    if (args.records, args.genome, args.truth) == (10_000_000, 50_000_000, 1_000_000):
+        return "BASELINE configs[3] shape (per-GPU shard)"
+    return "custom shape"
 
 
 def shuffled_variant(eng, tid, args, nv, tseed, sorted_roc):
