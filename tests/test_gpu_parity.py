@@ -447,3 +447,27 @@ def test_integration_md_ctypes_stub_runs_as_written(tmp_path):
         os.chdir(cwd)
     for k in ("filtered", "tp", "fp"):
         assert open(outs[k], "rb").read() == open(os.path.join(g, e["expected"][k]), "rb").read(), k
+
+
+def test_batch_beyond_two_to_the_32_records(engine, oracle):
+    """BASELINE configs[3]: one GPU's shard is 1.25e10 records -- global record indices need 64 bits everywhere.
+    440 VCFs x 10 M = 4.4e9 records (94 GB resident); the last VCF lies entirely past the 2^32nd record."""
+    from oracle.synth import synth_truth_keys
+    L, T, N, NV = 50_000_000, 1_000_000, 10_000_000, 440
+    assert NV * N > (1 << 32) + N
+    tid = engine.truth_synth(L, T, 4)
+    b = engine.batch([N] * NV, [tid] * NV)
+    b.synth(L, T, 4, 4000)
+    b.run(); b.finish()
+    roc, scal = b.roc(), b.scalars()
+    assert (scal[:, 6] == N).all() and (scal[:, 5] == 1).all()
+    assert np.array_equal(roc[:, 0, 20].astype(np.int64), scal[:, 1]) and np.array_equal(roc[:, 1, 20].astype(np.int64), scal[:, 2])
+    assert np.array_equal(b.global_counts()[tid], roc.sum(axis=0))
+    truth = synth_truth_keys(L, T, 4)
+    for v in (0, NV - 1):
+        cls, oroc, sc = oracle.classify_columns(*b.columns(v), *truth)
+        assert np.array_equal(b.cls(v), cls) and np.array_equal(roc[v], oroc)
+        assert [int(x) for x in scal[v][:5]] == [sc[k] for k in ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R")]
+        idx = b.idx(v)
+        assert np.array_equal(idx[:sc["tp_lines"]], np.nonzero(cls == 3)[0]) and np.array_equal(idx[N - sc["fp_lines"]:], np.nonzero(cls == 1)[0])
+    b.close()
