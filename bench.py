@@ -246,10 +246,11 @@ def alleles_variant(eng, args, nv):
     import numpy as np
     from oracle import qm_oracle as O
     from oracle.synth import synth_truth_keys
-    pct, tseed = 30, 5
-    tid = eng.truth_synth(args.genome, args.truth, tseed, indel_pct=pct)
-    b = eng.batch([args.records] * nv, [tid] * nv, n_bins=args.bins, alleles=True)
-    b.synth(args.genome, args.truth, tseed, 5000, indel_pct=pct)
+    pct, tseeds = 30, (5, 6, 7)
+    tids = [eng.truth_synth(args.genome, args.truth, ts, indel_pct=pct) for ts in tseeds]   # three truth sets: VCF v uses v mod 3
+    tid, tseed = tids[0], tseeds[0]
+    b = eng.batch([args.records] * nv, [tids[v % 3] for v in range(nv)], n_bins=args.bins, alleles=True)
+    b.synth(args.genome, args.truth, None, 5000, indel_pct=pct)
     b.run(); b.finish()
     b.set_timing(True)
     steps = 5

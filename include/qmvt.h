@@ -142,10 +142,12 @@ void qm_batch_destroy(qm_batch* b);
 int qm_batch_upload(qm_batch* b, int vcf, const int32_t* pos, const int32_t* ref, const int32_t* alt,
                     const float* qual, const uint8_t* flags);
 
+#define QM_SYNTH_TRUTH_PER_VCF 0xffffffffffffffffull
 typedef struct qm_synth_cfg {
   int64_t genome_len;   /* L: positions 1..L                                  */
   uint64_t seed;        /* VCF v uses seed + v                                 */
-  uint64_t truth_seed;  /* must equal the seed passed to qm_truth_synth        */
+  uint64_t truth_seed;  /* must equal the seed passed to qm_truth_synth, or QM_SYNTH_TRUTH_PER_VCF: every VCF is
+                           generated against the synthetic truth set it was assigned at qm_batch_create */
   int64_t truth_n;      /* T of that truth set                                  */
   int32_t shuffled;     /* 0 = position sorted, 1 = records permuted            */
   int32_t indel_pct;    /* 0 = single-base records only (configs 3/4); > 0: that share of the

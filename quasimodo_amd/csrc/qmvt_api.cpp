@@ -48,6 +48,12 @@ struct Truth {
   int32_t *d_xref = nullptr, *d_xalt = nullptr, *d_xtidx = nullptr;
   int32_t xshift = 0, xnb = 0;
   int64_t xn = 0;
+  // how a synthetic truth set was generated (qm_truth_synth*): lets qm_batch_synth generate every VCF of a batch
+  // against the truth set it is assigned to
+  bool synthetic = false;
+  int64_t syn_L = 0, syn_T = 0;
+  uint64_t syn_seed = 0;
+  int syn_pct = 0;
 };
 
 struct qm_ctx {
@@ -236,7 +242,13 @@ extern "C" int qm_truth_synth_ext(qm_ctx* c, int64_t L, int64_t T, uint64_t tsee
     xe[(size_t)j] = XEntry{key, r, a};
     if ((uint32_t)(r | a) < 4u) keys.push_back(key);
   }
-  return truth_from_keys(c, keys, xe, truth_id);
+  int tid = -1;
+  int rc = truth_from_keys(c, keys, xe, &tid);
+  if (rc != QM_OK) return rc;
+  Truth& t = c->truths[(size_t)tid];
+  t.synthetic = true; t.syn_L = L; t.syn_T = T; t.syn_seed = tseed; t.syn_pct = indel_pct;
+  if (truth_id) *truth_id = tid;
+  return QM_OK;
 }
 extern "C" int qm_truth_synth(qm_ctx* c, int64_t L, int64_t T, uint64_t tseed, int* truth_id) {
   return qm_truth_synth_ext(c, L, T, tseed, 0, truth_id);
@@ -460,6 +472,19 @@ extern "C" int qm_batch_synth(qm_batch* b, const qm_synth_cfg* cfg) {
   SynthParams S;
   S.vcfs = b->d_vcfs; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
   S.genome_len = cfg->genome_len; S.truth_n = cfg->truth_n; S.truth_seed = cfg->truth_seed; S.seed = cfg->seed;
+  S.per_vcf_truth = 0;
+  if (cfg->truth_seed == QM_SYNTH_TRUTH_PER_VCF) {
+    // every VCF against the synthetic truth set it was assigned at qm_batch_create (configs[4]: VCF v uses truth v mod 3)
+    for (const VcfDesc& d : L.vcfs) {
+      const Truth& t = b->ctx->truths[(size_t)d.truth];
+      if (!t.synthetic || t.syn_L != cfg->genome_len || t.syn_T != cfg->truth_n || t.syn_pct != cfg->indel_pct || t.syn_seed > 0x7fffffffull)
+        return fail(QM_E_INVAL, "qm_batch_synth: truth set %d was not made by qm_truth_synth_ext with this genome_len / truth_n / indel_pct", d.truth);
+    }
+    for (VcfDesc& d : b->L.vcfs) d.pad = (int32_t)b->ctx->truths[(size_t)d.truth].syn_seed;
+    int rc = upload_layout(b);
+    if (rc != QM_OK) return rc;
+    S.per_vcf_truth = 1;
+  }
   S.shuffled = cfg->shuffled;
   S.indel_pct = cfg->indel_pct;
   if (cfg->indel_pct < 0 || cfg->indel_pct > 100) return fail(QM_E_INVAL, "qm_batch_synth: indel_pct must be 0..100");

@@ -71,7 +71,7 @@ struct VcfDesc {
   int32_t truth;
   int32_t tile0, ntiles;
   int32_t span0, nspans;
-  int32_t pad;
+  int32_t pad;     // qm_batch_synth with QM_SYNTH_TRUTH_PER_VCF: the seed of the VCF's synthetic truth set
 };
 
 struct SpanDesc {
@@ -163,6 +163,7 @@ struct SynthParams {
   uint64_t perm_a, perm_b;
   int32_t shuffled;
   int32_t indel_pct;
+  int32_t per_vcf_truth;   // 1: VCF v is generated against the truth set seeded VcfDesc.pad
 };
 
 // ---- synthetic workload: the same arithmetic on host and device -------------

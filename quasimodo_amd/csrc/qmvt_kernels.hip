@@ -997,7 +997,8 @@ __global__ void k_synth(SynthParams S) {
   int32_t p, r, a;
   float q;
   uint8_t f;
-  synth_record(S.genome_len, vd.n, S.truth_n, S.truth_seed, seed, src, &p, &r, &a, &q, &f, S.indel_pct);
+  const uint64_t tseed = S.per_vcf_truth ? (uint64_t)(uint32_t)vd.pad : S.truth_seed;
+  synth_record(S.genome_len, vd.n, S.truth_n, tseed, seed, src, &p, &r, &a, &q, &f, S.indel_pct);
   const int64_t g = vd.off + i;
   S.pos[g] = p; S.ref[g] = r; S.alt[g] = a; S.qual[g] = q; S.flags[g] = f;
 }

@@ -185,7 +185,9 @@ class Batch:
         self._ck(self._L.qm_batch_upload(self._h, int(v), *[_p(x) for x in a]))
 
     def synth(self, genome_len, truth_n, truth_seed, seed, shuffled=False, indel_pct=0):
-        cfg = SynthCfg(int(genome_len), int(seed), int(truth_seed), int(truth_n), int(bool(shuffled)), int(indel_pct))
+        """truth_seed=None: every VCF is generated against the synthetic truth set it was assigned (per-VCF truth sets)"""
+        ts = 0xffffffffffffffff if truth_seed is None else int(truth_seed)
+        cfg = SynthCfg(int(genome_len), int(seed), ts, int(truth_n), int(bool(shuffled)), int(indel_pct))
         self._ck(self._L.qm_batch_synth(self._h, C.byref(cfg)))
 
     def set_timing(self, on=True):

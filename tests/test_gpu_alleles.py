@@ -133,25 +133,25 @@ def test_config5_shape_generated_on_device(engine, oracle):
     for t, tid in zip(truths, tids):
         assert engine.truth_size(tid, alleles=True) == T
         assert engine.truth_size(tid) == int(((t[1] < 4) & (t[2] < 4)).sum())
-    n_vcf = 6
-    for w in range(3):          # the generator ties a batch to one truth set: one batch per truth
-        vs = [v for v in range(n_vcf) if v % 3 == w]
-        b = engine.batch([N] * len(vs), [tids[w]] * len(vs), alleles=True)
-        b.synth(L, T, seeds[w], 5000 + w, indel_pct=pct)
-        b.run()
-        b.finish()
-        roc, scal = b.roc(), b.scalars()
-        for k in range(len(vs)):
-            cols = b.columns(k)
-            assert 0.2 < float(((cols[1] >= 4) | (cols[2] >= 4)).mean()) < 0.4
-            cls, oroc, sc = oracle.classify_columns(*cols, *truths[w], ext=True)
-            assert np.array_equal(b.cls(k), cls) and np.array_equal(roc[k], oroc)
-            assert [int(x) for x in scal[k][:5]] == [sc[x] for x in ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R")]
-            assert int(scal[k][7]) == T and sc["tp_lines"] > 0.05 * N
-            idx = b.idx(k)
-            assert np.array_equal(idx[:sc["tp_lines"]], np.nonzero(cls == 3)[0])
-            assert np.array_equal(idx[N - sc["fp_lines"]:], np.nonzero(cls == 1)[0])
-        b.close()
+    n_vcf = 6                   # ONE batch, VCF v against truth set v mod 3
+    b = engine.batch([N] * n_vcf, [tids[v % 3] for v in range(n_vcf)], alleles=True)
+    b.synth(L, T, None, 5000, indel_pct=pct)
+    b.run()
+    b.finish()
+    roc, scal, glob = b.roc(), b.scalars(), b.global_counts()
+    for v in range(n_vcf):
+        cols = b.columns(v)
+        assert 0.2 < float(((cols[1] >= 4) | (cols[2] >= 4)).mean()) < 0.4
+        cls, oroc, sc = oracle.classify_columns(*cols, *truths[v % 3], ext=True)
+        assert np.array_equal(b.cls(v), cls) and np.array_equal(roc[v], oroc)
+        assert [int(x) for x in scal[v][:5]] == [sc[x] for x in ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R")]
+        assert int(scal[v][7]) == T and sc["tp_lines"] > 0.05 * N
+        idx = b.idx(v)
+        assert np.array_equal(idx[:sc["tp_lines"]], np.nonzero(cls == 3)[0])
+        assert np.array_equal(idx[N - sc["fp_lines"]:], np.nonzero(cls == 1)[0])
+    for w in range(3):          # the per-truth confusion counters (what the all-reduce carries) are sums of their VCFs' rows
+        assert np.array_equal(glob[tids[w]], roc[w::3].sum(axis=0))
+    b.close()
 
 
 def test_alleles_mode_unsorted_vcfs_take_the_radix_sort_path(engine, oracle):
