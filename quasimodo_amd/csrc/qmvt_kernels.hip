@@ -569,12 +569,15 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #ifndef K1_WAVES_PER_EU
 #define K1_WAVES_PER_EU 4
 #endif
+#ifndef K1_WAVES_EXT_MIN
+#define K1_WAVES_EXT_MIN 2
+#endif
 #ifndef K1_WAVES_MAX
 #define K1_WAVES_MAX 5
 #endif
 
 template <bool PACKED, bool EXT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? 2 : K1_WAVES_PER_EU, K1_WAVES_MAX))) void k_classify(ClassifyParams P) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAVES_EXT_MIN : K1_WAVES_PER_EU, K1_WAVES_MAX))) void k_classify(ClassifyParams P) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[(EXT ? L_TOTAL_X : L_TOTAL) + K1_LDS_PAD];
 
   const int lane = (int)threadIdx.x;
