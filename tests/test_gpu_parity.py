@@ -471,3 +471,48 @@ def test_batch_beyond_two_to_the_32_records(engine, oracle):
         idx = b.idx(v)
         assert np.array_equal(idx[:sc["tp_lines"]], np.nonzero(cls == 3)[0]) and np.array_equal(idx[N - sc["fp_lines"]:], np.nonzero(cls == 1)[0])
     b.close()
+
+
+def test_error_behaviour_of_the_abi(engine):
+    """bad arguments and wrong call order are refused with a code and a message, never guessed at"""
+    import ctypes as C
+    from quasimodo_amd import QmvtError
+    from quasimodo_amd import _lib
+    L = _lib.lib()
+    tid = engine.truth_load(np.array([5], np.int32), np.array([0], np.int32), np.array([1], np.int32))
+
+    def code(fn):
+        with pytest.raises(QmvtError) as e:
+            fn()
+        assert str(e.value)          # a message, not just a number
+        return e.value.code
+
+    assert code(lambda: engine.batch([10], [tid + 1000])) == -1          # unknown truth set
+    assert code(lambda: engine.batch([10], [-1])) == -1
+    assert code(lambda: engine.batch([-3], [tid])) == -1                 # negative record count
+    assert code(lambda: engine.batch([10], [tid], n_bins=0)) == -1
+    assert code(lambda: engine.batch([10], [tid], n_bins=257)) == -1
+    assert code(lambda: engine.truth_synth(1000, 7, 1)) == -1            # T does not divide L
+    assert code(lambda: engine.truth_load(np.array([1 << 28], np.int32), np.array([0], np.int32), np.array([1], np.int32))) == -5
+    b = engine.batch([100], [tid])
+    assert code(lambda: b.cls(0)) == -6                                   # nothing was run
+    assert code(lambda: b.finish()) == -6
+    assert code(lambda: b.timings()) == -6
+    with pytest.raises(ValueError):
+        b.upload(0, np.zeros(5, np.int32), np.zeros(5, np.int32), np.zeros(5, np.int32), np.zeros(5, np.float32), np.zeros(5, np.uint8))
+    assert code(lambda: b._ck(L.qm_batch_upload(b._h, 7, None, None, None, None, None))) == -1      # VCF index out of range
+    assert code(lambda: b._ck(L.qm_batch_upload(b._h, 0, None, None, None, None, None))) == -1      # NULL columns
+    assert code(lambda: b.synth(1000, 10, 3, 1, indel_pct=30)) == -1                                  # indels need an allele-extended batch
+    b.upload(0, np.arange(100, dtype=np.int32), np.zeros(100, np.int32), np.ones(100, np.int32), np.full(100, 30, np.float32), np.full(100, 3, np.uint8))
+    b.run()
+    assert code(lambda: b.cls(0)) == -6                                   # run but not finished
+    b.finish()
+    assert int(b.scalars()[0][0]) == 100 and int(b.scalars()[0][1]) == 1      # position 5, A>C is the one true positive
+    with pytest.raises(IndexError):
+        b.cls(3)
+    assert code(lambda: b._ck(L.qm_batch_get_cls(b._h, 3, np.zeros(4, np.uint8).ctypes.data_as(C.c_void_p)))) == -1
+    b.close()
+    # a second context on a device that does not exist
+    h = C.c_void_p()
+    assert L.qm_init(99, C.byref(h)) == -1 and b"out of range" in L.qm_last_error(None)
+    assert code(lambda: engine.fp_overlap([(np.zeros(1, np.int32),) * 3] * 6)) == -1                    # more than 5 sets
