@@ -4,7 +4,7 @@ Same function names and argument meaning as the reference
 (extract_tp_fp_snp :12, extract_tp_fp_custom_snp :60); the shell pipeline is
 replaced by one text scan on the host + the HIP engine.  `extract_many` is the
 batch form used by the rule bodies: every mixed-sample VCF of a run is
-classified in ONE qm_classify_batch call.
+classified in ONE engine batch (the qm_batch_* entry points; files are read, scanned and written by a thread pool).
 
 Differences from the reference, all deliberate:
   * errors raise (the CLI exits non-zero) instead of being ignored;
