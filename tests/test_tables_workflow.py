@@ -158,3 +158,51 @@ def test_vareval_workflow(engine, oracle, tmp_path):
         rc = oracle.count_text(exp["filtered"], truth, custom=True)
         assert line.split("\t")[1:5] == [str(rc["genomediff"]), str(rc["calleridentify"]), str(rc["TP"]), str(rc["FP"])]
         assert job.filtered_out.endswith("results/snp/callers/%s.filtered.vcf" % e["caller"])
+
+
+def test_module_cli_split_and_argument_errors(tmp_path):
+    """`python -m quasimodo_amd` -- the parts that need no GPU"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    probe = os.path.join(root, "tests", "golden", "split", "input", "probe.vcf")
+    out = tmp_path / "x.vcf"
+    env = dict(os.environ, QM_AWK_FLAVOUR="mawk-literal")
+    r = subprocess.run([sys.executable, "-m", "quasimodo_amd", "split", probe, str(out), "xsnp"], cwd=root, env=env, capture_output=True, text=True)
+    assert r.returncode == 0 and out.read_bytes() == open(os.path.join(root, "tests", "golden", "split", "expected", "probe.xsnp.vcf"), "rb").read()
+    r = subprocess.run([sys.executable, "-m", "quasimodo_amd", "extract", "a.vcf"], cwd=root, capture_output=True, text=True)
+    assert r.returncode == 2 and "--truth" in r.stderr
+
+
+@pytest.mark.gpu
+def test_module_cli_extract(tmp_path):
+    """one GPU batch from the command line; files and counts equal the golden ones"""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    from conftest import golden_cases, read_case
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = [c for c in golden_cases() if c["family"] == "hcmv" and not c["pure"]][:4]
+    g = os.path.join(root, "tests", "golden", "hcmv")
+    vcfs = []
+    for c in cases:
+        d = tmp_path / c["caller"]
+        (d / "fp").mkdir(parents=True, exist_ok=True)
+        dst = d / os.path.basename(c["vcf"])
+        shutil.copyfile(os.path.join(g, c["vcf"]), dst)
+        vcfs.append(str(dst))
+    same_truth = [c for c in cases if c["truth"] == cases[0]["truth"]]
+    sel = [v for v, c in zip(vcfs, cases) if c in same_truth]
+    js = tmp_path / "rows.json"
+    r = subprocess.run([sys.executable, "-m", "quasimodo_amd", "extract", "--truth", os.path.join(g, cases[0]["truth"]), "--json", str(js)] + sel,
+                       cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = json.load(open(js))
+    assert len(rows) == len(sel) and r.stdout.count("\n") == len(sel) + 1
+    for row, c in zip(rows, same_truth):
+        _, _, exp = read_case(c)
+        for k in ("filtered", "tp", "fp"):
+            assert open(row[k], "rb").read() == exp[k], (c["vcf"], k)
+        nd = lambda b: sum(1 for ln in b.split(b"\n") if ln and not ln.startswith(b"#"))
+        assert (row["n_pass"], row["tp_lines"], row["fp_lines"]) == (nd(exp["filtered"]), nd(exp["tp"]), nd(exp["fp"]))
