@@ -1238,18 +1238,24 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
       ii[s] = valid ? stI[s * 64 + lane] : 0u;
     }
     const uint32_t d = (kk[s] >> shift) & 255u;
-    uint64_t peers = ballot64(valid);
+    // peers = valid lanes with my digit.  Kept as two 32-bit halves and accumulated as "differs from me in some bit":
+    // per bit one sign-extending bit-field extract (0 / -1), one ballot, two XORs, two ORs -- the 64-bit select form
+    // the compiler made of `peers &= bit ? m : ~m` took nine VALU per bit, and this kernel is VALU-bound.
+    uint32_t np_lo = 0, np_hi = 0;
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-      const uint64_t m = ballot64((d >> b) & 1u);
-      peers &= ((d >> b) & 1u) ? m : ~m;
+      const int32_t t = ((int32_t)(d << (31 - b))) >> 31;          // all ones if bit b of my digit is set
+      const uint64_t m = ballot64(t != 0);
+      np_lo |= (uint32_t)m ^ (uint32_t)t;
+      np_hi |= (uint32_t)(m >> 32) ^ (uint32_t)t;
     }
-    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
-    const uint32_t r = (uint32_t)__popcll(peers & below);
+    const uint64_t vm = ballot64(valid);
+    const uint32_t p_lo = (uint32_t)vm & ~np_lo, p_hi = (uint32_t)(vm >> 32) & ~np_hi;
+    const uint32_t r = __builtin_amdgcn_mbcnt_hi(p_hi, __builtin_amdgcn_mbcnt_lo(p_lo, 0u));   // peers in lower lanes
     uint32_t basec = 0;
     if (valid) basec = s_cnt[wave][d];   // every peer reads before the leader writes (same wave, in order)
     rk[s] = basec + r;
-    if (valid && r == 0) s_cnt[wave][d] = basec + (uint32_t)__popcll(peers);
+    if (valid && r == 0) s_cnt[wave][d] = basec + (uint32_t)__popc(p_lo) + (uint32_t)__popc(p_hi);
   }
   __syncthreads();
   // thread d: digit d's count over the 4 waves -> exclusive scan over digits = tile-local run starts
