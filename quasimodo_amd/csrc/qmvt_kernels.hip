@@ -939,7 +939,6 @@ __global__ __launch_bounds__(64) void k_compact(CompactParams P) {
   F.first = F.end = ((uint32_t)vd.n - fp_total) + P.tile_fp_off[sp.tile0];
   T.drained = T.first & ~255u;
   F.drained = F.first & ~255u;
-  const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
 #pragma unroll
   for (int i = 0; i < K3_REGS; ++i) {
     const int wn = nwords - i * 64 < 64 ? nwords - i * 64 : 64;
@@ -949,8 +948,11 @@ __global__ __launch_bounds__(64) void k_compact(CompactParams P) {
       const uint64_t wt = ((uint64_t)thi << 32) | tlo;
       const uint64_t wf = (((uint64_t)phi << 32) | plo) & ~wt;
       const uint32_t rel = (uint32_t)(sb + (i * 64 + j) * 64 + lane);
-      if ((wt >> lane) & 1ull) T.buf[(T.end + (uint32_t)__popcll(wt & below)) & (K3_RING - 1)] = rel;
-      if ((wf >> lane) & 1ull) F.buf[(F.end + (uint32_t)__popcll(wf & below)) & (K3_RING - 1)] = rel;
+      // the word IS the execution mask (inverse ballot: no per-lane bit test) and mbcnt ranks the lane inside it
+      if (__builtin_amdgcn_inverse_ballot_w64(wt))
+        T.buf[(T.end + __builtin_amdgcn_mbcnt_hi((uint32_t)(wt >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wt, 0u))) & (K3_RING - 1)] = rel;
+      if (__builtin_amdgcn_inverse_ballot_w64(wf))
+        F.buf[(F.end + __builtin_amdgcn_mbcnt_hi((uint32_t)(wf >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wf, 0u))) & (K3_RING - 1)] = rel;
       T.end += (uint32_t)__popcll(wt);
       F.end += (uint32_t)__popcll(wf);
       // drain complete 256-entry chunks (wave-uniform conditions)
