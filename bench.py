@@ -151,6 +151,12 @@ def main():
     # algorithmic bytes of one k_classify launch: 17 B per record + 12 B per truth key per VCF
     alg_bytes = n_vcf * (17.0 * args.records + 12.0 * t_unique)
     k1_s = tm["classify_ms"] * 1e-3
+    roof_kernel = "k_classify"
+    if args.shuffled:
+        # the optimistic k_classify pass stops early on shuffled VCFs; the work is the radix-sort path, which is
+        # overhead in SURVEY 8d's accounting: the same algorithmic bytes over the whole step
+        k1_s = dt / args.steps
+        roof_kernel = "whole step (optimistic pass + radix-sort path + packed k_classify)"
     achieved = alg_bytes / k1_s / 1e9 if k1_s > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes per launch from a separate --pmc pass
@@ -179,9 +185,9 @@ def main():
                                % (workload_name(args), n_vcf, args.records, args.genome, t_unique, args.bins, ", records shuffled (radix-sort path)" if args.shuffled else ", position sorted"),
                    "vcfs_per_gpu": n_vcf, "records_per_vcf": args.records, "parallelism": "vcf-shard x%d" % world,
                    "collective": "1 all-reduce of [%d x 3 x %d] int64 per step" % (eng.n_truth, args.bins) if world > 1 else "none"},
-        "roofline": {"bound": "hbm", "kernel": "k_classify", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": roof_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": tm["classify_ms"]},
+                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k1_s * 1e3},
         "kernels_ms": tm,
         "device_bytes": batch.device_bytes,
     }
