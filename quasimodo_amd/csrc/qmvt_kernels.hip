@@ -591,7 +591,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
   const int vn = sp.vn;
   const int sp_end = (int)(sp.end - sp.voff);
   const int nb = P.n_bins;
-  const int ablate = P.ablate;
+#ifdef QM_ABLATE_SUPPORT
+  const int ablate = P.ablate;   // debug builds only: phases can be switched off to price them
+#else
+  constexpr int ablate = 0;
+#endif
 
   for (int i = lane; i < L_KEYS; i += 64) lds[i] = 0;   // histograms
   Acc A = {0u, 0u, 0u, 0u, 0u, 0u};
