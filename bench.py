@@ -192,6 +192,16 @@ def main():
         "device_bytes": batch.device_bytes,
     }
 
+    if rank == 0:
+        # the second denominator SURVEY 8d asks for: what a plain device-to-device copy moves on this very GPU
+        # (bytes read + bytes written per second), measured after the timed region
+        try:
+            cp = measured_copy_GBps(dev)
+            out["roofline"]["measured_copy_GBps"] = cp
+            out["roofline"]["frac_of_measured_copy"] = achieved / cp if cp > 0 else None
+        except Exception as e:   # never fatal
+            out["roofline"]["measured_copy_GBps"] = None
+            out["roofline"]["measured_copy_error"] = str(e)[:120]
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(batch, args, min(args.cpu_sample, n_vcf), args.genome, args.truth, tseed)
     if rank == 0 and world == 1 and args.shell_sample > 0:
@@ -209,6 +219,25 @@ def main():
     eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def measured_copy_GBps(dev, nbytes=2 << 30, reps=5):
+    """device-to-device copy of 2 GiB: (bytes read + bytes written) / second"""
+    import torch
+    a = torch.empty(nbytes // 4, dtype=torch.int32, device=dev)
+    b = torch.empty_like(a)
+    a.fill_(1)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del a, b
+    return 2.0 * nbytes / (ms * 1e-3) / 1e9
 
 
 def workload_name(args):
