@@ -20,10 +20,15 @@
  *                awk test `$6>=t` (t = 0..n_bins-1); '.' and passing non-numeric
  *                spellings are +inf, failing ones -inf
  *   flags uint8  bit0 QM_F_PASS  = line kept by the A2 filter (extract_TP_FP_SNPs.py:24)
- *                bit1 QM_F_IDDOT = ID column is exactly "."
+ *                bit1 QM_F_IDDOT = ID column is exactly "." (a key match makes the line a TP line);
+ *                                  cleared by qm_vcf_hostpath for a line it found NOT selected
  *                bit2 QM_F_NOKEY = the line has no comparable key (POS is not a canonical
  *                                  decimal): it can never be in the truth set; the packer
  *                                  gives it the previous record's pos so order is kept
+ *                bit3 QM_F_TPLINE = the text side (qm_vcf_hostpath) found the line selected by
+ *                                  `fgrep -wf` where the columns cannot tell (pattern aligned at
+ *                                  other columns, POS spelled non-canonically, ...): a TP LINE
+ *                                  whatever its key says; unique-key (R path) counts ignore it
  */
 #ifndef QMVT_H
 #define QMVT_H
@@ -35,7 +40,7 @@
 extern "C" {
 #endif
 
-#define QM_ABI_VERSION 1
+#define QM_ABI_VERSION 2
 
 #define QM_OK 0
 #define QM_E_INVAL (-1)     /* bad argument */
@@ -68,6 +73,7 @@ extern "C" {
 #define QM_F_PASS 1u
 #define QM_F_IDDOT 2u
 #define QM_F_NOKEY 4u
+#define QM_F_TPLINE 8u
 
 #define QM_CLS_KEPT 1u /* out_cls bit0: line is in <x>.filtered.vcf */
 #define QM_CLS_TP 2u   /* out_cls bit1: line is in tp/<x>.tp.vcf (else, if kept, fp/) */
@@ -110,7 +116,11 @@ int qm_truth_load(qm_ctx* ctx, const int32_t* pos, const int32_t* ref, const int
 int qm_truth_size(qm_ctx* ctx, int truth_id, int64_t* n_unique);
 /* distinct valid (pos, ref, alt) entries of any allele length: T' of allele-extended batches */
 int qm_truth_size_ext(qm_ctx* ctx, int truth_id, int64_t* n_unique);
+/* number of truth-set slots of the context (released ones included: ids are stable) */
 int qm_truth_count(qm_ctx* ctx);
+/* Frees a truth set's device memory.  Its id may be handed out again by a later load; a batch created
+ * against the released set refuses to run (QM_E_STATE). */
+int qm_truth_release(qm_ctx* ctx, int truth_id);
 
 /* ---- one-shot, host buffers -------------------------------------------------
  * What n_vcf invocations of the reference script compute (A2 flags in, A4/A5
@@ -178,7 +188,7 @@ int qm_bench_synth(qm_ctx* ctx, const qm_synth_cfg* cfg, int n_vcf, int64_t reco
 /* Enqueue the whole path on `stream` (a hipStream_t; NULL = the context's own
  * stream): classify -> finalize (ROC suffix sums, tile offsets, per-truth sums)
  * -> compaction of TP/FP line indices.  Asynchronous.  If global_dev is not
- * NULL it must be a device buffer of [n_truth_sets][3][n_bins] uint64 that
+ * NULL it must be a device buffer of [qm_batch_n_truth(b)][3][n_bins] uint64 that
  * receives the per-truth sums (the caller all-reduces it across ranks). */
 int qm_batch_run(qm_batch* b, void* stream, void* global_dev);
 /* Wait for the stream, then redo VCFs found unsorted through the radix-sort path. */
@@ -193,11 +203,14 @@ int qm_batch_get_cls(qm_batch* b, int vcf, uint8_t* out_cls);
 int qm_batch_get_idx(qm_batch* b, int vcf, int32_t* out_idx);
 int qm_batch_get_roc(qm_batch* b, uint64_t* out_roc /*[n_vcf][3][n_bins]*/);
 int qm_batch_get_scalars(qm_batch* b, int64_t* out /*[n_vcf][QM_N_SCALARS]*/);
-int qm_batch_get_global(qm_batch* b, uint64_t* out /*[n_truth_sets][3][n_bins]*/);
+int qm_batch_get_global(qm_batch* b, uint64_t* out /*[qm_batch_n_truth(b)][3][n_bins]*/);
 int qm_batch_get_columns(qm_batch* b, int vcf, int32_t* pos, int32_t* ref, int32_t* alt, float* qual,
                          uint8_t* flags);
 /* Bytes the engine holds in HBM for this batch. */
 int64_t qm_batch_device_bytes(qm_batch* b);
+/* Rows of the per-truth sums ([n][3][n_bins]; qm_batch_get_global, qm_batch_run's global_dev): the number of
+ * truth-set slots the context had when the batch was created.  Truth sets loaded later do not change it. */
+int qm_batch_n_truth(qm_batch* b);
 
 /* ---- FP overlap (rules/compare_FP.smk + scripts/snpcaller_fp_compare.R:36-47) -
  * n_sets (<= 5) key lists (fp.vcf rows as packed columns); regions[m] = number
@@ -209,15 +222,25 @@ int qm_fp_overlap(qm_ctx* ctx, int n_sets, const int64_t* set_offsets, const int
  * Replaces the three awk passes + `grep -E "^#"` per VCF
  * (extract_TP_FP_SNPs.py:24-32,50,52) with one scan.  qm_vcf_scan fills, for
  * every line of the text (header lines included), its byte offset; for data
- * lines the packed columns.  Returns the number of lines, or a negative code.
- * line_kind: 0 = data, 1 = header ('#'), 2 = data line the engine refuses in
- * strict mode (QM_E_NONCANON reasons), 3 = header line that also
- * satisfies the A2 filter (awk would emit it as data too; refused in strict mode). */
+ * lines the packed columns.  Returns QM_OK or a negative code.  line_kind: */
+#define QM_LINE_DATA 0          /* data line, described completely by its columns */
+#define QM_LINE_HEADER 1        /* begins with '#' */
+#define QM_LINE_DATA_HOST 2     /* single-base data line whose fgrep answer the columns cannot give (POS not a
+                                   canonical decimal, or a "\t.\t" that a pattern could sit on after the ALT column):
+                                   qm_vcf_hostpath decides it and writes the decision into its flags */
+#define QM_LINE_HEADER_KEPT 3   /* '#' line that also satisfies the A2 filter: awk does not skip it, so the reference
+                                   emits it in the header block AND among the kept lines (and then in tp or fp) */
+#define QM_LINE_HEADER_KEPT_TP 4 /* the same once qm_vcf_hostpath found it selected by fgrep -wf */
+#define QM_LINE_REFUSED 5       /* kept data line holding NUL or bytes >= 0x80: the reference's answer depends on the
+                                   locale Python exports to grep (PEP 538); strict callers stop with QM_E_NONCANON */
+#define QM_LINE_HEADER_REFUSED 6 /* the same for a '#' line that satisfies the A2 filter */
 typedef struct qm_vcf_cols {
   int64_t n_lines;      /* all lines */
   int64_t n_data;       /* data lines = records */
-  int64_t n_noncanon;   /* kept lines with locale-dependent / non-canonical matching */
-  int64_t first_noncanon_line; /* 1-based, 0 = none */
+  int64_t n_host;       /* lines for qm_vcf_hostpath (kinds 2 and 3) */
+  int64_t n_refused;    /* kinds 5 and 6 */
+  int64_t first_refused_line; /* 1-based, 0 = none */
+  int64_t n_nokey_kept; /* kept data lines without a comparable key (QM_F_NOKEY): qm_vcf_hostpath counts their keys as text */
 } qm_vcf_cols;
 typedef struct qm_dict qm_dict;
 int64_t qm_vcf_count_lines(const uint8_t* text, size_t len);
@@ -226,10 +249,12 @@ int qm_vcf_scan(const uint8_t* text, size_t len, int64_t cap_lines, int64_t* lin
                 qm_vcf_cols* info);
 /* Truth text -> key columns.  mode 0 = VCF as written by mummer2vcf.py
  * (columns 2,4,5), mode 1 = 12-column show-snps TSV (columns 1,2,3).
- * out_counts[0] = rows R counts as `genomediff`, [1] = keys emitted,
- * [2] = rows with a pattern that can never match canonical lines, [3] = rows refused. */
+ * out_counts[0] = rows R counts as `genomediff`, [1] = keys emitted (rows that are not comments, with a
+ * canonical position and single-base alleles: the only patterns a line can match through its columns),
+ * [2] = rows whose pattern can match no such line (they live in qm_patterns only), [3] = rows refused
+ * (NUL / non-ASCII bytes), [4] = '#' rows that awk turns into a pattern all the same. */
 int64_t qm_truth_scan(const uint8_t* text, size_t len, int mode, int64_t cap, int32_t* pos, int32_t* ref,
-                      int32_t* alt, int64_t* out_counts);
+                      int32_t* alt, int64_t* out_counts /*[5]*/);
 /* Allele-extended tokenising (QM_BATCH_ALLELES): the filter's `^[ACGT]$` becomes `^[ACGT]+$`, ref / alt
  * carry allele codes, alleles longer than QM_ALLELE_INLINE_MAX bases are interned in `dict`, which the
  * truth set and every VCF of a batch must share.  dict == NULL is qm_vcf_scan / qm_truth_scan.
@@ -245,9 +270,36 @@ int qm_vcf_scan_ext(const uint8_t* text, size_t len, int64_t cap_lines, int64_t*
                     int32_t* pos, int32_t* ref, int32_t* alt, float* qual, uint8_t* flags, qm_vcf_cols* info,
                     qm_dict* dict);
 int64_t qm_truth_scan_ext(const uint8_t* text, size_t len, int mode, int64_t cap, int32_t* pos, int32_t* ref,
-                          int32_t* alt, int64_t* out_counts, qm_dict* dict);
+                          int32_t* alt, int64_t* out_counts /*[5]*/, qm_dict* dict);
+
+/* ---- host path for what the columns cannot describe -----------
+ * qm_patterns is the pattern list the reference feeds to `fgrep -wf` (extract_TP_FP_SNPs.py:47-53, :92-98), kept as
+ * TEXT: one pattern X \t . \t Y \t Z per truth row that satisfies the awk program, '#' rows included.  mode as
+ * qm_truth_scan; ext != 0 widens `^[ACGT]$` to `^[ACGT]+$` (allele-extended mode, mode 0 only).
+ * info[0] = distinct patterns, [1] = patterns whose Y / Z are not one character each, [2] = canonical keys that only
+ * '#' rows carry (fgrep sees them, R does not), [3] = rows refused (NUL / non-ASCII).  When [1] or [2] is non-zero the
+ * columns alone cannot reproduce the reference for ANY line compared with this truth set: qm_vcf_hostpath then
+ * decides every single-base data line from the text. */
+typedef struct qm_patterns qm_patterns;
+qm_patterns* qm_patterns_create(const uint8_t* truth_text, size_t len, int mode, int ext);
+void qm_patterns_destroy(qm_patterns* p);
+int qm_patterns_info(const qm_patterns* p, int64_t* info /*[4]*/);
+/* Exact `fgrep -w` (GNU grep 3.7: a pattern occurrence with a non-word character or the line edge on both sides) for
+ * the lines of one scanned VCF that need it: kind QM_LINE_DATA_HOST lines get QM_F_TPLINE set or QM_F_IDDOT cleared
+ * in `flags` (indexed by data line), QM_LINE_HEADER_KEPT lines become QM_LINE_HEADER_KEPT_TP when selected.  Run it
+ * between qm_vcf_scan and the upload of the columns; the device then counts and lists these lines like any other.
+ * R's unique-key counts (caller_performance_compare.R:84-99) take the key of a line as TEXT; for kept lines without
+ * a comparable key the device counts distinct (carried pos, ref, alt) instead, so out[2..4] carry the exchange:
+ * out[0] = lines decided here, [1] = of them selected, [2] = what the device will add to FP_R for the QM_F_NOKEY
+ * lines, [3] = their distinct text keys found in the truth file as R reads it (add to TP_R), [4] = the other
+ * distinct text keys (add to FP_R after subtracting [2]).  pos / ref / alt: the scan's columns. */
+int qm_vcf_hostpath(const qm_patterns* p, const uint8_t* text, size_t len, int64_t n_lines, const int64_t* line_off,
+                    uint8_t* line_kind, const int32_t* pos, const int32_t* ref, const int32_t* alt, uint8_t* flags,
+                    int64_t* out /*[5]*/);
+
 /* Writes header lines + selected data lines, verbatim, newline-terminated
- * (SURVEY Q7).  select: 0 = kept (filtered.vcf), 1 = TP, 2 = FP. */
+ * (SURVEY Q7).  select: 0 = kept (filtered.vcf), 1 = TP, 2 = FP.  QM_LINE_HEADER_KEPT(_TP) lines appear in the
+ * header block and again, in input order, among the selected lines.  Atomic (temp file + rename). */
 int qm_vcf_write(const char* path, const uint8_t* text, size_t len, int64_t n_lines, const int64_t* line_off,
                  const uint8_t* line_kind, const uint8_t* cls /*per data line*/, int select);
 /* SNP / indel splitters of rules/vis_eval_vcf.smk:35,50,66,81 (`extract_snp`, `extract_indel`,

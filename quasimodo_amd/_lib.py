@@ -12,6 +12,7 @@ SCALAR_NAMES = ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R", "sorted", "n_r
 ERRORS = {-1: "QM_E_INVAL", -2: "QM_E_NODEVICE", -3: "QM_E_HIP", -4: "QM_E_NOMEM", -5: "QM_E_RANGE",
           -6: "QM_E_STATE", -7: "QM_E_IO", -8: "QM_E_NONCANON", -9: "QM_E_LIMIT"}
 QM_BATCH_ALLELES = 1
+QM_ABI_VERSION = 2
 
 # every symbol include/qmvt.h declares
 EXPORTS = (
@@ -22,7 +23,8 @@ EXPORTS = (
     "qm_fp_overlap", "qm_vcf_count_lines", "qm_vcf_scan", "qm_truth_scan", "qm_vcf_write", "qm_vcf_split_write",
     "qm_truth_size_ext", "qm_truth_synth_ext", "qm_batch_create_ext", "qm_classify_batch_ext",
     "qm_dict_create", "qm_dict_destroy", "qm_dict_size", "qm_allele_code", "qm_allele_spell", "qm_vcf_scan_ext", "qm_truth_scan_ext",
-    "qm_bench_synth",
+    "qm_bench_synth", "qm_truth_release", "qm_batch_n_truth",
+    "qm_patterns_create", "qm_patterns_destroy", "qm_patterns_info", "qm_vcf_hostpath",
 )
 
 
@@ -44,8 +46,8 @@ class SynthCfg(C.Structure):
 
 
 class VcfCols(C.Structure):
-    _fields_ = [("n_lines", C.c_int64), ("n_data", C.c_int64), ("n_noncanon", C.c_int64),
-                ("first_noncanon_line", C.c_int64)]
+    _fields_ = [("n_lines", C.c_int64), ("n_data", C.c_int64), ("n_host", C.c_int64), ("n_refused", C.c_int64),
+                ("first_refused_line", C.c_int64), ("n_nokey_kept", C.c_int64)]
 
 
 def library_path():
@@ -89,6 +91,8 @@ def lib():
     L.qm_batch_create_ext.argtypes = [vp, i32, vp, vp, i32, C.c_uint, C.POINTER(vp)]
     L.qm_classify_batch_ext.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, C.c_uint, vp, vp, vp, vp, vp]
     L.qm_truth_count.argtypes = [vp]
+    L.qm_truth_release.argtypes = [vp, i32]
+    L.qm_batch_n_truth.argtypes = [vp]
     L.qm_classify_batch.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     L.qm_batch_create.argtypes = [vp, i32, vp, vp, i32, C.POINTER(vp)]
     L.qm_batch_destroy.argtypes = [vp]
@@ -127,6 +131,12 @@ def lib():
     L.qm_allele_code.restype = i32
     L.qm_allele_spell.argtypes = [vp, i32, C.c_char_p, C.c_size_t]
     L.qm_allele_spell.restype = i64
+    L.qm_patterns_create.argtypes = [C.c_char_p, C.c_size_t, i32, i32]
+    L.qm_patterns_create.restype = vp
+    L.qm_patterns_destroy.argtypes = [vp]
+    L.qm_patterns_destroy.restype = None
+    L.qm_patterns_info.argtypes = [vp, vp]
+    L.qm_vcf_hostpath.argtypes = [vp, C.c_char_p, C.c_size_t, i64, vp, vp, vp, vp, vp, vp, vp]
     L.qm_vcf_write.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, i64, vp, vp, vp, i32]
     L.qm_vcf_split_write.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, i32, i32, C.POINTER(C.c_int64)]
     _lib = L

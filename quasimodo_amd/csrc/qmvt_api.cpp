@@ -54,6 +54,10 @@ struct Truth {
   int64_t syn_L = 0, syn_T = 0;
   uint64_t syn_seed = 0;
   int syn_pct = 0;
+  // qm_truth_release: the slot stays (ids are stable) and may be reused by a later load; `gen` tells a batch that was
+  // created against an earlier tenant of the slot that its truth set is gone
+  bool released = false;
+  uint32_t gen = 0;
 };
 
 struct qm_ctx {
@@ -201,11 +205,37 @@ static int truth_from_keys(qm_ctx* c, std::vector<uint32_t>& keys, std::vector<X
   Truth t;
   int rc = truth_build(keys, xe, t);
   if (rc != QM_OK) { truth_free(t); return rc; }   // nothing half-built stays behind
-  c->truths.push_back(t);
+  int slot = -1;
+  for (size_t i = 0; i < c->truths.size(); ++i) if (c->truths[i].released) { slot = (int)i; break; }
+  if (slot >= 0) {   // a released slot is reused: long-lived contexts do not grow without bound
+    t.gen = c->truths[(size_t)slot].gen + 1;
+    c->truths[(size_t)slot] = t;
+  } else {
+    c->truths.push_back(t);
+    slot = (int)c->truths.size() - 1;
+  }
   rc = upload_truth_table(c);
-  if (rc != QM_OK) { truth_free(c->truths.back()); c->truths.pop_back(); return rc; }
-  if (truth_id) *truth_id = (int)c->truths.size() - 1;
+  if (rc != QM_OK) {
+    const uint32_t g = c->truths[(size_t)slot].gen;
+    truth_free(c->truths[(size_t)slot]);
+    if (slot == (int)c->truths.size() - 1 && g == 0) c->truths.pop_back();
+    else { c->truths[(size_t)slot].released = true; c->truths[(size_t)slot].gen = g; }
+    return rc;
+  }
+  if (truth_id) *truth_id = slot;
   return QM_OK;
+}
+
+extern "C" int qm_truth_release(qm_ctx* c, int truth_id) {
+  if (!c || truth_id < 0 || truth_id >= (int)c->truths.size() || c->truths[(size_t)truth_id].released)
+    return fail(QM_E_INVAL, "qm_truth_release: no live truth set %d", truth_id);
+  HIPCHK(hipSetDevice(c->dev));
+  HIPCHK(hipStreamSynchronize(c->stream));   // nothing of this context still reads it
+  const uint32_t g = c->truths[(size_t)truth_id].gen;
+  truth_free(c->truths[(size_t)truth_id]);
+  c->truths[(size_t)truth_id].released = true;
+  c->truths[(size_t)truth_id].gen = g;
+  return upload_truth_table(c);
 }
 
 extern "C" int qm_truth_load(qm_ctx* c, const int32_t* pos, const int32_t* ref, const int32_t* alt, int64_t n, int* truth_id) {
@@ -255,12 +285,12 @@ extern "C" int qm_truth_synth(qm_ctx* c, int64_t L, int64_t T, uint64_t tseed, i
 }
 
 extern "C" int qm_truth_size(qm_ctx* c, int truth_id, int64_t* n_unique) {
-  if (!c || truth_id < 0 || truth_id >= (int)c->truths.size() || !n_unique) return fail(QM_E_INVAL, "qm_truth_size: bad arguments");
+  if (!c || truth_id < 0 || truth_id >= (int)c->truths.size() || c->truths[(size_t)truth_id].released || !n_unique) return fail(QM_E_INVAL, "qm_truth_size: bad arguments");
   *n_unique = c->truths[(size_t)truth_id].n;
   return QM_OK;
 }
 extern "C" int qm_truth_size_ext(qm_ctx* c, int truth_id, int64_t* n_unique) {
-  if (!c || truth_id < 0 || truth_id >= (int)c->truths.size() || !n_unique) return fail(QM_E_INVAL, "qm_truth_size_ext: bad arguments");
+  if (!c || truth_id < 0 || truth_id >= (int)c->truths.size() || c->truths[(size_t)truth_id].released || !n_unique) return fail(QM_E_INVAL, "qm_truth_size_ext: bad arguments");
   *n_unique = c->truths[(size_t)truth_id].xn;
   return QM_OK;
 }
@@ -350,6 +380,10 @@ struct qm_batch {
   bool ran = false, finished = false;
   bool ext = false;   // allele-extended: any valid allele code takes part (build-defined widening, config 5)
   uint64_t* last_global = nullptr;
+  // The per-truth sums are laid out for the truth sets that existed when the batch was created: later loads on the
+  // same context change neither the size of global_acc nor what qm_batch_get_global copies.
+  int n_truth = 1;
+  std::vector<std::pair<int, uint32_t>> truth_gens;   // (truth id, generation) of every truth set a VCF names
 };
 
 static void batch_free(qm_batch* b) {
@@ -385,6 +419,11 @@ static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int
   b->cap_tiles = L.tile_vcf.size();
   const size_t np = (size_t)L.n_pad;
   const size_t nt = std::max<size_t>(1, (size_t)c->truths.size());
+  b->n_truth = (int)nt;
+  for (int v = 0; v < n_vcf; ++v) {
+    const std::pair<int, uint32_t> tg(truth_ids[v], c->truths[(size_t)truth_ids[v]].gen);
+    if (std::find(b->truth_gens.begin(), b->truth_gens.end(), tg) == b->truth_gens.end()) b->truth_gens.push_back(tg);
+  }
   int rc = QM_OK;
 #define A_(p, n) if (rc == QM_OK) { rc = dalloc(&(p), (n)); if (rc == QM_OK) b->dev_bytes += (int64_t)((n) * sizeof(*(p))); }
   if (packed) {
@@ -423,7 +462,7 @@ extern "C" int qm_batch_create_ext(qm_ctx* c, int n_vcf, const int64_t* n_record
   *out = nullptr;
   for (int v = 0; v < n_vcf; ++v) {
     if (n_records[v] < 0 || n_records[v] > 0x7fffff00ll) return fail(QM_E_INVAL, "qm_batch_create: VCF %d has %lld records", v, (long long)n_records[v]);
-    if (truth_id_per_vcf[v] < 0 || truth_id_per_vcf[v] >= (int)c->truths.size())
+    if (truth_id_per_vcf[v] < 0 || truth_id_per_vcf[v] >= (int)c->truths.size() || c->truths[(size_t)truth_id_per_vcf[v]].released)
       return fail(QM_E_INVAL, "qm_batch_create: VCF %d names truth set %d (have %zu)", v, truth_id_per_vcf[v], c->truths.size());
   }
   HIPCHK(hipSetDevice(c->dev));
@@ -438,6 +477,7 @@ extern "C" int qm_batch_create(qm_ctx* c, int n_vcf, const int64_t* n_records, c
 
 extern "C" void qm_batch_destroy(qm_batch* b) { batch_free(b); }
 extern "C" int64_t qm_batch_device_bytes(qm_batch* b) { return b ? b->dev_bytes : 0; }
+extern "C" int qm_batch_n_truth(qm_batch* b) { return b ? b->n_truth : 0; }
 
 extern "C" int qm_batch_upload(qm_batch* b, int v, const int32_t* pos, const int32_t* ref, const int32_t* alt, const float* qual,
                                const uint8_t* flags) {
@@ -547,7 +587,10 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
   HIPCHK(hipSetDevice(c->dev));
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   uint64_t* g = global_dev ? (uint64_t*)global_dev : b->global_acc;
-  const size_t gbytes = std::max<size_t>(1, c->truths.size()) * 3 * (size_t)b->n_bins * 8;
+  for (const auto& tg : b->truth_gens)
+    if (tg.first >= (int)c->truths.size() || c->truths[(size_t)tg.first].released || c->truths[(size_t)tg.first].gen != tg.second)
+      return fail(QM_E_STATE, "qm_batch_run: truth set %d was released after the batch was created", tg.first);
+  const size_t gbytes = (size_t)b->n_truth * 3 * (size_t)b->n_bins * 8;   // as allocated at batch creation
   HIPCHK(hipMemsetAsync(g, 0, gbytes, st));
   hipEvent_t* ev = b->ev[b->n_timed % qm_batch::EV_RING];
   if (b->timing) HIPCHK(hipEventRecord(ev[0], st));
@@ -590,10 +633,11 @@ static int regrow(T** p, int64_t* cap, int64_t need, int64_t* bytes) {
   if (need <= *cap) return QM_OK;
   (void)hipFree(*p);
   *p = nullptr;
+  *bytes -= *cap * (int64_t)sizeof(T);
   *cap = 0;
   int rc = dalloc(p, (size_t)need);
   if (rc != QM_OK) return rc;
-  *bytes += (need - *cap) * (int64_t)sizeof(T);
+  *bytes += need * (int64_t)sizeof(T);
   *cap = need;
   return QM_OK;
 }
@@ -694,6 +738,8 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   HIPCHK(hipStreamSynchronize(st));
   for (int i = 0; i < nseg; ++i) {
     if (sfl[(size_t)i] & SPANF_UNSORTED) return fail(QM_E_HIP, "internal: VCF %d still unsorted after the radix sort", vs[(size_t)i]);
+    // the optimistic pass stops streaming at the first out-of-order tile: a bad position behind it shows up only here
+    if (sfl[(size_t)i] & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", vs[(size_t)i]);
     if (sfl[(size_t)i] & SPANF_RUNLIMIT)
       return fail(QM_E_LIMIT, "VCF %d repeats one position more than %d times between equal alleles (allele-extended de-duplication limit)",
                   vs[(size_t)i], 1 << 14);
@@ -801,7 +847,7 @@ extern "C" int qm_batch_get_scalars(qm_batch* b, int64_t* out) {
 extern "C" int qm_batch_get_global(qm_batch* b, uint64_t* out) {
   NEED_FINISHED(b, "qm_batch_get_global");
   HIPCHK(hipSetDevice(b->ctx->dev));
-  HIPCHK(hipMemcpy(out, b->last_global, b->ctx->truths.size() * 3 * (size_t)b->n_bins * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out, b->last_global, (size_t)b->n_truth * 3 * (size_t)b->n_bins * 8, hipMemcpyDeviceToHost));
   return QM_OK;
 }
 extern "C" int qm_batch_get_columns(qm_batch* b, int v, int32_t* pos, int32_t* ref, int32_t* alt, float* qual, uint8_t* flags) {
@@ -874,7 +920,7 @@ extern "C" int qm_bench_synth(qm_ctx* c, const qm_synth_cfg* cfg, int n_vcf, int
   std::vector<int32_t> tids((size_t)n_vcf, tid);
   qm_batch* b = nullptr;
   rc = qm_batch_create_ext(c, n_vcf, n.data(), tids.data(), n_bins, cfg->indel_pct > 0 ? QM_BATCH_ALLELES : 0u, &b);
-  if (rc != QM_OK) return rc;
+  if (rc != QM_OK) { std::string keep = g_err; (void)qm_truth_release(c, tid); g_err = keep; return rc; }
   rc = qm_batch_synth(b, cfg);
   if (rc == QM_OK) rc = qm_batch_run(b, nullptr, nullptr);      // warm-up, also sorts what needs sorting once
   if (rc == QM_OK) rc = qm_batch_finish(b, nullptr);
@@ -905,6 +951,7 @@ extern "C" int qm_bench_synth(qm_ctx* c, const qm_synth_cfg* cfg, int n_vcf, int
   }
   std::string keep = g_err;
   qm_batch_destroy(b);
+  (void)qm_truth_release(c, tid);   // the synthetic truth set belonged to this run only
   g_err = keep;
   return rc;
 }

@@ -31,6 +31,7 @@ constexpr int QM_POS_LIMIT_DEV = 1 << 28;
 constexpr uint32_t QMF_PASS = 1u;
 constexpr uint32_t QMF_IDDOT = 2u;
 constexpr uint32_t QMF_NOKEY = 4u;
+constexpr uint32_t QMF_TPLINE = 8u;   // decided on the host: a TP line whatever the key says (include/qmvt.h)
 constexpr uint32_t SPANF_UNSORTED = 1u;
 constexpr uint32_t SPANF_BADPOS = 2u;
 constexpr uint32_t SPANF_RUNLIMIT = 4u;   // allele-extended batch: more records at one position than the dedupe walk allows

@@ -7,6 +7,9 @@
 //   grep -E "^#"                                                    :27,50,52
 //   awk ... {print $2,".",$4,$5}  /  {print $1,".",$2,$3}           :47, :92
 //   shell `>` redirection of the selected lines                     :50-53
+#include <algorithm>
+#include <array>
+#include <atomic>
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
@@ -18,6 +21,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/uio.h>
 #include <unistd.h>
 
 #include "../../include/qmvt.h"
@@ -188,8 +193,10 @@ inline int split_head(const uint8_t* line, size_t n, Span* f, int maxf) {
   }
   return nf;
 }
-// could a truth pattern X\t.\tY\tZ also be found at later columns?  Walks the fields from QUAL
-// (field 5) to the end of the line with a window of four: (ends in a digit, ".", Y-like, Z-like then non-word).
+// could a truth pattern X\t.\tY\tZ also sit on a "\t.\t" behind the ID column?  Walks the fields from
+// ALT (field 4) to the end of the line with a window of four: (anything, ".", Y-like, Z-like then a non-word character).
+// Y-like / Z-like = one character each (allele-extended: [ACGT]+); truth sets holding patterns of other shapes send
+// every line to the host path anyway (qm_patterns_info).
 bool pattern_at_later_fields(const uint8_t* s, const uint8_t* end, bool ext) {
   Span w[4] = {{s, 0}, {s, 0}, {s, 0}, {s, 0}};
   int have = 0;
@@ -197,7 +204,7 @@ bool pattern_at_later_fields(const uint8_t* s, const uint8_t* end, bool ext) {
     const uint8_t* t = (const uint8_t*)memchr(s, '\t', (size_t)(end - s));
     w[0] = w[1]; w[1] = w[2]; w[2] = w[3];
     w[3].p = s; w[3].n = (size_t)((t ? t : end) - s);
-    if (++have >= 4 && is_dot(w[1]) && w[0].n && w[0].p[w[0].n - 1] >= '0' && w[0].p[w[0].n - 1] <= '9' &&
+    if (++have >= 4 && is_dot(w[1]) &&
         (ext ? acgt_all(w[2]) && acgt_prefix_word(w[3]) : w[2].n == 1 && w[3].n >= 1 && (w[3].n == 1 || !is_word(w[3].p[1]))))
       return true;
     if (!t) return false;
@@ -225,7 +232,7 @@ struct ScanChunk {
   size_t begin = 0, end = 0;       // byte range
   int64_t nl = 0, nd = 0;          // lines / data lines in the chunk
   int64_t l0 = 0, d0 = 0;          // global index of its first line / data line
-  int64_t nnc = 0, first_nc = 0;   // non-canonical kept lines; 1-based global line of the first
+  int64_t nhost = 0, nref = 0, first_ref = 0, nnokey = 0;   // host-path lines; refused lines, 1-based global line of the first; kept NOKEY lines
   int32_t last_pos = 0;            // last canonical POS seen in the chunk (0 if none)
   int64_t lead_nokey = 0;          // data lines before the chunk's first canonical POS
   bool any_pos = false;
@@ -251,20 +258,27 @@ static void scan_chunk(const uint8_t* text, ScanChunk& c, bool count_only, int64
     } else {
       const int64_t gl = c.l0 + nl, gd = c.d0 + nd;
       line_off[gl] = (int64_t)off;
+      auto dirty = [&]() {   // NUL / non-ASCII: the reference's answer depends on the locale its grep runs under
+        for (size_t i = 0; i < n; ++i) if (s[i] == 0 || s[i] >= 0x80) return true;
+        return false;
+      };
       if (header) {
-        // awk does not skip '#': a header line that also satisfies the A2 filter is emitted twice by the
-        // reference (once by grep, once by awk) while R's read.table ignores it -- refuse to guess (kind 3)
-        uint8_t kind = 1;
+        // awk does not skip '#': a header line that also satisfies the A2 filter is emitted twice by the reference
+        // (once by grep, once by awk, then in tp or fp as fgrep decides) while R's read.table ignores it
+        uint8_t kind = QM_LINE_HEADER;
         const int nf = split_head(s, n, f, MAXF);
         if (nf >= 5 && allele_ok(f[3]) && allele_ok(f[4])) {
           bool ge20 = false;
           const Span empty = {(const uint8_t*)"", 0};
           (void)effective_qual(nf > 5 ? f[5] : empty, &ge20);
-          if (ge20) { kind = 3; ++c.nnc; if (!c.first_nc) c.first_nc = gl + 1; }
+          if (ge20) {
+            if (dirty()) { kind = QM_LINE_HEADER_REFUSED; ++c.nref; if (!c.first_ref) c.first_ref = gl + 1; }
+            else { kind = QM_LINE_HEADER_KEPT; ++c.nhost; }
+          }
         }
         line_kind[gl] = kind;
       } else {
-        uint8_t kind = 0;
+        uint8_t kind = QM_LINE_DATA;
         const int nf = split_head(s, n, f, MAXF);
         const Span empty = {(const uint8_t*)"", 0};
         const Span fpos = nf > 1 ? f[1] : empty, fid = nf > 2 ? f[2] : empty, fref = nf > 3 ? f[3] : empty,
@@ -276,12 +290,14 @@ static void scan_chunk(const uint8_t* text, ScanChunk& c, bool count_only, int64
         int32_t p = -1;
         const bool cpos = canon_pos(fpos, &p);
         if (cpos) { last_pos = p; any_pos = true; } else { p = last_pos; if (!any_pos) c.lead_nokey++; }
-        if (pass) {
-          bool nc = !cpos;  // fgrep compares POS as a string: only canonical spellings are safe
-          for (size_t i = 0; i < n && !nc; ++i) nc = s[i] == 0 || s[i] >= 0x80;  // locale-dependent in the reference
-          if (!nc && nf > 5) nc = pattern_at_later_fields(f[5].p, s + n, dict != nullptr);
-          if (nc) { kind = 2; ++c.nnc; if (!c.first_nc) c.first_nc = gl + 1; }
+        if (pass && dirty()) {
+          kind = QM_LINE_REFUSED; ++c.nref; if (!c.first_ref) c.first_ref = gl + 1;
+        } else if (snp && (!cpos || (nf > 5 && pattern_at_later_fields(f[4].p, s + n, dict != nullptr)))) {
+          // every single-base line, whatever its QUAL: the ROC sweep moves the threshold.  fgrep compares POS as
+          // text, so only canonical spellings are safe on the device
+          kind = QM_LINE_DATA_HOST; ++c.nhost;
         }
+        if (pass && !cpos) ++c.nnokey;
         line_kind[gl] = kind;
         if (pos) {
           pos[gd] = p;
@@ -348,20 +364,22 @@ extern "C" int qm_vcf_scan_ext(const uint8_t* text, size_t len, int64_t cap_line
   for (auto& c : ch) { c.l0 = nl; c.d0 = nd; nl += c.nl; nd += c.nd; }
   if (nl > cap_lines) return QM_E_INVAL;
   run(false);
-  int64_t nnc = 0, first_nc = 0;
+  int64_t nhost = 0, nref = 0, first_ref = 0, nnokey = 0;
   int32_t carry = 0;
   for (auto& c : ch) {
     if (pos && carry != 0)
       for (int64_t i = 0; i < c.lead_nokey; ++i) pos[c.d0 + i] = carry;   // leading records had no position of their own
     if (c.any_pos) carry = c.last_pos;
-    nnc += c.nnc;
-    if (!first_nc && c.first_nc) first_nc = c.first_nc;
+    nhost += c.nhost; nref += c.nref; nnokey += c.nnokey;
+    if (!first_ref && c.first_ref) first_ref = c.first_ref;
   }
   line_off[nl] = (int64_t)len;
   info->n_lines = nl;
   info->n_data = nd;
-  info->n_noncanon = nnc;
-  info->first_noncanon_line = first_nc;
+  info->n_host = nhost;
+  info->n_refused = nref;
+  info->first_refused_line = first_ref;
+  info->n_nokey_kept = nnokey;
   return QM_OK;
 }
 
@@ -416,7 +434,7 @@ extern "C" int64_t qm_truth_scan_ext(const uint8_t* text, size_t len, int mode, 
   if ((!text && len) || (mode != 0 && mode != 1)) return QM_E_INVAL;
   if (dict && mode != 0) return QM_E_INVAL;   // show-snps tables spell gaps as '.', not as VCF alleles
   auto allele_ok = [dict](Span f) { return dict ? acgt_all(f) : acgt1(f); };
-  int64_t genomediff = 0, nkeys = 0, never = 0, refused = 0;
+  int64_t genomediff = 0, nkeys = 0, never = 0, refused = 0, ncomment = 0;
   size_t off = 0;
   Span f[6];
   const Span empty = {(const uint8_t*)"", 0};
@@ -440,7 +458,7 @@ extern "C" int64_t qm_truth_scan_ext(const uint8_t* text, size_t len, int mode, 
       if (pattern && !comment && n) ++genomediff;
     }
     if (!pattern) continue;
-    if (comment) { ++refused; continue; }  // awk makes a pattern of it, R skips it: refuse to guess
+    if (comment) { ++ncomment; continue; }  // awk makes a pattern of it, R skips it: never a device key (qm_patterns keeps it)
     bool ascii = true;
     for (size_t i = 0; i < n && ascii; ++i) ascii = s[i] != 0 && s[i] < 0x80;
     int32_t p;
@@ -459,48 +477,323 @@ extern "C" int64_t qm_truth_scan_ext(const uint8_t* text, size_t len, int mode, 
     }
     ++nkeys;
   }
-  if (out_counts) { out_counts[0] = genomediff; out_counts[1] = nkeys; out_counts[2] = never; out_counts[3] = refused; }
+  if (out_counts) { out_counts[0] = genomediff; out_counts[1] = nkeys; out_counts[2] = never; out_counts[3] = refused; out_counts[4] = ncomment; }
   return nkeys;
 }
 
-extern "C" int qm_vcf_write(const char* path, const uint8_t* text, size_t len, int64_t n_lines, const int64_t* line_off,
-                            const uint8_t* line_kind, const uint8_t* cls, int select) {
-  if (!path || !line_off || !line_kind || select < 0 || select > 2) return QM_E_INVAL;
-  const std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid());
-  FILE* fh = fopen(tmp.c_str(), "wb");
-  if (!fh) return QM_E_IO;
-  std::vector<char> buf;
-  buf.reserve(1 << 20);
-  auto flush = [&]() -> bool {
-    if (buf.empty()) return true;
-    const bool ok = fwrite(buf.data(), 1, buf.size(), fh) == buf.size();
-    buf.clear();
-    return ok;
-  };
-  auto put_line = [&](int64_t i) -> bool {
+// ---------------------------------------------------------------------------
+// Host path for the lines the columns cannot describe.
+//
+// The reference decides TP / FP with `fgrep -wf <(awk patterns) <(awk filter)` (program/extract_TP_FP_SNPs.py:47-53,
+// custom :92-98): a line is selected when some pattern X\t.\tY\tZ occurs in it with a non-word character (or the line
+// edge) on both sides.  For a line with a canonical POS and no other "\t.\t" a pattern could sit on, that is the key
+// lookup the device does.  For the rest -- POS spelled "01000" or "1-1000", the pattern found at the QUAL/FILTER/INFO
+// columns, ALT followed by ",T" there, '#' lines that pass the filter -- the answer needs the TEXT of the patterns.
+// ---------------------------------------------------------------------------
+namespace {
+
+// set of byte strings: open addressing over one arena (lookups take a pointer + length, nothing is copied)
+struct ByteSet {
+  std::string arena;
+  std::vector<std::pair<uint32_t, uint32_t>> items;   // (offset, length)
+  std::vector<int32_t> slots;                         // index into items, -1 = empty
+  static uint64_t hash(const uint8_t* p, size_t n) {
+    uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)n;
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 0x100000001b3ull; h ^= h >> 29; }
+    return h;
+  }
+  void grow() {
+    const size_t cap = slots.empty() ? 64 : slots.size() * 2;
+    slots.assign(cap, -1);
+    for (size_t k = 0; k < items.size(); ++k) {
+      size_t i = (size_t)hash((const uint8_t*)arena.data() + items[k].first, items[k].second) & (cap - 1);
+      while (slots[i] >= 0) i = (i + 1) & (cap - 1);
+      slots[i] = (int32_t)k;
+    }
+  }
+  bool has(const uint8_t* p, size_t n) const {
+    if (slots.empty()) return false;
+    const size_t cap = slots.size();
+    for (size_t i = (size_t)hash(p, n) & (cap - 1); slots[i] >= 0; i = (i + 1) & (cap - 1)) {
+      const auto& it = items[(size_t)slots[i]];
+      if (it.second == n && memcmp(arena.data() + it.first, p, n) == 0) return true;
+    }
+    return false;
+  }
+  bool add(const uint8_t* p, size_t n) {   // false: was there already
+    if (has(p, n)) return false;
+    if ((items.size() + 1) * 2 > slots.size()) grow();
+    items.emplace_back((uint32_t)arena.size(), (uint32_t)n);
+    arena.append((const char*)p, n);
+    const size_t cap = slots.size();
+    size_t i = (size_t)hash(p, n) & (cap - 1);
+    while (slots[i] >= 0) i = (i + 1) & (cap - 1);
+    slots[i] = (int32_t)(items.size() - 1);
+    return true;
+  }
+  size_t size() const { return items.size(); }
+};
+
+inline void join3(std::string& out, Span a, const char* sep1, Span b, const char* sep2, Span c) {
+  out.assign((const char*)a.p, a.n);
+  out.append(sep1);
+  out.append((const char*)b.p, b.n);
+  out.append(sep2);
+  out.append((const char*)c.p, c.n);
+}
+
+}  // namespace
+
+struct qm_patterns {
+  ByteSet pats;        // X \t . \t Y \t Z of every truth row the awk program accepts
+  ByteSet r_nokey;     // X \t Y \t Z of the rows R reads (no comments) whose X is no canonical position: the truth side of
+                       // the text keys of QM_F_NOKEY lines
+  int64_t n_exotic = 0, n_comment_only = 0, n_refused = 0;
+  bool ext = false;
+};
+
+extern "C" qm_patterns* qm_patterns_create(const uint8_t* text, size_t len, int mode, int ext) {
+  if ((!text && len) || (mode != 0 && mode != 1) || (ext && mode != 0)) return nullptr;
+  qm_patterns* P = new qm_patterns();
+  P->ext = ext != 0;
+  auto allele_ok = [ext](Span f) { return ext ? acgt_all(f) : acgt1(f); };
+  ByteSet device_keys, comment_keys;   // canonical patterns from rows R reads / from '#' rows
+  std::string pat, rk;
+  size_t off = 0;
+  Span f[6];
+  const Span empty = {(const uint8_t*)"", 0};
+  while (off < len) {
+    const uint8_t* s = text + off;
+    const uint8_t* e = (const uint8_t*)memchr(s, '\n', len - off);
+    const size_t n = e ? (size_t)(e - s) : len - off;
+    off += n + 1;
+    const int nf = split_tabs(s, n, f, 6);
+    for (int i = nf < 6 ? nf : 6; i < 6; ++i) f[i] = empty;
+    Span X, Y, Z;
+    if (mode == 0) {   // awk -F"\t" '$4~/^[ACGT]$/&&$5~/^[ACGT]$/{print $2,".",$4,$5}'
+      X = f[1]; Y = f[3]; Z = f[4];
+      if (!allele_ok(Y) || !allele_ok(Z)) continue;
+    } else {           // awk -F"\t" '$2!="."&&$3!="."{print $1,".",$2,$3}'
+      X = f[0]; Y = f[1]; Z = f[2];
+      if (is_dot(Y) || is_dot(Z)) continue;
+    }
+    bool ascii = true;
+    for (size_t i = 0; i < n && ascii; ++i) ascii = s[i] != 0 && s[i] < 0x80;
+    if (!ascii) { ++P->n_refused; continue; }
+    join3(pat, X, "\t.\t", Y, "\t", Z);
+    const bool fresh = P->pats.add((const uint8_t*)pat.data(), pat.size());
+    if (fresh && (ext ? !(acgt_all(Y) && acgt_all(Z)) : (Y.n != 1 || Z.n != 1))) ++P->n_exotic;
+    const bool comment = n && s[0] == '#';
+    int32_t p;
+    const bool canon = canon_pos(X, &p) && allele_ok(Y) && allele_ok(Z);
+    if (canon) (comment ? comment_keys : device_keys).add((const uint8_t*)pat.data(), pat.size());
+    if (!comment && !canon_pos(X, &p) && (mode == 1 ? n > 0 : true)) {
+      join3(rk, X, "\t", Y, "\t", Z);
+      P->r_nokey.add((const uint8_t*)rk.data(), rk.size());
+    }
+  }
+  for (const auto& it : comment_keys.items)
+    if (!device_keys.has((const uint8_t*)comment_keys.arena.data() + it.first, it.second)) ++P->n_comment_only;
+  return P;
+}
+extern "C" void qm_patterns_destroy(qm_patterns* p) { delete p; }
+extern "C" int qm_patterns_info(const qm_patterns* p, int64_t* info) {
+  if (!p || !info) return QM_E_INVAL;
+  info[0] = (int64_t)p->pats.size(); info[1] = p->n_exotic; info[2] = p->n_comment_only; info[3] = p->n_refused;
+  return QM_OK;
+}
+
+namespace {
+
+// Does `fgrep -w` with the pattern list select the line?  Every pattern is X \t . \t Y \t Z with tab-free X, Y, Z and
+// Y, Z != ".", so its first tab sits on a "\t.\t" of the line: X is a suffix of the field before it, Y the whole field
+// after it, Z a prefix of the one after that.
+bool fgrep_w_selects(const qm_patterns& P, const uint8_t* s, size_t n) {
+  if (P.pats.size() == 0) return false;
+  for (size_t j = 0; j + 2 < n; ++j) {
+    if (s[j] != '\t' || s[j + 1] != '.' || s[j + 2] != '\t') continue;
+    if (j == 0) continue;   // the pattern's own first tab follows X inside the line: a "." in the first field has no tab before it
+    size_t fb = j;
+    while (fb > 0 && s[fb - 1] != '\t') --fb;
+    const size_t yb = j + 3;
+    const uint8_t* t = yb < n ? (const uint8_t*)memchr(s + yb, '\t', n - yb) : nullptr;
+    if (!t) break;   // no field after Y: no pattern fits here, nor on any later "\t.\t"
+    const size_t zb = (size_t)(t - s) + 1;
+    size_t ze = zb;
+    while (ze < n && s[ze] != '\t') ++ze;
+    for (size_t i = fb; i <= j; ++i) {
+      if (i > fb && is_word(s[i - 1])) continue;    // i == fb: a tab or the line start precedes
+      for (size_t e = zb; e <= ze; ++e) {
+        if (e < ze && is_word(s[e])) continue;      // e == ze: a tab or the line end follows
+        if (P.pats.has(s + i, e - i)) return true;
+      }
+    }
+  }
+  return false;
+}
+
+}  // namespace
+
+extern "C" int qm_vcf_hostpath(const qm_patterns* P, const uint8_t* text, size_t len, int64_t n_lines, const int64_t* line_off,
+                               uint8_t* line_kind, const int32_t* pos, const int32_t* ref, const int32_t* alt, uint8_t* flags,
+                               int64_t* out) {
+  if (!P || (!text && len) || !line_off || !line_kind || (!flags && n_lines)) return QM_E_INVAL;
+  const bool full = P->n_exotic > 0 || P->n_comment_only > 0;   // the columns cannot stand in for this pattern list at all
+  int64_t decided = 0, selected = 0;
+  ByteSet text_keys;                         // X \t Y \t Z of kept QM_F_NOKEY lines
+  std::vector<std::array<int32_t, 3>> trip;  // what the device tells such lines apart by: (carried pos, ref, alt)
+  int64_t tp_r = 0, fp_r = 0;
+  std::string rk;
+  int64_t r = 0;
+  for (int64_t i = 0; i < n_lines; ++i) {
+    const uint8_t kind = line_kind[i];
+    if (kind == QM_LINE_HEADER || kind == QM_LINE_HEADER_REFUSED) continue;
     size_t b = (size_t)line_off[i], e = (size_t)line_off[i + 1];
     if (e > len) e = len;
     if (e > b && text[e - 1] == '\n') --e;
-    buf.insert(buf.end(), (const char*)text + b, (const char*)text + e);
-    buf.push_back('\n');
-    return buf.size() < (1u << 20) || flush();
-  };
+    if (kind == QM_LINE_HEADER_KEPT || kind == QM_LINE_HEADER_KEPT_TP) {
+      const bool sel = fgrep_w_selects(*P, text + b, e - b);
+      line_kind[i] = sel ? QM_LINE_HEADER_KEPT_TP : QM_LINE_HEADER_KEPT;
+      ++decided; selected += sel ? 1 : 0;
+      continue;
+    }
+    const int64_t d = r++;
+    if (kind == QM_LINE_DATA_HOST || (full && kind == QM_LINE_DATA)) {
+      const bool sel = fgrep_w_selects(*P, text + b, e - b);
+      flags[d] = (uint8_t)(sel ? (flags[d] | QM_F_TPLINE) : (flags[d] & ~(QM_F_IDDOT | QM_F_TPLINE)));
+      ++decided; selected += sel ? 1 : 0;
+    }
+    if ((flags[d] & (QM_F_PASS | QM_F_NOKEY)) == (QM_F_PASS | QM_F_NOKEY)) {
+      // R keys a line by the text of its POS / REF / ALT fields (caller_performance_compare.R:29-55)
+      Span f[5];
+      const Span empty = {(const uint8_t*)"", 0};
+      const int nf = split_head(text + b, e - b, f, 5);
+      for (int k = nf; k < 5; ++k) f[k] = empty;
+      join3(rk, f[1], "\t", f[3], "\t", f[4]);
+      if (text_keys.add((const uint8_t*)rk.data(), rk.size())) {
+        if (P->r_nokey.has((const uint8_t*)rk.data(), rk.size())) ++tp_r; else ++fp_r;
+      }
+      if (pos && ref && alt) trip.push_back({pos[d], ref[d], alt[d]});
+    }
+  }
+  std::sort(trip.begin(), trip.end());
+  const int64_t dev_unique = (int64_t)(std::unique(trip.begin(), trip.end()) - trip.begin());
+  if (out) { out[0] = decided; out[1] = selected; out[2] = dev_unique; out[3] = tp_r; out[4] = fp_r; }
+  return QM_OK;
+}
+
+namespace {
+
+// Gathers byte ranges of the input text into a file: neighbouring selected lines leave as ONE range, ranges go out in
+// writev batches straight from the (mapped) input -- no staging copy in user space.  Small scattered ranges (the TP
+// file: a few per cent of the lines, one line each) are packed into a buffer first, since a writev entry per 40-byte
+// line costs more than copying it.
+class RangeWriter {
+ public:
+  explicit RangeWriter(int fd) : fd_(fd) { iov_.reserve(kMaxIov); small_.reserve(kSmallCap); }
+  bool add(const uint8_t* p, size_t n) {
+    if (n == 0) return true;
+    if (n < kSmallRange) {
+      // entries pointing into small_ hold offsets until flush() resolves them (the buffer may still move)
+      if (small_.size() + n > kSmallCap && !flush()) return false;
+      const size_t at = small_.size();
+      small_.insert(small_.end(), p, p + n);
+      if (!iov_.empty() && small_tail_ && (size_t)(uintptr_t)iov_.back().iov_base + iov_.back().iov_len == at) {
+        iov_.back().iov_len += n;
+        return true;
+      }
+      push((void*)(uintptr_t)at, n, true);
+    } else {
+      push((void*)p, n, false);
+    }
+    return iov_.size() < kMaxIov || flush();
+  }
+  bool flush() {
+    for (size_t k = 0; k < iov_.size(); ++k)
+      if (is_small_[k]) iov_[k].iov_base = small_.data() + (size_t)(uintptr_t)iov_[k].iov_base;
+    size_t k = 0;
+    while (k < iov_.size()) {
+      const ssize_t w = writev(fd_, &iov_[k], (int)std::min<size_t>(iov_.size() - k, kMaxIov));
+      if (w < 0) { if (errno == EINTR) continue; return false; }
+      size_t left = (size_t)w;
+      while (left > 0 && k < iov_.size()) {
+        if (left >= iov_[k].iov_len) { left -= iov_[k].iov_len; ++k; }
+        else { iov_[k].iov_base = (char*)iov_[k].iov_base + left; iov_[k].iov_len -= left; left = 0; }
+      }
+    }
+    iov_.clear(); is_small_.clear(); small_.clear(); small_tail_ = false;
+    return true;
+  }
+
+ private:
+  static constexpr size_t kMaxIov = 1024, kSmallRange = 512, kSmallCap = 1 << 20;
+  void push(void* p, size_t n, bool small) {
+    iovec v; v.iov_base = p; v.iov_len = n;
+    iov_.push_back(v); is_small_.push_back(small); small_tail_ = small;
+  }
+  int fd_;
+  std::vector<iovec> iov_;
+  std::vector<char> is_small_;
+  std::vector<uint8_t> small_;
+  bool small_tail_ = false;
+};
+
+// header block, then the selected lines in input order; a missing final newline is added
+int write_selected(const char* path, const uint8_t* text, size_t len, int64_t n_lines, const int64_t* line_off, const uint8_t* line_kind,
+                   const uint8_t* cls, int select) {
+  static std::atomic<unsigned> serial{0};
+  const std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid()) + "." + std::to_string(serial.fetch_add(1));
+  const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+  if (fd < 0) return QM_E_IO;
+  RangeWriter W(fd);
+  static const uint8_t NL = '\n';
   bool ok = true;
-  for (int64_t i = 0; i < n_lines && ok; ++i)
-    if (line_kind[i] == 1 || line_kind[i] == 3) ok = put_line(i);
+  size_t run_b = 0, run_e = 0;   // pending contiguous range [run_b, run_e) of whole lines
+  auto put = [&](int64_t i) {
+    size_t b = (size_t)line_off[i], e = (size_t)line_off[i + 1];
+    if (e > len) e = len;
+    if (b >= e) { b = e; }
+    const bool has_nl = e > b && text[e - 1] == '\n';
+    if (run_e == b && run_e > run_b) run_e = e;
+    else { if (run_e > run_b) ok = ok && W.add(text + run_b, run_e - run_b); run_b = b; run_e = e; }
+    if (!has_nl) {   // only the last line of a text can lack its newline (or be empty without one)
+      if (run_e > run_b) ok = ok && W.add(text + run_b, run_e - run_b);
+      run_b = run_e = 0;
+      ok = ok && W.add(&NL, 1);
+    }
+  };
+  for (int64_t i = 0; i < n_lines && ok; ++i) {
+    const uint8_t k = line_kind[i];
+    if (k == QM_LINE_HEADER || k == QM_LINE_HEADER_KEPT || k == QM_LINE_HEADER_KEPT_TP || k == QM_LINE_HEADER_REFUSED) put(i);
+  }
   int64_t r = 0;
   for (int64_t i = 0; i < n_lines && ok; ++i) {
-    if (line_kind[i] == 1 || line_kind[i] == 3) continue;
-    const uint8_t c = cls ? cls[r] : 0;
-    ++r;
-    const bool sel = select == 0 ? (c & QM_CLS_KEPT) : select == 1 ? ((c & 3u) == 3u) : ((c & 3u) == 1u);
-    if (sel) ok = put_line(i);
+    const uint8_t k = line_kind[i];
+    if (k == QM_LINE_HEADER || k == QM_LINE_HEADER_REFUSED) continue;
+    bool sel;
+    if (k == QM_LINE_HEADER_KEPT || k == QM_LINE_HEADER_KEPT_TP) {   // awk printed it among the kept lines too
+      sel = select == 0 || (select == 1) == (k == QM_LINE_HEADER_KEPT_TP);
+    } else {
+      const uint8_t c = cls ? cls[r] : 0;
+      ++r;
+      sel = select == 0 ? (c & QM_CLS_KEPT) : select == 1 ? ((c & 3u) == 3u) : ((c & 3u) == 1u);
+    }
+    if (sel) put(i);
   }
-  ok = ok && flush();
-  ok = (fclose(fh) == 0) && ok;
+  if (ok && run_e > run_b) ok = W.add(text + run_b, run_e - run_b);
+  ok = ok && W.flush();
+  ok = (close(fd) == 0) && ok;
   if (!ok) { remove(tmp.c_str()); return QM_E_IO; }
   if (rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return QM_E_IO; }
   return QM_OK;
+}
+
+}  // namespace
+
+extern "C" int qm_vcf_write(const char* path, const uint8_t* text, size_t len, int64_t n_lines, const int64_t* line_off,
+                            const uint8_t* line_kind, const uint8_t* cls, int select) {
+  if (!path || !line_off || !line_kind || select < 0 || select > 2 || (!text && len)) return QM_E_INVAL;
+  return write_selected(path, text, len, n_lines, line_off, line_kind, cls, select);
 }
 
 // ---------------------------------------------------------------------------

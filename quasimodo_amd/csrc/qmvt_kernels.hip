@@ -100,14 +100,18 @@ __device__ __forceinline__ int lds_lower_bound(const uint32_t* __restrict__ k, i
 // All record indices are 32-bit and relative to the VCF (n < 2^31).
 // ---------------------------------------------------------------------------
 
-// 16-bit info of a record (what a matching truth key and the per-record pass need)
+// info of a record.  The low 16 bits are what a matching truth key needs (they are what the join sees in LDS):
 constexpr uint32_t I_BIN1 = 0x1ffu;      // bin + 1; 0 = passes no threshold or is not a live (single-base, in-range) record
 constexpr uint32_t I_PASS = 1u << 9;     // flags bit0
 constexpr uint32_t I_IDDOT = 1u << 10;   // flags bit1
 constexpr uint32_t I_NOKEY = 1u << 11;   // flags bit2
 constexpr uint32_t I_LIVE = 1u << 12;    // position in range, single-base alleles
 constexpr uint32_t I_BADPOS = 1u << 13;  // position outside [0, 2^28)
-constexpr uint32_t I_KEPT = 1u << 14;    // live and PASS: the line is in <x>.filtered.vcf
+// The per-record pass reads three bits per record, kept four bits apart in the high half (and nothing else there), so
+// that `(inf >> 16) << k` OR-ed over the lane's four records yields the three nibbles at once:
+constexpr uint32_t I_KEPT = 1u << 16;    // live and PASS: the line is in <x>.filtered.vcf
+constexpr uint32_t I_IDDOT4 = 1u << 20;  // copy of I_IDDOT
+constexpr uint32_t I_TPLINE = 1u << 24;  // flags bit3: the host found the line selected by fgrep (a TP line whatever its key says)
 
 // key and info of one record from its columns (qmvt_dev.h: the radix-sort path uses the same)
 // EXT (allele-extended batches, include/qmvt.h "allele codes"): any valid allele code is live; the
@@ -127,7 +131,7 @@ __device__ __forceinline__ void pack_record(int p, int r, int a, float q, uint32
   }
   key = ((uint32_t)p << 4) | (live ? nib : 0u);
   inf = (live ? (uint32_t)(qual_bin(q, nb) + 1) : 0u) | ((fl & 7u) << 9) | (live ? I_LIVE : 0u) | (okpos ? 0u : I_BADPOS) |
-        ((live && (fl & QMF_PASS)) ? I_KEPT : 0u);
+        ((live && (fl & QMF_PASS)) ? I_KEPT : 0u) | ((fl & QMF_IDDOT) ? I_IDDOT4 : 0u) | ((live && (fl & QMF_TPLINE)) ? I_TPLINE : 0u);
 }
 
 struct Cols {  // bases of one VCF: the five columns, or the packed pair
@@ -487,15 +491,15 @@ template <bool PACKED, bool EXT>
 __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, const In4& X, int rbase, int te, int prev_last, int nb,
                                                int ablate, int mslot, Acc& A, int lane) {
   const uint32_t hit = (lds[L_HITS + (lane >> 3)] >> (4 * (lane & 7))) & 15u;
-  uint32_t pass = 0, iddot = 0, anyinf = 0;
+  uint32_t nib = 0, anyinf = 0;   // nib: kept in bits 0..3, ID-is-'.' in 4..7, host-decided TP line in 8..11 (one bit per record)
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    pass |= ((X.inf[k] >> 14) & 1u) << k;
-    iddot |= ((X.inf[k] >> 10) & 1u) << k;
+    nib |= (X.inf[k] >> 16) << k;
     anyinf |= X.inf[k];
   }
+  const uint32_t pass = nib & 15u, iddot = (nib >> 4) & 15u, tpline = (nib >> 8) & 15u;
   A.bad |= (anyinf & I_BADPOS) ? 2u : 0u;
-  const uint32_t tpkey = hit & iddot;
+  const uint32_t tpkey = (hit & iddot) | tpline;
   const uint32_t tp = pass & tpkey;
   const uint32_t fpkey = pass & ~hit;
   A.n_pass += (uint32_t)__popc(pass);

@@ -65,6 +65,10 @@ class Engine:
         check((self._L.qm_truth_size_ext if alleles else self._L.qm_truth_size)(self._h, int(tid), C.byref(n)), self._h)
         return n.value
 
+    def truth_release(self, tid):
+        """free a truth set's HBM; its id may be reused by a later load"""
+        check(self._L.qm_truth_release(self._h, int(tid)), self._h)
+
     @property
     def n_truth(self):
         return self._L.qm_truth_count(self._h)
@@ -227,8 +231,13 @@ class Batch:
         self._ck(self._L.qm_batch_get_scalars(self._h, _p(out)))
         return out
 
+    @property
+    def n_truth(self):
+        """rows of the per-truth sums: truth-set slots of the context when the batch was created"""
+        return int(self._L.qm_batch_n_truth(self._h))
+
     def global_counts(self):
-        out = np.zeros((max(self.engine.n_truth, 1), 3, self.n_bins), np.uint64)
+        out = np.zeros((self.n_truth, 3, self.n_bins), np.uint64)
         self._ck(self._L.qm_batch_get_global(self._h, _p(out)))
         return out
 

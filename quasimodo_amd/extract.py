@@ -20,7 +20,7 @@ import numpy as np
 
 from ._lib import SCALAR_NAMES, QmvtError
 from .engine import Engine
-from .vcfio import AlleleDict, scan_truth, scan_vcf
+from .vcfio import AlleleDict, Patterns, scan_truth, scan_vcf
 
 
 def is_pure_strain(vcf_file):
@@ -104,43 +104,67 @@ def extract_many(jobs, engine=None, strict=None, n_bins=256, alleles=None):
         raise
     for j, job in enumerate(jobs):
         sv = all_scanned[j]
-        if sv.n_noncanon and strict:
+        if sv.n_refused and strict:
             pool.shutdown()
-            raise QmvtError(-8, "%s line %d: the reference's answer for this kept line depends on locale or on "
-                                "non-canonical field alignment (non-ASCII bytes, POS not a plain decimal < 2^28, or a "
-                                "'.' column after QUAL); set QM_LENIENT=1 to classify by the canonical columns"
-                            % (job.vcf_file, sv.first_noncanon_line))
+            raise QmvtError(-8, "%s line %d: a kept line holds NUL or non-ASCII bytes -- the reference's answer for it depends on "
+                                "the locale Python exports to grep; set QM_LENIENT=1 to classify it by its columns"
+                            % (job.vcf_file, sv.first_refused_line))
         scanned.append(sv)
         if not is_pure_strain(job.vcf_file):
             mixed.append(j)
-    results = {}
+    results, r_exchange = {}, {}
     if mixed:
         if engine is None:
             engine = Engine(int(os.environ.get("QM_DEVICE", "0")))
+        truth_ids, patterns = {}, {}
         try:
-            truth_ids, truth_info = {}, {}
+            truth_info = {}
             for j in mixed:
                 key = (os.path.abspath(jobs[j].snp_file), jobs[j].mode)
                 if key not in truth_ids:
                     with open(jobs[j].snp_file, "rb") as fh:
-                        tk = scan_truth(fh.read(), custom=jobs[j].mode == "custom", alleles=adict)
+                        ttext = fh.read()
+                    tk = scan_truth(ttext, custom=jobs[j].mode == "custom", alleles=adict)
                     if tk.n_refused and strict:
-                        raise QmvtError(-8, "%s: %d truth rows the engine refuses to guess about (comment rows with a "
-                                            "valid pattern or non-ASCII bytes)" % (jobs[j].snp_file, tk.n_refused))
+                        raise QmvtError(-8, "%s: %d truth rows hold NUL or non-ASCII bytes" % (jobs[j].snp_file, tk.n_refused))
                     truth_ids[key] = engine.truth_load(tk.pos, tk.ref, tk.alt)
                     truth_info[key] = tk
+                    patterns[key] = Patterns(ttext, custom=jobs[j].mode == "custom", alleles=alleles)
+            # lines whose fgrep answer the columns cannot give are decided on the host, from the text of
+            # the patterns, BEFORE the upload: the decision travels in the flags column and the device counts and
+            # lists these lines like all others
+            def _host(j):
+                key = (os.path.abspath(jobs[j].snp_file), jobs[j].mode)
+                pt = patterns[key]
+                if scanned[j].n_host or scanned[j].n_nokey_kept or pt.needs_full_hostpath:
+                    return scanned[j].hostpath(pt)
+                return None
+            for j, ex in zip(mixed, pool.map(_host, mixed)):
+                if ex is not None:
+                    r_exchange[j] = ex
             cols = [scanned[j].columns for j in mixed]
             tids = [truth_ids[(os.path.abspath(jobs[j].snp_file), jobs[j].mode)] for j in mixed]
             res, _ = engine.classify_batch(cols, tids, n_bins=n_bins, alleles=alleles)
             for j, r in zip(mixed, res):
                 r["genomediff"] = truth_info[(os.path.abspath(jobs[j].snp_file), jobs[j].mode)].genomediff
+                ex = r_exchange.get(j)
+                if ex is not None:
+                    # R keys a line by the TEXT of POS / REF / ALT; for lines without a comparable key the device
+                    # counted distinct (carried pos, ref, alt) instead: swap those for the text keys
+                    r["scalars"]["FP_R"] += ex["fp_r"] - ex["device_nokey_keys"]
+                    r["scalars"]["TP_R"] += ex["tp_r"]
                 results[j] = r
         except BaseException:
             pool.shutdown()
             raise
         finally:
+            for pt in patterns.values():
+                pt.close()
             if own:
                 engine.close()
+            else:
+                for tid in truth_ids.values():   # a shared engine does not keep this call's truth sets
+                    engine.truth_release(tid)
     writes = []
     for j, job in enumerate(jobs):
         sv = scanned[j]
@@ -152,14 +176,14 @@ def extract_many(jobs, engine=None, strict=None, n_bins=256, alleles=None):
             writes += [pool.submit(sv.write, job.filtered_out, cls, 0), pool.submit(sv.write, job.tp_out, cls, 1),
                        pool.submit(sv.write, job.fp_out, cls, 2)]
             job.stats = dict(r["scalars"])
-            job.stats.update(pure_strain=False, genomediff=r["genomediff"], roc=r["roc"])
+            job.stats.update(pure_strain=False, genomediff=r["genomediff"], roc=r["roc"], header_kept=sv.header_kept)
         else:  # pure strain: fp is a copy of filtered, truth never read (:33-36)
             cls = (sv.flags & 1).astype(np.uint8)
             writes += [pool.submit(sv.write, job.filtered_out, cls, 0), pool.submit(sv.write, job.fp_out, cls, 0)]
             job.tp_out = ""
             npass = int(cls.sum())
             job.stats = dict(zip(SCALAR_NAMES, (npass, 0, npass, 0, 0, 1, sv.n_records, 0)))
-            job.stats.update(pure_strain=True, genomediff=0, roc=None)
+            job.stats.update(pure_strain=True, genomediff=0, roc=None, header_kept=sv.header_kept)
     try:
         for w in writes:
             w.result()          # the first writer error surfaces here

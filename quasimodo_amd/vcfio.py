@@ -21,14 +21,17 @@ class ScannedVcf:
     text: bytes
     n_lines: int
     line_off: np.ndarray   # int64 [n_lines + 1]
-    line_kind: np.ndarray  # uint8 [n_lines]: 0 data, 1 header, 2 data (non-canonical), 3 header that also passes the A2 filter (2 and 3: strict mode refuses)
+    line_kind: np.ndarray  # uint8 [n_lines]: QM_LINE_* of include/qmvt.h (0 data, 1 header, 2 data for the host path,
+                           # 3 / 4 header line that passes the A2 filter (4: selected by fgrep), 5 / 6 refused: NUL or non-ASCII)
     pos: np.ndarray
     ref: np.ndarray
     alt: np.ndarray
     qual: np.ndarray
     flags: np.ndarray
-    n_noncanon: int
-    first_noncanon_line: int
+    n_host: int            # lines whose fgrep answer needs the text of the patterns (hostpath)
+    n_refused: int
+    first_refused_line: int
+    n_nokey_kept: int      # kept lines without a comparable key (POS not a canonical decimal)
 
     @property
     def n_records(self):
@@ -37,6 +40,23 @@ class ScannedVcf:
     @property
     def columns(self):
         return self.pos, self.ref, self.alt, self.qual, self.flags
+
+    def hostpath(self, patterns):
+        """decide the lines the columns cannot describe with the exact `fgrep -w` of the reference
+        (extract_TP_FP_SNPs.py:50-53) and write the decisions into the flags column / line kinds.  Call before the
+        columns are uploaded.  Returns the exchange for R's unique-key counts (qm_vcf_hostpath, include/qmvt.h)."""
+        out = np.zeros(5, np.int64)
+        rc = _lib.lib().qm_vcf_hostpath(patterns._h, self.text, len(self.text), self.n_lines, _p(self.line_off), _p(self.line_kind),
+                                        _p(self.pos), _p(self.ref), _p(self.alt), _p(self.flags) if self.n_records else _p(np.zeros(1, np.uint8)),
+                                        _p(out))
+        if rc < 0:
+            raise QmvtError(rc, "qm_vcf_hostpath failed")
+        return dict(decided=int(out[0]), selected=int(out[1]), device_nokey_keys=int(out[2]), tp_r=int(out[3]), fp_r=int(out[4]))
+
+    @property
+    def header_kept(self):
+        """'#' lines that pass the A2 filter: (all, those fgrep selects)"""
+        return int(np.count_nonzero((self.line_kind == 3) | (self.line_kind == 4))), int(np.count_nonzero(self.line_kind == 4))
 
     def write(self, path, cls, select):
         """select: 0 = kept lines (filtered.vcf), 1 = TP lines, 2 = FP lines; header lines always first."""
@@ -99,7 +119,37 @@ def scan_vcf(text: bytes, alleles: "AlleleDict | None" = None) -> ScannedVcf:
     n, d = int(info.n_lines), int(info.n_data)
     # views, not copies: the spare tail of each buffer is a line or two
     return ScannedVcf(text, n, line_off[:n + 1], kind[:n], pos[:d], ref[:d], alt[:d], qual[:d], flags[:d],
-                      int(info.n_noncanon), int(info.first_noncanon_line))
+                      int(info.n_host), int(info.n_refused), int(info.first_refused_line), int(info.n_nokey_kept))
+
+
+class Patterns:
+    """The pattern list the reference feeds to `fgrep -wf`, as text (qm_patterns): what the host path matches
+    against.  custom=False: truth VCF (extract_TP_FP_SNPs.py:47); custom=True: show-snps table (:92)."""
+
+    def __init__(self, truth_text: bytes, custom: bool = False, alleles: bool = False):
+        self._L = _lib.lib()
+        self._h = self._L.qm_patterns_create(truth_text, len(truth_text), int(bool(custom)), int(bool(alleles)))
+        if not self._h:
+            raise QmvtError(-1, "qm_patterns_create failed")
+        info = np.zeros(4, np.int64)
+        check(self._L.qm_patterns_info(self._h, _p(info)))
+        self.n_patterns, self.n_exotic, self.n_comment_only, self.n_refused = (int(x) for x in info)
+
+    @property
+    def needs_full_hostpath(self):
+        """patterns no column key can stand for: every line compared with this truth set is decided from the text"""
+        return self.n_exotic > 0 or self.n_comment_only > 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.qm_patterns_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 @dataclass
@@ -108,8 +158,9 @@ class TruthKeys:
     ref: np.ndarray
     alt: np.ndarray
     genomediff: int   # rows R counts as `genomediff` (caller_performance_compare.R:90)
-    n_never: int      # rows whose pattern can never match a canonical kept line
-    n_refused: int    # rows the engine refuses to guess about (strict mode)
+    n_never: int      # rows whose pattern can never match a line through its columns (they live in Patterns only)
+    n_refused: int    # rows holding NUL / non-ASCII bytes (strict mode stops)
+    n_comment: int    # '#' rows awk turns into patterns all the same (Patterns keeps them; R does not read them)
 
 
 def scan_truth(text: bytes, custom: bool = False, alleles: "AlleleDict | None" = None) -> TruthKeys:
@@ -121,12 +172,12 @@ def scan_truth(text: bytes, custom: bool = False, alleles: "AlleleDict | None" =
     L = _lib.lib()
     cap = int(L.qm_vcf_count_lines(text, len(text))) + 1
     pos, ref, alt = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.int32)
-    counts = np.zeros(4, np.int64)
+    counts = np.zeros(5, np.int64)
     n = int(L.qm_truth_scan_ext(text, len(text), int(bool(custom)), cap, _p(pos), _p(ref), _p(alt), _p(counts),
                                 alleles._h if alleles is not None else None))
     if n < 0:
         raise QmvtError(n, "qm_truth_scan failed")
-    return TruthKeys(pos[:n].copy(), ref[:n].copy(), alt[:n].copy(), int(counts[0]), int(counts[2]), int(counts[3]))
+    return TruthKeys(pos[:n].copy(), ref[:n].copy(), alt[:n].copy(), int(counts[0]), int(counts[2]), int(counts[3]), int(counts[4]))
 
 
 AWK_POSIX, AWK_MAWK_LITERAL = 0, 1

@@ -91,6 +91,11 @@ def random_columns(rng, n, genome_len, truth, frac_truth=0.3, sorted_=True, dup_
     iddot = rng.random(n) > (0.05 if weird else 0.0)
     nokey = (rng.random(n) < 0.02) if weird else np.zeros(n, bool)
     flags = (passed.astype(np.uint8)) | (iddot.astype(np.uint8) << 1) | (nokey.astype(np.uint8) << 2)
+    if weird and n:
+        # decisions of the host path (include/qmvt.h): QM_F_TPLINE on a few records (with or without '.' ID, with or
+        # without a key in the truth set), QM_F_IDDOT cleared on a few others
+        tpl = np.random.default_rng(int(n) * 7919 + 13).random(n) < 0.03
+        flags = flags | (tpl.astype(np.uint8) << 3)
     if sorted_ and n:
         o = np.argsort(pos, kind="stable")
         pos, ref, alt, qual, flags = pos[o], ref[o], alt[o], qual[o], flags[o]

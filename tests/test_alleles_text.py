@@ -24,7 +24,7 @@ def test_tokenizer_and_writers_reproduce_the_widened_pipeline(qmlib, oracle, tmp
     d = vcfio.AlleleDict()
     sv = vcfio.scan_vcf(_read(c["vcf"]), alleles=d)
     tk = vcfio.scan_truth(_read(c["truth"]), alleles=d)
-    assert sv.n_noncanon == 0 and tk.n_refused == 0
+    assert sv.n_host == 0 and sv.n_refused == 0 and tk.n_refused == 0
     cls, roc, sc = oracle.classify_columns(*sv.columns, tk.pos, tk.ref, tk.alt, ext=True)
     for sel, k in ((0, "filtered"), (1, "tp"), (2, "fp")):
         out = tmp_path / (k + ".vcf")

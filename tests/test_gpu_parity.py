@@ -126,6 +126,54 @@ def test_position_out_of_range_is_an_error(engine):
         engine.truth_load(np.array([-1], np.int32), np.array([0], np.int32), np.array([1], np.int32))
 
 
+def test_position_out_of_range_behind_an_unsorted_stretch(engine):
+    """The optimistic pass stops streaming a VCF at its first out-of-order tile; a bad position behind it is found by
+    the radix-sort path and is the same error."""
+    import quasimodo_amd as q
+    tid = engine.truth_load(np.array([5], np.int32), np.array([0], np.int32), np.array([1], np.int32))
+    n = 40000
+    pos = np.arange(n, 0, -1, dtype=np.int32)       # descending: out of order from the first tile on
+    pos[-7] = 1 << 28
+    cols = (pos, np.zeros(n, np.int32), np.ones(n, np.int32), np.full(n, 50, np.float32), np.full(n, 3, np.uint8))
+    with pytest.raises(q.QmvtError) as ei:
+        engine.classify_batch([cols], [tid])
+    assert ei.value.code == -5
+
+
+def test_truth_sets_can_be_released_and_batches_keep_their_layout(engine, oracle):
+    """qm_truth_release frees a slot for reuse; a batch created against the released set refuses to run; a truth set
+    loaded AFTER a batch was created changes neither the size of its per-truth sums nor what it reads back."""
+    import quasimodo_amd as q
+    rng = np.random.default_rng(31)
+    L = 30000
+    t1, t2 = random_truth(rng, 900, L), random_truth(rng, 500, L)
+    a = engine.truth_load(*t1)
+    cols = random_columns(rng, 7000, L, t1)
+    b = engine.batch([7000], [a])
+    rows = b.n_truth
+    b.upload(0, *cols)
+    later = [engine.truth_load(*t2) for _ in range(5)]          # the context's truth table grows past the batch's rows
+    assert engine.n_truth >= rows + 5 or min(later) < rows      # (released slots of earlier tests may be reused)
+    b.run(); b.finish()
+    g = b.global_counts()
+    assert g.shape[0] == rows and np.array_equal(g[a], b.roc()[0])
+    cls, roc, sc = oracle.classify_columns(*cols, *t1)
+    assert np.array_equal(b.cls(0), cls) and np.array_equal(b.roc()[0], roc)
+    engine.truth_release(a)
+    with pytest.raises(q.QmvtError) as ei:
+        b.run()
+    assert ei.value.code == -6
+    again = engine.truth_load(*t1)                                # the slot comes back ...
+    assert again == a
+    with pytest.raises(q.QmvtError):                              # ... but it is another truth set to the old batch
+        b.run()
+    b.close()
+    for t in later + [again]:
+        engine.truth_release(t)
+    with pytest.raises(q.QmvtError):
+        engine.truth_release(again)
+
+
 @pytest.mark.parametrize("shuffled", [False, True])
 def test_synthetic_batch_vs_oracle(engine, oracle, shuffled):
     """The on-device generator of the bench workload, at a size the oracle finishes in seconds."""
@@ -239,9 +287,7 @@ def test_golden_end_to_end_bytes(engine, oracle, tmp_path):
     import quasimodo_amd as q
     from quasimodo_amd.extract import Job
     jobs, exps = [], []
-    for e in CASES:
-        if e["family"] == "quirks":
-            continue
+    for e in CASES:      # the `quirks` family too: its lines are decided on the product's host path
         vcf, truth, exp = read_case(e)
         root = tmp_path / e["family"] / e["mode"]
         vp = root / e["vcf"][len("input/"):]
@@ -252,7 +298,9 @@ def test_golden_end_to_end_bytes(engine, oracle, tmp_path):
         tp.write_bytes(truth)
         jobs.append(Job(str(vp), str(tp), e["mode"], str(root / e["outdir"]), e["caller"]))
         exps.append((e, exp, truth))
-    q.extract_many(jobs, engine=engine)
+    n_truth_before = engine.n_truth
+    q.extract_many(jobs, engine=engine, strict=True)
+    assert engine.n_truth <= n_truth_before + 8        # the call released its truth sets: a shared engine does not grow
     for job, (e, exp, truth) in zip(jobs, exps):
         assert open(job.filtered_out, "rb").read() == exp["filtered"], case_id(e)
         assert open(job.fp_out, "rb").read() == exp["fp"], case_id(e)
@@ -265,8 +313,11 @@ def test_golden_end_to_end_bytes(engine, oracle, tmp_path):
             assert job.filtered_out.endswith(e["expected"]["filtered"][len("expected/"):])
         rc = oracle.count_text(exp["filtered"], truth, custom=e["mode"] == "custom")
         assert job.stats["n_pass"] == rc["calleridentify"] and job.stats["genomediff"] == rc["genomediff"]
-        assert job.stats["TP_R"] == rc["TP"] and job.stats["FP_R"] == rc["FP"]
+        assert job.stats["TP_R"] == rc["TP"] and job.stats["FP_R"] == rc["FP"], case_id(e)
         assert job.stats["truth_unique"] - job.stats["TP_R"] <= rc["FN"]   # R's FN also counts never-matching rows
+        # the line counts are those of the files the reference wrote ('#' lines that pass the filter sit in tp / fp too)
+        nl = lambda b: sum(1 for ln in b.split(b"\n") if ln and not ln.startswith(b"#"))
+        assert job.stats["tp_lines"] == nl(exp["tp"]) and job.stats["fp_lines"] == nl(exp["fp"]), case_id(e)
 
 
 def test_cli_dropin(engine, tmp_path):

@@ -40,10 +40,24 @@ static void exercise(const std::vector<uint8_t>& t, qm_dict* dict, const char* o
       const std::string o = std::string(outdir) + "/w.vcf";
       qm_vcf_write(o.c_str(), text, len, info.n_lines, off.data(), kind.data(), cls.data(), sel);
     }
-    int64_t counts[4];
+    int64_t counts[5];
+    std::vector<int32_t> tpos((size_t)cap), tref((size_t)cap), talt((size_t)cap);
     for (int mode = 0; mode < 2; ++mode) {
       if (ext && mode == 1) continue;
-      qm_truth_scan_ext(text, len, mode, cap, pos.data(), ref.data(), alt.data(), counts, ext ? dict : nullptr);
+      qm_truth_scan_ext(text, len, mode, cap, tpos.data(), tref.data(), talt.data(), counts, ext ? dict : nullptr);
+      // the host path with the file as its own truth text: every pattern shape the file can produce, against every line
+      qm_patterns* pt = qm_patterns_create(text, len, mode, ext);
+      if (!pt) { fprintf(stderr, "qm_patterns_create failed\n"); exit(1); }
+      int64_t pinfo[4], ex[5];
+      qm_patterns_info(pt, pinfo);
+      std::vector<uint8_t> k2 = kind, f2 = flags;
+      if (qm_vcf_hostpath(pt, text, len, info.n_lines, off.data(), k2.data(), pos.data(), ref.data(), alt.data(), f2.data(), ex) != QM_OK) {
+        fprintf(stderr, "hostpath failed\n"); exit(1);
+      }
+      const std::string o = std::string(outdir) + "/h.vcf";
+      qm_vcf_write(o.c_str(), text, len, info.n_lines, off.data(), k2.data(), cls.data(), 1);
+      qm_patterns_destroy(pt);
+      g_calls += 3;
     }
     g_calls += 6;
   }
