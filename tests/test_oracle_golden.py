@@ -92,15 +92,17 @@ def _python_restatement(pos, ref, alt, qual, flags, truth, n_bins):
         hit = snp and k in tset and not (flags[i] & 4)
         iddot = bool(flags[i] & 2)
         passed = bool(flags[i] & 1) and snp
+        tpline = (hit and iddot) or (snp and bool(flags[i] & 8))   # bit3: the host path found the line selected by fgrep
         if passed:
-            cls[i] = 3 if (hit and iddot) else 1
+            cls[i] = 3 if tpline else 1
             (tr_keys if hit else fp_keys).add(k + (bool(flags[i] & 4),))   # keyless records are keys of their own
         q = float(qual[i])
         b = -1 if (q != q or q < 0) else int(min(np.floor(q), n_bins - 1))
         if snp and b >= 0:
-            if hit and iddot:
+            if tpline:
                 hist[0, b] += 1
-                tmax[k] = max(tmax.get(k, -1), b)
+                if hit and iddot:
+                    tmax[k] = max(tmax.get(k, -1), b)
             else:
                 hist[1, b] += 1
     for b in tmax.values():
