@@ -63,6 +63,7 @@ struct Truth {
 struct qm_ctx {
   int dev = 0;
   hipStream_t stream = nullptr;
+  hipStream_t aux = nullptr;     // compaction of one span range runs here, beside the classification of the next
   std::vector<Truth> truths;
   TruthDev* d_truths = nullptr;  // device copy of the descriptors
   int d_truths_cap = 0;
@@ -98,7 +99,8 @@ extern "C" int qm_init(int device_id, qm_ctx** out) {
   qm_ctx* c = new qm_ctx();
   c->dev = device_id;
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  if (e != hipSuccess) { delete c; return fail(QM_E_NODEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
+  if (e != hipSuccess) { if (c->stream) (void)hipStreamDestroy(c->stream); delete c; return fail(QM_E_NODEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
   *out = c;
   return QM_OK;
 }
@@ -112,6 +114,7 @@ extern "C" void qm_destroy(qm_ctx* c) {
   }
   (void)hipFree(c->d_truths);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->aux) (void)hipStreamDestroy(c->aux);
   delete c;
 }
 
@@ -372,10 +375,18 @@ struct qm_batch {
   int32_t *d_tile_seg = nullptr, *d_ktile_seg = nullptr, *d_ktile_local = nullptr;
   int64_t cap_sort_n = 0, cap_sort_hist = 0;
   int cap_segs = 0, cap_stiles = 0, cap_ktiles = 0;
+  // The run is pipelined over a few ranges of VCFs: k_compact of range i (issue-bound, writes) runs on the context's
+  // second stream beside k_classify of range i + 1 (latency-bound, reads).
+  static constexpr int MAX_CHUNKS = 8;
+  struct Chunk { int v0, v1, s0, s1; };
+  std::vector<Chunk> chunks;
+  hipEvent_t ev_sync[MAX_CHUNKS + 2] = {};   // ordering between the two streams (no timing)
   // timing
   bool timing = false;
   static constexpr int EV_RING = 32;   // per-kernel events of the latest runs
-  hipEvent_t ev[EV_RING][4] = {};
+  static constexpr int EV_PER_RUN = 2 + 5 * MAX_CHUNKS;   // [0] start [1] end, then per chunk: classify start / end, finalize end (main stream); compact start / end (second stream)
+  hipEvent_t ev[EV_RING][EV_PER_RUN] = {};
+  int ev_chunks[EV_RING] = {};
   int64_t n_timed = 0;
   bool ran = false, finished = false;
   bool ext = false;   // allele-extended: any valid allele code takes part (build-defined widening, config 5)
@@ -396,6 +407,7 @@ static void batch_free(qm_batch* b) {
                   b->sv[1], b->si[0], b->si[1], b->shist, b->sorbits, b->d_segs, b->d_tile_seg, b->d_ktile_seg, b->d_ktile_local};
   for (void* p : ptrs) (void)hipFree(p);
   for (auto& r : b->ev) for (auto& e : r) if (e) (void)hipEventDestroy(e);
+  for (auto& e : b->ev_sync) if (e) (void)hipEventDestroy(e);
   delete b;
 }
 
@@ -438,6 +450,30 @@ static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int
   A_(b->d_vcfs, (size_t)n_vcf) A_(b->d_spans, b->cap_spans) A_(b->d_tile_vcf, b->cap_tiles) A_(b->cls_scratch, (size_t)L.max_n)
 #undef A_
   if (rc == QM_OK) rc = upload_layout(b);
+  if (rc == QM_OK) {
+    // ranges of whole VCFs with about equal numbers of spans; small batches stay in one piece
+    int want = 4;
+    if (const char* e = getenv("QM_PIPE_CHUNKS")) want = atoi(e);
+    want = std::max(1, std::min(want, (int)qm_batch::MAX_CHUNKS));
+    const int ns = (int)L.spans.size();
+    int min_spans = 4096;   // a range should fill the chip (5 120 waves) a few times over
+    if (const char* e = getenv("QM_PIPE_MIN_SPANS")) min_spans = std::max(1, atoi(e));
+    if (ns < min_spans * want) want = std::max(1, ns / min_spans);
+    int v = 0;
+    for (int k = 0; k < want && v < n_vcf; ++k) {
+      qm_batch::Chunk ck;
+      ck.v0 = v; ck.s0 = L.vcfs[(size_t)v].span0;
+      const int target = (int)((int64_t)ns * (k + 1) / want);
+      while (v < n_vcf && (k == want - 1 || L.vcfs[(size_t)v].span0 + L.vcfs[(size_t)v].nspans <= target || v == ck.v0)) ++v;
+      ck.v1 = v; ck.s1 = v < n_vcf ? L.vcfs[(size_t)v].span0 : ns;
+      b->chunks.push_back(ck);
+    }
+    if (b->chunks.empty()) b->chunks.push_back(qm_batch::Chunk{0, n_vcf, 0, ns});
+    b->chunks.back().v1 = n_vcf; b->chunks.back().s1 = ns;
+    for (auto& e : b->ev_sync) {
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rc = fail(QM_E_HIP, "hipEventCreate failed"); break; }
+    }
+  }
   if (rc == QM_OK && !packed) {
     // padding lanes are masked in the kernels, but keep the columns defined.  On the context's
     // stream (hipMemset on the null stream would not be ordered before work on a non-blocking stream).
@@ -555,6 +591,7 @@ static ClassifyParams classify_params(qm_batch* b) {
   const char* ab = getenv("QM_ABLATE");
   P.ablate = ab ? atoi(ab) : 0;
   P.ext = b->ext ? 1 : 0;
+  P.span_base = 0;
   return P;
 }
 static FinalizeParams finalize_params(qm_batch* b, uint64_t* global) {
@@ -562,13 +599,14 @@ static FinalizeParams finalize_params(qm_batch* b, uint64_t* global) {
   F.vcfs = b->d_vcfs; F.truths = b->ctx->d_truths; F.span_hist = b->span_hist; F.span_scal = b->span_scal;
   F.tile_tp = b->tile_tp; F.tile_fp = b->tile_fp; F.tile_tp_off = b->tile_tp_off; F.tile_fp_off = b->tile_fp_off;
   F.roc = b->roc; F.scalars = b->scalars; F.vcf_flags = b->vcf_flags; F.global_acc = global; F.n_bins = b->n_bins; F.ext = b->ext ? 1 : 0;
+  F.vcf_base = 0;
   return F;
 }
 static CompactParams compact_params(qm_batch* b) {
   CompactParams C;
   C.vcfs = b->d_vcfs; C.spans = b->d_spans; C.mask_pass = b->mask_pass; C.mask_tp = b->mask_tp;
   C.tile_fp = b->tile_fp; C.tile_tp_off = b->tile_tp_off; C.tile_fp_off = b->tile_fp_off; C.idx = b->idx;
-  C.vcf_flags = b->vcf_flags; C.skip_unsorted = 1;
+  C.vcf_flags = b->vcf_flags; C.skip_unsorted = 1; C.span_base = 0;
   return C;
 }
 
@@ -593,13 +631,44 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
   const size_t gbytes = (size_t)b->n_truth * 3 * (size_t)b->n_bins * 8;   // as allocated at batch creation
   HIPCHK(hipMemsetAsync(g, 0, gbytes, st));
   hipEvent_t* ev = b->ev[b->n_timed % qm_batch::EV_RING];
-  if (b->timing) HIPCHK(hipEventRecord(ev[0], st));
-  launch_classify(classify_params(b), (int)b->L.spans.size(), st);
-  if (b->timing) HIPCHK(hipEventRecord(ev[1], st));
-  launch_finalize(finalize_params(b, g), b->n_vcf, st);
-  if (b->timing) HIPCHK(hipEventRecord(ev[2], st));
-  launch_compact(compact_params(b), (int)b->L.spans.size(), st);
-  if (b->timing) { HIPCHK(hipEventRecord(ev[3], st)); b->n_timed++; }
+  const int nch = (int)b->chunks.size();
+  const bool T = b->timing;
+  if (T) { HIPCHK(hipEventRecord(ev[0], st)); b->ev_chunks[b->n_timed % qm_batch::EV_RING] = nch; }
+  // main stream: classify and finalize of every range, in order; second stream: the compaction of a range as soon as its
+  // tile offsets exist.  The second stream starts behind everything queued on the main one so far (an earlier run's
+  // compaction reads the masks this run rewrites) and the main stream ends behind the last compaction.
+  hipStream_t aux = nch > 1 ? c->aux : st;
+  if (nch > 1) {
+    HIPCHK(hipEventRecord(b->ev_sync[qm_batch::MAX_CHUNKS], st));
+    HIPCHK(hipStreamWaitEvent(aux, b->ev_sync[qm_batch::MAX_CHUNKS], 0));
+  }
+  for (int k = 0; k < nch; ++k) {
+    const qm_batch::Chunk& ck = b->chunks[(size_t)k];
+    hipEvent_t* e5 = ev + 2 + 5 * k;
+    ClassifyParams P = classify_params(b);
+    P.span_base = ck.s0;
+    if (T) HIPCHK(hipEventRecord(e5[0], st));
+    launch_classify(P, ck.s1 - ck.s0, st);
+    if (T) HIPCHK(hipEventRecord(e5[1], st));
+    FinalizeParams F = finalize_params(b, g);
+    F.vcf_base = ck.v0;
+    launch_finalize(F, ck.v1 - ck.v0, st);
+    if (T) HIPCHK(hipEventRecord(e5[2], st));
+    CompactParams K = compact_params(b);
+    K.span_base = ck.s0;
+    if (nch > 1) {
+      HIPCHK(hipEventRecord(b->ev_sync[k], st));
+      HIPCHK(hipStreamWaitEvent(aux, b->ev_sync[k], 0));
+    }
+    if (T) HIPCHK(hipEventRecord(e5[3], aux));
+    launch_compact(K, ck.s1 - ck.s0, aux);
+    if (T) HIPCHK(hipEventRecord(e5[4], aux));
+  }
+  if (nch > 1) {
+    HIPCHK(hipEventRecord(b->ev_sync[qm_batch::MAX_CHUNKS + 1], aux));
+    HIPCHK(hipStreamWaitEvent(st, b->ev_sync[qm_batch::MAX_CHUNKS + 1], 0));
+  }
+  if (T) { HIPCHK(hipEventRecord(ev[1], st)); b->n_timed++; }
   HIPCHK(hipGetLastError());
   b->ran = true;
   b->finished = false;
@@ -613,13 +682,17 @@ extern "C" int qm_batch_timings(qm_batch* b, float* ms4) {
   const int n = (int)std::min<int64_t>(b->n_timed, qm_batch::EV_RING);
   double acc[4] = {0, 0, 0, 0};
   for (int i = 0; i < n; ++i) {   // averages over the latest runs since qm_batch_set_timing(1)
-    hipEvent_t* ev = b->ev[(b->n_timed - 1 - i) % qm_batch::EV_RING];
-    HIPCHK(hipEventSynchronize(ev[3]));
+    const int slot = (int)((b->n_timed - 1 - i) % qm_batch::EV_RING);
+    hipEvent_t* ev = b->ev[slot];
+    HIPCHK(hipEventSynchronize(ev[1]));
     float t;
-    HIPCHK(hipEventElapsedTime(&t, ev[0], ev[1])); acc[0] += t;
-    HIPCHK(hipEventElapsedTime(&t, ev[1], ev[2])); acc[1] += t;
-    HIPCHK(hipEventElapsedTime(&t, ev[2], ev[3])); acc[2] += t;
-    HIPCHK(hipEventElapsedTime(&t, ev[0], ev[3])); acc[3] += t;
+    for (int k = 0; k < b->ev_chunks[slot]; ++k) {   // kernel times add up over the ranges; compaction overlaps the next range's classification
+      hipEvent_t* e5 = ev + 2 + 5 * k;
+      HIPCHK(hipEventElapsedTime(&t, e5[0], e5[1])); acc[0] += t;
+      HIPCHK(hipEventElapsedTime(&t, e5[1], e5[2])); acc[1] += t;
+      HIPCHK(hipEventElapsedTime(&t, e5[3], e5[4])); acc[2] += t;
+    }
+    HIPCHK(hipEventElapsedTime(&t, ev[0], ev[1])); acc[3] += t;
   }
   for (int k = 0; k < 4; ++k) ms4[k] = (float)(acc[k] / n);
   return QM_OK;

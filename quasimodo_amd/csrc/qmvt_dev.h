@@ -105,6 +105,7 @@ struct ClassifyParams {
   int32_t n_bins;
   int32_t ablate;  // debug only (QM_ABLATE): skip phases to price them; results are wrong when non-zero
   int32_t ext;     // allele-extended batch: k_classify<false, true> against the truth sets' extended tables
+  int32_t span_base;   // first span of this launch (the batch is run in a few span ranges so that compaction overlaps classification)
 };
 
 struct FinalizeParams {
@@ -122,6 +123,7 @@ struct FinalizeParams {
   uint64_t* global_acc;  // [n_truth][3][n_bins] or null
   int32_t n_bins;
   int32_t ext;           // allele-extended batch: T' is the size of the extended truth table
+  int32_t vcf_base;      // first VCF of this launch
 };
 
 struct CompactParams {
@@ -135,6 +137,7 @@ struct CompactParams {
   int32_t* idx;
   const uint32_t* vcf_flags;   // written by k_finalize of the same run
   int32_t skip_unsorted;       // 1: leave VCFs flagged unsorted alone (they are redone); 0: compact everything
+  int32_t span_base;           // first span of this launch
 };
 
 // one unsorted VCF inside a sort chunk

@@ -585,7 +585,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
   __shared__ __attribute__((aligned(16))) uint32_t lds[(EXT ? L_TOTAL_X : L_TOTAL) + K1_LDS_PAD];
 
   const int lane = (int)threadIdx.x;
-  const SpanDesc sp = P.spans[blockIdx.x];
+  const int span_id = (int)blockIdx.x + P.span_base;
+  const SpanDesc sp = P.spans[span_id];
   const TruthG tr = truth_global<EXT>(P.truths[sp.truth]);
   Cols C;
   C.pos = P.pos + sp.voff; C.ref = P.ref + sp.voff; C.alt = P.alt + sp.voff; C.qual = P.qual + sp.voff; C.flags = P.flags + sp.voff;
@@ -768,7 +769,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
   __syncthreads();
   const uint32_t top_tp = A.top_tp, top_fp = A.top_fp;
   // a span holds at most SPAN_TILES * K1_TILE < 65 536 records: two bins per dword (bin 2i low, 2i + 1 high)
-  uint32_t* oh = P.span_hist + (size_t)blockIdx.x * SPAN_HIST_WORDS;
+  uint32_t* oh = P.span_hist + (size_t)span_id * SPAN_HIST_WORDS;
   for (int i = lane; i < 128; i += 64) {
     const int b0 = 2 * i, b1 = 2 * i + 1;
     oh[i] = (lds[L_HTP + 1 + b0] + (b0 == nb - 1 ? top_tp : 0u)) | ((lds[L_HTP + 1 + b1] + (b1 == nb - 1 ? top_tp : 0u)) << 16);
@@ -776,7 +777,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
     oh[256 + i] = lds[L_HU + b0] | (lds[L_HU + b1] << 16);
   }
   if (lane == 0) {
-    uint32_t* sc = P.span_scal + (size_t)blockIdx.x * 8;
+    uint32_t* sc = P.span_scal + (size_t)span_id * 8;
     sc[0] = acc_pass; sc[1] = acc_tp; sc[2] = acc_pass - acc_tp; sc[3] = acc_tpr; sc[4] = A.fpr;
     sc[5] = (any_uns ? SPANF_UNSORTED : 0u) | (any_bad ? SPANF_BADPOS : 0u) | (any_lim ? SPANF_RUNLIMIT : 0u);
     sc[6] = 0; sc[7] = 0;
@@ -789,7 +790,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
 __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
   __shared__ uint32_t s_h[3][256];
   __shared__ uint32_t s_scan[256];
-  const int v = (int)blockIdx.x;
+  const int v = (int)blockIdx.x + P.vcf_base;
   const int tid = (int)threadIdx.x;
   const VcfDesc vd = P.vcfs[v];
   const int nb = P.n_bins;
@@ -921,7 +922,7 @@ __device__ __forceinline__ void ring_drain_part(Ring& R, uint32_t chunk, uint32_
 __global__ __launch_bounds__(64) void k_compact(CompactParams P) {
   __shared__ __attribute__((aligned(16))) uint32_t s_ring[2][K3_RING];
   const int lane = (int)threadIdx.x;
-  const SpanDesc sp = P.spans[blockIdx.x];
+  const SpanDesc sp = P.spans[(int)blockIdx.x + P.span_base];
   // VCFs found out of order by this run are redone by the sort path: their masks and counts are not meaningful yet
   if (P.skip_unsorted && (P.vcf_flags[sp.vcf] & SPANF_UNSORTED)) return;
   const VcfDesc vd = P.vcfs[sp.vcf];
@@ -1393,7 +1394,7 @@ __global__ void k_overlap_count(const uint32_t* keys, const uint32_t* vals, int6
 // ---------------------------------------------------------------------------
 // launchers (called from qmvt_api.cpp through qmvt_dev.h)
 // ---------------------------------------------------------------------------
-void launch_classify(const ClassifyParams& P, int n_spans, hipStream_t st) {
+void launch_classify(const ClassifyParams& P, int n_spans, hipStream_t st) {   // spans P.span_base .. + n_spans
   if (n_spans <= 0) return;
   if (P.pkey && P.ext) hipLaunchKernelGGL((k_classify<true, true>), dim3(n_spans), dim3(64), 0, st, P);
   else if (P.pkey) hipLaunchKernelGGL((k_classify<true, false>), dim3(n_spans), dim3(64), 0, st, P);
