@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- variant TP/FP classifications/sec on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W [--config {2,3,4}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W [--config {2,3,4}]
 
-Workload (config.workload): BASELINE.json configs[2] -- per GPU 1 000 synthetic VCFs x
-1 000 000 SNP records on a 5 Mb reference, 100 000-key truth set, 256-threshold ROC sweep,
-generated on the device (DESIGN.md "Synthetic generator") and resident in HBM before the
-timed region.  A step = one pass of the whole path over that batch: classify (LDS-staged
-merge-join, ballot masks, ROC histograms) -> finalize -> TP/FP index compaction, plus, for
-N > 1, the one RCCL all-reduce of the per-truth-set confusion counters.  VCFs shard over
-ranks with no data-path collective (weak scaling: per-GPU work fixed).
+Workloads (config.workload names the one that ran; all synthetic, generated on the device, resident in HBM
+before the timed region, DESIGN.md "Synthetic generator"):
+  --config 2 (default)  BASELINE.json configs[2]: per GPU 1 000 VCFs x 1 000 000 SNP records, 5 Mb reference,
+                        100 000-key truth set, 256-threshold ROC sweep
+  --config 3            configs[3], one GPU's shard of the 8-GPU run: 1 250 VCFs x 10 000 000 records, 50 Mb
+                        reference, 1 000 000 truth keys (267 GB resident)
+  --config 4            configs[4], one GPU's shard: 6 250 VCFs x 2 000 000 mixed SNP + indel records (30 % with
+                        variable-length alleles), three truth sets (VCF v against set v mod 3), allele-extended mode
+`--vcfs` overrides the VCFs per GPU (rehearsals on small boxes).
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k_classify), timed
-with HIP events on its own stream inside the timed region; `cpu_baseline` is the oracle
-(a C restatement of the reference's awk/fgrep semantics) timed on this box's host cores
-on a bounded sample of the same VCFs -- a reported baseline, not the target.
+A step = one pass of the whole path over the batch: classify (LDS-staged merge-join, class masks, ROC
+histograms) -> finalize -> TP/FP index compaction -> qm_batch_finish (reads the per-VCF flags: unsorted VCFs
+would be redone through the radix sort here), plus, for N > 1, the one RCCL all-reduce of the per-truth-set
+confusion counters.  VCFs shard over ranks with no data-path collective (weak scaling: per-GPU work fixed).
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k_classify), timed with HIP events on its own
+stream inside the timed region; `roofline.step_frac` is SURVEY 8d's formula over the whole step.  `cpu_baseline` is
+the oracle (a C restatement of the reference's awk/fgrep semantics) timed on this box's host cores on a bounded
+sample of the same VCFs -- a reported baseline, not the target.
 """
 import argparse
 import json
@@ -29,27 +36,47 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
 
+PRESETS = {
+    2: dict(vcfs=1000, records=1_000_000, genome=5_000_000, truth=100_000, truth_seeds=(3,), seed=3000, indel_pct=0,
+            name="BASELINE configs[2]"),
+    3: dict(vcfs=1250, records=10_000_000, genome=50_000_000, truth=1_000_000, truth_seeds=(4,), seed=4000, indel_pct=0,
+            name="BASELINE configs[3] (one GPU's shard of 10 000 VCFs x 10 M over 8 GPUs)"),
+    4: dict(vcfs=6250, records=2_000_000, genome=10_000_000, truth=200_000, truth_seeds=(5, 6, 7), seed=5000, indel_pct=30,
+            name="BASELINE configs[4] (one GPU's shard of 50 000 VCFs x 2 M over 8 GPUs; mixed SNP + indel, allele-extended mode)"),
+}
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--vcfs", type=int, default=int(os.environ.get("QM_BENCH_VCFS", "1000")), help="VCFs per GPU")
-    ap.add_argument("--records", type=int, default=1_000_000, help="records per VCF")
-    ap.add_argument("--genome", type=int, default=5_000_000)
-    ap.add_argument("--truth", type=int, default=100_000)
+    ap.add_argument("--config", type=int, default=int(os.environ.get("QM_BENCH_CONFIG", "2")), choices=sorted(PRESETS),
+                    help="which BASELINE.json configuration (index into its `configs`)")
+    ap.add_argument("--vcfs", type=int, default=int(os.environ.get("QM_BENCH_VCFS", "0")), help="VCFs per GPU (0 = the preset's)")
+    ap.add_argument("--records", type=int, default=0, help="records per VCF (0 = the preset's)")
+    ap.add_argument("--genome", type=int, default=0)
+    ap.add_argument("--truth", type=int, default=0)
     ap.add_argument("--bins", type=int, default=256)
-    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("QM_BENCH_CPU_VCFS", "100")),
-                    help="VCFs timed through the CPU oracle on rank 0 (N=1 only); 0 disables")
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("QM_BENCH_CPU_RECORDS", "100000000")),
+                    help="records timed through the CPU oracle on rank 0 (N=1 only); 0 disables")
     ap.add_argument("--shell-sample", type=int, default=int(os.environ.get("QM_BENCH_SHELL_VCFS", "3")),
-                    help="VCFs timed through the reference's own mechanism (awk + fgrep pipeline) on rank 0 (N=1 only); 0 disables")
+                    help="VCFs timed through the reference's own mechanism (awk + fgrep pipeline) on rank 0 (N=1, config 2 only); 0 disables")
     ap.add_argument("--shuffled", action="store_true", help="records permuted: every VCF takes the radix-sort path")
     ap.add_argument("--shuffled-vcfs", type=int, default=int(os.environ.get("QM_BENCH_SHUFFLED_VCFS", "128")),
-                    help="also time the shuffled variant (radix-sort path) on this many VCFs at N=1; 0 disables")
+                    help="also time the shuffled variant (radix-sort path) on this many VCFs at N=1, config 2; 0 disables")
     ap.add_argument("--alleles-vcfs", type=int, default=int(os.environ.get("QM_BENCH_ALLELES_VCFS", "128")),
-                    help="also time the allele-extended variant (config 5 shape: 30 %% indels) on this many VCFs at N=1; 0 disables")
+                    help="also time the allele-extended variant (config 4's record shape) on this many VCFs at N=1, config 2; 0 disables")
+    ap.add_argument("--check-vcfs", type=int, default=2, help="VCFs of this rank's batch checked against the oracle after the timed region (N > 1 and configs 3 / 4)")
     args = ap.parse_args()
+    P = dict(PRESETS[args.config])
+    custom = False
+    for k in ("vcfs", "records", "genome", "truth"):
+        v = getattr(args, k)
+        if v:
+            custom = custom or (k != "vcfs" and v != P[k])
+            P[k] = v
+    alleles = P["indel_pct"] > 0
 
     import numpy as np
     import torch
@@ -87,24 +114,24 @@ def main():
                 time.sleep(0.5)
             time.sleep(1.0)
     eng = q.Engine(local_rank)
-    tseed = 3
-    tid = eng.truth_synth(args.genome, args.truth, tseed)
-    t_unique = eng.truth_size(tid)
-    n_vcf = args.vcfs
-    batch = eng.batch([args.records] * n_vcf, [tid] * n_vcf, n_bins=args.bins)
-    # VCF v of rank r is global VCF r * n_vcf + v: seed 3000 + that
-    batch.synth(args.genome, args.truth, tseed, 3000 + rank * n_vcf, shuffled=args.shuffled)
+    tseeds = P["truth_seeds"]
+    tids = [eng.truth_synth(P["genome"], P["truth"], ts, indel_pct=P["indel_pct"]) for ts in tseeds]
+    t_unique = eng.truth_size(tids[0], alleles=alleles)
+    n_vcf = P["vcfs"]
+    # VCF v of rank r is global VCF r * n_vcf + v: seed (preset seed) + that, truth set (global v) mod 3 in config 4
+    g0 = rank * n_vcf
+    batch = eng.batch([P["records"]] * n_vcf, [tids[(g0 + v) % len(tids)] for v in range(n_vcf)], n_bins=args.bins, alleles=alleles)
+    batch.synth(P["genome"], P["truth"], None if len(tseeds) > 1 else tseeds[0], P["seed"] + g0, shuffled=args.shuffled, indel_pct=P["indel_pct"])
     # One explicit (non-default) stream carries the engine's kernels AND the collective, so the all-reduce is
     # ordered after the counters it sums.  (A NULL handle would make the engine use its own private stream.)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
-    glob = torch.zeros((eng.n_truth, 3, args.bins), dtype=torch.int64, device=dev)
+    glob = torch.zeros((batch.n_truth, 3, args.bins), dtype=torch.int64, device=dev)
     assert stream.cuda_stream != 0
 
     def step():
         batch.run(stream=stream.cuda_stream, global_dev=glob.data_ptr())
-        if args.shuffled:
-            batch.finish(stream=stream.cuda_stream)      # radix-sort path completes here
+        batch.finish(stream=stream.cuda_stream)          # per-VCF flags read back; the radix-sort path of unsorted VCFs completes here
         if world > 1:
             dist.all_reduce(glob, op=dist.ReduceOp.SUM)   # the path's only collective
 
@@ -130,13 +157,14 @@ def main():
         dt = float(tmax.item())
 
     # ---- correctness guards on the timed data (cheap, outside the timed region) ----
-    batch.finish(stream=stream.cuda_stream)
     scal = batch.scalars()
     roc = batch.roc()
-    assert int(scal[:, 6].sum()) == n_vcf * args.records
+    assert int(scal[:, 6].sum()) == n_vcf * P["records"]
     assert np.array_equal(roc[:, 0, 20].astype(np.int64), scal[:, 1]) and np.array_equal(roc[:, 1, 20].astype(np.int64), scal[:, 2])
-    local_sum = roc.sum(axis=0).astype(np.int64)
-    got = glob.cpu().numpy()[tid]
+    local_sum = np.zeros((batch.n_truth, 3, args.bins), np.int64)
+    for w, t_ in enumerate(tids):
+        local_sum[t_] = roc[(w - g0) % len(tids)::len(tids)].sum(axis=0).astype(np.int64)
+    got = glob.cpu().numpy()
     if world == 1:
         assert np.array_equal(got, local_sum), "per-truth counters != sum of the per-VCF ROC rows"
     else:
@@ -145,17 +173,21 @@ def main():
         if not np.array_equal(got, ref.cpu().numpy()):
             raise AssertionError("all-reduced counters != sum over ranks of the per-VCF ROC rows: rank %d got %d, local %d, summed %d"
                                  % (rank, int(got.sum()), int(local_sum.sum()), int(ref.sum().item())))
+    checked = 0
+    if (world > 1 or args.config != 2) and args.check_vcfs > 0:
+        checked = oracle_check(batch, P, tseeds, g0, alleles, args.bins, min(args.check_vcfs, n_vcf), roc, scal)
 
-    total_records = float(n_vcf) * args.records * world
+    total_records = float(n_vcf) * P["records"] * world
     value = total_records * args.steps / dt
     # algorithmic bytes of one k_classify launch: 17 B per record + 12 B per truth key per VCF
-    alg_bytes = n_vcf * (17.0 * args.records + 12.0 * t_unique)
+    alg_bytes = n_vcf * (17.0 * P["records"] + 12.0 * t_unique)
     k1_s = tm["classify_ms"] * 1e-3
+    step_s = dt / args.steps
     roof_kernel = "k_classify"
     if args.shuffled:
         # the optimistic k_classify pass stops early on shuffled VCFs; the work is the radix-sort path, which is
         # overhead in SURVEY 8d's accounting: the same algorithmic bytes over the whole step
-        k1_s = dt / args.steps
+        k1_s = step_s
         roof_kernel = "whole step (optimistic pass + radix-sort path + packed k_classify)"
     achieved = alg_bytes / k1_s / 1e9 if k1_s > 0 else 0.0
     traffic = None
@@ -163,11 +195,15 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("vcfs") == n_vcf and tj.get("records") == args.records and not args.shuffled:
+            if tj.get("vcfs") == n_vcf and tj.get("records") == P["records"] and not args.shuffled and not alleles:
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
+    workload = "%s%s: %d VCFs x %d %s per GPU, %d bp reference, %d truth keys%s, %d-threshold ROC%s" % (
+        P["name"], " (custom shape)" if custom else "", n_vcf, P["records"], "mixed SNP + indel records" if alleles else "SNPs",
+        P["genome"], t_unique, " x %d truth sets" % len(tids) if len(tids) > 1 else "", args.bins,
+        ", records shuffled (radix-sort path)" if args.shuffled else ", position sorted")
     out = {
         "metric": "variant TP/FP classifications/sec across all caller x sample VCFs",
         "value": value,
@@ -175,44 +211,46 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step": step_s * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "int32",
-        "data": "synthetic (generated on device; seeds 3000+v, truth seed 3)",
-        "config": {"workload": "%s: %d VCFs x %d SNPs per GPU, %d bp reference, %d truth keys, %d-threshold ROC%s"
-                               % (workload_name(args), n_vcf, args.records, args.genome, t_unique, args.bins, ", records shuffled (radix-sort path)" if args.shuffled else ", position sorted"),
-                   "vcfs_per_gpu": n_vcf, "records_per_vcf": args.records, "parallelism": "vcf-shard x%d" % world,
-                   "collective": "1 all-reduce of [%d x 3 x %d] int64 per step" % (eng.n_truth, args.bins) if world > 1 else "none"},
+        "data": "synthetic (generated on device; VCF seeds %d+v, truth seed%s %s)" % (P["seed"], "s" if len(tseeds) > 1 else "", ",".join(map(str, tseeds))),
+        "config": {"workload": workload, "baseline_config_index": args.config,
+                   "vcfs_per_gpu": n_vcf, "records_per_vcf": P["records"], "parallelism": "vcf-shard x%d" % world,
+                   "collective": "1 all-reduce of [%d x 3 x %d] int64 per step" % (batch.n_truth, args.bins) if world > 1 else "none",
+                   "vcfs_checked_against_oracle_per_rank": checked},
         "roofline": {"bound": "hbm", "kernel": roof_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k1_s * 1e3},
+                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k1_s * 1e3,
+                     # SURVEY 8d's own formula over the WHOLE step: 18.2 B x classifications/s / peak
+                     "step_frac": alg_bytes / step_s / 1e9 / HBM_PEAK_GBS},
         "kernels_ms": tm,
         "device_bytes": batch.device_bytes,
     }
 
     if rank == 0:
-        # the second denominator SURVEY 8d asks for: what a plain device-to-device copy moves on this very GPU
-        # (bytes read + bytes written per second), measured after the timed region
+        # the second denominator SURVEY 8d asks for: what this very GPU streams, measured with the library's own
+        # 16-byte-per-lane kernels after the timed region (read only / copy = read + written / write only)
         try:
-            cp = measured_copy_GBps(dev)
-            out["roofline"]["measured_copy_GBps"] = cp
-            out["roofline"]["frac_of_measured_copy"] = achieved / cp if cp > 0 else None
+            bw = eng.bw_probe(4 << 30, 5)
+            out["roofline"].update(measured_read_GBps=bw["read_GBps"], measured_copy_GBps=bw["copy_GBps"], measured_write_GBps=bw["write_GBps"],
+                                   frac_of_measured_read=achieved / bw["read_GBps"] if bw["read_GBps"] > 0 else None)
         except Exception as e:   # never fatal
-            out["roofline"]["measured_copy_GBps"] = None
-            out["roofline"]["measured_copy_error"] = str(e)[:120]
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
-        out["cpu_baseline"] = cpu_baseline(batch, args, min(args.cpu_sample, n_vcf), args.genome, args.truth, tseed)
-    if rank == 0 and world == 1 and args.shell_sample > 0:
+            out["roofline"]["measured_error"] = str(e)[:120]
+    side = rank == 0 and world == 1
+    if side and args.cpu_sample > 0:
+        out["cpu_baseline"] = cpu_baseline(batch, P, tseeds, alleles, args.bins, max(1, min(n_vcf, args.cpu_sample // P["records"])))
+    if side and args.config == 2 and not custom and args.shell_sample > 0:
         try:
-            out["cpu_baseline_shell"] = shell_baseline(batch, args, min(args.shell_sample, n_vcf), tseed)
+            out["cpu_baseline_shell"] = shell_baseline(batch, P, min(args.shell_sample, n_vcf), tseeds[0])
         except Exception as e:   # awk / GNU grep missing on the box: a reported extra, never fatal
             out["cpu_baseline_shell"] = {"error": str(e)[:200]}
-    if rank == 0 and world == 1 and not args.shuffled and args.shuffled_vcfs > 0:
-        out["shuffled_variant"] = shuffled_variant(eng, tid, args, min(args.shuffled_vcfs, n_vcf), tseed, roc)
-    if rank == 0 and world == 1 and not args.shuffled and args.alleles_vcfs > 0:
-        out["alleles_variant"] = alleles_variant(eng, args, min(args.alleles_vcfs, n_vcf))
+    if side and args.config == 2 and not custom and not args.shuffled and args.shuffled_vcfs > 0:
+        out["shuffled_variant"] = shuffled_variant(eng, tids[0], P, args.bins, min(args.shuffled_vcfs, n_vcf), tseeds[0], roc)
+    if side and args.config == 2 and not custom and not args.shuffled and args.alleles_vcfs > 0:
+        out["alleles_variant"] = alleles_variant(eng, P, args.bins, min(args.alleles_vcfs, n_vcf))
     if rank == 0:
         print(json.dumps(out))
     batch.close()
@@ -221,42 +259,45 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_copy_GBps(dev, nbytes=2 << 30, reps=5):
-    """device-to-device copy of 2 GiB: (bytes read + bytes written) / second"""
-    import torch
-    a = torch.empty(nbytes // 4, dtype=torch.int32, device=dev)
-    b = torch.empty_like(a)
-    a.fill_(1)
-    b.copy_(a)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        b.copy_(a)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    del a, b
-    return 2.0 * nbytes / (ms * 1e-3) / 1e9
+def truth_of(P, tseeds, gv):
+    """the (cached) truth keys VCF `gv` (global index) was generated against"""
+    from oracle.synth import synth_truth_keys
+    ts = tseeds[gv % len(tseeds)]
+    key = (P["genome"], P["truth"], ts, P["indel_pct"])
+    if key not in truth_of.cache:
+        truth_of.cache[key] = synth_truth_keys(P["genome"], P["truth"], ts, P["indel_pct"])
+    return truth_of.cache[key]
 
 
-def workload_name(args):
-    """which BASELINE.json configuration the arguments describe (the default is configs[2])"""
-    if (args.records, args.genome, args.truth) == (1_000_000, 5_000_000, 100_000):
-        return "BASELINE configs[2]"
-    if (args.records, args.genome, args.truth) == (10_000_000, 50_000_000, 1_000_000):
-        return "BASELINE configs[3] shape (per-GPU shard)"
-    return "custom shape"
+truth_of.cache = {}
 
 
-def shuffled_variant(eng, tid, args, nv, tseed, sorted_roc):
+def oracle_check(batch, P, tseeds, g0, alleles, bins, n_check, roc, scal):
+    """first / last VCFs of this rank's batch against the oracle (checker only, after the timed region)"""
+    import numpy as np
+    from oracle import qm_oracle as O
+    nv = batch.n_vcf
+    picks = sorted({0, nv - 1} if n_check >= 2 else {0})
+    for v in picks:
+        cols = batch.columns(v)
+        cls, oroc, sc = O.classify_columns(*cols, *truth_of(P, tseeds, g0 + v), n_bins=bins, ext=alleles)
+        assert np.array_equal(batch.cls(v), cls), "class bits of VCF %d differ from the oracle" % v
+        assert np.array_equal(roc[v], oroc), "ROC row of VCF %d differs from the oracle" % v
+        assert [int(x) for x in scal[v][:5]] == [sc[k] for k in ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R")]
+        idx = batch.idx(v)
+        n = len(cols[0])
+        assert np.array_equal(idx[:sc["tp_lines"]], np.nonzero(cls == 3)[0]) and np.array_equal(idx[n - sc["fp_lines"]:], np.nonzero(cls == 1)[0])
+    return len(picks)
+
+
+def shuffled_variant(eng, tid, P, bins, nv, tseed, sorted_roc):
     """Config 3's second variant: the same VCFs with their records permuted, so every VCF takes the
     optimistic pass, is found out of order and goes through the batched radix-sort path.  A side
     measurement on a subset; its counters must equal those of the sorted VCFs."""
     import numpy as np
     import torch
-    b = eng.batch([args.records] * nv, [tid] * nv, n_bins=args.bins)
-    b.synth(args.genome, args.truth, tseed, 3000, shuffled=True)
+    b = eng.batch([P["records"]] * nv, [tid] * nv, n_bins=bins)
+    b.synth(P["genome"], P["truth"], tseed, P["seed"], shuffled=True)
     for _ in range(1):
         b.run()
         b.finish()
@@ -269,23 +310,23 @@ def shuffled_variant(eng, tid, args, nv, tseed, sorted_roc):
     dt = time.perf_counter() - t0
     ok = bool(np.array_equal(b.roc(), sorted_roc[:nv])) and int(b.scalars()[:, 5].sum()) == 0
     b.close()
-    return {"value": nv * float(args.records) * steps / dt, "unit": "classifications/s", "vcfs": nv, "steps": steps,
+    return {"value": nv * float(P["records"]) * steps / dt, "unit": "classifications/s", "vcfs": nv, "steps": steps,
             "ms_per_step": dt / steps * 1e3, "roc_equals_sorted_variant": ok,
             "note": "records permuted: optimistic pass (stops early) + batched LSD radix sort (8-bit digits, XCD-aware tile order) + packed k_classify + TP bits scattered back"}
 
 
-def alleles_variant(eng, args, nv):
-    """BASELINE configs[4]'s shape on one GPU: mixed SNP + indel records (30 %) with variable-length
+def alleles_variant(eng, P, bins, nv):
+    """BASELINE configs[4]'s record shape on config 2's sizes: mixed SNP + indel records (30 %) with variable-length
     alleles, matched exactly in the allele-extended mode (a build-defined widening of the reference's
     single-base filter).  A side measurement on a subset; VCF 0 is checked against the oracle."""
     import numpy as np
     from oracle import qm_oracle as O
     from oracle.synth import synth_truth_keys
     pct, tseeds = 30, (5, 6, 7)
-    tids = [eng.truth_synth(args.genome, args.truth, ts, indel_pct=pct) for ts in tseeds]   # three truth sets: VCF v uses v mod 3
+    tids = [eng.truth_synth(P["genome"], P["truth"], ts, indel_pct=pct) for ts in tseeds]   # three truth sets: VCF v uses v mod 3
     tid, tseed = tids[0], tseeds[0]
-    b = eng.batch([args.records] * nv, [tids[v % 3] for v in range(nv)], n_bins=args.bins, alleles=True)
-    b.synth(args.genome, args.truth, None, 5000, indel_pct=pct)
+    b = eng.batch([P["records"]] * nv, [tids[v % 3] for v in range(nv)], n_bins=bins, alleles=True)
+    b.synth(P["genome"], P["truth"], None, 5000, indel_pct=pct)
     b.run(); b.finish()
     b.set_timing(True)
     steps = 5
@@ -296,18 +337,20 @@ def alleles_variant(eng, args, nv):
     dt = time.perf_counter() - t0
     tm = b.timings()
     cols = b.columns(0)
-    cls, roc, sc = O.classify_columns(*cols, *synth_truth_keys(args.genome, args.truth, tseed, pct), n_bins=args.bins, ext=True)
+    cls, roc, sc = O.classify_columns(*cols, *synth_truth_keys(P["genome"], P["truth"], tseed, pct), n_bins=bins, ext=True)
     ok = bool(np.array_equal(b.cls(0), cls) and np.array_equal(b.roc()[0], roc))
     t_ext = eng.truth_size(tid, alleles=True)
     b.close()
-    alg = nv * (17.0 * args.records + 12.0 * t_ext)
-    return {"value": nv * float(args.records) * steps / dt, "unit": "classifications/s", "vcfs": nv, "steps": steps,
+    for t in tids:
+        eng.truth_release(t)
+    alg = nv * (17.0 * P["records"] + 12.0 * t_ext)
+    return {"value": nv * float(P["records"]) * steps / dt, "unit": "classifications/s", "vcfs": nv, "steps": steps,
             "ms_per_step": dt / steps * 1e3, "classify_ms": tm["classify_ms"], "classify_GBps": alg / tm["classify_ms"] / 1e6,
             "indel_pct": pct, "equals_oracle_on_vcf0": ok,
             "note": "k_classify<false,true>: allele codes staged in LDS beside the keys, (key, ref, alt) equality"}
 
 
-def shell_baseline(batch, args, n_sample, tseed):
+def shell_baseline(batch, P, n_sample, tseed):
     """The reference's mechanism on this box's host: the same five shell commands per VCF that
     program/extract_TP_FP_SNPs.py:24-57 issues (awk filter, grep header, fgrep -wf / -wvf with
     process substitution), authored here (the reference file itself does not travel), on text
@@ -323,7 +366,7 @@ def shell_baseline(batch, args, n_sample, tseed):
             raise RuntimeError("%s not found" % tool)
     awkv = subprocess.run("awk -W version 2>&1 | head -1 || awk --version | head -1", shell=True, capture_output=True, text=True).stdout.strip()
     bases = np.array([b"A", b"C", b"G", b"T"])
-    tp, tr, ta = synth_truth_keys(args.genome, args.truth, tseed)
+    tp, tr, ta = synth_truth_keys(P["genome"], P["truth"], tseed)
     scal = batch.scalars()
     hdr = b"##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n"
 
@@ -359,24 +402,23 @@ def shell_baseline(batch, args, n_sample, tseed):
             nl = lambda q: sum(1 for ln in open(q, "rb") if not ln.startswith(b"#"))
             assert nl(p + ".filtered") == scal[v][0] and nl(p + ".tp") == scal[v][1] and nl(p + ".fp") == scal[v][2], \
                 "shell pipeline and GPU disagree on VCF %d" % v
-    n = float(n_sample) * args.records
+    n = float(n_sample) * P["records"]
     return {"value": n / dt, "unit": "classifications/s", "cores": 3, "kind": "reference-mechanism",
             "sample": "first %d VCFs as text (%.0f MB each), awk filter + fgrep -wf/-wvf as extract_TP_FP_SNPs.py:24-57, VCFs serial, "
                       "<= 3 concurrent pipelines per VCF, %.1f s; line counts equal the GPU's" % (n_sample, mb, dt),
             "awk": awkv}
 
 
-def cpu_baseline(batch, args, n_sample, L, T, tseed):
+def cpu_baseline(batch, P, tseeds, alleles, bins, n_sample):
     """The oracle (single thread, C) on the first n_sample VCFs of this very batch; its
     answers are also checked against the GPU's.  Reported, never used by the product."""
     import numpy as np
     from oracle import qm_oracle as O
-    from oracle.synth import synth_truth_keys
-    truth = synth_truth_keys(L, T, tseed)
+    truths = [truth_of(P, tseeds, v) for v in range(n_sample)]
     cols = [batch.columns(v) for v in range(n_sample)]
     roc = batch.roc()
     t0 = time.perf_counter()
-    res = [O.classify_columns(*c, *truth, n_bins=args.bins) for c in cols]
+    res = [O.classify_columns(*c, *t, n_bins=bins, ext=alleles) for c, t in zip(cols, truths)]
     dt = time.perf_counter() - t0
     for v, (cls, oroc, sc) in enumerate(res):
         assert np.array_equal(oroc, roc[v]), "GPU ROC row %d differs from the oracle" % v
@@ -391,7 +433,7 @@ def cpu_baseline(batch, args, n_sample, L, T, tseed):
     cores = max(1, min(cores, len(cols)))   # one VCF per thread: more threads than VCFs would idle
     with ThreadPoolExecutor(cores) as ex:
         t0 = time.perf_counter()
-        res2 = list(ex.map(lambda c: O.classify_columns(*c, *truth, n_bins=args.bins), cols))
+        res2 = list(ex.map(lambda ct: O.classify_columns(*ct[0], *ct[1], n_bins=bins, ext=alleles), list(zip(cols, truths))))
         dt2 = time.perf_counter() - t0
     assert all(np.array_equal(a[1], b[1]) for a, b in zip(res, res2))
     out["all_cores"] = {"value": n / dt2, "cores": cores, "seconds": dt2}

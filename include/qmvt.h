@@ -212,6 +212,11 @@ int64_t qm_batch_device_bytes(qm_batch* b);
  * truth-set slots the context had when the batch was created.  Truth sets loaded later do not change it. */
 int qm_batch_n_truth(qm_batch* b);
 
+/* What this GPU streams with 16-byte accesses per lane over `bytes` of HBM (>= 1 MiB; use a size far beyond the 256 MiB
+ * Infinity Cache), `reps` passes each: gbps[0] = read only, gbps[1] = copy (bytes read + bytes written per second),
+ * gbps[2] = write only.  The measured denominators bench.py quotes beside the data sheet's 8 TB/s. */
+int qm_bw_probe(qm_ctx* ctx, int64_t bytes, int reps, double* gbps /*[3]*/);
+
 /* ---- FP overlap (rules/compare_FP.smk + scripts/snpcaller_fp_compare.R:36-47) -
  * n_sets (<= 5) key lists (fp.vcf rows as packed columns); regions[m] = number
  * of distinct keys whose membership mask is m.  regions has 1 << n_sets slots. */

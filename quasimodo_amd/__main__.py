@@ -24,7 +24,7 @@ def _extract(a):
         jobs = [Job(v, a.truth, "custom", a.custom, lab) for v, lab in zip(vcfs, labels)]
     else:
         jobs = [Job(v, a.truth, "hcmv") for v in vcfs]
-    extract_many(jobs, alleles=True if a.alleles else None)
+    extract_many(jobs, alleles=True if a.alleles else None, gpus=a.gpus)
     cols = ("n_records", "n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R", "genomediff", "truth_unique", "pure_strain")
     print("\t".join(("vcf",) + cols))
     out = []
@@ -53,6 +53,8 @@ def main(argv=None):
     e.add_argument("--custom", metavar="OUTDIR", default=None, help="custom (vareval) mode: outputs under OUTDIR, truth is a .snps table")
     e.add_argument("--labels", default=None, help="comma-separated output labels for --custom")
     e.add_argument("--alleles", action="store_true", help="allele-extended mode: indels / MNPs matched exactly (off by default)")
+    e.add_argument("--gpus", type=int, default=1, help="deal the VCFs to this many GPUs of the node: one process per GPU, one all-reduce "
+                                                       "of the confusion counters (RCCL), rows gathered on rank 0")
     e.add_argument("--json", default=None, help="also write the rows as JSON")
     e.add_argument("vcf", nargs="+")
     e.set_defaults(fn=_extract)

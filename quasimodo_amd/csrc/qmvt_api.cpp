@@ -452,7 +452,7 @@ static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int
   if (rc == QM_OK) rc = upload_layout(b);
   if (rc == QM_OK) {
     // ranges of whole VCFs with about equal numbers of spans; small batches stay in one piece
-    int want = 4;
+    int want = 1;   // measured on MI355X: more than one range is SLOWER (the two kernels slow each other down by more than the overlap gains; profiles/README.md)
     if (const char* e = getenv("QM_PIPE_CHUNKS")) want = atoi(e);
     want = std::max(1, std::min(want, (int)qm_batch::MAX_CHUNKS));
     const int ns = (int)L.spans.size();
@@ -1027,6 +1027,41 @@ extern "C" int qm_bench_synth(qm_ctx* c, const qm_synth_cfg* cfg, int n_vcf, int
   (void)qm_truth_release(c, tid);   // the synthetic truth set belonged to this run only
   g_err = keep;
   return rc;
+}
+
+// ---------------------------------------------------------------------------
+// what this GPU streams: the measured denominators beside the 8 TB/s of the data sheet
+// ---------------------------------------------------------------------------
+extern "C" int qm_bw_probe(qm_ctx* c, int64_t bytes, int reps, double* gbps3) {
+  if (!c || !gbps3 || bytes < (1 << 20) || reps < 1) return fail(QM_E_INVAL, "qm_bw_probe: bad arguments");
+  HIPCHK(hipSetDevice(c->dev));
+  bytes &= ~(int64_t)4095;
+  uint8_t *a = nullptr, *d = nullptr;
+  uint32_t* sink = nullptr;
+  int rc = dalloc(&a, (size_t)bytes);
+  if (rc == QM_OK) rc = dalloc(&d, (size_t)bytes);
+  if (rc == QM_OK) rc = dalloc(&sink, 1);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  auto done = [&](int r) { (void)hipFree(a); (void)hipFree(d); (void)hipFree(sink); if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); return r; };
+  if (rc != QM_OK) return done(rc);
+  hipError_t e = hipMemsetAsync(a, 1, (size_t)bytes, c->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(d, 2, (size_t)bytes, c->stream);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  if (e != hipSuccess) return done(fail(QM_E_HIP, "qm_bw_probe: %s", hipGetErrorString(e)));
+  for (int mode = 0; mode < 3; ++mode) {   // 0 read only, 1 copy (bytes read + bytes written), 2 write only
+    launch_bw_probe(mode, a, d, bytes, sink, c->stream);   // warm-up
+    (void)hipEventRecord(e0, c->stream);
+    for (int r = 0; r < reps; ++r) launch_bw_probe(mode, a, d, bytes, sink, c->stream);
+    (void)hipEventRecord(e1, c->stream);
+    e = hipEventSynchronize(e1);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) return done(fail(QM_E_HIP, "qm_bw_probe: %s", hipGetErrorString(e)));
+    gbps3[mode] = (mode == 1 ? 2.0 : 1.0) * (double)bytes * reps / ((double)ms * 1e-3) / 1e9;
+  }
+  return done(QM_OK);
 }
 
 // ---------------------------------------------------------------------------

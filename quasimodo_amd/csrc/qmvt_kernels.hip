@@ -253,8 +253,8 @@ constexpr int L_HU = 514;                               // [256] distinct-truth-
 constexpr int L_KEYS = 772;                             // [K1_SLICE] staged truth keys of the tile
 constexpr int L_SMAX = L_KEYS + K1_SLICE;               // [K1_SLICE] per key: max(bin + 1) of '.'-ID matches
 constexpr int L_SRF = L_SMAX + K1_SLICE;                // [K1_SLICE / 32] per key: matched by a kept record
-constexpr int L_RKEY = (L_SRF + K1_SLICE / 32 + 3) & ~3;  // [256] record keys of the round (16-byte aligned)
-constexpr int L_RINF = L_RKEY + 256;                    // [128] record infos, u16 each
+constexpr int L_RKEY = (L_SRF + K1_SLICE / 32 + 3) & ~3;  // [256 + 28] record keys of the round (16-byte aligned), see rk()
+constexpr int L_RINF = L_RKEY + 288;                    // [128] record infos, u16 each
 constexpr int L_HITS = L_RINF + 128;                    // [8] one bit per record of the round: matched a truth key
 constexpr int L_MASK = L_HITS + 8;                        // [2][32] the tile's kept / TP mask words, stored once per tile
 constexpr int L_TOTAL = L_MASK + 64;
@@ -270,6 +270,15 @@ static_assert(L_XRREF % 4 == 0, "b128 LDS stores need natural alignment");
 static_assert(L_RKEY % 4 == 0 && L_RINF % 2 == 0, "b128 / b64 LDS stores need natural alignment");
 static_assert(K1_ROUNDS == 4, "one store covers the 32 + 32 mask words of a four-round tile");
 static_assert(K1_ROUNDS >= 3 && K1_SLICE % 64 == 0, "the next tile's slice is fetched over rounds 0..2 of the current one");
+
+// The record keys of a round are bisected by the truth keys: probe k of every lane lands on indices that differ by
+// multiples of 256 >> k, i.e. on ONE bank of the 32.  Four dwords of padding after every 32 keys put the eight 32-key
+// blocks on eight different banks (and keep every lane's four keys one aligned 16-byte store).
+#ifndef QM_NO_RKEY_PAD
+__device__ __forceinline__ int rk(int i) { return L_RKEY + i + ((i >> 5) << 2); }
+#else
+__device__ __forceinline__ int rk(int i) { return L_RKEY + i; }
+#endif
 
 struct Slice {
   int keys, smax, srf;  // dword offsets of the active buffer
@@ -336,7 +345,7 @@ __device__ __forceinline__ void stage_round(uint32_t* lds, In4& X, int i0, int t
   kv.x = X.key[0]; kv.y = X.key[1]; kv.z = X.key[2]; kv.w = X.key[3];
   uint2 iv;
   iv.x = (X.inf[0] & 0xffffu) | (X.inf[1] << 16); iv.y = (X.inf[2] & 0xffffu) | (X.inf[3] << 16);
-  *reinterpret_cast<uint4*>(&lds[L_RKEY + lane * 4]) = kv;
+  *reinterpret_cast<uint4*>(&lds[rk(lane * 4)]) = kv;
   *reinterpret_cast<uint2*>(&lds[L_RINF + lane * 2]) = iv;
   if (EXT) {   // records beyond `te` keep whatever codes they loaded: their key matches nothing
     uint4 rv, av;
@@ -354,8 +363,8 @@ __device__ __forceinline__ void stage_round(uint32_t* lds, In4& X, int i0, int t
 template <bool EXT>
 __device__ __forceinline__ void join_round(uint32_t* lds, const Slice& S, int nrec, int own_a, int lane) {
   if (S.m <= 0 || nrec <= 0) return;
-  const uint32_t first_pos = lds[L_RKEY] >> 4;
-  const uint32_t last_pos = lds[L_RKEY + nrec - 1] >> 4;
+  const uint32_t first_pos = lds[rk(0)] >> 4;
+  const uint32_t last_pos = lds[rk(nrec - 1)] >> 4;
   // keys of the slice inside [first_pos, last_pos]: counted with ballots
   int rlo = 0, rhi = 0;
   for (int base = 0; base < S.m; base += 64) {
@@ -375,14 +384,14 @@ __device__ __forceinline__ void join_round(uint32_t* lds, const Slice& S, int nr
 #pragma unroll
       for (int step = 128; step > 0; step >>= 1) {
         const int idx = s + step;
-        if (lds[L_RKEY + idx - 1] < kfloor) s = idx;   // idx - 1 <= 254
+        if (lds[rk(idx - 1)] < kfloor) s = idx;   // idx - 1 <= 254
       }
-      if (s < 256 && lds[L_RKEY + s] < kfloor) s += 1;   // s == 255 still below
+      if (s < 256 && lds[rk(s)] < kfloor) s += 1;   // s == 255 still below
       uint32_t mx = 0, rf = 0;
       for (; s < nrec; ++s) {   // the run of records at this position
-        const uint32_t rk = lds[L_RKEY + s];
-        if ((rk & ~15u) != kfloor) break;
-        if (rk != kkey) continue;
+        const uint32_t rkey = lds[rk(s)];
+        if ((rkey & ~15u) != kfloor) break;
+        if (rkey != kkey) continue;
         if (EXT) {   // the nibble of an extended key is a hash: the allele codes decide
           if (lds[L_XRREF + s] != lds[S.ref + j] || lds[L_XRALT + s] != lds[S.alt + j]) continue;
         }
@@ -707,7 +716,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
       }
       __syncthreads();
       classify_round<PACKED, EXT>(lds, C, X, rbase, te, prev_last, nb, ablate, 8 * r, A, lane);
-      prev_last = (int)(lds[L_RKEY + 255] >> 4);
+      prev_last = (int)(lds[rk(255)] >> 4);
       __syncthreads();
     }
 
@@ -1392,8 +1401,59 @@ __global__ void k_overlap_count(const uint32_t* keys, const uint32_t* vals, int6
 }
 
 // ---------------------------------------------------------------------------
+// bandwidth probes: what this GPU streams with 16 bytes per lane, read only / copy / write only (qm_bw_probe)
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_bw_probe(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16, uint32_t* sink) {
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  v4u acc = {0u, 0u, 0u, 0u};
+  // four independent 16-byte accesses per lane and trip: 4 KiB per wave in flight
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    if (MODE != 2) {
+      const v4u x0 = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(src + i));
+      const v4u x1 = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(src + i + stride));
+      const v4u x2 = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(src + i + 2 * stride));
+      const v4u x3 = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(src + i + 3 * stride));
+      if (MODE == 1) {
+        __builtin_nontemporal_store(x0, reinterpret_cast<v4u*>(dst + i));
+        __builtin_nontemporal_store(x1, reinterpret_cast<v4u*>(dst + i + stride));
+        __builtin_nontemporal_store(x2, reinterpret_cast<v4u*>(dst + i + 2 * stride));
+        __builtin_nontemporal_store(x3, reinterpret_cast<v4u*>(dst + i + 3 * stride));
+      } else {
+        acc ^= x0 ^ x1 ^ x2 ^ x3;
+      }
+    } else {
+      const v4u v = {(unsigned)i, 1u, 2u, 3u};
+      __builtin_nontemporal_store(v, reinterpret_cast<v4u*>(dst + i));
+      __builtin_nontemporal_store(v, reinterpret_cast<v4u*>(dst + i + stride));
+      __builtin_nontemporal_store(v, reinterpret_cast<v4u*>(dst + i + 2 * stride));
+      __builtin_nontemporal_store(v, reinterpret_cast<v4u*>(dst + i + 3 * stride));
+    }
+  }
+  for (; i < n16; i += stride) {
+    if (MODE != 2) {
+      const v4u x = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(src + i));
+      if (MODE == 1) __builtin_nontemporal_store(x, reinterpret_cast<v4u*>(dst + i)); else acc ^= x;
+    } else {
+      const v4u v = {(unsigned)i, 1u, 2u, 3u};
+      __builtin_nontemporal_store(v, reinterpret_cast<v4u*>(dst + i));
+    }
+  }
+  if (MODE == 0 && (acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) *sink = 1u;   // keeps the loads alive; never true for the probe's fill pattern
+}
+
+// ---------------------------------------------------------------------------
 // launchers (called from qmvt_api.cpp through qmvt_dev.h)
 // ---------------------------------------------------------------------------
+void launch_bw_probe(int mode, const uint8_t* src, uint8_t* dst, int64_t bytes, uint32_t* sink, hipStream_t st) {
+  const int64_t n16 = bytes / 16;
+  const dim3 grid(256 * 8), block(256);
+  if (mode == 0) hipLaunchKernelGGL((k_bw_probe<0>), grid, block, 0, st, (const uint4*)src, (uint4*)dst, n16, sink);
+  else if (mode == 1) hipLaunchKernelGGL((k_bw_probe<1>), grid, block, 0, st, (const uint4*)src, (uint4*)dst, n16, sink);
+  else hipLaunchKernelGGL((k_bw_probe<2>), grid, block, 0, st, (const uint4*)src, (uint4*)dst, n16, sink);
+}
 void launch_classify(const ClassifyParams& P, int n_spans, hipStream_t st) {   // spans P.span_base .. + n_spans
   if (n_spans <= 0) return;
   if (P.pkey && P.ext) hipLaunchKernelGGL((k_classify<true, true>), dim3(n_spans), dim3(64), 0, st, P);

@@ -135,6 +135,12 @@ class Engine:
         check(self._L.qm_bench_synth(self._h, C.byref(cfg), int(n_vcf), int(records), int(n_bins), int(steps), C.byref(r)), self._h)
         return {k: getattr(r, k) for k, _ in r._fields_ if k != "reserved"}
 
+    def bw_probe(self, nbytes=4 << 30, reps=5):
+        """qm_bw_probe: GB/s this GPU streams read-only, copying (read + written) and write-only"""
+        out = (C.c_double * 3)()
+        check(self._L.qm_bw_probe(self._h, int(nbytes), int(reps), out), self._h)
+        return {"read_GBps": out[0], "copy_GBps": out[1], "write_GBps": out[2]}
+
     def fp_overlap(self, key_sets):
         """key_sets: list of (pos, ref, alt) arrays, one per caller.  Returns region
         counts indexed by membership mask (snpcaller_fp_compare.R:36-47)."""

@@ -74,14 +74,20 @@ def _alleles_default():
     return os.environ.get("QM_ALLELES", "0") not in ("", "0")
 
 
-def extract_many(jobs, engine=None, strict=None, n_bins=256, alleles=None):
+def extract_many(jobs, engine=None, strict=None, n_bins=256, alleles=None, gpus=None):
     """Classify and write filtered / tp / fp VCFs for a list of Job.  Returns the jobs
     with .stats filled (line counts, R-path counts, ROC rows).
+    gpus > 1: the VCFs are dealt to that many GPUs of this node, one process each (quasimodo_amd.multigpu).
     alleles=True (or QM_ALLELES=1): the allele-extended mode -- every record whose REF and ALT are
     [ACGT]+ takes part, not only single bases (a build-defined widening of the reference's filter,
     include/qmvt.h; hcmv mode only)."""
     strict = _strict_default() if strict is None else strict
     alleles = _alleles_default() if alleles is None else bool(alleles)
+    if gpus is not None and int(gpus) > 1:
+        if engine is not None:
+            raise ValueError("gpus > 1 starts one process (and one engine) per GPU: do not pass an engine")
+        from .multigpu import extract_many_sharded
+        return extract_many_sharded(jobs, int(gpus), n_bins=n_bins, alleles=alleles, strict=strict)[0]
     if alleles and any(j.mode != "hcmv" for j in jobs):
         raise ValueError("the allele-extended mode needs VCF truth sets (hcmv mode)")
     adict = AlleleDict() if alleles else None

@@ -1,67 +1,85 @@
-"""N > 1 path on CPU: world_size-2 gloo.  VCFs shard over ranks (LPT), each rank's confusion
-counters are summed with the path's single all-reduce, and the result equals the single-process
-total.  The per-rank classification here is the ORACLE (there is no GPU in this test); what is
-under test is the sharding and the collective bench.py / a multi-GPU host use."""
+"""N > 1 path on CPU: world_size-2 gloo through the PRODUCT's multi-GPU entry point
+(quasimodo_amd.multigpu.extract_many_sharded): the parent starts one process per rank, the ranks deal the VCFs by
+LPT, each classifies its share and writes its files, the confusion counters of every truth set go through the
+path's single all-reduce and the per-VCF rows are gathered on rank 0.  There is no GPU here, so the per-rank
+classification is injected (tests/sharded_cpu_classify.py: product host code + the oracle as the device); the
+sharding, the collective, the gather and the process handling under test are the product's own."""
 import os
-import socket
-import sys
 
 import numpy as np
 import pytest
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+from conftest import ROOT, case_id, golden_cases, read_case
+
+CASES = [c for c in golden_cases() if c["family"] in ("hcmv", "quirks", "custom", "edge")]
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+def _jobs(tmp_path):
+    from quasimodo_amd.extract import Job
+    jobs, exps = [], []
+    for e in CASES:
+        vcf, truth, exp = read_case(e)
+        root = tmp_path / e["family"] / e["mode"]
+        vp = root / e["vcf"][len("input/"):]
+        tp = root / e["truth"][len("input/"):]
+        vp.parent.mkdir(parents=True, exist_ok=True)
+        tp.parent.mkdir(parents=True, exist_ok=True)
+        vp.write_bytes(vcf)
+        tp.write_bytes(truth)
+        jobs.append(Job(str(vp), str(tp), e["mode"], str(root / e["outdir"]), e["caller"]))
+        exps.append((e, exp))
+    return jobs, exps
 
 
-def _worker(rank, world, port, q):
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import torch
-    import torch.distributed as dist
-    from conftest import random_columns, random_truth
-    from oracle import qm_oracle as O
-    from quasimodo_amd.sharding import allreduce_counters, lpt_shards
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    rng = np.random.default_rng(2024)                       # same inputs on every rank
-    truths = [random_truth(rng, 500, 20000), random_truth(rng, 200, 20000)]
-    sizes = [3000, 10, 1200, 800, 2500, 1, 900]
-    cols = [random_columns(rng, n, 20000, truths[i % 2]) for i, n in enumerate(sizes)]
-    shards = lpt_shards(sizes, world)
-    local = np.zeros((2, 3, 256), np.int64)
-    for v in shards[rank]:
-        _, roc, _ = O.classify_columns(*cols[v], *truths[v % 2])
-        local[v % 2] += roc.astype(np.int64)
-    t = torch.from_numpy(local.copy())
-    allreduce_counters(t)
-    total = np.zeros((2, 3, 256), np.int64)
-    for v in range(len(sizes)):
-        _, roc, _ = O.classify_columns(*cols[v], *truths[v % 2])
-        total[v % 2] += roc.astype(np.int64)
-    q.put((rank, bool(np.array_equal(t.numpy(), total)), [len(s) for s in shards]))
-    dist.barrier()
-    dist.destroy_process_group()
+def test_sharded_extract_gloo_world2(tmp_path, monkeypatch, oracle, qmlib):
+    from quasimodo_amd.multigpu import extract_many_sharded, job_weights, truth_key
+    from quasimodo_amd.sharding import lpt_shards
+    monkeypatch.setenv("PYTHONPATH", os.path.join(ROOT, "tests") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    jobs, exps = _jobs(tmp_path)
+    jobs, res = extract_many_sharded(jobs, 2, backend="gloo", classify="sharded_cpu_classify:classify", timeout=300)
+    # every rank wrote its own files: the reference's bytes, whichever rank a VCF went to
+    for job, (e, exp) in zip(jobs, exps):
+        assert open(job.filtered_out, "rb").read() == exp["filtered"], case_id(e)
+        assert open(job.fp_out, "rb").read() == exp["fp"], case_id(e)
+        if not e["pure"]:
+            assert open(job.tp_out, "rb").read() == exp["tp"], case_id(e)
+    # LPT on the file sizes, both ranks busy, rows gathered back in job order
+    shards = lpt_shards(job_weights(jobs), 2)
+    assert res["shards"] == shards and all(len(s) > 0 for s in shards)
+    w = np.array(job_weights(jobs))
+    loads = [int(w[s].sum()) for s in shards]
+    assert abs(loads[0] - loads[1]) <= int(w.max())          # LPT: the loads differ by at most one job
+    for r, s in enumerate(shards):
+        for i in s:
+            assert jobs[i].stats["rank"] == r and jobs[i].stats["device"] == r
+    # the single all-reduce: per truth set, the sum over ALL VCFs of their ROC rows
+    keys = res["truth_keys"]
+    want = np.zeros((len(keys), 3, 256), np.int64)
+    for j in jobs:
+        if j.stats["roc"] is not None:
+            want[keys.index(truth_key(j))] += j.stats["roc"].astype(np.int64)
+    assert np.array_equal(res["counters"], want) and want.sum() > 0
+    assert len(keys) == len({truth_key(j) for j, (e, _) in zip(jobs, exps) if not e["pure"]})
 
 
-def test_vcf_sharding_allreduce_gloo_world2():
-    import torch.multiprocessing as mp
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=120) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert all(ok for _, ok, _ in res), res
-    assert sum(res[0][2]) == 7
+def test_sharded_extract_reports_a_failing_rank(tmp_path, monkeypatch, qmlib):
+    from quasimodo_amd.extract import Job
+    from quasimodo_amd.multigpu import extract_many_sharded
+    monkeypatch.setenv("PYTHONPATH", os.path.join(ROOT, "tests") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    (tmp_path / "a.vcf").write_bytes(b"#h\nc\t1\t.\tA\tG\t50\n")
+    (tmp_path / "b.vcf").write_bytes(b"#h\nc\t1\t.\tA\tG\t50\n")
+    jobs = [Job(str(tmp_path / "a.vcf"), str(tmp_path / "missing.vcf"), "hcmv"), Job(str(tmp_path / "b.vcf"), str(tmp_path / "missing.vcf"), "hcmv")]
+    with pytest.raises(RuntimeError) as ei:
+        extract_many_sharded(jobs, 2, backend="gloo", classify="sharded_cpu_classify:classify", timeout=300)
+    assert "rank" in str(ei.value) and "missing.vcf" in str(ei.value)
+
+
+def test_lpt_shards_properties():
+    from quasimodo_amd.sharding import lpt_shards
+    rng = np.random.default_rng(5)
+    for world in (1, 2, 3, 8):
+        n = rng.integers(1, 10**7, size=50)
+        sh = lpt_shards(n, world)
+        assert sorted(i for s in sh for i in s) == list(range(50)) and all(s == sorted(s) for s in sh)
+        loads = [int(n[s].sum()) for s in sh]
+        assert max(loads) - min(loads) <= int(n.max())

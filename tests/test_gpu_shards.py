@@ -1,0 +1,93 @@
+"""Driver-run checks of the shapes BASELINE.json names beyond configs[2]: one GPU's FULL shard of the 8-GPU
+configurations (configs[3]: 1 250 VCFs x 10 M records; configs[4]: 6 250 VCFs x 2 M mixed SNP + indel records, three
+truth sets) -- 1.25e10 records, 267 GB resident of the 288 GB -- and the product's multi-GPU entry point with two ranks
+on this one GPU.  First / middle / last VCF against the oracle, size-independent invariants over all of them."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, case_id, golden_cases, read_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _full_shard(engine, oracle, nv, L, T, N, seeds, vseed, pct):
+    from oracle.synth import synth_truth_keys
+    ext = pct > 0
+    tids = [engine.truth_synth(L, T, ts, indel_pct=pct) for ts in seeds]
+    b = engine.batch([N] * nv, [tids[v % len(tids)] for v in range(nv)], alleles=ext)
+    try:
+        assert b.device_bytes > 250e9
+        b.synth(L, T, None if len(seeds) > 1 else seeds[0], vseed, indel_pct=pct)
+        b.set_timing(True)
+        for _ in range(2):
+            b.run()
+        b.finish()
+        tm = b.timings()
+        roc, scal = b.roc(), b.scalars()
+        assert (scal[:, 6] == N).all() and (scal[:, 5] == 1).all()
+        assert np.array_equal(roc[:, 0, 20].astype(np.int64), scal[:, 1]) and np.array_equal(roc[:, 1, 20].astype(np.int64), scal[:, 2])
+        assert (scal[:, 1] + scal[:, 2] == scal[:, 0]).all() and (scal[:, 3] <= scal[:, 7]).all()
+        glob = b.global_counts()
+        for w, t_ in enumerate(tids):      # what the all-reduce carries: per truth set, the sum of its VCFs' rows
+            assert np.array_equal(glob[t_], roc[w::len(tids)].sum(axis=0))
+        truths = [synth_truth_keys(L, T, ts, pct) for ts in seeds]
+        for v in (0, nv // 2, nv - 1):     # the last one lies far beyond the 2^32nd record of the batch
+            cols = b.columns(v)
+            cls, oroc, sc = oracle.classify_columns(*cols, *truths[v % len(tids)], ext=ext)
+            assert np.array_equal(b.cls(v), cls) and np.array_equal(roc[v], oroc), v
+            assert [int(x) for x in scal[v][:5]] == [sc[k] for k in ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R")], v
+            idx = b.idx(v)
+            assert np.array_equal(idx[:sc["tp_lines"]], np.nonzero(cls == 3)[0]) and np.array_equal(idx[N - sc["fp_lines"]:], np.nonzero(cls == 1)[0])
+        rate = nv * float(N) / (tm["total_ms"] * 1e-3)
+        print("full shard %d x %d: %.1f ms per pass, %.3g classifications/s, k_classify %.0f GB/s algorithmic" %
+              (nv, N, tm["total_ms"], rate, nv * (17.0 * N + 12.0 * T) / tm["classify_ms"] / 1e6))
+        assert rate > 1e11
+    finally:
+        b.close()
+        for t in tids:
+            engine.truth_release(t)
+
+
+def test_configs3_full_per_gpu_shard(engine, oracle):
+    """BASELINE configs[3]: 10 000 VCFs x 10 M over 8 GPUs = 1 250 VCFs per GPU"""
+    _full_shard(engine, oracle, 1250, 50_000_000, 1_000_000, 10_000_000, (4,), 4000, 0)
+
+
+def test_configs4_full_per_gpu_shard(engine, oracle):
+    """BASELINE configs[4]: 50 000 VCFs x 2 M mixed SNP + indel over 8 GPUs = 6 250 VCFs per GPU, VCF v against truth set v mod 3"""
+    _full_shard(engine, oracle, 6250, 10_000_000, 200_000, 2_000_000, (5, 6, 7), 5000, 30)
+
+
+def test_product_multi_gpu_entry_point_two_ranks_on_this_gpu(tmp_path, qmlib):
+    """quasimodo_amd.multigpu.extract_many_sharded with the HIP engine on both ranks (same device, gloo for the collective
+    since RCCL refuses two ranks on one GPU): LPT shards, files by both ranks, one all-reduce, rows gathered."""
+    from quasimodo_amd.extract import Job
+    from quasimodo_amd.multigpu import extract_many_sharded, truth_key
+    cases = [c for c in golden_cases() if c["family"] in ("hcmv", "quirks", "custom")]
+    jobs, exps = [], []
+    for e in cases:
+        vcf, truth, exp = read_case(e)
+        root = tmp_path / e["family"] / e["mode"]
+        vp = root / e["vcf"][len("input/"):]
+        tp = root / e["truth"][len("input/"):]
+        vp.parent.mkdir(parents=True, exist_ok=True)
+        tp.parent.mkdir(parents=True, exist_ok=True)
+        vp.write_bytes(vcf)
+        tp.write_bytes(truth)
+        jobs.append(Job(str(vp), str(tp), e["mode"], str(root / e["outdir"]), e["caller"]))
+        exps.append((e, exp))
+    jobs, res = extract_many_sharded(jobs, 2, backend="gloo", same_device=True, strict=True, timeout=600)
+    for job, (e, exp) in zip(jobs, exps):
+        assert open(job.filtered_out, "rb").read() == exp["filtered"], case_id(e)
+        assert open(job.fp_out, "rb").read() == exp["fp"], case_id(e)
+        if not e["pure"]:
+            assert open(job.tp_out, "rb").read() == exp["tp"], case_id(e)
+    assert all(len(s) > 0 for s in res["shards"])
+    keys = res["truth_keys"]
+    want = np.zeros((len(keys), 3, 256), np.int64)
+    for j in jobs:
+        if j.stats.get("roc") is not None:
+            want[keys.index(truth_key(j))] += np.asarray(j.stats["roc"]).astype(np.int64)
+    assert np.array_equal(res["counters"], want) and want.sum() > 0
