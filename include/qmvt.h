@@ -313,6 +313,10 @@ int qm_vcf_write(const char* path, const uint8_t* text, size_t len, int64_t n_li
  * as awk prints them).  mode 0 = xsnp, 1 = xindel.  flavour 0 reads `{2,}` as a POSIX interval
  * (gawk), flavour 1 as literal text (mawk 1.3.4 20200120).  Atomic (temp file + rename). */
 int qm_vcf_split_write(const char* path, const uint8_t* text, size_t len, int mode, int flavour, int64_t* n_written);
+/* `bgzip -c` (the *.vcf.gz outputs the same rules declare, rules/vis_eval_vcf.smk:29,36 ...): BGZF = gzip members of at
+ * most 64 KiB with a 'BC' extra field + the EOF member; zcat and tabix / htslib read it.  level -1 = zlib's default (6,
+ * bgzip's default).  Atomic. */
+int qm_bgzf_write(const char* path, const uint8_t* data, size_t len, int level);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,7 @@ EXPORTS = (
     "qm_truth_size_ext", "qm_truth_synth_ext", "qm_batch_create_ext", "qm_classify_batch_ext",
     "qm_dict_create", "qm_dict_destroy", "qm_dict_size", "qm_allele_code", "qm_allele_spell", "qm_vcf_scan_ext", "qm_truth_scan_ext",
     "qm_bench_synth", "qm_truth_release", "qm_batch_n_truth",
-    "qm_bw_probe", "qm_patterns_create", "qm_patterns_destroy", "qm_patterns_info", "qm_vcf_hostpath",
+    "qm_bw_probe", "qm_bgzf_write", "qm_patterns_create", "qm_patterns_destroy", "qm_patterns_info", "qm_vcf_hostpath",
 )
 
 
@@ -131,6 +131,7 @@ def lib():
     L.qm_allele_code.restype = i32
     L.qm_allele_spell.argtypes = [vp, i32, C.c_char_p, C.c_size_t]
     L.qm_allele_spell.restype = i64
+    L.qm_bgzf_write.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, i32]
     L.qm_bw_probe.argtypes = [vp, i64, i32, C.POINTER(C.c_double)]
     L.qm_patterns_create.argtypes = [C.c_char_p, C.c_size_t, i32, i32]
     L.qm_patterns_create.restype = vp

@@ -24,6 +24,7 @@
 #include <fcntl.h>
 #include <sys/uio.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include "../../include/qmvt.h"
 
@@ -794,6 +795,61 @@ extern "C" int qm_vcf_write(const char* path, const uint8_t* text, size_t len, i
                             const uint8_t* line_kind, const uint8_t* cls, int select) {
   if (!path || !line_off || !line_kind || select < 0 || select > 2 || (!text && len)) return QM_E_INVAL;
   return write_selected(path, text, len, n_lines, line_off, line_kind, cls, select);
+}
+
+// ---------------------------------------------------------------------------
+// BGZF (what `bgzip -c` writes in rules/vis_eval_vcf.smk:36,51,67,82): a series of gzip members of at most 64 KiB, each
+// carrying its compressed size in a 'BC' extra field, closed by the fixed empty EOF member.  Readable by zcat / gzip and
+// by tabix / htslib.  (SAM/BAM specification, section 4.1.)
+// ---------------------------------------------------------------------------
+namespace {
+
+const uint8_t kBgzfEof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+// one member from at most 0xff00 input bytes; returns the member size, 0 on error
+size_t bgzf_block(const uint8_t* in, size_t n, int level, uint8_t* out /* >= 0x10000 */) {
+  static const uint8_t head[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0};
+  memcpy(out, head, 16);
+  z_stream zs;
+  memset(&zs, 0, sizeof zs);
+  if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return 0;
+  zs.next_in = const_cast<Bytef*>(in);
+  zs.avail_in = (uInt)n;
+  zs.next_out = out + 18;
+  zs.avail_out = 0x10000 - 18 - 8;
+  const int rc = deflate(&zs, Z_FINISH);
+  const size_t clen = zs.total_out;
+  deflateEnd(&zs);
+  if (rc != Z_STREAM_END) return 0;   // cannot happen for <= 0xff00 bytes: deflate's worst case fits
+  const size_t total = 18 + clen + 8;
+  const uint16_t bsize = (uint16_t)(total - 1);
+  out[16] = (uint8_t)(bsize & 0xff); out[17] = (uint8_t)(bsize >> 8);
+  const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in, (uInt)n);
+  const uint32_t isz = (uint32_t)n;
+  for (int k = 0; k < 4; ++k) { out[18 + clen + k] = (uint8_t)(crc >> (8 * k)); out[22 + clen + k] = (uint8_t)(isz >> (8 * k)); }
+  return total;
+}
+
+}  // namespace
+
+extern "C" int qm_bgzf_write(const char* path, const uint8_t* data, size_t len, int level) {
+  if (!path || (!data && len) || level < -1 || level > 9) return QM_E_INVAL;
+  static std::atomic<unsigned> serial{0};
+  const std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid()) + "." + std::to_string(serial.fetch_add(1));
+  FILE* fh = fopen(tmp.c_str(), "wb");
+  if (!fh) return QM_E_IO;
+  std::vector<uint8_t> blk(0x10000);
+  bool ok = true;
+  for (size_t off = 0; off < len && ok; off += 0xff00) {
+    const size_t n = std::min<size_t>(0xff00, len - off);
+    const size_t m = bgzf_block(data + off, n, level, blk.data());
+    ok = m > 0 && fwrite(blk.data(), 1, m, fh) == m;
+  }
+  ok = ok && fwrite(kBgzfEof, 1, sizeof kBgzfEof, fh) == sizeof kBgzfEof;
+  ok = (fclose(fh) == 0) && ok;
+  if (!ok) { remove(tmp.c_str()); return QM_E_IO; }
+  if (rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return QM_E_IO; }
+  return QM_OK;
 }
 
 // ---------------------------------------------------------------------------

@@ -192,9 +192,21 @@ def awk_flavour_default() -> int:
     return AWK_MAWK_LITERAL if v == "mawk-literal" else AWK_POSIX
 
 
-def split_variants(vcf_path, out_path, kind, flavour=None) -> int:
+def bgzip(src_path, dst_path=None, level=-1) -> str:
+    """`bgzip -c src > dst` (rules/vis_eval_vcf.smk:36,51,67,82) without the tool: BGZF members + EOF block."""
+    dst_path = dst_path or src_path + ".gz"
+    with open(src_path, "rb") as fh:
+        data = fh.read()
+    rc = _lib.lib().qm_bgzf_write(os.fsencode(dst_path), data, len(data), int(level))
+    if rc < 0:
+        raise QmvtError(rc, "cannot write %s" % dst_path)
+    return dst_path
+
+
+def split_variants(vcf_path, out_path, kind, flavour=None, bgz=False) -> int:
     """`extract_snp` / `extract_indel` / `extract_nucmer_*` (rules/vis_eval_vcf.smk:25-86) without
-    awk: kind "xsnp" or "xindel"; returns the number of lines written."""
+    awk: kind "xsnp" or "xindel"; returns the number of lines written.  bgz=True also writes the rules' second
+    declared output, <out_path>.gz (BGZF, what `bgzip -c` makes of it)."""
     if kind not in ("xsnp", "xindel"):
         raise ValueError("kind must be xsnp or xindel")
     with open(vcf_path, "rb") as fh:
@@ -204,4 +216,6 @@ def split_variants(vcf_path, out_path, kind, flavour=None) -> int:
                                        awk_flavour_default() if flavour is None else int(flavour), C.byref(n))
     if rc < 0:
         raise QmvtError(rc, "cannot write %s" % out_path)
+    if bgz:
+        bgzip(out_path)
     return int(n.value)

@@ -78,13 +78,13 @@ def run_hcmv_variantcall(data_dir, outpath, callers=None, engine=None, dryrun=Fa
         jobs.append(Job(dst, os.path.join(snp_dir, "nucmer", "%s.maskrepeat.variants.vcf" % s[:2]), "hcmv", d, c))
         meta.append((c, s))
     from .vcfio import split_variants
-    for kind in ("xsnp", "xindel"):                                      # extract_snp / extract_indel / extract_nucmer_*
-        for j in jobs:
-            split_variants(j.vcf_file, j.vcf_file[:-4] + ".%s.vcf" % kind, kind)
+    for kind in ("xsnp", "xindel"):                                      # extract_snp / extract_indel / extract_nucmer_*:
+        for j in jobs:                                                   # both declared outputs, *.vcf and its bgzip
+            split_variants(j.vcf_file, j.vcf_file[:-4] + ".%s.vcf" % kind, kind, bgz=True)
         for mix in ("TM", "TA"):
             t = os.path.join(snp_dir, "nucmer", "%s.maskrepeat.variants.vcf" % mix)
             if os.path.exists(t):
-                split_variants(t, os.path.join(snp_dir, "nucmer", "%s.maskrepeat.%s.vcf" % (mix, kind)), kind)
+                split_variants(t, os.path.join(snp_dir, "nucmer", "%s.maskrepeat.%s.vcf" % (mix, kind)), kind, bgz=True)
     own = engine is None
     if own:
         engine = Engine(int(os.environ.get("QM_DEVICE", "0")))
@@ -93,11 +93,15 @@ def run_hcmv_variantcall(data_dir, outpath, callers=None, engine=None, dryrun=Fa
         os.makedirs(os.path.join(results, "final_tables"), exist_ok=True)
         write_caller_performance(os.path.join(results, "final_tables", "caller_performance.tsv"),
                                  [(c, s, j.stats) for (c, s), j in zip(meta, jobs)])
-        for (c, smp), j in zip(meta, jobs):                              # exact-match ROC where rules/vis_eval_vcf.smk puts RTG's
+        # The engine's exact-match ROC sweeps, in the column layout of RTG's weighted_roc.tsv.gz but under a directory of
+        # their own: results/snp/rtg/ belongs to the reference's rtg rules (rules/vis_eval_vcf.smk:5-121), whose
+        # haplotype-aware numbers these are not.
+        for (c, smp), j in zip(meta, jobs):
             if not j.stats.get("pure_strain") and j.stats.get("roc") is not None:
-                d = os.path.join(snp_dir, "rtg", c, "%s.%s.xsnp" % (smp, SAMPLE_REF[smp]))
+                d = os.path.join(snp_dir, "qmvt_roc", c, "%s.%s.xsnp" % (smp, SAMPLE_REF[smp]))
                 os.makedirs(d, exist_ok=True)
-                write_weighted_roc(os.path.join(d, "weighted_roc.tsv.gz"), j.stats["roc"], j.stats["truth_unique"])
+                write_weighted_roc(os.path.join(d, "exact_roc.tsv.gz"), j.stats["roc"], j.stats["truth_unique"])
+        indel_roc(engine, [(c, smp, j) for (c, smp), j in zip(meta, jobs) if not j.stats.get("pure_strain")], snp_dir)
         mixed = [s for s in samples if not s.endswith(("-1-0", "-0-1"))]
         cmp_callers = [c for c in FP_COMPARED if c in callers]
         if mixed and len(cmp_callers) >= 2:                              # compareFP (counts only)
@@ -108,6 +112,43 @@ def run_hcmv_variantcall(data_dir, outpath, callers=None, engine=None, dryrun=Fa
         if own:
             engine.close()
     return jobs
+
+
+def indel_roc(engine, items, snp_dir, n_bins=256):
+    """The xindel counterpart of the exact-match ROC: the caller's *.xindel.vcf against the truth's *.xindel.vcf
+    (extract_indel / extract_nucmer_indel, rules/vis_eval_vcf.smk:40-86) in the allele-extended mode -- REF and ALT
+    matched as whole [ACGT]+ strings -- one batch for all VCFs.  Build-defined (the reference leaves indels to rtg
+    vcfeval, rule rtg_indel); rows whose alleles are not [ACGT]+ (multi-allelic, lower case) take no part."""
+    from .vcfio import AlleleDict, scan_truth, scan_vcf
+    if not items:
+        return
+    adict = AlleleDict()
+    tids, cols, keep = {}, [], []
+    try:
+        for c, smp, j in items:
+            tfile = os.path.join(snp_dir, "nucmer", "%s.maskrepeat.xindel.vcf" % smp[:2])
+            vfile = j.vcf_file[:-4] + ".xindel.vcf"
+            if not (os.path.exists(tfile) and os.path.exists(vfile)):
+                continue
+            if tfile not in tids:
+                with open(tfile, "rb") as fh:
+                    tk = scan_truth(fh.read(), alleles=adict)
+                tids[tfile] = engine.truth_load(tk.pos, tk.ref, tk.alt)
+            with open(vfile, "rb") as fh:
+                sv = scan_vcf(fh.read(), alleles=adict)
+            cols.append(sv.columns)
+            keep.append((c, smp, tids[tfile]))
+        if not cols:
+            return
+        res, _ = engine.classify_batch(cols, [k[2] for k in keep], n_bins=n_bins, alleles=True)
+        for (c, smp, tid), r in zip(keep, res):
+            d = os.path.join(snp_dir, "qmvt_roc", c, "%s.%s.xindel" % (smp, SAMPLE_REF[smp]))
+            os.makedirs(d, exist_ok=True)
+            write_weighted_roc(os.path.join(d, "exact_roc.tsv.gz"), r["roc"], r["scalars"]["truth_unique"])
+    finally:
+        for t in tids.values():
+            engine.truth_release(t)
+        adict.close()
 
 
 def run_vareval(vcfs, snps_file, outpath, labels=None, engine=None, dryrun=False):

@@ -265,6 +265,35 @@ def test_splitter_equals_awk_output(qmlib, tmp_path, g, c):
     assert n == exp.count(b"\n")
 
 
+def test_bgzf_writer(qmlib, tmp_path):
+    """the rules' second output (`bgzip -c`, rules/vis_eval_vcf.smk:36,51,67,82): BGZF members of at most 64 KiB with a
+    'BC' extra field carrying their size, the fixed EOF member last; gzip reads the concatenation"""
+    import gzip
+    import struct
+    from quasimodo_amd import vcfio
+    eof = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    rng = np.random.default_rng(1)
+    for name, data in (("empty", b""), ("small", b"##x\n#CHROM\nc\t1\t.\tA\tG\n"), ("edge", b"A" * 0xff00), ("edge1", b"C" * (0xff00 + 1)),
+                       ("noise", rng.integers(0, 256, 200000, dtype=np.uint8).tobytes()), ("text", b"chr1\t12345\t.\tA\tAC\t99\tPASS\tDP=10\n" * 20000)):
+        src = tmp_path / (name + ".vcf")
+        src.write_bytes(data)
+        gz = open(vcfio.bgzip(str(src)), "rb").read()
+        assert gzip.decompress(gz) == data and gz.endswith(eof)
+        off = total = 0
+        while off < len(gz):                                   # walk the members by their BSIZE fields
+            assert gz[off:off + 4] == b"\x1f\x8b\x08\x04" and gz[off + 10:off + 16] == b"\x06\x00BC\x02\x00"
+            bsize = struct.unpack_from("<H", gz, off + 16)[0] + 1
+            isize = struct.unpack_from("<I", gz, off + bsize - 4)[0]
+            assert isize <= 0x10000 and bsize <= 0x10000
+            total += isize
+            off += bsize
+        assert off == len(gz) and total == len(data)
+    g = os.path.join(os.path.dirname(__file__), "golden", "split", "input", "probe.vcf")
+    out = tmp_path / "p.xsnp.vcf"
+    vcfio.split_variants(g, str(out), "xsnp", bgz=True)
+    assert gzip.decompress(open(str(out) + ".gz", "rb").read()) == out.read_bytes()
+
+
 def test_splitter_posix_interval_flavour(qmlib, tmp_path):
     """`{2,}` as an interval: REF or ALT *starting* with two bases (the pattern has no `$`), '#' lines
     always, and twice when they satisfy the pattern themselves.  Hand-derived from the awk program."""

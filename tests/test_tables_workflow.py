@@ -110,16 +110,38 @@ def test_hcmv_variantcall_workflow(engine, oracle, tmp_path):
     import gzip
     e = cases["TA-1-10.AD169.lofreq.vcf"]
     _, _, exp = read_case(e)
-    rocf = results / "snp" / "rtg" / "lofreq" / "TA-1-10.AD169.xsnp" / "weighted_roc.tsv.gz"
+    assert not (results / "snp" / "rtg").exists()       # that directory belongs to the reference's rtg rules
+    rocf = results / "snp" / "qmvt_roc" / "lofreq" / "TA-1-10.AD169.xsnp" / "exact_roc.tsv.gz"
     r20 = [ln.split("\t") for ln in gzip.open(rocf, "rt").read().splitlines() if ln.startswith("20\t")][0]
     nd = lambda b: sum(1 for ln in b.split(b"\n") if ln and not ln.startswith(b"#"))
     assert int(r20[3]) == nd(exp["tp"]) and int(r20[2]) == nd(exp["fp"])
+    # the xindel sweep (allele-extended mode on the rules' own xindel files): its score-20 row against set arithmetic
+    # on the two texts -- whole-string (pos, ref, alt) keys, ID '.', QUAL >= 20
+    xrocf = results / "snp" / "qmvt_roc" / "lofreq" / "TA-1-10.AD169.xindel" / "exact_roc.tsv.gz"
+    xr = [ln.split("\t") for ln in gzip.open(xrocf, "rt").read().splitlines() if not ln.startswith("#")]
+    acgt = lambda s: len(s) > 0 and set(s) <= set(b"ACGT")
+    rowsof = lambda p: [ln.split(b"\t") for ln in open(p, "rb").read().split(b"\n") if ln and not ln.startswith(b"#")]
+    tkeys = {(f[1], f[3], f[4]) for f in rowsof(results / "snp" / "nucmer" / "TA.maskrepeat.xindel.vcf") if acgt(f[3]) and acgt(f[4])}
+    crow = [f for f in rowsof(results / "snp" / "callers" / "lofreq" / "TA-1-10.AD169.lofreq.xindel.vcf")
+            if acgt(f[3]) and acgt(f[4]) and oracle.awk_ge(f[5] if len(f) > 5 else b"", 20)]
+    tp20 = sum(1 for f in crow if (f[1], f[3], f[4]) in tkeys and f[2] == b".")
+    got20 = [r for r in xr if r[0] == "20"]
+    if crow:
+        assert got20 and int(got20[0][3]) == tp20 and int(got20[0][2]) == len(crow) - tp20
+    assert len(tkeys) > 0 and "#total baseline variants: %d" % len(tkeys) in gzip.open(xrocf, "rt").read()
     # extract_snp / extract_indel / extract_nucmer_* outputs sit where rules/vis_eval_vcf.smk:25-86 put them
     cdir = results / "snp" / "callers" / "lofreq"
     xs = (cdir / "TA-1-10.AD169.lofreq.xsnp.vcf").read_bytes().split(b"\n")
     assert all(ln.startswith(b"#") or (len(ln.split(b"\t")[3]) == 1 and len(ln.split(b"\t")[4]) == 1) for ln in xs if ln)
     assert (cdir / "TA-1-10.AD169.lofreq.xindel.vcf").exists()
     assert (results / "snp" / "nucmer" / "TA.maskrepeat.xsnp.vcf").exists() and (results / "snp" / "nucmer" / "TA.maskrepeat.xindel.vcf").exists()
+    # ... each with its bgzip (BGZF: gzip members with a 'BC' field, closed by the EOF member; zcat gives the plain file)
+    eof = bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    for plain in (cdir / "TA-1-10.AD169.lofreq.xsnp.vcf", cdir / "TA-1-10.AD169.lofreq.xindel.vcf",
+                  results / "snp" / "nucmer" / "TA.maskrepeat.xsnp.vcf", results / "snp" / "nucmer" / "TM.maskrepeat.xindel.vcf"):
+        gz = open(str(plain) + ".gz", "rb").read()
+        assert gz[:4] == b"\x1f\x8b\x08\x04" and gz[12:16] == b"BC\x02\x00" and gz.endswith(eof)
+        assert gzip.decompress(gz) == plain.read_bytes()
     # FP overlap regions against the oracle's restatement of snpcaller_fp_compare.R
     table = (results / "final_tables" / "snpcaller_fp_snp_compare.txt").read_text().splitlines()[1:]
     got = {}

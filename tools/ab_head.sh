@@ -11,5 +11,5 @@ sed -i 's|../../include/qmvt.h|../include/qmvt.h|' $D/qmvt_api.cpp $D/qmvt_host.
 (cd $D && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -o k.o qmvt_kernels.hip 2>/dev/null \
   && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -c -o a.o qmvt_api.cpp 2>/dev/null \
   && g++ -O3 -std=c++17 -fPIC -pthread -c -o h.o qmvt_host.cpp \
-  && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libqmvt.so k.o a.o h.o)
+  && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libqmvt.so k.o a.o h.o -lz)
 echo "built $D/libqmvt.so from $REV"

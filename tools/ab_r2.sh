@@ -6,7 +6,7 @@ for spec in "$@"; do
   TAG=${spec%%=*}; FLAGS=${spec#*=}
   D=$PWD/gpurun_out/ab/$TAG; mkdir -p $D
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $FLAGS -c -o $D/k.o $S/qmvt_kernels.hip 2>/dev/null || echo "build failed: $TAG"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libqmvt.so $D/k.o $S/qmvt_api.o $S/qmvt_host.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libqmvt.so $D/k.o $S/qmvt_api.o $S/qmvt_host.o -lz
 done
 for r in 1 2 3; do
   for spec in "$@"; do

@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../.."
 OUT=$(mktemp -d)
 g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-sanitize-recover=all -fno-omit-frame-pointer -pthread \
-    -o $OUT/host_asan tools/asan/host_asan_main.cpp quasimodo_amd/csrc/qmvt_host.cpp
+    -o $OUT/host_asan tools/asan/host_asan_main.cpp quasimodo_amd/csrc/qmvt_host.cpp -lz
 FILES=$(find tests/golden -type f \( -name "*.vcf" -o -name "*.snps" \) | sort)
 QM_HOST_THREADS=4 $OUT/host_asan $OUT $FILES
 rm -rf $OUT
@@ -29,6 +29,6 @@ for i in range(60000):
     L.append("chr\t%d\t.\t%s\t%s\t%d\tPASS\tDP=%d;AF=0.1\n" % (i * 7 + 1, ref, alt, random.randint(0, 300), i))
 open("$OUT/big.vcf", "w").write("##x\n#CHROM\n" + "".join(L))
 PY
-g++ -O1 -g -std=c++17 -fsanitize=thread -pthread -o $OUT/host_tsan tools/asan/host_asan_main.cpp quasimodo_amd/csrc/qmvt_host.cpp
+g++ -O1 -g -std=c++17 -fsanitize=thread -pthread -o $OUT/host_tsan tools/asan/host_asan_main.cpp quasimodo_amd/csrc/qmvt_host.cpp -lz
 QM_HOST_THREADS=8 $OUT/host_tsan $OUT $OUT/big.vcf
 rm -rf $OUT
