@@ -199,7 +199,12 @@ int qm_batch_finish(qm_batch* b, void* stream);
 int qm_batch_set_timing(qm_batch* b, int on);
 int qm_batch_timings(qm_batch* b, float* ms4);
 
+/* qm_batch_upload from page-locked host memory, asynchronous on `stream` (NULL = the context's own). */
+int qm_batch_upload_async(qm_batch* b, int vcf, const int32_t* pos, const int32_t* ref, const int32_t* alt,
+                          const float* qual, const uint8_t* flags, void* stream);
 int qm_batch_get_cls(qm_batch* b, int vcf, uint8_t* out_cls);
+/* the class masks as they sit in HBM: bit r of word r / 64 = record r; (n + 63) / 64 words per mask */
+int qm_batch_get_masks(qm_batch* b, int vcf, uint64_t* kept, uint64_t* tp);
 int qm_batch_get_idx(qm_batch* b, int vcf, int32_t* out_idx);
 int qm_batch_get_roc(qm_batch* b, uint64_t* out_roc /*[n_vcf][3][n_bins]*/);
 int qm_batch_get_scalars(qm_batch* b, int64_t* out /*[n_vcf][QM_N_SCALARS]*/);
@@ -313,6 +318,36 @@ int qm_vcf_write(const char* path, const uint8_t* text, size_t len, int64_t n_li
  * as awk prints them).  mode 0 = xsnp, 1 = xindel.  flavour 0 reads `{2,}` as a POSIX interval
  * (gawk), flavour 1 as literal text (mawk 1.3.4 20200120).  Atomic (temp file + rename). */
 int qm_vcf_split_write(const char* path, const uint8_t* text, size_t len, int mode, int flavour, int64_t* n_written);
+/* ---- files in, files out: the reference's per-VCF worker for MANY VCFs in one call ------------------------------
+ * What n_jobs invocations of `python program/extract_TP_FP_SNPs.py <vcf> <truth> {hcmv,custom} <outdir> <caller>`
+ * (extract_TP_FP_SNPs.py:124-140; rules/extract_TP.smk:20, eval_variant_custom.smk:73) do: inputs are mapped,
+ * tokenised by host threads straight into page-locked buffers and uploaded while the next file is tokenised, the
+ * host path decides what the columns cannot describe, ONE engine batch classifies every mixed-sample VCF, the class
+ * masks come back (2 bits per record) and the three files of every VCF are gathered from the mapped input with
+ * writev.  Output paths are the caller's (the reference derives them, :19-22,39-41 / :71-72,91); their directories
+ * must exist.  pure != 0: pure-strain sample (:33-36): fp is a copy of filtered, no tp file, the truth is never read.
+ * strict != 0: QM_E_NONCANON for kept lines / truth rows holding NUL or non-ASCII bytes (their reference answer depends
+ * on the locale); 0: such lines are classified by their columns.  mode: 0 or QM_BATCH_ALLELES.
+ * stats[j] / roc[j][3][n_bins] (either may be NULL): the per-VCF rows; phase_seconds[6] (may be NULL): map + count,
+ * truth sets, tokenise + host path + uploads, engine, masks back, write. */
+typedef struct qm_file_job {
+  const char* vcf_path;
+  const char* truth_path;   /* may be NULL when pure */
+  int32_t mode;             /* 0: truth VCF (hcmv), 1: show-snps table (custom) */
+  int32_t pure;
+  const char* filtered_out;
+  const char* tp_out;       /* may be NULL when pure */
+  const char* fp_out;
+} qm_file_job;
+typedef struct qm_file_stats {
+  int64_t scalars[QM_N_SCALARS];   /* QM_S_*; TP_R / FP_R with the text keys of QM_F_NOKEY lines exchanged in */
+  int64_t n_lines, n_refused, genomediff;
+  int64_t header_kept, header_kept_tp;   /* '#' lines that pass the A2 filter (awk emits them among the kept lines too) */
+  int64_t host_decided;                  /* lines decided by the host path */
+} qm_file_stats;
+int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs, int n_bins, unsigned mode, int strict,
+                     qm_file_stats* stats, uint64_t* roc, double* phase_seconds);
+
 /* `bgzip -c` (the *.vcf.gz outputs the same rules declare, rules/vis_eval_vcf.smk:29,36 ...): BGZF = gzip members of at
  * most 64 KiB with a 'BC' extra field + the EOF member; zcat and tabix / htslib read it.  level -1 = zlib's default (6,
  * bgzip's default).  Atomic. */

@@ -24,7 +24,7 @@ EXPORTS = (
     "qm_truth_size_ext", "qm_truth_synth_ext", "qm_batch_create_ext", "qm_classify_batch_ext",
     "qm_dict_create", "qm_dict_destroy", "qm_dict_size", "qm_allele_code", "qm_allele_spell", "qm_vcf_scan_ext", "qm_truth_scan_ext",
     "qm_bench_synth", "qm_truth_release", "qm_batch_n_truth",
-    "qm_bw_probe", "qm_bgzf_write", "qm_patterns_create", "qm_patterns_destroy", "qm_patterns_info", "qm_vcf_hostpath",
+    "qm_bw_probe", "qm_bgzf_write", "qm_extract_files", "qm_batch_upload_async", "qm_batch_get_masks", "qm_patterns_create", "qm_patterns_destroy", "qm_patterns_info", "qm_vcf_hostpath",
 )
 
 
@@ -43,6 +43,16 @@ class QmvtError(RuntimeError):
 class SynthCfg(C.Structure):
     _fields_ = [("genome_len", C.c_int64), ("seed", C.c_uint64), ("truth_seed", C.c_uint64), ("truth_n", C.c_int64),
                 ("shuffled", C.c_int32), ("indel_pct", C.c_int32)]
+
+
+class FileJob(C.Structure):
+    _fields_ = [("vcf_path", C.c_char_p), ("truth_path", C.c_char_p), ("mode", C.c_int32), ("pure", C.c_int32),
+                ("filtered_out", C.c_char_p), ("tp_out", C.c_char_p), ("fp_out", C.c_char_p)]
+
+
+class FileStats(C.Structure):
+    _fields_ = [("scalars", C.c_int64 * QM_N_SCALARS), ("n_lines", C.c_int64), ("n_refused", C.c_int64), ("genomediff", C.c_int64),
+                ("header_kept", C.c_int64), ("header_kept_tp", C.c_int64), ("host_decided", C.c_int64)]
 
 
 class VcfCols(C.Structure):
@@ -131,6 +141,9 @@ def lib():
     L.qm_allele_code.restype = i32
     L.qm_allele_spell.argtypes = [vp, i32, C.c_char_p, C.c_size_t]
     L.qm_allele_spell.restype = i64
+    L.qm_extract_files.argtypes = [vp, i32, C.POINTER(FileJob), i32, C.c_uint, i32, C.POINTER(FileStats), vp, C.POINTER(C.c_double)]
+    L.qm_batch_upload_async.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
+    L.qm_batch_get_masks.argtypes = [vp, i32, vp, vp]
     L.qm_bgzf_write.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, i32]
     L.qm_bw_probe.argtypes = [vp, i64, i32, C.POINTER(C.c_double)]
     L.qm_patterns_create.argtypes = [C.c_char_p, C.c_size_t, i32, i32]

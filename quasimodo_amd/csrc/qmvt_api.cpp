@@ -32,6 +32,8 @@ static int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+void qm_set_error(const char* msg) { g_err = msg ? msg : ""; }   // for the other translation units of the library
+
 #define HIPCHK(expr)                                                                          \
   do {                                                                                        \
     hipError_t e_ = (expr);                                                                   \
@@ -532,6 +534,26 @@ extern "C" int qm_batch_upload(qm_batch* b, int v, const int32_t* pos, const int
   return QM_OK;
 }
 
+// The same from page-locked host memory (hipHostMalloc / hipHostRegister), asynchronous on `stream` (NULL = the
+// context's own stream): the copies of one VCF overlap the tokenising of the next.
+extern "C" int qm_batch_upload_async(qm_batch* b, int v, const int32_t* pos, const int32_t* ref, const int32_t* alt, const float* qual,
+                                     const uint8_t* flags, void* stream) {
+  if (!b || v < 0 || v >= b->n_vcf) return fail(QM_E_INVAL, "qm_batch_upload_async: bad arguments");
+  const VcfDesc& d = b->L.vcfs[(size_t)v];
+  if (d.n == 0) return QM_OK;
+  if (!pos || !ref || !alt || !qual || !flags) return fail(QM_E_INVAL, "qm_batch_upload_async: NULL column");
+  HIPCHK(hipSetDevice(b->ctx->dev));
+  hipStream_t st = stream ? (hipStream_t)stream : b->ctx->stream;
+  const size_t n = (size_t)d.n;
+  HIPCHK(hipMemcpyAsync(b->pos + d.off, pos, n * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->ref + d.off, ref, n * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->alt + d.off, alt, n * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->qual + d.off, qual, n * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->flags + d.off, flags, n, hipMemcpyHostToDevice, st));
+  b->ran = b->finished = false;
+  return QM_OK;
+}
+
 static uint64_t gcd64(uint64_t a, uint64_t b) { while (b) { uint64_t t = a % b; a = b; b = t; } return a; }
 
 extern "C" int qm_batch_synth(qm_batch* b, const qm_synth_cfg* cfg) {
@@ -895,6 +917,25 @@ extern "C" int qm_batch_get_cls(qm_batch* b, int v, uint8_t* out) {
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, b->cls_scratch, (size_t)d.n, hipMemcpyDeviceToHost, b->ctx->stream));
   HIPCHK(hipStreamSynchronize(b->ctx->stream));
+  return QM_OK;
+}
+// class masks of one VCF as they sit in HBM: bit r of word r / 64 = record r (1 bit per record and mask instead of the
+// byte per record of qm_batch_get_cls).  (n + 63) / 64 words each.
+extern "C" int qm_batch_get_masks(qm_batch* b, int v, uint64_t* kept, uint64_t* tp) {
+  NEED_FINISHED(b, "qm_batch_get_masks");
+  if (v < 0 || v >= b->n_vcf || !kept || !tp) return fail(QM_E_INVAL, "qm_batch_get_masks: bad arguments");
+  HIPCHK(hipSetDevice(b->ctx->dev));
+  const VcfDesc& d = b->L.vcfs[(size_t)v];
+  const size_t nw = (size_t)((d.n + 63) / 64);
+  if (nw) {
+    HIPCHK(hipMemcpyAsync(kept, b->mask_pass + (d.off >> 6), nw * 8, hipMemcpyDeviceToHost, b->ctx->stream));
+    HIPCHK(hipMemcpyAsync(tp, b->mask_tp + (d.off >> 6), nw * 8, hipMemcpyDeviceToHost, b->ctx->stream));
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    if (d.n & 63) {   // bits beyond the VCF's last record are not defined on the device
+      const uint64_t m = (1ull << (d.n & 63)) - 1ull;
+      kept[nw - 1] &= m; tp[nw - 1] &= m;
+    }
+  }
   return QM_OK;
 }
 extern "C" int qm_batch_get_idx(qm_batch* b, int v, int32_t* out) {

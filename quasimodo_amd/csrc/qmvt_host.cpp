@@ -334,11 +334,14 @@ static int host_threads() {
 // Two passes over whole-line chunks, each pass with one thread per chunk: count, then fill at
 // known offsets.  The only cross-chunk state, the position carried onto records without a
 // comparable POS, is patched for the (few) records that precede a chunk's first canonical POS.
-extern "C" int qm_vcf_scan_ext(const uint8_t* text, size_t len, int64_t cap_lines, int64_t* line_off, uint8_t* line_kind,
-                               int32_t* pos, int32_t* ref, int32_t* alt, float* qual, uint8_t* flags, qm_vcf_cols* info,
-                               qm_dict* dict) {
+int qm_host_threads(void) { return host_threads(); }
+
+// internal: qm_vcf_scan_ext with the number of threads given (qmvt_pipeline.cpp spreads its threads over files first)
+int qm_host_scan_threads(const uint8_t* text, size_t len, int64_t cap_lines, int64_t* line_off, uint8_t* line_kind,
+                         int32_t* pos, int32_t* ref, int32_t* alt, float* qual, uint8_t* flags, qm_vcf_cols* info,
+                         qm_dict* dict, int nt) {
   if ((!text && len) || !line_off || !line_kind || !info) return QM_E_INVAL;
-  int nt = host_threads();
+  if (nt < 1) nt = 1;
   if (len < (size_t)(1 << 20)) nt = 1;
   std::vector<ScanChunk> ch((size_t)nt);
   size_t b = 0;
@@ -382,6 +385,12 @@ extern "C" int qm_vcf_scan_ext(const uint8_t* text, size_t len, int64_t cap_line
   info->first_refused_line = first_ref;
   info->n_nokey_kept = nnokey;
   return QM_OK;
+}
+
+extern "C" int qm_vcf_scan_ext(const uint8_t* text, size_t len, int64_t cap_lines, int64_t* line_off, uint8_t* line_kind,
+                               int32_t* pos, int32_t* ref, int32_t* alt, float* qual, uint8_t* flags, qm_vcf_cols* info,
+                               qm_dict* dict) {
+  return qm_host_scan_threads(text, len, cap_lines, line_off, line_kind, pos, ref, alt, qual, flags, info, dict, host_threads());
 }
 
 extern "C" int qm_vcf_scan(const uint8_t* text, size_t len, int64_t cap_lines, int64_t* line_off, uint8_t* line_kind,
@@ -739,9 +748,11 @@ class RangeWriter {
   bool small_tail_ = false;
 };
 
-// header block, then the selected lines in input order; a missing final newline is added
+// header block, then the selected lines in input order; a missing final newline is added.
+// cls_of(r) = QM_CLS_* bits of data line r.
+template <typename ClsOf>
 int write_selected(const char* path, const uint8_t* text, size_t len, int64_t n_lines, const int64_t* line_off, const uint8_t* line_kind,
-                   const uint8_t* cls, int select) {
+                   ClsOf cls_of, int select) {
   static std::atomic<unsigned> serial{0};
   const std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid()) + "." + std::to_string(serial.fetch_add(1));
   const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
@@ -775,7 +786,7 @@ int write_selected(const char* path, const uint8_t* text, size_t len, int64_t n_
     if (k == QM_LINE_HEADER_KEPT || k == QM_LINE_HEADER_KEPT_TP) {   // awk printed it among the kept lines too
       sel = select == 0 || (select == 1) == (k == QM_LINE_HEADER_KEPT_TP);
     } else {
-      const uint8_t c = cls ? cls[r] : 0;
+      const uint8_t c = cls_of(r);
       ++r;
       sel = select == 0 ? (c & QM_CLS_KEPT) : select == 1 ? ((c & 3u) == 3u) : ((c & 3u) == 1u);
     }
@@ -794,7 +805,18 @@ int write_selected(const char* path, const uint8_t* text, size_t len, int64_t n_
 extern "C" int qm_vcf_write(const char* path, const uint8_t* text, size_t len, int64_t n_lines, const int64_t* line_off,
                             const uint8_t* line_kind, const uint8_t* cls, int select) {
   if (!path || !line_off || !line_kind || select < 0 || select > 2 || (!text && len)) return QM_E_INVAL;
-  return write_selected(path, text, len, n_lines, line_off, line_kind, cls, select);
+  return write_selected(path, text, len, n_lines, line_off, line_kind, [cls](int64_t r) -> uint8_t { return cls ? cls[r] : 0; }, select);
+}
+
+// internal (qmvt_pipeline.cpp): the same from the class masks as they come back from the device (bit r of word r / 64),
+// or, without masks (pure-strain samples never reach the device), from the A2 verdict in the flags column
+int qm_host_write_masks(const char* path, const uint8_t* text, size_t len, int64_t n_lines, const int64_t* line_off,
+                        const uint8_t* line_kind, const uint64_t* kept, const uint64_t* tp, const uint8_t* flags, int select) {
+  if (!path || !line_off || !line_kind || select < 0 || select > 2 || (!text && len)) return QM_E_INVAL;
+  if (kept && tp)
+    return write_selected(path, text, len, n_lines, line_off, line_kind, [kept, tp](int64_t r) -> uint8_t {
+      return (uint8_t)(((kept[r >> 6] >> (r & 63)) & 1u) | (((tp[r >> 6] >> (r & 63)) & 1u) << 1)); }, select);
+  return write_selected(path, text, len, n_lines, line_off, line_kind, [flags](int64_t r) -> uint8_t { return flags ? (flags[r] & QM_F_PASS) : 0; }, select);
 }
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,346 @@
+// qmvt_pipeline.cpp -- qm_extract_files: the whole per-VCF worker of the reference
+// (program/extract_TP_FP_SNPs.py:12-57 hcmv, :60-105 custom) for MANY VCFs in one call, files in, files out:
+//
+//   map the inputs  ->  tokenise (host threads, straight into page-locked column buffers)  ->  host path for the
+//   lines the columns cannot describe  ->  asynchronous upload of each VCF as soon as it is tokenised  ->  ONE
+//   engine batch (classify, finalize, compact)  ->  class masks back (2 bits per record)  ->  the three output
+//   files of every VCF, gathered from the mapped input with writev (host threads).
+//
+// Replaces, per VCF: three awk passes + grep over the input, two awk passes over the truth file, fgrep -wf and
+// fgrep -wvf (extract_TP_FP_SNPs.py:24-32,47-57), and the `>` redirections.  Nothing here classifies on the CPU:
+// without a HIP device qm_init has already failed.
+#include <hip/hip_runtime.h>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/qmvt.h"
+
+// from qmvt_host.cpp (same library, not part of the public ABI)
+int qm_host_scan_threads(const uint8_t* text, size_t len, int64_t cap_lines, int64_t* line_off, uint8_t* line_kind, int32_t* pos,
+                         int32_t* ref, int32_t* alt, float* qual, uint8_t* flags, qm_vcf_cols* info, qm_dict* dict, int nthreads);
+int qm_host_write_masks(const char* path, const uint8_t* text, size_t len, int64_t n_lines, const int64_t* line_off,
+                        const uint8_t* line_kind, const uint64_t* kept, const uint64_t* tp, const uint8_t* flags, int select);
+int qm_host_threads(void);
+void qm_set_error(const char* msg);   // qmvt_api.cpp: what qm_last_error returns
+
+namespace {
+
+double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct Mapped {
+  const uint8_t* p = nullptr;
+  size_t n = 0;
+  bool ok = false;
+  Mapped() = default;
+  Mapped(const Mapped&) = delete;
+  Mapped& operator=(const Mapped&) = delete;
+  Mapped(Mapped&& o) noexcept : p(o.p), n(o.n), ok(o.ok) { o.p = nullptr; o.n = 0; o.ok = false; }
+  void open_file(const char* path) {
+    const int fd = ::open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return;
+    struct stat st;
+    if (fstat(fd, &st) != 0) { ::close(fd); return; }
+    n = (size_t)st.st_size;
+    if (n == 0) { ok = true; ::close(fd); return; }
+    void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (m == MAP_FAILED) { n = 0; return; }
+    (void)madvise(m, n, MADV_SEQUENTIAL | MADV_WILLNEED);
+    p = (const uint8_t*)m;
+    ok = true;
+  }
+  ~Mapped() { if (p) munmap((void*)p, n); }
+};
+
+template <typename F> void parallel_for(int n, int nthreads, F f) {
+  if (n <= 0) return;
+  nthreads = std::max(1, std::min(nthreads, n));
+  if (nthreads == 1) { for (int i = 0; i < n; ++i) f(i); return; }
+  std::atomic<int> next{0};
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; ++t)
+    th.emplace_back([&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) f(i); });
+  for (auto& x : th) x.join();
+}
+
+// page-locked column buffers, kept by the process across calls (pinning memory costs more than filling it)
+struct PinnedArena {
+  uint8_t* base = nullptr;
+  size_t cap = 0;
+  bool pinned = false;
+  uint8_t* get(size_t need) {
+    if (need <= cap) return base;
+    release();
+    need = need + need / 4 + (1 << 20);
+    void* p = nullptr;
+    if (hipHostMalloc(&p, need, hipHostMallocDefault) == hipSuccess) { base = (uint8_t*)p; cap = need; pinned = true; return base; }
+    (void)hipGetLastError();
+    base = (uint8_t*)malloc(need);   // pageable: the copies still work, only slower
+    cap = base ? need : 0;
+    pinned = false;
+    return base;
+  }
+  void release() {
+    if (base) { if (pinned) (void)hipHostFree(base); else free(base); }
+    base = nullptr; cap = 0;
+  }
+  ~PinnedArena() { release(); }
+};
+// never destroyed: at process exit the HIP runtime may be gone before static destructors run
+PinnedArena& g_arena = *new PinnedArena();
+std::mutex* g_arena_mu = new std::mutex();
+
+struct JobState {
+  Mapped vcf;
+  int64_t n_lines = 0, n_data = 0;
+  std::vector<int64_t> line_off;
+  std::vector<uint8_t> line_kind;
+  int32_t *pos = nullptr, *ref = nullptr, *alt = nullptr;
+  float* qual = nullptr;
+  uint8_t* flags = nullptr;
+  uint64_t *kept = nullptr, *tp = nullptr;   // class masks, (n_data + 63) / 64 words each
+  qm_vcf_cols info{};
+  int64_t ex[5] = {0, 0, 0, 0, 0};
+  int truth = -1;      // index into the call's distinct truth files
+  int batch_v = -1;    // VCF index inside the engine batch (mixed samples only)
+  int rc = QM_OK;
+};
+
+struct TruthState {
+  std::string path;
+  int mode = 0;
+  Mapped file;
+  qm_patterns* pats = nullptr;
+  int64_t info[4] = {0, 0, 0, 0}, counts[5] = {0, 0, 0, 0, 0};
+  int tid = -1;
+  int rc = QM_OK;
+};
+
+int fail(int code, const std::string& msg) { qm_set_error(msg.c_str()); return code; }
+
+}  // namespace
+
+extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs, int n_bins, unsigned mode, int strict,
+                                qm_file_stats* stats, uint64_t* roc_out, double* phase_seconds) {
+  if (!ctx || n_jobs < 0 || (n_jobs && !jobs) || n_bins < 1 || n_bins > QM_MAX_BINS || (mode & ~(unsigned)QM_BATCH_ALLELES))
+    return fail(QM_E_INVAL, "qm_extract_files: bad arguments");
+  const bool ext = (mode & QM_BATCH_ALLELES) != 0;
+  double ph[6] = {0, 0, 0, 0, 0, 0};   // map + count, truth sets, tokenise + host path (+ uploads beside it), engine, masks back, write
+  const int nthr = qm_host_threads();
+  std::vector<JobState> J((size_t)n_jobs);
+  for (int j = 0; j < n_jobs; ++j) {
+    const qm_file_job& q = jobs[j];
+    if (!q.vcf_path || !q.filtered_out || !q.fp_out || (!q.pure && (!q.truth_path || !q.tp_out)) || (q.mode != 0 && q.mode != 1))
+      return fail(QM_E_INVAL, "qm_extract_files: job " + std::to_string(j) + " is incomplete");
+    if (ext && !q.pure && q.mode != 0) return fail(QM_E_INVAL, "qm_extract_files: the allele-extended mode needs VCF truth sets (mode 0)");
+  }
+  qm_dict* dict = ext ? qm_dict_create() : nullptr;
+  std::vector<TruthState> T;
+  qm_batch* batch = nullptr;
+  auto cleanup = [&]() {
+    if (batch) qm_batch_destroy(batch);
+    for (auto& t : T) { if (t.pats) qm_patterns_destroy(t.pats); if (t.tid >= 0) (void)qm_truth_release(ctx, t.tid); }
+    if (dict) qm_dict_destroy(dict);
+  };
+
+  // ---- 1. map every VCF, count its lines / data lines (the batch layout needs the record counts) ----
+  double t0 = now();
+  parallel_for(n_jobs, nthr, [&](int j) {
+    JobState& s = J[(size_t)j];
+    s.vcf.open_file(jobs[j].vcf_path);
+    if (!s.vcf.ok) { s.rc = QM_E_IO; return; }
+    const uint8_t* p = s.vcf.p;
+    const uint8_t* end = p + s.vcf.n;
+    int64_t nl = 0, nd = 0;
+    while (p < end) {
+      nd += *p != '#';
+      ++nl;
+      const uint8_t* e = (const uint8_t*)memchr(p, '\n', (size_t)(end - p));
+      if (!e) break;
+      p = e + 1;
+    }
+    s.n_lines = nl; s.n_data = nd;
+  });
+  for (int j = 0; j < n_jobs; ++j)
+    if (J[(size_t)j].rc != QM_OK) { cleanup(); return fail(QM_E_IO, std::string("cannot read ") + jobs[j].vcf_path); }
+  ph[0] = now() - t0;
+
+  // ---- 2. the distinct truth files: keys for the device, patterns as text for the host path ----
+  t0 = now();
+  {
+    std::map<std::pair<std::string, int>, int> seen;
+    for (int j = 0; j < n_jobs; ++j) {
+      if (jobs[j].pure) continue;
+      const auto key = std::make_pair(std::string(jobs[j].truth_path), (int)jobs[j].mode);
+      auto it = seen.find(key);
+      if (it == seen.end()) { it = seen.emplace(key, (int)T.size()).first; T.emplace_back(); T.back().path = key.first; T.back().mode = key.second; }
+      J[(size_t)j].truth = it->second;
+    }
+  }
+  parallel_for((int)T.size(), nthr, [&](int k) {
+    TruthState& t = T[(size_t)k];
+    t.file.open_file(t.path.c_str());
+    if (!t.file.ok) { t.rc = QM_E_IO; return; }
+    t.pats = qm_patterns_create(t.file.p, t.file.n, t.mode, ext ? 1 : 0);
+    if (!t.pats) { t.rc = QM_E_INVAL; return; }
+    (void)qm_patterns_info(t.pats, t.info);
+  });
+  for (auto& t : T) {
+    if (t.rc != QM_OK) { const std::string p = t.path; cleanup(); return fail(t.rc, "cannot read truth file " + p); }
+    if (strict && t.info[3] > 0) {
+      const std::string msg = t.path + ": " + std::to_string(t.info[3]) + " truth rows hold NUL or non-ASCII bytes";
+      cleanup();
+      return fail(QM_E_NONCANON, msg);
+    }
+    const int64_t cap = qm_vcf_count_lines(t.file.p, t.file.n) + 1;
+    std::vector<int32_t> tp((size_t)cap), tr((size_t)cap), ta((size_t)cap);
+    const int64_t k = qm_truth_scan_ext(t.file.p, t.file.n, t.mode, cap, tp.data(), tr.data(), ta.data(), t.counts, dict);
+    int rc = k < 0 ? (int)k : qm_truth_load(ctx, tp.data(), tr.data(), ta.data(), k, &t.tid);
+    if (rc != QM_OK) { if (k < 0) qm_set_error("qm_truth_scan failed"); cleanup(); return rc; }
+  }
+  ph[1] = now() - t0;
+
+  // ---- 3. batch layout for the mixed samples; column buffers for everything ----
+  std::vector<int64_t> nrec;
+  std::vector<int32_t> tids;
+  for (int j = 0; j < n_jobs; ++j)
+    if (!jobs[j].pure) { J[(size_t)j].batch_v = (int)nrec.size(); nrec.push_back(J[(size_t)j].n_data); tids.push_back(T[(size_t)J[(size_t)j].truth].tid); }
+  if (!nrec.empty()) {
+    const int rc = qm_batch_create_ext(ctx, (int)nrec.size(), nrec.data(), tids.data(), n_bins, mode, &batch);
+    if (rc != QM_OK) { cleanup(); return rc; }
+  }
+  std::unique_lock<std::mutex> arena_lock(*g_arena_mu);   // one call at a time uses the process's page-locked arena
+  size_t need = 0;
+  std::vector<size_t> aoff((size_t)n_jobs);
+  for (int j = 0; j < n_jobs; ++j) {
+    aoff[(size_t)j] = need;
+    const size_t cap = (size_t)J[(size_t)j].n_lines + 1;
+    need += ((cap * 17 + 255) & ~(size_t)255) + ((((cap + 63) / 64) * 16 + 255) & ~(size_t)255);
+  }
+  uint8_t* arena = g_arena.get(need);
+  if (!arena) { cleanup(); return fail(QM_E_NOMEM, "qm_extract_files: no memory for the column buffers"); }
+  hipStream_t copy_stream = nullptr;
+  if (hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess) { cleanup(); return fail(QM_E_HIP, "hipStreamCreate failed"); }
+
+  // ---- 4. tokenise + host path, each VCF uploaded (asynchronously) as soon as it is ready ----
+  t0 = now();
+  const int per_file_threads = std::max(1, nthr / std::max(1, std::min(n_jobs, nthr)));
+  parallel_for(n_jobs, nthr, [&](int j) {
+    JobState& s = J[(size_t)j];
+    const size_t cap = (size_t)s.n_lines + 1;
+    uint8_t* a = arena + aoff[(size_t)j];
+    s.pos = (int32_t*)a; s.ref = s.pos + cap; s.alt = s.ref + cap; s.qual = (float*)(s.alt + cap); s.flags = (uint8_t*)(s.qual + cap);
+    s.kept = (uint64_t*)(a + ((cap * 17 + 255) & ~(size_t)255)); s.tp = s.kept + (cap + 63) / 64;
+    s.line_off.resize(cap + 1);
+    s.line_kind.resize(cap);
+    s.rc = qm_host_scan_threads(s.vcf.p, s.vcf.n, (int64_t)cap, s.line_off.data(), s.line_kind.data(), s.pos, s.ref, s.alt, s.qual, s.flags,
+                                &s.info, dict, per_file_threads);
+    if (s.rc != QM_OK || s.info.n_data != s.n_data) { if (s.rc == QM_OK) s.rc = QM_E_INVAL; return; }
+    if (jobs[j].pure) return;
+    const TruthState& t = T[(size_t)s.truth];
+    if (s.info.n_host || s.info.n_nokey_kept || t.info[1] > 0 || t.info[2] > 0)
+      s.rc = qm_vcf_hostpath(t.pats, s.vcf.p, s.vcf.n, s.info.n_lines, s.line_off.data(), s.line_kind.data(), s.pos, s.ref, s.alt, s.flags, s.ex);
+    if (s.rc == QM_OK && !(strict && s.info.n_refused))
+      s.rc = qm_batch_upload_async(batch, s.batch_v, s.pos, s.ref, s.alt, s.qual, s.flags, copy_stream);
+  });
+  int rc = QM_OK;
+  for (int j = 0; j < n_jobs && rc == QM_OK; ++j) {
+    const JobState& s = J[(size_t)j];
+    if (s.rc != QM_OK) rc = fail(s.rc, std::string("tokenising / uploading failed for ") + jobs[j].vcf_path);
+    else if (strict && s.info.n_refused)
+      rc = fail(QM_E_NONCANON, std::string(jobs[j].vcf_path) + " line " + std::to_string(s.info.first_refused_line) +
+                                   ": a kept line holds NUL or non-ASCII bytes -- the reference's answer for it depends on the locale "
+                                   "Python exports to grep; set QM_LENIENT=1 to classify it by its columns");
+  }
+  if (hipStreamSynchronize(copy_stream) != hipSuccess && rc == QM_OK) rc = fail(QM_E_HIP, "upload failed");
+  ph[2] = now() - t0;
+
+  // ---- 5. the engine: one batch for every mixed-sample VCF of the call ----
+  t0 = now();
+  std::vector<int64_t> scal;
+  std::vector<uint64_t> roc;
+  if (rc == QM_OK && batch) {
+    rc = qm_batch_run(batch, nullptr, nullptr);
+    if (rc == QM_OK) rc = qm_batch_finish(batch, nullptr);
+    scal.resize(nrec.size() * QM_N_SCALARS);
+    roc.resize(nrec.size() * 3 * (size_t)n_bins);
+    if (rc == QM_OK) rc = qm_batch_get_scalars(batch, scal.data());
+    if (rc == QM_OK) rc = qm_batch_get_roc(batch, roc.data());
+  }
+  ph[3] = now() - t0;
+  t0 = now();
+  for (int j = 0; j < n_jobs && rc == QM_OK; ++j) {
+    JobState& s = J[(size_t)j];
+    if (jobs[j].pure) continue;
+    rc = qm_batch_get_masks(batch, s.batch_v, s.kept, s.tp);
+  }
+  ph[4] = now() - t0;
+  (void)hipStreamDestroy(copy_stream);
+  if (rc != QM_OK) { cleanup(); return rc; }
+
+  // ---- 6. the output files: filtered / tp / fp of every VCF, each a task of its own ----
+  t0 = now();
+  struct WTask { int j, select; const char* path; bool pure; };
+  std::vector<WTask> W;
+  for (int j = 0; j < n_jobs; ++j) {
+    if (jobs[j].pure) { W.push_back({j, 0, jobs[j].filtered_out, true}); W.push_back({j, 0, jobs[j].fp_out, true}); }   // cp filtered fp (:33-36)
+    else { W.push_back({j, 0, jobs[j].filtered_out, false}); W.push_back({j, 1, jobs[j].tp_out, false}); W.push_back({j, 2, jobs[j].fp_out, false}); }
+  }
+  std::vector<int> wrc(W.size(), QM_OK);
+  parallel_for((int)W.size(), nthr, [&](int k) {
+    const WTask& w = W[(size_t)k];
+    const JobState& s = J[(size_t)w.j];
+    // pure-strain samples never reach the device: kept = the A2 filter's verdict, which the tokenizer left in the flags
+    wrc[(size_t)k] = qm_host_write_masks(w.path, s.vcf.p, s.vcf.n, s.info.n_lines, s.line_off.data(), s.line_kind.data(),
+                                         w.pure ? nullptr : s.kept, w.pure ? nullptr : s.tp, s.flags, w.select);
+  });
+  for (size_t k = 0; k < W.size(); ++k)
+    if (wrc[k] != QM_OK) { const std::string p = W[k].path; cleanup(); return fail(wrc[k], "cannot write " + p); }
+  ph[5] = now() - t0;
+
+  // ---- 7. per-VCF rows ----
+  for (int j = 0; j < n_jobs; ++j) {
+    const JobState& s = J[(size_t)j];
+    int64_t hk = 0, hk_tp = 0;
+    for (int64_t i = 0; i < s.info.n_lines; ++i) { hk += s.line_kind[(size_t)i] == QM_LINE_HEADER_KEPT || s.line_kind[(size_t)i] == QM_LINE_HEADER_KEPT_TP; hk_tp += s.line_kind[(size_t)i] == QM_LINE_HEADER_KEPT_TP; }
+    if (stats) {
+      qm_file_stats& o = stats[j];
+      memset(&o, 0, sizeof o);
+      o.n_lines = s.info.n_lines; o.n_refused = s.info.n_refused; o.header_kept = hk; o.header_kept_tp = hk_tp; o.host_decided = s.ex[0];
+      if (jobs[j].pure) {
+        int64_t np = 0;
+        for (int64_t r = 0; r < s.n_data; ++r) np += s.flags[r] & QM_F_PASS;
+        o.scalars[QM_S_NPASS] = np; o.scalars[QM_S_FP_LINES] = np; o.scalars[QM_S_SORTED] = 1; o.scalars[QM_S_NREC] = s.n_data;
+      } else {
+        memcpy(o.scalars, &scal[(size_t)s.batch_v * QM_N_SCALARS], sizeof o.scalars);
+        // R keys a line by the TEXT of POS / REF / ALT; for lines without a comparable key the device counted distinct
+        // (carried pos, ref, alt) instead: swap those for the text keys (qm_vcf_hostpath)
+        o.scalars[QM_S_FP_R] += s.ex[4] - s.ex[2];
+        o.scalars[QM_S_TP_R] += s.ex[3];
+        o.genomediff = T[(size_t)s.truth].counts[0];
+      }
+    }
+    if (roc_out) {
+      uint64_t* dst = roc_out + (size_t)j * 3 * (size_t)n_bins;
+      if (jobs[j].pure) memset(dst, 0, sizeof(uint64_t) * 3 * (size_t)n_bins);
+      else memcpy(dst, &roc[(size_t)s.batch_v * 3 * (size_t)n_bins], sizeof(uint64_t) * 3 * (size_t)n_bins);
+    }
+  }
+  if (phase_seconds) memcpy(phase_seconds, ph, sizeof ph);
+  cleanup();
+  return QM_OK;
+}

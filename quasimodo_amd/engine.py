@@ -135,6 +135,30 @@ class Engine:
         check(self._L.qm_bench_synth(self._h, C.byref(cfg), int(n_vcf), int(records), int(n_bins), int(steps), C.byref(r)), self._h)
         return {k: getattr(r, k) for k, _ in r._fields_ if k != "reserved"}
 
+    def extract_files(self, file_jobs, n_bins=256, alleles=False, strict=True):
+        """qm_extract_files: files in, files out, everything between in the library (host threads + ONE engine batch).
+        file_jobs: list of dicts vcf / truth / mode ("hcmv" | "custom") / pure / filtered / tp / fp.
+        Returns (list of per-VCF dicts: scalars by name + n_lines, genomediff, header_kept, host_decided, roc; phase seconds)."""
+        import os
+        n = len(file_jobs)
+        arr = (_lib.FileJob * max(n, 1))()
+        enc = lambda p: None if p is None else os.fsencode(p)
+        for k, j in enumerate(file_jobs):
+            arr[k] = _lib.FileJob(enc(j["vcf"]), enc(j.get("truth")), 1 if j.get("mode", "hcmv") == "custom" else 0, int(bool(j.get("pure"))),
+                                  enc(j["filtered"]), enc(j.get("tp")), enc(j["fp"]))
+        st = (_lib.FileStats * max(n, 1))()
+        roc = np.zeros((max(n, 1), 3, n_bins), np.uint64)
+        ph = (C.c_double * 6)()
+        check(self._L.qm_extract_files(self._h, n, arr, int(n_bins), _lib.QM_BATCH_ALLELES if alleles else 0, int(bool(strict)), st, _p(roc), ph), self._h)
+        rows = []
+        for k in range(n):
+            r = dict(zip(SCALAR_NAMES, list(st[k].scalars)))
+            r.update(n_lines=st[k].n_lines, n_refused=st[k].n_refused, genomediff=st[k].genomediff,
+                     header_kept=(st[k].header_kept, st[k].header_kept_tp), host_decided=st[k].host_decided, roc=roc[k].copy())
+            rows.append(r)
+        phases = dict(zip(("map_count", "truth", "tokenise_upload", "engine", "masks_back", "write"), list(ph)))
+        return rows, phases
+
     def bw_probe(self, nbytes=4 << 30, reps=5):
         """qm_bw_probe: GB/s this GPU streams read-only, copying (read + written) and write-only"""
         out = (C.c_double * 3)()

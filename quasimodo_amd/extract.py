@@ -13,14 +13,13 @@ Differences from the reference, all deliberate:
   * fp/ and tp/ are created when missing (the reference relies on Snakemake for fp/).
 """
 import os
-from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 
 import numpy as np
 
 from ._lib import SCALAR_NAMES, QmvtError
 from .engine import Engine
-from .vcfio import AlleleDict, Patterns, scan_truth, scan_vcf
+from .vcfio import scan_vcf
 
 
 def is_pure_strain(vcf_file):
@@ -90,112 +89,61 @@ def extract_many(jobs, engine=None, strict=None, n_bins=256, alleles=None, gpus=
         return extract_many_sharded(jobs, int(gpus), n_bins=n_bins, alleles=alleles, strict=strict)[0]
     if alleles and any(j.mode != "hcmv" for j in jobs):
         raise ValueError("the allele-extended mode needs VCF truth sets (hcmv mode)")
-    adict = AlleleDict() if alleles else None
     own = engine is None
-    scanned, mixed = [], []
     for job in jobs:
         _paths(job)
-
-    def _scan(job):
-        with open(job.vcf_file, "rb") as fh:
-            return scan_vcf(fh.read(), alleles=adict)
-
-    # files are read, tokenized and (below) written by a small pool: the library drops the GIL, and
-    # one VCF's scan is itself multi-threaded only when the file is large
-    pool = ThreadPoolExecutor(max(1, min(len(jobs), _io_threads())))
+    if not jobs:
+        return jobs
+    pure = [is_pure_strain(j.vcf_file) for j in jobs]
+    if engine is None:
+        # a context is needed even for a batch of pure-strain samples only when something is to be classified
+        engine = Engine(int(os.environ.get("QM_DEVICE", "0"))) if not all(pure) else None
     try:
-        all_scanned = list(pool.map(_scan, jobs))
-    except BaseException:
-        pool.shutdown()
-        raise
-    for j, job in enumerate(jobs):
-        sv = all_scanned[j]
-        if sv.n_refused and strict:
-            pool.shutdown()
-            raise QmvtError(-8, "%s line %d: a kept line holds NUL or non-ASCII bytes -- the reference's answer for it depends on "
-                                "the locale Python exports to grep; set QM_LENIENT=1 to classify it by its columns"
-                            % (job.vcf_file, sv.first_refused_line))
-        scanned.append(sv)
-        if not is_pure_strain(job.vcf_file):
-            mixed.append(j)
-    results, r_exchange = {}, {}
-    if mixed:
+        for job, p in zip(jobs, pure):
+            os.makedirs(os.path.dirname(job.fp_out) or ".", exist_ok=True)
+            os.makedirs(os.path.dirname(job.filtered_out) or ".", exist_ok=True)
+            if not p:
+                os.makedirs(os.path.dirname(job.tp_out) or ".", exist_ok=True)
+        fj = [dict(vcf=j.vcf_file, truth=None if p else j.snp_file, mode=j.mode, pure=p, filtered=j.filtered_out,
+                   tp=None if p else j.tp_out, fp=j.fp_out) for j, p in zip(jobs, pure)]
         if engine is None:
-            engine = Engine(int(os.environ.get("QM_DEVICE", "0")))
-        truth_ids, patterns = {}, {}
-        try:
-            truth_info = {}
-            for j in mixed:
-                key = (os.path.abspath(jobs[j].snp_file), jobs[j].mode)
-                if key not in truth_ids:
-                    with open(jobs[j].snp_file, "rb") as fh:
-                        ttext = fh.read()
-                    tk = scan_truth(ttext, custom=jobs[j].mode == "custom", alleles=adict)
-                    if tk.n_refused and strict:
-                        raise QmvtError(-8, "%s: %d truth rows hold NUL or non-ASCII bytes" % (jobs[j].snp_file, tk.n_refused))
-                    truth_ids[key] = engine.truth_load(tk.pos, tk.ref, tk.alt)
-                    truth_info[key] = tk
-                    patterns[key] = Patterns(ttext, custom=jobs[j].mode == "custom", alleles=alleles)
-            # lines whose fgrep answer the columns cannot give are decided on the host, from the text of
-            # the patterns, BEFORE the upload: the decision travels in the flags column and the device counts and
-            # lists these lines like all others
-            def _host(j):
-                key = (os.path.abspath(jobs[j].snp_file), jobs[j].mode)
-                pt = patterns[key]
-                if scanned[j].n_host or scanned[j].n_nokey_kept or pt.needs_full_hostpath:
-                    return scanned[j].hostpath(pt)
-                return None
-            for j, ex in zip(mixed, pool.map(_host, mixed)):
-                if ex is not None:
-                    r_exchange[j] = ex
-            cols = [scanned[j].columns for j in mixed]
-            tids = [truth_ids[(os.path.abspath(jobs[j].snp_file), jobs[j].mode)] for j in mixed]
-            res, _ = engine.classify_batch(cols, tids, n_bins=n_bins, alleles=alleles)
-            for j, r in zip(mixed, res):
-                r["genomediff"] = truth_info[(os.path.abspath(jobs[j].snp_file), jobs[j].mode)].genomediff
-                ex = r_exchange.get(j)
-                if ex is not None:
-                    # R keys a line by the TEXT of POS / REF / ALT; for lines without a comparable key the device
-                    # counted distinct (carried pos, ref, alt) instead: swap those for the text keys
-                    r["scalars"]["FP_R"] += ex["fp_r"] - ex["device_nokey_keys"]
-                    r["scalars"]["TP_R"] += ex["tp_r"]
-                results[j] = r
-        except BaseException:
-            pool.shutdown()
-            raise
-        finally:
-            for pt in patterns.values():
-                pt.close()
-            if own:
-                engine.close()
-            else:
-                for tid in truth_ids.values():   # a shared engine does not keep this call's truth sets
-                    engine.truth_release(tid)
-    writes = []
-    for j, job in enumerate(jobs):
-        sv = scanned[j]
-        os.makedirs(os.path.dirname(job.fp_out) or ".", exist_ok=True)
-        if j in results:
-            r = results[j]
-            cls = r["cls"]
-            os.makedirs(os.path.dirname(job.tp_out) or ".", exist_ok=True)
-            writes += [pool.submit(sv.write, job.filtered_out, cls, 0), pool.submit(sv.write, job.tp_out, cls, 1),
-                       pool.submit(sv.write, job.fp_out, cls, 2)]
-            job.stats = dict(r["scalars"])
-            job.stats.update(pure_strain=False, genomediff=r["genomediff"], roc=r["roc"], header_kept=sv.header_kept)
-        else:  # pure strain: fp is a copy of filtered, truth never read (:33-36)
-            cls = (sv.flags & 1).astype(np.uint8)
-            writes += [pool.submit(sv.write, job.filtered_out, cls, 0), pool.submit(sv.write, job.fp_out, cls, 0)]
-            job.tp_out = ""
-            npass = int(cls.sum())
-            job.stats = dict(zip(SCALAR_NAMES, (npass, 0, npass, 0, 0, 1, sv.n_records, 0)))
-            job.stats.update(pure_strain=True, genomediff=0, roc=None, header_kept=sv.header_kept)
-    try:
-        for w in writes:
-            w.result()          # the first writer error surfaces here
+            rows = _pure_only(fj, strict)
+        else:
+            rows, phases = engine.extract_files(fj, n_bins=n_bins, alleles=alleles, strict=strict)
+            extract_many.last_phases = phases
     finally:
-        pool.shutdown()
+        if own and engine is not None:
+            engine.close()
+    for job, p, r in zip(jobs, pure, rows):
+        job.stats = r
+        job.stats.update(pure_strain=p)
+        if p:
+            job.tp_out = ""
+            job.stats["roc"] = None
     return jobs
+
+
+extract_many.last_phases = None
+
+
+def _pure_only(file_jobs, strict):
+    """Pure-strain samples need no device (extract_TP_FP_SNPs.py:33-36: fp is a copy of filtered): when a call holds
+    nothing else, no context is created and the host side of the library does the work."""
+    rows = []
+    for j in file_jobs:
+        with open(j["vcf"], "rb") as fh:
+            sv = scan_vcf(fh.read())
+        if sv.n_refused and strict:
+            raise QmvtError(-8, "%s line %d: a kept line holds NUL or non-ASCII bytes -- the reference's answer for it depends on the "
+                                "locale Python exports to grep; set QM_LENIENT=1 to classify it by its columns" % (j["vcf"], sv.first_refused_line))
+        cls = (sv.flags & 1).astype(np.uint8)
+        sv.write(j["filtered"], cls, 0)
+        sv.write(j["fp"], cls, 0)
+        npass = int(cls.sum())
+        r = dict(zip(SCALAR_NAMES, (npass, 0, npass, 0, 0, 1, sv.n_records, 0)))
+        r.update(n_lines=sv.n_lines, n_refused=sv.n_refused, genomediff=0, header_kept=sv.header_kept, host_decided=0, roc=None)
+        rows.append(r)
+    return rows
 
 
 def extract_tp_fp_snp(vcf_file, snp_file, engine=None, strict=None):

@@ -99,9 +99,11 @@ def test_noncanonical_lines_are_flagged(qmlib):
     assert sum(b"\t30\t.\tA\tC" in ln for ln in flagged) == 2 and any(b"\t77\t.\tG\tT\tz" in ln for ln in flagged)
 
 
+@pytest.mark.gpu
 def test_strict_mode_refuses_only_locale_dependent_lines(qmlib, tmp_path):
-    """extract_many raises before touching the GPU when a kept line holds NUL / non-ASCII bytes -- the one kind of
-    input left whose reference answer the engine does not reproduce (it depends on the locale grep runs under)."""
+    """extract_many refuses (before any kernel runs) when a kept line holds NUL / non-ASCII bytes -- the one kind of
+    input left whose reference answer the engine does not reproduce (it depends on the locale grep runs under);
+    QM_LENIENT / strict=False classifies such lines by their columns."""
     import quasimodo_amd as q
     from quasimodo_amd.extract import Job
     d = tmp_path / "q"
@@ -110,7 +112,9 @@ def test_strict_mode_refuses_only_locale_dependent_lines(qmlib, tmp_path):
     (tmp_path / "t.vcf").write_bytes(b"c\t5\t.\tA\tG\n")
     with pytest.raises(q.QmvtError) as ei:
         q.extract_many([Job(str(d / "QK-1-10.R.q.vcf"), str(tmp_path / "t.vcf"), "hcmv")], strict=True)
-    assert ei.value.code == -8
+    assert ei.value.code == -8 and "line 2" in str(ei.value)
+    job = q.extract_many([Job(str(d / "QK-1-10.R.q.vcf"), str(tmp_path / "t.vcf"), "hcmv")], strict=False)[0]
+    assert job.stats["tp_lines"] == 1 and open(job.tp_out, "rb").read().count(b"\n") == 2
 
 
 def test_non_ascii_kept_line_flagged(qmlib, oracle):

@@ -59,25 +59,39 @@ mb = len(one) / 1e6
 print("inputs: %d VCFs x %d lines (%.1f MB each) written in %.1f s; host cores %d" % (nv, N, mb, time.time() - t0, os.cpu_count()))
 
 eng = q.Engine(0)
-# ---- phases, measured one by one -------------------------------------------------------------
+# ---- the product entry point as a whole: extract_many -> qm_extract_files (everything between the files in C++) ----
+import json
+jobs = [Job(p, truth, "hcmv") for p in paths]
+best = None
+for rep in range(3):          # the first call pins the process's column arena; steady state from the second on
+    t = time.time()
+    extract_many(jobs, engine=eng)
+    dt = time.time() - t
+    ph = dict(extract_many.last_phases)
+    print("extract_many run %d: %.3f s for %d VCFs = %.3e records/s (%.0f MB/s of VCF text); phases %s"
+          % (rep, dt, nv, nv * N / dt, nv * mb / dt, json.dumps({k: round(v, 4) for k, v in ph.items()})), flush=True)
+    if best is None or dt < best[0]:
+        best = (dt, ph)
+kept = sum(j.stats["n_pass"] for j in jobs); tp = sum(j.stats["tp_lines"] for j in jobs)
+print("kept %d, TP %d, FP %d" % (kept, tp, kept - tp))
+out_bytes = sum(os.path.getsize(x) for j in jobs for x in (j.filtered_out, j.tp_out, j.fp_out))
+print(json.dumps({"vcfs": nv, "lines_per_vcf": N, "input_MB": round(nv * mb, 1), "output_MB": round(out_bytes / 1e6, 1), "host_threads": os.cpu_count(),
+                  "best_seconds": round(best[0], 4), "records_per_s": nv * N / best[0], "phases_s": {k: round(v, 4) for k, v in best[1].items()}}))
+# ---- the pieces through the Python-level API, one by one (the round-1 flow), for comparison ----
 t = time.time(); texts = [open(p, "rb").read() for p in paths]; t_read = time.time() - t
 t = time.time(); sv = [vcfio.scan_vcf(x) for x in texts]; t_scan = time.time() - t
 tk = vcfio.scan_truth(open(truth, "rb").read())
 tid = eng.truth_load(tk.pos, tk.ref, tk.alt)
 t = time.time(); res, _ = eng.classify_batch([s.columns for s in sv], [tid] * nv); t_gpu = time.time() - t
 t = time.time()
-for s, r, p in zip(sv, res, paths):
-    s.write(p + ".f", r["cls"], 0); s.write(p + ".t", r["cls"], 1); s.write(p + ".p", r["cls"], 2)
+for s_, r, p in zip(sv, res, paths):
+    s_.write(p + ".f", r["cls"], 0); s_.write(p + ".t", r["cls"], 1); s_.write(p + ".p", r["cls"], 2)
 t_write = time.time() - t
 tot = t_read + t_scan + t_gpu + t_write
-print("phases for %d VCFs: read %.2f s, tokenize %.2f s (%.0f MB/s), one-shot classify incl. H2D/D2H %.2f s (%.2e records/s), "
-      "write 3 files %.2f s; sum %.2f s = %.2e records/s" % (nv, t_read, t_scan, nv * mb / t_scan, t_gpu, nv * N / t_gpu, t_write, tot, nv * N / tot))
-kept = sum(r["scalars"]["n_pass"] for r in res); tp = sum(r["scalars"]["tp_lines"] for r in res)
-print("kept %d, TP %d, FP %d" % (kept, tp, kept - tp))
-# ---- the product entry point as a whole --------------------------------------------------------
-t = time.time()
-extract_many([Job(p, truth, "hcmv") for p in paths], engine=eng)
-dt = time.time() - t
-print("extract_many end to end: %.2f s for %d VCFs = %.2e records/s (%.0f MB/s of VCF text)" % (dt, nv, nv * N / dt, nv * mb / dt))
+print("piecewise (serial, pageable copies): read %.2f s, tokenize %.2f s (%.0f MB/s), one-shot classify incl. H2D/D2H %.2f s (%.2e records/s), "
+      "write 3 files %.2f s; sum %.2f s = %.2e records/s" % (t_read, t_scan, nv * mb / t_scan, t_gpu, nv * N / t_gpu, t_write, tot, nv * N / tot))
+for j, p in zip(jobs, paths):   # both flows write the same bytes
+    assert open(j.filtered_out, "rb").read() == open(p + ".f", "rb").read() and open(j.tp_out, "rb").read() == open(p + ".t", "rb").read()
+    break
 if len(sys.argv) <= 2:
     shutil.rmtree(work, ignore_errors=True)
