@@ -328,8 +328,9 @@ int qm_vcf_split_write(const char* path, const uint8_t* text, size_t len, int mo
  * must exist.  pure != 0: pure-strain sample (:33-36): fp is a copy of filtered, no tp file, the truth is never read.
  * strict != 0: QM_E_NONCANON for kept lines / truth rows holding NUL or non-ASCII bytes (their reference answer depends
  * on the locale); 0: such lines are classified by their columns.  mode: 0 or QM_BATCH_ALLELES.
- * stats[j] / roc[j][3][n_bins] (either may be NULL): the per-VCF rows; phase_seconds[6] (may be NULL): map + count,
- * truth sets, tokenise + host path + uploads, engine, masks back, write. */
+ * stats[j] / roc[j][3][n_bins] (either may be NULL): the per-VCF rows; phase_seconds[8] (may be NULL): map + count,
+ * truth sets (on a thread beside the former), batch layout, tokenise + host path + uploads, engine, masks back, write,
+ * release. */
 typedef struct qm_file_job {
   const char* vcf_path;
   const char* truth_path;   /* may be NULL when pure */

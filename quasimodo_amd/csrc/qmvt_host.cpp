@@ -260,7 +260,13 @@ static void scan_chunk(const uint8_t* text, ScanChunk& c, bool count_only, int64
       const int64_t gl = c.l0 + nl, gd = c.d0 + nd;
       line_off[gl] = (int64_t)off;
       auto dirty = [&]() {   // NUL / non-ASCII: the reference's answer depends on the locale its grep runs under
-        for (size_t i = 0; i < n; ++i) if (s[i] == 0 || s[i] >= 0x80) return true;
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) {   // eight bytes at a time: any high bit, or any zero byte
+          uint64_t x;
+          memcpy(&x, s + i, 8);
+          if ((x & 0x8080808080808080ull) || ((x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull)) return true;
+        }
+        for (; i < n; ++i) if (s[i] == 0 || s[i] >= 0x80) return true;
         return false;
       };
       if (header) {
@@ -340,6 +346,8 @@ int qm_host_threads(void) { return host_threads(); }
 int qm_host_scan_threads(const uint8_t* text, size_t len, int64_t cap_lines, int64_t* line_off, uint8_t* line_kind,
                          int32_t* pos, int32_t* ref, int32_t* alt, float* qual, uint8_t* flags, qm_vcf_cols* info,
                          qm_dict* dict, int nt) {
+  // nt < 0: one thread AND the caller has counted the lines itself (cap_lines is exact or larger): no counting pass
+  const bool counted = nt < 0;
   if ((!text && len) || !line_off || !line_kind || !info) return QM_E_INVAL;
   if (nt < 1) nt = 1;
   if (len < (size_t)(1 << 20)) nt = 1;
@@ -363,11 +371,14 @@ int qm_host_scan_threads(const uint8_t* text, size_t len, int64_t cap_lines, int
       th.emplace_back([&, t]() { scan_chunk(text, ch[(size_t)t], count_only, line_off, line_kind, pos, ref, alt, qual, flags, dict); });
     for (auto& x : th) x.join();
   };
-  run(true);
   int64_t nl = 0, nd = 0;
-  for (auto& c : ch) { c.l0 = nl; c.d0 = nd; nl += c.nl; nd += c.nd; }
-  if (nl > cap_lines) return QM_E_INVAL;
+  if (!counted) {
+    run(true);
+    for (auto& c : ch) { c.l0 = nl; c.d0 = nd; nl += c.nl; nd += c.nd; }
+    if (nl > cap_lines) return QM_E_INVAL;
+  }
   run(false);
+  if (counted) { nl = ch[0].nl; nd = ch[0].nd; }
   int64_t nhost = 0, nref = 0, first_ref = 0, nnokey = 0;
   int32_t carry = 0;
   for (auto& c : ch) {

@@ -139,7 +139,7 @@ extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs
   if (!ctx || n_jobs < 0 || (n_jobs && !jobs) || n_bins < 1 || n_bins > QM_MAX_BINS || (mode & ~(unsigned)QM_BATCH_ALLELES))
     return fail(QM_E_INVAL, "qm_extract_files: bad arguments");
   const bool ext = (mode & QM_BATCH_ALLELES) != 0;
-  double ph[6] = {0, 0, 0, 0, 0, 0};   // map + count, truth sets, tokenise + host path (+ uploads beside it), engine, masks back, write
+  double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // map + count, truth sets (beside the former), batch layout, tokenise + host path (+ uploads beside it), engine, masks back, write, release
   const int nthr = qm_host_threads();
   std::vector<JobState> J((size_t)n_jobs);
   for (int j = 0; j < n_jobs; ++j) {
@@ -157,7 +157,44 @@ extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs
     if (dict) qm_dict_destroy(dict);
   };
 
-  // ---- 1. map every VCF, count its lines / data lines (the batch layout needs the record counts) ----
+  // ---- 1. the distinct truth files (keys for the device, patterns as text for the host path), on a thread of their own ...
+  {
+    std::map<std::pair<std::string, int>, int> seen;
+    for (int j = 0; j < n_jobs; ++j) {
+      if (jobs[j].pure) continue;
+      const auto key = std::make_pair(std::string(jobs[j].truth_path), (int)jobs[j].mode);
+      auto it = seen.find(key);
+      if (it == seen.end()) { it = seen.emplace(key, (int)T.size()).first; T.emplace_back(); T.back().path = key.first; T.back().mode = key.second; }
+      J[(size_t)j].truth = it->second;
+    }
+  }
+  int truth_rc = QM_OK;
+  std::string truth_msg;
+  std::thread truth_thread([&]() {
+    const double tt0 = now();
+    parallel_for((int)T.size(), std::max(1, nthr / 4), [&](int k) {
+      TruthState& t = T[(size_t)k];
+      t.file.open_file(t.path.c_str());
+      if (!t.file.ok) { t.rc = QM_E_IO; return; }
+      t.pats = qm_patterns_create(t.file.p, t.file.n, t.mode, ext ? 1 : 0);
+      if (!t.pats) { t.rc = QM_E_INVAL; return; }
+      (void)qm_patterns_info(t.pats, t.info);
+    });
+    for (auto& t : T) {
+      if (truth_rc != QM_OK) break;
+      if (t.rc != QM_OK) { truth_rc = t.rc; truth_msg = "cannot read truth file " + t.path; break; }
+      if (strict && t.info[3] > 0) { truth_rc = QM_E_NONCANON; truth_msg = t.path + ": " + std::to_string(t.info[3]) + " truth rows hold NUL or non-ASCII bytes"; break; }
+      const int64_t cap = qm_vcf_count_lines(t.file.p, t.file.n) + 1;
+      std::vector<int32_t> tp((size_t)cap), tr((size_t)cap), ta((size_t)cap);
+      const int64_t k = qm_truth_scan_ext(t.file.p, t.file.n, t.mode, cap, tp.data(), tr.data(), ta.data(), t.counts, dict);
+      if (k < 0) { truth_rc = (int)k; truth_msg = "qm_truth_scan failed for " + t.path; break; }
+      const int rc = qm_truth_load(ctx, tp.data(), tr.data(), ta.data(), k, &t.tid);
+      if (rc != QM_OK) { truth_rc = rc; truth_msg = qm_last_error(ctx); break; }
+    }
+    ph[1] = now() - tt0;
+  });
+
+  // ---- 2. ... while every VCF is mapped and its lines / data lines are counted (the batch layout needs the record counts) ----
   double t0 = now();
   parallel_for(n_jobs, nthr, [&](int j) {
     JobState& s = J[(size_t)j];
@@ -175,46 +212,14 @@ extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs
     }
     s.n_lines = nl; s.n_data = nd;
   });
+  ph[0] = now() - t0;
+  truth_thread.join();
   for (int j = 0; j < n_jobs; ++j)
     if (J[(size_t)j].rc != QM_OK) { cleanup(); return fail(QM_E_IO, std::string("cannot read ") + jobs[j].vcf_path); }
-  ph[0] = now() - t0;
-
-  // ---- 2. the distinct truth files: keys for the device, patterns as text for the host path ----
-  t0 = now();
-  {
-    std::map<std::pair<std::string, int>, int> seen;
-    for (int j = 0; j < n_jobs; ++j) {
-      if (jobs[j].pure) continue;
-      const auto key = std::make_pair(std::string(jobs[j].truth_path), (int)jobs[j].mode);
-      auto it = seen.find(key);
-      if (it == seen.end()) { it = seen.emplace(key, (int)T.size()).first; T.emplace_back(); T.back().path = key.first; T.back().mode = key.second; }
-      J[(size_t)j].truth = it->second;
-    }
-  }
-  parallel_for((int)T.size(), nthr, [&](int k) {
-    TruthState& t = T[(size_t)k];
-    t.file.open_file(t.path.c_str());
-    if (!t.file.ok) { t.rc = QM_E_IO; return; }
-    t.pats = qm_patterns_create(t.file.p, t.file.n, t.mode, ext ? 1 : 0);
-    if (!t.pats) { t.rc = QM_E_INVAL; return; }
-    (void)qm_patterns_info(t.pats, t.info);
-  });
-  for (auto& t : T) {
-    if (t.rc != QM_OK) { const std::string p = t.path; cleanup(); return fail(t.rc, "cannot read truth file " + p); }
-    if (strict && t.info[3] > 0) {
-      const std::string msg = t.path + ": " + std::to_string(t.info[3]) + " truth rows hold NUL or non-ASCII bytes";
-      cleanup();
-      return fail(QM_E_NONCANON, msg);
-    }
-    const int64_t cap = qm_vcf_count_lines(t.file.p, t.file.n) + 1;
-    std::vector<int32_t> tp((size_t)cap), tr((size_t)cap), ta((size_t)cap);
-    const int64_t k = qm_truth_scan_ext(t.file.p, t.file.n, t.mode, cap, tp.data(), tr.data(), ta.data(), t.counts, dict);
-    int rc = k < 0 ? (int)k : qm_truth_load(ctx, tp.data(), tr.data(), ta.data(), k, &t.tid);
-    if (rc != QM_OK) { if (k < 0) qm_set_error("qm_truth_scan failed"); cleanup(); return rc; }
-  }
-  ph[1] = now() - t0;
+  if (truth_rc != QM_OK) { cleanup(); return fail(truth_rc, truth_msg); }
 
   // ---- 3. batch layout for the mixed samples; column buffers for everything ----
+  t0 = now();
   std::vector<int64_t> nrec;
   std::vector<int32_t> tids;
   for (int j = 0; j < n_jobs; ++j)
@@ -236,6 +241,8 @@ extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs
   hipStream_t copy_stream = nullptr;
   if (hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess) { cleanup(); return fail(QM_E_HIP, "hipStreamCreate failed"); }
 
+  ph[2] = now() - t0;
+
   // ---- 4. tokenise + host path, each VCF uploaded (asynchronously) as soon as it is ready ----
   t0 = now();
   const int per_file_threads = std::max(1, nthr / std::max(1, std::min(n_jobs, nthr)));
@@ -248,7 +255,7 @@ extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs
     s.line_off.resize(cap + 1);
     s.line_kind.resize(cap);
     s.rc = qm_host_scan_threads(s.vcf.p, s.vcf.n, (int64_t)cap, s.line_off.data(), s.line_kind.data(), s.pos, s.ref, s.alt, s.qual, s.flags,
-                                &s.info, dict, per_file_threads);
+                                &s.info, dict, per_file_threads > 1 ? per_file_threads : -1);   // -1: one thread, lines counted above
     if (s.rc != QM_OK || s.info.n_data != s.n_data) { if (s.rc == QM_OK) s.rc = QM_E_INVAL; return; }
     if (jobs[j].pure) return;
     const TruthState& t = T[(size_t)s.truth];
@@ -267,7 +274,7 @@ extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs
                                    "Python exports to grep; set QM_LENIENT=1 to classify it by its columns");
   }
   if (hipStreamSynchronize(copy_stream) != hipSuccess && rc == QM_OK) rc = fail(QM_E_HIP, "upload failed");
-  ph[2] = now() - t0;
+  ph[3] = now() - t0;
 
   // ---- 5. the engine: one batch for every mixed-sample VCF of the call ----
   t0 = now();
@@ -281,14 +288,14 @@ extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs
     if (rc == QM_OK) rc = qm_batch_get_scalars(batch, scal.data());
     if (rc == QM_OK) rc = qm_batch_get_roc(batch, roc.data());
   }
-  ph[3] = now() - t0;
+  ph[4] = now() - t0;
   t0 = now();
   for (int j = 0; j < n_jobs && rc == QM_OK; ++j) {
     JobState& s = J[(size_t)j];
     if (jobs[j].pure) continue;
     rc = qm_batch_get_masks(batch, s.batch_v, s.kept, s.tp);
   }
-  ph[4] = now() - t0;
+  ph[5] = now() - t0;
   (void)hipStreamDestroy(copy_stream);
   if (rc != QM_OK) { cleanup(); return rc; }
 
@@ -310,7 +317,7 @@ extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs
   });
   for (size_t k = 0; k < W.size(); ++k)
     if (wrc[k] != QM_OK) { const std::string p = W[k].path; cleanup(); return fail(wrc[k], "cannot write " + p); }
-  ph[5] = now() - t0;
+  ph[6] = now() - t0;
 
   // ---- 7. per-VCF rows ----
   for (int j = 0; j < n_jobs; ++j) {
@@ -340,7 +347,10 @@ extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs
       else memcpy(dst, &roc[(size_t)s.batch_v * 3 * (size_t)n_bins], sizeof(uint64_t) * 3 * (size_t)n_bins);
     }
   }
-  if (phase_seconds) memcpy(phase_seconds, ph, sizeof ph);
+  t0 = now();
   cleanup();
+  parallel_for(n_jobs, nthr, [&](int j) { JobState tmp = std::move(J[(size_t)j]); (void)tmp; });   // unmap / free in parallel
+  ph[7] = now() - t0;
+  if (phase_seconds) memcpy(phase_seconds, ph, sizeof ph);
   return QM_OK;
 }

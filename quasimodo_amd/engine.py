@@ -148,7 +148,7 @@ class Engine:
                                   enc(j["filtered"]), enc(j.get("tp")), enc(j["fp"]))
         st = (_lib.FileStats * max(n, 1))()
         roc = np.zeros((max(n, 1), 3, n_bins), np.uint64)
-        ph = (C.c_double * 6)()
+        ph = (C.c_double * 8)()
         check(self._L.qm_extract_files(self._h, n, arr, int(n_bins), _lib.QM_BATCH_ALLELES if alleles else 0, int(bool(strict)), st, _p(roc), ph), self._h)
         rows = []
         for k in range(n):
@@ -156,7 +156,7 @@ class Engine:
             r.update(n_lines=st[k].n_lines, n_refused=st[k].n_refused, genomediff=st[k].genomediff,
                      header_kept=(st[k].header_kept, st[k].header_kept_tp), host_decided=st[k].host_decided, roc=roc[k].copy())
             rows.append(r)
-        phases = dict(zip(("map_count", "truth", "tokenise_upload", "engine", "masks_back", "write"), list(ph)))
+        phases = dict(zip(("map_count", "truth_beside", "batch_layout", "tokenise_upload", "engine", "masks_back", "write", "release"), list(ph)))
         return rows, phases
 
     def bw_probe(self, nbytes=4 << 30, reps=5):
