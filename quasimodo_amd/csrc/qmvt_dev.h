@@ -46,7 +46,13 @@ __host__ __device__ inline bool allele_valid(int32_t c) {
 // low nibble of the 32-bit key: exact for single-base pairs, a hash for the others
 __host__ __device__ inline uint32_t allele_nib(int32_t r, int32_t a) {
   if ((uint32_t)(r | a) < 4u) return ((uint32_t)r << 2) | (uint32_t)a;
-  return ((((uint32_t)r * 0x9e3779b1u) ^ ((uint32_t)a * 0x85ebca6bu)) * 0xc2b2ae35u) >> 28;
+  // a 4-bit fold of the two codes: shifts and XORs only (32-bit multiplies run at a quarter of the VALU rate, and every
+  // record of an allele-extended batch pays for this line)
+  uint32_t h = (uint32_t)r ^ (((uint32_t)a << 13) | ((uint32_t)a >> 19));
+  h ^= h >> 16;
+  h ^= h >> 8;
+  h ^= h >> 4;
+  return h & 15u;
 }
 
 struct TruthDev {

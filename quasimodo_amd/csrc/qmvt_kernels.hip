@@ -247,10 +247,28 @@ __device__ __forceinline__ TruthG truth_global(const TruthDev& t) {
 }
 
 // LDS layout of the wave (dword offsets into one array, so every access is a ds_ op)
-constexpr int L_HTP = 0;                                // [257] TP histogram indexed by bin + 1; slot 0 swallows the uncounted records
-constexpr int L_HFP = 257;                              // [257] FP histogram, same indexing
-constexpr int L_HU = 514;                               // [256] distinct-truth-key histogram indexed by bin
-constexpr int L_KEYS = 772;                             // [K1_SLICE] staged truth keys of the tile
+// The three histograms of the span are u16 pairs (a span holds < 65 536 records): slot s lives in the (s & 1) half of dword s >> 1.
+// That is the layout span_hist has in memory, and 1.5 KB of LDS less per wave than a dword per slot.
+#ifndef QM_HIST_U32
+constexpr int H_PACK = 1;
+constexpr int L_HTP = 0;                                // [130] TP histogram, slot = bin + 1; slot 0 swallows the uncounted records
+constexpr int L_HFP = 130;                              // [130] FP histogram, same indexing
+constexpr int L_HU = 260;                               // [128] distinct-truth-key histogram, slot = bin
+constexpr int L_KEYS = 388;                             // [K1_SLICE] staged truth keys of the tile
+#else
+constexpr int H_PACK = 0;
+constexpr int L_HTP = 0;                                // [257] a dword per slot (A/B builds only)
+constexpr int L_HFP = 257;
+constexpr int L_HU = 514;
+constexpr int L_KEYS = 772;
+#endif
+__device__ __forceinline__ void hist_add(uint32_t* lds, int table, uint32_t slot) {
+  if (H_PACK) atomicAdd(&lds[table + (slot >> 1)], 1u << (16u * (slot & 1u)));
+  else atomicAdd(&lds[table + slot], 1u);
+}
+__device__ __forceinline__ uint32_t hist_get(const uint32_t* lds, int table, uint32_t slot) {
+  return H_PACK ? (lds[table + (slot >> 1)] >> (16u * (slot & 1u))) & 0xffffu : lds[table + slot];
+}
 constexpr int L_SMAX = L_KEYS + K1_SLICE;               // [K1_SLICE] per key: max(bin + 1) of '.'-ID matches
 constexpr int L_SRF = L_SMAX + K1_SLICE;                // [K1_SLICE / 32] per key: matched by a kept record
 constexpr int L_RKEY = (L_SRF + K1_SLICE / 32 + 3) & ~3;  // [256 + 28] record keys of the round (16-byte aligned), see rk()
@@ -452,7 +470,7 @@ __device__ __forceinline__ uint32_t flush_slice(uint32_t* lds, const Slice& S, i
   uint32_t tpr = 0;
   for (int j = lane; j < S.m; j += 64) {
     const uint32_t mx = lds[S.smax + j];
-    if (mx) atomicAdd(&lds[L_HU + mx - 1], 1u);
+    if (mx) hist_add(lds, L_HU, mx - 1u);
     tpr += (lds[S.srf + (j >> 5)] >> (j & 31)) & 1u;
   }
   return tpr;
@@ -546,7 +564,7 @@ __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, con
         A.top_tp += ntp;
         A.top_fp += (uint32_t)popc64(mtop) - ntp;
       }
-      if (!top) atomicAdd(&lds[(uint32_t)L_HTP + notp * 257u + b1], 1u);
+      if (!top) hist_add(lds, notp ? L_HFP : L_HTP, b1);
     }
     pp = p;
   }
@@ -555,7 +573,11 @@ __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, con
   if (cand && !(ablate & 8)) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if ((cand >> k) & 1u) A.fpr -= repeated_key<PACKED, EXT>(C, i0 + k, X.key[k], X.inf[k] & I_NOKEY, nb, X.r[k], X.a[k], A.bad);
+      if ((cand >> k) & 1u) {
+        // EXT: the allele codes come back from their LDS staging on this rare path instead of living in registers across the join
+        const int32_t rr = EXT ? (int32_t)lds[L_XRREF + lane * 4 + k] : 0, aa = EXT ? (int32_t)lds[L_XRALT + lane * 4 + k] : 0;
+        A.fpr -= repeated_key<PACKED, EXT>(C, i0 + k, X.key[k], X.inf[k] & I_NOKEY, nb, rr, aa, A.bad);
+      }
   }
 }
 
@@ -583,7 +605,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #define K1_WAVES_PER_EU 4
 #endif
 #ifndef K1_WAVES_EXT_MIN
-#define K1_WAVES_EXT_MIN 2
+#define K1_WAVES_EXT_MIN 5   // 96 VGPRs, no scratch: the fifth wave per SIMD is worth 7 % to the allele-extended instantiation (same-box A/B)
 #endif
 #ifndef K1_WAVES_MAX
 #define K1_WAVES_MAX 5
@@ -647,9 +669,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
 
     SegBounds NB = B;
     int nlo = 0, nhi = 0;
-    uint32_t nkeys[K1_SLICE / 64], nref[K1_SLICE / 64], nalt[K1_SLICE / 64];   // nref / nalt: EXT only
+    constexpr int NSL = (EXT ? SLICE_CAP_X : K1_SLICE) / 64;   // registers per lane that hold the next tile's slice
+    uint32_t nkeys[NSL], nref[NSL], nalt[NSL];   // nref / nalt: EXT only
 #pragma unroll
-    for (int q = 0; q < K1_SLICE / 64; ++q) { nkeys[q] = 0u; nref[q] = 0u; nalt[q] = 0u; }
+    for (int q = 0; q < NSL; ++q) { nkeys[q] = 0u; nref[q] = 0u; nalt[q] = 0u; }
     int prev_last = B.prevp;
     for (int r = 0; r < nrounds; ++r) {
       In4 X;
@@ -666,7 +689,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
         } else if (r == 2) {
           const int nm = (nhi - nlo) <= slice_cap<EXT>() ? (nhi - nlo) : 0;
 #pragma unroll
-          for (int q = 0; q < K1_SLICE / 64; ++q) {
+          for (int q = 0; q < NSL; ++q) {
             const bool in = q * 64 + lane < nm;
             nkeys[q] = in ? tr.keys[nlo + q * 64 + lane] : 0u;
             if (EXT) { nref[q] = in ? (uint32_t)tr.ref[nlo + q * 64 + lane] : 0u; nalt[q] = in ? (uint32_t)tr.alt[nlo + q * 64 + lane] : 0u; }
@@ -758,7 +781,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
     hi = nhi;
     S.m = (hi - lo) <= slice_cap<EXT>() ? (hi - lo) : 0;
 #pragma unroll
-    for (int q = 0; q < K1_SLICE / 64; ++q) {
+    for (int q = 0; q < NSL; ++q) {
       const int j = q * 64 + lane;
       if (j < S.m) {
         lds[S.keys + j] = nkeys[q]; lds[S.smax + j] = 0;
@@ -781,9 +804,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
   uint32_t* oh = P.span_hist + (size_t)span_id * SPAN_HIST_WORDS;
   for (int i = lane; i < 128; i += 64) {
     const int b0 = 2 * i, b1 = 2 * i + 1;
-    oh[i] = (lds[L_HTP + 1 + b0] + (b0 == nb - 1 ? top_tp : 0u)) | ((lds[L_HTP + 1 + b1] + (b1 == nb - 1 ? top_tp : 0u)) << 16);
-    oh[128 + i] = (lds[L_HFP + 1 + b0] + (b0 == nb - 1 ? top_fp : 0u)) | ((lds[L_HFP + 1 + b1] + (b1 == nb - 1 ? top_fp : 0u)) << 16);
-    oh[256 + i] = lds[L_HU + b0] | (lds[L_HU + b1] << 16);
+    oh[i] = (hist_get(lds, L_HTP, 1 + b0) + (b0 == nb - 1 ? top_tp : 0u)) | ((hist_get(lds, L_HTP, 1 + b1) + (b1 == nb - 1 ? top_tp : 0u)) << 16);
+    oh[128 + i] = (hist_get(lds, L_HFP, 1 + b0) + (b0 == nb - 1 ? top_fp : 0u)) | ((hist_get(lds, L_HFP, 1 + b1) + (b1 == nb - 1 ? top_fp : 0u)) << 16);
+    oh[256 + i] = hist_get(lds, L_HU, b0) | (hist_get(lds, L_HU, b1) << 16);
   }
   if (lane == 0) {
     uint32_t* sc = P.span_scal + (size_t)span_id * 8;
