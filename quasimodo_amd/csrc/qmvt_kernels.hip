@@ -134,6 +134,27 @@ __device__ __forceinline__ void pack_record(int p, int r, int a, float q, uint32
         ((live && (fl & QMF_PASS)) ? I_KEPT : 0u) | ((fl & QMF_IDDOT) ? I_IDDOT4 : 0u) | ((live && (fl & QMF_TPLINE)) ? I_TPLINE : 0u);
 }
 
+// The flag byte's part of the info word: PASS / IDDOT / NOKEY to bits 9..11, PASS, IDDOT and TPLINE again to the nibble
+// lanes of the high half, I_LIVE on top.  k_classify keeps the sixteen values in LDS (one read instead of eight VALU).
+__host__ __device__ inline uint32_t flag_info(uint32_t f) {
+  return ((f & 7u) << 9) | I_LIVE | ((f & QMF_PASS) ? I_KEPT : 0u) | ((f & QMF_IDDOT) ? I_IDDOT4 : 0u) | ((f & QMF_TPLINE) ? I_TPLINE : 0u);
+}
+
+// The same key and info as pack_record<false> for a record that is in range (out-of-range positions are collected by
+// the caller in one OR over the round), written for the VALU-bound main loop: 15 vector instructions and one LDS
+// read per record.  bin + 1 = min(floor(max(q, -1)), n_bins - 1) + 1 (NaN -> 0); flut = the flag_info table in LDS.
+__device__ __forceinline__ void pack_record_fast(int p, int r, int a, float q, uint32_t f4x4 /* flag byte index * 4 */, float nbm1f,
+                                                 const uint32_t* flut, uint32_t& key, uint32_t& inf) {
+  const uint32_t t = (uint32_t)r | (uint32_t)a;
+  const bool live = (((uint32_t)p >> 26) | t) < 4u;          // 0 <= p < 2^28 and both alleles single bases
+  const uint32_t nib = ((uint32_t)r << 2) | (uint32_t)a;
+  key = ((uint32_t)p << 4) | (live ? nib : 0u);
+  const float c = fminf(fmaxf(q, -1.0f), nbm1f);            // NaN -> -1
+  const uint32_t b1 = (uint32_t)((int)floorf(c) + 1);
+  const uint32_t g = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(flut) + f4x4);
+  inf = live ? (b1 | g) : 0u;
+}
+
 struct Cols {  // bases of one VCF: the five columns, or the packed pair
   const int32_t* pos;
   const int32_t* ref;
@@ -180,10 +201,23 @@ __device__ __forceinline__ void load_raw(const Cols& C, int idx, Raw4<true>& R) 
 struct In4 {   // the lane's 4 records of the round, packed
   uint32_t key[4], inf[4];
   int32_t r[4], a[4];   // EXT only: the allele codes behind the key's nibble
+  uint32_t posor;       // column input, !EXT: OR of the four positions (anything at or above bit 28 = out of range)
 };
 
 template <bool EXT>
-__device__ __forceinline__ void unpack_raw(const Raw4<false>& R, int nb, In4& X) {
+__device__ __forceinline__ void unpack_raw(const Raw4<false>& R, int nb, In4& X, const uint32_t* flut) {
+  X.posor = 0u;
+#ifndef QM_NO_FAST_PACK
+  if (!EXT) {
+    const float nbm1f = (float)(nb - 1);
+    pack_record_fast(R.p.x, R.r.x, R.a.x, R.q.x, (R.f << 2) & 0x3cu, nbm1f, flut, X.key[0], X.inf[0]);
+    pack_record_fast(R.p.y, R.r.y, R.a.y, R.q.y, (R.f >> 6) & 0x3cu, nbm1f, flut, X.key[1], X.inf[1]);
+    pack_record_fast(R.p.z, R.r.z, R.a.z, R.q.z, (R.f >> 14) & 0x3cu, nbm1f, flut, X.key[2], X.inf[2]);
+    pack_record_fast(R.p.w, R.r.w, R.a.w, R.q.w, (R.f >> 22) & 0x3cu, nbm1f, flut, X.key[3], X.inf[3]);
+    X.posor = (uint32_t)R.p.x | (uint32_t)R.p.y | (uint32_t)R.p.z | (uint32_t)R.p.w;
+    return;
+  }
+#endif
   pack_record<EXT>(R.p.x, R.r.x, R.a.x, R.q.x, R.f, nb, X.key[0], X.inf[0]);
   pack_record<EXT>(R.p.y, R.r.y, R.a.y, R.q.y, R.f >> 8, nb, X.key[1], X.inf[1]);
   pack_record<EXT>(R.p.z, R.r.z, R.a.z, R.q.z, R.f >> 16, nb, X.key[2], X.inf[2]);
@@ -194,7 +228,8 @@ __device__ __forceinline__ void unpack_raw(const Raw4<false>& R, int nb, In4& X)
   }
 }
 template <bool EXT>
-__device__ __forceinline__ void unpack_raw(const Raw4<true>& R, int, In4& X) {
+__device__ __forceinline__ void unpack_raw(const Raw4<true>& R, int, In4& X, const uint32_t*) {
+  X.posor = 0u;
   if (EXT) {
     X.r[0] = R.r.x; X.r[1] = R.r.y; X.r[2] = R.r.z; X.r[3] = R.r.w;
     X.a[0] = R.a.x; X.a[1] = R.a.y; X.a[2] = R.a.z; X.a[3] = R.a.w;
@@ -274,10 +309,21 @@ constexpr int L_SRF = L_SMAX + K1_SLICE;                // [K1_SLICE / 32] per k
 constexpr int L_RKEY = (L_SRF + K1_SLICE / 32 + 3) & ~3;  // [256 + 28] record keys of the round (16-byte aligned), see rk()
 constexpr int L_RINF = L_RKEY + 288;                    // [128] record infos, u16 each
 constexpr int L_HITS = L_RINF + 128;                    // [8] one bit per record of the round: matched a truth key
-constexpr int L_MASK = L_HITS + 8;                        // [2][32] the tile's kept / TP mask words, stored once per tile
-constexpr int L_TOTAL = L_MASK + 64;
+constexpr int L_FLUT = L_HITS + 8;                      // [16] flag_info of the sixteen flag nibbles
+constexpr int L_TCNT = L_FLUT + 16;                     // [2][SPAN_TILES] TP / FP line counts of the span's tiles, stored once per span
+#ifndef QM_MASK_TILES
+#define QM_MASK_TILES 8
+#endif
+#ifndef QM_MASK_TILES_X
+#define QM_MASK_TILES_X 2
+#endif
+// The kept / TP mask words wait in LDS for MASK_TILES tiles and leave as ONE 16-byte-per-lane store per mask (1 KiB
+// contiguous for 8 tiles): a 256-byte store per tile in the middle of the read stream cost 8 % of the kernel.
+template <bool EXT> __device__ __forceinline__ constexpr int mask_tiles() { return EXT ? QM_MASK_TILES_X : QM_MASK_TILES; }
+constexpr int L_MASK = (L_TCNT + 2 * SPAN_TILES + 3) & ~3;   // [2][mask_tiles][32]: kept words of the batch, then TP words (16-byte aligned)
+constexpr int L_TOTAL = L_MASK + 64 * QM_MASK_TILES;
 // allele-extended instantiation only: the allele codes behind the staged keys
-constexpr int L_XRREF = L_TOTAL;                        // [256] record REF codes of the round
+constexpr int L_XRREF = L_MASK + 64 * QM_MASK_TILES_X;  // [256] record REF codes of the round (behind the shorter mask batch of this instantiation)
 constexpr int L_XRALT = L_XRREF + 256;                  // [256] record ALT codes
 constexpr int L_TOTAL_X = L_XRALT + 256;
 // The allele-extended instantiation stages at most SLICE_CAP_X truth entries per tile and keeps their REF / ALT codes
@@ -286,7 +332,8 @@ constexpr int SLICE_CAP_X = K1_SLICE / 2;
 template <bool EXT> __device__ __forceinline__ constexpr int slice_cap() { return EXT ? SLICE_CAP_X : K1_SLICE; }
 static_assert(L_XRREF % 4 == 0, "b128 LDS stores need natural alignment");
 static_assert(L_RKEY % 4 == 0 && L_RINF % 2 == 0, "b128 / b64 LDS stores need natural alignment");
-static_assert(K1_ROUNDS == 4, "one store covers the 32 + 32 mask words of a four-round tile");
+static_assert(K1_ROUNDS == 4, "a tile is 32 + 32 mask words");
+static_assert(SPAN_TILES % QM_MASK_TILES == 0 && SPAN_TILES % QM_MASK_TILES_X == 0 && (32 * QM_MASK_TILES) % 8 == 0, "mask batches tile the span");
 static_assert(K1_ROUNDS >= 3 && K1_SLICE % 64 == 0, "the next tile's slice is fetched over rounds 0..2 of the current one");
 
 // The record keys of a round are bisected by the truth keys: probe k of every lane lands on indices that differ by
@@ -397,7 +444,20 @@ __device__ __forceinline__ void join_round(uint32_t* lds, const Slice& S, int nr
       const uint32_t kkey = lds[S.keys + j];
       const uint32_t kpos = kkey >> 4;
       const uint32_t kfloor = kkey & ~15u;   // smallest key at this position: (rk >> 4) < kpos  <=>  rk < kfloor
-      // first staged record with position >= kpos
+      // first staged record with position >= kpos: a branch-free lower bound over the 256 keys
+#if !defined(QM_NO_RKEY_PAD) && !defined(QM_NO_PADWALK)
+      // ... walked in the PADDED index space (36 dwords per block of 32 keys): three steps pick the block, five the
+      // key inside it, none of them crosses padding; three vector instructions and one LDS read per step
+      int pp = 0;
+#pragma unroll
+      for (int st = 144; st >= 36; st >>= 1)
+        if (lds[L_RKEY + pp + st - 5] < kfloor) pp += st;   // last key of the block(s) below: logical 32 b - 1 = padded 36 b - 5
+#pragma unroll
+      for (int st = 16; st > 0; st >>= 1)
+        if (lds[L_RKEY + pp + st - 1] < kfloor) pp += st;
+      int s = pp - 4 * ((pp * 1821) >> 16);   // back to the logical index: pp / 36 blocks of padding lie below (exact for pp < 288)
+      if (s < 256 && lds[L_RKEY + pp] < kfloor) s += 1;   // s == 255 still below (pp = 283: the last key)
+#else
       int s = 0;
 #pragma unroll
       for (int step = 128; step > 0; step >>= 1) {
@@ -405,6 +465,7 @@ __device__ __forceinline__ void join_round(uint32_t* lds, const Slice& S, int nr
         if (lds[rk(idx - 1)] < kfloor) s = idx;   // idx - 1 <= 254
       }
       if (s < 256 && lds[rk(s)] < kfloor) s += 1;   // s == 255 still below
+#endif
       uint32_t mx = 0, rf = 0;
       for (; s < nrec; ++s) {   // the run of records at this position
         const uint32_t rkey = lds[rk(s)];
@@ -516,7 +577,7 @@ __device__ __forceinline__ uint32_t or_reduce8(uint32_t v) {
 // prev_last = position of the record before the round (INT32_MIN at the VCF start).
 template <bool PACKED, bool EXT>
 __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, const In4& X, int rbase, int te, int prev_last, int nb,
-                                               int ablate, int mslot, Acc& A, int lane) {
+                                               int ablate, int mslot, Acc& A, int lane) {   // mslot: the round's first word inside the batch's kept half
   const uint32_t hit = (lds[L_HITS + (lane >> 3)] >> (4 * (lane & 7))) & 15u;
   uint32_t nib = 0, anyinf = 0;   // nib: kept in bits 0..3, ID-is-'.' in 4..7, host-decided TP line in 8..11 (one bit per record)
 #pragma unroll
@@ -525,7 +586,7 @@ __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, con
     anyinf |= X.inf[k];
   }
   const uint32_t pass = nib & 15u, iddot = (nib >> 4) & 15u, tpline = (nib >> 8) & 15u;
-  A.bad |= (anyinf & I_BADPOS) ? 2u : 0u;
+  A.bad |= ((anyinf & I_BADPOS) | (X.posor >> 28)) ? 2u : 0u;
   const uint32_t tpkey = (hit & iddot) | tpline;
   const uint32_t tp = pass & tpkey;
   const uint32_t fpkey = pass & ~hit;
@@ -539,7 +600,7 @@ __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, con
     const uint32_t wt = or_reduce8(tp << sh);
     if ((lane & 7) == 7) {
       lds[L_MASK + mslot + (lane >> 3)] = wp;
-      lds[L_MASK + 32 + mslot + (lane >> 3)] = wt;
+      lds[L_MASK + 32 * mask_tiles<EXT>() + mslot + (lane >> 3)] = wt;
     }
   }
   int pp = __shfl_up((int)(X.key[3] >> 4), 1);
@@ -602,7 +663,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #define K1_PREFETCH 1
 #endif
 #ifndef K1_WAVES_PER_EU
-#define K1_WAVES_PER_EU 4
+#define K1_WAVES_PER_EU 5   // the register allocator is told to stay within 96 VGPRs (5 waves per SIMD)
 #endif
 #ifndef K1_WAVES_EXT_MIN
 #define K1_WAVES_EXT_MIN 5   // 96 VGPRs, no scratch: the fifth wave per SIMD is worth 7 % to the allele-extended instantiation (same-box A/B)
@@ -634,6 +695,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
 #endif
 
   for (int i = lane; i < L_KEYS; i += 64) lds[i] = 0;   // histograms
+  if (lane < 16) lds[L_FLUT + lane] = flag_info((uint32_t)lane);
   Acc A = {0u, 0u, 0u, 0u, 0u, 0u};
   uint32_t acc_pass = 0, acc_tp = 0;  // wave-uniform
   uint32_t acc_tpr = 0;               // per lane, reduced at the end
@@ -676,7 +738,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
     int prev_last = B.prevp;
     for (int r = 0; r < nrounds; ++r) {
       In4 X;
-      unpack_raw<EXT>(N, nb, X);
+      unpack_raw<EXT>(N, nb, X, lds + L_FLUT);
       const int rbase = tb + r * 256;
       const int rend = rbase + 256 < te ? rbase + 256 : te;
       // the next tile's slice is fetched as a side chain spread over this tile's rounds, so none of
@@ -738,7 +800,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
         }
       }
       __syncthreads();
-      classify_round<PACKED, EXT>(lds, C, X, rbase, te, prev_last, nb, ablate, 8 * r, A, lane);
+      classify_round<PACKED, EXT>(lds, C, X, rbase, te, prev_last, nb, ablate, 32 * ((tile - sp.tile0) % mask_tiles<EXT>()) + 8 * r, A, lane);
       prev_last = (int)(lds[rk(255)] >> 4);
       __syncthreads();
     }
@@ -749,28 +811,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
       __syncthreads();
       acc_tpr += flush_slice(lds, S, lane);
     }
-    if (!(ablate & 4)) {   // the tile's 32 + 32 mask words leave with one store: lanes 0..31 kept, 32..63 TP
-      const int w = lane & 31;
-      if (w < 8 * nrounds) {
-        uint32_t* dst = (lane < 32 ? mpass32 : mtp32) + (tb >> 5) + w;
-        *dst = lds[L_MASK + lane];
-      }
-    }
     {
       const uint32_t tile_np = wave_sum(A.n_pass), tile_nt = wave_sum(A.n_tp);
       A.n_pass = 0; A.n_tp = 0;
-      if (lane == 0) {
-        P.tile_tp[tile] = tile_nt;
-        P.tile_fp[tile] = tile_np - tile_nt;
+      if (lane == 0) {   // the tile counts wait for the end of the span
+        lds[L_TCNT + (tile - sp.tile0)] = tile_nt;
+        lds[L_TCNT + SPAN_TILES + (tile - sp.tile0)] = tile_np - tile_nt;
       }
       acc_pass += tile_np;
       acc_tp += tile_nt;
+    }
+    const bool stop_unsorted = !PACKED && ballot64(A.bad & 1u) != 0ull;
+    if (!(ablate & 4)) {
+      // a full batch of mask words, or the span's last tiles: one 16-byte store per lane and mask (dword stores for a ragged end)
+      constexpr int MT = mask_tiles<EXT>();
+      const int tin = (tile - sp.tile0) % MT;
+      if (tin == MT - 1 || !has_next_tile || stop_unsorted) {
+        __syncthreads();
+        const int b0 = tb - tin * K1_TILE;                    // first record of the batch (VCF-relative)
+        const int nd = ((te - b0 + 255) >> 8) * 8;            // dwords of the rounds that ran (whole rounds: every VCF owns its masks up to a multiple of 256 records, and k_compact reads 64-bit words); the rest of the LDS batch is stale
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          uint32_t* dst = (half ? mtp32 : mpass32) + (b0 >> 5);
+          const int src = L_MASK + half * 32 * MT;
+          for (int w = 4 * lane; w < 32 * MT; w += 256) {
+            if (w + 3 < nd) *reinterpret_cast<uint4*>(dst + w) = *reinterpret_cast<const uint4*>(&lds[src + w]);
+            else for (int k = 0; k < 4; ++k) if (w + k < nd) dst[w + k] = lds[src + w + k];
+          }
+        }
+      }
     }
 
     if (!has_next_tile) break;
     // Out of order: the VCF will be redone through the radix sort and nothing computed here is used
     // (k_compact skips it, the sort path rewrites its masks, counts and rows) -- stop streaming it.
-    if (!PACKED && ballot64(A.bad & 1u) != 0ull) break;
+    if (stop_unsorted) break;
     // ---- stage the next tile's slice into the other LDS half ----------------------------
     // (a full tile has K1_ROUNDS >= 3 rounds, so the side chain above has run to its end)
     B = NB;
@@ -807,6 +882,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
     oh[i] = (hist_get(lds, L_HTP, 1 + b0) + (b0 == nb - 1 ? top_tp : 0u)) | ((hist_get(lds, L_HTP, 1 + b1) + (b1 == nb - 1 ? top_tp : 0u)) << 16);
     oh[128 + i] = (hist_get(lds, L_HFP, 1 + b0) + (b0 == nb - 1 ? top_fp : 0u)) | ((hist_get(lds, L_HFP, 1 + b1) + (b1 == nb - 1 ? top_fp : 0u)) << 16);
     oh[256 + i] = hist_get(lds, L_HU, b0) | (hist_get(lds, L_HU, b1) << 16);
+  }
+  {   // the span's tile counts: lanes 0..15 TP, 16..31 FP (tiles never reached on an unsorted VCF hold nothing anyone reads)
+    const int nt_span = (sp_end - (int)(sp.begin - sp.voff) + K1_TILE - 1) / K1_TILE;
+    const int t = lane & (SPAN_TILES - 1);
+    if (lane < 2 * SPAN_TILES && t < nt_span) (lane < SPAN_TILES ? P.tile_tp : P.tile_fp)[sp.tile0 + t] = lds[L_TCNT + lane];
   }
   if (lane == 0) {
     uint32_t* sc = P.span_scal + (size_t)span_id * 8;

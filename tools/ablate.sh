@@ -5,9 +5,7 @@ set -e
 D=$PWD/gpurun_out/ab/ablate; mkdir -p $D
 S=$PWD/quasimodo_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DQM_ABLATE_SUPPORT -c -o $D/k.o $S/qmvt_kernels.hip
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -c -o $D/a.o $S/qmvt_api.cpp
-g++ -O3 -std=c++17 -fPIC -pthread -c -o $D/h.o $S/qmvt_host.cpp
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libqmvt.so $D/k.o $D/a.o $D/h.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libqmvt.so $D/k.o $S/qmvt_api.o $S/qmvt_host.o $S/qmvt_pipeline.o -lz
 for ab in ${ABLATES:-0 1 2 4 3 7 15}; do
   echo -n "ablate=$ab: "; QM_LIBQMVT=$D/libqmvt.so QM_ABLATE=$ab python3 tools/run_once.py ${NV:-256} 6 2>&1 | grep -v amdgpu.ids
 done
