@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--shuffled", action="store_true", help="records permuted: every VCF takes the radix-sort path")
     ap.add_argument("--shuffled-vcfs", type=int, default=int(os.environ.get("QM_BENCH_SHUFFLED_VCFS", "128")),
                     help="also time the shuffled variant (radix-sort path) on this many VCFs at N=1, config 2; 0 disables")
-    ap.add_argument("--alleles-vcfs", type=int, default=int(os.environ.get("QM_BENCH_ALLELES_VCFS", "128")),
+    ap.add_argument("--alleles-vcfs", type=int, default=int(os.environ.get("QM_BENCH_ALLELES_VCFS", "512")),
                     help="also time the allele-extended variant (config 4's record shape) on this many VCFs at N=1, config 2; 0 disables")
     ap.add_argument("--check-vcfs", type=int, default=2, help="VCFs of this rank's batch checked against the oracle after the timed region (N > 1 and configs 3 / 4)")
     args = ap.parse_args()
