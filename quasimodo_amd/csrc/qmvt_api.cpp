@@ -361,7 +361,11 @@ struct qm_batch {
   uint64_t *mask_pass = nullptr, *mask_tp = nullptr;
   int32_t* idx = nullptr;
   uint32_t *tile_tp = nullptr, *tile_fp = nullptr, *tile_tp_off = nullptr, *tile_fp_off = nullptr;
-  uint32_t *span_hist = nullptr, *span_scal = nullptr, *vcf_flags = nullptr;
+  uint32_t *span_hist = nullptr, *span_scal = nullptr, *vcf_flags = nullptr, *vcf_posor = nullptr;
+  // bucket path of the unsorted VCFs: one "span" row per (segment, bucket), fake VCF descriptors for k_finalize
+  uint32_t *bk_hist = nullptr, *bk_scal = nullptr;
+  VcfDesc* d_bk_vcfs = nullptr;
+  int64_t cap_bk_rows = 0, cap_bk_vcfs = 0;
   uint64_t *roc = nullptr, *global_acc = nullptr;
   int64_t* scalars = nullptr;
   VcfDesc* d_vcfs = nullptr;
@@ -404,7 +408,7 @@ static void batch_free(qm_batch* b) {
   (void)hipSetDevice(b->ctx->dev);
   if (b->sub) { batch_free(b->sub); b->sub = nullptr; }
   void* ptrs[] = {b->pkey, b->pinf, b->pos, b->ref, b->alt, b->qual, b->flags, b->mask_pass, b->mask_tp, b->idx, b->tile_tp, b->tile_fp,
-                  b->tile_tp_off, b->tile_fp_off, b->span_hist, b->span_scal, b->vcf_flags, b->roc, b->global_acc,
+                  b->tile_tp_off, b->tile_fp_off, b->span_hist, b->span_scal, b->vcf_flags, b->vcf_posor, b->bk_hist, b->bk_scal, b->d_bk_vcfs, b->roc, b->global_acc,
                   b->scalars, b->d_vcfs, b->d_spans, b->d_tile_vcf, b->cls_scratch, b->sk[0], b->sk[1], b->sv[0],
                   b->sv[1], b->si[0], b->si[1], b->shist, b->sorbits, b->d_segs, b->d_tile_seg, b->d_ktile_seg, b->d_ktile_local};
   for (void* p : ptrs) (void)hipFree(p);
@@ -447,7 +451,7 @@ static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int
   else { A_(b->pos, np) A_(b->ref, np) A_(b->alt, np) A_(b->qual, np) A_(b->flags, np) }
   A_(b->mask_pass, np / 64 + 64) A_(b->mask_tp, np / 64 + 64) A_(b->idx, np)
   A_(b->tile_tp, b->cap_tiles) A_(b->tile_fp, b->cap_tiles) A_(b->tile_tp_off, b->cap_tiles) A_(b->tile_fp_off, b->cap_tiles)
-  A_(b->span_hist, b->cap_spans * SPAN_HIST_WORDS) A_(b->span_scal, b->cap_spans * 8) A_(b->vcf_flags, (size_t)n_vcf)
+  A_(b->span_hist, b->cap_spans * SPAN_HIST_WORDS) A_(b->span_scal, b->cap_spans * 8) A_(b->vcf_flags, (size_t)n_vcf) A_(b->vcf_posor, (size_t)n_vcf)
   A_(b->roc, (size_t)n_vcf * 3 * (size_t)n_bins) A_(b->global_acc, nt * 3 * (size_t)n_bins) A_(b->scalars, (size_t)n_vcf * 8)
   A_(b->d_vcfs, (size_t)n_vcf) A_(b->d_spans, b->cap_spans) A_(b->d_tile_vcf, b->cap_tiles) A_(b->cls_scratch, (size_t)L.max_n)
 #undef A_
@@ -620,7 +624,7 @@ static FinalizeParams finalize_params(qm_batch* b, uint64_t* global) {
   FinalizeParams F;
   F.vcfs = b->d_vcfs; F.truths = b->ctx->d_truths; F.span_hist = b->span_hist; F.span_scal = b->span_scal;
   F.tile_tp = b->tile_tp; F.tile_fp = b->tile_fp; F.tile_tp_off = b->tile_tp_off; F.tile_fp_off = b->tile_fp_off;
-  F.roc = b->roc; F.scalars = b->scalars; F.vcf_flags = b->vcf_flags; F.global_acc = global; F.n_bins = b->n_bins; F.ext = b->ext ? 1 : 0;
+  F.roc = b->roc; F.scalars = b->scalars; F.vcf_flags = b->vcf_flags; F.vcf_posor = b->vcf_posor; F.global_acc = global; F.n_bins = b->n_bins; F.ext = b->ext ? 1 : 0;
   F.vcf_base = 0;
   return F;
 }
@@ -737,7 +741,8 @@ static int regrow(T** p, int64_t* cap, int64_t need, int64_t* bytes) {
   return QM_OK;
 }
 
-static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global) {
+// posor[v]: OR of the positions the optimistic pass saw in VCF v (which position bits are in use)
+static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, const std::vector<uint32_t>& posor) {
   const int nseg = (int)vs.size();
   // --- scratch batch holding the sorted copies (rebuilt only when the chunk's shape changes)
   std::vector<int64_t> sig((size_t)nseg);
@@ -766,7 +771,13 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     SortSeg& g = segs[(size_t)i];
     g.src_off = d.off; g.dst_off = s->L.vcfs[(size_t)i].off; g.koff = koff; g.hoff = hoff; g.n = d.n;
     g.tile0 = (int32_t)tile_seg.size(); g.ntiles = (int32_t)((d.n + SORT_TILE - 1) / SORT_TILE);
-    g.main_vcf = vs[(size_t)i]; g.sub_vcf = i; g.main_tile0 = d.tile0; g.pad = 0;
+    g.main_vcf = vs[(size_t)i]; g.sub_vcf = i; g.main_tile0 = d.tile0;
+    {   // bucket path: the shift that makes the top eight key bits in use the bucket number (key = pos << 4 | nibble)
+      const uint32_t kor = (posor[(size_t)vs[(size_t)i]] << 4) | 15u;
+      int msb = 31;
+      while (msb > 0 && !((kor >> msb) & 1u)) --msb;
+      g.pad = std::max(4, msb - 7);
+    }
     for (int t = 0; t < g.ntiles; ++t) tile_seg.push_back(i);
     for (int t = 0; t < d.ntiles; ++t) { ktile_seg.push_back(i); ktile_local.push_back(t); }
     koff += (d.n + 63) / 64 * 64;
@@ -790,16 +801,66 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     if (rc == QM_OK) b->cap_ktiles = std::max(b->cap_ktiles, nkt);
   }
   if (rc == QM_OK && !b->sorbits) rc = dalloc(&b->sorbits, 1);
+  // The bucket path (k_classify_hash): ONE scatter pass, no sort.  For batches of the default mode whose VCFs are small enough
+  // for 256 buckets of at most HB_MAX_RECORDS records; QM_SORT_PATH=radix keeps everything on the radix sort.
+  bool try_buckets = !b->ext;
+  if (const char* e = getenv("QM_SORT_PATH")) try_buckets = try_buckets && strcmp(e, "radix") != 0;
+  for (int i = 0; i < nseg && try_buckets; ++i) try_buckets = segs[(size_t)i].n <= (int64_t)HB_BUCKETS * HB_MAX_RECORDS * 3 / 4;   // fuller than that, some bucket will overflow
+  if (rc == QM_OK && try_buckets) {
+    const int64_t rows = (int64_t)nseg * HB_BUCKETS;   // cap_bk_rows counts rows for both arrays
+    int64_t c1 = b->cap_bk_rows * SPAN_HIST_WORDS, c2 = b->cap_bk_rows * 8;
+    rc = regrow(&b->bk_hist, &c1, rows * SPAN_HIST_WORDS, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->bk_scal, &c2, rows * 8, &b->dev_bytes);
+    if (rc == QM_OK) b->cap_bk_rows = std::max(b->cap_bk_rows, rows);
+    if (rc == QM_OK) rc = regrow(&b->d_bk_vcfs, &b->cap_bk_vcfs, (int64_t)nseg, &b->dev_bytes);
+  }
   if (rc != QM_OK) return rc;
   HIPCHK(hipMemcpyAsync(b->d_segs, segs.data(), sizeof(SortSeg) * segs.size(), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->d_tile_seg, tile_seg.data(), 4 * tile_seg.size(), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->d_ktile_seg, ktile_seg.data(), 4 * ktile_seg.size(), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->d_ktile_local, ktile_local.data(), 4 * ktile_local.size(), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemsetAsync(b->sorbits, 0, 4, st));
+  SortCols src = {b->pos, b->ref, b->alt, b->qual, b->flags};
+  if (try_buckets) {
+    // --- bucket path: histogram + ONE scatter on each VCF's top eight key bits, then the hash-join per bucket
+    std::vector<VcfDesc> fake((size_t)nseg);
+    for (int i = 0; i < nseg; ++i) {
+      VcfDesc& f = fake[(size_t)i];
+      f = VcfDesc();
+      f.off = 0; f.n = segs[(size_t)i].n; f.truth = tids[(size_t)i]; f.tile0 = 0; f.ntiles = 0; f.span0 = i * HB_BUCKETS; f.nspans = HB_BUCKETS; f.pad = 0;
+    }
+    HIPCHK(hipMemcpyAsync(b->d_bk_vcfs, fake.data(), sizeof(VcfDesc) * fake.size(), hipMemcpyHostToDevice, st));
+    launch_sort_first_hist(b->d_segs, b->d_tile_seg, nst, b->pos, b->shist, b->sorbits, st, 1);
+    launch_sort_first_scatter(b->d_segs, b->d_tile_seg, nseg, nst, src, b->n_bins, 0, b->shist, s->pkey, s->pinf, b->sv[0], 1, b->mask_pass, b->mask_tp, st, 1);
+    HashParams H;
+    H.segs = b->d_segs; H.keys = s->pkey; H.infs = s->pinf; H.perm = b->sv[0]; H.hist = b->shist; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
+    H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_bins = b->n_bins;
+    launch_classify_hash(H, nseg, st);
+    FinalizeParams F = finalize_params(s, nullptr);   // the rows join the per-truth sums only once no bucket is known to have overflowed
+    F.vcfs = b->d_bk_vcfs; F.span_hist = b->bk_hist; F.span_scal = b->bk_scal; F.vcf_posor = nullptr;
+    launch_finalize(F, nseg, st);
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> hfl((size_t)nseg);
+    HIPCHK(hipMemcpyAsync(hfl.data(), s->vcf_flags, 4 * hfl.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));   // also makes the host tables above safe to free
+    bool overflow = false;
+    for (int i = 0; i < nseg; ++i) {
+      if (hfl[(size_t)i] & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", vs[(size_t)i]);
+      overflow = overflow || (hfl[(size_t)i] & SPANF_OVERFLOW);
+    }
+    if (!overflow) {
+      launch_sort_copy_rows(b->d_segs, nseg, s->roc, s->scalars, b->roc, b->scalars, b->n_bins, st, global, b->d_vcfs);
+      launch_tile_counts(b->d_segs, b->d_ktile_seg, b->d_ktile_local, nkt, b->mask_pass, b->mask_tp, b->tile_tp, b->tile_fp, st);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(st));
+      return QM_OK;
+    }
+    // a bucket did not fit its tables (dense positions, a dense truth set): the radix sort redoes the chunk from the columns
+    HIPCHK(hipMemcpyAsync(b->d_segs, segs.data(), sizeof(SortSeg) * segs.size(), hipMemcpyHostToDevice, st));
+  }
   // --- 1. + 2. stable LSD radix sort by position (key bits 4..31), only the digits in use.  The first pass packs the
   //        records to (key, info, original index) on the fly; the last pass drops keys and infos straight into the
   //        scratch batch.
-  SortCols src = {b->pos, b->ref, b->alt, b->qual, b->flags};
   launch_sort_first_hist(b->d_segs, b->d_tile_seg, nst, b->pos, b->shist, b->sorbits, st);
   uint32_t orbits = 0;
   HIPCHK(hipMemcpyAsync(&orbits, b->sorbits, 4, hipMemcpyDeviceToHost, st));
@@ -852,7 +913,7 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   HIPCHK(hipStreamSynchronize(st));
   if (b->finished) return QM_OK;
-  std::vector<uint32_t> fl((size_t)b->n_vcf);
+  std::vector<uint32_t> fl((size_t)b->n_vcf), posor((size_t)b->n_vcf);
   HIPCHK(hipMemcpy(fl.data(), b->vcf_flags, 4 * fl.size(), hipMemcpyDeviceToHost));
   std::vector<int> todo;
   for (int v = 0; v < b->n_vcf; ++v) {
@@ -862,12 +923,13 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
     if (fl[(size_t)v] & SPANF_UNSORTED) todo.push_back(v);
   }
   if (!todo.empty()) {
+    HIPCHK(hipMemcpy(posor.data(), b->vcf_posor, 4 * posor.size(), hipMemcpyDeviceToHost));
     std::vector<int> chunk;
     int64_t chunk_n = 0;
     for (size_t i = 0; i <= todo.size(); ++i) {
       const bool flush = i == todo.size() || (!chunk.empty() && chunk_n + b->L.vcfs[(size_t)todo[i]].n > SORT_CHUNK_RECORDS);
       if (flush && !chunk.empty()) {
-        int rc = sort_chunk(b, chunk, st, b->last_global);
+        int rc = sort_chunk(b, chunk, st, b->last_global, posor);
         if (rc != QM_OK) return rc;
         chunk.clear();
         chunk_n = 0;
@@ -891,7 +953,7 @@ static int rescan_and_compact(qm_batch* b, hipStream_t st) {
   DALLOC(tmp_scal, (size_t)b->n_vcf * 8);
   DALLOC(tmp_flags, (size_t)b->n_vcf);
   FinalizeParams F = finalize_params(b, nullptr);
-  F.roc = tmp_roc; F.scalars = tmp_scal; F.vcf_flags = tmp_flags;
+  F.roc = tmp_roc; F.scalars = tmp_scal; F.vcf_flags = tmp_flags; F.vcf_posor = nullptr;
   launch_finalize(F, b->n_vcf, st);
   CompactParams CP = compact_params(b);
   CP.skip_unsorted = 0;   // the flags still say 'unsorted' for the VCFs just redone: compact them too

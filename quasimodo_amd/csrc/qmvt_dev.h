@@ -34,7 +34,8 @@ constexpr uint32_t QMF_NOKEY = 4u;
 constexpr uint32_t QMF_TPLINE = 8u;   // decided on the host: a TP line whatever the key says (include/qmvt.h)
 constexpr uint32_t SPANF_UNSORTED = 1u;
 constexpr uint32_t SPANF_BADPOS = 2u;
-constexpr uint32_t SPANF_RUNLIMIT = 4u;   // allele-extended batch: more records at one position than the dedupe walk allows
+constexpr uint32_t SPANF_RUNLIMIT = 4u;
+constexpr uint32_t SPANF_OVERFLOW = 8u;   // bucket path: a bucket does not fit its LDS tables (the VCF is redone by the radix sort)   // allele-extended batch: more records at one position than the dedupe walk allows
 
 // ---- allele codes (include/qmvt.h): 0..3 single base, >= QM_ALLELE_EXT_MIN and non-negative = an
 // inline-packed (2..13 bases) or dictionary-interned longer allele; everything else takes no part.
@@ -126,6 +127,7 @@ struct FinalizeParams {
   uint64_t* roc;      // [n_vcf][3][n_bins]
   int64_t* scalars;   // [n_vcf][8]
   uint32_t* vcf_flags;
+  uint32_t* vcf_posor;   // or null: OR of the positions the optimistic pass saw in each VCF (which position bits are in use)
   uint64_t* global_acc;  // [n_truth][3][n_bins] or null
   int32_t n_bins;
   int32_t ext;           // allele-extended batch: T' is the size of the extended truth table
@@ -156,6 +158,24 @@ struct SortSeg {
   int32_t tile0, ntiles;     // sort tiles (SORT_TILE records), numbered over the chunk
   int32_t main_vcf, sub_vcf;
   int32_t main_tile0, pad;   // first K1 tile of the VCF in the main batch
+};
+// bucket path (k_classify_hash): one workgroup per (segment, bucket of the one scatter pass)
+constexpr int HB_BUCKETS = 256;
+constexpr int HB_MAX_RECORDS = 8188;     // records per bucket (16 per thread of the bucket's workgroup, kept in registers between its two passes)
+constexpr int HB_TRUTH_SLOTS = 2048;     // truth keys of the bucket's positions (<= 50 % full)
+constexpr int HB_NOKEY_SLOTS = 512;      // kept records without a comparable key
+struct HashParams {
+  const SortSeg* segs;
+  const uint32_t* keys;       // bucketed (key, info) pairs at SortSeg.dst_off, original index at SortSeg.koff
+  const uint32_t* infs;
+  const uint32_t* perm;
+  const uint32_t* hist;       // scanned [256][ntiles] tables of the scatter pass: the bucket boundaries
+  const TruthDev* truths;
+  const VcfDesc* vcfs;        // main batch (truth set of a segment's VCF)
+  uint64_t* mask_tp;          // main batch: TP bits in input order (cleared by the scatter pass)
+  uint32_t* row_hist;         // [n_seg * 256][SPAN_HIST_WORDS]
+  uint32_t* row_scal;         // [n_seg * 256][8]
+  int32_t n_bins;
 };
 struct SortCols { const int32_t* pos; const int32_t* ref; const int32_t* alt; const float* qual; const uint8_t* flags; };
 
@@ -254,11 +274,12 @@ void launch_finalize(const FinalizeParams& P, int n_vcf, hipStream_t st);
 void launch_compact(const CompactParams& P, int n_spans, hipStream_t st);
 void launch_masks_to_cls(const uint64_t* mp, const uint64_t* mt, int64_t off, int64_t n, uint8_t* cls, hipStream_t st);
 void launch_synth(const SynthParams& S, int n_vcf, int64_t max_n, hipStream_t st);
+void launch_classify_hash(const HashParams& P, int nseg, hipStream_t st);
 void launch_sort_first_hist(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const int32_t* pos_col, uint32_t* hist, uint32_t* orbits,
-                            hipStream_t st);
+                            hipStream_t st, int msd = 0);
 void launch_sort_first_scatter(const SortSeg* segs, const int32_t* tile_seg, int nseg, int ntiles, const SortCols& src, int n_bins, int ext,
                                uint32_t* hist, uint32_t* okeys, uint32_t* oinfs, uint32_t* ovals, int final_dst, uint64_t* mask_pass,
-                               uint64_t* mask_tp, hipStream_t st);
+                               uint64_t* mask_tp, hipStream_t st, int msd = 0);
 void launch_sort_gather_alleles(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const uint32_t* perm, const int32_t* src_ref,
                                 const int32_t* src_alt, int32_t* dst_ref, int32_t* dst_alt, hipStream_t st);
 void launch_sort_pass(const SortSeg* segs, const int32_t* tile_seg, int nseg, int ntiles, const uint32_t* keys, const uint32_t* infs,
@@ -269,7 +290,7 @@ void launch_sort_scatter_tp(const SortSeg* segs, const int32_t* tile_seg, int nt
 void launch_tile_counts(const SortSeg* segs, const int32_t* ktile_seg, const int32_t* ktile_local, int nktiles, const uint64_t* mp,
                         const uint64_t* mt, uint32_t* tile_tp, uint32_t* tile_fp, hipStream_t st);
 void launch_sort_copy_rows(const SortSeg* segs, int nseg, const uint64_t* sub_roc, const int64_t* sub_scal, uint64_t* roc,
-                           int64_t* scal, int n_bins, hipStream_t st);
+                           int64_t* scal, int n_bins, hipStream_t st, uint64_t* global_add = nullptr, const VcfDesc* vcfs = nullptr);
 void launch_bw_probe(int mode, const uint8_t* src, uint8_t* dst, int64_t bytes, uint32_t* sink, hipStream_t st);
 void launch_overlap_pack(const int32_t* pos, const int32_t* ref, const int32_t* alt, const int32_t* set_of, int64_t n,
                          uint32_t* keys, uint32_t* vals, uint32_t* bad, hipStream_t st);

@@ -563,6 +563,7 @@ struct Acc {
   uint32_t fpr;              // per lane: distinct kept keys outside the truth set
   uint32_t n_pass, n_tp;     // per lane: kept / TP lines of the current tile
   uint32_t top_tp, top_fp;   // wave-uniform: records of the saturated top bin (TP, FP)
+  uint32_t posor;            // per lane: OR of the positions seen (column input): tells the sort path which position bits are in use
 };
 
 // inclusive OR over each group of 8 lanes, valid in lanes 8g+7 (DPP row_shr 1,2,4; rows are 16 lanes)
@@ -587,6 +588,7 @@ __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, con
   }
   const uint32_t pass = nib & 15u, iddot = (nib >> 4) & 15u, tpline = (nib >> 8) & 15u;
   A.bad |= ((anyinf & I_BADPOS) | (X.posor >> 28)) ? 2u : 0u;
+  A.posor |= X.posor;
   const uint32_t tpkey = (hit & iddot) | tpline;
   const uint32_t tp = pass & tpkey;
   const uint32_t fpkey = pass & ~hit;
@@ -696,7 +698,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
 
   for (int i = lane; i < L_KEYS; i += 64) lds[i] = 0;   // histograms
   if (lane < 16) lds[L_FLUT + lane] = flag_info((uint32_t)lane);
-  Acc A = {0u, 0u, 0u, 0u, 0u, 0u};
+  Acc A = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
   uint32_t acc_pass = 0, acc_tp = 0;  // wave-uniform
   uint32_t acc_tpr = 0;               // per lane, reduced at the end
 
@@ -892,7 +894,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
     uint32_t* sc = P.span_scal + (size_t)span_id * 8;
     sc[0] = acc_pass; sc[1] = acc_tp; sc[2] = acc_pass - acc_tp; sc[3] = acc_tpr; sc[4] = A.fpr;
     sc[5] = (any_uns ? SPANF_UNSORTED : 0u) | (any_bad ? SPANF_BADPOS : 0u) | (any_lim ? SPANF_RUNLIMIT : 0u);
-    sc[6] = 0; sc[7] = 0;
+    sc[7] = 0;
+  }
+  {
+    uint32_t po = A.posor;   // OR over the wave (once per span)
+    for (int o = 32; o > 0; o >>= 1) po |= (uint32_t)__shfl_xor((int)po, o);
+    if (lane == 0) P.span_scal[(size_t)span_id * 8 + 6] = po;
   }
 }
 
@@ -913,6 +920,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
   const bool unsorted = __syncthreads_or((int)(fl & SPANF_UNSORTED)) != 0;
   const bool badpos = __syncthreads_or((int)(fl & SPANF_BADPOS)) != 0;
   const bool runlim = __syncthreads_or((int)(fl & SPANF_RUNLIMIT)) != 0;
+  const bool overflow = __syncthreads_or((int)(fl & SPANF_OVERFLOW)) != 0;
 
   // sum span histograms (thread = bin)
   uint32_t h0 = 0, h1 = 0, h2 = 0;
@@ -938,11 +946,11 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
   }
   // scalars
   if (tid < 8) {
-    uint64_t acc = 0;
-    for (int s = 0; s < vd.nspans; ++s) acc += P.span_scal[(size_t)(vd.span0 + s) * 8 + tid];
+    uint64_t acc = 0, acc_or = 0;
+    for (int s = 0; s < vd.nspans; ++s) { acc += P.span_scal[(size_t)(vd.span0 + s) * 8 + tid]; acc_or |= P.span_scal[(size_t)(vd.span0 + s) * 8 + 6]; }
     int64_t* sc = P.scalars + (size_t)v * 8;
     if (tid < 5) sc[tid] = (int64_t)acc;
-    else if (tid == 5) { sc[5] = unsorted ? 0 : 1; P.vcf_flags[v] = (unsorted ? SPANF_UNSORTED : 0u) | (badpos ? SPANF_BADPOS : 0u) | (runlim ? SPANF_RUNLIMIT : 0u); }
+    else if (tid == 5) { sc[5] = unsorted ? 0 : 1; if (P.vcf_posor) P.vcf_posor[v] = (uint32_t)acc_or; P.vcf_flags[v] = (unsorted ? SPANF_UNSORTED : 0u) | (badpos ? SPANF_BADPOS : 0u) | (runlim ? SPANF_RUNLIMIT : 0u) | (overflow ? SPANF_OVERFLOW : 0u); }
     else if (tid == 6) sc[6] = vd.n;
     else sc[7] = P.ext ? P.truths[vd.truth].xn : P.truths[vd.truth].n;
   }
@@ -1164,6 +1172,15 @@ __device__ __forceinline__ int xcd_contiguous_block() {
 #endif
 }
 
+// The digit of a key in one pass.  shift >= 0: a pass of the LSD sort, 8 bits at `shift`.  shift < 0: the ONE pass of the
+// bucket path -- the segment's own shift (SortSeg.pad: its top eight position bits in use, estimated from what the
+// optimistic pass saw), everything above them clamped into the last bucket.
+__device__ __forceinline__ uint32_t digit_of(uint32_t key, int shift, int seg_shift) {
+  if (shift >= 0) return (key >> shift) & 255u;
+  const uint32_t d = key >> seg_shift;
+  return d < 255u ? d : 255u;
+}
+
 // per-tile digit histogram of a segment: hist[hoff + digit * ntiles + tile]
 // FIRST: the first pass reads the position column itself (key bits >= 4 are the position) and also collects the OR of
 // all keys, which tells the host how many digits are in use.
@@ -1191,10 +1208,10 @@ __global__ __launch_bounds__(256) void k_sort_hist(const SortSeg* segs, const in
       } else {
         v = *reinterpret_cast<const uint4*>(keys + sg.koff + i);
       }
-      atomicAdd(&s[(v.x >> shift) & 255u], 1u);
-      if (i + 1 < sg.n) atomicAdd(&s[(v.y >> shift) & 255u], 1u);
-      if (i + 2 < sg.n) atomicAdd(&s[(v.z >> shift) & 255u], 1u);
-      if (i + 3 < sg.n) atomicAdd(&s[(v.w >> shift) & 255u], 1u);
+      atomicAdd(&s[digit_of(v.x, shift, sg.pad)], 1u);
+      if (i + 1 < sg.n) atomicAdd(&s[digit_of(v.y, shift, sg.pad)], 1u);
+      if (i + 2 < sg.n) atomicAdd(&s[digit_of(v.z, shift, sg.pad)], 1u);
+      if (i + 3 < sg.n) atomicAdd(&s[digit_of(v.w, shift, sg.pad)], 1u);
     }
   }
   __syncthreads();
@@ -1360,7 +1377,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
       vv[s] = valid ? stV[s * 64 + lane] : 0u;
       ii[s] = valid ? stI[s * 64 + lane] : 0u;
     }
-    const uint32_t d = (kk[s] >> shift) & 255u;
+    const uint32_t d = digit_of(kk[s], shift, sg.pad);
     // peers = valid lanes with my digit.  Kept as two 32-bit halves and accumulated as "differs from me in some bit":
     // per bit one sign-extending bit-field extract (0 / -1), one ballot, two XORs, two ORs -- the 64-bit select form
     // the compiler made of `peers &= bit ? m : ~m` took nine VALU per bit, and this kernel is VALU-bound.
@@ -1405,7 +1422,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
   for (int s = 0; s < STEPS; ++s) {
     const int64_t i = wbase + s * 64 + lane;
     if (i < sg.n) {
-      const uint32_t d = (kk[s] >> shift) & 255u;
+      const uint32_t d = digit_of(kk[s], shift, sg.pad);
       const uint32_t lp = s_cnt[wave][d] + rk[s];
       s_k[lp] = kk[s]; s_i[lp] = ii[s]; s_v[lp] = vv[s];
     }
@@ -1415,10 +1432,235 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
   const int64_t kbase = final_dst ? sg.dst_off : sg.koff;
   for (int idx = tid; idx < nvalid; idx += 256) {
     const uint32_t k = s_k[idx];
-    const uint32_t g = s_glob[(k >> shift) & 255u] + (uint32_t)idx;
+    const uint32_t g = s_glob[digit_of(k, shift, sg.pad)] + (uint32_t)idx;
     okeys[kbase + g] = k;
     if (FIRST || infs) oinfs[kbase + g] = s_i[idx];
     ovals[sg.koff + g] = s_v[idx];
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// k_classify_hash -- the bucket path for unsorted VCFs: no sort inside a bucket.
+//
+// ONE scatter pass (the segment's top eight position bits in use) has put every record of a position range into one
+// bucket, in no particular order.  Everything the sorted kernel gets from order -- which records sit at a truth key's
+// position, which kept keys repeat -- a bucket gets from small tables in LDS, because all records of one position
+// (hence all equal keys, and all matches of a truth key) are in the same bucket.  The common path of a record is
+// three LDS operations without a loop (the first version probed open-addressing tables with compare-and-swap loops
+// per record and spent 2.65 ms of its 3.3 ms per 2.56e8 records in dependent LDS round trips):
+//   * truth keys: an exact table (key -> slot; state: best bin of a '.'-ID match, matched-by-kept bit) behind a
+//     16 K-bit filter -- one LDS read tells 9 records in 10 that they match nothing;
+//   * distinct kept keys outside the truth set (FP_R): a 64 K-bit map, one fetch-OR per record.  A key whose bit was
+//     clear is new; bits that were hit twice are marked in a second map, and only the keys on marked bits (a few per
+//     cent: true repeats and collisions) meet again in a small exact set in a second pass over the thread's own
+//     registers.  Keys on unmarked bits are distinct by construction: the count is exact;
+//   * kept records without a comparable key: a small exact set of their own (they are keys of their own, as in k_classify).
+// One workgroup of 512 threads per (segment, bucket), 16 records per thread at most, 46 KB of LDS, three workgroups per
+// CU.  TP bits go straight to the main batch's TP mask in input order (one 64-bit atomic OR per true positive); the
+// bucket's histograms and scalars are a "span" row that k_finalize sums exactly like the rows of k_classify.  A bucket
+// that does not fit (more than HB_MAX_RECORDS records, 1 024 truth keys, ...) flags the VCF: the radix sort redoes it.
+// ---------------------------------------------------------------------------
+constexpr uint32_t HB_EMPTY = 0xffffffffu;
+__device__ __forceinline__ uint32_t hb_hash(uint32_t v) { return v * 0x9e3779b1u; }
+// returns the slot of v, inserting it when absent (*fresh says which); tables are never full (callers bound the load)
+__device__ __forceinline__ uint32_t hb_insert(uint32_t* tab, uint32_t log2n, uint32_t v, bool* fresh) {
+  const uint32_t mask = (1u << log2n) - 1u;
+  uint32_t s = hb_hash(v) >> (32u - log2n);
+  for (;;) {
+    const uint32_t old = atomicCAS(&tab[s], HB_EMPTY, v);
+    if (old == HB_EMPTY) { *fresh = true; return s; }
+    if (old == v) { *fresh = false; return s; }
+    s = (s + 1u) & mask;
+  }
+}
+__device__ __forceinline__ int hb_find(const uint32_t* tab, uint32_t log2n, uint32_t v) {
+  const uint32_t mask = (1u << log2n) - 1u;
+  uint32_t s = hb_hash(v) >> (32u - log2n);
+  for (;;) {
+    const uint32_t cur = tab[s];
+    if (cur == v) return (int)s;
+    if (cur == HB_EMPTY) return -1;
+    s = (s + 1u) & mask;
+  }
+}
+
+__global__ __launch_bounds__(512) void k_classify_hash(HashParams P) {
+  constexpr uint32_t LTR = 11, LNK = 9, LX = 11;       // exact tables: truth keys, keyless records, keys on marked bits
+  constexpr uint32_t LTB = 14, LFB = 16;                 // bit maps: truth filter, kept keys
+  constexpr int PER = 16;                                // records per thread at most: four trips of four
+  static_assert((1 << LTR) == HB_TRUTH_SLOTS && (1 << LNK) == HB_NOKEY_SLOTS && HB_MAX_RECORDS + 3 <= 512 * PER, "table sizes; a ragged first trip costs up to three slots");
+  __shared__ uint32_t s_tk[1 << LTR];
+  __shared__ uint32_t s_ts[1 << LTR];                // best bin + 1 of a '.'-ID match
+  __shared__ uint32_t s_tf[(1 << LTR) / 32];         // matched by a kept record (ID ignored)
+  __shared__ uint32_t s_tb[(1 << LTB) / 32];         // truth filter
+  __shared__ uint32_t s_b1[(1 << LFB) / 32];         // kept keys outside the truth set: seen
+  __shared__ uint32_t s_b2[(1 << LFB) / 32];         //                                  seen more than once (or collided)
+  __shared__ uint32_t s_x[1 << LX];                  // the keys on marked bits, exactly
+  __shared__ uint32_t s_nk[1 << LNK];
+  __shared__ uint32_t s_h[3 * 128];                  // TP / FP / U histograms, two u16 bins per dword (a bucket holds < 65 536 records)
+  __shared__ uint32_t s_c[8];                        // kept, TP lines, distinct FP keys, matched truth keys, flags, truth keys staged, keyless inserts, marked inserts
+  const int tid = (int)threadIdx.x;
+  const int d = (int)blockIdx.x;
+  const SortSeg sg = P.segs[blockIdx.y];
+  const size_t row = (size_t)blockIdx.y * HB_BUCKETS + (size_t)d;
+  const uint32_t b = P.hist[sg.hoff + (size_t)d * sg.ntiles];
+  const uint32_t e = d + 1 < HB_BUCKETS ? P.hist[sg.hoff + (size_t)(d + 1) * sg.ntiles] : (uint32_t)sg.n;
+  const uint32_t nrec = e - b;
+  if (nrec == 0u) {   // two buckets in five are empty (a genome rarely ends on a power of two): a row of zeros, nothing else
+    uint32_t* oh0 = P.row_hist + row * SPAN_HIST_WORDS;
+    if (tid < 3 * 128) oh0[tid] = 0u;
+    if (tid < 8) P.row_scal[row * 8 + tid] = 0u;
+    return;
+  }
+  for (int i = tid; i < (1 << LTR); i += 512) { s_tk[i] = HB_EMPTY; s_ts[i] = 0u; s_x[i] = HB_EMPTY; }
+  for (int i = tid; i < (1 << LFB) / 32; i += 512) { s_b1[i] = 0u; s_b2[i] = 0u; }
+  if (tid < (1 << LTB) / 32) s_tb[tid] = 0u;
+  if (tid < (1 << LTR) / 32) s_tf[tid] = 0u;
+  if (tid < (1 << LNK)) s_nk[tid] = HB_EMPTY;
+  if (tid < 3 * 128) s_h[tid] = 0u;
+  if (tid < 8) s_c[tid] = 0u;
+  __syncthreads();
+  const uint32_t shift = (uint32_t)sg.pad;                   // >= 4: a bucket is a whole range of positions
+  const uint32_t kbase = (uint32_t)d << shift;               // every key of the bucket is >= kbase (the last bucket also takes what lies above)
+  if (nrec > (uint32_t)HB_MAX_RECORDS) {
+    if (tid == 0) s_c[4] = SPANF_OVERFLOW;
+  }
+#ifndef HB_SKIP_TRUTH   // (timing builds only: phases of the kernel switched off, results wrong)
+  else if (nrec > 0) {
+    // ---- the truth keys of the bucket's positions, from the coarse position index ----
+    const TruthDev tr = P.truths[P.vcfs[sg.main_vcf].truth];
+    const uint32_t plo = kbase >> 4;
+    const uint32_t phi = d + 1 < HB_BUCKETS ? ((((uint32_t)(d + 1)) << shift) - 1u) >> 4 : 0x0fffffffu;
+    uint32_t ba = plo >> tr.shift, bb = (phi >> tr.shift) + 1u;
+    const uint32_t lim = (uint32_t)tr.nb + 1u;
+    ba = ba < lim ? ba : lim; bb = bb < lim ? bb : lim;
+    const int lo = tr.tidx[ba], hi = tr.tidx[bb];
+    for (int j = lo + tid; j < hi; j += 512) {
+      const uint32_t k = tr.keys[j];
+      const uint32_t kp = k >> 4;
+      if (kp >= plo && kp <= phi) {
+        if (atomicAdd(&s_c[5], 1u) >= (1u << LTR) / 2u) { atomicOr(&s_c[4], SPANF_OVERFLOW); break; }
+        bool fresh;
+        const uint32_t v = k - kbase;
+        (void)hb_insert(s_tk, LTR, v, &fresh);
+        const uint32_t h = hb_hash(v) >> (32u - LTB);
+        atomicOr(&s_tb[h >> 5], 1u << (h & 31));
+      }
+    }
+  }
+#endif
+  __syncthreads();
+  uint32_t n_pass = 0, n_tp = 0, fpr = 0, bad = 0;
+#ifndef HB_SKIP_RECORDS
+  if (nrec > 0 && !(s_c[4] & SPANF_OVERFLOW)) {
+    const uint32_t* keys = P.keys + sg.dst_off;
+    const uint32_t* infs = P.infs + sg.dst_off;
+    const uint32_t* perm = P.perm + sg.koff;
+    unsigned long long* mtp = reinterpret_cast<unsigned long long*>(P.mask_tp);
+    uint32_t vq[PER];          // the thread's records stay in registers for the second pass
+    uint32_t cand = 0;         // bit k: record k is a kept key outside the truth set (with a comparable key)
+    // Four consecutive records per thread and trip, fetched with one 16-byte load per array (dword loads are bound by the
+    // rate of memory instructions), the next trip's loads in flight while this one is worked on.  Trips start at a multiple
+    // of four records: the bucket's first and last trip are ragged.
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const uint32_t a0 = (b & ~3u) + 4u * (uint32_t)tid;
+    v4u kq[2], iq[2], pq[2];
+    const v4u z4 = {0u, 0u, 0u, 0u};
+    kq[0] = z4; iq[0] = z4; pq[0] = z4;
+    if (a0 < e) {
+      kq[0] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(keys + a0));
+      iq[0] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(infs + a0));
+      pq[0] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(perm + a0));
+    }
+#pragma unroll
+    for (int g = 0; g < PER / 4; ++g) {
+      const uint32_t i0 = a0 + (uint32_t)g * 2048u;
+      if (g + 1 < PER / 4) {
+        const uint32_t i1 = i0 + 2048u;
+        kq[(g + 1) & 1] = z4; iq[(g + 1) & 1] = z4; pq[(g + 1) & 1] = z4;
+        if (i1 < e) {
+          kq[(g + 1) & 1] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(keys + i1));
+          iq[(g + 1) & 1] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(infs + i1));
+          pq[(g + 1) & 1] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(perm + i1));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t i = i0 + (uint32_t)u;
+        const uint32_t inf = (i >= b && i < e) ? iq[g & 1][u] : 0u;   // records of the neighbouring buckets in a ragged trip take no part
+        const uint32_t v = kq[g & 1][u] - kbase;
+        vq[4 * g + u] = v;
+        bad |= inf & I_BADPOS;
+        if (!(inf & I_LIVE)) continue;                          // not a single-base record in range: in no file, in no histogram
+        const uint32_t b1 = inf & I_BIN1;
+        const bool kept = (inf & I_KEPT) != 0u, nokey = (inf & I_NOKEY) != 0u;
+        const uint32_t hv = hb_hash(v);
+        int t = -1;
+        if (!nokey && ((s_tb[hv >> (37u - LTB)] >> ((hv >> (32u - LTB)) & 31u)) & 1u)) t = hb_find(s_tk, LTR, v);   // 9 in 10 stop at the filter
+        const bool hit = t >= 0;
+        const bool tpl = (hit && (inf & I_IDDOT)) || (inf & I_TPLINE);
+        if (hit) {
+          if ((inf & I_IDDOT) && b1) atomicMax(&s_ts[t], b1);
+          if (inf & I_PASS) atomicOr(&s_tf[t >> 5], 1u << (t & 31));
+        }
+        if (b1) atomicAdd(&s_h[(tpl ? 0 : 128) + ((b1 - 1u) >> 1)], 1u << (16u * ((b1 - 1u) & 1u)));
+        if (kept) {
+          ++n_pass;
+          if (tpl) {
+            ++n_tp;
+            const int64_t o = sg.src_off + (int64_t)pq[g & 1][u];
+            atomicOr(mtp + (o >> 6), 1ull << (o & 63));
+          }
+          if (!hit) {   // a kept key outside the truth set counts once per VCF
+            if (nokey) {   // rare: an exact set of their own, every insertion reserved (a probe of a full table would not return)
+              if (atomicAdd(&s_c[6], 1u) >= (1u << LNK) / 2u) { atomicOr(&s_c[4], SPANF_OVERFLOW); continue; }
+              bool fresh;
+              (void)hb_insert(s_nk, LNK, v, &fresh);
+              fpr += fresh ? 1u : 0u;
+            } else {
+              cand |= 1u << (4 * g + u);
+              const uint32_t h = hv >> (32u - LFB), bit = 1u << (h & 31u);
+              if (atomicOr(&s_b1[h >> 5], bit) & bit) atomicOr(&s_b2[h >> 5], bit);   // seen before (or a collision): both meet again below
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // second pass over the thread's own registers: keys on unmarked bits are distinct; keys on marked bits are counted exactly
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      if (!((cand >> k) & 1u)) continue;
+      const uint32_t v = vq[k];
+      const uint32_t h = hb_hash(v) >> (32u - LFB);
+      if (!((s_b2[h >> 5] >> (h & 31u)) & 1u)) { ++fpr; continue; }
+      if (atomicAdd(&s_c[7], 1u) >= (1u << LX) / 2u) { atomicOr(&s_c[4], SPANF_OVERFLOW); continue; }
+      bool fresh;
+      (void)hb_insert(s_x, LX, v, &fresh);
+      fpr += fresh ? 1u : 0u;
+    }
+  }
+#endif
+  // ---- bucket epilogue: per-entry state -> U histogram and TP_R, counters, the row ----
+  atomicAdd(&s_c[0], n_pass); atomicAdd(&s_c[1], n_tp); atomicAdd(&s_c[2], fpr);
+  if (bad) atomicOr(&s_c[4], SPANF_BADPOS);
+  __syncthreads();
+  uint32_t tpr = 0;
+  for (int t = tid; t < (1 << LTR); t += 512) {
+    if (s_tk[t] == HB_EMPTY) continue;
+    const uint32_t mx = s_ts[t];
+    if (mx) atomicAdd(&s_h[256 + ((mx - 1u) >> 1)], 1u << (16u * ((mx - 1u) & 1u)));
+    tpr += (s_tf[t >> 5] >> (t & 31)) & 1u;
+  }
+  if (tpr) atomicAdd(&s_c[3], tpr);
+  __syncthreads();
+  uint32_t* oh = P.row_hist + row * SPAN_HIST_WORDS;
+  if (tid < 3 * 128) oh[tid] = s_h[tid];
+  if (tid == 0) {
+    uint32_t* sc = P.row_scal + row * 8;
+    const uint32_t fl = s_c[4];
+    sc[0] = s_c[0]; sc[1] = s_c[1]; sc[2] = s_c[0] - s_c[1]; sc[3] = s_c[3]; sc[4] = s_c[2]; sc[5] = fl; sc[6] = 0u; sc[7] = 0u;
   }
 }
 
@@ -1470,10 +1712,15 @@ __global__ __launch_bounds__(256) void k_tile_counts(const SortSeg* segs, const 
 
 // ROC rows and scalars of the sorted scratch VCFs back under the original VCFs
 __global__ __launch_bounds__(256) void k_sort_copy_rows(const SortSeg* segs, const uint64_t* sub_roc, const int64_t* sub_scal,
-                                                        uint64_t* roc, int64_t* scal, int n_bins) {
+                                                        uint64_t* roc, int64_t* scal, int n_bins, uint64_t* global_add, const VcfDesc* vcfs) {
   const SortSeg sg = segs[blockIdx.x];
   const int n = 3 * n_bins;
-  for (int i = (int)threadIdx.x; i < n; i += 256) roc[(size_t)sg.main_vcf * n + i] = sub_roc[(size_t)sg.sub_vcf * n + i];
+  for (int i = (int)threadIdx.x; i < n; i += 256) {
+    const uint64_t v = sub_roc[(size_t)sg.sub_vcf * n + i];
+    roc[(size_t)sg.main_vcf * n + i] = v;
+    // bucket path: the rows join the per-truth sums only here, once the host knows no bucket overflowed
+    if (global_add && v) atomicAdd(reinterpret_cast<unsigned long long*>(global_add) + (size_t)vcfs[sg.main_vcf].truth * n + i, (unsigned long long)v);
+  }
   if (threadIdx.x < 8) {
     int64_t v = sub_scal[(size_t)sg.sub_vcf * 8 + threadIdx.x];
     if (threadIdx.x == 5) v = 0;   // QM_S_SORTED: the original was not
@@ -1580,17 +1827,17 @@ void launch_synth(const SynthParams& S, int n_vcf, int64_t max_n, hipStream_t st
 }
 // first pass of the batch's sort, in two steps because the host needs the OR of the keys in between
 void launch_sort_first_hist(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const int32_t* pos_col, uint32_t* hist, uint32_t* orbits,
-                            hipStream_t st) {
+                            hipStream_t st, int msd) {   // msd: the bucket path's one pass (per-segment shift, SortSeg.pad)
   if (ntiles > 0)
-    hipLaunchKernelGGL((k_sort_hist<true>), dim3(ntiles), dim3(256), 0, st, segs, tile_seg, (const uint32_t*)nullptr, 4, hist, pos_col, orbits);
+    hipLaunchKernelGGL((k_sort_hist<true>), dim3(ntiles), dim3(256), 0, st, segs, tile_seg, (const uint32_t*)nullptr, msd ? -1 : 4, hist, pos_col, orbits);
 }
 void launch_sort_first_scatter(const SortSeg* segs, const int32_t* tile_seg, int nseg, int ntiles, const SortCols& src, int n_bins, int ext,
                                uint32_t* hist, uint32_t* okeys, uint32_t* oinfs, uint32_t* ovals, int final_dst, uint64_t* mask_pass,
-                               uint64_t* mask_tp, hipStream_t st) {
+                               uint64_t* mask_tp, hipStream_t st, int msd) {
   if (ntiles <= 0) return;
   hipLaunchKernelGGL(k_sort_scan, dim3(nseg), dim3(256), 0, st, segs, hist);
   hipLaunchKernelGGL((k_sort_scatter<true>), dim3(ntiles), dim3(256), 0, st, segs, tile_seg, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
-                     (const uint32_t*)nullptr, 4, hist, okeys, oinfs, ovals, final_dst, src, n_bins, ext, mask_pass, mask_tp);
+                     (const uint32_t*)nullptr, msd ? -1 : 4, hist, okeys, oinfs, ovals, final_dst, src, n_bins, ext, mask_pass, mask_tp);
 }
 void launch_sort_gather_alleles(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const uint32_t* perm, const int32_t* src_ref,
                                 const int32_t* src_alt, int32_t* dst_ref, int32_t* dst_alt, hipStream_t st) {
@@ -1619,8 +1866,11 @@ void launch_tile_counts(const SortSeg* segs, const int32_t* ktile_seg, const int
                        tile_tp, tile_fp);
 }
 void launch_sort_copy_rows(const SortSeg* segs, int nseg, const uint64_t* sub_roc, const int64_t* sub_scal, uint64_t* roc,
-                           int64_t* scal, int n_bins, hipStream_t st) {
-  if (nseg > 0) hipLaunchKernelGGL(k_sort_copy_rows, dim3(nseg), dim3(256), 0, st, segs, sub_roc, sub_scal, roc, scal, n_bins);
+                           int64_t* scal, int n_bins, hipStream_t st, uint64_t* global_add, const VcfDesc* vcfs) {
+  if (nseg > 0) hipLaunchKernelGGL(k_sort_copy_rows, dim3(nseg), dim3(256), 0, st, segs, sub_roc, sub_scal, roc, scal, n_bins, global_add, vcfs);
+}
+void launch_classify_hash(const HashParams& P, int nseg, hipStream_t st) {
+  if (nseg > 0) hipLaunchKernelGGL(k_classify_hash, dim3(HB_BUCKETS, nseg), dim3(512), 0, st, P);
 }
 void launch_overlap_pack(const int32_t* pos, const int32_t* ref, const int32_t* alt, const int32_t* set_of, int64_t n,
                          uint32_t* keys, uint32_t* vals, uint32_t* bad, hipStream_t st) {
