@@ -312,7 +312,8 @@ def shuffled_variant(eng, tid, P, bins, nv, tseed, sorted_roc):
     b.close()
     return {"value": nv * float(P["records"]) * steps / dt, "unit": "classifications/s", "vcfs": nv, "steps": steps,
             "ms_per_step": dt / steps * 1e3, "roc_equals_sorted_variant": ok,
-            "note": "records permuted: optimistic pass (stops early) + batched LSD radix sort (8-bit digits, XCD-aware tile order) + packed k_classify + TP bits scattered back"}
+            "note": "records permuted: optimistic pass (stops early) + bucket path (one scatter pass into 256 position buckets per VCF, k_classify_hash: filters and "
+                    "sets in LDS, no sort inside a bucket, TP bits straight into the input-order mask); VCFs too large for the buckets take the batched LSD radix sort"}
 
 
 def alleles_variant(eng, P, bins, nv):

@@ -366,6 +366,12 @@ struct qm_batch {
   uint32_t *bk_hist = nullptr, *bk_scal = nullptr;
   VcfDesc* d_bk_vcfs = nullptr;
   int64_t cap_bk_rows = 0, cap_bk_vcfs = 0;
+  // throw-away outputs of the rescan after a sort (kept: an allocation per finish costs more than the rescan)
+  uint64_t* rs_roc = nullptr;
+  int64_t* rs_scal = nullptr;
+  uint32_t* rs_flags = nullptr;
+  // the segment tables of the last chunk, as uploaded: a batch that is run again with the same VCFs unsorted skips the upload
+  std::vector<SortSeg> last_segs;
   uint64_t *roc = nullptr, *global_acc = nullptr;
   int64_t* scalars = nullptr;
   VcfDesc* d_vcfs = nullptr;
@@ -376,6 +382,7 @@ struct qm_batch {
   // sort path scratch (lazy): one chunk of unsorted VCFs at a time
   qm_batch* sub = nullptr;               // sorted copies of the chunk's VCFs
   std::vector<int64_t> sub_sig;          // record counts the scratch batch was built for
+  std::vector<int32_t> sub_tids;         // truth ids its layout was uploaded with
   uint32_t *sk[2] = {nullptr, nullptr}, *sv[2] = {nullptr, nullptr}, *si[2] = {nullptr, nullptr}, *shist = nullptr, *sorbits = nullptr;
   SortSeg* d_segs = nullptr;
   int32_t *d_tile_seg = nullptr, *d_ktile_seg = nullptr, *d_ktile_local = nullptr;
@@ -408,7 +415,7 @@ static void batch_free(qm_batch* b) {
   (void)hipSetDevice(b->ctx->dev);
   if (b->sub) { batch_free(b->sub); b->sub = nullptr; }
   void* ptrs[] = {b->pkey, b->pinf, b->pos, b->ref, b->alt, b->qual, b->flags, b->mask_pass, b->mask_tp, b->idx, b->tile_tp, b->tile_fp,
-                  b->tile_tp_off, b->tile_fp_off, b->span_hist, b->span_scal, b->vcf_flags, b->vcf_posor, b->bk_hist, b->bk_scal, b->d_bk_vcfs, b->roc, b->global_acc,
+                  b->tile_tp_off, b->tile_fp_off, b->span_hist, b->span_scal, b->vcf_flags, b->vcf_posor, b->bk_hist, b->bk_scal, b->d_bk_vcfs, b->rs_roc, b->rs_scal, b->rs_flags, b->roc, b->global_acc,
                   b->scalars, b->d_vcfs, b->d_spans, b->d_tile_vcf, b->cls_scratch, b->sk[0], b->sk[1], b->sv[0],
                   b->sv[1], b->si[0], b->si[1], b->shist, b->sorbits, b->d_segs, b->d_tile_seg, b->d_ktile_seg, b->d_ktile_local};
   for (void* p : ptrs) (void)hipFree(p);
@@ -755,7 +762,9 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     b->sub->ext = b->ext;
     b->dev_bytes += b->sub->dev_bytes;
     b->sub_sig = sig;
-  } else {
+    b->sub_tids = tids;
+  } else if (b->sub_tids != tids) {
+    b->sub_tids = tids;
     for (int i = 0; i < nseg; ++i) b->sub->L.vcfs[(size_t)i].truth = tids[(size_t)i];
     for (SpanDesc& sd : b->sub->L.spans) sd.truth = b->sub->L.vcfs[(size_t)sd.vcf].truth;
     int rc = upload_layout(b->sub);
@@ -815,10 +824,15 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     if (rc == QM_OK) rc = regrow(&b->d_bk_vcfs, &b->cap_bk_vcfs, (int64_t)nseg, &b->dev_bytes);
   }
   if (rc != QM_OK) return rc;
-  HIPCHK(hipMemcpyAsync(b->d_segs, segs.data(), sizeof(SortSeg) * segs.size(), hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(b->d_tile_seg, tile_seg.data(), 4 * tile_seg.size(), hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(b->d_ktile_seg, ktile_seg.data(), 4 * ktile_seg.size(), hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(b->d_ktile_local, ktile_local.data(), 4 * ktile_local.size(), hipMemcpyHostToDevice, st));
+  const bool same_tables = b->last_segs.size() == segs.size() && memcmp(b->last_segs.data(), segs.data(), sizeof(SortSeg) * segs.size()) == 0;
+  if (!same_tables) {   // the tile maps follow from the segment table
+    HIPCHK(hipMemcpyAsync(b->d_segs, segs.data(), sizeof(SortSeg) * segs.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b->d_tile_seg, tile_seg.data(), 4 * tile_seg.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b->d_ktile_seg, ktile_seg.data(), 4 * ktile_seg.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b->d_ktile_local, ktile_local.data(), 4 * ktile_local.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));   // the host vectors die with this call
+    b->last_segs = segs;
+  }
   HIPCHK(hipMemsetAsync(b->sorbits, 0, 4, st));
   SortCols src = {b->pos, b->ref, b->alt, b->qual, b->flags};
   if (try_buckets) {
@@ -852,11 +866,9 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
       launch_sort_copy_rows(b->d_segs, nseg, s->roc, s->scalars, b->roc, b->scalars, b->n_bins, st, global, b->d_vcfs);
       launch_tile_counts(b->d_segs, b->d_ktile_seg, b->d_ktile_local, nkt, b->mask_pass, b->mask_tp, b->tile_tp, b->tile_fp, st);
       HIPCHK(hipGetLastError());
-      HIPCHK(hipStreamSynchronize(st));
-      return QM_OK;
+      return QM_OK;   // no wait: the rescan that follows is on the same stream and ends with one
     }
     // a bucket did not fit its tables (dense positions, a dense truth set): the radix sort redoes the chunk from the columns
-    HIPCHK(hipMemcpyAsync(b->d_segs, segs.data(), sizeof(SortSeg) * segs.size(), hipMemcpyHostToDevice, st));
   }
   // --- 1. + 2. stable LSD radix sort by position (key bits 4..31), only the digits in use.  The first pass packs the
   //        records to (key, info, original index) on the fly; the last pass drops keys and infos straight into the
@@ -946,21 +958,20 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
 // k_finalize recomputes the offsets of every tile; to keep ROC rows and per-truth
 // sums untouched it runs on a throw-away output set.
 static int rescan_and_compact(qm_batch* b, hipStream_t st) {
-  uint64_t* tmp_roc = nullptr;
-  int64_t* tmp_scal = nullptr;
-  uint32_t* tmp_flags = nullptr;
-  DALLOC(tmp_roc, (size_t)b->n_vcf * 3 * (size_t)b->n_bins);
-  DALLOC(tmp_scal, (size_t)b->n_vcf * 8);
-  DALLOC(tmp_flags, (size_t)b->n_vcf);
+  if (!b->rs_roc) {
+    DALLOC(b->rs_roc, (size_t)b->n_vcf * 3 * (size_t)b->n_bins);
+    DALLOC(b->rs_scal, (size_t)b->n_vcf * 8);
+    DALLOC(b->rs_flags, (size_t)b->n_vcf);
+    b->dev_bytes += (int64_t)b->n_vcf * (3 * b->n_bins * 8 + 64 + 4);
+  }
   FinalizeParams F = finalize_params(b, nullptr);
-  F.roc = tmp_roc; F.scalars = tmp_scal; F.vcf_flags = tmp_flags; F.vcf_posor = nullptr;
+  F.roc = b->rs_roc; F.scalars = b->rs_scal; F.vcf_flags = b->rs_flags; F.vcf_posor = nullptr;
   launch_finalize(F, b->n_vcf, st);
   CompactParams CP = compact_params(b);
   CP.skip_unsorted = 0;   // the flags still say 'unsorted' for the VCFs just redone: compact them too
   launch_compact(CP, (int)b->L.spans.size(), st);
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  (void)hipFree(tmp_roc); (void)hipFree(tmp_scal); (void)hipFree(tmp_flags);
   if (e != hipSuccess) return fail(QM_E_HIP, "rescan/compact: %s", hipGetErrorString(e));
   return QM_OK;
 }
