@@ -107,6 +107,29 @@ def test_unsorted_vcfs_take_the_radix_sort_path(engine, oracle):
     assert np.array_equal(glob[tid], want)
 
 
+def test_unsorted_vcfs_too_dense_for_the_bucket_path_fall_back_to_the_radix_sort(engine, oracle):
+    """Unsorted VCFs normally take the bucket path (one scatter pass + k_classify_hash).  Buckets that do not fit its LDS
+    tables -- here 300 000 records on 16 positions, and a truth set with every allele pair at every position -- flag the
+    VCF, and the radix sort redoes it: same answers, many repeated keys."""
+    rng = np.random.default_rng(71)
+    tpos = np.repeat(np.arange(900, 1300, dtype=np.int32), 16)
+    truth = (tpos, np.tile(np.repeat(np.arange(4, dtype=np.int32), 4), 400), np.tile(np.arange(4, dtype=np.int32), 1600))
+    tid = engine.truth_load(*truth)
+    cols = []
+    for n, lo, hi in ((300000, 1000, 1016), (50000, 900, 1300), (9000, 1, 5000)):
+        pos = rng.integers(lo, hi, n).astype(np.int32)
+        ref = rng.integers(0, 4, n).astype(np.int32)
+        alt = rng.integers(0, 4, n).astype(np.int32)
+        qual = rng.integers(0, 300, n).astype(np.float32)
+        flags = ((qual >= 20).astype(np.uint8) | ((rng.random(n) > 0.1).astype(np.uint8) << 1) | ((rng.random(n) < 0.01).astype(np.uint8) << 2)).astype(np.uint8)
+        cols.append((pos, ref, alt, qual, flags))
+    res, glob = engine.classify_batch(cols, [tid] * len(cols))
+    for r, c in zip(res, cols):
+        check_vcf(oracle, r, c, truth, expect_sorted=False)
+    assert np.array_equal(glob[tid], sum((r["roc"] for r in res), np.zeros((3, 256), np.uint64)))
+    engine.truth_release(tid)
+
+
 def test_long_equal_position_runs_across_tiles(engine, oracle):
     """Runs of one position longer than a tile: ownership of the truth entries and the
     R-path de-duplication must not double count across tile and span boundaries."""
