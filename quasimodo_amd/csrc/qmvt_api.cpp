@@ -366,6 +366,13 @@ struct qm_batch {
   uint32_t *bk_hist = nullptr, *bk_scal = nullptr;
   VcfDesc* d_bk_vcfs = nullptr;
   int64_t cap_bk_rows = 0, cap_bk_vcfs = 0;
+  uint64_t* bk_ent = nullptr;       // the bucket regions: [segment][256][8][SortSeg.bk_cap] packed records
+  uint32_t* bk_cursor = nullptr;    // [segment][256][8] fill counts, then one flag word per segment
+  int32_t* d_bk_tile_seg = nullptr;
+  HashRow* bk_rows = nullptr;       // one descriptor per (segment, bucket)
+  int64_t cap_bk_rowdesc = 0;
+  int64_t cap_bk_ent = 0, cap_bk_cursor = 0, cap_bk_tiles = 0;
+  bool bk_tiles_valid = false;      // d_bk_tile_seg holds the tile map of last_segs
   // throw-away outputs of the rescan after a sort (kept: an allocation per finish costs more than the rescan)
   uint64_t* rs_roc = nullptr;
   int64_t* rs_scal = nullptr;
@@ -415,7 +422,7 @@ static void batch_free(qm_batch* b) {
   (void)hipSetDevice(b->ctx->dev);
   if (b->sub) { batch_free(b->sub); b->sub = nullptr; }
   void* ptrs[] = {b->pkey, b->pinf, b->pos, b->ref, b->alt, b->qual, b->flags, b->mask_pass, b->mask_tp, b->idx, b->tile_tp, b->tile_fp,
-                  b->tile_tp_off, b->tile_fp_off, b->span_hist, b->span_scal, b->vcf_flags, b->vcf_posor, b->bk_hist, b->bk_scal, b->d_bk_vcfs, b->rs_roc, b->rs_scal, b->rs_flags, b->roc, b->global_acc,
+                  b->tile_tp_off, b->tile_fp_off, b->span_hist, b->span_scal, b->vcf_flags, b->vcf_posor, b->bk_hist, b->bk_scal, b->d_bk_vcfs, b->bk_ent, b->bk_cursor, b->d_bk_tile_seg, b->bk_rows, b->rs_roc, b->rs_scal, b->rs_flags, b->roc, b->global_acc,
                   b->scalars, b->d_vcfs, b->d_spans, b->d_tile_vcf, b->cls_scratch, b->sk[0], b->sk[1], b->sv[0],
                   b->sv[1], b->si[0], b->si[1], b->shist, b->sorbits, b->d_segs, b->d_tile_seg, b->d_ktile_seg, b->d_ktile_local};
   for (void* p : ptrs) (void)hipFree(p);
@@ -773,8 +780,8 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   qm_batch* s = b->sub;
   // --- segment table and tile maps
   std::vector<SortSeg> segs((size_t)nseg);
-  std::vector<int32_t> tile_seg, ktile_seg, ktile_local;
-  int64_t koff = 0, hoff = 0;
+  std::vector<int32_t> tile_seg, ktile_seg, ktile_local, bk_tile_seg;
+  int64_t koff = 0, hoff = 0, bk_ents = 0;
   for (int i = 0; i < nseg; ++i) {
     const VcfDesc& d = b->L.vcfs[(size_t)vs[(size_t)i]];
     SortSeg& g = segs[(size_t)i];
@@ -786,6 +793,14 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
       int msb = 31;
       while (msb > 0 && !((kor >> msb) & 1u)) --msb;
       g.pad = std::max(4, msb - 7);
+      // room per sub-region: between 128 and 256 buckets are in use, a sub-region takes every eighth tile; half as much again on top
+      int64_t want = d.n / (128 * HB_SUBS) * 3 / 2 + 16, cap2 = 16;
+      while (cap2 < want && cap2 < HB_SUB_MAX) cap2 *= 2;
+      g.bk_cap = (int32_t)cap2;
+      g.bk_off = bk_ents;
+      g.bk_tile0 = (int32_t)bk_tile_seg.size();
+      bk_ents += (int64_t)HB_BUCKETS * HB_SUBS * cap2;
+      for (int64_t t = 0; t < (d.n + BK_TILE - 1) / BK_TILE; ++t) bk_tile_seg.push_back(i);
     }
     for (int t = 0; t < g.ntiles; ++t) tile_seg.push_back(i);
     for (int t = 0; t < d.ntiles; ++t) { ktile_seg.push_back(i); ktile_local.push_back(t); }
@@ -814,7 +829,9 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   // for 256 buckets of at most HB_MAX_RECORDS records; QM_SORT_PATH=radix keeps everything on the radix sort.
   bool try_buckets = !b->ext;
   if (const char* e = getenv("QM_SORT_PATH")) try_buckets = try_buckets && strcmp(e, "radix") != 0;
-  for (int i = 0; i < nseg && try_buckets; ++i) try_buckets = segs[(size_t)i].n <= (int64_t)HB_BUCKETS * HB_MAX_RECORDS * 3 / 4;   // fuller than that, some bucket will overflow
+  // fuller than five eighths of 256 x 8 x 1 024, some sub-region will overflow; an entry has HB_INDEX_BITS for the record's index
+  for (int i = 0; i < nseg && try_buckets; ++i)
+    try_buckets = segs[(size_t)i].n <= (int64_t)HB_BUCKETS * HB_MAX_RECORDS * 5 / 8 && segs[(size_t)i].n <= ((int64_t)1 << HB_INDEX_BITS);
   if (rc == QM_OK && try_buckets) {
     const int64_t rows = (int64_t)nseg * HB_BUCKETS;   // cap_bk_rows counts rows for both arrays
     int64_t c1 = b->cap_bk_rows * SPAN_HIST_WORDS, c2 = b->cap_bk_rows * 8;
@@ -822,6 +839,13 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     if (rc == QM_OK) rc = regrow(&b->bk_scal, &c2, rows * 8, &b->dev_bytes);
     if (rc == QM_OK) b->cap_bk_rows = std::max(b->cap_bk_rows, rows);
     if (rc == QM_OK) rc = regrow(&b->d_bk_vcfs, &b->cap_bk_vcfs, (int64_t)nseg, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->bk_ent, &b->cap_bk_ent, bk_ents, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->bk_rows, &b->cap_bk_rowdesc, rows, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->bk_cursor, &b->cap_bk_cursor, rows * HB_SUBS + nseg + 32, &b->dev_bytes);   // + 32: phase clocks of a profiling build
+    if (rc == QM_OK && (int64_t)bk_tile_seg.size() > b->cap_bk_tiles) {
+      b->bk_tiles_valid = false;
+      rc = regrow(&b->d_bk_tile_seg, &b->cap_bk_tiles, (int64_t)bk_tile_seg.size(), &b->dev_bytes);
+    }
   }
   if (rc != QM_OK) return rc;
   const bool same_tables = b->last_segs.size() == segs.size() && memcmp(b->last_segs.data(), segs.data(), sizeof(SortSeg) * segs.size()) == 0;
@@ -830,13 +854,18 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     HIPCHK(hipMemcpyAsync(b->d_tile_seg, tile_seg.data(), 4 * tile_seg.size(), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(b->d_ktile_seg, ktile_seg.data(), 4 * ktile_seg.size(), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(b->d_ktile_local, ktile_local.data(), 4 * ktile_local.size(), hipMemcpyHostToDevice, st));
+    b->bk_tiles_valid = false;
+  }
+  if (try_buckets && !b->bk_tiles_valid) HIPCHK(hipMemcpyAsync(b->d_bk_tile_seg, bk_tile_seg.data(), 4 * bk_tile_seg.size(), hipMemcpyHostToDevice, st));
+  if (!same_tables || (try_buckets && !b->bk_tiles_valid)) {
     HIPCHK(hipStreamSynchronize(st));   // the host vectors die with this call
     b->last_segs = segs;
+    b->bk_tiles_valid = try_buckets;
   }
   HIPCHK(hipMemsetAsync(b->sorbits, 0, 4, st));
   SortCols src = {b->pos, b->ref, b->alt, b->qual, b->flags};
   if (try_buckets) {
-    // --- bucket path: histogram + ONE scatter on each VCF's top eight key bits, then the hash-join per bucket
+    // --- bucket path: ONE scatter on each VCF's top eight key bits into fixed-size bucket regions, then the hash-join per bucket
     std::vector<VcfDesc> fake((size_t)nseg);
     for (int i = 0; i < nseg; ++i) {
       VcfDesc& f = fake[(size_t)i];
@@ -844,11 +873,17 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
       f.off = 0; f.n = segs[(size_t)i].n; f.truth = tids[(size_t)i]; f.tile0 = 0; f.ntiles = 0; f.span0 = i * HB_BUCKETS; f.nspans = HB_BUCKETS; f.pad = 0;
     }
     HIPCHK(hipMemcpyAsync(b->d_bk_vcfs, fake.data(), sizeof(VcfDesc) * fake.size(), hipMemcpyHostToDevice, st));
-    launch_sort_first_hist(b->d_segs, b->d_tile_seg, nst, b->pos, b->shist, b->sorbits, st, 1);
-    launch_sort_first_scatter(b->d_segs, b->d_tile_seg, nseg, nst, src, b->n_bins, 0, b->shist, s->pkey, s->pinf, b->sv[0], 1, b->mask_pass, b->mask_tp, st, 1);
+    const size_t ncur = ((size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg + 32) * 4;
+    HIPCHK(hipMemsetAsync(b->bk_cursor, 0, ncur, st));
+    BucketScatterParams S;
+    S.segs = b->d_segs; S.tile_seg = b->d_bk_tile_seg; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
+    S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
+    S.n_seg = nseg; S.n_bins = b->n_bins;
+    launch_bucket_scatter(S, (int)bk_tile_seg.size(), st);
     HashParams H;
-    H.segs = b->d_segs; H.keys = s->pkey; H.infs = s->pinf; H.perm = b->sv[0]; H.hist = b->shist; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
-    H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_bins = b->n_bins;
+    H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
+    H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins;
+    launch_bucket_rows(H, nseg, st);
     launch_classify_hash(H, nseg, st);
     FinalizeParams F = finalize_params(s, nullptr);   // the rows join the per-truth sums only once no bucket is known to have overflowed
     F.vcfs = b->d_bk_vcfs; F.span_hist = b->bk_hist; F.span_scal = b->bk_scal; F.vcf_posor = nullptr;
@@ -857,6 +892,13 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     std::vector<uint32_t> hfl((size_t)nseg);
     HIPCHK(hipMemcpyAsync(hfl.data(), s->vcf_flags, 4 * hfl.size(), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));   // also makes the host tables above safe to free
+    if (getenv("QM_HB_PROFILE")) {   // kernels built with -DHB_PROFILE: clock ticks per phase, summed over the workgroups
+      uint32_t pr[32];
+      HIPCHK(hipMemcpy(pr, b->bk_cursor + (size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg, sizeof(pr), hipMemcpyDeviceToHost));
+      fprintf(stderr, "hb profile: wgs %u;", pr[0]);
+      for (int i = 1; i < 12; ++i) fprintf(stderr, " p%d %.0f", i, pr[0] ? (double)pr[i] * 16.0 / pr[0] : 0.0);
+      fprintf(stderr, " (ticks per workgroup)\n");
+    }
     bool overflow = false;
     for (int i = 0; i < nseg; ++i) {
       if (hfl[(size_t)i] & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", vs[(size_t)i]);

@@ -155,26 +155,65 @@ struct SortSeg {
   int64_t koff;      // offset of the segment in the chunk's key / payload / class arrays
   int64_t hoff;      // offset of the segment's [256][ntiles] digit histogram
   int64_t n;
+  int64_t bk_off;    // bucket path: first entry of the segment's [256][8][bk_cap] bucket regions
   int32_t tile0, ntiles;     // sort tiles (SORT_TILE records), numbered over the chunk
   int32_t main_vcf, sub_vcf;
-  int32_t main_tile0, pad;   // first K1 tile of the VCF in the main batch
+  int32_t main_tile0, pad;   // first K1 tile of the VCF in the main batch; pad: the bucket path's shift (key >> pad = bucket)
+  int32_t bk_tile0, bk_cap;  // bucket path: first scatter tile (BK_TILE records) of the segment; entries per sub-region (a power of two)
 };
-// bucket path (k_classify_hash): one workgroup per (segment, bucket of the one scatter pass)
+// bucket path (k_bucket_scatter + k_classify_hash): one workgroup per (segment, bucket of the one scatter pass)
+#ifndef QM_BK_TILE
+#define QM_BK_TILE 4096
+#endif
+constexpr int BK_TILE = QM_BK_TILE;      // records per scatter workgroup (512 threads)
 constexpr int HB_BUCKETS = 256;
-constexpr int HB_MAX_RECORDS = 8188;     // records per bucket (16 per thread of the bucket's workgroup, kept in registers between its two passes)
+constexpr int HB_SUBS = 8;               // sub-regions of a bucket: tile g of the scatter launch fills sub-region g % 8 (one per XCD)
+constexpr int HB_SUB_MAX = 1024;         // entries per sub-region at most
+constexpr int HB_MAX_RECORDS = HB_SUBS * HB_SUB_MAX;   // records per bucket (16 per thread of the bucket's workgroup, kept in registers between its two passes)
 constexpr int HB_TRUTH_SLOTS = 2048;     // truth keys of the bucket's positions (<= 50 % full)
 constexpr int HB_NOKEY_SLOTS = 512;      // kept records without a comparable key
+constexpr int HB_INDEX_BITS = 21;        // a bucket entry holds the record's index inside its VCF
+// a bucket entry (8 bytes): key - (bucket << shift) in bits 0..23, info bits 0..11 (bin + 1, PASS, IDDOT, NOKEY) in 24..35,
+// the host-decided TP-line bit in 36, the record's index inside the VCF in 37..57
+struct BucketScatterParams {
+  const SortSeg* segs;
+  const int32_t* tile_seg;    // segment of every scatter tile
+  const int32_t* pos;
+  const int32_t* ref;
+  const int32_t* alt;
+  const float* qual;
+  const uint8_t* flags;
+  uint32_t* cursor;           // [n_seg][256][8] entries written so far, then [n_seg] flag words (SPANF_*); zeroed before the launch
+  uint64_t* ent;
+  uint32_t* mask_pass;        // main batch, as 32-bit words: the kept mask is written here, the TP mask cleared
+  uint32_t* mask_tp;
+  int32_t n_seg;
+  int32_t n_bins;
+};
+// everything k_classify_hash needs to know about one (segment, bucket), laid out by k_bucket_rows before it runs: the
+// workgroup of a bucket lives only a few microseconds, and every dependent load on its way to the data (segment table ->
+// VCF -> truth set -> position index -> keys) would cost it one memory round trip with nothing else to do
+struct HashRow {
+  const uint64_t* ent;        // the bucket's [8][cap] entries
+  const uint32_t* tkeys;      // the truth keys of the bucket's positions (a superset: whole cells of the coarse position index)
+  int64_t src_off;            // first record of the VCF in the main batch
+  int32_t tn;                 // how many
+  uint32_t cap;               // entries per sub-region
+  uint32_t shift;             // key >> shift = bucket
+  uint32_t pad;
+};
 struct HashParams {
   const SortSeg* segs;
-  const uint32_t* keys;       // bucketed (key, info) pairs at SortSeg.dst_off, original index at SortSeg.koff
-  const uint32_t* infs;
-  const uint32_t* perm;
-  const uint32_t* hist;       // scanned [256][ntiles] tables of the scatter pass: the bucket boundaries
+  const HashRow* rows;        // [n_seg * 256]
+  HashRow* rows_out;          // the same, for k_bucket_rows
+  const uint64_t* ent;
+  const uint32_t* cursor;
   const TruthDev* truths;
   const VcfDesc* vcfs;        // main batch (truth set of a segment's VCF)
   uint64_t* mask_tp;          // main batch: TP bits in input order (cleared by the scatter pass)
   uint32_t* row_hist;         // [n_seg * 256][SPAN_HIST_WORDS]
   uint32_t* row_scal;         // [n_seg * 256][8]
+  int32_t n_seg;
   int32_t n_bins;
 };
 struct SortCols { const int32_t* pos; const int32_t* ref; const int32_t* alt; const float* qual; const uint8_t* flags; };
@@ -275,6 +314,8 @@ void launch_compact(const CompactParams& P, int n_spans, hipStream_t st);
 void launch_masks_to_cls(const uint64_t* mp, const uint64_t* mt, int64_t off, int64_t n, uint8_t* cls, hipStream_t st);
 void launch_synth(const SynthParams& S, int n_vcf, int64_t max_n, hipStream_t st);
 void launch_classify_hash(const HashParams& P, int nseg, hipStream_t st);
+void launch_bucket_rows(const HashParams& P, int nseg, hipStream_t st);
+void launch_bucket_scatter(const BucketScatterParams& P, int ntiles, hipStream_t st);
 void launch_sort_first_hist(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const int32_t* pos_col, uint32_t* hist, uint32_t* orbits,
                             hipStream_t st, int msd = 0);
 void launch_sort_first_scatter(const SortSeg* segs, const int32_t* tile_seg, int nseg, int ntiles, const SortCols& src, int n_bins, int ext,

@@ -1441,14 +1441,148 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
 
 
 // ---------------------------------------------------------------------------
-// k_classify_hash -- the bucket path for unsorted VCFs: no sort inside a bucket.
+// The bucket path for unsorted VCFs: no sort at all.
 //
-// ONE scatter pass (the segment's top eight position bits in use) has put every record of a position range into one
-// bucket, in no particular order.  Everything the sorted kernel gets from order -- which records sit at a truth key's
-// position, which kept keys repeat -- a bucket gets from small tables in LDS, because all records of one position
-// (hence all equal keys, and all matches of a truth key) are in the same bucket.  The common path of a record is
-// three LDS operations without a loop (the first version probed open-addressing tables with compare-and-swap loops
-// per record and spent 2.65 ms of its 3.3 ms per 2.56e8 records in dependent LDS round trips):
+// k_bucket_scatter: ONE pass over the columns puts every live record, packed to 8 bytes (qmvt_dev.h "bucket entry"), into
+// the bucket of its position range (the segment's top eight position bits in use).  Nothing downstream needs an order
+// inside a bucket, so there is no histogram pass, no scan and no stable ranking: a tile counts its digits in LDS with one
+// returning atomic per record, reserves room for each digit's run with ONE global atomic on the bucket's cursor, reorders
+// the tile by digit in LDS and writes every run as one contiguous piece.  Bucket regions have a fixed capacity (what
+// k_classify_hash can hold anyway); a bucket has eight sub-regions with a cursor each, and tile g of the launch fills
+// sub-region g % 8: workgroups go round-robin to the eight XCDs, so all pieces of a sub-region come from ONE XCD, whose
+// L2 merges neighbouring pieces into whole lines before they leave for HBM.  The kernel has every record's info in
+// input order in hand: it also writes the VCF's kept mask (kept = live and PASS needs no truth set) and clears its TP mask.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_bucket_scatter(BucketScatterParams P) {
+  constexpr int PER = BK_TILE / 512;          // records per thread, in groups of four consecutive ones
+  static_assert(BK_TILE % 2048 == 0 && PER >= 4, "whole 16-byte loads, 256 records per wave and group");
+  __shared__ uint32_t s_cnt[256];             // records of digit d in the tile (running during the ranking)
+  __shared__ uint32_t s_loc[256];             // tile-local start of digit d's run
+  __shared__ int32_t s_glob[256];             // place of digit d's run in its sub-region, minus s_loc[d]
+  __shared__ uint32_t s_scan[5];
+  __shared__ uint64_t s_e[BK_TILE];
+  __shared__ uint8_t s_d[BK_TILE];
+  const int bid = (int)blockIdx.x;
+  const int seg = P.tile_seg[bid];
+  const SortSeg sg = P.segs[seg];
+  const int sub = bid & (HB_SUBS - 1);
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 256) s_cnt[tid] = 0u;
+  __syncthreads();
+  const int64_t tbase = (int64_t)(bid - sg.bk_tile0) * BK_TILE;
+  const uint32_t shift = (uint32_t)sg.pad;
+  uint64_t ent[PER];
+  uint32_t dr[PER];   // digit << 16 | rank inside the tile's digit; 0xffffffff: the record is not live
+  uint32_t segfl = 0;
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4i p[PER / 4], r[PER / 4], a[PER / 4];
+  v4f q[PER / 4];
+  uint32_t f[PER / 4];
+#pragma unroll
+  for (int j = 0; j < PER / 4; ++j) {   // all loads first: whole 16-byte pieces, the columns are padded past every VCF
+    const int64_t i4 = tbase + (int64_t)j * 2048 + tid * 4;
+    f[j] = 0u;
+    if (i4 < sg.n) {
+      const int64_t g = sg.src_off + i4;
+      p[j] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(P.pos + g));
+      r[j] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(P.ref + g));
+      a[j] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(P.alt + g));
+      q[j] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(P.qual + g));
+      f[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(P.flags + g));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PER / 4; ++j) {
+    const int64_t i4 = tbase + (int64_t)j * 2048 + tid * 4;
+    uint32_t kept = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = 4 * j + u;
+      dr[k] = 0xffffffffu;
+      ent[k] = 0ull;
+      if (i4 + u < sg.n) {
+        uint32_t key, inf;
+        pack_record<false>(p[j][u], r[j][u], a[j][u], q[j][u], f[j] >> (8 * u), P.n_bins, key, inf);
+        segfl |= (inf & I_BADPOS) ? SPANF_BADPOS : 0u;
+        if (inf & I_LIVE) {
+          kept |= ((inf >> 16) & 1u) << u;
+          const uint32_t d = key >> shift;
+          if (d >= (uint32_t)HB_BUCKETS) {
+            segfl |= SPANF_OVERFLOW;   // a position above what the optimistic pass saw of this VCF: the radix sort redoes it
+          } else {
+            const uint32_t v = key - (d << shift);   // < 2^24: shift <= 24
+            ent[k] = (uint64_t)v | ((uint64_t)((inf & 0xfffu) | ((inf >> 12) & 0x1000u)) << 24) | ((uint64_t)(uint32_t)(i4 + u) << 37);
+            dr[k] = (d << 16) | atomicAdd(&s_cnt[d], 1u);
+          }
+        }
+      }
+    }
+    // natural-order mask words: 8 lanes x 4 records = one 32-bit word
+    const uint32_t wp = or_reduce8(kept << (4u * (uint32_t)(lane & 7)));
+    const int64_t w0 = i4 - 4 * (lane & 7);   // first record of the word
+    if ((lane & 7) == 7 && w0 < sg.n) {
+      P.mask_pass[(sg.src_off + w0) >> 5] = wp;
+      P.mask_tp[(sg.src_off + w0) >> 5] = 0u;
+    }
+  }
+  if (segfl) atomicOr(&P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg], segfl);
+  __syncthreads();
+  // thread d: exclusive scan over the digit counts = tile-local run starts; room for the run in the bucket's sub-region
+  uint32_t cnt = 0, incl = 0;
+  if (tid < 256) {
+    cnt = s_cnt[tid];
+    incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_up(incl, o);
+      if (lane >= o) incl += y;
+    }
+    if (lane == 63) s_scan[wave] = incl;
+  }
+  __syncthreads();
+  if (tid < 256) {
+    uint32_t woff = 0;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) woff += w < wave ? s_scan[w] : 0u;
+    const uint32_t loc = woff + incl - cnt;
+    s_loc[tid] = loc;
+    uint32_t g = 0;
+    if (cnt) {
+      g = atomicAdd(&P.cursor[((size_t)seg * HB_BUCKETS + tid) * HB_SUBS + sub], cnt);
+      if (g + cnt > (uint32_t)sg.bk_cap) atomicOr(&P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg], SPANF_OVERFLOW);
+    }
+    s_glob[tid] = (int32_t)g - (int32_t)loc;
+    if (tid == 255) s_scan[4] = loc + cnt;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    if (dr[k] != 0xffffffffu) {
+      const uint32_t d = dr[k] >> 16;
+      const uint32_t lp = s_loc[d] + (dr[k] & 0xffffu);
+      s_e[lp] = ent[k];
+      s_d[lp] = (uint8_t)d;
+    }
+  }
+  __syncthreads();
+  const int total = (int)s_scan[4];
+  uint64_t* out = P.ent + sg.bk_off;
+  for (int idx = tid; idx < total; idx += 512) {
+    const uint32_t d = s_d[idx];
+    const int32_t w = s_glob[d] + idx;
+    if (w < sg.bk_cap) out[((size_t)d * HB_SUBS + sub) * (size_t)sg.bk_cap + (size_t)w] = s_e[idx];   // beyond: the VCF is flagged and redone
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_classify_hash -- the join of one bucket, without an order inside it.
+//
+// Everything the sorted kernel gets from order -- which records sit at a truth key's position, which kept keys repeat --
+// a bucket gets from small tables in LDS, because all records of one position (hence all equal keys, and all matches of a
+// truth key) are in the same bucket.  The common path of a record is three LDS operations without a loop (the first
+// version probed open-addressing tables with compare-and-swap loops per record and spent 2.65 ms of its 3.3 ms per
+// 2.56e8 records in dependent LDS round trips):
 //   * truth keys: an exact table (key -> slot; state: best bin of a '.'-ID match, matched-by-kept bit) behind a
 //     16 K-bit filter -- one LDS read tells 9 records in 10 that they match nothing;
 //   * distinct kept keys outside the truth set (FP_R): a 64 K-bit map, one fetch-OR per record.  A key whose bit was
@@ -1459,7 +1593,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
 // One workgroup of 512 threads per (segment, bucket), 16 records per thread at most, 46 KB of LDS, three workgroups per
 // CU.  TP bits go straight to the main batch's TP mask in input order (one 64-bit atomic OR per true positive); the
 // bucket's histograms and scalars are a "span" row that k_finalize sums exactly like the rows of k_classify.  A bucket
-// that does not fit (more than HB_MAX_RECORDS records, 1 024 truth keys, ...) flags the VCF: the radix sort redoes it.
+// that does not fit (a full sub-region, 1 024 truth keys, ...) flags the VCF: the radix sort redoes it.
 // ---------------------------------------------------------------------------
 constexpr uint32_t HB_EMPTY = 0xffffffffu;
 __device__ __forceinline__ uint32_t hb_hash(uint32_t v) { return v * 0x9e3779b1u; }
@@ -1485,11 +1619,56 @@ __device__ __forceinline__ int hb_find(const uint32_t* tab, uint32_t log2n, uint
   }
 }
 
-__global__ __launch_bounds__(512) void k_classify_hash(HashParams P) {
+// one descriptor per (segment, bucket) for k_classify_hash (qmvt_dev.h HashRow): grid = segments, thread = bucket
+__global__ __launch_bounds__(HB_BUCKETS) void k_bucket_rows(HashParams P) {
+  const SortSeg sg = P.segs[blockIdx.x];
+  const TruthDev tr = P.truths[P.vcfs[sg.main_vcf].truth];
+  const uint32_t d = threadIdx.x, shift = (uint32_t)sg.pad;
+  const uint32_t plo = (d << shift) >> 4;
+  const uint32_t phi = (((d + 1u) << shift) - 1u) >> 4;   // d + 1 = 256 with shift = 24 wraps to 0 - 1: the top of the key space
+  uint32_t ba = plo >> tr.shift, bb = (phi >> tr.shift) + 1u;
+  const uint32_t lim = (uint32_t)tr.nb + 1u;
+  ba = ba < lim ? ba : lim; bb = bb < lim ? bb : lim;
+  const int lo = tr.tidx[ba], hi = tr.tidx[bb];
+  HashRow R;
+  R.ent = P.ent + sg.bk_off + (size_t)d * HB_SUBS * (size_t)sg.bk_cap;
+  R.tkeys = tr.keys + lo;
+  R.src_off = sg.src_off;
+  R.tn = hi - lo;
+  R.cap = (uint32_t)sg.bk_cap;
+  R.shift = shift;
+  R.pad = 0u;
+  P.rows_out[(size_t)blockIdx.x * HB_BUCKETS + d] = R;
+}
+
+constexpr int HB_THREADS = 512;
+// A place in a list (or a budget) for every lane that wants one, with ONE returning atomic per wave.  A wave of returning
+// atomics on one LDS address takes ~450 cycles (tools/probe/lds_atomic_probe.hip: 0.14 lane-ops per clock, against 10 on
+// random addresses), during which the CU's LDS serves nobody else.  Call with the whole wave active or from a divergent
+// branch (the lanes outside simply do not want).
+__device__ __forceinline__ uint32_t wave_reserve(uint32_t* ctr, bool want) {
+  const uint64_t m = ballot64(want);
+  if (m == 0ull) return 0u;
+  const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+  const uint32_t rank = __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+  uint32_t base = 0u;
+  if (want && rank == 0u) base = atomicAdd(ctr, (uint32_t)__popc(lo) + (uint32_t)__popc(hi));
+  base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(m));
+  return base + rank;
+}
+#ifdef HB_PROFILE   // phase clocks of wave 0 (s_memtime), summed in 16-tick units behind the segment flags
+#define HB_TICK(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(hb_prof + (i), (uint32_t)((t_ - hb_t) >> 4)); hb_t = t_; } } while (0)
+#else
+#define HB_TICK(i) do { } while (0)
+#endif
+// Waves of a bucket's workgroup meet at three barriers only and walk their records independently in between: versions that
+// split the record loop into workgroup-wide phases (filter pass, a queue of the filter-positive records settled with full
+// waves, ...) removed the divergent steps but put every wave in the same phase at the same time, and lost 20-40 %.
+__global__ __launch_bounds__(HB_THREADS) void k_classify_hash(HashParams P) {
   constexpr uint32_t LTR = 11, LNK = 9, LX = 11;       // exact tables: truth keys, keyless records, keys on marked bits
   constexpr uint32_t LTB = 14, LFB = 16;                 // bit maps: truth filter, kept keys
   constexpr int PER = 16;                                // records per thread at most: four trips of four
-  static_assert((1 << LTR) == HB_TRUTH_SLOTS && (1 << LNK) == HB_NOKEY_SLOTS && HB_MAX_RECORDS + 3 <= 512 * PER, "table sizes; a ragged first trip costs up to three slots");
+  static_assert((1 << LTR) == HB_TRUTH_SLOTS && (1 << LNK) == HB_NOKEY_SLOTS && HB_MAX_RECORDS <= HB_THREADS * PER, "table sizes");
   __shared__ uint32_t s_tk[1 << LTR];
   __shared__ uint32_t s_ts[1 << LTR];                // best bin + 1 of a '.'-ID match
   __shared__ uint32_t s_tf[(1 << LTR) / 32];         // matched by a kept record (ID ignored)
@@ -1502,45 +1681,87 @@ __global__ __launch_bounds__(512) void k_classify_hash(HashParams P) {
   __shared__ uint32_t s_c[8];                        // kept, TP lines, distinct FP keys, matched truth keys, flags, truth keys staged, keyless inserts, marked inserts
   const int tid = (int)threadIdx.x;
   const int d = (int)blockIdx.x;
-  const SortSeg sg = P.segs[blockIdx.y];
   const size_t row = (size_t)blockIdx.y * HB_BUCKETS + (size_t)d;
-  const uint32_t b = P.hist[sg.hoff + (size_t)d * sg.ntiles];
-  const uint32_t e = d + 1 < HB_BUCKETS ? P.hist[sg.hoff + (size_t)(d + 1) * sg.ntiles] : (uint32_t)sg.n;
-  const uint32_t nrec = e - b;
+#ifdef HB_PROFILE
+  uint32_t* hb_prof = const_cast<uint32_t*>(P.cursor) + (size_t)P.n_seg * HB_BUCKETS * HB_SUBS + (size_t)P.n_seg;
+  unsigned long long hb_t = __builtin_amdgcn_s_memtime();
+#endif
+  const HashRow R = P.rows[row];                                 // one scalar load beside the cursors: nothing below waits for more than
+  const uint32_t* cur = P.cursor + row * HB_SUBS;                // one further round trip (the entries and the truth keys, together)
+  const uint32_t segfl = d == 0 ? P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + blockIdx.y] : 0u;   // the segment's flags travel in its first row
+  const uint32_t cap = R.cap;
+  uint32_t nsub[HB_SUBS];     // wave-uniform (scalar loads)
+  uint32_t nrec = 0, over = 0;
+#pragma unroll
+  for (int k = 0; k < HB_SUBS; ++k) {
+    const uint32_t c = cur[k];
+    over |= c > cap ? 1u : 0u;
+    nsub[k] = c < cap ? c : cap;
+    nrec += nsub[k];
+  }
   if (nrec == 0u) {   // two buckets in five are empty (a genome rarely ends on a power of two): a row of zeros, nothing else
     uint32_t* oh0 = P.row_hist + row * SPAN_HIST_WORDS;
     if (tid < 3 * 128) oh0[tid] = 0u;
-    if (tid < 8) P.row_scal[row * 8 + tid] = 0u;
+    if (tid < 8) P.row_scal[row * 8 + tid] = tid == 5 ? segfl : 0u;
     return;
   }
-  for (int i = tid; i < (1 << LTR); i += 512) { s_tk[i] = HB_EMPTY; s_ts[i] = 0u; s_x[i] = HB_EMPTY; }
-  for (int i = tid; i < (1 << LFB) / 32; i += 512) { s_b1[i] = 0u; s_b2[i] = 0u; }
+#ifdef HB_PROFILE
+  if (threadIdx.x == 0) atomicAdd(hb_prof, 1u);
+#endif
+  // A trip gives every thread four consecutive entries of one sub-region (32 bytes, two 16-byte loads: dword loads are bound
+  // by the rate of memory instructions).  The first trip and the thread's truth key are in flight before the tables are
+  // even cleared; later trips are fetched one ahead.
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  const uint32_t lcap = 31u - (uint32_t)__clz(cap);            // cap is a power of two >= 4
+  const uint32_t nslots = (HB_SUBS * cap) >> 2;
+  v4u ea[2], eb[2];
+  uint32_t nv[2];            // valid entries of the trip's four
+  const v4u z4 = {0u, 0u, 0u, 0u};
+  auto fetch = [&](int g, int buf) {
+    const uint32_t slot = (uint32_t)g * HB_THREADS + (uint32_t)tid;
+    const uint32_t e0 = slot << 2, sb = e0 >> lcap, w = e0 & (cap - 1u);
+    uint32_t n = 0;
+#pragma unroll
+    for (int k = 0; k < HB_SUBS; ++k) n = sb == (uint32_t)k ? nsub[k] : n;
+    ea[buf] = z4; eb[buf] = z4; nv[buf] = 0u;
+    if (slot < nslots && w < n && !over) {
+      nv[buf] = n - w < 4u ? n - w : 4u;
+      const v4u* src = reinterpret_cast<const v4u*>(R.ent + e0);
+      ea[buf] = __builtin_nontemporal_load(src);
+      eb[buf] = __builtin_nontemporal_load(src + 1);
+    }
+  };
+  fetch(0, 0);
+  const uint32_t shift = R.shift;                            // >= 4: a bucket is a whole range of positions
+  const uint32_t kbase = (uint32_t)d << shift;               // every key of the bucket is >= kbase
+  const uint32_t klast = ((uint32_t)(d + 1) << shift) - 1u;  // d + 1 = 256 with shift = 24 wraps to 0 - 1: the top of the key space
+  uint32_t tkey0 = 0u;
+#ifndef HB_SKIP_TRUTH   // (timing builds only: phases of the kernel switched off, results wrong)
+  const int tn = over ? 0 : R.tn;
+#else
+  const int tn = 0;
+#endif
+  if (tid < tn) tkey0 = R.tkeys[tid];
+  for (int i = tid; i < (1 << LTR); i += HB_THREADS) { s_tk[i] = HB_EMPTY; s_ts[i] = 0u; s_x[i] = HB_EMPTY; }
+  for (int i = tid; i < (1 << LFB) / 32; i += HB_THREADS) { s_b1[i] = 0u; s_b2[i] = 0u; }
   if (tid < (1 << LTB) / 32) s_tb[tid] = 0u;
   if (tid < (1 << LTR) / 32) s_tf[tid] = 0u;
   if (tid < (1 << LNK)) s_nk[tid] = HB_EMPTY;
   if (tid < 3 * 128) s_h[tid] = 0u;
-  if (tid < 8) s_c[tid] = 0u;
+  if (tid < 8) s_c[tid] = tid == 4 ? (segfl | (over ? SPANF_OVERFLOW : 0u)) : 0u;
+  HB_TICK(1);
   __syncthreads();
-  const uint32_t shift = (uint32_t)sg.pad;                   // >= 4: a bucket is a whole range of positions
-  const uint32_t kbase = (uint32_t)d << shift;               // every key of the bucket is >= kbase (the last bucket also takes what lies above)
-  if (nrec > (uint32_t)HB_MAX_RECORDS) {
-    if (tid == 0) s_c[4] = SPANF_OVERFLOW;
-  }
-#ifndef HB_SKIP_TRUTH   // (timing builds only: phases of the kernel switched off, results wrong)
-  else if (nrec > 0) {
-    // ---- the truth keys of the bucket's positions, from the coarse position index ----
-    const TruthDev tr = P.truths[P.vcfs[sg.main_vcf].truth];
-    const uint32_t plo = kbase >> 4;
-    const uint32_t phi = d + 1 < HB_BUCKETS ? ((((uint32_t)(d + 1)) << shift) - 1u) >> 4 : 0x0fffffffu;
-    uint32_t ba = plo >> tr.shift, bb = (phi >> tr.shift) + 1u;
-    const uint32_t lim = (uint32_t)tr.nb + 1u;
-    ba = ba < lim ? ba : lim; bb = bb < lim ? bb : lim;
-    const int lo = tr.tidx[ba], hi = tr.tidx[bb];
-    for (int j = lo + tid; j < hi; j += 512) {
-      const uint32_t k = tr.keys[j];
-      const uint32_t kp = k >> 4;
-      if (kp >= plo && kp <= phi) {
-        if (atomicAdd(&s_c[5], 1u) >= (1u << LTR) / 2u) { atomicOr(&s_c[4], SPANF_OVERFLOW); break; }
+  HB_TICK(2);
+  // ---- the truth keys of the bucket's positions (the coarse position index hands out whole cells) ----
+  for (int j0 = 0; j0 < tn; j0 += HB_THREADS) {   // wave-uniform trip count
+    const int j = j0 + tid;
+    const uint32_t k = j >= tn ? 0u : j0 == 0 ? tkey0 : R.tkeys[j];
+    const bool in = j < tn && k >= kbase && k <= klast;
+    const uint32_t at = wave_reserve(&s_c[5], in);
+    if (in) {
+      if (at >= (1u << LTR) / 2u) {
+        atomicOr(&s_c[4], SPANF_OVERFLOW);
+      } else {
         bool fresh;
         const uint32_t v = k - kbase;
         (void)hb_insert(s_tk, LTR, v, &fresh);
@@ -1549,112 +1770,102 @@ __global__ __launch_bounds__(512) void k_classify_hash(HashParams P) {
       }
     }
   }
-#endif
+  HB_TICK(3);
   __syncthreads();
-  uint32_t n_pass = 0, n_tp = 0, fpr = 0, bad = 0;
+  HB_TICK(4);
+  uint32_t n_pass = 0, n_tp = 0, fpr = 0;
 #ifndef HB_SKIP_RECORDS
-  if (nrec > 0 && !(s_c[4] & SPANF_OVERFLOW)) {
-    const uint32_t* keys = P.keys + sg.dst_off;
-    const uint32_t* infs = P.infs + sg.dst_off;
-    const uint32_t* perm = P.perm + sg.koff;
+  if (!(s_c[4] & SPANF_OVERFLOW)) {
     unsigned long long* mtp = reinterpret_cast<unsigned long long*>(P.mask_tp);
     uint32_t vq[PER];          // the thread's records stay in registers for the second pass
     uint32_t cand = 0;         // bit k: record k is a kept key outside the truth set (with a comparable key)
-    // Four consecutive records per thread and trip, fetched with one 16-byte load per array (dword loads are bound by the
-    // rate of memory instructions), the next trip's loads in flight while this one is worked on.  Trips start at a multiple
-    // of four records: the bucket's first and last trip are ragged.
-    typedef unsigned v4u __attribute__((ext_vector_type(4)));
-    const uint32_t a0 = (b & ~3u) + 4u * (uint32_t)tid;
-    v4u kq[2], iq[2], pq[2];
-    const v4u z4 = {0u, 0u, 0u, 0u};
-    kq[0] = z4; iq[0] = z4; pq[0] = z4;
-    if (a0 < e) {
-      kq[0] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(keys + a0));
-      iq[0] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(infs + a0));
-      pq[0] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(perm + a0));
-    }
 #pragma unroll
     for (int g = 0; g < PER / 4; ++g) {
-      const uint32_t i0 = a0 + (uint32_t)g * 2048u;
-      if (g + 1 < PER / 4) {
-        const uint32_t i1 = i0 + 2048u;
-        kq[(g + 1) & 1] = z4; iq[(g + 1) & 1] = z4; pq[(g + 1) & 1] = z4;
-        if (i1 < e) {
-          kq[(g + 1) & 1] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(keys + i1));
-          iq[(g + 1) & 1] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(infs + i1));
-          pq[(g + 1) & 1] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(perm + i1));
-        }
-      }
+      if (g + 1 < PER / 4) fetch(g + 1, (g + 1) & 1);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const uint32_t i = i0 + (uint32_t)u;
-        const uint32_t inf = (i >= b && i < e) ? iq[g & 1][u] : 0u;   // records of the neighbouring buckets in a ragged trip take no part
-        const uint32_t v = kq[g & 1][u] - kbase;
+        const uint32_t elo = u == 0 ? ea[g & 1][0] : u == 1 ? ea[g & 1][2] : u == 2 ? eb[g & 1][0] : eb[g & 1][2];
+        const uint32_t ehi = u == 0 ? ea[g & 1][1] : u == 1 ? ea[g & 1][3] : u == 2 ? eb[g & 1][1] : eb[g & 1][3];
+        const uint32_t v = elo & 0xffffffu;
         vq[4 * g + u] = v;
-        bad |= inf & I_BADPOS;
-        if (!(inf & I_LIVE)) continue;                          // not a single-base record in range: in no file, in no histogram
+        if ((uint32_t)u >= nv[g & 1]) continue;
+        const uint32_t inf = (elo >> 24) | ((ehi & 0x1fu) << 8);     // bits 0..11 as in the info word, bit 12 = TP line
         const uint32_t b1 = inf & I_BIN1;
-        const bool kept = (inf & I_KEPT) != 0u, nokey = (inf & I_NOKEY) != 0u;
+        const bool kept = (inf & I_PASS) != 0u, nokey = (inf & I_NOKEY) != 0u;   // every entry is a live record
         const uint32_t hv = hb_hash(v);
         int t = -1;
         if (!nokey && ((s_tb[hv >> (37u - LTB)] >> ((hv >> (32u - LTB)) & 31u)) & 1u)) t = hb_find(s_tk, LTR, v);   // 9 in 10 stop at the filter
         const bool hit = t >= 0;
-        const bool tpl = (hit && (inf & I_IDDOT)) || (inf & I_TPLINE);
+        const bool tpl = (hit && (inf & I_IDDOT)) || (inf & 0x1000u);
         if (hit) {
           if ((inf & I_IDDOT) && b1) atomicMax(&s_ts[t], b1);
-          if (inf & I_PASS) atomicOr(&s_tf[t >> 5], 1u << (t & 31));
+          if (kept) atomicOr(&s_tf[t >> 5], 1u << (t & 31));
         }
         if (b1) atomicAdd(&s_h[(tpl ? 0 : 128) + ((b1 - 1u) >> 1)], 1u << (16u * ((b1 - 1u) & 1u)));
         if (kept) {
           ++n_pass;
           if (tpl) {
             ++n_tp;
-            const int64_t o = sg.src_off + (int64_t)pq[g & 1][u];
+            const int64_t o = R.src_off + (int64_t)(ehi >> 5);
             atomicOr(mtp + (o >> 6), 1ull << (o & 63));
           }
           if (!hit) {   // a kept key outside the truth set counts once per VCF
             if (nokey) {   // rare: an exact set of their own, every insertion reserved (a probe of a full table would not return)
-              if (atomicAdd(&s_c[6], 1u) >= (1u << LNK) / 2u) { atomicOr(&s_c[4], SPANF_OVERFLOW); continue; }
+              if (wave_reserve(&s_c[6], true) >= (1u << LNK) / 2u) { atomicOr(&s_c[4], SPANF_OVERFLOW); continue; }
               bool fresh;
               (void)hb_insert(s_nk, LNK, v, &fresh);
               fpr += fresh ? 1u : 0u;
             } else {
               cand |= 1u << (4 * g + u);
               const uint32_t h = hv >> (32u - LFB), bit = 1u << (h & 31u);
+#ifndef HB_SKIP_FPR
               if (atomicOr(&s_b1[h >> 5], bit) & bit) atomicOr(&s_b2[h >> 5], bit);   // seen before (or a collision): both meet again below
+#endif
             }
           }
         }
       }
     }
+    HB_TICK(5);
     __syncthreads();
+    HB_TICK(6);
     // second pass over the thread's own registers: keys on unmarked bits are distinct; keys on marked bits are counted exactly
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      if (!((cand >> k) & 1u)) continue;
       const uint32_t v = vq[k];
       const uint32_t h = hb_hash(v) >> (32u - LFB);
-      if (!((s_b2[h >> 5] >> (h & 31u)) & 1u)) { ++fpr; continue; }
-      if (atomicAdd(&s_c[7], 1u) >= (1u << LX) / 2u) { atomicOr(&s_c[4], SPANF_OVERFLOW); continue; }
-      bool fresh;
-      (void)hb_insert(s_x, LX, v, &fresh);
-      fpr += fresh ? 1u : 0u;
+      const bool c = ((cand >> k) & 1u) != 0u;
+      const bool marked = c && ((s_b2[h >> 5] >> (h & 31u)) & 1u);
+      fpr += (c && !marked) ? 1u : 0u;
+      const uint32_t at = wave_reserve(&s_c[7], marked);
+      if (marked) {
+        if (at >= (1u << LX) / 2u) {
+          atomicOr(&s_c[4], SPANF_OVERFLOW);
+        } else {
+          bool fresh;
+          (void)hb_insert(s_x, LX, v, &fresh);
+          fpr += fresh ? 1u : 0u;
+        }
+      }
     }
   }
 #endif
+  HB_TICK(7);
   // ---- bucket epilogue: per-entry state -> U histogram and TP_R, counters, the row ----
   atomicAdd(&s_c[0], n_pass); atomicAdd(&s_c[1], n_tp); atomicAdd(&s_c[2], fpr);
-  if (bad) atomicOr(&s_c[4], SPANF_BADPOS);
   __syncthreads();
+  HB_TICK(8);
   uint32_t tpr = 0;
-  for (int t = tid; t < (1 << LTR); t += 512) {
+  for (int t = tid; t < (1 << LTR); t += HB_THREADS) {
     if (s_tk[t] == HB_EMPTY) continue;
     const uint32_t mx = s_ts[t];
     if (mx) atomicAdd(&s_h[256 + ((mx - 1u) >> 1)], 1u << (16u * ((mx - 1u) & 1u)));
     tpr += (s_tf[t >> 5] >> (t & 31)) & 1u;
   }
   if (tpr) atomicAdd(&s_c[3], tpr);
+  HB_TICK(9);
   __syncthreads();
+  HB_TICK(10);
   uint32_t* oh = P.row_hist + row * SPAN_HIST_WORDS;
   if (tid < 3 * 128) oh[tid] = s_h[tid];
   if (tid == 0) {
@@ -1662,6 +1873,7 @@ __global__ __launch_bounds__(512) void k_classify_hash(HashParams P) {
     const uint32_t fl = s_c[4];
     sc[0] = s_c[0]; sc[1] = s_c[1]; sc[2] = s_c[0] - s_c[1]; sc[3] = s_c[3]; sc[4] = s_c[2]; sc[5] = fl; sc[6] = 0u; sc[7] = 0u;
   }
+  HB_TICK(11);
 }
 
 // TP bits of the sorted scratch VCFs back to input order: only the records that ARE true positives
@@ -1870,7 +2082,13 @@ void launch_sort_copy_rows(const SortSeg* segs, int nseg, const uint64_t* sub_ro
   if (nseg > 0) hipLaunchKernelGGL(k_sort_copy_rows, dim3(nseg), dim3(256), 0, st, segs, sub_roc, sub_scal, roc, scal, n_bins, global_add, vcfs);
 }
 void launch_classify_hash(const HashParams& P, int nseg, hipStream_t st) {
-  if (nseg > 0) hipLaunchKernelGGL(k_classify_hash, dim3(HB_BUCKETS, nseg), dim3(512), 0, st, P);
+  if (nseg > 0) hipLaunchKernelGGL(k_classify_hash, dim3(HB_BUCKETS, nseg), dim3(HB_THREADS), 0, st, P);
+}
+void launch_bucket_rows(const HashParams& P, int nseg, hipStream_t st) {
+  if (nseg > 0) hipLaunchKernelGGL(k_bucket_rows, dim3(nseg), dim3(HB_BUCKETS), 0, st, P);
+}
+void launch_bucket_scatter(const BucketScatterParams& P, int ntiles, hipStream_t st) {
+  if (ntiles > 0) hipLaunchKernelGGL(k_bucket_scatter, dim3(ntiles), dim3(512), 0, st, P);
 }
 void launch_overlap_pack(const int32_t* pos, const int32_t* ref, const int32_t* alt, const int32_t* set_of, int64_t n,
                          uint32_t* keys, uint32_t* vals, uint32_t* bad, hipStream_t st) {
