@@ -810,13 +810,6 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   const int nst = (int)tile_seg.size(), nkt = (int)ktile_seg.size();
   int rc = QM_OK;
   int64_t cap;
-  for (int i = 0; i < 2 && rc == QM_OK; ++i) {
-    cap = b->cap_sort_n; rc = regrow(&b->sk[i], &cap, koff, &b->dev_bytes);
-    if (rc == QM_OK) { cap = b->cap_sort_n; rc = regrow(&b->sv[i], &cap, koff, &b->dev_bytes); }
-    if (rc == QM_OK) { cap = b->cap_sort_n; rc = regrow(&b->si[i], &cap, koff, &b->dev_bytes); }
-  }
-  if (rc == QM_OK) b->cap_sort_n = std::max(b->cap_sort_n, koff);
-  if (rc == QM_OK) rc = regrow(&b->shist, &b->cap_sort_hist, hoff, &b->dev_bytes);
   if (rc == QM_OK) { cap = b->cap_segs; rc = regrow(&b->d_segs, &cap, (int64_t)nseg, &b->dev_bytes); b->cap_segs = (int)cap; }
   if (rc == QM_OK) { cap = b->cap_stiles; rc = regrow(&b->d_tile_seg, &cap, (int64_t)nst, &b->dev_bytes); b->cap_stiles = (int)cap; }
   if (rc == QM_OK) {
@@ -914,7 +907,15 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   }
   // --- 1. + 2. stable LSD radix sort by position (key bits 4..31), only the digits in use.  The first pass packs the
   //        records to (key, info, original index) on the fly; the last pass drops keys and infos straight into the
-  //        scratch batch.
+  //        scratch batch.  (Its ping-pong arrays exist only once a chunk has come this way.)
+  for (int i = 0; i < 2 && rc == QM_OK; ++i) {
+    cap = b->cap_sort_n; rc = regrow(&b->sk[i], &cap, koff, &b->dev_bytes);
+    if (rc == QM_OK) { cap = b->cap_sort_n; rc = regrow(&b->sv[i], &cap, koff, &b->dev_bytes); }
+    if (rc == QM_OK) { cap = b->cap_sort_n; rc = regrow(&b->si[i], &cap, koff, &b->dev_bytes); }
+  }
+  if (rc == QM_OK) b->cap_sort_n = std::max(b->cap_sort_n, koff);
+  if (rc == QM_OK) rc = regrow(&b->shist, &b->cap_sort_hist, hoff, &b->dev_bytes);
+  if (rc != QM_OK) return rc;
   launch_sort_first_hist(b->d_segs, b->d_tile_seg, nst, b->pos, b->shist, b->sorbits, st);
   uint32_t orbits = 0;
   HIPCHK(hipMemcpyAsync(&orbits, b->sorbits, 4, hipMemcpyDeviceToHost, st));

@@ -317,10 +317,10 @@ void launch_classify_hash(const HashParams& P, int nseg, hipStream_t st);
 void launch_bucket_rows(const HashParams& P, int nseg, hipStream_t st);
 void launch_bucket_scatter(const BucketScatterParams& P, int ntiles, hipStream_t st);
 void launch_sort_first_hist(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const int32_t* pos_col, uint32_t* hist, uint32_t* orbits,
-                            hipStream_t st, int msd = 0);
+                            hipStream_t st);
 void launch_sort_first_scatter(const SortSeg* segs, const int32_t* tile_seg, int nseg, int ntiles, const SortCols& src, int n_bins, int ext,
                                uint32_t* hist, uint32_t* okeys, uint32_t* oinfs, uint32_t* ovals, int final_dst, uint64_t* mask_pass,
-                               uint64_t* mask_tp, hipStream_t st, int msd = 0);
+                               uint64_t* mask_tp, hipStream_t st);
 void launch_sort_gather_alleles(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const uint32_t* perm, const int32_t* src_ref,
                                 const int32_t* src_alt, int32_t* dst_ref, int32_t* dst_alt, hipStream_t st);
 void launch_sort_pass(const SortSeg* segs, const int32_t* tile_seg, int nseg, int ntiles, const uint32_t* keys, const uint32_t* infs,

@@ -1172,14 +1172,8 @@ __device__ __forceinline__ int xcd_contiguous_block() {
 #endif
 }
 
-// The digit of a key in one pass.  shift >= 0: a pass of the LSD sort, 8 bits at `shift`.  shift < 0: the ONE pass of the
-// bucket path -- the segment's own shift (SortSeg.pad: its top eight position bits in use, estimated from what the
-// optimistic pass saw), everything above them clamped into the last bucket.
-__device__ __forceinline__ uint32_t digit_of(uint32_t key, int shift, int seg_shift) {
-  if (shift >= 0) return (key >> shift) & 255u;
-  const uint32_t d = key >> seg_shift;
-  return d < 255u ? d : 255u;
-}
+// the digit of a key in one pass of the LSD sort: 8 bits at `shift`
+__device__ __forceinline__ uint32_t digit_of(uint32_t key, int shift) { return (key >> shift) & 255u; }
 
 // per-tile digit histogram of a segment: hist[hoff + digit * ntiles + tile]
 // FIRST: the first pass reads the position column itself (key bits >= 4 are the position) and also collects the OR of
@@ -1208,10 +1202,10 @@ __global__ __launch_bounds__(256) void k_sort_hist(const SortSeg* segs, const in
       } else {
         v = *reinterpret_cast<const uint4*>(keys + sg.koff + i);
       }
-      atomicAdd(&s[digit_of(v.x, shift, sg.pad)], 1u);
-      if (i + 1 < sg.n) atomicAdd(&s[digit_of(v.y, shift, sg.pad)], 1u);
-      if (i + 2 < sg.n) atomicAdd(&s[digit_of(v.z, shift, sg.pad)], 1u);
-      if (i + 3 < sg.n) atomicAdd(&s[digit_of(v.w, shift, sg.pad)], 1u);
+      atomicAdd(&s[digit_of(v.x, shift)], 1u);
+      if (i + 1 < sg.n) atomicAdd(&s[digit_of(v.y, shift)], 1u);
+      if (i + 2 < sg.n) atomicAdd(&s[digit_of(v.z, shift)], 1u);
+      if (i + 3 < sg.n) atomicAdd(&s[digit_of(v.w, shift)], 1u);
     }
   }
   __syncthreads();
@@ -1377,7 +1371,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
       vv[s] = valid ? stV[s * 64 + lane] : 0u;
       ii[s] = valid ? stI[s * 64 + lane] : 0u;
     }
-    const uint32_t d = digit_of(kk[s], shift, sg.pad);
+    const uint32_t d = digit_of(kk[s], shift);
     // peers = valid lanes with my digit.  Kept as two 32-bit halves and accumulated as "differs from me in some bit":
     // per bit one sign-extending bit-field extract (0 / -1), one ballot, two XORs, two ORs -- the 64-bit select form
     // the compiler made of `peers &= bit ? m : ~m` took nine VALU per bit, and this kernel is VALU-bound.
@@ -1422,7 +1416,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
   for (int s = 0; s < STEPS; ++s) {
     const int64_t i = wbase + s * 64 + lane;
     if (i < sg.n) {
-      const uint32_t d = digit_of(kk[s], shift, sg.pad);
+      const uint32_t d = digit_of(kk[s], shift);
       const uint32_t lp = s_cnt[wave][d] + rk[s];
       s_k[lp] = kk[s]; s_i[lp] = ii[s]; s_v[lp] = vv[s];
     }
@@ -1432,7 +1426,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
   const int64_t kbase = final_dst ? sg.dst_off : sg.koff;
   for (int idx = tid; idx < nvalid; idx += 256) {
     const uint32_t k = s_k[idx];
-    const uint32_t g = s_glob[digit_of(k, shift, sg.pad)] + (uint32_t)idx;
+    const uint32_t g = s_glob[digit_of(k, shift)] + (uint32_t)idx;
     okeys[kbase + g] = k;
     if (FIRST || infs) oinfs[kbase + g] = s_i[idx];
     ovals[sg.koff + g] = s_v[idx];
@@ -2039,17 +2033,17 @@ void launch_synth(const SynthParams& S, int n_vcf, int64_t max_n, hipStream_t st
 }
 // first pass of the batch's sort, in two steps because the host needs the OR of the keys in between
 void launch_sort_first_hist(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const int32_t* pos_col, uint32_t* hist, uint32_t* orbits,
-                            hipStream_t st, int msd) {   // msd: the bucket path's one pass (per-segment shift, SortSeg.pad)
+                            hipStream_t st) {
   if (ntiles > 0)
-    hipLaunchKernelGGL((k_sort_hist<true>), dim3(ntiles), dim3(256), 0, st, segs, tile_seg, (const uint32_t*)nullptr, msd ? -1 : 4, hist, pos_col, orbits);
+    hipLaunchKernelGGL((k_sort_hist<true>), dim3(ntiles), dim3(256), 0, st, segs, tile_seg, (const uint32_t*)nullptr, 4, hist, pos_col, orbits);
 }
 void launch_sort_first_scatter(const SortSeg* segs, const int32_t* tile_seg, int nseg, int ntiles, const SortCols& src, int n_bins, int ext,
                                uint32_t* hist, uint32_t* okeys, uint32_t* oinfs, uint32_t* ovals, int final_dst, uint64_t* mask_pass,
-                               uint64_t* mask_tp, hipStream_t st, int msd) {
+                               uint64_t* mask_tp, hipStream_t st) {
   if (ntiles <= 0) return;
   hipLaunchKernelGGL(k_sort_scan, dim3(nseg), dim3(256), 0, st, segs, hist);
   hipLaunchKernelGGL((k_sort_scatter<true>), dim3(ntiles), dim3(256), 0, st, segs, tile_seg, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
-                     (const uint32_t*)nullptr, msd ? -1 : 4, hist, okeys, oinfs, ovals, final_dst, src, n_bins, ext, mask_pass, mask_tp);
+                     (const uint32_t*)nullptr, 4, hist, okeys, oinfs, ovals, final_dst, src, n_bins, ext, mask_pass, mask_tp);
 }
 void launch_sort_gather_alleles(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const uint32_t* perm, const int32_t* src_ref,
                                 const int32_t* src_alt, int32_t* dst_ref, int32_t* dst_alt, hipStream_t st) {
