@@ -62,10 +62,10 @@ def main():
                     help="records timed through the CPU oracle on rank 0 (N=1 only); 0 disables")
     ap.add_argument("--shell-sample", type=int, default=int(os.environ.get("QM_BENCH_SHELL_VCFS", "3")),
                     help="VCFs timed through the reference's own mechanism (awk + fgrep pipeline) on rank 0 (N=1, config 2 only); 0 disables")
-    ap.add_argument("--shuffled", action="store_true", help="records permuted: every VCF takes the radix-sort path")
-    ap.add_argument("--shuffled-vcfs", type=int, default=int(os.environ.get("QM_BENCH_SHUFFLED_VCFS", "128")),
-                    help="also time the shuffled variant (radix-sort path) on this many VCFs at N=1, config 2; 0 disables")
-    ap.add_argument("--alleles-vcfs", type=int, default=int(os.environ.get("QM_BENCH_ALLELES_VCFS", "512")),
+    ap.add_argument("--shuffled", action="store_true", help="records permuted: every VCF takes the path of the unsorted ones (buckets, radix sort behind them)")
+    ap.add_argument("--shuffled-vcfs", type=int, default=int(os.environ.get("QM_BENCH_SHUFFLED_VCFS", "256")),
+                    help="also time the shuffled variant (bucket path) on this many VCFs at N=1, config 2; 0 disables")
+    ap.add_argument("--alleles-vcfs", type=int, default=int(os.environ.get("QM_BENCH_ALLELES_VCFS", "1000")),
                     help="also time the allele-extended variant (config 4's record shape) on this many VCFs at N=1, config 2; 0 disables")
     ap.add_argument("--check-vcfs", type=int, default=2, help="VCFs of this rank's batch checked against the oracle after the timed region (N > 1 and configs 3 / 4)")
     args = ap.parse_args()

@@ -627,3 +627,64 @@ def test_error_behaviour_of_the_abi(engine):
     h = C.c_void_p()
     assert L.qm_init(99, C.byref(h)) == -1 and b"out of range" in L.qm_last_error(None)
     assert code(lambda: engine.fp_overlap([(np.zeros(1, np.int32),) * 3] * 6)) == -1                    # more than 5 sets
+
+
+def test_truth_builder_feeds_the_gpu_path(engine, oracle, tmp_path):
+    """SURVEY f-2 end to end on the device: a `show-snps -CTHlr` table (SNVs, same-position SNVs that fold into a
+    multi-allelic row, insertion and deletion runs, N bases) -> quasimodo_amd.mummer2vcf (the restatement of
+    program/mummer2vcf.py: genome_diff.smk:22-24) -> `<sample>.maskrepeat.variants.vcf` -> extractTP on the GPU,
+    byte for byte what the oracle's awk / fgrep restatement makes of the same two files."""
+    import quasimodo_amd as q
+    from quasimodo_amd.extract import Job
+    from quasimodo_amd.mummer2vcf import convert
+    rng = np.random.default_rng(11)
+    L = 60_000
+    bases = np.array(list("ACGT"))
+    seq = "".join(bases[rng.integers(0, 4, L)])
+    fa = tmp_path / "ref.fa"
+    fa.write_text(">Merlin\n" + "\n".join(seq[i:i + 70] for i in range(0, L, 70)) + "\n")
+    rows, p2 = [], 1
+    for p in np.sort(rng.choice(np.arange(2, L - 2), 6000, replace=False)):
+        ref = seq[p - 1]
+        kind = rng.random()
+        p2 += 7
+        col = lambda a, b, c: "\t".join([str(a), b, c, str(p2), "5", "100", str(L), str(L), "1", "1", "Merlin", "qry"]) + "\n"
+        if kind < 0.80:                      # SNV, sometimes a second allele at the same place, sometimes an N
+            alt = "ACGT"[("ACGT".index(ref) + int(rng.integers(1, 4))) & 3]
+            rows.append(col(p, ref, "N" if kind < 0.02 else alt))
+            if kind > 0.74:
+                rows.append(col(p, ref, "ACGT"[("ACGT".index(alt) + 1) & 3] if "ACGT"[("ACGT".index(alt) + 1) & 3] != ref else alt))
+        elif kind < 0.90:                    # insertion run: '.' in the reference column, consecutive query positions
+            for k in range(int(rng.integers(1, 4))):
+                rows.append(col(p, ".", "ACGT"[int(rng.integers(0, 4))]))
+                p2 += 1
+        else:                                # deletion: '.' in the query column
+            rows.append(col(p, ref, "."))
+    truth_text = ("\n".join(convert(rows, reference=str(fa), no_ns=True, output_header=True)) + "\n").encode()
+    tpath = tmp_path / "TM.maskrepeat.variants.vcf"
+    tpath.write_bytes(truth_text)
+    tk = q.scan_truth(truth_text)
+    assert tk.n_refused == 0 and len(tk.pos) > 3000
+    # a caller's VCF over the same genome: half of its records on truth SNVs, PASS and non-PASS, sorted
+    n = 20_000
+    pos = np.sort(np.where(rng.random(n) < 0.5, tk.pos[rng.integers(0, len(tk.pos), n)], rng.integers(1, L + 1, n)))
+    j = np.searchsorted(tk.pos, pos).clip(0, len(tk.pos) - 1)
+    on = tk.pos[j] == pos
+    ref = np.where(on, tk.ref[j], rng.integers(0, 4, n))
+    alt = np.where(on & (rng.random(n) < 0.85), tk.alt[j], (ref + rng.integers(1, 4, n)) & 3)
+    lines = [b"##fileformat=VCFv4.2", b"#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO"]
+    for p, r, a, ql, ps in zip(pos, ref, alt, rng.integers(0, 300, n), rng.random(n) < 0.9):
+        lines.append(b"Merlin\t%d\t.\t%s\t%s\t%d\t%s\tDP=50" % (p, b"ACGT"[r:r + 1], b"ACGT"[a:a + 1], ql, b"PASS" if ps else b"q10"))
+    vcf_text = b"\n".join(lines) + b"\n"
+    d = tmp_path / "lofreq"
+    d.mkdir()
+    vpath = d / "TM-1-10.Merlin.lofreq.vcf"
+    vpath.write_bytes(vcf_text)
+    job = Job(str(vpath), str(tpath), "hcmv")
+    q.extract_many([job], engine=engine, strict=True)
+    want_f, want_t, want_p, _ = oracle.extract_text(vcf_text, truth_text)
+    assert open(job.filtered_out, "rb").read() == want_f
+    assert open(job.tp_out, "rb").read() == want_t and open(job.fp_out, "rb").read() == want_p
+    assert job.stats["tp_lines"] > 5000
+    rc = oracle.count_text(want_f, truth_text)
+    assert job.stats["TP_R"] == rc["TP"] and job.stats["FP_R"] == rc["FP"] and job.stats["genomediff"] == rc["genomediff"]
