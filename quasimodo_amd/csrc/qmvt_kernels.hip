@@ -1515,7 +1515,7 @@ __global__ __launch_bounds__(512) void k_bucket_scatter(BucketScatterParams P) {
     // natural-order mask words: 8 lanes x 4 records = one 32-bit word
     const uint32_t wp = or_reduce8(kept << (4u * (uint32_t)(lane & 7)));
     const int64_t w0 = i4 - 4 * (lane & 7);   // first record of the word
-    if ((lane & 7) == 7 && w0 < sg.n) {
+    if ((lane & 7) == 7 && w0 < ((sg.n + 255) & ~(int64_t)255)) {   // to the end of the VCF's padding: the masks are read in 64-bit words
       P.mask_pass[(sg.src_off + w0) >> 5] = wp;
       P.mask_tp[(sg.src_off + w0) >> 5] = 0u;
     }
@@ -1636,6 +1636,7 @@ __global__ __launch_bounds__(HB_BUCKETS) void k_bucket_rows(HashParams P) {
 }
 
 constexpr int HB_THREADS = 512;
+constexpr int HB_FQ_SLOTS = 1024;
 // A place in a list (or a budget) for every lane that wants one, with ONE returning atomic per wave.  A wave of returning
 // atomics on one LDS address takes ~450 cycles (tools/probe/lds_atomic_probe.hip: 0.14 lane-ops per clock, against 10 on
 // random addresses), during which the CU's LDS serves nobody else.  Call with the whole wave active or from a divergent
@@ -1658,7 +1659,10 @@ __device__ __forceinline__ uint32_t wave_reserve(uint32_t* ctr, bool want) {
 // Waves of a bucket's workgroup meet at three barriers only and walk their records independently in between: versions that
 // split the record loop into workgroup-wide phases (filter pass, a queue of the filter-positive records settled with full
 // waves, ...) removed the divergent steps but put every wave in the same phase at the same time, and lost 20-40 %.
-__global__ __launch_bounds__(HB_THREADS) void k_classify_hash(HashParams P) {
+#ifndef HB_WAVES_PER_EU
+#define HB_WAVES_PER_EU 6   // three workgroups per CU: 80 VGPRs
+#endif
+__global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_WAVES_PER_EU, 8))) void k_classify_hash(HashParams P) {
   constexpr uint32_t LTR = 11, LNK = 9, LX = 11;       // exact tables: truth keys, keyless records, keys on marked bits
   constexpr uint32_t LTB = 14, LFB = 16;                 // bit maps: truth filter, kept keys
   constexpr int PER = 16;                                // records per thread at most: four trips of four
@@ -1669,10 +1673,11 @@ __global__ __launch_bounds__(HB_THREADS) void k_classify_hash(HashParams P) {
   __shared__ uint32_t s_tb[(1 << LTB) / 32];         // truth filter
   __shared__ uint32_t s_b1[(1 << LFB) / 32];         // kept keys outside the truth set: seen
   __shared__ uint32_t s_b2[(1 << LFB) / 32];         //                                  seen more than once (or collided)
-  __shared__ uint32_t s_x[1 << LX];                  // the keys on marked bits, exactly
+  __shared__ __attribute__((aligned(8))) uint32_t s_x[1 << LX];   // first the waves' rings of parked records, then the keys on marked bits, exactly
+  __shared__ uint32_t s_fq[HB_FQ_SLOTS];             // kept keys outside the truth set that were settled from a ring
   __shared__ uint32_t s_nk[1 << LNK];
   __shared__ uint32_t s_h[3 * 128];                  // TP / FP / U histograms, two u16 bins per dword (a bucket holds < 65 536 records)
-  __shared__ uint32_t s_c[8];                        // kept, TP lines, distinct FP keys, matched truth keys, flags, truth keys staged, keyless inserts, marked inserts
+  __shared__ uint32_t s_c[9];                        // kept, TP lines, distinct FP keys, matched truth keys, flags, truth keys staged, keyless inserts, marked inserts, listed keys
   const int tid = (int)threadIdx.x;
   const int d = (int)blockIdx.x;
   const size_t row = (size_t)blockIdx.y * HB_BUCKETS + (size_t)d;
@@ -1729,27 +1734,28 @@ __global__ __launch_bounds__(HB_THREADS) void k_classify_hash(HashParams P) {
   const uint32_t shift = R.shift;                            // >= 4: a bucket is a whole range of positions
   const uint32_t kbase = (uint32_t)d << shift;               // every key of the bucket is >= kbase
   const uint32_t klast = ((uint32_t)(d + 1) << shift) - 1u;  // d + 1 = 256 with shift = 24 wraps to 0 - 1: the top of the key space
-  uint32_t tkey0 = 0u;
+  uint32_t tkey0 = 0u, tkey1 = 0u;
 #ifndef HB_SKIP_TRUTH   // (timing builds only: phases of the kernel switched off, results wrong)
   const int tn = over ? 0 : R.tn;
 #else
   const int tn = 0;
 #endif
   if (tid < tn) tkey0 = R.tkeys[tid];
-  for (int i = tid; i < (1 << LTR); i += HB_THREADS) { s_tk[i] = HB_EMPTY; s_ts[i] = 0u; s_x[i] = HB_EMPTY; }
+  if (tid + HB_THREADS < tn) tkey1 = R.tkeys[tid + HB_THREADS];   // up to 1 024 keys: all a bucket can take are in flight here
+  for (int i = tid; i < (1 << LTR); i += HB_THREADS) { s_tk[i] = HB_EMPTY; s_ts[i] = 0u; }
   for (int i = tid; i < (1 << LFB) / 32; i += HB_THREADS) { s_b1[i] = 0u; s_b2[i] = 0u; }
   if (tid < (1 << LTB) / 32) s_tb[tid] = 0u;
   if (tid < (1 << LTR) / 32) s_tf[tid] = 0u;
   if (tid < (1 << LNK)) s_nk[tid] = HB_EMPTY;
   if (tid < 3 * 128) s_h[tid] = 0u;
-  if (tid < 8) s_c[tid] = tid == 4 ? (segfl | (over ? SPANF_OVERFLOW : 0u)) : 0u;
+  if (tid < 9) s_c[tid] = tid == 4 ? (segfl | (over ? SPANF_OVERFLOW : 0u)) : 0u;
   HB_TICK(1);
   __syncthreads();
   HB_TICK(2);
   // ---- the truth keys of the bucket's positions (the coarse position index hands out whole cells) ----
   for (int j0 = 0; j0 < tn; j0 += HB_THREADS) {   // wave-uniform trip count
     const int j = j0 + tid;
-    const uint32_t k = j >= tn ? 0u : j0 == 0 ? tkey0 : R.tkeys[j];
+    const uint32_t k = j >= tn ? 0u : j0 == 0 ? tkey0 : j0 == HB_THREADS ? tkey1 : R.tkeys[j];
     const bool in = j < tn && k >= kbase && k <= klast;
     const uint32_t at = wave_reserve(&s_c[5], in);
     if (in) {
@@ -1768,82 +1774,162 @@ __global__ __launch_bounds__(HB_THREADS) void k_classify_hash(HashParams P) {
   __syncthreads();
   HB_TICK(4);
   uint32_t n_pass = 0, n_tp = 0, fpr = 0;
+  uint32_t vq[PER];          // the thread's records stay in registers for the second pass
+  uint32_t cand = 0;         // bit k: record k is a kept key outside the truth set (with a comparable key)
+  unsigned long long* mtp = reinterpret_cast<unsigned long long*>(P.mask_tp);
+  // What remains of a record once its truth slot is known (t < 0: no truth key): the truth key's state, the ROC histograms,
+  // the line counts, the TP bit.  Returns whether the record is a kept key outside the truth set.
+  auto settle = [&](uint32_t elo, uint32_t ehi, int t) -> bool {
+    const uint32_t inf = (elo >> 24) | ((ehi & 0x1fu) << 8);     // bits 0..11 as in the info word, bit 12 = TP line
+    const uint32_t b1 = inf & I_BIN1;
+    const bool kept = (inf & I_PASS) != 0u;                       // every entry is a live record
+    const bool hit = t >= 0;
+    const bool tpl = (hit && (inf & I_IDDOT)) || (inf & 0x1000u);
+    if (hit) {
+      if ((inf & I_IDDOT) && b1) atomicMax(&s_ts[t], b1);
+      if (kept) atomicOr(&s_tf[t >> 5], 1u << (t & 31));
+    }
+    if (b1) atomicAdd(&s_h[(tpl ? 0 : 128) + ((b1 - 1u) >> 1)], 1u << (16u * ((b1 - 1u) & 1u)));
+    if (kept) {
+      ++n_pass;
+      if (tpl) {
+        ++n_tp;
+        const int64_t o = R.src_off + (int64_t)(ehi >> 5);
+        atomicOr(mtp + (o >> 6), 1ull << (o & 63));
+      }
+    }
+    return kept && !hit;
+  };
+  // marks a kept key outside the truth set in the maps; a second mark (a repeat or a collision) sends both to the second pass
+  auto mark = [&](uint32_t v) {
+    const uint32_t h = hb_hash(v) >> (32u - LFB), bt = 1u << (h & 31u);
+    if (atomicOr(&s_b1[h >> 5], bt) & bt) atomicOr(&s_b2[h >> 5], bt);
+  };
 #ifndef HB_SKIP_RECORDS
   if (!(s_c[4] & SPANF_OVERFLOW)) {
-    unsigned long long* mtp = reinterpret_cast<unsigned long long*>(P.mask_tp);
-    uint32_t vq[PER];          // the thread's records stay in registers for the second pass
-    uint32_t cand = 0;         // bit k: record k is a kept key outside the truth set (with a comparable key)
+    // The records whose key passes the truth filter (1 in 10; most of them true matches) are what costs here: their way
+    // through the tables is a chain of dependent, divergent steps, and walked where they stand it runs in EVERY step of
+    // the wave with a handful of lanes (PMC of that version: 41 % of the VALU lanes in use, SALU 71 % busy with the
+    // bookkeeping of the branches).  So a wave only PARKS them -- ballot, rank, one 8-byte LDS store into a ring of its
+    // own, no atomics, no barrier -- and settles 64 at a time with every lane busy.  A trip that would overrun the ring
+    // (more than a quarter of its records parked twice in a row: a VCF that mostly matches) is walked the old way.
+    constexpr uint32_t RING = 128;                                 // entries per wave
+    uint2* ring = reinterpret_cast<uint2*>(s_x) + (tid >> 6) * RING;
+    const uint32_t lane = (uint32_t)tid & 63u;
+    uint32_t head = 0, tail = 0;                                   // wave-uniform
+    auto drain = [&](uint32_t n) {                                 // the first n <= 64 parked records, one per lane
+      if (lane < n) {
+        const uint2 e = ring[(head + lane) & (RING - 1u)];
+        const uint32_t v = e.x & 0xffffffu;
+        if (settle(e.x, e.y, hb_find(s_tk, LTR, v))) {             // the filter's false positives: kept keys outside the truth set after all
+          mark(v);
+          const uint32_t at = wave_reserve(&s_c[8], true);         // not this thread's own record: it joins the second pass through a list
+          if (at < HB_FQ_SLOTS) s_fq[at] = v; else atomicOr(&s_c[4], SPANF_OVERFLOW);
+        }
+      }
+      head += n;
+    };
 #pragma unroll
     for (int g = 0; g < PER / 4; ++g) {
       if (g + 1 < PER / 4) fetch(g + 1, (g + 1) & 1);
+      uint32_t elo[4], ehi[4], hv[4], mb = 0;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const uint32_t elo = u == 0 ? ea[g & 1][0] : u == 1 ? ea[g & 1][2] : u == 2 ? eb[g & 1][0] : eb[g & 1][2];
-        const uint32_t ehi = u == 0 ? ea[g & 1][1] : u == 1 ? ea[g & 1][3] : u == 2 ? eb[g & 1][1] : eb[g & 1][3];
-        const uint32_t v = elo & 0xffffffu;
+        elo[u] = u == 0 ? ea[g & 1][0] : u == 1 ? ea[g & 1][2] : u == 2 ? eb[g & 1][0] : eb[g & 1][2];
+        ehi[u] = u == 0 ? ea[g & 1][1] : u == 1 ? ea[g & 1][3] : u == 2 ? eb[g & 1][1] : eb[g & 1][3];
+        const uint32_t v = elo[u] & 0xffffffu;
         vq[4 * g + u] = v;
-        if ((uint32_t)u >= nv[g & 1]) continue;
-        const uint32_t inf = (elo >> 24) | ((ehi & 0x1fu) << 8);     // bits 0..11 as in the info word, bit 12 = TP line
-        const uint32_t b1 = inf & I_BIN1;
-        const bool kept = (inf & I_PASS) != 0u, nokey = (inf & I_NOKEY) != 0u;   // every entry is a live record
-        const uint32_t hv = hb_hash(v);
-        int t = -1;
-        if (!nokey && ((s_tb[hv >> (37u - LTB)] >> ((hv >> (32u - LTB)) & 31u)) & 1u)) t = hb_find(s_tk, LTR, v);   // 9 in 10 stop at the filter
-        const bool hit = t >= 0;
-        const bool tpl = (hit && (inf & I_IDDOT)) || (inf & 0x1000u);
-        if (hit) {
-          if ((inf & I_IDDOT) && b1) atomicMax(&s_ts[t], b1);
-          if (kept) atomicOr(&s_tf[t >> 5], 1u << (t & 31));
-        }
-        if (b1) atomicAdd(&s_h[(tpl ? 0 : 128) + ((b1 - 1u) >> 1)], 1u << (16u * ((b1 - 1u) & 1u)));
-        if (kept) {
-          ++n_pass;
-          if (tpl) {
-            ++n_tp;
-            const int64_t o = R.src_off + (int64_t)(ehi >> 5);
-            atomicOr(mtp + (o >> 6), 1ull << (o & 63));
-          }
-          if (!hit) {   // a kept key outside the truth set counts once per VCF
-            if (nokey) {   // rare: an exact set of their own, every insertion reserved (a probe of a full table would not return)
-              if (wave_reserve(&s_c[6], true) >= (1u << LNK) / 2u) { atomicOr(&s_c[4], SPANF_OVERFLOW); continue; }
-              bool fresh;
-              (void)hb_insert(s_nk, LNK, v, &fresh);
-              fpr += fresh ? 1u : 0u;
-            } else {
-              cand |= 1u << (4 * g + u);
-              const uint32_t h = hv >> (32u - LFB), bit = 1u << (h & 31u);
-#ifndef HB_SKIP_FPR
-              if (atomicOr(&s_b1[h >> 5], bit) & bit) atomicOr(&s_b2[h >> 5], bit);   // seen before (or a collision): both meet again below
-#endif
-            }
-          }
-        }
+        hv[u] = hb_hash(v);
+        const uint32_t fw = s_tb[hv[u] >> (37u - LTB)];
+        const uint32_t valid = (uint32_t)u < nv[g & 1] ? 1u : 0u;
+        mb |= (valid & ~(ehi[u] >> 3) & (fw >> ((hv[u] >> (32u - LTB)) & 31u)) & 1u) << u;   // entry bit 35 = I_NOKEY: no comparable key
       }
-    }
-    HB_TICK(5);
-    __syncthreads();
-    HB_TICK(6);
-    // second pass over the thread's own registers: keys on unmarked bits are distinct; keys on marked bits are counted exactly
+      uint64_t m[4];
+      uint32_t tot = 0;
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      const uint32_t v = vq[k];
-      const uint32_t h = hb_hash(v) >> (32u - LFB);
-      const bool c = ((cand >> k) & 1u) != 0u;
-      const bool marked = c && ((s_b2[h >> 5] >> (h & 31u)) & 1u);
-      fpr += (c && !marked) ? 1u : 0u;
-      const uint32_t at = wave_reserve(&s_c[7], marked);
-      if (marked) {
-        if (at >= (1u << LX) / 2u) {
-          atomicOr(&s_c[4], SPANF_OVERFLOW);
-        } else {
-          bool fresh;
-          (void)hb_insert(s_x, LX, v, &fresh);
-          fpr += fresh ? 1u : 0u;
+      for (int u = 0; u < 4; ++u) { m[u] = ballot64((mb >> u) & 1u); tot += (uint32_t)popc64(m[u]); }
+      while (tail - head >= 64u || (tail != head && tail - head + tot > RING)) drain(tail - head < 64u ? tail - head : 64u);
+      const bool park = tot <= RING;                               // wave-uniform
+      if (park) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if ((mb >> u) & 1u) {
+            const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[u], 0u));
+            ring[(tail + r) & (RING - 1u)] = make_uint2(elo[u], ehi[u]);
+          }
+          tail += (uint32_t)popc64(m[u]);
         }
       }
+      // the records that match nothing (and, if the trip is not parked, the others too, the old way).  Making this part
+      // branch-free (unconditional atomics with zero operands) was measured twice and lost both times: the extra LDS
+      // atomics cost more than the branches they replace.
+      uint32_t old[4], bit[4], wd[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t valid = (uint32_t)u < nv[g & 1] ? 1u : 0u;
+        const uint32_t maybe = (mb >> u) & 1u;
+        bit[u] = 0u; wd[u] = 0u;
+        bool c = false;
+        if (valid & ~maybe) c = settle(elo[u], ehi[u], -1);
+        else if (maybe && !park) c = settle(elo[u], ehi[u], hb_find(s_tk, LTR, elo[u] & 0xffffffu));
+        if (c) {
+          if ((ehi[u] >> 3) & 1u) {   // rare: keyless records are keys of their own, in an exact set, every insertion reserved
+            if (wave_reserve(&s_c[6], true) >= (1u << LNK) / 2u) { atomicOr(&s_c[4], SPANF_OVERFLOW); }
+            else {
+              bool fresh;
+              (void)hb_insert(s_nk, LNK, elo[u] & 0xffffffu, &fresh);
+              fpr += fresh ? 1u : 0u;
+            }
+          } else {
+            cand |= 1u << (4 * g + u);
+            const uint32_t h = hv[u] >> (32u - LFB);
+            bit[u] = 1u << (h & 31u); wd[u] = h >> 5;
+          }
+        }
+      }
+#ifndef HB_SKIP_FPR
+      // the four fetch-ORs of a trip in flight together (a zero bit changes nothing)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) old[u] = atomicOr(&s_b1[wd[u]], bit[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (old[u] & bit[u]) atomicOr(&s_b2[wd[u]], bit[u]);   // seen before (or a collision): both meet again below
+#endif
     }
+    while (tail != head) drain(tail - head < 64u ? tail - head : 64u);
   }
 #endif
+  HB_TICK(5);
+  __syncthreads();   // the rings are empty: their room becomes the exact set of the keys on marked bits
+  HB_TICK(6);
+  for (int i = tid; i < (1 << LX); i += HB_THREADS) s_x[i] = HB_EMPTY;
+  __syncthreads();
+  // second pass: keys on unmarked bits are distinct; keys on marked bits are counted exactly -- the thread's own candidates
+  // from its registers, then the listed ones (the filter's false positives, settled by some lane of their wave)
+  auto count_key = [&](uint32_t v, bool c) {
+    const uint32_t h = hb_hash(v) >> (32u - LFB);
+    const bool marked = c && ((s_b2[h >> 5] >> (h & 31u)) & 1u);
+    fpr += (c && !marked) ? 1u : 0u;
+    const uint32_t at = wave_reserve(&s_c[7], marked);
+    if (marked) {
+      if (at >= (1u << LX) / 2u) {
+        atomicOr(&s_c[4], SPANF_OVERFLOW);
+      } else {
+        bool fresh;
+        (void)hb_insert(s_x, LX, v, &fresh);
+        fpr += fresh ? 1u : 0u;
+      }
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < PER; ++k) count_key(vq[k], ((cand >> k) & 1u) != 0u);
+  {
+    const uint32_t nfq = s_c[8] < (uint32_t)HB_FQ_SLOTS ? s_c[8] : (uint32_t)HB_FQ_SLOTS;
+    for (uint32_t i0 = 0; i0 < nfq; i0 += HB_THREADS) {   // wave-uniform trip count
+      const uint32_t i = i0 + (uint32_t)tid;
+      count_key(i < nfq ? s_fq[i] : 0u, i < nfq);
+    }
+  }
   HB_TICK(7);
   // ---- bucket epilogue: per-entry state -> U histogram and TP_R, counters, the row ----
   atomicAdd(&s_c[0], n_pass); atomicAdd(&s_c[1], n_tp); atomicAdd(&s_c[2], fpr);

@@ -688,3 +688,28 @@ def test_truth_builder_feeds_the_gpu_path(engine, oracle, tmp_path):
     assert job.stats["tp_lines"] > 5000
     rc = oracle.count_text(want_f, truth_text)
     assert job.stats["TP_R"] == rc["TP"] and job.stats["FP_R"] == rc["FP"] and job.stats["genomediff"] == rc["genomediff"]
+
+
+def test_unsorted_vcf_behind_stale_mask_words(engine, oracle):
+    """The bucket path's scatter writes the kept mask in 32-bit words, the compaction reads 64-bit ones: the words
+    between a VCF's last record and the end of its padding must be written too.  Found by `tools/gpu_fuzz.py 100 8`
+    (round 99: an unsorted VCF of 1 025 records whose FP index list picked up bits that had been left in that memory),
+    which is the reliable reproducer -- whether this test meets dirty memory depends on the allocator; it pins the
+    batch shape and leaves ones behind from a first batch of the same padded sizes."""
+    from conftest import random_columns, random_truth
+    rng = np.random.default_rng(5)
+    L = (1 << 28) - 1
+    truth = random_truth(rng, 50, L)
+    tid = engine.truth_load(*truth)
+    sizes = [4096, 4096, 1025, 1024, 1024, 1023]
+    # same shapes, every record kept and in order: leaves ones in every mask word of the padded regions
+    full = []
+    for n in sizes:
+        n_pad = (n + 255) // 256 * 256
+        pos = np.arange(1, n_pad + 1, dtype=np.int32)
+        full.append((pos, np.zeros(n_pad, np.int32), np.ones(n_pad, np.int32), np.full(n_pad, 99, np.float32), np.full(n_pad, 3, np.uint8)))
+    engine.classify_batch(full, [tid] * len(sizes))
+    cols = [random_columns(rng, n, L, truth, sorted_=False) for n in sizes]
+    res, _ = engine.classify_batch(cols, [tid] * len(sizes))
+    for r, c in zip(res, cols):
+        check_vcf(oracle, r, c, truth)

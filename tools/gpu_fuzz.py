@@ -105,6 +105,10 @@ def run(rounds, seed, eng=None):
             if not ok:
                 bad += 1
                 print("MISMATCH round %d vcf %d: ext=%s nb=%d L=%d T=%d n=%d scal=%s oracle=%s" % (it, v, ext, nb, L, T, len(c[0]), r["scalars"], sc))
+                dc = np.nonzero(r["cls"] != cls)[0]
+                print("  differs: cls %d places (first %s: got %s want %s), roc %s, tp_idx %s, fp_idx %s; batch sizes %s" % (
+                    len(dc), dc[:8], r["cls"][dc[:8]], cls[dc[:8]], not np.array_equal(r["roc"], roc),
+                    not np.array_equal(r["tp_idx"], np.nonzero(cls == 3)[0]), not np.array_equal(r["fp_idx"], np.nonzero(cls == 1)[0]), [len(x[0]) for x in cols]))
                 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True); np.savez_compressed(os.path.join(ROOT, "gpurun_out", "fuzz_fail_%d_%d_%d.npz" % (seed, it, v)), *c, *truth)
         if not np.array_equal(glob[tid], want_glob):
             bad += 1
