@@ -18,6 +18,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -151,7 +152,9 @@ extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs
   qm_dict* dict = ext ? qm_dict_create() : nullptr;
   std::vector<TruthState> T;
   qm_batch* batch = nullptr;
+  std::thread truth_thread;   // ends with the patterns of the truth files
   auto cleanup = [&]() {
+    if (truth_thread.joinable()) truth_thread.join();
     if (batch) qm_batch_destroy(batch);
     for (auto& t : T) { if (t.pats) qm_patterns_destroy(t.pats); if (t.tid >= 0) (void)qm_truth_release(ctx, t.tid); }
     if (dict) qm_dict_destroy(dict);
@@ -170,20 +173,33 @@ extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs
   }
   int truth_rc = QM_OK;
   std::string truth_msg;
-  std::thread truth_thread([&]() {
+  // The keys go first (the batch layout needs the truth ids as soon as the VCFs are counted); the patterns as text -- a hash
+  // set of every row, wanted only by the host path and by the decision whether a VCF needs it -- are built on a thread of
+  // their own and waited for by the first VCF that has been tokenised.
+  std::mutex pats_mu;
+  std::condition_variable pats_cv;
+  bool pats_ready = false, keys_ready = false;
+  truth_thread = std::thread([&]() {
     const double tt0 = now();
     parallel_for((int)T.size(), std::max(1, nthr / 4), [&](int k) {
       TruthState& t = T[(size_t)k];
       t.file.open_file(t.path.c_str());
-      if (!t.file.ok) { t.rc = QM_E_IO; return; }
-      t.pats = qm_patterns_create(t.file.p, t.file.n, t.mode, ext ? 1 : 0);
-      if (!t.pats) { t.rc = QM_E_INVAL; return; }
-      (void)qm_patterns_info(t.pats, t.info);
+      if (!t.file.ok) t.rc = QM_E_IO;
+    });
+    std::thread pats_thread([&]() {
+      parallel_for((int)T.size(), std::max(1, nthr / 4), [&](int k) {
+        TruthState& t = T[(size_t)k];
+        if (t.rc != QM_OK) return;
+        t.pats = qm_patterns_create(t.file.p, t.file.n, t.mode, ext ? 1 : 0);
+        if (!t.pats) { t.rc = QM_E_INVAL; return; }
+        (void)qm_patterns_info(t.pats, t.info);
+      });
+      { std::lock_guard<std::mutex> g(pats_mu); pats_ready = true; }
+      pats_cv.notify_all();
     });
     for (auto& t : T) {
       if (truth_rc != QM_OK) break;
-      if (t.rc != QM_OK) { truth_rc = t.rc; truth_msg = "cannot read truth file " + t.path; break; }
-      if (strict && t.info[3] > 0) { truth_rc = QM_E_NONCANON; truth_msg = t.path + ": " + std::to_string(t.info[3]) + " truth rows hold NUL or non-ASCII bytes"; break; }
+      if (t.rc == QM_E_IO) { truth_rc = t.rc; truth_msg = "cannot read truth file " + t.path; break; }
       const int64_t cap = qm_vcf_count_lines(t.file.p, t.file.n) + 1;
       std::vector<int32_t> tp((size_t)cap), tr((size_t)cap), ta((size_t)cap);
       const int64_t k = qm_truth_scan_ext(t.file.p, t.file.n, t.mode, cap, tp.data(), tr.data(), ta.data(), t.counts, dict);
@@ -192,7 +208,11 @@ extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs
       if (rc != QM_OK) { truth_rc = rc; truth_msg = qm_last_error(ctx); break; }
     }
     ph[1] = now() - tt0;
+    { std::lock_guard<std::mutex> g(pats_mu); keys_ready = true; }
+    pats_cv.notify_all();
+    pats_thread.join();   // (the VCFs do not wait for this thread but for pats_ready)
   });
+  auto wait_patterns = [&]() { std::unique_lock<std::mutex> g(pats_mu); pats_cv.wait(g, [&] { return pats_ready; }); };
 
   // ---- 2. ... while every VCF is mapped and its lines / data lines are counted (the batch layout needs the record counts) ----
   double t0 = now();
@@ -213,7 +233,7 @@ extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs
     s.n_lines = nl; s.n_data = nd;
   });
   ph[0] = now() - t0;
-  truth_thread.join();
+  { std::unique_lock<std::mutex> g(pats_mu); pats_cv.wait(g, [&] { return keys_ready; }); }   // the thread itself ends with the patterns
   for (int j = 0; j < n_jobs; ++j)
     if (J[(size_t)j].rc != QM_OK) { cleanup(); return fail(QM_E_IO, std::string("cannot read ") + jobs[j].vcf_path); }
   if (truth_rc != QM_OK) { cleanup(); return fail(truth_rc, truth_msg); }
@@ -258,13 +278,21 @@ extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs
                                 &s.info, dict, per_file_threads > 1 ? per_file_threads : -1);   // -1: one thread, lines counted above
     if (s.rc != QM_OK || s.info.n_data != s.n_data) { if (s.rc == QM_OK) s.rc = QM_E_INVAL; return; }
     if (jobs[j].pure) return;
+    wait_patterns();
     const TruthState& t = T[(size_t)s.truth];
+    if (t.rc != QM_OK) { s.rc = t.rc; return; }
     if (s.info.n_host || s.info.n_nokey_kept || t.info[1] > 0 || t.info[2] > 0)
       s.rc = qm_vcf_hostpath(t.pats, s.vcf.p, s.vcf.n, s.info.n_lines, s.line_off.data(), s.line_kind.data(), s.pos, s.ref, s.alt, s.flags, s.ex);
     if (s.rc == QM_OK && !(strict && s.info.n_refused))
       s.rc = qm_batch_upload_async(batch, s.batch_v, s.pos, s.ref, s.alt, s.qual, s.flags, copy_stream);
   });
   int rc = QM_OK;
+  wait_patterns();
+  for (const auto& t : T) {
+    if (rc != QM_OK) break;
+    if (t.rc != QM_OK) rc = fail(t.rc, "cannot take the patterns of truth file " + t.path);
+    else if (strict && t.info[3] > 0) rc = fail(QM_E_NONCANON, t.path + ": " + std::to_string(t.info[3]) + " truth rows hold NUL or non-ASCII bytes");
+  }
   for (int j = 0; j < n_jobs && rc == QM_OK; ++j) {
     const JobState& s = J[(size_t)j];
     if (s.rc != QM_OK) rc = fail(s.rc, std::string("tokenising / uploading failed for ") + jobs[j].vcf_path);
