@@ -35,6 +35,10 @@ struct qm_dict {
   std::vector<std::string> strings;
 };
 
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
 namespace {
 
 struct Span { const uint8_t* p; size_t n; };
@@ -213,19 +217,157 @@ bool pattern_at_later_fields(const uint8_t* s, const uint8_t* end, bool ext) {
   }
 }
 
+
+// Lines and header lines ('#' first) of a piece of text without looking at it line by line: newlines are counted with a
+// population count over compare masks, header lines are the line starts (offset 0, every byte behind a newline) that hold '#'.
+// A last line without a newline counts; an empty line is a data line (as everywhere in the tokenizer).
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) void count_lines_avx2(const uint8_t* p, size_t len, int64_t* nl, int64_t* nh, uint32_t* carry) {
+  const __m256i vn = _mm256_set1_epi8('\n'), vh = _mm256_set1_epi8('#');
+  int64_t l = 0, h = 0;
+  uint32_t c = *carry;
+  size_t i = 0;
+  for (; i + 32 <= len; i += 32) {
+    const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p + i));
+    const uint32_t mn = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(x, vn)), mh = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(x, vh));
+    l += __builtin_popcount(mn);
+    h += __builtin_popcount(((mn << 1) | c) & mh);
+    c = mn >> 31;
+  }
+  for (; i < len; ++i) { h += (c && p[i] == '#') ? 1 : 0; c = p[i] == '\n'; l += c; }
+  *nl += l; *nh += h; *carry = c;
+}
+bool cpu_has_avx2() { static const bool v = __builtin_cpu_supports("avx2"); return v; }
+#endif
+void count_lines_fast(const uint8_t* p, size_t len, int64_t* n_lines, int64_t* n_data) {
+  int64_t l = 0, h = 0;
+  uint32_t c = 1;   // offset 0 starts a line
+  size_t i = 0;
+#if defined(__x86_64__)
+  if (cpu_has_avx2()) {
+    count_lines_avx2(p, len, &l, &h, &c);
+    i = len;
+  } else {
+    const __m128i vn = _mm_set1_epi8('\n'), vh = _mm_set1_epi8('#');
+    for (; i + 16 <= len; i += 16) {
+      const __m128i x = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p + i));
+      const uint32_t mn = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, vn)), mh = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, vh));
+      l += __builtin_popcount(mn);
+      h += __builtin_popcount(((mn << 1) | c) & mh & 0xffffu);
+      c = (mn >> 15) & 1u;
+    }
+  }
+#endif
+  for (; i < len; ++i) { h += (c && p[i] == '#') ? 1 : 0; c = p[i] == '\n'; l += c; }
+  if (len && p[len - 1] != '\n') ++l;
+  *n_lines = l;
+  *n_data = l - h;
+}
+
+// One pass over a line, 16 or 32 bytes per compare (SURVEY f-1: "SIMD tab/newline scan"): its length, where its tabs are,
+// whether it holds a NUL or a non-ASCII byte.  The tokenizer used to find the same things with one memchr per field, a second
+// walk for the byte check and a third for pattern_at_later_fields; fields are a few bytes long, so the calls cost more than
+// the bytes.
+constexpr int LINE_MAXT = 48;   // tab positions kept (a line with more falls back to the walks above)
+struct LineIndex {
+  size_t n;        // length without the newline
+  int ntab;        // all tabs of the line
+  bool dirty;      // NUL or non-ASCII byte
+  uint32_t tab[LINE_MAXT];
+};
+#define QM_INDEX_TABS(mt, off) while (mt) { const uint32_t i_ = (uint32_t)__builtin_ctz(mt); mt &= mt - 1u; if (nt < LINE_MAXT) L.tab[nt] = (off) + i_; ++nt; }
+inline void index_line_tail(const uint8_t* s, const uint8_t* p, const uint8_t* lim, int nt, bool dirty, LineIndex& L) {
+  for (; p < lim && *p != '\n'; ++p) {
+    if (*p == '\t') { if (nt < LINE_MAXT) L.tab[nt] = (uint32_t)(p - s); ++nt; }
+    dirty = dirty || *p == 0 || *p >= 0x80;
+  }
+  L.n = (size_t)(p - s); L.ntab = nt; L.dirty = dirty;
+}
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) void index_line_avx2(const uint8_t* s, const uint8_t* lim, LineIndex& L) {
+  const uint8_t* p = s;
+  int nt = 0;
+  bool dirty = false;
+  const __m256i vt = _mm256_set1_epi8('\t'), vn = _mm256_set1_epi8('\n'), vz = _mm256_setzero_si256();
+  while (p + 32 <= lim) {
+    const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p));
+    uint32_t mt = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(x, vt));
+    const uint32_t mn = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(x, vn));
+    uint32_t md = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(x, vz)) | (uint32_t)_mm256_movemask_epi8(x);   // zero bytes | high bits
+    const uint32_t off = (uint32_t)(p - s);
+    if (mn) {
+      const uint32_t e = (uint32_t)__builtin_ctz(mn), below = e ? (0xffffffffu >> (32u - e)) : 0u;
+      mt &= below; md &= below;
+      dirty = dirty || md != 0;
+      QM_INDEX_TABS(mt, off)
+      L.n = (size_t)off + e; L.ntab = nt; L.dirty = dirty;
+      return;
+    }
+    dirty = dirty || md != 0;
+    QM_INDEX_TABS(mt, off)
+    p += 32;
+  }
+  index_line_tail(s, p, lim, nt, dirty, L);
+}
+#endif
+inline void index_line(const uint8_t* s, const uint8_t* lim, LineIndex& L) {   // lim: end of the chunk (whole lines; inside the mapping)
+#if defined(__x86_64__)
+  if (cpu_has_avx2()) { index_line_avx2(s, lim, L); return; }
+  const uint8_t* p = s;
+  int nt = 0;
+  bool dirty = false;
+  const __m128i vt = _mm_set1_epi8('\t'), vn = _mm_set1_epi8('\n'), vz = _mm_setzero_si128();
+  while (p + 16 <= lim) {
+    const __m128i x = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p));
+    uint32_t mt = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, vt));
+    const uint32_t mn = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, vn));
+    uint32_t md = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, vz)) | (uint32_t)_mm_movemask_epi8(x);   // zero bytes | high bits
+    const uint32_t off = (uint32_t)(p - s);
+    if (mn) {
+      const uint32_t e = (uint32_t)__builtin_ctz(mn), below = (1u << e) - 1u;
+      mt &= below; md &= below;
+      dirty = dirty || md != 0;
+      QM_INDEX_TABS(mt, off)
+      L.n = (size_t)off + e; L.ntab = nt; L.dirty = dirty;
+      return;
+    }
+    dirty = dirty || md != 0;
+    QM_INDEX_TABS(mt, off)
+    p += 16;
+  }
+  index_line_tail(s, p, lim, nt, dirty, L);
+#else
+  index_line_tail(s, s, lim, 0, false, L);
+#endif
+}
+#undef QM_INDEX_TABS
+// field k of an indexed line (k <= ntab <= LINE_MAXT)
+inline Span line_field(const uint8_t* s, const LineIndex& L, int k) {
+  const size_t b = k ? (size_t)L.tab[k - 1] + 1 : 0, e = k < L.ntab ? (size_t)L.tab[k] : L.n;
+  return Span{s + b, e - b};
+}
+// pattern_at_later_fields on an indexed line: windows (field k-3, ".", Y, Z) for k >= 7
+inline bool pattern_at_later_fields_indexed(const uint8_t* s, const LineIndex& L, bool ext) {
+  for (int k = 7; k <= L.ntab; ++k) {
+    const Span d = line_field(s, L, k - 2);
+    if (!is_dot(d)) continue;
+    const Span y = line_field(s, L, k - 1), z = line_field(s, L, k);
+    if (ext ? acgt_all(y) && acgt_prefix_word(z) : y.n == 1 && z.n >= 1 && (z.n == 1 || !is_word(z.p[1]))) return true;
+  }
+  return false;
+}
+
 }  // namespace
 
 extern "C" int64_t qm_vcf_count_lines(const uint8_t* text, size_t len) {
-  int64_t c = 0;
-  const uint8_t* p = text;
-  const uint8_t* end = text + len;
-  while (p < end) {
-    const uint8_t* nl = (const uint8_t*)memchr(p, '\n', (size_t)(end - p));
-    ++c;
-    if (!nl) break;
-    p = nl + 1;
-  }
-  return c;
+  int64_t nl = 0, nd = 0;
+  if (text && len) count_lines_fast(text, len, &nl, &nd);
+  return nl;
+}
+// internal (qmvt_pipeline.cpp): lines and data lines of a whole file
+void qm_host_count_lines(const uint8_t* text, size_t len, int64_t* n_lines, int64_t* n_data) {
+  *n_lines = 0; *n_data = 0;
+  if (text && len) count_lines_fast(text, len, n_lines, n_data);
 }
 
 // One chunk of the text (whole lines).  count_only: just the number of lines / data lines.
@@ -249,31 +391,33 @@ static void scan_chunk(const uint8_t* text, ScanChunk& c, bool count_only, int64
   size_t off = c.begin;
   enum { MAXF = 6 };   // CHROM POS ID REF ALT QUAL
   Span f[MAXF];
+  if (count_only) {
+    count_lines_fast(text + c.begin, c.end - c.begin, &c.nl, &c.nd);
+    return;
+  }
+  LineIndex L;
   while (off < c.end) {
     const uint8_t* s = text + off;
-    const uint8_t* e = (const uint8_t*)memchr(s, '\n', c.end - off);
-    const size_t n = e ? (size_t)(e - s) : c.end - off;
+    index_line(s, text + c.end, L);
+    const size_t n = L.n;
     const bool header = n && s[0] == '#';
-    if (count_only) {
-      nd += header ? 0 : 1;
-    } else {
+    {
       const int64_t gl = c.l0 + nl, gd = c.d0 + nd;
       line_off[gl] = (int64_t)off;
-      auto dirty = [&]() {   // NUL / non-ASCII: the reference's answer depends on the locale its grep runs under
-        size_t i = 0;
-        for (; i + 8 <= n; i += 8) {   // eight bytes at a time: any high bit, or any zero byte
-          uint64_t x;
-          memcpy(&x, s + i, 8);
-          if ((x & 0x8080808080808080ull) || ((x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull)) return true;
-        }
-        for (; i < n; ++i) if (s[i] == 0 || s[i] >= 0x80) return true;
-        return false;
+      const bool indexed = L.ntab <= LINE_MAXT;   // every tab of the line is in the index
+      auto dirty = [&]() { return L.dirty; };     // NUL / non-ASCII: the reference's answer depends on the locale its grep runs under
+      auto head = [&](Span* f) -> int {           // the first MAXF fields (CHROM..QUAL); returns how many the line has of them
+        if (n == 0) return 0;
+        if (!indexed) return split_head(s, n, f, MAXF);
+        const int nf = L.ntab + 1 < (int)MAXF ? L.ntab + 1 : (int)MAXF;
+        for (int k = 0; k < nf; ++k) f[k] = line_field(s, L, k);
+        return nf;
       };
       if (header) {
         // awk does not skip '#': a header line that also satisfies the A2 filter is emitted twice by the reference
         // (once by grep, once by awk, then in tp or fp as fgrep decides) while R's read.table ignores it
         uint8_t kind = QM_LINE_HEADER;
-        const int nf = split_head(s, n, f, MAXF);
+        const int nf = head(f);
         if (nf >= 5 && allele_ok(f[3]) && allele_ok(f[4])) {
           bool ge20 = false;
           const Span empty = {(const uint8_t*)"", 0};
@@ -286,7 +430,7 @@ static void scan_chunk(const uint8_t* text, ScanChunk& c, bool count_only, int64
         line_kind[gl] = kind;
       } else {
         uint8_t kind = QM_LINE_DATA;
-        const int nf = split_head(s, n, f, MAXF);
+        const int nf = head(f);
         const Span empty = {(const uint8_t*)"", 0};
         const Span fpos = nf > 1 ? f[1] : empty, fid = nf > 2 ? f[2] : empty, fref = nf > 3 ? f[3] : empty,
                    falt = nf > 4 ? f[4] : empty, fq = nf > 5 ? f[5] : empty;
@@ -299,7 +443,7 @@ static void scan_chunk(const uint8_t* text, ScanChunk& c, bool count_only, int64
         if (cpos) { last_pos = p; any_pos = true; } else { p = last_pos; if (!any_pos) c.lead_nokey++; }
         if (pass && dirty()) {
           kind = QM_LINE_REFUSED; ++c.nref; if (!c.first_ref) c.first_ref = gl + 1;
-        } else if (snp && (!cpos || (nf > 5 && pattern_at_later_fields(f[4].p, s + n, dict != nullptr)))) {
+        } else if (snp && (!cpos || (nf > 5 && (indexed ? pattern_at_later_fields_indexed(s, L, dict != nullptr) : pattern_at_later_fields(f[4].p, s + n, dict != nullptr))))) {
           // every single-base line, whatever its QUAL: the ROC sweep moves the threshold.  fgrep compares POS as
           // text, so only canonical spellings are safe on the device
           kind = QM_LINE_DATA_HOST; ++c.nhost;

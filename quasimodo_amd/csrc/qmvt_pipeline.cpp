@@ -31,6 +31,7 @@
 #include "../../include/qmvt.h"
 
 // from qmvt_host.cpp (same library, not part of the public ABI)
+void qm_host_count_lines(const uint8_t* text, size_t len, int64_t* n_lines, int64_t* n_data);
 int qm_host_scan_threads(const uint8_t* text, size_t len, int64_t cap_lines, int64_t* line_off, uint8_t* line_kind, int32_t* pos,
                          int32_t* ref, int32_t* alt, float* qual, uint8_t* flags, qm_vcf_cols* info, qm_dict* dict, int nthreads);
 int qm_host_write_masks(const char* path, const uint8_t* text, size_t len, int64_t n_lines, const int64_t* line_off,
@@ -220,16 +221,8 @@ extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs
     JobState& s = J[(size_t)j];
     s.vcf.open_file(jobs[j].vcf_path);
     if (!s.vcf.ok) { s.rc = QM_E_IO; return; }
-    const uint8_t* p = s.vcf.p;
-    const uint8_t* end = p + s.vcf.n;
     int64_t nl = 0, nd = 0;
-    while (p < end) {
-      nd += *p != '#';
-      ++nl;
-      const uint8_t* e = (const uint8_t*)memchr(p, '\n', (size_t)(end - p));
-      if (!e) break;
-      p = e + 1;
-    }
+    qm_host_count_lines(s.vcf.p, s.vcf.n, &nl, &nd);
     s.n_lines = nl; s.n_data = nd;
   });
   ph[0] = now() - t0;

@@ -331,3 +331,33 @@ def test_many_sample_columns_are_tokenised_without_a_field_limit(qmlib, oracle):
     # and the reference mechanism agrees that the hazard is real: truth 77 . C T matches line 2 by its tail
     f, tp, fp, st = oracle.extract_text(text, b"c\t77\t.\tC\tT\t30\tPASS\tX\n")
     assert st["tp_lines"] == 1 and tp.count(b"\t200\t") == 1
+
+
+def test_vector_scan_equals_the_line_by_line_rules(qmlib):
+    """The tokenizer counts lines / header lines with population counts over compare masks and indexes a line's tabs 16 or 32
+    bytes at a time (SURVEY f-1): the same answers as the plain rules -- a last line without a newline counts, an empty line
+    is a data line, '#' only counts at a line start -- with line starts, tabs, NUL and non-ASCII bytes on every offset of a
+    vector block, and more tabs in a line than the index keeps."""
+    import ctypes as C
+    from quasimodo_amd import vcfio
+    rng = np.random.default_rng(23)
+    L = qmlib
+    L.qm_vcf_count_lines.restype = C.c_int64
+    alphabet = np.frombuffer(b"\n\n\t\t#AC.1 \xc3\x00", np.uint8)
+    for trial in range(300):
+        n = int(rng.integers(0, 200))
+        raw = alphabet[rng.integers(0, len(alphabet) - (2 if trial % 3 else 0), n)].tobytes()
+        lines = raw.split(b"\n")
+        if raw.endswith(b"\n") or not raw:
+            lines = lines[:-1]
+        assert L.qm_vcf_count_lines(raw, len(raw)) == len(lines), raw
+        sv = vcfio.scan_vcf(raw)
+        assert sv.n_lines == len(lines)
+        assert sv.n_records == sum(1 for ln in lines if not ln.startswith(b"#")), raw
+        off = np.cumsum([0] + [len(ln) + 1 for ln in lines])[:len(lines)]
+        assert list(sv.line_off[:len(lines)]) == list(off), raw
+    # a data line with 100 sample columns (more tabs than the index keeps) and a pattern-shaped window far behind the ID column
+    many = b"chr\t7\t.\tA\tG\t50\tPASS\tDP=1\tGT" + b"\t0/1" * 60 + b"\t.\tA\tG\n"
+    few = b"chr\t7\t.\tA\tG\t50\tPASS\tDP=1\tGT\t.\tA\tG;x\n"
+    sv = vcfio.scan_vcf(many + few + b"chr\t8\t.\tA\tG\t50\tPASS\tDP=1\n")
+    assert list(sv.line_kind[:3]) == [2, 2, 0]      # QM_LINE_DATA_HOST twice: the text decides, on the host path
