@@ -415,6 +415,10 @@ struct qm_batch {
   // same context change neither the size of global_acc nor what qm_batch_get_global copies.
   int n_truth = 1;
   std::vector<std::pair<int, uint32_t>> truth_gens;   // (truth id, generation) of every truth set a VCF names
+  // one word of host memory the device can write: k_finalize sets it when any VCF carries a flag (unsorted, bad position, ...), so
+  // that qm_batch_finish reads the per-VCF flags back only then
+  uint32_t* h_summary = nullptr;
+  uint32_t* d_summary = nullptr;
 };
 
 static void batch_free(qm_batch* b) {
@@ -426,6 +430,7 @@ static void batch_free(qm_batch* b) {
                   b->scalars, b->d_vcfs, b->d_spans, b->d_tile_vcf, b->cls_scratch, b->sk[0], b->sk[1], b->sv[0],
                   b->sv[1], b->si[0], b->si[1], b->shist, b->sorbits, b->d_segs, b->d_tile_seg, b->d_ktile_seg, b->d_ktile_local};
   for (void* p : ptrs) (void)hipFree(p);
+  if (b->h_summary) (void)hipHostFree(b->h_summary);
   for (auto& r : b->ev) for (auto& e : r) if (e) (void)hipEventDestroy(e);
   for (auto& e : b->ev_sync) if (e) (void)hipEventDestroy(e);
   delete b;
@@ -504,6 +509,18 @@ static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int
     if (e == hipSuccess) e = hipMemsetAsync(b->qual, 0, np * 4, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) rc = fail(QM_E_HIP, "hipMemset: %s", hipGetErrorString(e));
+  }
+  if (rc == QM_OK && !packed) {   // (the scratch batches of the sort path are finalized without it)
+    void* h = nullptr;
+    void* d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+      b->h_summary = static_cast<uint32_t*>(h);
+      b->d_summary = static_cast<uint32_t*>(d);
+      *b->h_summary = 0u;
+    } else {   // not fatal: qm_batch_finish then reads the flags back every time
+      if (h) (void)hipHostFree(h);
+      (void)hipGetLastError();
+    }
   }
   if (rc != QM_OK) { batch_free(b); return rc; }
   *out = b;
@@ -632,6 +649,7 @@ static ClassifyParams classify_params(qm_batch* b) {
   P.ablate = ab ? atoi(ab) : 0;
   P.ext = b->ext ? 1 : 0;
   P.span_base = 0;
+  P.zero_acc = nullptr; P.zero_words = 0;
   return P;
 }
 static FinalizeParams finalize_params(qm_batch* b, uint64_t* global) {
@@ -640,6 +658,7 @@ static FinalizeParams finalize_params(qm_batch* b, uint64_t* global) {
   F.tile_tp = b->tile_tp; F.tile_fp = b->tile_fp; F.tile_tp_off = b->tile_tp_off; F.tile_fp_off = b->tile_fp_off;
   F.roc = b->roc; F.scalars = b->scalars; F.vcf_flags = b->vcf_flags; F.vcf_posor = b->vcf_posor; F.global_acc = global; F.n_bins = b->n_bins; F.ext = b->ext ? 1 : 0;
   F.vcf_base = 0;
+  F.flag_summary = nullptr;
   return F;
 }
 static CompactParams compact_params(qm_batch* b) {
@@ -669,7 +688,7 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
     if (tg.first >= (int)c->truths.size() || c->truths[(size_t)tg.first].released || c->truths[(size_t)tg.first].gen != tg.second)
       return fail(QM_E_STATE, "qm_batch_run: truth set %d was released after the batch was created", tg.first);
   const size_t gbytes = (size_t)b->n_truth * 3 * (size_t)b->n_bins * 8;   // as allocated at batch creation
-  HIPCHK(hipMemsetAsync(g, 0, gbytes, st));
+  if (b->h_summary) *reinterpret_cast<volatile uint32_t*>(b->h_summary) = 0u;
   hipEvent_t* ev = b->ev[b->n_timed % qm_batch::EV_RING];
   const int nch = (int)b->chunks.size();
   const bool T = b->timing;
@@ -687,11 +706,16 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
     hipEvent_t* e5 = ev + 2 + 5 * k;
     ClassifyParams P = classify_params(b);
     P.span_base = ck.s0;
+    if (k == 0) {   // k_finalize, behind this launch, adds to the per-truth sums: the first wave of the launch clears them
+      if (ck.s1 > ck.s0) { P.zero_acc = g; P.zero_words = (int32_t)(gbytes / 8); }
+      else HIPCHK(hipMemsetAsync(g, 0, gbytes, st));   // a batch of empty VCFs launches nothing
+    }
     if (T) HIPCHK(hipEventRecord(e5[0], st));
     launch_classify(P, ck.s1 - ck.s0, st);
     if (T) HIPCHK(hipEventRecord(e5[1], st));
     FinalizeParams F = finalize_params(b, g);
     F.vcf_base = ck.v0;
+    F.flag_summary = b->d_summary;
     launch_finalize(F, ck.v1 - ck.v0, st);
     if (T) HIPCHK(hipEventRecord(e5[2], st));
     CompactParams K = compact_params(b);
@@ -968,6 +992,10 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   HIPCHK(hipStreamSynchronize(st));
   if (b->finished) return QM_OK;
+  if (b->h_summary && *reinterpret_cast<volatile uint32_t*>(b->h_summary) == 0u) {   // no VCF of the run carries a flag: nothing to read back
+    b->finished = true;
+    return QM_OK;
+  }
   std::vector<uint32_t> fl((size_t)b->n_vcf), posor((size_t)b->n_vcf);
   HIPCHK(hipMemcpy(fl.data(), b->vcf_flags, 4 * fl.size(), hipMemcpyDeviceToHost));
   std::vector<int> todo;

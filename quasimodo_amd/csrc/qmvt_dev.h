@@ -113,6 +113,8 @@ struct ClassifyParams {
   int32_t ablate;  // debug only (QM_ABLATE): skip phases to price them; results are wrong when non-zero
   int32_t ext;     // allele-extended batch: k_classify<false, true> against the truth sets' extended tables
   int32_t span_base;   // first span of this launch (the batch is run in a few span ranges so that compaction overlaps classification)
+  uint64_t* zero_acc;  // or null: the per-truth sums k_finalize adds to, cleared by the first wave of this launch (saves a memset node per run)
+  int32_t zero_words;
 };
 
 struct FinalizeParams {
@@ -132,6 +134,7 @@ struct FinalizeParams {
   int32_t n_bins;
   int32_t ext;           // allele-extended batch: T' is the size of the extended truth table
   int32_t vcf_base;      // first VCF of this launch
+  uint32_t* flag_summary; // or null: host-mapped word, set to 1 if any VCF of the launch carries a flag
 };
 
 struct CompactParams {

@@ -698,6 +698,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
 
   for (int i = lane; i < L_KEYS; i += 64) lds[i] = 0;   // histograms
   if (lane < 16) lds[L_FLUT + lane] = flag_info((uint32_t)lane);
+  if (P.zero_acc && blockIdx.x == 0)
+    for (int i = lane; i < P.zero_words; i += 64) P.zero_acc[i] = 0ull;
   Acc A = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
   uint32_t acc_pass = 0, acc_tp = 0;  // wave-uniform
   uint32_t acc_tpr = 0;               // per lane, reduced at the end
@@ -907,21 +909,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
 // k_finalize: one workgroup (256 threads) per VCF
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
-  __shared__ uint32_t s_h[3][256];
+  __shared__ uint32_t s_h[3][4];
   __shared__ uint32_t s_scan[256];
   const int v = (int)blockIdx.x + P.vcf_base;
   const int tid = (int)threadIdx.x;
   const VcfDesc vd = P.vcfs[v];
   const int nb = P.n_bins;
 
-  // flags first: an unsorted VCF's numbers are discarded (redone by the sort path)
-  uint32_t fl = 0;
-  for (int s = tid; s < vd.nspans; s += 256) fl |= P.span_scal[(size_t)(vd.span0 + s) * 8 + 5];
-  const bool unsorted = __syncthreads_or((int)(fl & SPANF_UNSORTED)) != 0;
-  const bool badpos = __syncthreads_or((int)(fl & SPANF_BADPOS)) != 0;
-  const bool runlim = __syncthreads_or((int)(fl & SPANF_RUNLIMIT)) != 0;
-  const bool overflow = __syncthreads_or((int)(fl & SPANF_OVERFLOW)) != 0;
-
+  // the spans' scalar rows (8 words each: five counters, the flags, the OR of the positions), every thread two or three of
+  // the words: one round of coalesced loads and LDS atomics.  (Eight threads walking the rows one after the other were the
+  // long pole of this kernel: 62 dependent round trips per VCF.)
+  __shared__ unsigned long long s_sc[5];
+  __shared__ uint32_t s_fl, s_or;
+  if (tid < 5) s_sc[tid] = 0ull;
+  if (tid == 5) s_fl = 0u;
+  if (tid == 6) s_or = 0u;
+  __syncthreads();
+  for (int i = tid; i < vd.nspans * 8; i += 256) {
+    const uint32_t x = P.span_scal[(size_t)vd.span0 * 8 + i];
+    const int k = i & 7;
+    if (k < 5) { if (x) atomicAdd(&s_sc[k], (unsigned long long)x); }
+    else if (k == 5) { if (x) atomicOr(&s_fl, x); }
+    else if (k == 6) { if (x) atomicOr(&s_or, x); }
+  }
   // sum span histograms (thread = bin)
   uint32_t h0 = 0, h1 = 0, h2 = 0;
   const int hw = tid >> 1, hs = 16 * (tid & 1);   // two u16 bins per dword
@@ -930,29 +940,45 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
     const uint32_t* sh = P.span_hist + (size_t)(vd.span0 + s) * SPAN_HIST_WORDS;
     h0 += (sh[hw] >> hs) & 0xffffu; h1 += (sh[128 + hw] >> hs) & 0xffffu; h2 += (sh[256 + hw] >> hs) & 0xffffu;
   }
-  s_h[0][tid] = h0; s_h[1][tid] = h1; s_h[2][tid] = h2;
-  __syncthreads();
-  if (tid < nb) {
-    uint64_t c0 = 0, c1 = 0, c2 = 0;
-    for (int b = tid; b < nb; ++b) { c0 += s_h[0][b]; c1 += s_h[1][b]; c2 += s_h[2][b]; }
-    uint64_t* roc = P.roc + (size_t)v * 3 * nb;
-    roc[tid] = c0; roc[nb + tid] = c1; roc[2 * nb + tid] = c2;
-    if (P.global_acc && !unsorted) {
-      unsigned long long* g = reinterpret_cast<unsigned long long*>(P.global_acc) + (size_t)vd.truth * 3 * nb;
-      if (c0) atomicAdd(&g[tid], (unsigned long long)c0);
-      if (c1) atomicAdd(&g[nb + tid], (unsigned long long)c1);
-      if (c2) atomicAdd(&g[2 * nb + tid], (unsigned long long)c2);
+  // ROC = suffix sums over the bins (bins at and above n_bins are empty): shuffles inside the wave, the waves' totals through LDS
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t i0 = h0, i1 = h1, i2 = h2;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y0 = __shfl_down(i0, o), y1 = __shfl_down(i1, o), y2 = __shfl_down(i2, o);
+      if (lane + o < 64) { i0 += y0; i1 += y1; i2 += y2; }
     }
-  }
-  // scalars
-  if (tid < 8) {
-    uint64_t acc = 0, acc_or = 0;
-    for (int s = 0; s < vd.nspans; ++s) { acc += P.span_scal[(size_t)(vd.span0 + s) * 8 + tid]; acc_or |= P.span_scal[(size_t)(vd.span0 + s) * 8 + 6]; }
-    int64_t* sc = P.scalars + (size_t)v * 8;
-    if (tid < 5) sc[tid] = (int64_t)acc;
-    else if (tid == 5) { sc[5] = unsorted ? 0 : 1; if (P.vcf_posor) P.vcf_posor[v] = (uint32_t)acc_or; P.vcf_flags[v] = (unsorted ? SPANF_UNSORTED : 0u) | (badpos ? SPANF_BADPOS : 0u) | (runlim ? SPANF_RUNLIMIT : 0u) | (overflow ? SPANF_OVERFLOW : 0u); }
-    else if (tid == 6) sc[6] = vd.n;
-    else sc[7] = P.ext ? P.truths[vd.truth].xn : P.truths[vd.truth].n;
+    if (lane == 0) { s_h[0][wave] = i0; s_h[1][wave] = i1; s_h[2][wave] = i2; }
+    __syncthreads();   // also: the scalar rows are summed
+    uint64_t c0 = i0, c1 = i1, c2 = i2;
+    for (int w = wave + 1; w < 4; ++w) { c0 += s_h[0][w]; c1 += s_h[1][w]; c2 += s_h[2][w]; }
+    const uint32_t fl = s_fl;
+    const bool unsorted = (fl & SPANF_UNSORTED) != 0u;
+    if (tid < nb) {
+      uint64_t* roc = P.roc + (size_t)v * 3 * nb;
+      roc[tid] = c0; roc[nb + tid] = c1; roc[2 * nb + tid] = c2;
+      if (P.global_acc && !unsorted) {   // an unsorted VCF's numbers are discarded (redone by the sort path)
+        unsigned long long* g = reinterpret_cast<unsigned long long*>(P.global_acc) + (size_t)vd.truth * 3 * nb;
+        if (c0) atomicAdd(&g[tid], (unsigned long long)c0);
+        if (c1) atomicAdd(&g[nb + tid], (unsigned long long)c1);
+        if (c2) atomicAdd(&g[2 * nb + tid], (unsigned long long)c2);
+      }
+    }
+    // scalars
+    if (tid < 8) {
+      int64_t* sc = P.scalars + (size_t)v * 8;
+      if (tid < 5) sc[tid] = (int64_t)s_sc[tid];
+      else if (tid == 5) {
+        sc[5] = unsorted ? 0 : 1;
+        if (P.vcf_posor) P.vcf_posor[v] = s_or;
+        const uint32_t out = fl & (SPANF_UNSORTED | SPANF_BADPOS | SPANF_RUNLIMIT | SPANF_OVERFLOW);
+        P.vcf_flags[v] = out;
+        if (out && P.flag_summary) *reinterpret_cast<volatile uint32_t*>(P.flag_summary) = 1u;   // host-mapped: tells qm_batch_finish that the per-VCF flags are worth a copy
+      }
+      else if (tid == 6) sc[6] = vd.n;
+      else sc[7] = P.ext ? P.truths[vd.truth].xn : P.truths[vd.truth].n;
+    }
   }
   // exclusive scan of the tile counts (TP and FP together) over the VCF's tiles: four consecutive tiles
   // per thread in registers, the 256 thread totals with wave shuffles -- two barriers per 1 024 tiles

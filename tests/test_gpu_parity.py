@@ -713,3 +713,17 @@ def test_unsorted_vcf_behind_stale_mask_words(engine, oracle):
     res, _ = engine.classify_batch(cols, [tid] * len(sizes))
     for r, c in zip(res, cols):
         check_vcf(oracle, r, c, truth)
+
+
+def test_batch_of_empty_vcfs(engine, oracle):
+    """No record at all: k_classify is not launched (its first wave is what clears the per-truth sums), the sums are still zero."""
+    from conftest import random_truth
+    rng = np.random.default_rng(2)
+    truth = random_truth(rng, 100, 10_000)
+    tid = engine.truth_load(*truth)
+    e = (np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32), np.zeros(0, np.uint8))
+    for _ in range(2):
+        res, glob = engine.classify_batch([e, e, e], [tid] * 3)
+        assert not glob[tid].any()
+        for r in res:
+            check_vcf(oracle, r, e, truth)
