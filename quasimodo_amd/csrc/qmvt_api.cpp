@@ -779,8 +779,20 @@ static int regrow(T** p, int64_t* cap, int64_t need, int64_t* bytes) {
   return QM_OK;
 }
 
+// Which unsorted VCFs go through the bucket path (k_bucket_scatter + k_classify_hash): default-mode batches; large enough to be
+// worth 256 workgroups and 256 histogram rows (smaller ones are sorted in no time); small enough for 256 buckets x 8 sub-regions
+// x 1 024 entries at five eighths full and for the 21 index bits of an entry.  QM_SORT_PATH=radix keeps everything on the sort,
+// QM_BUCKET_MIN moves the lower limit.
+static bool bucket_path_takes(const qm_batch* b, int64_t n) {
+  if (b->ext) return false;
+  if (const char* e = getenv("QM_SORT_PATH")) if (strcmp(e, "radix") == 0) return false;
+  int64_t lo = HB_MIN_RECORDS;
+  if (const char* e = getenv("QM_BUCKET_MIN")) lo = atoll(e);   // tests and tools/gpu_fuzz.py send their small VCFs through the buckets too
+  return n >= lo && n <= (int64_t)HB_BUCKETS * HB_MAX_RECORDS * 5 / 8 && n <= ((int64_t)1 << HB_INDEX_BITS);
+}
+
 // posor[v]: OR of the positions the optimistic pass saw in VCF v (which position bits are in use)
-static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, const std::vector<uint32_t>& posor) {
+static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, const std::vector<uint32_t>& posor, bool buckets) {
   const int nseg = (int)vs.size();
   // --- scratch batch holding the sorted copies (rebuilt only when the chunk's shape changes)
   std::vector<int64_t> sig((size_t)nseg);
@@ -844,11 +856,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   if (rc == QM_OK && !b->sorbits) rc = dalloc(&b->sorbits, 1);
   // The bucket path (k_classify_hash): ONE scatter pass, no sort.  For batches of the default mode whose VCFs are small enough
   // for 256 buckets of at most HB_MAX_RECORDS records; QM_SORT_PATH=radix keeps everything on the radix sort.
-  bool try_buckets = !b->ext;
-  if (const char* e = getenv("QM_SORT_PATH")) try_buckets = try_buckets && strcmp(e, "radix") != 0;
-  // fuller than five eighths of 256 x 8 x 1 024, some sub-region will overflow; an entry has HB_INDEX_BITS for the record's index
-  for (int i = 0; i < nseg && try_buckets; ++i)
-    try_buckets = segs[(size_t)i].n <= (int64_t)HB_BUCKETS * HB_MAX_RECORDS * 5 / 8 && segs[(size_t)i].n <= ((int64_t)1 << HB_INDEX_BITS);
+  bool try_buckets = buckets;   // the caller chose the chunk's VCFs by size (bucket_path_takes)
   if (rc == QM_OK && try_buckets) {
     const int64_t rows = (int64_t)nseg * HB_BUCKETS;   // cap_bk_rows counts rows for both arrays
     int64_t c1 = b->cap_bk_rows * SPAN_HIST_WORDS, c2 = b->cap_bk_rows * 8;
@@ -1007,17 +1015,23 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
   }
   if (!todo.empty()) {
     HIPCHK(hipMemcpy(posor.data(), b->vcf_posor, 4 * posor.size(), hipMemcpyDeviceToHost));
-    std::vector<int> chunk;
-    int64_t chunk_n = 0;
-    for (size_t i = 0; i <= todo.size(); ++i) {
-      const bool flush = i == todo.size() || (!chunk.empty() && chunk_n + b->L.vcfs[(size_t)todo[i]].n > SORT_CHUNK_RECORDS);
-      if (flush && !chunk.empty()) {
-        int rc = sort_chunk(b, chunk, st, b->last_global, posor);
-        if (rc != QM_OK) return rc;
-        chunk.clear();
-        chunk_n = 0;
+    // the VCFs the bucket path takes (by size: a VCF costs it 256 workgroups and 256 rows whatever it holds, and its
+    // buckets hold 8 192 records at most) in chunks of their own, the others on the radix sort
+    std::vector<int> part[2];
+    for (int v : todo) part[bucket_path_takes(b, b->L.vcfs[(size_t)v].n) ? 1 : 0].push_back(v);
+    for (int kind = 1; kind >= 0; --kind) {
+      std::vector<int> chunk;
+      int64_t chunk_n = 0;
+      for (size_t i = 0; i <= part[kind].size(); ++i) {
+        const bool flush = i == part[kind].size() || (!chunk.empty() && chunk_n + b->L.vcfs[(size_t)part[kind][i]].n > SORT_CHUNK_RECORDS);
+        if (flush && !chunk.empty()) {
+          int rc = sort_chunk(b, chunk, st, b->last_global, posor, kind == 1);
+          if (rc != QM_OK) return rc;
+          chunk.clear();
+          chunk_n = 0;
+        }
+        if (i < part[kind].size()) { chunk.push_back(part[kind][i]); chunk_n += b->L.vcfs[(size_t)part[kind][i]].n; }
       }
-      if (i < todo.size()) { chunk.push_back(todo[i]); chunk_n += b->L.vcfs[(size_t)todo[i]].n; }
     }
     int rc = rescan_and_compact(b, st);
     if (rc != QM_OK) return rc;

@@ -175,6 +175,7 @@ constexpr int HB_SUB_MAX = 1024;         // entries per sub-region at most
 constexpr int HB_MAX_RECORDS = HB_SUBS * HB_SUB_MAX;   // records per bucket (16 per thread of the bucket's workgroup, kept in registers between its two passes)
 constexpr int HB_TRUTH_SLOTS = 2048;     // truth keys of the bucket's positions (<= 50 % full)
 constexpr int HB_NOKEY_SLOTS = 512;      // kept records without a comparable key
+constexpr int HB_MIN_RECORDS = 16384;    // smaller unsorted VCFs take the radix sort
 constexpr int HB_INDEX_BITS = 21;        // a bucket entry holds the record's index inside its VCF
 // a bucket entry (8 bytes): key - (bucket << shift) in bits 0..23, info bits 0..11 (bin + 1, PASS, IDDOT, NOKEY) in 24..35,
 // the host-decided TP-line bit in 36, the record's index inside the VCF in 37..57

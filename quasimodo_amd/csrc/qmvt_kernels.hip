@@ -1473,7 +1473,10 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
 // L2 merges neighbouring pieces into whole lines before they leave for HBM.  The kernel has every record's info in
 // input order in hand: it also writes the VCF's kept mask (kept = live and PASS needs no truth set) and clears its TP mask.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_bucket_scatter(BucketScatterParams P) {
+#ifndef BK_WAVES_PER_EU
+#define BK_WAVES_PER_EU 6
+#endif
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BK_WAVES_PER_EU, 8))) void k_bucket_scatter(BucketScatterParams P) {
   constexpr int PER = BK_TILE / 512;          // records per thread, in groups of four consecutive ones
   static_assert(BK_TILE % 2048 == 0 && PER >= 4, "whole 16-byte loads, 256 records per wave and group");
   __shared__ uint32_t s_cnt[256];             // records of digit d in the tile (running during the ranking)

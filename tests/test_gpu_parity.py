@@ -690,13 +690,14 @@ def test_truth_builder_feeds_the_gpu_path(engine, oracle, tmp_path):
     assert job.stats["TP_R"] == rc["TP"] and job.stats["FP_R"] == rc["FP"] and job.stats["genomediff"] == rc["genomediff"]
 
 
-def test_unsorted_vcf_behind_stale_mask_words(engine, oracle):
+def test_unsorted_vcf_behind_stale_mask_words(engine, oracle, monkeypatch):
     """The bucket path's scatter writes the kept mask in 32-bit words, the compaction reads 64-bit ones: the words
     between a VCF's last record and the end of its padding must be written too.  Found by `tools/gpu_fuzz.py 100 8`
     (round 99: an unsorted VCF of 1 025 records whose FP index list picked up bits that had been left in that memory),
     which is the reliable reproducer -- whether this test meets dirty memory depends on the allocator; it pins the
     batch shape and leaves ones behind from a first batch of the same padded sizes."""
     from conftest import random_columns, random_truth
+    monkeypatch.setenv("QM_BUCKET_MIN", "0")    # VCFs this small take the radix sort otherwise
     rng = np.random.default_rng(5)
     L = (1 << 28) - 1
     truth = random_truth(rng, 50, L)
@@ -727,3 +728,25 @@ def test_batch_of_empty_vcfs(engine, oracle):
         assert not glob[tid].any()
         for r in res:
             check_vcf(oracle, r, e, truth)
+
+
+def test_many_small_unsorted_vcfs_and_a_few_large_ones(engine, oracle):
+    """The unsorted VCFs of a batch are split by size: the bucket path takes the large ones (it costs 256 workgroups and 256
+    histogram rows per VCF), the radix sort the small ones -- here 1 500 VCFs of a few hundred records beside three of 40 000."""
+    from conftest import random_columns, random_truth
+    rng = np.random.default_rng(77)
+    L = 300_000
+    truth = random_truth(rng, 5000, L)
+    tid = engine.truth_load(*truth)
+    sizes = [int(x) for x in rng.integers(1, 700, 1500)] + [40_000, 40_001, 39_999]
+    order = rng.permutation(len(sizes))
+    sizes = [sizes[i] for i in order]
+    cols = [random_columns(rng, n, L, truth, sorted_=bool(rng.random() < 0.2)) for n in sizes]
+    res, glob = engine.classify_batch(cols, [tid] * len(sizes))
+    want = np.zeros((3, 256), np.uint64)
+    for i, (r, c) in enumerate(zip(res, cols)):
+        want += r["roc"]
+        if i % 25 == 0 or len(c[0]) > 30_000:
+            check_vcf(oracle, r, c, truth)
+    assert np.array_equal(glob[tid], want)
+    engine.truth_release(tid)

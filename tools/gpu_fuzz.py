@@ -11,6 +11,7 @@ import time
 import numpy as np
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+os.environ.setdefault("QM_BUCKET_MIN", "0")   # the fuzzed VCFs are small: send the unsorted ones through the bucket path all the same
 sys.path.insert(0, ROOT)
 import quasimodo_amd as q
 from oracle import qm_oracle as O
