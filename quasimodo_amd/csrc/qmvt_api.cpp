@@ -1023,7 +1023,8 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
       std::vector<int> chunk;
       int64_t chunk_n = 0;
       for (size_t i = 0; i <= part[kind].size(); ++i) {
-        const bool flush = i == part[kind].size() || (!chunk.empty() && chunk_n + b->L.vcfs[(size_t)part[kind][i]].n > SORT_CHUNK_RECORDS);
+        const bool flush = i == part[kind].size() || (!chunk.empty() && chunk_n + b->L.vcfs[(size_t)part[kind][i]].n > SORT_CHUNK_RECORDS) ||
+                           (kind == 1 && chunk.size() >= 4096);   // 256 rows of 1.5 KB and >= 1 MB of bucket regions per VCF: bounded per chunk
         if (flush && !chunk.empty()) {
           int rc = sort_chunk(b, chunk, st, b->last_global, posor, kind == 1);
           if (rc != QM_OK) return rc;

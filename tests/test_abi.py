@@ -60,13 +60,13 @@ def test_null_arguments_are_rejected(qmlib):
     assert b"NULL" in qmlib.qm_last_error(None)
 
 
-def _build_c_example(tmp_path):
+def _build_c_example(tmp_path, name="qm_bench"):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "qm_bench")
+    exe = str(tmp_path / name)
     libdir = os.path.join(root, "quasimodo_amd", "csrc")
-    subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), "-o", exe,
-                    os.path.join(root, "examples", "qm_bench.c"), "-L" + libdir, "-lqmvt", "-Wl,-rpath," + libdir], check=True)
+    subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-pthread", "-I" + os.path.join(root, "include"), "-o", exe,
+                    os.path.join(root, "examples", name + ".c"), "-L" + libdir, "-lqmvt", "-Wl,-rpath," + libdir], check=True)
     return exe
 
 
@@ -93,3 +93,27 @@ def test_c_program_runs_the_synthetic_workload(qmlib, tmp_path):
     r2 = subprocess.run([exe, "4", "1000000", "2", "1"], capture_output=True, text=True)      # shuffled: the radix-sort path
     d2 = json.loads(r2.stdout)
     assert r2.returncode == 0 and d2["kept"] > 0
+
+
+def test_multi_device_c_program_fails_loudly_without_a_gpu(qmlib, tmp_path):
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by the gpu test")
+    exe = _build_c_example(tmp_path, "qm_multi")
+    r = subprocess.run([exe, "0,0", "4", "1000", "1"], capture_output=True, text=True)
+    assert r.returncode == 2 and "no CPU fallback" in r.stderr and r.stdout == ""
+
+
+@pytest.mark.gpu
+def test_multi_device_c_program_shards_sum_to_the_single_batch(qmlib, tmp_path):
+    """examples/qm_multi.c: one host thread and one context per device (here the same card twice), contiguous VCF shards, the
+    counters summed on the host -- identical to the same VCFs in one batch."""
+    import json
+    import subprocess
+    exe = _build_c_example(tmp_path, "qm_multi")
+    r = subprocess.run([exe, "0,0", "10", "1000000", "2", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout)
+    assert d["devices"] == 2 and d["vcfs"] == 10 and d["equals_one_batch"] is True
+    assert d["kept"] == d["tp_lines"] + d["fp_lines"] and d["roc_tp_at_20"] == d["tp_lines"]
