@@ -1935,28 +1935,62 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
   __syncthreads();
   // second pass: keys on unmarked bits are distinct; keys on marked bits are counted exactly -- the thread's own candidates
   // from its registers, then the listed ones (the filter's false positives, settled by some lane of their wave)
-  auto count_key = [&](uint32_t v, bool c) {
-    const uint32_t h = hb_hash(v) >> (32u - LFB);
-    const bool marked = c && ((s_b2[h >> 5] >> (h & 31u)) & 1u);
-    fpr += (c && !marked) ? 1u : 0u;
-    const uint32_t at = wave_reserve(&s_c[7], marked);
-    if (marked) {
-      if (at >= (1u << LX) / 2u) {
-        atomicOr(&s_c[4], SPANF_OVERFLOW);
-      } else {
-        bool fresh;
-        (void)hb_insert(s_x, LX, v, &fresh);
-        fpr += fresh ? 1u : 0u;
+  // which candidates sit on marked bits: one LDS read each, no branch; the others are distinct by construction
+  uint32_t mm = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const uint32_t h = hb_hash(vq[k]) >> (32u - LFB);
+    mm |= ((s_b2[h >> 5] >> (h & 31u)) & (cand >> k) & 1u) << k;
+  }
+  fpr += (uint32_t)__popc(cand & ~mm);
+  {
+    // room in the exact set for the marked ones: one reservation per wave (prefix sum of the lanes' counts by DPP-free shuffles)
+    const uint32_t lane = (uint32_t)tid & 63u;
+    const uint32_t cnt = (uint32_t)__popc(mm);
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_up(incl, o);
+      if (lane >= (uint32_t)o) incl += y;
+    }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (total) {   // wave-uniform
+      uint32_t base = 0u;
+      if (lane == 0u) base = atomicAdd(&s_c[7], total);
+      uint32_t at = (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + incl - cnt;
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        if ((mm >> k) & 1u) {
+          if (at >= (1u << LX) / 2u) {
+            atomicOr(&s_c[4], SPANF_OVERFLOW);
+          } else {
+            bool fresh;
+            (void)hb_insert(s_x, LX, vq[k], &fresh);
+            fpr += fresh ? 1u : 0u;
+          }
+          ++at;
+        }
       }
     }
-  };
-#pragma unroll
-  for (int k = 0; k < PER; ++k) count_key(vq[k], ((cand >> k) & 1u) != 0u);
+  }
   {
     const uint32_t nfq = s_c[8] < (uint32_t)HB_FQ_SLOTS ? s_c[8] : (uint32_t)HB_FQ_SLOTS;
     for (uint32_t i0 = 0; i0 < nfq; i0 += HB_THREADS) {   // wave-uniform trip count
       const uint32_t i = i0 + (uint32_t)tid;
-      count_key(i < nfq ? s_fq[i] : 0u, i < nfq);
+      const uint32_t v = i < nfq ? s_fq[i] : 0u;
+      const uint32_t h = hb_hash(v) >> (32u - LFB);
+      const bool marked = i < nfq && ((s_b2[h >> 5] >> (h & 31u)) & 1u);
+      fpr += (i < nfq && !marked) ? 1u : 0u;
+      const uint32_t at = wave_reserve(&s_c[7], marked);
+      if (marked) {
+        if (at >= (1u << LX) / 2u) {
+          atomicOr(&s_c[4], SPANF_OVERFLOW);
+        } else {
+          bool fresh;
+          (void)hb_insert(s_x, LX, v, &fresh);
+          fpr += fresh ? 1u : 0u;
+        }
+      }
     }
   }
   HB_TICK(7);
