@@ -974,7 +974,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
         if (P.vcf_posor) P.vcf_posor[v] = s_or;
         const uint32_t out = fl & (SPANF_UNSORTED | SPANF_BADPOS | SPANF_RUNLIMIT | SPANF_OVERFLOW);
         P.vcf_flags[v] = out;
-        if (out && P.flag_summary) *reinterpret_cast<volatile uint32_t*>(P.flag_summary) = 1u;   // host-mapped: tells qm_batch_finish that the per-VCF flags are worth a copy
+        if (out && P.flag_summary) __hip_atomic_store(P.flag_summary, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-mapped: tells qm_batch_finish that the per-VCF flags are worth a copy
       }
       else if (tid == 6) sc[6] = vd.n;
       else sc[7] = P.ext ? P.truths[vd.truth].xn : P.truths[vd.truth].n;
@@ -1717,6 +1717,12 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
   const HashRow R = P.rows[row];                                 // one scalar load beside the cursors: nothing below waits for more than
   const uint32_t* cur = P.cursor + row * HB_SUBS;                // one further round trip (the entries and the truth keys, together)
   const uint32_t segfl = d == 0 ? P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + blockIdx.y] : 0u;   // the segment's flags travel in its first row
+  // pointers that come out of memory are generic to the compiler: loads through them would be flat_load, which counts on
+  // the LDS counter too -- every wait for an LDS result would then also wait for the entries in flight
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(1))) v4u* gv4p;
+  const gv4p g_ent = (gv4p)R.ent;
+  const gu32p g_tkeys = (gu32p)R.tkeys;
   const uint32_t cap = R.cap;
   uint32_t nsub[HB_SUBS];     // wave-uniform (scalar loads)
   uint32_t nrec = 0, over = 0;
@@ -1739,7 +1745,6 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
   // A trip gives every thread four consecutive entries of one sub-region (32 bytes, two 16-byte loads: dword loads are bound
   // by the rate of memory instructions).  The first trip and the thread's truth key are in flight before the tables are
   // even cleared; later trips are fetched one ahead.
-  typedef unsigned v4u __attribute__((ext_vector_type(4)));
   const uint32_t lcap = 31u - (uint32_t)__clz(cap);            // cap is a power of two >= 4
   const uint32_t nslots = (HB_SUBS * cap) >> 2;
   v4u ea[2], eb[2];
@@ -1754,7 +1759,7 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
     ea[buf] = z4; eb[buf] = z4; nv[buf] = 0u;
     if (slot < nslots && w < n && !over) {
       nv[buf] = n - w < 4u ? n - w : 4u;
-      const v4u* src = reinterpret_cast<const v4u*>(R.ent + e0);
+      const gv4p src = g_ent + (e0 >> 1);   // two entries per 16 bytes
       ea[buf] = __builtin_nontemporal_load(src);
       eb[buf] = __builtin_nontemporal_load(src + 1);
     }
@@ -1769,8 +1774,8 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
 #else
   const int tn = 0;
 #endif
-  if (tid < tn) tkey0 = R.tkeys[tid];
-  if (tid + HB_THREADS < tn) tkey1 = R.tkeys[tid + HB_THREADS];   // up to 1 024 keys: all a bucket can take are in flight here
+  if (tid < tn) tkey0 = g_tkeys[tid];
+  if (tid + HB_THREADS < tn) tkey1 = g_tkeys[tid + HB_THREADS];   // up to 1 024 keys: all a bucket can take are in flight here
   for (int i = tid; i < (1 << LTR); i += HB_THREADS) { s_tk[i] = HB_EMPTY; s_ts[i] = 0u; }
   for (int i = tid; i < (1 << LFB) / 32; i += HB_THREADS) { s_b1[i] = 0u; s_b2[i] = 0u; }
   if (tid < (1 << LTB) / 32) s_tb[tid] = 0u;
@@ -1784,7 +1789,7 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
   // ---- the truth keys of the bucket's positions (the coarse position index hands out whole cells) ----
   for (int j0 = 0; j0 < tn; j0 += HB_THREADS) {   // wave-uniform trip count
     const int j = j0 + tid;
-    const uint32_t k = j >= tn ? 0u : j0 == 0 ? tkey0 : j0 == HB_THREADS ? tkey1 : R.tkeys[j];
+    const uint32_t k = j >= tn ? 0u : j0 == 0 ? tkey0 : j0 == HB_THREADS ? tkey1 : g_tkeys[j];
     const bool in = j < tn && k >= kbase && k <= klast;
     const uint32_t at = wave_reserve(&s_c[5], in);
     if (in) {
