@@ -2052,22 +2052,31 @@ __global__ __launch_bounds__(256) void k_sort_scatter_tp(const SortSeg* segs, co
 // per-tile TP / FP line counts of the redone VCFs from their rebuilt masks (one thread per K1 tile)
 __global__ __launch_bounds__(256) void k_tile_counts(const SortSeg* segs, const int32_t* ktile_seg, const int32_t* ktile_local, int nktiles,
                                                      const uint64_t* mp, const uint64_t* mt, uint32_t* tile_tp, uint32_t* tile_fp) {
-  const int kt = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (kt >= nktiles) return;
-  const SortSeg sg = segs[ktile_seg[kt]];
-  const int t = ktile_local[kt];
-  const int64_t tb = (int64_t)t * K1_TILE;
-  const int64_t w0 = (sg.src_off + tb) >> 6;
+  // sixteen lanes per tile, one 64-record mask word each (neighbouring lanes read neighbouring words), summed with shuffles
+  static_assert(K1_TILE / 64 == 16, "sixteen mask words per tile");
+  const int kt = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+  const int w = (int)threadIdx.x & 15;
   uint32_t ntp = 0, nfp = 0;
-  for (int w = 0; w < K1_TILE / 64; ++w) {
+  SortSeg sg;
+  int t = 0;
+  const bool live = kt < nktiles;
+  if (live) {
+    sg = segs[ktile_seg[kt]];
+    t = ktile_local[kt];
+    const int64_t tb = (int64_t)t * K1_TILE;
     if (tb + (int64_t)w * 64 < sg.n) {
-      const uint64_t bp = mp[w0 + w], bt = mt[w0 + w];
-      ntp += (uint32_t)__popcll(bt);
-      nfp += (uint32_t)__popcll(bp & ~bt);
+      const int64_t i = ((sg.src_off + tb) >> 6) + w;
+      const uint64_t bp = mp[i], bt = mt[i];
+      ntp = (uint32_t)__popcll(bt);
+      nfp = (uint32_t)__popcll(bp & ~bt);
     }
   }
-  tile_tp[sg.main_tile0 + t] = ntp;
-  tile_fp[sg.main_tile0 + t] = nfp;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) { ntp += __shfl_xor(ntp, o); nfp += __shfl_xor(nfp, o); }
+  if (live && w == 0) {
+    tile_tp[sg.main_tile0 + t] = ntp;
+    tile_fp[sg.main_tile0 + t] = nfp;
+  }
 }
 
 // ROC rows and scalars of the sorted scratch VCFs back under the original VCFs
@@ -2222,7 +2231,7 @@ void launch_sort_scatter_tp(const SortSeg* segs, const int32_t* tile_seg, int nt
 void launch_tile_counts(const SortSeg* segs, const int32_t* ktile_seg, const int32_t* ktile_local, int nktiles, const uint64_t* mp,
                         const uint64_t* mt, uint32_t* tile_tp, uint32_t* tile_fp, hipStream_t st) {
   if (nktiles > 0)
-    hipLaunchKernelGGL(k_tile_counts, dim3((unsigned)((nktiles + 255) / 256)), dim3(256), 0, st, segs, ktile_seg, ktile_local, nktiles, mp, mt,
+    hipLaunchKernelGGL(k_tile_counts, dim3((unsigned)((nktiles + 15) / 16)), dim3(256), 0, st, segs, ktile_seg, ktile_local, nktiles, mp, mt,
                        tile_tp, tile_fp);
 }
 void launch_sort_copy_rows(const SortSeg* segs, int nseg, const uint64_t* sub_roc, const int64_t* sub_scal, uint64_t* roc,
