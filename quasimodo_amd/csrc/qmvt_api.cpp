@@ -373,6 +373,7 @@ struct qm_batch {
   int64_t cap_bk_rowdesc = 0;
   int64_t cap_bk_ent = 0, cap_bk_cursor = 0, cap_bk_tiles = 0;
   bool bk_tiles_valid = false;      // d_bk_tile_seg holds the tile map of last_segs
+  bool bk_fake_valid = false;       // d_bk_vcfs holds the row descriptors of last_segs
   // throw-away outputs of the rescan after a sort (kept: an allocation per finish costs more than the rescan)
   uint64_t* rs_roc = nullptr;
   int64_t* rs_scal = nullptr;
@@ -806,8 +807,10 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     b->dev_bytes += b->sub->dev_bytes;
     b->sub_sig = sig;
     b->sub_tids = tids;
+    b->bk_fake_valid = false;
   } else if (b->sub_tids != tids) {
     b->sub_tids = tids;
+    b->bk_fake_valid = false;   // the row descriptors name the truth sets
     for (int i = 0; i < nseg; ++i) b->sub->L.vcfs[(size_t)i].truth = tids[(size_t)i];
     for (SpanDesc& sd : b->sub->L.spans) sd.truth = b->sub->L.vcfs[(size_t)sd.vcf].truth;
     int rc = upload_layout(b->sub);
@@ -816,13 +819,12 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   qm_batch* s = b->sub;
   // --- segment table and tile maps
   std::vector<SortSeg> segs((size_t)nseg);
-  std::vector<int32_t> tile_seg, ktile_seg, ktile_local, bk_tile_seg;
-  int64_t koff = 0, hoff = 0, bk_ents = 0;
+  int64_t koff = 0, hoff = 0, bk_ents = 0, nst64 = 0, nkt64 = 0, nbt64 = 0;
   for (int i = 0; i < nseg; ++i) {
     const VcfDesc& d = b->L.vcfs[(size_t)vs[(size_t)i]];
     SortSeg& g = segs[(size_t)i];
     g.src_off = d.off; g.dst_off = s->L.vcfs[(size_t)i].off; g.koff = koff; g.hoff = hoff; g.n = d.n;
-    g.tile0 = (int32_t)tile_seg.size(); g.ntiles = (int32_t)((d.n + SORT_TILE - 1) / SORT_TILE);
+    g.tile0 = (int32_t)nst64; g.ntiles = (int32_t)((d.n + SORT_TILE - 1) / SORT_TILE);
     g.main_vcf = vs[(size_t)i]; g.sub_vcf = i; g.main_tile0 = d.tile0;
     {   // bucket path: the shift that makes the top eight key bits in use the bucket number (key = pos << 4 | nibble)
       const uint32_t kor = (posor[(size_t)vs[(size_t)i]] << 4) | 15u;
@@ -834,16 +836,29 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
       while (cap2 < want && cap2 < HB_SUB_MAX) cap2 *= 2;
       g.bk_cap = (int32_t)cap2;
       g.bk_off = bk_ents;
-      g.bk_tile0 = (int32_t)bk_tile_seg.size();
+      g.bk_tile0 = (int32_t)nbt64;
       bk_ents += (int64_t)HB_BUCKETS * HB_SUBS * cap2;
-      for (int64_t t = 0; t < (d.n + BK_TILE - 1) / BK_TILE; ++t) bk_tile_seg.push_back(i);
+      nbt64 += (d.n + BK_TILE - 1) / BK_TILE;
     }
-    for (int t = 0; t < g.ntiles; ++t) tile_seg.push_back(i);
-    for (int t = 0; t < d.ntiles; ++t) { ktile_seg.push_back(i); ktile_local.push_back(t); }
+    nst64 += g.ntiles;
+    nkt64 += d.ntiles;
     koff += (d.n + 63) / 64 * 64;
     hoff += (int64_t)g.ntiles * 256;
   }
-  const int nst = (int)tile_seg.size(), nkt = (int)ktile_seg.size();
+  if (nst64 > INT32_MAX || nkt64 > INT32_MAX || nbt64 > INT32_MAX) return fail(QM_E_LIMIT, "sort chunk: too many tiles");
+  const int nst = (int)nst64, nkt = (int)nkt64, nbt = (int)nbt64;
+  // the tile maps (which segment a tile belongs to) follow from the segment table and are only spelled out when it changed:
+  // a batch that is run again and again with the same VCFs out of order keeps them on the device
+  std::vector<int32_t> tile_seg, ktile_seg, ktile_local, bk_tile_seg;
+  auto build_tile_maps = [&]() {
+    tile_seg.reserve((size_t)nst); ktile_seg.reserve((size_t)nkt); ktile_local.reserve((size_t)nkt); bk_tile_seg.reserve((size_t)nbt);
+    for (int i = 0; i < nseg; ++i) {
+      const VcfDesc& d = b->L.vcfs[(size_t)vs[(size_t)i]];
+      for (int t = 0; t < segs[(size_t)i].ntiles; ++t) tile_seg.push_back(i);
+      for (int t = 0; t < d.ntiles; ++t) { ktile_seg.push_back(i); ktile_local.push_back(t); }
+      for (int64_t t = 0; t < (d.n + BK_TILE - 1) / BK_TILE; ++t) bk_tile_seg.push_back(i);
+    }
+  };
   int rc = QM_OK;
   int64_t cap;
   if (rc == QM_OK) { cap = b->cap_segs; rc = regrow(&b->d_segs, &cap, (int64_t)nseg, &b->dev_bytes); b->cap_segs = (int)cap; }
@@ -867,22 +882,24 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     if (rc == QM_OK) rc = regrow(&b->bk_ent, &b->cap_bk_ent, bk_ents, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_rows, &b->cap_bk_rowdesc, rows, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_cursor, &b->cap_bk_cursor, rows * HB_SUBS + nseg + 32, &b->dev_bytes);   // + 32: phase clocks of a profiling build
-    if (rc == QM_OK && (int64_t)bk_tile_seg.size() > b->cap_bk_tiles) {
+    if (rc == QM_OK && (int64_t)nbt > b->cap_bk_tiles) {
       b->bk_tiles_valid = false;
-      rc = regrow(&b->d_bk_tile_seg, &b->cap_bk_tiles, (int64_t)bk_tile_seg.size(), &b->dev_bytes);
+      rc = regrow(&b->d_bk_tile_seg, &b->cap_bk_tiles, (int64_t)nbt, &b->dev_bytes);
     }
   }
   if (rc != QM_OK) return rc;
   const bool same_tables = b->last_segs.size() == segs.size() && memcmp(b->last_segs.data(), segs.data(), sizeof(SortSeg) * segs.size()) == 0;
-  if (!same_tables) {   // the tile maps follow from the segment table
-    HIPCHK(hipMemcpyAsync(b->d_segs, segs.data(), sizeof(SortSeg) * segs.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(b->d_tile_seg, tile_seg.data(), 4 * tile_seg.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(b->d_ktile_seg, ktile_seg.data(), 4 * ktile_seg.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(b->d_ktile_local, ktile_local.data(), 4 * ktile_local.size(), hipMemcpyHostToDevice, st));
-    b->bk_tiles_valid = false;
-  }
-  if (try_buckets && !b->bk_tiles_valid) HIPCHK(hipMemcpyAsync(b->d_bk_tile_seg, bk_tile_seg.data(), 4 * bk_tile_seg.size(), hipMemcpyHostToDevice, st));
   if (!same_tables || (try_buckets && !b->bk_tiles_valid)) {
+    build_tile_maps();
+    if (!same_tables) {
+      HIPCHK(hipMemcpyAsync(b->d_segs, segs.data(), sizeof(SortSeg) * segs.size(), hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(b->d_tile_seg, tile_seg.data(), 4 * tile_seg.size(), hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(b->d_ktile_seg, ktile_seg.data(), 4 * ktile_seg.size(), hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemcpyAsync(b->d_ktile_local, ktile_local.data(), 4 * ktile_local.size(), hipMemcpyHostToDevice, st));
+      b->bk_tiles_valid = false;
+      b->bk_fake_valid = false;
+    }
+    if (try_buckets && !b->bk_tiles_valid) HIPCHK(hipMemcpyAsync(b->d_bk_tile_seg, bk_tile_seg.data(), 4 * bk_tile_seg.size(), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));   // the host vectors die with this call
     b->last_segs = segs;
     b->bk_tiles_valid = try_buckets;
@@ -891,20 +908,24 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   SortCols src = {b->pos, b->ref, b->alt, b->qual, b->flags};
   if (try_buckets) {
     // --- bucket path: ONE scatter on each VCF's top eight key bits into fixed-size bucket regions, then the hash-join per bucket
-    std::vector<VcfDesc> fake((size_t)nseg);
-    for (int i = 0; i < nseg; ++i) {
-      VcfDesc& f = fake[(size_t)i];
-      f = VcfDesc();
-      f.off = 0; f.n = segs[(size_t)i].n; f.truth = tids[(size_t)i]; f.tile0 = 0; f.ntiles = 0; f.span0 = i * HB_BUCKETS; f.nspans = HB_BUCKETS; f.pad = 0;
+    if (!b->bk_fake_valid) {   // the buckets of a VCF as the "spans" of a VCF, for k_finalize
+      std::vector<VcfDesc> fake((size_t)nseg);
+      for (int i = 0; i < nseg; ++i) {
+        VcfDesc& f = fake[(size_t)i];
+        f = VcfDesc();
+        f.off = 0; f.n = segs[(size_t)i].n; f.truth = tids[(size_t)i]; f.tile0 = 0; f.ntiles = 0; f.span0 = i * HB_BUCKETS; f.nspans = HB_BUCKETS; f.pad = 0;
+      }
+      HIPCHK(hipMemcpyAsync(b->d_bk_vcfs, fake.data(), sizeof(VcfDesc) * fake.size(), hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));
+      b->bk_fake_valid = true;
     }
-    HIPCHK(hipMemcpyAsync(b->d_bk_vcfs, fake.data(), sizeof(VcfDesc) * fake.size(), hipMemcpyHostToDevice, st));
     const size_t ncur = ((size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg + 32) * 4;
     HIPCHK(hipMemsetAsync(b->bk_cursor, 0, ncur, st));
     BucketScatterParams S;
     S.segs = b->d_segs; S.tile_seg = b->d_bk_tile_seg; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
     S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
     S.n_seg = nseg; S.n_bins = b->n_bins;
-    launch_bucket_scatter(S, (int)bk_tile_seg.size(), st);
+    launch_bucket_scatter(S, nbt, st);
     HashParams H;
     H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
     H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins;
