@@ -924,13 +924,43 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     BucketScatterParams S;
     S.segs = b->d_segs; S.tile_seg = b->d_bk_tile_seg; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
     S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
-    S.n_seg = nseg; S.n_bins = b->n_bins;
-    launch_bucket_scatter(S, nbt, st);
+    S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0;
     HashParams H;
     H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
-    H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins;
+    H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.seg_base = 0;
     launch_bucket_rows(H, nseg, st);
-    launch_classify_hash(H, nseg, st);
+    // The scatter streams (memory-bound, its SIMDs half idle), the join issues instructions (and hardly waits for memory): in a
+    // few segment ranges, the join of one range on the second stream beside the scatter of the next, they fill each other's gaps.
+    int parts = nseg >= 8 && b->ev_sync[0] ? 4 : 1;
+    if (const char* e = getenv("QM_BUCKET_PARTS")) parts = std::max(1, std::min({atoi(e), nseg, (int)qm_batch::MAX_CHUNKS}));
+    if (!b->ev_sync[0]) parts = 1;
+    hipStream_t aux = parts > 1 ? b->ctx->aux : st;
+    int i0 = 0;
+    for (int p = 0; p < parts; ++p) {
+      // ranges of about equal record counts
+      int i1 = p + 1 == parts ? nseg : i0;
+      if (p + 1 < parts) {
+        const int64_t want = (int64_t)nbt * (p + 1) / parts;
+        while (i1 < nseg && segs[(size_t)i1].bk_tile0 < want) ++i1;
+        i1 = std::max(i1, i0);
+      }
+      if (i1 > i0) {
+        const int t0 = segs[(size_t)i0].bk_tile0, t1 = i1 < nseg ? segs[(size_t)i1].bk_tile0 : nbt;
+        S.tile_base = t0;
+        launch_bucket_scatter(S, t1 - t0, st);
+        if (parts > 1) {
+          HIPCHK(hipEventRecord(b->ev_sync[p], st));
+          HIPCHK(hipStreamWaitEvent(aux, b->ev_sync[p], 0));
+        }
+        H.seg_base = i0;
+        launch_classify_hash(H, i1 - i0, aux);
+      }
+      i0 = i1;
+    }
+    if (parts > 1) {
+      HIPCHK(hipEventRecord(b->ev_sync[qm_batch::MAX_CHUNKS + 1], aux));
+      HIPCHK(hipStreamWaitEvent(st, b->ev_sync[qm_batch::MAX_CHUNKS + 1], 0));
+    }
     FinalizeParams F = finalize_params(s, nullptr);   // the rows join the per-truth sums only once no bucket is known to have overflowed
     F.vcfs = b->d_bk_vcfs; F.span_hist = b->bk_hist; F.span_scal = b->bk_scal; F.vcf_posor = nullptr;
     launch_finalize(F, nseg, st);

@@ -193,6 +193,7 @@ struct BucketScatterParams {
   uint32_t* mask_tp;
   int32_t n_seg;
   int32_t n_bins;
+  int32_t tile_base;          // first scatter tile of this launch (the chunk is scattered in a few segment ranges)
 };
 // everything k_classify_hash needs to know about one (segment, bucket), laid out by k_bucket_rows before it runs: the
 // workgroup of a bucket lives only a few microseconds, and every dependent load on its way to the data (segment table ->
@@ -219,6 +220,7 @@ struct HashParams {
   uint32_t* row_scal;         // [n_seg * 256][8]
   int32_t n_seg;
   int32_t n_bins;
+  int32_t seg_base;           // first segment of this launch of k_classify_hash
 };
 struct SortCols { const int32_t* pos; const int32_t* ref; const int32_t* alt; const float* qual; const uint8_t* flags; };
 
@@ -317,9 +319,9 @@ void launch_finalize(const FinalizeParams& P, int n_vcf, hipStream_t st);
 void launch_compact(const CompactParams& P, int n_spans, hipStream_t st);
 void launch_masks_to_cls(const uint64_t* mp, const uint64_t* mt, int64_t off, int64_t n, uint8_t* cls, hipStream_t st);
 void launch_synth(const SynthParams& S, int n_vcf, int64_t max_n, hipStream_t st);
-void launch_classify_hash(const HashParams& P, int nseg, hipStream_t st);
+void launch_classify_hash(const HashParams& P, int nseg, hipStream_t st);   // segments P.seg_base .. + nseg
 void launch_bucket_rows(const HashParams& P, int nseg, hipStream_t st);
-void launch_bucket_scatter(const BucketScatterParams& P, int ntiles, hipStream_t st);
+void launch_bucket_scatter(const BucketScatterParams& P, int ntiles, hipStream_t st);   // tiles P.tile_base .. + ntiles
 void launch_sort_first_hist(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const int32_t* pos_col, uint32_t* hist, uint32_t* orbits,
                             hipStream_t st);
 void launch_sort_first_scatter(const SortSeg* segs, const int32_t* tile_seg, int nseg, int ntiles, const SortCols& src, int n_bins, int ext,

@@ -1485,7 +1485,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BK_WAVES_PE
   __shared__ uint32_t s_scan[5];
   __shared__ uint64_t s_e[BK_TILE];
   __shared__ uint8_t s_d[BK_TILE];
-  const int bid = (int)blockIdx.x;
+  const int bid = (int)blockIdx.x + P.tile_base;
   const int seg = P.tile_seg[bid];
   const SortSeg sg = P.segs[seg];
   const int sub = bid & (HB_SUBS - 1);
@@ -1709,14 +1709,15 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
   __shared__ uint32_t s_c[9];                        // kept, TP lines, distinct FP keys, matched truth keys, flags, truth keys staged, keyless inserts, marked inserts, listed keys
   const int tid = (int)threadIdx.x;
   const int d = (int)blockIdx.x;
-  const size_t row = (size_t)blockIdx.y * HB_BUCKETS + (size_t)d;
+  const int seg_id = (int)blockIdx.y + P.seg_base;
+  const size_t row = (size_t)seg_id * HB_BUCKETS + (size_t)d;
 #ifdef HB_PROFILE
   uint32_t* hb_prof = const_cast<uint32_t*>(P.cursor) + (size_t)P.n_seg * HB_BUCKETS * HB_SUBS + (size_t)P.n_seg;
   unsigned long long hb_t = __builtin_amdgcn_s_memtime();
 #endif
   const HashRow R = P.rows[row];                                 // one scalar load beside the cursors: nothing below waits for more than
   const uint32_t* cur = P.cursor + row * HB_SUBS;                // one further round trip (the entries and the truth keys, together)
-  const uint32_t segfl = d == 0 ? P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + blockIdx.y] : 0u;   // the segment's flags travel in its first row
+  const uint32_t segfl = d == 0 ? P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg_id] : 0u;   // the segment's flags travel in its first row
   // pointers that come out of memory are generic to the compiler: loads through them would be flat_load, which counts on
   // the LDS counter too -- every wait for an LDS result would then also wait for the entries in flight
   typedef unsigned v4u __attribute__((ext_vector_type(4)));
