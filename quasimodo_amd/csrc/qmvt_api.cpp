@@ -660,6 +660,7 @@ static FinalizeParams finalize_params(qm_batch* b, uint64_t* global) {
   F.roc = b->roc; F.scalars = b->scalars; F.vcf_flags = b->vcf_flags; F.vcf_posor = b->vcf_posor; F.global_acc = global; F.n_bins = b->n_bins; F.ext = b->ext ? 1 : 0;
   F.vcf_base = 0;
   F.flag_summary = nullptr;
+  F.parts = 3;
   return F;
 }
 static CompactParams compact_params(qm_batch* b) {
@@ -717,6 +718,18 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
     FinalizeParams F = finalize_params(b, g);
     F.vcf_base = ck.v0;
     F.flag_summary = b->d_summary;
+    // In one piece (the default), the compaction waits only for what it needs of k_finalize -- per-VCF flags and tile offsets --
+    // and the rows (ROC, scalars, per-truth sums: 96 MB of span histograms to sum) go to the second stream beside it.
+    static const bool split_on = !getenv("QM_FINALIZE_SPLIT") || atoi(getenv("QM_FINALIZE_SPLIT")) != 0;
+    const bool split = split_on && nch == 1 && b->ev_sync[0] != nullptr;
+    if (split) {
+      HIPCHK(hipEventRecord(b->ev_sync[0], st));
+      HIPCHK(hipStreamWaitEvent(c->aux, b->ev_sync[0], 0));
+      F.parts = 2;
+      launch_finalize(F, ck.v1 - ck.v0, c->aux);
+      HIPCHK(hipEventRecord(b->ev_sync[1], c->aux));
+      F.parts = 1;
+    }
     launch_finalize(F, ck.v1 - ck.v0, st);
     if (T) HIPCHK(hipEventRecord(e5[2], st));
     CompactParams K = compact_params(b);
@@ -732,6 +745,8 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
   if (nch > 1) {
     HIPCHK(hipEventRecord(b->ev_sync[qm_batch::MAX_CHUNKS + 1], aux));
     HIPCHK(hipStreamWaitEvent(st, b->ev_sync[qm_batch::MAX_CHUNKS + 1], 0));
+  } else if (b->ev_sync[0] != nullptr && (!getenv("QM_FINALIZE_SPLIT") || atoi(getenv("QM_FINALIZE_SPLIT")) != 0)) {
+    HIPCHK(hipStreamWaitEvent(st, b->ev_sync[1], 0));   // the rows of k_finalize
   }
   if (T) { HIPCHK(hipEventRecord(ev[1], st)); b->n_timed++; }
   HIPCHK(hipGetLastError());

@@ -135,6 +135,7 @@ struct FinalizeParams {
   int32_t ext;           // allele-extended batch: T' is the size of the extended truth table
   int32_t vcf_base;      // first VCF of this launch
   uint32_t* flag_summary; // or null: host-mapped word, set to 1 if any VCF of the launch carries a flag
+  int32_t parts;          // 1 = flags and tile offsets (what k_compact needs), 2 = ROC / scalars / per-truth sums, 3 = both
 };
 
 struct CompactParams {

@@ -932,13 +932,18 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
     else if (k == 5) { if (x) atomicOr(&s_fl, x); }
     else if (k == 6) { if (x) atomicOr(&s_or, x); }
   }
+  // P.parts: bit 0 = the part the compaction waits for (per-VCF flags, tile offsets), bit 1 = the rows (ROC, scalars, per-truth
+  // sums).  qm_batch_run launches the two apart, the rows on the second stream beside the compaction; everybody else wants both.
+  const bool rows = (P.parts & 2) != 0, offsets = (P.parts & 1) != 0;
   // sum span histograms (thread = bin)
   uint32_t h0 = 0, h1 = 0, h2 = 0;
   const int hw = tid >> 1, hs = 16 * (tid & 1);   // two u16 bins per dword
+  if (rows) {
 #pragma unroll 8
-  for (int s = 0; s < vd.nspans; ++s) {   // unrolled: the loads of eight spans are in flight together (10 M-record VCFs have 611 spans)
-    const uint32_t* sh = P.span_hist + (size_t)(vd.span0 + s) * SPAN_HIST_WORDS;
-    h0 += (sh[hw] >> hs) & 0xffffu; h1 += (sh[128 + hw] >> hs) & 0xffffu; h2 += (sh[256 + hw] >> hs) & 0xffffu;
+    for (int s = 0; s < vd.nspans; ++s) {   // unrolled: the loads of eight spans are in flight together (10 M-record VCFs have 611 spans)
+      const uint32_t* sh = P.span_hist + (size_t)(vd.span0 + s) * SPAN_HIST_WORDS;
+      h0 += (sh[hw] >> hs) & 0xffffu; h1 += (sh[128 + hw] >> hs) & 0xffffu; h2 += (sh[256 + hw] >> hs) & 0xffffu;
+    }
   }
   // ROC = suffix sums over the bins (bins at and above n_bins are empty): shuffles inside the wave, the waves' totals through LDS
   {
@@ -955,7 +960,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
     for (int w = wave + 1; w < 4; ++w) { c0 += s_h[0][w]; c1 += s_h[1][w]; c2 += s_h[2][w]; }
     const uint32_t fl = s_fl;
     const bool unsorted = (fl & SPANF_UNSORTED) != 0u;
-    if (tid < nb) {
+    if (rows && tid < nb) {
       uint64_t* roc = P.roc + (size_t)v * 3 * nb;
       roc[tid] = c0; roc[nb + tid] = c1; roc[2 * nb + tid] = c2;
       if (P.global_acc && !unsorted) {   // an unsorted VCF's numbers are discarded (redone by the sort path)
@@ -966,20 +971,21 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
       }
     }
     // scalars
-    if (tid < 8) {
+    if (rows && tid < 8) {
       int64_t* sc = P.scalars + (size_t)v * 8;
       if (tid < 5) sc[tid] = (int64_t)s_sc[tid];
-      else if (tid == 5) {
-        sc[5] = unsorted ? 0 : 1;
-        if (P.vcf_posor) P.vcf_posor[v] = s_or;
-        const uint32_t out = fl & (SPANF_UNSORTED | SPANF_BADPOS | SPANF_RUNLIMIT | SPANF_OVERFLOW);
-        P.vcf_flags[v] = out;
-        if (out && P.flag_summary) __hip_atomic_store(P.flag_summary, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-mapped: tells qm_batch_finish that the per-VCF flags are worth a copy
-      }
+      else if (tid == 5) sc[5] = unsorted ? 0 : 1;
       else if (tid == 6) sc[6] = vd.n;
       else sc[7] = P.ext ? P.truths[vd.truth].xn : P.truths[vd.truth].n;
     }
+    if (offsets && tid == 5) {
+      if (P.vcf_posor) P.vcf_posor[v] = s_or;
+      const uint32_t out = fl & (SPANF_UNSORTED | SPANF_BADPOS | SPANF_RUNLIMIT | SPANF_OVERFLOW);
+      P.vcf_flags[v] = out;
+      if (out && P.flag_summary) __hip_atomic_store(P.flag_summary, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-mapped: tells qm_batch_finish that the per-VCF flags are worth a copy
+    }
   }
+  if (!offsets) return;
   // exclusive scan of the tile counts (TP and FP together) over the VCF's tiles: four consecutive tiles
   // per thread in registers, the 256 thread totals with wave shuffles -- two barriers per 1 024 tiles
   {
