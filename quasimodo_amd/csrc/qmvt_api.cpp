@@ -680,6 +680,12 @@ extern "C" int qm_batch_set_timing(qm_batch* b, int on) {
   return QM_OK;
 }
 
+// QM_FINALIZE_SPLIT=0: k_finalize in one launch in front of the compaction (tools/ab_split.sh)
+static bool finalize_split_on() {
+  static const bool on = !getenv("QM_FINALIZE_SPLIT") || atoi(getenv("QM_FINALIZE_SPLIT")) != 0;
+  return on;
+}
+
 extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
   if (!b) return fail(QM_E_INVAL, "qm_batch_run: NULL batch");
   qm_ctx* c = b->ctx;
@@ -720,8 +726,7 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
     F.flag_summary = b->d_summary;
     // In one piece (the default), the compaction waits only for what it needs of k_finalize -- per-VCF flags and tile offsets --
     // and the rows (ROC, scalars, per-truth sums: 96 MB of span histograms to sum) go to the second stream beside it.
-    static const bool split_on = !getenv("QM_FINALIZE_SPLIT") || atoi(getenv("QM_FINALIZE_SPLIT")) != 0;
-    const bool split = split_on && nch == 1 && b->ev_sync[0] != nullptr;
+    const bool split = finalize_split_on() && nch == 1 && b->ev_sync[0] != nullptr;
     if (split) {
       HIPCHK(hipEventRecord(b->ev_sync[0], st));
       HIPCHK(hipStreamWaitEvent(c->aux, b->ev_sync[0], 0));
@@ -745,7 +750,7 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
   if (nch > 1) {
     HIPCHK(hipEventRecord(b->ev_sync[qm_batch::MAX_CHUNKS + 1], aux));
     HIPCHK(hipStreamWaitEvent(st, b->ev_sync[qm_batch::MAX_CHUNKS + 1], 0));
-  } else if (b->ev_sync[0] != nullptr && (!getenv("QM_FINALIZE_SPLIT") || atoi(getenv("QM_FINALIZE_SPLIT")) != 0)) {
+  } else if (b->ev_sync[0] != nullptr && finalize_split_on()) {
     HIPCHK(hipStreamWaitEvent(st, b->ev_sync[1], 0));   // the rows of k_finalize
   }
   if (T) { HIPCHK(hipEventRecord(ev[1], st)); b->n_timed++; }
