@@ -26,3 +26,5 @@ t = b.timings()
 byts = nv * (17e6 + 1.2e6)
 print("n_vcf=%d classify %.3f ms (%.0f GB/s algorithmic) finalize %.3f compact %.3f total %.3f" %
       (nv, t["classify_ms"], byts / t["classify_ms"] / 1e6, t["finalize_ms"], t["compact_ms"], t["total_ms"]))
+sc = b.scalars()
+print("  sums: kept %d tp_lines %d fp_lines %d TP_R %d FP_R %d" % tuple(int(sum(int(r[k]) for r in sc)) for k in range(5)))
