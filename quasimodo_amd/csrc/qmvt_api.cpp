@@ -812,6 +812,11 @@ static bool bucket_path_takes(const qm_batch* b, int64_t n) {
   return n >= lo && n <= (int64_t)HB_BUCKETS * HB_MAX_RECORDS * 5 / 8 && n <= ((int64_t)1 << HB_INDEX_BITS);
 }
 
+static bool join_hash_forced() {
+  static const bool on = getenv("QM_JOIN") && strcmp(getenv("QM_JOIN"), "hash") == 0;
+  return on;
+}
+
 // posor[v]: OR of the positions the optimistic pass saw in VCF v (which position bits are in use)
 static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, const std::vector<uint32_t>& posor, bool buckets) {
   const int nseg = (int)vs.size();
@@ -839,6 +844,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   qm_batch* s = b->sub;
   // --- segment table and tile maps
   std::vector<SortSeg> segs((size_t)nseg);
+  std::vector<int> nbk_used((size_t)nseg, HB_BUCKETS);
   int64_t koff = 0, hoff = 0, bk_ents = 0, nst64 = 0, nkt64 = 0, nbt64 = 0;
   for (int i = 0; i < nseg; ++i) {
     const VcfDesc& d = b->L.vcfs[(size_t)vs[(size_t)i]];
@@ -851,6 +857,8 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
       int msb = 31;
       while (msb > 0 && !((kor >> msb) & 1u)) --msb;
       g.pad = std::max(4, msb - 7);
+      nbk_used[(size_t)i] = (int)(kor >> g.pad) + 1;   // buckets above the VCF's highest position are empty by construction: <= 256
+      g.nbk = std::min(nbk_used[(size_t)i], (int)HB_BUCKETS); g.pad2 = 0;
       // room per sub-region: between 128 and 256 buckets are in use, a sub-region takes every eighth tile; half as much again on top
       int64_t want = d.n / (128 * HB_SUBS) * 3 / 2 + 16, cap2 = 16;
       while (cap2 < want && cap2 < HB_SUB_MAX) cap2 *= 2;
@@ -901,7 +909,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     if (rc == QM_OK) rc = regrow(&b->d_bk_vcfs, &b->cap_bk_vcfs, (int64_t)nseg, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_ent, &b->cap_bk_ent, bk_ents, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_rows, &b->cap_bk_rowdesc, rows, &b->dev_bytes);
-    if (rc == QM_OK) rc = regrow(&b->bk_cursor, &b->cap_bk_cursor, rows * HB_SUBS + nseg + 32, &b->dev_bytes);   // + 32: phase clocks of a profiling build
+    if (rc == QM_OK) rc = regrow(&b->bk_cursor, &b->cap_bk_cursor, rows * HB_SUBS + nseg + 32 + 16 * 65, &b->dev_bytes);   // + 32 + 16 * 65: phase clocks of a profiling build
     if (rc == QM_OK && (int64_t)nbt > b->cap_bk_tiles) {
       b->bk_tiles_valid = false;
       rc = regrow(&b->d_bk_tile_seg, &b->cap_bk_tiles, (int64_t)nbt, &b->dev_bytes);
@@ -933,13 +941,13 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
       for (int i = 0; i < nseg; ++i) {
         VcfDesc& f = fake[(size_t)i];
         f = VcfDesc();
-        f.off = 0; f.n = segs[(size_t)i].n; f.truth = tids[(size_t)i]; f.tile0 = 0; f.ntiles = 0; f.span0 = i * HB_BUCKETS; f.nspans = HB_BUCKETS; f.pad = 0;
+        f.off = 0; f.n = segs[(size_t)i].n; f.truth = tids[(size_t)i]; f.tile0 = 0; f.ntiles = 0; f.span0 = i * HB_BUCKETS; f.nspans = std::min(nbk_used[(size_t)i], (int)HB_BUCKETS); f.pad = 0;
       }
       HIPCHK(hipMemcpyAsync(b->d_bk_vcfs, fake.data(), sizeof(VcfDesc) * fake.size(), hipMemcpyHostToDevice, st));
       HIPCHK(hipStreamSynchronize(st));
       b->bk_fake_valid = true;
     }
-    const size_t ncur = ((size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg + 32) * 4;
+    const size_t ncur = ((size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg + 32 + 16 * 65) * 4;
     HIPCHK(hipMemsetAsync(b->bk_cursor, 0, ncur, st));
     BucketScatterParams S;
     S.segs = b->d_segs; S.tile_seg = b->d_bk_tile_seg; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
@@ -951,7 +959,14 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     launch_bucket_rows(H, nseg, st);
     // The scatter streams (memory-bound, its SIMDs half idle), the join issues instructions (and hardly waits for memory): in a
     // few segment ranges, the join of one range on the second stream beside the scatter of the next, they fill each other's gaps.
-    int parts = nseg >= 8 && b->ev_sync[0] ? 4 : 1;
+    int lb_all = 0, nbk_all = 1;
+    for (int i = 0; i < nseg; ++i) { lb_all = std::max(lb_all, (int)segs[(size_t)i].pad); nbk_all = std::max(nbk_all, std::min(nbk_used[(size_t)i], (int)HB_BUCKETS)); }
+    const bool direct = lb_all <= DJ_MAX_SHIFT && !join_hash_forced();
+    // k_classify_hash issues instructions where the scatter waits for memory: a few segment ranges, the join of one on the second
+    // stream beside the scatter of the next, fill each other's gaps (- 7 %).  k_join_direct is bound by the latency of a
+    // workgroup's serial steps and wants every LDS slot of the chip: beside a scatter it only loses (3.06 ms in one piece
+    // against 3.11 - 3.22 in 2 - 8 ranges, same box)
+    int parts = nseg >= 8 && b->ev_sync[0] && !direct ? 4 : 1;
     if (const char* e = getenv("QM_BUCKET_PARTS")) parts = std::max(1, std::min({atoi(e), nseg, (int)qm_batch::MAX_CHUNKS}));
     if (!b->ev_sync[0]) parts = 1;
     hipStream_t aux = parts > 1 ? b->ctx->aux : st;
@@ -973,7 +988,10 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
           HIPCHK(hipStreamWaitEvent(aux, b->ev_sync[p], 0));
         }
         H.seg_base = i0;
-        launch_classify_hash(H, i1 - i0, aux);
+        // the join: one bit per key of the bucket in LDS where a bucket's key range allows it (k_join_direct), the hashed
+        // tables of k_classify_hash otherwise (QM_JOIN=hash: always)
+        if (direct) launch_join_direct(H, i1 - i0, lb_all, nbk_all, aux);
+        else launch_classify_hash(H, i1 - i0, aux);
       }
       i0 = i1;
     }
@@ -994,6 +1012,15 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
       fprintf(stderr, "hb profile: wgs %u;", pr[0]);
       for (int i = 1; i < 12; ++i) fprintf(stderr, " p%d %.0f", i, pr[0] ? (double)pr[i] * 16.0 / pr[0] : 0.0);
       fprintf(stderr, " (ticks per workgroup)\n");
+      uint32_t pj[16 * 65];   // k_join_direct: 64 replicas of [workgroups, phase 1 .. 15] behind the first sixteen words
+      HIPCHK(hipMemcpy(pj, b->bk_cursor + (size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg, sizeof(pj), hipMemcpyDeviceToHost));
+      double sum[16] = {0};
+      for (int r = 1; r <= 64; ++r) for (int i = 0; i < 16; ++i) sum[i] += pj[16 * r + i];
+      if (sum[0] > 0) {
+        fprintf(stderr, "dj profile: wgs %.0f;", sum[0]);
+        for (int i = 1; i < 12; ++i) fprintf(stderr, " p%d %.0f", i, sum[i] * 16.0 / sum[0]);
+        fprintf(stderr, " (ticks per workgroup)\n");
+      }
     }
     bool overflow = false;
     for (int i = 0; i < nseg; ++i) {

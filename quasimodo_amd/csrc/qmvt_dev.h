@@ -164,6 +164,7 @@ struct SortSeg {
   int32_t main_vcf, sub_vcf;
   int32_t main_tile0, pad;   // first K1 tile of the VCF in the main batch; pad: the bucket path's shift (key >> pad = bucket)
   int32_t bk_tile0, bk_cap;  // bucket path: first scatter tile (BK_TILE records) of the segment; entries per sub-region (a power of two)
+  int32_t nbk, pad2;         // bucket path: buckets in use (those above the VCF's highest position hold nothing)
 };
 // bucket path (k_bucket_scatter + k_classify_hash): one workgroup per (segment, bucket of the one scatter pass)
 #ifndef QM_BK_TILE
@@ -178,6 +179,7 @@ constexpr int HB_TRUTH_SLOTS = 2048;     // truth keys of the bucket's positions
 constexpr int HB_NOKEY_SLOTS = 512;      // kept records without a comparable key
 constexpr int HB_MIN_RECORDS = 16384;    // smaller unsorted VCFs take the radix sort
 constexpr int HB_INDEX_BITS = 21;        // a bucket entry holds the record's index inside its VCF
+constexpr int DJ_MAX_SHIFT = 19;         // k_join_direct: a bucket's key range (2^shift keys) as ONE bit map in LDS, 64 KB at most
 // a bucket entry (8 bytes): key - (bucket << shift) in bits 0..23, info bits 0..11 (bin + 1, PASS, IDDOT, NOKEY) in 24..35,
 // the host-decided TP-line bit in 36, the record's index inside the VCF in 37..57
 struct BucketScatterParams {
@@ -322,6 +324,7 @@ void launch_masks_to_cls(const uint64_t* mp, const uint64_t* mt, int64_t off, in
 void launch_synth(const SynthParams& S, int n_vcf, int64_t max_n, hipStream_t st);
 void launch_classify_hash(const HashParams& P, int nseg, hipStream_t st);   // segments P.seg_base .. + nseg
 void launch_bucket_rows(const HashParams& P, int nseg, hipStream_t st);
+void launch_join_direct(const HashParams& P, int nseg, int lb, int nbk, hipStream_t st);   // segments P.seg_base .. + nseg, every bucket shift <= lb <= DJ_MAX_SHIFT
 void launch_bucket_scatter(const BucketScatterParams& P, int ntiles, hipStream_t st);   // tiles P.tile_base .. + ntiles
 void launch_sort_first_hist(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const int32_t* pos_col, uint32_t* hist, uint32_t* orbits,
                             hipStream_t st);

@@ -26,6 +26,7 @@
 //   R intersect/setdiff/length  scripts/caller_performance_compare.R:94-96
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "qmvt_dev.h"
 
@@ -1688,7 +1689,13 @@ __device__ __forceinline__ uint32_t wave_reserve(uint32_t* ctr, bool want) {
 }
 #ifdef HB_PROFILE   // phase clocks of wave 0 (s_memtime), summed in 16-tick units behind the segment flags
 #define HB_TICK(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(hb_prof + (i), (uint32_t)((t_ - hb_t) >> 4)); hb_t = t_; } } while (0)
+// the same kept in LDS and flushed once, at the end of the workgroup, into one of 64 replicas (k_join_direct: twelve atomics of
+// every workgroup on the same twelve words doubled the kernel's time and with it every share)
+#define DJ_TICK(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); s_prof[i] = (uint32_t)((t_ - hb_t) >> 4); hb_t = t_; } } while (0)
+#define DJ_FLUSH() do { if (threadIdx.x < 16) atomicAdd(hb_prof + 16 * (1 + (blockIdx.x & 63)) + threadIdx.x, threadIdx.x == 0 ? 1u : s_prof[threadIdx.x]); } while (0)
 #else
+#define DJ_TICK(i) do { } while (0)
+#define DJ_FLUSH() do { } while (0)
 #define HB_TICK(i) do { } while (0)
 #endif
 // Waves of a bucket's workgroup meet at three barriers only and walk their records independently in between: versions that
@@ -2007,7 +2014,8 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
   }
   HB_TICK(7);
   // ---- bucket epilogue: per-entry state -> U histogram and TP_R, counters, the row ----
-  atomicAdd(&s_c[0], n_pass); atomicAdd(&s_c[1], n_tp); atomicAdd(&s_c[2], fpr);
+  n_pass = wave_sum(n_pass); n_tp = wave_sum(n_tp); fpr = wave_sum(fpr);   // (not atomics of per-lane values on one address: hipcc makes a 64-step serial loop of each)
+  if ((tid & 63) == 0) { atomicAdd(&s_c[0], n_pass); atomicAdd(&s_c[1], n_tp); atomicAdd(&s_c[2], fpr); }
   __syncthreads();
   HB_TICK(8);
   uint32_t tpr = 0;
@@ -2017,7 +2025,8 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
     if (mx) atomicAdd(&s_h[256 + ((mx - 1u) >> 1)], 1u << (16u * ((mx - 1u) & 1u)));
     tpr += (s_tf[t >> 5] >> (t & 31)) & 1u;
   }
-  if (tpr) atomicAdd(&s_c[3], tpr);
+  tpr = wave_sum(tpr);
+  if ((tid & 63) == 0 && tpr) atomicAdd(&s_c[3], tpr);
   HB_TICK(9);
   __syncthreads();
   HB_TICK(10);
@@ -2029,6 +2038,335 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
     sc[0] = s_c[0]; sc[1] = s_c[1]; sc[2] = s_c[0] - s_c[1]; sc[3] = s_c[3]; sc[4] = s_c[2]; sc[5] = fl; sc[6] = 0u; sc[7] = 0u;
   }
   HB_TICK(11);
+}
+
+// ---------------------------------------------------------------------------
+// k_join_direct -- the join of one bucket whose whole key range fits ONE bit map in LDS (round 3).
+//
+// k_classify_hash is bound by instruction issue: every record is hashed, filtered, looked up and de-duplicated through
+// small tables, and the branches around those steps are what the SIMDs issue (~350 vector instructions per record slot).
+// A bucket of the one-pass scatter covers 2^shift consecutive keys (pos << 4 | nibble); when shift <= 19 a bit per KEY
+// is 64 KB of LDS, and then nothing has to be hashed, probed or settled twice:
+//   * the truth keys of the bucket set their bits; "is this record's key in the truth set" is ONE LDS read and a shift;
+//   * the same map then takes the kept keys OUTSIDE the truth set (a key is in the truth set or it is not, so the two
+//     kinds of bits never meet): one non-returning ds_or per record in a second pass over the thread's registers, and
+//     FP_R = popcount(map) - truth bits.  Exact, no collisions, no second look at anything;
+//   * the records that hit a truth key (a few per cent) are parked in a ring of their wave and settled 64 at a time with
+//     every lane busy: their truth entry is found by bisection of the bucket's sorted slice of the truth keys (no hash
+//     table), best bin / matched-by-kept state and the input-order TP bit follow.
+// Two workgroups of 512 threads per CU at shift 19 (80 KB each), more for smaller key ranges (LB = log2 of the map's bits is
+// a template parameter).  Rows, flags and overflow behaviour are those of k_classify_hash, which stays for buckets with
+// wider key ranges.
+// ---------------------------------------------------------------------------
+constexpr int DJ_THREADS = 512;
+constexpr int DJ_TRUTH_MAX = 1024;   // staged truth keys per bucket (whole cells of the coarse position index)
+constexpr int DJ_NK_LOG2 = 7;        // exact set of the kept records without a comparable key
+constexpr uint32_t DJ_RING = 64;     // parked records per wave
+template <int LB>
+__global__ __launch_bounds__(DJ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_join_direct(HashParams P) {
+  constexpr int PER = 16;                                // records per thread at most: four trips of four
+  constexpr int BM_WORDS = LB >= 7 ? (1 << (LB - 5)) : 4;
+  static_assert(HB_MAX_RECORDS <= DJ_THREADS * PER && BM_WORDS % 4 == 0, "table sizes");
+  __shared__ __attribute__((aligned(16))) uint32_t s_bm[BM_WORDS];   // bit v: key kbase + v is a truth key, or (second pass) a kept key outside the truth set
+  __shared__ uint32_t s_tk[DJ_TRUTH_MAX];            // the staged truth keys, sorted (absolute keys)
+  __shared__ uint32_t s_ts[DJ_TRUTH_MAX];            // per staged key: best bin + 1 of a '.'-ID match
+  __shared__ uint32_t s_tf[DJ_TRUTH_MAX / 32];       // matched by a kept record (ID ignored)
+  __shared__ uint32_t s_htp[130], s_hfp[130];        // TP / FP histograms: slot = bin + 1 (slot 0 swallows records without a bin), two u16 slots per dword
+  __shared__ uint32_t s_hu[128];                     // distinct-truth-key histogram, two u16 bins per dword
+  __shared__ __attribute__((aligned(8))) uint2 s_ring[(DJ_THREADS / 64) * DJ_RING];
+  __shared__ uint32_t s_nk[1 << DJ_NK_LOG2];
+  __shared__ uint32_t s_c[10];                       // kept, TP lines, keyless distinct, matched truth keys, flags, truth bits in range, keyless inserts, top-bin TP, top-bin FP, map bits
+  const int tid = (int)threadIdx.x;
+  const int d = (int)blockIdx.x;
+  const int seg_id = (int)blockIdx.y + P.seg_base;
+  const size_t row = (size_t)seg_id * HB_BUCKETS + (size_t)d;
+#ifdef HB_PROFILE
+  uint32_t* hb_prof = const_cast<uint32_t*>(P.cursor) + (size_t)P.n_seg * HB_BUCKETS * HB_SUBS + (size_t)P.n_seg;
+  unsigned long long hb_t = __builtin_amdgcn_s_memtime();
+  __shared__ uint32_t s_prof[16];
+  if (threadIdx.x < 16) s_prof[threadIdx.x] = 0u;
+#endif
+  const HashRow R = P.rows[row];
+  const uint32_t* cur = P.cursor + row * HB_SUBS;
+  const uint32_t segfl = d == 0 ? P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg_id] : 0u;   // the segment's flags travel in its first row
+  // the map, the truth state and the histograms are cleared while the descriptor and the cursors are on their way (nothing
+  // here depends on them: the whole map of the instantiation, not only the 2^shift bits in use)
+  for (int i = tid; i < BM_WORDS / 4; i += DJ_THREADS) *reinterpret_cast<uint4*>(&s_bm[4 * i]) = make_uint4(0u, 0u, 0u, 0u);
+  s_ts[tid] = 0u; s_ts[tid + DJ_THREADS] = 0u;
+  if (tid < DJ_TRUTH_MAX / 32) s_tf[tid] = 0u;
+  if (tid < 130) { s_htp[tid] = 0u; s_hfp[tid] = 0u; }
+  if (tid < 128) s_hu[tid] = 0u;
+  if (tid < (1 << DJ_NK_LOG2)) s_nk[tid] = HB_EMPTY;
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(1))) v4u* gv4p;
+  const gv4p g_ent = (gv4p)R.ent;
+  const gu32p g_tkeys = (gu32p)R.tkeys;
+  const uint32_t cap = R.cap;
+  uint32_t nsub[HB_SUBS];     // wave-uniform (scalar loads)
+  uint32_t nrec = 0, over = 0;
+#pragma unroll
+  for (int k = 0; k < HB_SUBS; ++k) {
+    const uint32_t c = cur[k];
+    over |= c > cap ? 1u : 0u;
+    nsub[k] = c < cap ? c : cap;
+    nrec += nsub[k];
+  }
+  uint32_t* oh = P.row_hist + row * SPAN_HIST_WORDS;
+  if (nrec == 0u) {   // an empty bucket: a row of zeros, nothing else
+    if (tid < 3 * 128) oh[tid] = 0u;
+    if (tid < 8) P.row_scal[row * 8 + tid] = tid == 5 ? segfl : 0u;
+    return;
+  }
+  over |= R.shift > (uint32_t)LB ? 1u : 0u;                  // (the host never launches this instantiation for such a segment)
+  const uint32_t shift = R.shift > (uint32_t)LB ? (uint32_t)LB : R.shift;   // 4 <= shift <= LB: a bucket is a whole range of positions
+  const uint32_t kbase = (uint32_t)d << shift;               // every key of the bucket is >= kbase
+  const uint32_t klast = ((uint32_t)(d + 1) << shift) - 1u;
+  const int tn_all = R.tn;
+  over |= tn_all > DJ_TRUTH_MAX ? 1u : 0u;
+  const int tn = over ? 0 : tn_all;
+  const uint32_t lcap = 31u - (uint32_t)__clz(cap);            // cap is a power of two >= 4
+  const uint32_t nslots = (HB_SUBS * cap) >> 2;
+  const int ntrips = (int)((nslots + DJ_THREADS - 1) / DJ_THREADS) < PER / 4 ? (int)((nslots + DJ_THREADS - 1) / DJ_THREADS) : PER / 4;
+  // every trip of the thread is in flight before anything else happens: with two workgroups per CU nothing hides a memory
+  // round trip (3 000+ cycles under load), and a workgroup that fetched trip by trip paid one per trip
+  v4u ea[PER / 4], eb[PER / 4];
+  uint32_t nv[PER / 4];      // valid entries of the trip's four
+  const v4u z4 = {0u, 0u, 0u, 0u};
+  auto fetch = [&](int g, int buf) {
+    const uint32_t slot = (uint32_t)g * DJ_THREADS + (uint32_t)tid;
+    const uint32_t e0 = slot << 2, sb = e0 >> lcap, w = e0 & (cap - 1u);
+    uint32_t n = 0;
+#pragma unroll
+    for (int k = 0; k < HB_SUBS; ++k) n = sb == (uint32_t)k ? nsub[k] : n;
+    ea[buf] = z4; eb[buf] = z4; nv[buf] = 0u;
+    if (slot < nslots && w < n && !over) {
+      nv[buf] = n - w < 4u ? n - w : 4u;
+      const gv4p src = g_ent + (e0 >> 1);   // two entries per 16 bytes
+      ea[buf] = __builtin_nontemporal_load(src);
+      eb[buf] = __builtin_nontemporal_load(src + 1);
+    }
+  };
+  DJ_TICK(1);
+#pragma unroll
+  for (int g = 0; g < PER / 4; ++g) fetch(g, g);   // (trips beyond the bucket's capacity load nothing)
+  uint32_t tkey0 = 0xffffffffu, tkey1 = 0xffffffffu;
+  if (tid < tn) tkey0 = g_tkeys[tid];
+  if (tid + DJ_THREADS < tn) tkey1 = g_tkeys[tid + DJ_THREADS];
+  const int nw4 = (int)(((1u << shift) + 127u) >> 7);        // 16-byte pieces of the map in use
+  if (tid < 10) s_c[tid] = tid == 4 ? (segfl | (over ? SPANF_OVERFLOW : 0u)) : 0u;
+  DJ_TICK(2);
+  __syncthreads();
+  DJ_TICK(3);
+  // ---- the truth keys of the bucket's positions: the sorted slice as it is (its keys outside the bucket match nothing), a bit per key inside ----
+  {
+    uint32_t nin = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = tid + h * DJ_THREADS;
+      const uint32_t k = h ? tkey1 : tkey0;
+      const bool in = j < tn && k >= kbase && k <= klast;
+      if (j < tn) s_tk[j] = k;
+      if (in) atomicOr(&s_bm[(k - kbase) >> 5], 1u << ((k - kbase) & 31u));
+      nin += (uint32_t)popc64(ballot64(in));
+    }
+    if ((tid & 63) == 0 && nin) atomicAdd(&s_c[5], nin);
+  }
+  DJ_TICK(4);
+  __syncthreads();
+  DJ_TICK(5);
+  const int nb = P.n_bins;
+  int ttop = 0;                                              // largest power of two <= tn
+  if (tn > 0) ttop = 1 << (31 - __clz(tn));
+  uint32_t n_pass = 0, n_tp = 0;
+  uint32_t top_tp = 0, top_fp = 0;                           // per lane: records of the saturated top bin
+  uint32_t vq[PER];          // the thread's keys stay in registers for the second pass
+  uint32_t cand = 0;         // bit k: record k is a kept key outside the truth set (with a comparable key)
+  uint32_t candnk = 0;       // the same without a comparable key
+  unsigned long long* mtp = reinterpret_cast<unsigned long long*>(P.mask_tp);
+  // a record that hit a truth key, or a TP line by the host's decision: truth-entry state and the input-order TP bit
+  auto settle = [&](uint32_t elo, uint32_t ehi) {
+    const uint32_t v = elo & 0xffffffu;
+    const uint32_t inf = (elo >> 24) | ((ehi & 0x1fu) << 8);     // bits 0..11 as in the info word, bit 12 = TP line
+    const uint32_t b1 = inf & I_BIN1;
+    const bool kept = (inf & I_PASS) != 0u;
+    const bool hit = ((s_bm[v >> 5] >> (v & 31u)) & 1u) && !(inf & I_NOKEY);
+    if (hit) {
+      const int j = lds_lower_bound(s_tk, tn, ttop, kbase + v);   // the key IS there
+      if ((inf & I_IDDOT) && b1) atomicMax(&s_ts[j], b1);
+      if (kept) atomicOr(&s_tf[j >> 5], 1u << (j & 31));
+    }
+#ifndef DJ_NO_TPATOMIC   // (timing builds only: phases of the kernel switched off, results wrong)
+    if (kept && ((hit && (inf & I_IDDOT)) || (inf & 0x1000u))) {
+      const int64_t o = R.src_off + (int64_t)(ehi >> 5);
+      atomicOr(mtp + (o >> 6), 1ull << (o & 63));
+    }
+#endif
+  };
+  if (!(s_c[4] & SPANF_OVERFLOW)) {
+    uint2* ring = s_ring + (tid >> 6) * DJ_RING;
+    const uint32_t lane = (uint32_t)tid & 63u;
+    uint32_t head = 0, tail = 0;                                   // wave-uniform
+    auto drain = [&](uint32_t n) {                                 // the first n <= 64 parked records, one per lane
+      if (lane < n) {
+        const uint2 e = ring[(head + lane) & (DJ_RING - 1u)];
+        settle(e.x, e.y);
+      }
+      head += n;
+    };
+    // the map reads of all the thread's records first, in flight together (as the compiler orders the loop below, every read
+    // would be waited for on the spot: sixteen LDS round trips one after the other)
+    uint32_t hitm = 0, vmask = 0;
+    {
+      uint32_t w[PER];
+#pragma unroll
+      for (int g = 0; g < PER / 4; ++g) {
+        vmask |= ((1u << nv[g]) - 1u) << (4 * g);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t elo_ = u == 0 ? ea[g][0] : u == 1 ? ea[g][2] : u == 2 ? eb[g][0] : eb[g][2];
+          vq[4 * g + u] = elo_ & 0xffffffu;
+          w[4 * g + u] = s_bm[vq[4 * g + u] >> 5];
+        }
+      }
+#pragma unroll
+      for (int k2 = 0; k2 < PER; ++k2) hitm |= ((w[k2] >> (vq[k2] & 31u)) & 1u) << k2;
+      hitm &= vmask;
+    }
+#pragma unroll
+    for (int g = 0; g < PER / 4; ++g) {
+      if (g < ntrips) {                                            // wave-uniform
+        uint32_t elo[4], ehi[4], mb = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          elo[u] = u == 0 ? ea[g][0] : u == 1 ? ea[g][2] : u == 2 ? eb[g][0] : eb[g][2];
+          ehi[u] = u == 0 ? ea[g][1] : u == 1 ? ea[g][3] : u == 2 ? eb[g][1] : eb[g][3];
+          const uint32_t valid = (vmask >> (4 * g + u)) & 1u;
+          const uint32_t inf = (elo[u] >> 24) | ((ehi[u] & 0x1fu) << 8);
+          const uint32_t keyed = ~(inf >> 11) & 1u;                 // I_NOKEY clear
+          const uint32_t hit = (hitm >> (4 * g + u)) & keyed;
+          const uint32_t kept = (inf >> 9) & valid & 1u;            // every valid entry is a live record
+          const uint32_t tplh = (inf >> 12) & valid & 1u;           // a TP line by the host's decision
+          const uint32_t tpl = (hit & (inf >> 10)) | tplh;
+          const uint32_t b1 = inf & I_BIN1;
+          // ROC histograms; the saturated top bin, where real QUALs pile up, is counted in registers (the lanes of a wave
+          // would serialise on its one address); the empty slots of a trip sit the add out for the same reason
+          const uint32_t top = (b1 == (uint32_t)nb ? 1u : 0u) & valid;
+          top_tp += top & tpl;
+          top_fp += top & ~tpl;
+#ifndef DJ_NO_HIST
+          if (valid & ~top) atomicAdd(tpl ? &s_htp[b1 >> 1] : &s_hfp[b1 >> 1], 1u << (16u * (b1 & 1u)));
+#endif
+          n_pass += kept;
+          n_tp += kept & tpl;
+#ifndef DJ_NO_SETTLE
+          mb |= (hit | (kept & tplh)) << u;
+#endif
+          cand |= (kept & ~hit & keyed) << (4 * g + u);
+          candnk |= (kept & ~hit & ~keyed & 1u) << (4 * g + u);
+        }
+        uint64_t m[4];
+        uint32_t tot = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { m[u] = ballot64((mb >> u) & 1u); tot += (uint32_t)popc64(m[u]); }
+        while (tail - head >= 64u || (tail != head && tail - head + tot > DJ_RING)) drain(tail - head < 64u ? tail - head : 64u);
+        if (tot <= DJ_RING) {                                       // wave-uniform
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if ((mb >> u) & 1u) {
+              const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[u], 0u));
+              ring[(tail + r) & (DJ_RING - 1u)] = make_uint2(elo[u], ehi[u]);
+            }
+            tail += (uint32_t)popc64(m[u]);
+          }
+        } else {                                                    // a VCF that mostly matches: settled where they stand
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if ((mb >> u) & 1u) settle(elo[u], ehi[u]);
+        }
+      }
+    }
+    while (tail != head) drain(tail - head < 64u ? tail - head : 64u);
+  }
+  DJ_TICK(6);
+  __syncthreads();   // every read of a truth bit is done: the map now also takes the kept keys outside the truth set
+#ifndef DJ_NO_PASS2
+#pragma unroll
+  for (int k = 0; k < PER; ++k)
+    if ((cand >> k) & 1u) atomicOr(&s_bm[vq[k] >> 5], 1u << (vq[k] & 31u));   // no return value: ds_or_b32
+#endif
+  uint32_t fpr_nk = 0;
+  if (ballot64(candnk != 0u)) {   // rare: keyless records are keys of their own, in an exact set, every insertion reserved
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const bool want = (candnk >> k) & 1u;
+      const uint32_t at = wave_reserve(&s_c[6], want);
+      if (want) {
+        if (at >= (1u << DJ_NK_LOG2) / 2u) { atomicOr(&s_c[4], SPANF_OVERFLOW); }
+        else {
+          bool fresh;
+          (void)hb_insert(s_nk, DJ_NK_LOG2, vq[k], &fresh);
+          fpr_nk += fresh ? 1u : 0u;
+        }
+      }
+    }
+  }
+  // (hipcc turns an LDS atomic add of a per-lane value on ONE address into a serial loop over the 64 lanes -- readlane, add,
+  // next lane: 2 000+ cycles each, a quarter of this workgroup's life when there were five of them; DPP sums instead)
+  n_pass = wave_sum(n_pass); n_tp = wave_sum(n_tp);
+  if (ballot64(fpr_nk != 0u)) fpr_nk = wave_sum(fpr_nk);
+  if (ballot64((top_tp | top_fp) != 0u)) { top_tp = wave_sum(top_tp); top_fp = wave_sum(top_fp); }
+  if ((tid & 63) == 0) {
+    atomicAdd(&s_c[0], n_pass); atomicAdd(&s_c[1], n_tp);
+    if (fpr_nk) atomicAdd(&s_c[2], fpr_nk);
+    if (top_tp) atomicAdd(&s_c[7], top_tp);
+    if (top_fp) atomicAdd(&s_c[8], top_fp);
+  }
+  DJ_TICK(7);
+  __syncthreads();
+  DJ_TICK(8);
+  // ---- bucket epilogue: bits of the map, per-entry state -> U histogram and TP_R, counters, the row ----
+  {
+    uint32_t bits = 0;
+    for (int i = tid; i < nw4; i += DJ_THREADS) {
+      const uint4 w = *reinterpret_cast<const uint4*>(&s_bm[4 * i]);
+      bits += (uint32_t)__popc(w.x) + (uint32_t)__popc(w.y) + (uint32_t)__popc(w.z) + (uint32_t)__popc(w.w);
+    }
+    bits = wave_sum(bits);
+    if ((tid & 63) == 0 && bits) atomicAdd(&s_c[9], bits);
+  }
+  uint32_t tpr = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int j = tid + h * DJ_THREADS;
+    if (j < tn) {
+      const uint32_t mx = s_ts[j];
+      if (mx) atomicAdd(&s_hu[(mx - 1u) >> 1], 1u << (16u * ((mx - 1u) & 1u)));
+      tpr += (s_tf[j >> 5] >> (j & 31)) & 1u;
+    }
+  }
+  tpr = wave_sum(tpr);
+  if ((tid & 63) == 0 && tpr) atomicAdd(&s_c[3], tpr);
+  DJ_TICK(9);
+  __syncthreads();
+  DJ_TICK(10);
+  if (tid < 128) {
+    const uint32_t ttp = s_c[7], tfp = s_c[8];
+    const int b0 = 2 * tid, b1 = 2 * tid + 1;
+    auto get = [&](const uint32_t* t, int slot) { return (t[slot >> 1] >> (16 * (slot & 1))) & 0xffffu; };
+    oh[tid] = (get(s_htp, 1 + b0) + (b0 == nb - 1 ? ttp : 0u)) | ((get(s_htp, 1 + b1) + (b1 == nb - 1 ? ttp : 0u)) << 16);
+    oh[128 + tid] = (get(s_hfp, 1 + b0) + (b0 == nb - 1 ? tfp : 0u)) | ((get(s_hfp, 1 + b1) + (b1 == nb - 1 ? tfp : 0u)) << 16);
+    oh[256 + tid] = s_hu[tid];
+  }
+  if (tid == 0) {
+    uint32_t* sc = P.row_scal + row * 8;
+    const uint32_t fl = s_c[4];
+    sc[0] = s_c[0]; sc[1] = s_c[1]; sc[2] = s_c[0] - s_c[1]; sc[3] = s_c[3];
+    sc[4] = s_c[9] - s_c[5] + s_c[2];   // distinct kept keys outside the truth set: bits of the map minus the truth bits, plus the keyless ones
+    sc[5] = fl; sc[6] = 0u; sc[7] = 0u;
+  }
+  DJ_TICK(11);
+  __syncthreads();
+  DJ_FLUSH();
 }
 
 // TP bits of the sorted scratch VCFs back to input order: only the records that ARE true positives
@@ -2247,6 +2585,14 @@ void launch_sort_copy_rows(const SortSeg* segs, int nseg, const uint64_t* sub_ro
 }
 void launch_classify_hash(const HashParams& P, int nseg, hipStream_t st) {
   if (nseg > 0) hipLaunchKernelGGL(k_classify_hash, dim3(HB_BUCKETS, nseg), dim3(HB_THREADS), 0, st, P);
+}
+// lb: log2 of the widest bucket key range among the launch's segments (SortSeg.pad), <= DJ_MAX_SHIFT
+// nbk: buckets in use at most among the launch's segments (the grid; buckets above a VCF's highest position hold nothing)
+void launch_join_direct(const HashParams& P, int nseg, int lb, int nbk, hipStream_t st) {
+  if (nseg <= 0) return;
+  static const int pad = getenv("QM_DJ_PAD") ? atoi(getenv("QM_DJ_PAD")) : 0;   // experiment: extra (unused) dynamic LDS bounds the workgroups per CU
+  if (lb <= 16) hipLaunchKernelGGL((k_join_direct<16>), dim3(nbk, nseg), dim3(DJ_THREADS), pad, st, P);
+  else hipLaunchKernelGGL((k_join_direct<DJ_MAX_SHIFT>), dim3(nbk, nseg), dim3(DJ_THREADS), pad, st, P);
 }
 void launch_bucket_rows(const HashParams& P, int nseg, hipStream_t st) {
   if (nseg > 0) hipLaunchKernelGGL(k_bucket_rows, dim3(nseg), dim3(HB_BUCKETS), 0, st, P);
