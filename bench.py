@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- variant TP/FP classifications/sec on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W [--config {2,3,4}]
+    python bench.py --gpus N --steps K --warmup W [--config {2,3,4}]      (N > 1: starts one process per GPU itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W [--config {2,3,4}]
 
@@ -78,16 +78,36 @@ def main():
             P[k] = v
     alleles = P["indel_pct"] > 0
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as typed: this process has touched no GPU (nothing of torch or HIP is imported yet) and
+        # becomes the launcher -- one fresh child per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rank 0's JSON line
+        # relayed, everybody stopped and a non-zero exit if one rank fails.  Under torch.distributed.run WORLD_SIZE is set
+        # and every process is a rank.
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("qm_launch", os.path.join(ROOT, "quasimodo_amd", "launch.py"))
+        launch = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(launch)
+        sys.exit(launch.main_relay([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
+                                   timeout=float(os.environ.get("QM_BENCH_TIMEOUT", "3000"))))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if os.environ.get("QM_BENCH_INJECT"):
+        # tests of the launcher: the step is injected (module:function -> the dict rank 0 prints); no GPU is touched
+        import importlib
+        mod, fn = os.environ["QM_BENCH_INJECT"].split(":")
+        out = getattr(importlib.import_module(mod), fn)(args, rank, world)
+        if rank == 0:
+            print(json.dumps(out))
+        return
+
     import numpy as np
     import torch
     import torch.distributed as dist
     import quasimodo_amd as q
 
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
     if os.environ.get("QM_BENCH_SAME_DEVICE") == "1":   # rehearsal of the N > 1 code path on a one-GPU box

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define QM_ABI_VERSION 2
+#define QM_ABI_VERSION 3
 
 #define QM_OK 0
 #define QM_E_INVAL (-1)     /* bad argument */
@@ -211,6 +211,10 @@ int qm_batch_get_scalars(qm_batch* b, int64_t* out /*[n_vcf][QM_N_SCALARS]*/);
 int qm_batch_get_global(qm_batch* b, uint64_t* out /*[qm_batch_n_truth(b)][3][n_bins]*/);
 int qm_batch_get_columns(qm_batch* b, int vcf, int32_t* pos, int32_t* ref, int32_t* alt, float* qual,
                          uint8_t* flags);
+/* Device address of the per-truth sums of the last run ([qm_batch_n_truth(b)][3][n_bins] uint64; the caller's global_dev when
+ * qm_batch_run was given one): valid until the batch runs again or is destroyed.  For callers that hand the counters to a
+ * collective without a trip through the host. */
+int qm_batch_global_device(qm_batch* b, void** dev);
 /* Bytes the engine holds in HBM for this batch. */
 int64_t qm_batch_device_bytes(qm_batch* b);
 /* Rows of the per-truth sums ([n][3][n_bins]; qm_batch_get_global, qm_batch_run's global_dev): the number of
@@ -348,6 +352,15 @@ typedef struct qm_file_stats {
 } qm_file_stats;
 int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs, int n_bins, unsigned mode, int strict,
                      qm_file_stats* stats, uint64_t* roc, double* phase_seconds);
+/* The same for one rank of a multi-GPU run (rules/extract_TP.smk:17-20 runs one process per VCF; here one process per GPU
+ * takes a share of them): global_dev, a DEVICE buffer of [n_slots][3][n_bins] uint64, receives the per-truth-file sums of this
+ * call's VCFs -- cleared first; VCF j adds to row truth_slot[j] (the caller's layout: every rank uses the same row for the
+ * same truth file; pure-strain jobs are ignored; jobs that name the same truth file must name the same row) -- ready for the
+ * one all-reduce of the confusion counters (RCCL).  n_jobs == 0 is allowed: the buffer is cleared, nothing else happens.
+ * truth_slot / global_dev NULL: qm_extract_files. */
+int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs, int n_bins, unsigned mode, int strict,
+                        qm_file_stats* stats, uint64_t* roc, double* phase_seconds, const int32_t* truth_slot, int n_slots,
+                        void* global_dev);
 
 /* `bgzip -c` (the *.vcf.gz outputs the same rules declare, rules/vis_eval_vcf.smk:29,36 ...): BGZF = gzip members of at
  * most 64 KiB with a 'BC' extra field + the EOF member; zcat and tabix / htslib read it.  level -1 = zlib's default (6,

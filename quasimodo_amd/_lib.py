@@ -12,7 +12,7 @@ SCALAR_NAMES = ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R", "sorted", "n_r
 ERRORS = {-1: "QM_E_INVAL", -2: "QM_E_NODEVICE", -3: "QM_E_HIP", -4: "QM_E_NOMEM", -5: "QM_E_RANGE",
           -6: "QM_E_STATE", -7: "QM_E_IO", -8: "QM_E_NONCANON", -9: "QM_E_LIMIT"}
 QM_BATCH_ALLELES = 1
-QM_ABI_VERSION = 2
+QM_ABI_VERSION = 3
 
 # every symbol include/qmvt.h declares
 EXPORTS = (
@@ -24,7 +24,7 @@ EXPORTS = (
     "qm_truth_size_ext", "qm_truth_synth_ext", "qm_batch_create_ext", "qm_classify_batch_ext",
     "qm_dict_create", "qm_dict_destroy", "qm_dict_size", "qm_allele_code", "qm_allele_spell", "qm_vcf_scan_ext", "qm_truth_scan_ext",
     "qm_bench_synth", "qm_truth_release", "qm_batch_n_truth",
-    "qm_bw_probe", "qm_bgzf_write", "qm_extract_files", "qm_batch_upload_async", "qm_batch_get_masks", "qm_patterns_create", "qm_patterns_destroy", "qm_patterns_info", "qm_vcf_hostpath",
+    "qm_bw_probe", "qm_bgzf_write", "qm_extract_files", "qm_extract_files_ex", "qm_batch_global_device", "qm_batch_upload_async", "qm_batch_get_masks", "qm_patterns_create", "qm_patterns_destroy", "qm_patterns_info", "qm_vcf_hostpath",
 )
 
 
@@ -142,6 +142,8 @@ def lib():
     L.qm_allele_spell.argtypes = [vp, i32, C.c_char_p, C.c_size_t]
     L.qm_allele_spell.restype = i64
     L.qm_extract_files.argtypes = [vp, i32, C.POINTER(FileJob), i32, C.c_uint, i32, C.POINTER(FileStats), vp, C.POINTER(C.c_double)]
+    L.qm_extract_files_ex.argtypes = [vp, i32, C.POINTER(FileJob), i32, C.c_uint, i32, C.POINTER(FileStats), vp, C.POINTER(C.c_double), vp, i32, vp]
+    L.qm_batch_global_device.argtypes = [vp, C.POINTER(vp)]
     L.qm_batch_upload_async.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
     L.qm_batch_get_masks.argtypes = [vp, i32, vp, vp]
     L.qm_bgzf_write.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, i32]

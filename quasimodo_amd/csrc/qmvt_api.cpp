@@ -107,9 +107,12 @@ extern "C" int qm_init(int device_id, qm_ctx** out) {
   return QM_OK;
 }
 
+void qm_pipeline_ctx_destroyed(qm_ctx* ctx);   // qmvt_pipeline.cpp: the context's page-locked buffers
+
 extern "C" void qm_destroy(qm_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->dev);
+  qm_pipeline_ctx_destroyed(c);
   for (auto& t : c->truths) {
     (void)hipFree(t.d_keys); (void)hipFree(t.d_tidx);
     (void)hipFree(t.d_xkeys); (void)hipFree(t.d_xref); (void)hipFree(t.d_xalt); (void)hipFree(t.d_xtidx);
@@ -1219,6 +1222,12 @@ extern "C" int qm_batch_get_global(qm_batch* b, uint64_t* out) {
   NEED_FINISHED(b, "qm_batch_get_global");
   HIPCHK(hipSetDevice(b->ctx->dev));
   HIPCHK(hipMemcpy(out, b->last_global, (size_t)b->n_truth * 3 * (size_t)b->n_bins * 8, hipMemcpyDeviceToHost));
+  return QM_OK;
+}
+extern "C" int qm_batch_global_device(qm_batch* b, void** dev) {
+  NEED_FINISHED(b, "qm_batch_global_device");
+  if (!dev) return fail(QM_E_INVAL, "qm_batch_global_device: NULL");
+  *dev = b->last_global;
   return QM_OK;
 }
 extern "C" int qm_batch_get_columns(qm_batch* b, int v, int32_t* pos, int32_t* ref, int32_t* alt, float* qual, uint8_t* flags) {

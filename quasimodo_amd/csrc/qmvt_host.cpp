@@ -379,6 +379,8 @@ struct ScanChunk {
   int32_t last_pos = 0;            // last canonical POS seen in the chunk (0 if none)
   int64_t lead_nokey = 0;          // data lines before the chunk's first canonical POS
   bool any_pos = false;
+  int64_t cap_lines = INT64_MAX;   // room in the caller's line / column arrays (global line index)
+  bool overflow = false;           // the text holds more lines than that (a file that grew between the count and the scan)
 };
 
 // dict != nullptr: allele-extended tokenising -- the filter's `^[ACGT]$` becomes `^[ACGT]+$`
@@ -403,6 +405,7 @@ static void scan_chunk(const uint8_t* text, ScanChunk& c, bool count_only, int64
     const bool header = n && s[0] == '#';
     {
       const int64_t gl = c.l0 + nl, gd = c.d0 + nd;
+      if (gl >= c.cap_lines) { c.overflow = true; break; }   // never write past the caller's arrays, whoever counted the lines
       line_off[gl] = (int64_t)off;
       const bool indexed = L.ntab <= LINE_MAXT;   // every tab of the line is in the index
       auto dirty = [&]() { return L.dirty; };     // NUL / non-ASCII: the reference's answer depends on the locale its grep runs under
@@ -521,7 +524,9 @@ int qm_host_scan_threads(const uint8_t* text, size_t len, int64_t cap_lines, int
     for (auto& c : ch) { c.l0 = nl; c.d0 = nd; nl += c.nl; nd += c.nd; }
     if (nl > cap_lines) return QM_E_INVAL;
   }
+  for (auto& c : ch) c.cap_lines = cap_lines;
   run(false);
+  for (auto& c : ch) if (c.overflow) return QM_E_INVAL;
   if (counted) { nl = ch[0].nl; nd = ch[0].nd; }
   int64_t nhost = 0, nref = 0, first_ref = 0, nnokey = 0;
   int32_t carry = 0;

@@ -102,9 +102,18 @@ struct PinnedArena {
   }
   ~PinnedArena() { release(); }
 };
-// never destroyed: at process exit the HIP runtime may be gone before static destructors run
-PinnedArena& g_arena = *new PinnedArena();
-std::mutex* g_arena_mu = new std::mutex();
+// One arena per context (= per device): calls on different contexts -- a thread and a context per GPU, examples/qm_multi.c --
+// tokenise, upload and write side by side; two calls on ONE context take turns.  The table itself is never destroyed: at
+// process exit the HIP runtime may be gone before static destructors run; qm_destroy releases a context's arena.
+struct CtxArena { PinnedArena arena; std::mutex mu; };
+std::map<qm_ctx*, CtxArena*>& g_arenas = *new std::map<qm_ctx*, CtxArena*>();
+std::mutex* g_arenas_mu = new std::mutex();
+CtxArena* arena_of(qm_ctx* ctx) {
+  std::lock_guard<std::mutex> g(*g_arenas_mu);
+  CtxArena*& a = g_arenas[ctx];
+  if (!a) a = new CtxArena();
+  return a;
+}
 
 struct JobState {
   Mapped vcf;
@@ -120,6 +129,7 @@ struct JobState {
   int truth = -1;      // index into the call's distinct truth files
   int batch_v = -1;    // VCF index inside the engine batch (mixed samples only)
   int rc = QM_OK;
+  std::string err;     // the message that belongs to rc (qm_last_error is per thread: copied on the worker that failed)
 };
 
 struct TruthState {
@@ -136,10 +146,34 @@ int fail(int code, const std::string& msg) { qm_set_error(msg.c_str()); return c
 
 }  // namespace
 
+// called by qm_destroy: the page-locked buffers of a context go with it
+void qm_pipeline_ctx_destroyed(qm_ctx* ctx) {
+  CtxArena* a = nullptr;
+  {
+    std::lock_guard<std::mutex> g(*g_arenas_mu);
+    auto it = g_arenas.find(ctx);
+    if (it != g_arenas.end()) { a = it->second; g_arenas.erase(it); }
+  }
+  if (a) { { std::lock_guard<std::mutex> g(a->mu); a->arena.release(); } delete a; }
+}
+
 extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs, int n_bins, unsigned mode, int strict,
                                 qm_file_stats* stats, uint64_t* roc_out, double* phase_seconds) {
+  return qm_extract_files_ex(ctx, n_jobs, jobs, n_bins, mode, strict, stats, roc_out, phase_seconds, nullptr, 0, nullptr);
+}
+
+extern "C" int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs, int n_bins, unsigned mode, int strict,
+                                   qm_file_stats* stats, uint64_t* roc_out, double* phase_seconds, const int32_t* truth_slot,
+                                   int n_slots, void* global_dev) {
   if (!ctx || n_jobs < 0 || (n_jobs && !jobs) || n_bins < 1 || n_bins > QM_MAX_BINS || (mode & ~(unsigned)QM_BATCH_ALLELES))
     return fail(QM_E_INVAL, "qm_extract_files: bad arguments");
+  if (global_dev && (n_slots < 1 || (n_jobs && !truth_slot))) return fail(QM_E_INVAL, "qm_extract_files_ex: global_dev needs truth_slot and n_slots >= 1");
+  const size_t gbytes = global_dev ? (size_t)n_slots * 3 * (size_t)n_bins * sizeof(uint64_t) : 0;
+  if (global_dev && hipMemset(global_dev, 0, gbytes) != hipSuccess) return fail(QM_E_HIP, "qm_extract_files_ex: cannot clear global_dev");
+  if (n_jobs == 0) {   // nothing to do is not an error (a rank of a sharded run may hold no VCF)
+    if (phase_seconds) memset(phase_seconds, 0, 8 * sizeof(double));
+    return QM_OK;
+  }
   const bool ext = (mode & QM_BATCH_ALLELES) != 0;
   double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // map + count, truth sets (beside the former), batch layout, tokenise + host path (+ uploads beside it), engine, masks back, write, release
   const int nthr = qm_host_threads();
@@ -170,6 +204,19 @@ extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs
       auto it = seen.find(key);
       if (it == seen.end()) { it = seen.emplace(key, (int)T.size()).first; T.emplace_back(); T.back().path = key.first; T.back().mode = key.second; }
       J[(size_t)j].truth = it->second;
+    }
+  }
+  std::vector<int32_t> slot_of_truth(T.size(), -1);
+  if (global_dev) {
+    for (int j = 0; j < n_jobs; ++j) {
+      if (jobs[j].pure) continue;
+      const int32_t sl = truth_slot[j];
+      int32_t& have = slot_of_truth[(size_t)J[(size_t)j].truth];
+      if (sl < 0 || sl >= n_slots || (have >= 0 && have != sl)) {
+        if (dict) qm_dict_destroy(dict);
+        return fail(QM_E_INVAL, "qm_extract_files_ex: job " + std::to_string(j) + " names row " + std::to_string(sl) + " for a truth file that another job puts elsewhere (or outside [0, n_slots))");
+      }
+      have = sl;
     }
   }
   int truth_rc = QM_OK;
@@ -241,7 +288,8 @@ extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs
     const int rc = qm_batch_create_ext(ctx, (int)nrec.size(), nrec.data(), tids.data(), n_bins, mode, &batch);
     if (rc != QM_OK) { cleanup(); return rc; }
   }
-  std::unique_lock<std::mutex> arena_lock(*g_arena_mu);   // one call at a time uses the process's page-locked arena
+  CtxArena* const ca = arena_of(ctx);
+  std::unique_lock<std::mutex> arena_lock(ca->mu);   // one call at a time per context uses its page-locked arena
   size_t need = 0;
   std::vector<size_t> aoff((size_t)n_jobs);
   for (int j = 0; j < n_jobs; ++j) {
@@ -249,7 +297,7 @@ extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs
     const size_t cap = (size_t)J[(size_t)j].n_lines + 1;
     need += ((cap * 17 + 255) & ~(size_t)255) + ((((cap + 63) / 64) * 16 + 255) & ~(size_t)255);
   }
-  uint8_t* arena = g_arena.get(need);
+  uint8_t* arena = ca->arena.get(need);
   if (!arena) { cleanup(); return fail(QM_E_NOMEM, "qm_extract_files: no memory for the column buffers"); }
   hipStream_t copy_stream = nullptr;
   if (hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess) { cleanup(); return fail(QM_E_HIP, "hipStreamCreate failed"); }
@@ -269,15 +317,24 @@ extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs
     s.line_kind.resize(cap);
     s.rc = qm_host_scan_threads(s.vcf.p, s.vcf.n, (int64_t)cap, s.line_off.data(), s.line_kind.data(), s.pos, s.ref, s.alt, s.qual, s.flags,
                                 &s.info, dict, per_file_threads > 1 ? per_file_threads : -1);   // -1: one thread, lines counted above
-    if (s.rc != QM_OK || s.info.n_data != s.n_data) { if (s.rc == QM_OK) s.rc = QM_E_INVAL; return; }
+    if (s.rc != QM_OK || s.info.n_data != s.n_data) {
+      // (the file changed between the count and the scan: the scan stops at the room it was given)
+      s.err = s.rc == QM_OK || s.rc == QM_E_INVAL ? "the file changed while it was being read" : "tokenising failed";
+      if (s.rc == QM_OK) s.rc = QM_E_INVAL;
+      return;
+    }
     if (jobs[j].pure) return;
     wait_patterns();
     const TruthState& t = T[(size_t)s.truth];
     if (t.rc != QM_OK) { s.rc = t.rc; return; }
-    if (s.info.n_host || s.info.n_nokey_kept || t.info[1] > 0 || t.info[2] > 0)
+    if (s.info.n_host || s.info.n_nokey_kept || t.info[1] > 0 || t.info[2] > 0) {
       s.rc = qm_vcf_hostpath(t.pats, s.vcf.p, s.vcf.n, s.info.n_lines, s.line_off.data(), s.line_kind.data(), s.pos, s.ref, s.alt, s.flags, s.ex);
-    if (s.rc == QM_OK && !(strict && s.info.n_refused))
+      if (s.rc != QM_OK) s.err = "the host path (fgrep -w on the text) failed";
+    }
+    if (s.rc == QM_OK && !(strict && s.info.n_refused)) {
       s.rc = qm_batch_upload_async(batch, s.batch_v, s.pos, s.ref, s.alt, s.qual, s.flags, copy_stream);
+      if (s.rc != QM_OK) s.err = qm_last_error(ctx);   // this thread's message: the caller's thread would not see it
+    }
   });
   int rc = QM_OK;
   wait_patterns();
@@ -288,7 +345,7 @@ extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs
   }
   for (int j = 0; j < n_jobs && rc == QM_OK; ++j) {
     const JobState& s = J[(size_t)j];
-    if (s.rc != QM_OK) rc = fail(s.rc, std::string("tokenising / uploading failed for ") + jobs[j].vcf_path);
+    if (s.rc != QM_OK) rc = fail(s.rc, std::string("tokenising / uploading failed for ") + jobs[j].vcf_path + (s.err.empty() ? "" : ": " + s.err));
     else if (strict && s.info.n_refused)
       rc = fail(QM_E_NONCANON, std::string(jobs[j].vcf_path) + " line " + std::to_string(s.info.first_refused_line) +
                                    ": a kept line holds NUL or non-ASCII bytes -- the reference's answer for it depends on the locale "
@@ -308,6 +365,19 @@ extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs
     roc.resize(nrec.size() * 3 * (size_t)n_bins);
     if (rc == QM_OK) rc = qm_batch_get_scalars(batch, scal.data());
     if (rc == QM_OK) rc = qm_batch_get_roc(batch, roc.data());
+    if (rc == QM_OK && global_dev) {
+      // the per-truth-set sums as the engine left them in HBM, row by row into the caller's layout: what a multi-GPU caller
+      // all-reduces (device to device: the counters never visit the host)
+      void* src = nullptr;
+      rc = qm_batch_global_device(batch, &src);
+      const size_t rowb = 3 * (size_t)n_bins * sizeof(uint64_t);
+      for (size_t k = 0; k < T.size() && rc == QM_OK; ++k) {
+        if (slot_of_truth[k] < 0 || T[k].tid < 0) continue;
+        if (hipMemcpy((uint8_t*)global_dev + (size_t)slot_of_truth[k] * rowb, (const uint8_t*)src + (size_t)T[k].tid * rowb, rowb,
+                      hipMemcpyDeviceToDevice) != hipSuccess)
+          rc = fail(QM_E_HIP, "qm_extract_files_ex: copying the per-truth sums failed");
+      }
+    }
   }
   ph[4] = now() - t0;
   t0 = now();

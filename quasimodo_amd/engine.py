@@ -135,9 +135,11 @@ class Engine:
         check(self._L.qm_bench_synth(self._h, C.byref(cfg), int(n_vcf), int(records), int(n_bins), int(steps), C.byref(r)), self._h)
         return {k: getattr(r, k) for k, _ in r._fields_ if k != "reserved"}
 
-    def extract_files(self, file_jobs, n_bins=256, alleles=False, strict=True):
-        """qm_extract_files: files in, files out, everything between in the library (host threads + ONE engine batch).
+    def extract_files(self, file_jobs, n_bins=256, alleles=False, strict=True, truth_slots=None, n_slots=0, global_dev=None):
+        """qm_extract_files(_ex): files in, files out, everything between in the library (host threads + ONE engine batch).
         file_jobs: list of dicts vcf / truth / mode ("hcmv" | "custom") / pure / filtered / tp / fp.
+        truth_slots / n_slots / global_dev (device pointer, int): one rank of a multi-GPU run -- the per-truth-file sums of
+        this call's VCFs land in rows truth_slots[j] of the caller's [n_slots][3][n_bins] uint64 device buffer (cleared first).
         Returns (list of per-VCF dicts: scalars by name + n_lines, genomediff, header_kept, host_decided, roc; phase seconds)."""
         import os
         n = len(file_jobs)
@@ -149,7 +151,9 @@ class Engine:
         st = (_lib.FileStats * max(n, 1))()
         roc = np.zeros((max(n, 1), 3, n_bins), np.uint64)
         ph = (C.c_double * 8)()
-        check(self._L.qm_extract_files(self._h, n, arr, int(n_bins), _lib.QM_BATCH_ALLELES if alleles else 0, int(bool(strict)), st, _p(roc), ph), self._h)
+        slots = None if truth_slots is None else _c(list(truth_slots) + [0] * (1 if n == 0 else 0), np.int32)
+        check(self._L.qm_extract_files_ex(self._h, n, arr, int(n_bins), _lib.QM_BATCH_ALLELES if alleles else 0, int(bool(strict)), st, _p(roc), ph,
+                                          _p(slots), int(n_slots), C.c_void_p(global_dev) if global_dev else None), self._h)
         rows = []
         for k in range(n):
             r = dict(zip(SCALAR_NAMES, list(st[k].scalars)))

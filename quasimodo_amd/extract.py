@@ -73,13 +73,14 @@ def _alleles_default():
     return os.environ.get("QM_ALLELES", "0") not in ("", "0")
 
 
-def extract_many(jobs, engine=None, strict=None, n_bins=256, alleles=None, gpus=None):
+def extract_many(jobs, engine=None, strict=None, n_bins=256, alleles=None, gpus=None, truth_slots=None, n_slots=0, global_dev=None):
     """Classify and write filtered / tp / fp VCFs for a list of Job.  Returns the jobs
     with .stats filled (line counts, R-path counts, ROC rows).
     gpus > 1: the VCFs are dealt to that many GPUs of this node, one process each (quasimodo_amd.multigpu).
     alleles=True (or QM_ALLELES=1): the allele-extended mode -- every record whose REF and ALT are
     [ACGT]+ takes part, not only single bases (a build-defined widening of the reference's filter,
-    include/qmvt.h; hcmv mode only)."""
+    include/qmvt.h; hcmv mode only).
+    truth_slots / n_slots / global_dev: this call is one rank's share of a multi-GPU run (Engine.extract_files)."""
     strict = _strict_default() if strict is None else strict
     alleles = _alleles_default() if alleles is None else bool(alleles)
     if gpus is not None and int(gpus) > 1:
@@ -109,7 +110,8 @@ def extract_many(jobs, engine=None, strict=None, n_bins=256, alleles=None, gpus=
         if engine is None:
             rows = _pure_only(fj, strict)
         else:
-            rows, phases = engine.extract_files(fj, n_bins=n_bins, alleles=alleles, strict=strict)
+            rows, phases = engine.extract_files(fj, n_bins=n_bins, alleles=alleles, strict=strict, truth_slots=truth_slots, n_slots=n_slots,
+                                                global_dev=global_dev)
             extract_many.last_phases = phases
     finally:
         if own and engine is not None:

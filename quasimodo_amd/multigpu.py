@@ -2,25 +2,27 @@
 
 The caller x sample VCFs are independent units (the reference runs one process per VCF,
 rules/extract_TP.smk:17-20), so they shard over ranks with no data-path collective: one process
-per GPU, VCFs dealt by longest-processing-time-first on their size (`sharding.lpt_shards`), every
-rank runs the ordinary batch path (`extract_many`) on its share and writes its own files.  The
-only exchange is ONE all-reduce of the per-truth-set confusion counters [n_truth][3][n_bins]
-(RCCL over xGMI: torch.distributed backend "nccl"; "gloo" in the CPU tests) plus a gather of the
-per-VCF rows to rank 0 for the tables.
+per GPU, VCFs dealt by longest-processing-time-first on their size (`sharding.lpt_shards`) -- whole
+GROUPS of VCFs where something needs them together: the FP overlap of rules/compare_FP.smk:5-8 compares
+the callers of ONE sample, so the workflows deal by sample and every rank computes the overlap of its own
+samples with no exchange -- every rank runs the ordinary batch path (`extract_many` -> qm_extract_files_ex)
+on its share and writes its own files.  The only exchange is ONE all-reduce of the per-truth-file confusion
+counters [n_truth][3][n_bins], on the device buffer the engine filled (RCCL over xGMI: torch.distributed
+backend "nccl"; "gloo" in the CPU tests), plus a gather of the per-VCF rows to rank 0 for the tables.
 
 The parent never touches a GPU: it writes the job list to a spec file and starts one child per
-rank (`python -m quasimodo_amd.multigpu <spec> <rank>`); children rendezvous on 127.0.0.1.
+rank (`python -m quasimodo_amd.multigpu <spec>`, quasimodo_amd.launch.spawn_ranks); children rendezvous on 127.0.0.1.
 """
+import datetime
 import importlib
 import os
 import pickle
-import socket
-import subprocess
 import sys
 import tempfile
 
 import numpy as np
 
+from .launch import DEFAULT_TIMEOUT, RankFailure, spawn_ranks
 from .sharding import allreduce_counters, lpt_shards
 
 
@@ -34,50 +36,108 @@ def job_weights(jobs):
     return [os.path.getsize(j.vcf_file) for j in jobs]
 
 
-def default_classify(jobs, device, n_bins=256, alleles=None, strict=None):
-    """One rank's share through the ordinary batch path on GPU `device`."""
+def plan_shards(jobs, world, groups=None):
+    """Which job goes to which rank: LPT on the file sizes, over whole groups when `groups` (a list of lists of job
+    indices that must share a rank; jobs in no group are groups of their own) is given.  Returns a list (per rank) of
+    job indices in ascending order -- the same on every rank."""
+    w = job_weights(jobs)
+    if not groups:
+        return lpt_shards(w, world)
+    seen = set()
+    units = []
+    for g in groups:
+        g = sorted(set(int(i) for i in g))
+        if seen & set(g):
+            raise ValueError("a job is in two groups")
+        seen |= set(g)
+        if g:
+            units.append(g)
+    units += [[i] for i in range(len(jobs)) if i not in seen]
+    units.sort(key=lambda g: g[0])
+    shards_u = lpt_shards([sum(w[i] for i in g) for g in units], world)
+    return [sorted(i for u in su for i in units[u]) for su in shards_u]
+
+
+def truth_layout(jobs):
+    """The rows of the all-reduced counters: one per distinct truth file of the WHOLE run, in sorted order -- every rank
+    derives the same layout from the same job list.  Returns (keys, slot per job; -1 for pure-strain samples)."""
+    from .extract import is_pure_strain
+    keys = sorted({truth_key(j) for j in jobs if not is_pure_strain(j.vcf_file)})
+    kidx = {k: i for i, k in enumerate(keys)}
+    return keys, [-1 if is_pure_strain(j.vcf_file) else kidx[truth_key(j)] for j in jobs]
+
+
+def default_body(jobs, indices, device, opts):
+    """One rank's share through the ordinary batch path on GPU `device` (the product's per-rank body).
+    opts: n_bins, alleles, strict, slots (row of every job of `jobs` in the counters), n_slots, backend, post ("module:function",
+    optional: post(engine, jobs, indices, post_args) runs while the engine is alive and returns something picklable for rank 0),
+    post_args.  Returns {"stats": [...], "counters": device tensor [n_slots][3][n_bins] int64 filled by the engine, "extra": ...}."""
+    import torch
     from .engine import Engine
-    from .extract import extract_many
-    if not jobs:
-        return []
-    with Engine(device) as eng:
-        extract_many(jobs, engine=eng, strict=strict, n_bins=n_bins, alleles=alleles)
-    return [j.stats for j in jobs]
+    from .extract import extract_many, is_pure_strain
+    n_bins, n_slots = opts["n_bins"], max(opts["n_slots"], 1)
+    on_gpu = opts.get("backend", "nccl") == "nccl" or opts.get("device_counters", True)
+    dev = torch.device("cuda", device)
+    counters = torch.zeros((n_slots, 3, n_bins), dtype=torch.int64, device=dev) if on_gpu else None
+    extra = None
+    need_engine = bool(jobs) and (not all(is_pure_strain(j.vcf_file) for j in jobs) or opts.get("post"))
+    eng = Engine(device) if need_engine else None
+    try:
+        if jobs:
+            extract_many(jobs, engine=eng, strict=opts.get("strict"), n_bins=n_bins, alleles=opts.get("alleles"),
+                         truth_slots=opts["slots"] if counters is not None else None, n_slots=n_slots,
+                         global_dev=counters.data_ptr() if counters is not None and eng is not None else None)
+        if opts.get("post"):
+            extra = _resolve(opts["post"])(eng, jobs, indices, opts.get("post_args"))
+    finally:
+        if eng is not None:
+            eng.close()
+    if counters is not None:
+        torch.cuda.synchronize(dev)
+    return {"stats": [j.stats for j in jobs], "counters": counters, "extra": extra}
 
 
 def _resolve(name):
     if not name:
-        return default_classify
+        return default_body
+    if callable(name):
+        return name
     mod, fn = name.split(":")
     return getattr(importlib.import_module(mod), fn)
 
 
-def run_rank(jobs, rank, world, backend="nccl", classify=None, n_bins=256, alleles=None, strict=None, same_device=False):
-    """What one rank does.  Returns, on rank 0, {"stats": [per job], "counters": int64 [n_truth][3][n_bins],
-    "truth_keys": [...], "shards": [[job index, ...] per rank]}; None on the other ranks.
+def run_rank(jobs, rank, world, backend="nccl", body=None, n_bins=256, alleles=None, strict=None, same_device=False,
+             groups=None, post=None, post_args=None):
+    """What one rank does.  Returns, on rank 0, {"stats": [per job], "counters": int64 [n_truth][3][n_bins] summed over ALL
+    ranks, "truth_keys": [...], "shards": [[job index, ...] per rank], "extras": [per rank]}; None on the other ranks.
     torch.distributed must be initialised by the caller (world > 1)."""
     import torch
     import torch.distributed as dist
-    from .extract import is_pure_strain
-    classify = classify or default_classify
-    shards = lpt_shards(job_weights(jobs), world)
+    body = _resolve(body)
+    shards = plan_shards(jobs, world, groups)
     mine = shards[rank]
     device = 0 if same_device else rank
-    local = classify([jobs[i] for i in mine], device, n_bins=n_bins, alleles=alleles, strict=strict)
+    keys, slot = truth_layout(jobs)
+    opts = dict(n_bins=n_bins, alleles=alleles, strict=strict, slots=[slot[i] for i in mine], n_slots=len(keys), backend=backend,
+                post=post, post_args=post_args, rank=rank, world=world)
+    res = body([jobs[i] for i in mine], list(mine), device, opts)
+    local = res["stats"]
     if len(local) != len(mine):
-        raise RuntimeError("classify returned %d rows for %d jobs" % (len(local), len(mine)))
-    # the confusion counters of every truth set, summed over this rank's VCFs, in ONE tensor
-    keys = sorted({truth_key(j) for j in jobs if not is_pure_strain(j.vcf_file)})
-    kidx = {k: i for i, k in enumerate(keys)}
-    cnt = np.zeros((max(len(keys), 1), 3, n_bins), np.int64)
-    for i, st in zip(mine, local):
-        if st.get("roc") is not None:
-            cnt[kidx[truth_key(jobs[i])]] += np.asarray(st["roc"]).astype(np.int64)
-    t = torch.from_numpy(cnt)
-    if backend == "nccl":
-        t = t.to(torch.device("cuda", device))
+        raise RuntimeError("the rank body returned %d rows for %d jobs" % (len(local), len(mine)))
+    t = res.get("counters")
+    if t is None:
+        # a body without device counters (the CPU stand-in of the tests): the rows summed on the host
+        cnt = np.zeros((max(len(keys), 1), 3, n_bins), np.int64)
+        for i, st in zip(mine, local):
+            if st.get("roc") is not None:
+                cnt[slot[i]] += np.asarray(st["roc"]).astype(np.int64)
+        t = torch.from_numpy(cnt)
+        if backend == "nccl":
+            t = t.to(torch.device("cuda", device))
+    elif backend != "nccl" and t.is_cuda:
+        t = t.cpu()                            # rehearsals on one card: gloo sums host tensors
     allreduce_counters(t)                      # the path's single collective
-    rows = list(zip(mine, local))
+    rows = (list(zip(mine, local)), res.get("extra"))
     if world > 1:
         gathered = [None] * world if rank == 0 else None
         dist.gather_object(rows, gathered, dst=0)
@@ -86,74 +146,42 @@ def run_rank(jobs, rank, world, backend="nccl", classify=None, n_bins=256, allel
     if rank != 0:
         return None
     stats = [None] * len(jobs)
-    for part in gathered:
+    for part, _ in gathered:
         for i, st in part:
             stats[i] = st
-    return {"stats": stats, "counters": t.cpu().numpy(), "truth_keys": keys, "shards": shards}
+    return {"stats": stats, "counters": t.cpu().numpy(), "truth_keys": keys, "shards": shards, "extras": [e for _, e in gathered]}
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
-def extract_many_sharded(jobs, gpus, backend="nccl", classify=None, n_bins=256, alleles=None, strict=None, same_device=False,
-                         timeout=None):
+def extract_many_sharded(jobs, gpus, backend="nccl", body=None, n_bins=256, alleles=None, strict=None, same_device=False,
+                         timeout=None, groups=None, post=None, post_args=None, classify=None):
     """`extract_many` over `gpus` GPUs of this node: one child process per GPU, started before anything
-    touches a GPU.  `classify` ("module:function", optional) replaces the per-rank batch path (tests inject
-    a CPU stand-in; the product default is the HIP engine).  Returns (jobs with .stats filled, result dict of rank 0)."""
-    from .extract import Job, _paths
+    touches a GPU.  `body` ("module:function", optional) replaces the per-rank body (tests inject a CPU stand-in; the
+    product default is the HIP engine, `default_body`).  groups / post / post_args: see plan_shards / default_body.
+    timeout: seconds for the whole run (default QM_RANK_TIMEOUT, 3600): a rendezvous or a collective that hangs with every
+    rank alive must not hang the caller.  Returns (jobs with .stats filled, result dict of rank 0)."""
+    from .extract import _paths
     if gpus < 1:
         raise ValueError("gpus must be >= 1")
+    body = body or classify   # (the old name of the hook)
     for j in jobs:
         _paths(j)
+    timeout = DEFAULT_TIMEOUT if timeout is None else timeout
     with tempfile.TemporaryDirectory(prefix="qmvt_mgpu_") as tmp:
         spec = {"jobs": [dict(vcf_file=j.vcf_file, snp_file=j.snp_file, mode=j.mode, outdir=j.outdir, caller=j.caller) for j in jobs],
-                "world": gpus, "backend": backend, "classify": classify, "n_bins": n_bins, "alleles": alleles, "strict": strict,
-                "same_device": same_device, "result": os.path.join(tmp, "result.pkl")}
+                "world": gpus, "backend": backend, "body": body, "n_bins": n_bins, "alleles": alleles, "strict": strict,
+                "same_device": same_device, "result": os.path.join(tmp, "result.pkl"), "groups": groups, "post": post,
+                "post_args": post_args, "timeout": timeout}
         sp = os.path.join(tmp, "spec.pkl")
         with open(sp, "wb") as fh:
             pickle.dump(spec, fh)
-        env = dict(os.environ)
-        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(gpus))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
-        procs = []
-        for r in range(gpus):
-            e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-            with open(os.path.join(tmp, "rank%d.log" % r), "wb") as lf:
-                procs.append(subprocess.Popen([sys.executable, "-m", "quasimodo_amd.multigpu", sp, str(r)], env=e,
-                                              stdout=lf, stderr=subprocess.STDOUT))
-        # a rank that dies leaves its peers waiting in the collective: watch all of them, stop the rest when one fails
-        import time
-        logs = [os.path.join(tmp, "rank%d.log" % r) for r in range(gpus)]
-        t0, bad = time.monotonic(), []
-        while True:
-            codes = [p.poll() for p in procs]
-            bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
-            if bad or all(c == 0 for c in codes):
-                break
-            if timeout is not None and time.monotonic() - t0 > timeout:
-                bad = [r for r, c in enumerate(codes) if c is None]
-                break
-            time.sleep(0.05)
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-            p.wait()
-        if bad:
-            tails = []
-            for r in bad:
-                try:
-                    with open(logs[r], "rb") as fh:
-                        tails.append("--- rank %d ---\n%s" % (r, fh.read()[-3000:].decode("utf-8", "replace")))
-                except OSError:
-                    pass
-            raise RuntimeError("rank(s) %s failed or timed out:\n%s" % (bad, "\n".join(tails)))
+        cmd = [sys.executable, "-m", "quasimodo_amd.multigpu", sp]
+        try:
+            spawn_ranks(cmd, gpus, timeout=timeout)
+        except RankFailure as e:
+            if "EADDRINUSE" in str(e) or "Address already in use" in str(e):   # the port was taken between the probe and the bind
+                spawn_ranks(cmd, gpus, timeout=timeout)
+            else:
+                raise RuntimeError(str(e)) from None
         with open(spec["result"], "rb") as fh:
             res = pickle.load(fh)
     for j, st in zip(jobs, res["stats"]):
@@ -164,26 +192,28 @@ def extract_many_sharded(jobs, gpus, backend="nccl", classify=None, n_bins=256, 
 
 
 def _main(argv):
-    sp, rank = argv[0], int(argv[1])
+    sp = argv[0]
+    rank = int(os.environ["RANK"]) if len(argv) < 2 else int(argv[1])
     with open(sp, "rb") as fh:
         spec = pickle.load(fh)
     import torch
     import torch.distributed as dist
-    from .extract import Job
+    from .extract import Job, _paths
     world, backend = spec["world"], spec["backend"]
     jobs = [Job(**d) for d in spec["jobs"]]
-    from .extract import _paths
     for j in jobs:
         _paths(j)
+    tmo = datetime.timedelta(seconds=max(60.0, float(spec.get("timeout") or DEFAULT_TIMEOUT)))
     if backend == "nccl":
         dev = torch.device("cuda", 0 if spec["same_device"] else rank)
         torch.cuda.set_device(dev)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
     else:
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
     try:
-        res = run_rank(jobs, rank, world, backend=backend, classify=_resolve(spec["classify"]), n_bins=spec["n_bins"],
-                       alleles=spec["alleles"], strict=spec["strict"], same_device=spec["same_device"])
+        res = run_rank(jobs, rank, world, backend=backend, body=spec["body"], n_bins=spec["n_bins"],
+                       alleles=spec["alleles"], strict=spec["strict"], same_device=spec["same_device"], groups=spec.get("groups"),
+                       post=spec.get("post"), post_args=spec.get("post_args"))
         if rank == 0:
             with open(spec["result"] + ".tmp", "wb") as fh:
                 pickle.dump(res, fh)

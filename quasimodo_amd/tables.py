@@ -115,6 +115,10 @@ def write_weighted_roc(path, roc, truth_unique):
         f1 = 2 * prec * sens / (prec + sens) if prec + sens > 0 else 0.0
         lines.append("%d\t%d\t%d\t%d\t%d\t%.4f\t%.4f\t%.4f" % (t, tp_base, fp, tp_call, fn, prec, sens, f1))
     data = ("\n".join(lines) + "\n").encode()
-    opener = gzip.open if str(path).endswith(".gz") else open
-    with opener(path, "wb") as fh:
-        fh.write(data)
+    if str(path).endswith(".gz"):
+        # no name and no time stamp in the header: the same numbers give the same bytes, whoever writes them and when
+        with open(path, "wb") as raw, gzip.GzipFile(filename="", mode="wb", fileobj=raw, mtime=0) as fh:
+            fh.write(data)
+    else:
+        with open(path, "wb") as fh:
+            fh.write(data)

@@ -42,9 +42,34 @@ def fp_overlap_tables(engine, fp_files_by_sample, callers):
     return out
 
 
-def run_hcmv_variantcall(data_dir, outpath, callers=None, engine=None, dryrun=False):
+def hcmv_rank_post(engine, jobs, indices, args):
+    """What a rank of the multi-GPU workflow does with its own VCFs once they are extracted, while its engine is alive:
+    the FP overlap of its samples (rules/compare_FP.smk:5-8 compares the callers of ONE sample, and the workflow dealt the
+    VCFs by sample: no exchange) and the xindel sweeps of its VCFs.  Returns {"overlap": {sample: [region sizes]}}."""
+    meta = [args["meta"][i] for i in indices]
+    cmp_callers = args["cmp_callers"]
+    out = {}
+    if len(cmp_callers) >= 2:
+        by_sample = {}
+        for (c, s), j in zip(meta, jobs):
+            if c in cmp_callers and not s.endswith(("-1-0", "-0-1")):
+                by_sample.setdefault(s, {})[c] = j.fp_out
+        for s, files in by_sample.items():
+            if len(files) != len(cmp_callers):
+                raise WorkflowError("sample %s: the compared callers are not all on one rank" % s)
+            out[s] = [int(x) for x in fp_overlap_tables(engine, {s: files}, cmp_callers)[s]]
+    if args.get("indel_roc", True):
+        indel_roc(engine, [(c, s, j) for (c, s), j in zip(meta, jobs) if not j.stats.get("pure_strain")], args["snp_dir"])
+    return {"overlap": out}
+
+
+def run_hcmv_variantcall(data_dir, outpath, callers=None, engine=None, dryrun=False, gpus=None, _body=None, _backend="nccl",
+                         _same_device=False):
     """data_dir: the unpacked bundle (data/snp): vcf/{caller}/{sample}.{ref}.{caller}.vcf and
-    nucmer/{TM,TA}.maskrepeat.variants.vcf (rules/load_config.smk:28-36)."""
+    nucmer/{TM,TA}.maskrepeat.variants.vcf (rules/load_config.smk:28-36).
+    gpus > 1: one process per GPU (quasimodo_amd.multigpu); the VCFs are dealt by SAMPLE (longest first), so the four
+    compared callers of a sample meet on one rank and the FP overlap needs no exchange; every rank writes its own files,
+    the confusion counters go through the one all-reduce, the rows come to this process for the three tables."""
     callers = list(callers or SNPCALLERS)
     results = os.path.join(outpath.rstrip("/"), "results")
     snp_dir = os.path.join(results, "snp")
@@ -85,6 +110,30 @@ def run_hcmv_variantcall(data_dir, outpath, callers=None, engine=None, dryrun=Fa
             t = os.path.join(snp_dir, "nucmer", "%s.maskrepeat.variants.vcf" % mix)
             if os.path.exists(t):
                 split_variants(t, os.path.join(snp_dir, "nucmer", "%s.maskrepeat.%s.vcf" % (mix, kind)), kind, bgz=True)
+    mixed = [s for s in samples if not s.endswith(("-1-0", "-0-1"))]
+    cmp_callers = [c for c in FP_COMPARED if c in callers]
+    tables = os.path.join(results, "final_tables")
+    if gpus is not None and (int(gpus) > 1 or _body):
+        if engine is not None:
+            raise ValueError("gpus > 1 starts one process (and one engine) per GPU: do not pass an engine")
+        from .multigpu import extract_many_sharded
+        groups = [[i for i, (c, s) in enumerate(meta) if s == smp] for smp in samples]
+        jobs, res = extract_many_sharded(jobs, int(gpus), backend=_backend, body=_body, same_device=_same_device, groups=groups,
+                                         post="quasimodo_amd.workflow:hcmv_rank_post",
+                                         post_args=dict(meta=meta, cmp_callers=cmp_callers, snp_dir=snp_dir))
+        os.makedirs(tables, exist_ok=True)
+        write_caller_performance(os.path.join(tables, "caller_performance.tsv"), [(c, s, j.stats) for (c, s), j in zip(meta, jobs)])
+        _write_snp_rocs(meta, jobs, snp_dir)
+        if mixed and len(cmp_callers) >= 2:
+            reg = {}
+            for e in res["extras"]:
+                reg.update((e or {}).get("overlap", {}))
+            missing = [s for s in mixed if s not in reg]
+            if missing:
+                raise WorkflowError("no FP overlap came back for %s" % ", ".join(missing))
+            write_fp_overlap(os.path.join(tables, "snpcaller_fp_snp_compare.txt"), {s: reg[s] for s in mixed}, cmp_callers)
+        run_hcmv_variantcall.last_result = res
+        return jobs
     own = engine is None
     if own:
         engine = Engine(int(os.environ.get("QM_DEVICE", "0")))
@@ -93,17 +142,8 @@ def run_hcmv_variantcall(data_dir, outpath, callers=None, engine=None, dryrun=Fa
         os.makedirs(os.path.join(results, "final_tables"), exist_ok=True)
         write_caller_performance(os.path.join(results, "final_tables", "caller_performance.tsv"),
                                  [(c, s, j.stats) for (c, s), j in zip(meta, jobs)])
-        # The engine's exact-match ROC sweeps, in the column layout of RTG's weighted_roc.tsv.gz but under a directory of
-        # their own: results/snp/rtg/ belongs to the reference's rtg rules (rules/vis_eval_vcf.smk:5-121), whose
-        # haplotype-aware numbers these are not.
-        for (c, smp), j in zip(meta, jobs):
-            if not j.stats.get("pure_strain") and j.stats.get("roc") is not None:
-                d = os.path.join(snp_dir, "qmvt_roc", c, "%s.%s.xsnp" % (smp, SAMPLE_REF[smp]))
-                os.makedirs(d, exist_ok=True)
-                write_weighted_roc(os.path.join(d, "exact_roc.tsv.gz"), j.stats["roc"], j.stats["truth_unique"])
+        _write_snp_rocs(meta, jobs, snp_dir)
         indel_roc(engine, [(c, smp, j) for (c, smp), j in zip(meta, jobs) if not j.stats.get("pure_strain")], snp_dir)
-        mixed = [s for s in samples if not s.endswith(("-1-0", "-0-1"))]
-        cmp_callers = [c for c in FP_COMPARED if c in callers]
         if mixed and len(cmp_callers) >= 2:                              # compareFP (counts only)
             files = {s: {c: j.fp_out for (c, ss), j in zip(meta, jobs) if ss == s and c in cmp_callers} for s in mixed}
             reg = fp_overlap_tables(engine, files, cmp_callers)
@@ -112,6 +152,20 @@ def run_hcmv_variantcall(data_dir, outpath, callers=None, engine=None, dryrun=Fa
         if own:
             engine.close()
     return jobs
+
+
+run_hcmv_variantcall.last_result = None
+
+
+def _write_snp_rocs(meta, jobs, snp_dir):
+    """The engine's exact-match ROC sweeps, in the column layout of RTG's weighted_roc.tsv.gz but under a directory of
+    their own: results/snp/rtg/ belongs to the reference's rtg rules (rules/vis_eval_vcf.smk:5-121), whose
+    haplotype-aware numbers these are not."""
+    for (c, smp), j in zip(meta, jobs):
+        if not j.stats.get("pure_strain") and j.stats.get("roc") is not None:
+            d = os.path.join(snp_dir, "qmvt_roc", c, "%s.%s.xsnp" % (smp, SAMPLE_REF[smp]))
+            os.makedirs(d, exist_ok=True)
+            write_weighted_roc(os.path.join(d, "exact_roc.tsv.gz"), j.stats["roc"], j.stats["truth_unique"])
 
 
 def indel_roc(engine, items, snp_dir, n_bins=256):
@@ -151,8 +205,9 @@ def indel_roc(engine, items, snp_dir, n_bins=256):
         adict.close()
 
 
-def run_vareval(vcfs, snps_file, outpath, labels=None, engine=None, dryrun=False):
-    """eval_variant_custom.smk with the genome difference (show-snps -CTHIlr TSV) already computed."""
+def run_vareval(vcfs, snps_file, outpath, labels=None, engine=None, dryrun=False, gpus=None, _body=None, _backend="nccl", _same_device=False):
+    """eval_variant_custom.smk with the genome difference (show-snps -CTHIlr TSV) already computed.
+    gpus > 1: the VCFs are dealt to that many GPUs (one process each); the rows come back for the table."""
     results = os.path.join(outpath.rstrip("/"), "results")
     call_dir = os.path.join(results, "snp", "callers")
     labels = list(labels) if labels else [os.path.splitext(os.path.basename(v))[0] for v in vcfs]
@@ -166,8 +221,18 @@ def run_vareval(vcfs, snps_file, outpath, labels=None, engine=None, dryrun=False
         raise WorkflowError("No difference between two genomes!")       # custom_snp_benchmark.R:19-21
     os.makedirs(os.path.join(call_dir, "fp"), exist_ok=True)
     jobs = [Job(v, snps_file, "custom", call_dir, lab) for lab, v in zip(labels, vcfs)]
-    extract_many(jobs, engine=engine)
+    if gpus is not None and (int(gpus) > 1 or _body):
+        if engine is not None:
+            raise ValueError("gpus > 1 starts one process (and one engine) per GPU: do not pass an engine")
+        from .multigpu import extract_many_sharded
+        jobs, res = extract_many_sharded(jobs, int(gpus), backend=_backend, body=_body, same_device=_same_device)
+        run_vareval.last_result = res
+    else:
+        extract_many(jobs, engine=engine)
     os.makedirs(os.path.join(results, "final_tables"), exist_ok=True)
     write_snpcall_benchmark(os.path.join(results, "final_tables", "snpcall_benchmark.txt"),
                             [(lab, j.stats) for lab, j in zip(labels, jobs)])
     return jobs
+
+
+run_vareval.last_result = None

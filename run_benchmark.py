@@ -37,6 +37,7 @@ def common_options(f):
         click.option("-t", "--threads", type=int, default=2, show_default=True, help="The number of threads to use."),
         click.option("-c", "--conda_prefix", type=click.Path(exists=True), default=None, help="Accepted for compatibility; unused."),
         click.option("-o", "--outpath", type=click.Path(), default=None, help="The directory where to put the results."),
+        click.option("--gpus", type=int, default=1, show_default=True, help="GPUs of this node to shard the VCFs over (one process each)."),
     ]):
         f = opt(f)
     return f
@@ -54,7 +55,7 @@ def _fail(e):
 @click.option("-e", "--evaluation", required=True, type=click.Choice(["all", "variantcall", "assembly"]), help="The evaluation to run.")
 @click.option("-s", "--slow", is_flag=True, default=False, show_default=True, help="Run the evaluation based on reads (not supported by this build).")
 @click.option("--data", type=click.Path(), default=None, help="Unpacked bundle directory (default: <repo>/data/snp).")
-def hcmv(evaluation, dryrun=False, conda_prefix=None, slow=False, outpath=None, threads=2, data=None):
+def hcmv(evaluation, dryrun=False, conda_prefix=None, slow=False, outpath=None, threads=2, data=None, gpus=1):
     if slow:
         click.echo("--slow (reads -> VCF) is outside the accelerated path; not supported", err=True)
         sys.exit(2)
@@ -64,7 +65,7 @@ def hcmv(evaluation, dryrun=False, conda_prefix=None, slow=False, outpath=None, 
     from quasimodo_amd import workflow
     out = os.path.join(cd, outpath) if outpath else os.path.join(cd, "..", "revision_output_1")   # config/config.yaml outpath
     try:
-        workflow.run_hcmv_variantcall(data or os.path.join(wd, "data", "snp"), out, dryrun=dryrun)
+        workflow.run_hcmv_variantcall(data or os.path.join(wd, "data", "snp"), out, dryrun=dryrun, gpus=gpus if gpus > 1 else None)
     except Exception as e:
         _fail(e)
     if evaluation == "all":
@@ -79,7 +80,7 @@ def hcmv(evaluation, dryrun=False, conda_prefix=None, slow=False, outpath=None, 
 @click.option("--novenn", is_flag=True, help="Accepted for compatibility; no figure is drawn.")
 @click.option("--snps", type=click.Path(), default=None,
               help="show-snps -CTHIlr table of the two references; default <outpath>/results/snp/nucmer/<g1>_<g2>.maskrepeat.snps")
-def vareval(dryrun=False, conda_prefix=None, vcfs=None, labels=None, refs=None, novenn=False, outpath=None, threads=2, snps=None):
+def vareval(dryrun=False, conda_prefix=None, vcfs=None, labels=None, refs=None, novenn=False, outpath=None, threads=2, snps=None, gpus=1):
     if not vcfs or not outpath:
         _fail("The VCF files from SNP calling or the output directory are not specified.")
     vlist = [os.path.join(cd, v.strip()) for v in vcfs.split(",")]
@@ -91,7 +92,7 @@ def vareval(dryrun=False, conda_prefix=None, vcfs=None, labels=None, refs=None, 
         snps = os.path.join(out, "results", "snp", "nucmer", "%s_%s.maskrepeat.snps" % (g[0], g[1]))   # eval_variant_custom.smk:14-17,40
     from quasimodo_amd import workflow
     try:
-        workflow.run_vareval(vlist, snps, out, labels=labels.split(",") if labels else None, dryrun=dryrun)
+        workflow.run_vareval(vlist, snps, out, labels=labels.split(",") if labels else None, dryrun=dryrun, gpus=gpus if gpus > 1 else None)
     except Exception as e:
         _fail(e)
 

@@ -1,6 +1,6 @@
 """Per-rank classification for the world-2 gloo test of quasimodo_amd.multigpu: the product's own host side (scan,
 host path, writers -- all CPU code of libqmvt.so) with the ORACLE's column-level restatement standing in for the
-device (there is no GPU in that test).  Imported by the rank processes through the `classify` hook of
+device (there is no GPU in that test).  Imported by the rank processes through the `body` hook of
 extract_many_sharded; never by the product."""
 import os
 
@@ -42,3 +42,28 @@ def classify(jobs, device, n_bins=256, alleles=None, strict=None):
         st["device"] = device
         out.append(st)
     return out
+
+
+
+def body(jobs, indices, device, opts):
+    """the per-rank body of quasimodo_amd.multigpu (default_body's interface) without a GPU: no device counters (run_rank sums
+    the rows on the host then), the FP overlap of the rank's samples by the oracle's restatement of snpcaller_fp_compare.R"""
+    stats = classify(jobs, device, n_bins=opts["n_bins"], alleles=opts.get("alleles"), strict=opts.get("strict"))
+    for j, st in zip(jobs, stats):
+        j.stats = st
+    extra = None
+    if opts.get("post"):
+        from oracle import qm_oracle as O
+        args = opts["post_args"]
+        meta = [args["meta"][i] for i in indices]
+        cmp_callers = args["cmp_callers"]
+        by_sample = {}
+        for (c, s), j in zip(meta, jobs):
+            if c in cmp_callers and not s.endswith(("-1-0", "-0-1")):
+                by_sample.setdefault(s, {})[c] = j.fp_out
+        ov = {}
+        for s, files in by_sample.items():
+            assert len(files) == len(cmp_callers), "the compared callers of %s are not on one rank" % s
+            ov[s] = [int(x) for x in O.fp_overlap_text([open(files[c], "rb").read() for c in cmp_callers])]
+        extra = {"overlap": ov, "rank": opts["rank"], "samples": sorted({s for _, s in meta})}
+    return {"stats": stats, "counters": None, "extra": extra}

@@ -22,7 +22,7 @@ def test_header_symbols_exported(qmlib):
     for n in names:
         assert hasattr(qmlib, n), "libqmvt.so does not export %s" % n
     assert sorted(_lib.EXPORTS) == names
-    assert qmlib.qm_abi_version() == 2
+    assert qmlib.qm_abi_version() == 3
 
 
 def test_no_cpu_fallback_without_device(qmlib):

@@ -36,7 +36,7 @@ def test_sharded_extract_gloo_world2(tmp_path, monkeypatch, oracle, qmlib):
     from quasimodo_amd.sharding import lpt_shards
     monkeypatch.setenv("PYTHONPATH", os.path.join(ROOT, "tests") + os.pathsep + os.environ.get("PYTHONPATH", ""))
     jobs, exps = _jobs(tmp_path)
-    jobs, res = extract_many_sharded(jobs, 2, backend="gloo", classify="sharded_cpu_classify:classify", timeout=300)
+    jobs, res = extract_many_sharded(jobs, 2, backend="gloo", body="sharded_cpu_classify:body", timeout=300)
     # every rank wrote its own files: the reference's bytes, whichever rank a VCF went to
     for job, (e, exp) in zip(jobs, exps):
         assert open(job.filtered_out, "rb").read() == exp["filtered"], case_id(e)
@@ -70,8 +70,71 @@ def test_sharded_extract_reports_a_failing_rank(tmp_path, monkeypatch, qmlib):
     (tmp_path / "b.vcf").write_bytes(b"#h\nc\t1\t.\tA\tG\t50\n")
     jobs = [Job(str(tmp_path / "a.vcf"), str(tmp_path / "missing.vcf"), "hcmv"), Job(str(tmp_path / "b.vcf"), str(tmp_path / "missing.vcf"), "hcmv")]
     with pytest.raises(RuntimeError) as ei:
-        extract_many_sharded(jobs, 2, backend="gloo", classify="sharded_cpu_classify:classify", timeout=300)
+        extract_many_sharded(jobs, 2, backend="gloo", body="sharded_cpu_classify:body", timeout=300)
     assert "rank" in str(ei.value) and "missing.vcf" in str(ei.value)
+
+
+def _bundle(root):
+    from test_tables_workflow import _build_bundle
+    _build_bundle(str(root))
+
+
+def test_workflows_on_two_ranks_write_the_tables_of_one(tmp_path, monkeypatch, oracle, qmlib):
+    """run_hcmv_variantcall / run_vareval with gpus=2 (gloo, the per-rank body injected): VCFs dealt by SAMPLE, so the four
+    compared callers of a sample meet on one rank and its FP overlap is computed there; the three tables
+    (caller_performance.tsv, snpcaller_fp_snp_compare.txt, snpcall_benchmark.txt) are byte-identical to the one-rank run."""
+    from quasimodo_amd import workflow
+    monkeypatch.setenv("PYTHONPATH", os.path.join(ROOT, "tests") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    data = tmp_path / "data" / "snp"
+    _bundle(data)
+    outs = {}
+    for world in (1, 2):
+        out = tmp_path / ("out%d" % world)
+        jobs = workflow.run_hcmv_variantcall(str(data), str(out), gpus=world, _body="sharded_cpu_classify:body", _backend="gloo")
+        assert len(jobs) == 60
+        res = workflow.run_hcmv_variantcall.last_result
+        outs[world] = {n: (out / "results" / "final_tables" / n).read_bytes() for n in ("caller_performance.tsv", "snpcaller_fp_snp_compare.txt")}
+        # whole samples per rank, every rank busy, every sample's overlap from the rank that holds it
+        for r, sh in enumerate(res["shards"]):
+            assert len(sh) > 0 or world == 1
+            smp = {os.path.basename(jobs[i].vcf_file).split(".")[0] for i in sh}
+            for other in res["shards"][r + 1:]:
+                assert not smp & {os.path.basename(jobs[i].vcf_file).split(".")[0] for i in other}
+        assert sorted(s for e in res["extras"] for s in e["overlap"]) == sorted(s for s in workflow.SAMPLE_REF if not s.endswith(("-1-0", "-0-1")))
+    assert outs[1] == outs[2] and len(outs[1]["caller_performance.tsv"].splitlines()) == 61
+    assert len(outs[1]["snpcaller_fp_snp_compare.txt"].splitlines()) == 1 + 6 * 15
+    # vareval
+    cs = [e for e in golden_cases() if e["family"] == "custom"]
+    vcfs = []
+    for e in cs:
+        vcf, truth, _ = read_case(e)
+        p = tmp_path / os.path.basename(e["vcf"])
+        p.write_bytes(vcf)
+        vcfs.append(str(p))
+    snps = tmp_path / "g1_g2.maskrepeat.snps"
+    snps.write_bytes(truth)
+    t = {}
+    for world in (1, 2):
+        workflow.run_vareval(vcfs, str(snps), str(tmp_path / ("v%d" % world)), gpus=world, _body="sharded_cpu_classify:body", _backend="gloo")
+        t[world] = (tmp_path / ("v%d" % world) / "results" / "final_tables" / "snpcall_benchmark.txt").read_bytes()
+    assert t[1] == t[2] and len(t[1].splitlines()) == 1 + len(cs)
+
+
+def test_plan_shards_keeps_groups_together(tmp_path):
+    from quasimodo_amd.extract import Job
+    from quasimodo_amd.multigpu import plan_shards
+    jobs = []
+    for i, n in enumerate([10, 2000, 30, 400, 5, 60, 7000, 80]):
+        p = tmp_path / ("v%d.vcf" % i)
+        p.write_bytes(b"x" * n)
+        jobs.append(Job(str(p), "t"))
+    sh = plan_shards(jobs, 3, groups=[[0, 1], [2, 3, 4], [6]])
+    assert sorted(i for s in sh for i in s) == list(range(8))
+    where = {i: r for r, s in enumerate(sh) for i in s}
+    assert where[0] == where[1] and where[2] == where[3] == where[4]
+    assert plan_shards(jobs, 3) == __import__("quasimodo_amd.sharding", fromlist=["x"]).lpt_shards([10, 2000, 30, 400, 5, 60, 7000, 80], 3)
+    with pytest.raises(ValueError):
+        plan_shards(jobs, 2, groups=[[0, 1], [1, 2]])
 
 
 def test_lpt_shards_properties():

@@ -91,3 +91,51 @@ def test_product_multi_gpu_entry_point_two_ranks_on_this_gpu(tmp_path, qmlib):
         if j.stats.get("roc") is not None:
             want[keys.index(truth_key(j))] += np.asarray(j.stats["roc"]).astype(np.int64)
     assert np.array_equal(res["counters"], want) and want.sum() > 0
+
+
+def test_workflows_on_two_ranks_of_this_gpu_write_what_one_gpu_writes(tmp_path, qmlib, engine):
+    """run_hcmv_variantcall / run_vareval with gpus=2 and the HIP engine on both ranks (one card, gloo for the collective
+    since RCCL refuses two ranks on one GPU): the VCFs dealt by sample, the FP overlap by the rank that holds the sample, the
+    counters all-reduced from the device buffer qm_extract_files_ex filled -- every output file and the three tables byte for
+    byte what the one-GPU workflow writes."""
+    import filecmp
+    from quasimodo_amd import workflow
+    from test_tables_workflow import _build_bundle
+    data = tmp_path / "data" / "snp"
+    _build_bundle(str(data))
+    o1, o2 = tmp_path / "one", tmp_path / "two"
+    jobs1 = workflow.run_hcmv_variantcall(str(data), str(o1), engine=engine)
+    jobs2 = workflow.run_hcmv_variantcall(str(data), str(o2), gpus=2, _backend="gloo", _same_device=True)
+    res = workflow.run_hcmv_variantcall.last_result
+    assert len(jobs1) == len(jobs2) == 60 and all(len(s) > 0 for s in res["shards"])
+    n = 0
+    for root, _, files in os.walk(o1 / "results"):
+        for f in files:
+            a = os.path.join(root, f)
+            b = os.path.join(str(o2 / "results"), os.path.relpath(a, str(o1 / "results")))
+            assert os.path.exists(b) and filecmp.cmp(a, b, shallow=False), a
+            n += 1
+    assert n > 60 * 5
+    for t in ("caller_performance.tsv", "snpcaller_fp_snp_compare.txt"):
+        assert (o2 / "results" / "final_tables" / t).read_bytes() == (o1 / "results" / "final_tables" / t).read_bytes()
+    # the all-reduced counters = the sum of the rows of ALL VCFs, per truth file
+    from quasimodo_amd.multigpu import truth_key
+    keys = res["truth_keys"]
+    want = np.zeros((len(keys), 3, 256), np.int64)
+    for j in jobs2:
+        if j.stats.get("roc") is not None:
+            want[keys.index(truth_key(j))] += np.asarray(j.stats["roc"]).astype(np.int64)
+    assert np.array_equal(res["counters"], want) and want.sum() > 0
+    cs = [e for e in golden_cases() if e["family"] == "custom"]
+    vcfs = []
+    for e in cs:
+        vcf, truth, _ = read_case(e)
+        p = tmp_path / os.path.basename(e["vcf"])
+        p.write_bytes(vcf)
+        vcfs.append(str(p))
+    snps = tmp_path / "g1_g2.maskrepeat.snps"
+    snps.write_bytes(truth)
+    workflow.run_vareval(vcfs, str(snps), str(tmp_path / "v1"), engine=engine)
+    workflow.run_vareval(vcfs, str(snps), str(tmp_path / "v2"), gpus=2, _backend="gloo", _same_device=True)
+    assert (tmp_path / "v2" / "results" / "final_tables" / "snpcall_benchmark.txt").read_bytes() == \
+           (tmp_path / "v1" / "results" / "final_tables" / "snpcall_benchmark.txt").read_bytes()
