@@ -210,15 +210,24 @@ def main():
         k1_s = step_s
         roof_kernel = "whole step (optimistic pass + radix-sort path + packed k_classify)"
     achieved = alg_bytes / k1_s / 1e9 if k1_s > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")   # HBM bytes per launch from a separate --pmc pass
+    # HBM bytes per launch come from a SEPARATE --pmc pass (rocprofv3 cannot count inside this run): profiles/traffic.json, written
+    # by tools/pmc_to_profiles.py together with the id of the device code it profiled.  The figure is quoted only for the very
+    # same device code and workload; otherwise `traffic` is null and `traffic_note` says why.
+    traffic, traffic_build, traffic_note = None, None, "no profiles/traffic.json"
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("vcfs") == n_vcf and tj.get("records") == P["records"] and not args.shuffled and not alleles:
+            traffic_build = tj.get("kernels_build")
+            if args.shuffled or alleles or tj.get("vcfs") != n_vcf or tj.get("records") != P["records"]:
+                traffic_note = "the PMC pass measured another workload (%s VCFs x %s records, sorted, single-base)" % (tj.get("vcfs"), tj.get("records"))
+            elif traffic_build != q.kernel_source_id():
+                traffic_note = "stale: the PMC pass ran on device code %s, this is %s" % (traffic_build, q.kernel_source_id())
+            else:
                 traffic = tj.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+                traffic_note = "rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of k_classify, separate passes on this device code (tools/prof_pmc.sh)"
+        except Exception as e:
+            traffic, traffic_note = None, "unreadable profiles/traffic.json: %s" % str(e)[:80]
 
     workload = "%s%s: %d VCFs x %d %s per GPU, %d bp reference, %d truth keys%s, %d-threshold ROC%s" % (
         P["name"], " (custom shape)" if custom else "", n_vcf, P["records"], "mixed SNP + indel records" if alleles else "SNPs",
@@ -242,7 +251,8 @@ def main():
                    "collective": "1 all-reduce of [%d x 3 x %d] int64 per step" % (batch.n_truth, args.bins) if world > 1 else "none",
                    "vcfs_checked_against_oracle_per_rank": checked},
         "roofline": {"bound": "hbm", "kernel": roof_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_build": traffic_build, "traffic_note": traffic_note,
+                     "kernels_build": q.kernel_source_id(),
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k1_s * 1e3,
                      # SURVEY 8d's own formula over the WHOLE step: 18.2 B x classifications/s / peak
                      "step_frac": alg_bytes / step_s / 1e9 / HBM_PEAK_GBS},
@@ -329,11 +339,12 @@ def shuffled_variant(eng, tid, P, bins, nv, tseed, sorted_roc):
         b.finish()
     dt = time.perf_counter() - t0
     ok = bool(np.array_equal(b.roc(), sorted_roc[:nv])) and int(b.scalars()[:, 5].sum()) == 0
+    paths = b.path_stats()
     b.close()
     return {"value": nv * float(P["records"]) * steps / dt, "unit": "classifications/s", "vcfs": nv, "steps": steps,
-            "ms_per_step": dt / steps * 1e3, "roc_equals_sorted_variant": ok,
-            "note": "records permuted: optimistic pass (stops early) + bucket path (one scatter pass into 256 position buckets per VCF, k_classify_hash: filters and "
-                    "sets in LDS, no sort inside a bucket, TP bits straight into the input-order mask); VCFs too large for the buckets take the batched LSD radix sort"}
+            "ms_per_step": dt / steps * 1e3, "roc_equals_sorted_variant": ok, "paths": paths,
+            "note": "records permuted: optimistic pass (stops early) + bucket path (one scatter pass into 256 position buckets per VCF, k_join_direct: one bit per "
+                    "key of the bucket in LDS, no sort and no hashing inside a bucket, TP bits straight into the input-order mask); `paths` says where the VCFs went"}
 
 
 def alleles_variant(eng, P, bins, nv):

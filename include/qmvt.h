@@ -211,6 +211,19 @@ int qm_batch_get_scalars(qm_batch* b, int64_t* out /*[n_vcf][QM_N_SCALARS]*/);
 int qm_batch_get_global(qm_batch* b, uint64_t* out /*[qm_batch_n_truth(b)][3][n_bins]*/);
 int qm_batch_get_columns(qm_batch* b, int vcf, int32_t* pos, int32_t* ref, int32_t* alt, float* qual,
                          uint8_t* flags);
+/* Where the VCFs that the last qm_batch_finish found out of order went (a sorted batch reports zeros).  The bucket path
+ * has capacity limits (a bucket's records, the truth keys of its positions, the VCF's size); a VCF beyond them is redone by
+ * the radix sort -- correct, several times slower -- and these counters say how often that happened. */
+enum {
+  QM_PATH_UNSORTED = 0,              /* VCFs found out of order */
+  QM_PATH_DIRECT = 1,                /* ... joined bucket by bucket with one bit per key in LDS (k_join_direct) */
+  QM_PATH_HASHED = 2,                /* ... joined bucket by bucket through hashed tables (k_classify_hash: wide key ranges) */
+  QM_PATH_RADIX = 3,                 /* ... radix-sorted because the bucket path does not take them (size, allele-extended batch) */
+  QM_PATH_RADIX_AFTER_OVERFLOW = 4,  /* ... radix-sorted after a bucket of their chunk overflowed */
+  QM_PATH_BUCKET_CHUNKS = 5, QM_PATH_OVERFLOW_CHUNKS = 6, QM_PATH_RADIX_CHUNKS = 7,
+  QM_N_PATH_STATS = 8
+};
+int qm_batch_path_stats(qm_batch* b, int64_t* out /*[QM_N_PATH_STATS]*/);
 /* Device address of the per-truth sums of the last run ([qm_batch_n_truth(b)][3][n_bins] uint64; the caller's global_dev when
  * qm_batch_run was given one): valid until the batch runs again or is destroyed.  For callers that hand the counters to a
  * collective without a trip through the host. */

@@ -1,6 +1,7 @@
-"""numpy restatement of the synthetic-workload generator's truth set
-(quasimodo_amd/csrc/qmvt_dev.h: mix64 / hash3 / synth_truth).  Test infrastructure:
-lets the oracle classify device-generated VCFs without asking the engine for its keys."""
+"""numpy restatement of the synthetic-workload generator (quasimodo_amd/csrc/qmvt_dev.h: mix64 / hash3 /
+synth_truth / synth_record; DESIGN.md section 4.5 is the specification).  Test infrastructure: lets the
+oracle classify device-generated VCFs without asking the engine for its keys, and lets anybody regenerate
+the bench workload -- truth sets AND VCF columns -- from the specification alone (synth_vcf_columns)."""
 import numpy as np
 
 _M = np.uint64(0xFFFFFFFFFFFFFFFF)
@@ -73,3 +74,51 @@ def allele_string(code):
             w = [int(mix64(np.uint64(i * 2 + k))) for k in range(2)]
         return "".join("ACGT"[(w[k // 32] >> (2 * (k % 32))) & 3] for k in range(ln))
     raise ValueError("not an allele code: %d" % code)
+
+
+def synth_perm(n, vcf_sizes=None):
+    """qm_batch_synth's record permutation for shuffled VCFs: slot i of a VCF of n records holds generated record
+    (i * a + 12345) mod n, a = the first odd number >= 2654435761 coprime to the size of EVERY VCF of the batch."""
+    from math import gcd
+    sizes = list(vcf_sizes) if vcf_sizes is not None else [n]
+    a = 2654435761
+    while any(gcd(a, int(m)) != 1 for m in sizes):
+        a += 2
+    i = np.arange(n, dtype=object)
+    return np.array((i * a + 12345) % n, dtype=np.int64)
+
+
+def synth_vcf_columns(L, N, T, tseed, seed, indel_pct=0, shuffled=False, vcf_sizes=None):
+    """qmvt_dev.h synth_record for every record of one VCF: (pos, ref, alt, qual, flags) as the device generates them.
+    Genome 1..L in N strata of width L / N, one record per stratum; the truth set has one entry per stratum of width
+    L / T; a record takes the truth entry that falls into its stratum with probability 0.8, otherwise a random position
+    of its stratum with a random other base; QUAL uniform integer 0..255; ID '.'; PASS iff QUAL >= 20.
+    VCF v of a batch uses seed = (batch seed) + v."""
+    with np.errstate(over="ignore"):
+        u = np.uint64
+        i = np.arange(N, dtype=np.uint64)
+        w, wt = u(L // N), u(L // T)
+        s0 = i * w + u(1)
+        j = (s0 - u(1)) // wt
+        tp, tr, ta = synth_truth_keys(L, T, tseed, indel_pct)
+        jj = np.minimum(j, u(T - 1)).astype(np.int64)
+        tpj = tp[jj].astype(np.uint64)
+        take = (j < u(T)) & (tpj >= s0) & (tpj < s0 + w) & ((hash3(seed, i, u(10)) % u(10)) < u(8))
+        pp = s0 + hash3(seed, i, u(11)) % w
+        rr = hash3(3, pp, u(0)) & u(3)
+        aa = (rr + u(1) + hash3(seed, i, u(12)) % u(3)) & u(3)
+        rr, aa = rr.astype(np.int32), aa.astype(np.int32)
+        if indel_pct > 0:
+            ind = (hash3(seed, i, u(14)) % u(100)).astype(np.int64) < indel_pct
+            rr = np.where(ind, synth_allele(hash3(seed, i, u(15)), 1), rr)
+            aa = np.where(ind, synth_allele(hash3(seed, i, u(16)), 2), aa)
+        pos = np.where(take, tpj, pp).astype(np.int32)
+        ref = np.where(take, tr[jj], rr).astype(np.int32)
+        alt = np.where(take, ta[jj], aa).astype(np.int32)
+        qi = (hash3(seed, i, u(13)) & u(255)).astype(np.int64)
+        qual = qi.astype(np.float32)
+        flags = (2 | (qi >= 20)).astype(np.uint8)
+    if shuffled:
+        p = synth_perm(N, vcf_sizes)
+        pos, ref, alt, qual, flags = pos[p], ref[p], alt[p], qual[p], flags[p]
+    return pos, ref, alt, qual, flags

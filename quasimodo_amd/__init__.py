@@ -5,7 +5,7 @@ Drop-in for the TP/FP classification path of hzi-bifo/Quasimodo
 a Python host over a ctypes C ABI (include/qmvt.h) into libqmvt.so, whose HIP
 kernels run on gfx950.  There is no CPU fallback for the classification.
 """
-from ._lib import QmvtError, build_library, library_path  # noqa: F401
+from ._lib import QmvtError, build_library, kernel_source_id, library_path  # noqa: F401
 from .engine import Batch, Engine  # noqa: F401
 from .vcfio import ScannedVcf, TruthKeys, scan_truth, scan_vcf  # noqa: F401
 from .extract import (  # noqa: F401

@@ -24,7 +24,7 @@ EXPORTS = (
     "qm_truth_size_ext", "qm_truth_synth_ext", "qm_batch_create_ext", "qm_classify_batch_ext",
     "qm_dict_create", "qm_dict_destroy", "qm_dict_size", "qm_allele_code", "qm_allele_spell", "qm_vcf_scan_ext", "qm_truth_scan_ext",
     "qm_bench_synth", "qm_truth_release", "qm_batch_n_truth",
-    "qm_bw_probe", "qm_bgzf_write", "qm_extract_files", "qm_extract_files_ex", "qm_batch_global_device", "qm_batch_upload_async", "qm_batch_get_masks", "qm_patterns_create", "qm_patterns_destroy", "qm_patterns_info", "qm_vcf_hostpath",
+    "qm_bw_probe", "qm_bgzf_write", "qm_extract_files", "qm_extract_files_ex", "qm_batch_global_device", "qm_batch_path_stats", "qm_batch_upload_async", "qm_batch_get_masks", "qm_patterns_create", "qm_patterns_destroy", "qm_patterns_info", "qm_vcf_hostpath",
 )
 
 
@@ -62,6 +62,17 @@ class VcfCols(C.Structure):
 
 def library_path():
     return _SO
+
+
+def kernel_source_id():
+    """sha256 (first 16 hex digits) of the device code's sources: what a profile of the kernels belongs to (profiles/traffic.json
+    carries the id of the build its PMC passes ran on; bench.py quotes that traffic only for the same id)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("qmvt_kernels.hip", "qmvt_dev.h"):
+        with open(os.path.join(_CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def build_library(force=False):
@@ -144,6 +155,7 @@ def lib():
     L.qm_extract_files.argtypes = [vp, i32, C.POINTER(FileJob), i32, C.c_uint, i32, C.POINTER(FileStats), vp, C.POINTER(C.c_double)]
     L.qm_extract_files_ex.argtypes = [vp, i32, C.POINTER(FileJob), i32, C.c_uint, i32, C.POINTER(FileStats), vp, C.POINTER(C.c_double), vp, i32, vp]
     L.qm_batch_global_device.argtypes = [vp, C.POINTER(vp)]
+    L.qm_batch_path_stats.argtypes = [vp, vp]
     L.qm_batch_upload_async.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
     L.qm_batch_get_masks.argtypes = [vp, i32, vp, vp]
     L.qm_bgzf_write.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, i32]

@@ -423,6 +423,8 @@ struct qm_batch {
   // that qm_batch_finish reads the per-VCF flags back only then
   uint32_t* h_summary = nullptr;
   uint32_t* d_summary = nullptr;
+  // where the unsorted VCFs of the last qm_batch_finish went (qm_batch_path_stats)
+  int64_t path_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 static void batch_free(qm_batch* b) {
@@ -1030,14 +1032,21 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
       if (hfl[(size_t)i] & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", vs[(size_t)i]);
       overflow = overflow || (hfl[(size_t)i] & SPANF_OVERFLOW);
     }
+    b->path_stats[QM_PATH_BUCKET_CHUNKS] += 1;
     if (!overflow) {
+      b->path_stats[direct ? QM_PATH_DIRECT : QM_PATH_HASHED] += nseg;
       launch_sort_copy_rows(b->d_segs, nseg, s->roc, s->scalars, b->roc, b->scalars, b->n_bins, st, global, b->d_vcfs);
       launch_tile_counts(b->d_segs, b->d_ktile_seg, b->d_ktile_local, nkt, b->mask_pass, b->mask_tp, b->tile_tp, b->tile_fp, st);
       HIPCHK(hipGetLastError());
       return QM_OK;   // no wait: the rescan that follows is on the same stream and ends with one
     }
     // a bucket did not fit its tables (dense positions, a dense truth set): the radix sort redoes the chunk from the columns
+    b->path_stats[QM_PATH_OVERFLOW_CHUNKS] += 1;
+    b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += nseg;
+  } else {
+    b->path_stats[QM_PATH_RADIX] += nseg;
   }
+  b->path_stats[QM_PATH_RADIX_CHUNKS] += 1;
   // --- 1. + 2. stable LSD radix sort by position (key bits 4..31), only the digits in use.  The first pass packs the
   //        records to (key, info, original index) on the fly; the last pass drops keys and infos straight into the
   //        scratch batch.  (Its ping-pong arrays exist only once a chunk has come this way.)
@@ -1114,6 +1123,8 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
       return fail(QM_E_LIMIT, "VCF %d repeats one position more than %d times between equal alleles (allele-extended de-duplication limit)", v, 1 << 14);
     if (fl[(size_t)v] & SPANF_UNSORTED) todo.push_back(v);
   }
+  for (auto& x : b->path_stats) x = 0;
+  b->path_stats[QM_PATH_UNSORTED] = (int64_t)todo.size();
   if (!todo.empty()) {
     HIPCHK(hipMemcpy(posor.data(), b->vcf_posor, 4 * posor.size(), hipMemcpyDeviceToHost));
     // the VCFs the bucket path takes (by size: a VCF costs it 256 workgroups and 256 rows whatever it holds, and its
@@ -1222,6 +1233,12 @@ extern "C" int qm_batch_get_global(qm_batch* b, uint64_t* out) {
   NEED_FINISHED(b, "qm_batch_get_global");
   HIPCHK(hipSetDevice(b->ctx->dev));
   HIPCHK(hipMemcpy(out, b->last_global, (size_t)b->n_truth * 3 * (size_t)b->n_bins * 8, hipMemcpyDeviceToHost));
+  return QM_OK;
+}
+extern "C" int qm_batch_path_stats(qm_batch* b, int64_t* out) {
+  NEED_FINISHED(b, "qm_batch_path_stats");
+  if (!out) return fail(QM_E_INVAL, "qm_batch_path_stats: NULL");
+  memcpy(out, b->path_stats, sizeof b->path_stats);
   return QM_OK;
 }
 extern "C" int qm_batch_global_device(qm_batch* b, void** dev) {

@@ -282,6 +282,13 @@ class Batch:
         self._ck(self._L.qm_batch_get_columns(self._h, int(v), _p(pos), _p(ref), _p(alt), _p(qual), _p(flags)))
         return pos, ref, alt, qual, flags
 
+    def path_stats(self):
+        """qm_batch_path_stats: where the VCFs the last finish found out of order went"""
+        out = np.zeros(8, np.int64)
+        self._ck(self._L.qm_batch_path_stats(self._h, _p(out)))
+        return dict(zip(("unsorted", "bucket_direct", "bucket_hashed", "radix", "radix_after_overflow", "bucket_chunks", "overflow_chunks",
+                         "radix_chunks"), (int(x) for x in out)))
+
     @property
     def device_bytes(self):
         return int(self._L.qm_batch_device_bytes(self._h))

@@ -750,3 +750,22 @@ def test_many_small_unsorted_vcfs_and_a_few_large_ones(engine, oracle):
             check_vcf(oracle, r, c, truth)
     assert np.array_equal(glob[tid], want)
     engine.truth_release(tid)
+
+
+@pytest.mark.parametrize("shuffled,pct", [(False, 0), (True, 0), (False, 30)], ids=["sorted", "shuffled", "indels"])
+def test_synthetic_workload_is_what_the_specification_says(engine, shuffled, pct):
+    """DESIGN.md section 4.5 is THE definition of the bench workload: oracle/synth.py restates it in numpy, and the columns the
+    device generates (qm_batch_synth) equal that restatement record for record -- a third party can regenerate the
+    workload of the bench line from the text alone."""
+    from oracle.synth import synth_vcf_columns
+    L, T, N = 5_000_000, 100_000, 1_000_000
+    tid = engine.truth_synth(L, T, 3, indel_pct=pct)
+    b = engine.batch([N, N // 2, N], [tid] * 3, alleles=pct > 0)
+    b.synth(L, T, 3, 3000, shuffled=shuffled, indel_pct=pct)
+    for v, n in ((0, N), (1, N // 2), (2, N)):
+        want = synth_vcf_columns(L, n, T, 3, 3000 + v, indel_pct=pct, shuffled=shuffled, vcf_sizes=[N, N // 2, N])
+        got = b.columns(v)
+        for k, (g, w) in enumerate(zip(got, want)):
+            assert np.array_equal(g, w), (v, k)
+    b.close()
+    engine.truth_release(tid)
