@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--shuffled", action="store_true", help="records permuted: every VCF takes the path of the unsorted ones (buckets, radix sort behind them)")
     ap.add_argument("--shuffled-vcfs", type=int, default=int(os.environ.get("QM_BENCH_SHUFFLED_VCFS", "256")),
                     help="also time the shuffled variant (bucket path) on this many VCFs at N=1, config 2; 0 disables")
+    ap.add_argument("--shuffled3-vcfs", type=int, default=int(os.environ.get("QM_BENCH_SHUFFLED3_VCFS", "16")),
+                    help="also time shuffled VCFs of configs[3]'s shape (10 M records on a 50 Mb reference: the two-level bucket path) on this many VCFs at N=1, config 2; 0 disables")
     ap.add_argument("--alleles-vcfs", type=int, default=int(os.environ.get("QM_BENCH_ALLELES_VCFS", "1000")),
                     help="also time the allele-extended variant (config 4's record shape) on this many VCFs at N=1, config 2; 0 disables")
     ap.add_argument("--check-vcfs", type=int, default=2, help="VCFs of this rank's batch checked against the oracle after the timed region (N > 1 and configs 3 / 4)")
@@ -279,6 +281,8 @@ def main():
             out["cpu_baseline_shell"] = {"error": str(e)[:200]}
     if side and args.config == 2 and not custom and not args.shuffled and args.shuffled_vcfs > 0:
         out["shuffled_variant"] = shuffled_variant(eng, tids[0], P, args.bins, min(args.shuffled_vcfs, n_vcf), tseeds[0], roc)
+    if side and args.config == 2 and not custom and not args.shuffled and args.shuffled3_vcfs > 0:
+        out["shuffled_config3_variant"] = shuffled_config3_variant(eng, args.bins, args.shuffled3_vcfs)
     if side and args.config == 2 and not custom and not args.shuffled and args.alleles_vcfs > 0:
         out["alleles_variant"] = alleles_variant(eng, P, args.bins, min(args.alleles_vcfs, n_vcf))
     if rank == 0:
@@ -345,6 +349,39 @@ def shuffled_variant(eng, tid, P, bins, nv, tseed, sorted_roc):
             "ms_per_step": dt / steps * 1e3, "roc_equals_sorted_variant": ok, "paths": paths,
             "note": "records permuted: optimistic pass (stops early) + bucket path (one scatter pass into 256 position buckets per VCF, k_join_direct: one bit per "
                     "key of the bucket in LDS, no sort and no hashing inside a bucket, TP bits straight into the input-order mask); `paths` says where the VCFs went"}
+
+
+def shuffled_config3_variant(eng, bins, nv):
+    """configs[3]'s VCF shape (10 M records, 50 Mb reference, 10^6 truth keys) with the records permuted: too large for 256
+    buckets of 8 192 records, so the VCFs take the two-level bucket path (a first scatter into partitions of 2^27 keys sized
+    by a counting pass, then the one-level path per partition).  A side measurement; the counters must equal those of the
+    same VCFs in position order."""
+    import numpy as np
+    import torch
+    P3 = PRESETS[3]
+    tid = eng.truth_synth(P3["genome"], P3["truth"], P3["truth_seeds"][0])
+    rocs = {}
+    for shuffled in (False, True):
+        b = eng.batch([P3["records"]] * nv, [tid] * nv, n_bins=bins)
+        b.synth(P3["genome"], P3["truth"], P3["truth_seeds"][0], P3["seed"], shuffled=shuffled)
+        b.run(); b.finish()
+        if shuffled:
+            torch.cuda.synchronize()
+            steps = 3
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                b.run()
+                b.finish()
+            dt = time.perf_counter() - t0
+            paths = b.path_stats()
+        rocs[shuffled] = (b.roc(), b.scalars()[:, :5].copy())
+        b.close()
+    eng.truth_release(tid)
+    ok = bool(np.array_equal(rocs[True][0], rocs[False][0]) and np.array_equal(rocs[True][1], rocs[False][1]))
+    return {"value": nv * float(P3["records"]) * steps / dt, "unit": "classifications/s", "vcfs": nv, "records_per_vcf": P3["records"], "steps": steps,
+            "ms_per_step": dt / steps * 1e3, "equals_sorted_variant": ok, "paths": paths,
+            "note": "10 M-record VCFs permuted: k_part_hist + k_part_scatter (level 1: partitions of 2^27 keys, exact regions), then k_bucket_scatter from the "
+                    "level-1 entries and k_join_direct per partition"}
 
 
 def alleles_variant(eng, P, bins, nv):

@@ -221,7 +221,8 @@ enum {
   QM_PATH_RADIX = 3,                 /* ... radix-sorted because the bucket path does not take them (size, allele-extended batch) */
   QM_PATH_RADIX_AFTER_OVERFLOW = 4,  /* ... radix-sorted after a bucket of their chunk overflowed */
   QM_PATH_BUCKET_CHUNKS = 5, QM_PATH_OVERFLOW_CHUNKS = 6, QM_PATH_RADIX_CHUNKS = 7,
-  QM_N_PATH_STATS = 8
+  QM_PATH_DIRECT2 = 8,               /* ... too large for 256 buckets: dealt to partitions of 2^27 keys first, then as QM_PATH_DIRECT */
+  QM_N_PATH_STATS = 9
 };
 int qm_batch_path_stats(qm_batch* b, int64_t* out /*[QM_N_PATH_STATS]*/);
 /* Device address of the per-truth sums of the last run ([qm_batch_n_truth(b)][3][n_bins] uint64; the caller's global_dev when

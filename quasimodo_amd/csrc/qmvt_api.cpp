@@ -377,6 +377,24 @@ struct qm_batch {
   int64_t cap_bk_ent = 0, cap_bk_cursor = 0, cap_bk_tiles = 0;
   bool bk_tiles_valid = false;      // d_bk_tile_seg holds the tile map of last_segs
   bool bk_fake_valid = false;       // d_bk_vcfs holds the row descriptors of last_segs
+  // rows (ROC, scalars, flags) of the VCFs a bucket chunk redoes, before they are copied under the original VCFs
+  uint64_t* bk_roc = nullptr;
+  int64_t* bk_rscal = nullptr;
+  uint32_t* bk_vflags = nullptr;
+  int64_t cap_bk_roc = 0, cap_bk_rscal = 0, cap_bk_vflags = 0;
+  // two-level bucket path (large VCFs): level-1 descriptors, counts, offsets, cursors, entries; VCF-level segment table
+  PartSeg* p_segs = nullptr;
+  int32_t* p_tile_seg = nullptr;
+  uint32_t *p_cnt = nullptr, *p_off = nullptr, *p_cursor = nullptr, *p_flags = nullptr;
+  uint64_t* p_ent = nullptr;
+  SortSeg* d_vsegs = nullptr;
+  int32_t* d_vparts = nullptr;          // partitions in use per VCF
+  int64_t cap_vparts = 0;
+  std::vector<int> last2_vs;            // the chunk these tables were built for, and its counts: a batch run again with the same
+  std::vector<uint32_t> last2_cnt;      // VCFs out of order keeps them on the device (as last_segs does on the one-level path)
+  int last2_nseg = 0;
+  int64_t last2_nbt = 0, last2_nkt = 0;
+  int64_t cap_p_segs = 0, cap_p_tiles = 0, cap_p_cnt = 0, cap_p_off = 0, cap_p_cursor = 0, cap_p_flags = 0, cap_p_ent = 0, cap_vsegs = 0;
   // throw-away outputs of the rescan after a sort (kept: an allocation per finish costs more than the rescan)
   uint64_t* rs_roc = nullptr;
   int64_t* rs_scal = nullptr;
@@ -424,7 +442,7 @@ struct qm_batch {
   uint32_t* h_summary = nullptr;
   uint32_t* d_summary = nullptr;
   // where the unsorted VCFs of the last qm_batch_finish went (qm_batch_path_stats)
-  int64_t path_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t path_stats[QM_N_PATH_STATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 static void batch_free(qm_batch* b) {
@@ -432,7 +450,7 @@ static void batch_free(qm_batch* b) {
   (void)hipSetDevice(b->ctx->dev);
   if (b->sub) { batch_free(b->sub); b->sub = nullptr; }
   void* ptrs[] = {b->pkey, b->pinf, b->pos, b->ref, b->alt, b->qual, b->flags, b->mask_pass, b->mask_tp, b->idx, b->tile_tp, b->tile_fp,
-                  b->tile_tp_off, b->tile_fp_off, b->span_hist, b->span_scal, b->vcf_flags, b->vcf_posor, b->bk_hist, b->bk_scal, b->d_bk_vcfs, b->bk_ent, b->bk_cursor, b->d_bk_tile_seg, b->bk_rows, b->rs_roc, b->rs_scal, b->rs_flags, b->roc, b->global_acc,
+                  b->tile_tp_off, b->tile_fp_off, b->span_hist, b->span_scal, b->vcf_flags, b->vcf_posor, b->bk_hist, b->bk_scal, b->d_bk_vcfs, b->bk_ent, b->bk_cursor, b->d_bk_tile_seg, b->bk_rows, b->bk_roc, b->bk_rscal, b->bk_vflags, b->p_segs, b->p_tile_seg, b->p_cnt, b->p_off, b->p_cursor, b->p_flags, b->p_ent, b->d_vsegs, b->d_vparts, b->rs_roc, b->rs_scal, b->rs_flags, b->roc, b->global_acc,
                   b->scalars, b->d_vcfs, b->d_spans, b->d_tile_vcf, b->cls_scratch, b->sk[0], b->sk[1], b->sv[0],
                   b->sv[1], b->si[0], b->si[1], b->shist, b->sorbits, b->d_segs, b->d_tile_seg, b->d_ktile_seg, b->d_ktile_local};
   for (void* p : ptrs) (void)hipFree(p);
@@ -822,12 +840,12 @@ static bool join_hash_forced() {
   return on;
 }
 
-// posor[v]: OR of the positions the optimistic pass saw in VCF v (which position bits are in use)
-static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, const std::vector<uint32_t>& posor, bool buckets) {
+// the scratch batch of a chunk of unsorted VCFs: their sorted copies on the radix path, the rows (ROC, scalars, flags) of every
+// path; rebuilt only when the chunk's shape changes
+static int ensure_sub(qm_batch* b, const std::vector<int>& vs, std::vector<int32_t>& tids) {
   const int nseg = (int)vs.size();
-  // --- scratch batch holding the sorted copies (rebuilt only when the chunk's shape changes)
   std::vector<int64_t> sig((size_t)nseg);
-  std::vector<int32_t> tids((size_t)nseg);
+  tids.assign((size_t)nseg, 0);
   for (int i = 0; i < nseg; ++i) { sig[(size_t)i] = b->L.vcfs[(size_t)vs[(size_t)i]].n; tids[(size_t)i] = b->L.vcfs[(size_t)vs[(size_t)i]].truth; }
   if (!b->sub || b->sub_sig != sig) {
     if (b->sub) { b->dev_bytes -= b->sub->dev_bytes; batch_free(b->sub); b->sub = nullptr; }
@@ -846,15 +864,42 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     int rc = upload_layout(b->sub);
     if (rc != QM_OK) return rc;
   }
-  qm_batch* s = b->sub;
+  return QM_OK;
+}
+
+// the rows of a bucket chunk's VCFs (k_finalize over the buckets' rows writes them; k_sort_copy_rows takes them home): small
+// arrays of their own, so that a bucket chunk needs no scratch batch with room for sorted copies
+static int ensure_bucket_rows(qm_batch* b, int nv) {
+  int rc = regrow(&b->bk_roc, &b->cap_bk_roc, (int64_t)nv * 3 * b->n_bins, &b->dev_bytes);
+  if (rc == QM_OK) rc = regrow(&b->bk_rscal, &b->cap_bk_rscal, (int64_t)nv * 8, &b->dev_bytes);
+  if (rc == QM_OK) rc = regrow(&b->bk_vflags, &b->cap_bk_vflags, (int64_t)nv, &b->dev_bytes);
+  return rc;
+}
+static FinalizeParams bucket_rows_finalize(qm_batch* b) {
+  FinalizeParams F = finalize_params(b, nullptr);   // the rows join the per-truth sums only once no bucket is known to have overflowed
+  F.vcfs = b->d_bk_vcfs; F.span_hist = b->bk_hist; F.span_scal = b->bk_scal; F.vcf_posor = nullptr;
+  F.roc = b->bk_roc; F.scalars = b->bk_rscal; F.vcf_flags = b->bk_vflags;
+  return F;
+}
+
+// posor[v]: OR of the positions the optimistic pass saw in VCF v (which position bits are in use)
+static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, const std::vector<uint32_t>& posor, bool buckets) {
+  const int nseg = (int)vs.size();
+  std::vector<int32_t> tids((size_t)nseg);
+  for (int i = 0; i < nseg; ++i) tids[(size_t)i] = b->L.vcfs[(size_t)vs[(size_t)i]].truth;
+  if (!buckets) {   // the scratch batch of the sorted copies: only the radix sort needs it (a bucket chunk that overflows makes it below)
+    int rc = ensure_sub(b, vs, tids);
+    if (rc != QM_OK) return rc;
+  }
   // --- segment table and tile maps
   std::vector<SortSeg> segs((size_t)nseg);
   std::vector<int> nbk_used((size_t)nseg, HB_BUCKETS);
-  int64_t koff = 0, hoff = 0, bk_ents = 0, nst64 = 0, nkt64 = 0, nbt64 = 0;
+  int64_t koff = 0, hoff = 0, bk_ents = 0, nst64 = 0, nkt64 = 0, nbt64 = 0, dst_off = 0;
   for (int i = 0; i < nseg; ++i) {
     const VcfDesc& d = b->L.vcfs[(size_t)vs[(size_t)i]];
     SortSeg& g = segs[(size_t)i];
-    g.src_off = d.off; g.dst_off = s->L.vcfs[(size_t)i].off; g.koff = koff; g.hoff = hoff; g.n = d.n;
+    g.src_off = d.off; g.dst_off = dst_off; g.koff = koff; g.hoff = hoff; g.n = d.n;   // dst_off: as build_layout lays the scratch batch out
+    dst_off += (d.n + VCF_ALIGN - 1) / VCF_ALIGN * VCF_ALIGN;
     g.tile0 = (int32_t)nst64; g.ntiles = (int32_t)((d.n + SORT_TILE - 1) / SORT_TILE);
     g.main_vcf = vs[(size_t)i]; g.sub_vcf = i; g.main_tile0 = d.tile0;
     {   // bucket path: the shift that makes the top eight key bits in use the bucket number (key = pos << 4 | nibble)
@@ -863,7 +908,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
       while (msb > 0 && !((kor >> msb) & 1u)) --msb;
       g.pad = std::max(4, msb - 7);
       nbk_used[(size_t)i] = (int)(kor >> g.pad) + 1;   // buckets above the VCF's highest position are empty by construction: <= 256
-      g.nbk = std::min(nbk_used[(size_t)i], (int)HB_BUCKETS); g.pad2 = 0;
+      g.nbk = std::min(nbk_used[(size_t)i], (int)HB_BUCKETS); g.key_base = 0u;
       // room per sub-region: between 128 and 256 buckets are in use, a sub-region takes every eighth tile; half as much again on top
       int64_t want = d.n / (128 * HB_SUBS) * 3 / 2 + 16, cap2 = 16;
       while (cap2 < want && cap2 < HB_SUB_MAX) cap2 *= 2;
@@ -915,12 +960,14 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     if (rc == QM_OK) rc = regrow(&b->bk_ent, &b->cap_bk_ent, bk_ents, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_rows, &b->cap_bk_rowdesc, rows, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_cursor, &b->cap_bk_cursor, rows * HB_SUBS + nseg + 32 + 16 * 65, &b->dev_bytes);   // + 32 + 16 * 65: phase clocks of a profiling build
+    if (rc == QM_OK) rc = ensure_bucket_rows(b, nseg);
     if (rc == QM_OK && (int64_t)nbt > b->cap_bk_tiles) {
       b->bk_tiles_valid = false;
       rc = regrow(&b->d_bk_tile_seg, &b->cap_bk_tiles, (int64_t)nbt, &b->dev_bytes);
     }
   }
   if (rc != QM_OK) return rc;
+  b->last2_vs.clear();   // (the two-level path keeps its tables in the same arrays)
   const bool same_tables = b->last_segs.size() == segs.size() && memcmp(b->last_segs.data(), segs.data(), sizeof(SortSeg) * segs.size()) == 0;
   if (!same_tables || (try_buckets && !b->bk_tiles_valid)) {
     build_tile_maps();
@@ -957,7 +1004,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     BucketScatterParams S;
     S.segs = b->d_segs; S.tile_seg = b->d_bk_tile_seg; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
     S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
-    S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0;
+    S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = nullptr;
     HashParams H;
     H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
     H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.seg_base = 0;
@@ -1004,12 +1051,10 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
       HIPCHK(hipEventRecord(b->ev_sync[qm_batch::MAX_CHUNKS + 1], aux));
       HIPCHK(hipStreamWaitEvent(st, b->ev_sync[qm_batch::MAX_CHUNKS + 1], 0));
     }
-    FinalizeParams F = finalize_params(s, nullptr);   // the rows join the per-truth sums only once no bucket is known to have overflowed
-    F.vcfs = b->d_bk_vcfs; F.span_hist = b->bk_hist; F.span_scal = b->bk_scal; F.vcf_posor = nullptr;
-    launch_finalize(F, nseg, st);
+    launch_finalize(bucket_rows_finalize(b), nseg, st);
     HIPCHK(hipGetLastError());
     std::vector<uint32_t> hfl((size_t)nseg);
-    HIPCHK(hipMemcpyAsync(hfl.data(), s->vcf_flags, 4 * hfl.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hfl.data(), b->bk_vflags, 4 * hfl.size(), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));   // also makes the host tables above safe to free
     if (getenv("QM_HB_PROFILE")) {   // kernels built with -DHB_PROFILE: clock ticks per phase, summed over the workgroups
       uint32_t pr[32];
@@ -1035,11 +1080,13 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     b->path_stats[QM_PATH_BUCKET_CHUNKS] += 1;
     if (!overflow) {
       b->path_stats[direct ? QM_PATH_DIRECT : QM_PATH_HASHED] += nseg;
-      launch_sort_copy_rows(b->d_segs, nseg, s->roc, s->scalars, b->roc, b->scalars, b->n_bins, st, global, b->d_vcfs);
+      launch_sort_copy_rows(b->d_segs, nseg, b->bk_roc, b->bk_rscal, b->roc, b->scalars, b->n_bins, st, global, b->d_vcfs);
       launch_tile_counts(b->d_segs, b->d_ktile_seg, b->d_ktile_local, nkt, b->mask_pass, b->mask_tp, b->tile_tp, b->tile_fp, st);
       HIPCHK(hipGetLastError());
       return QM_OK;   // no wait: the rescan that follows is on the same stream and ends with one
     }
+    rc = ensure_sub(b, vs, tids);   // the radix sort needs room for the sorted copies after all
+    if (rc != QM_OK) return rc;
     // a bucket did not fit its tables (dense positions, a dense truth set): the radix sort redoes the chunk from the columns
     b->path_stats[QM_PATH_OVERFLOW_CHUNKS] += 1;
     b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += nseg;
@@ -1047,6 +1094,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     b->path_stats[QM_PATH_RADIX] += nseg;
   }
   b->path_stats[QM_PATH_RADIX_CHUNKS] += 1;
+  qm_batch* s = b->sub;
   // --- 1. + 2. stable LSD radix sort by position (key bits 4..31), only the digits in use.  The first pass packs the
   //        records to (key, info, original index) on the fly; the last pass drops keys and infos straight into the
   //        scratch batch.  (Its ping-pong arrays exist only once a chunk has come this way.)
@@ -1100,6 +1148,192 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   return QM_OK;
 }
 
+// ---- two-level bucket path (qmvt_dev.h): VCFs too large for 256 buckets of 8 192 records ----
+static bool bucket2_takes(const qm_batch* b, int64_t n) {
+  if (b->ext) return false;
+  if (const char* e = getenv("QM_SORT_PATH")) if (strcmp(e, "radix") == 0) return false;
+  if (const char* e = getenv("QM_BUCKET2")) if (atoi(e) == 0) return false;
+  if (join_hash_forced()) return false;
+  if (n > ((int64_t)1 << P2_INDEX_BITS)) return false;
+  if (const char* e = getenv("QM_BUCKET2")) if (atoi(e) == 2) return n > 0;   // tests and tools/gpu_fuzz.py: every unsorted VCF takes the two levels
+  return !bucket_path_takes(b, n) && n >= HB_MIN_RECORDS;
+}
+
+// *taken = false: the chunk is not for this path after all (a partition too dense for its buckets, a bucket overflowed): the
+// caller sends it through the radix sort; nothing the path wrote is kept in that case (the sort rewrites masks, counts and rows)
+static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, bool* taken) {
+  *taken = false;
+  const int nv = (int)vs.size();
+  std::vector<int32_t> tids((size_t)nv);
+  for (int i = 0; i < nv; ++i) tids[(size_t)i] = b->L.vcfs[(size_t)vs[(size_t)i]].truth;
+  int rc = ensure_bucket_rows(b, nv);
+  if (rc != QM_OK) return rc;
+  // --- level 1: descriptors, tile map, counting pass
+  std::vector<PartSeg> ps((size_t)nv);
+  std::vector<int32_t> ptile;
+  int64_t ent_total = 0, nt1 = 0;
+  const bool build1 = b->last2_vs != vs;   // the level-1 tables depend on the chunk's VCFs only
+  for (int i = 0; i < nv; ++i) {
+    const VcfDesc& d = b->L.vcfs[(size_t)vs[(size_t)i]];
+    PartSeg& g = ps[(size_t)i];
+    g.src_off = d.off; g.n = d.n; g.ent_off = ent_total; g.tile0 = (int32_t)nt1; g.main_vcf = vs[(size_t)i];
+    const int64_t t = (d.n + BK_TILE - 1) / BK_TILE;
+    if (build1) ptile.insert(ptile.end(), (size_t)t, (int32_t)i);
+    nt1 += t;
+    ent_total += d.n + 2 * P2_PARTS;   // every partition starts on a 16-byte boundary: at most one entry of padding each
+  }
+  if (nt1 > INT32_MAX) return fail(QM_E_LIMIT, "bucket path: too many tiles");
+  constexpr int NC = P2_PARTS * P2_SUBS;
+  if (rc == QM_OK) rc = regrow(&b->p_segs, &b->cap_p_segs, (int64_t)nv, &b->dev_bytes);
+  if (rc == QM_OK) rc = regrow(&b->p_tile_seg, &b->cap_p_tiles, nt1, &b->dev_bytes);
+  if (rc == QM_OK) rc = regrow(&b->p_cnt, &b->cap_p_cnt, (int64_t)nv * NC, &b->dev_bytes);
+  if (rc == QM_OK) rc = regrow(&b->p_off, &b->cap_p_off, (int64_t)nv * (NC + 1), &b->dev_bytes);
+  if (rc == QM_OK) rc = regrow(&b->p_cursor, &b->cap_p_cursor, (int64_t)nv * NC, &b->dev_bytes);
+  if (rc == QM_OK) rc = regrow(&b->p_flags, &b->cap_p_flags, (int64_t)nv, &b->dev_bytes);
+  if (rc == QM_OK) rc = regrow(&b->p_ent, &b->cap_p_ent, ent_total + 64, &b->dev_bytes);
+  if (rc != QM_OK) return rc;
+  const bool same_vs = b->last2_vs == vs;
+  if (!same_vs) {
+    b->last2_cnt.clear();
+    HIPCHK(hipMemcpyAsync(b->p_segs, ps.data(), sizeof(PartSeg) * ps.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b->p_tile_seg, ptile.data(), 4 * ptile.size(), hipMemcpyHostToDevice, st));
+  }
+  HIPCHK(hipMemsetAsync(b->p_cnt, 0, (size_t)nv * NC * 4, st));
+  HIPCHK(hipMemsetAsync(b->p_cursor, 0, (size_t)nv * NC * 4, st));
+  HIPCHK(hipMemsetAsync(b->p_flags, 0, (size_t)nv * 4, st));
+  PartParams PP;
+  PP.segs = b->p_segs; PP.tile_seg = b->p_tile_seg; PP.pos = b->pos; PP.ref = b->ref; PP.alt = b->alt; PP.qual = b->qual; PP.flags = b->flags;
+  PP.cnt = b->p_cnt; PP.off = b->p_off; PP.cursor = b->p_cursor; PP.segflags = b->p_flags; PP.ent = b->p_ent;
+  PP.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); PP.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp); PP.n_seg = nv; PP.n_bins = b->n_bins;
+  launch_part_hist(PP, (int)nt1, st);
+  std::vector<uint32_t> cnt((size_t)nv * NC), pfl((size_t)nv);
+  HIPCHK(hipMemcpyAsync(cnt.data(), b->p_cnt, 4 * cnt.size(), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(pfl.data(), b->p_flags, 4 * pfl.size(), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));   // (also: the host tables above may go)
+  for (int i = 0; i < nv; ++i)
+    if (pfl[(size_t)i] & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", vs[(size_t)i]);
+  // --- exact regions; one level-2 segment per (VCF, partition in use).  The same VCFs with the same counts as last time (a batch
+  //     run again): every table below is still on the device
+  const bool same_cnt = same_vs && b->last2_cnt == cnt && !b->last2_cnt.empty();
+  if (!same_cnt) {
+  std::vector<uint32_t> off((size_t)nv * (NC + 1));
+  std::vector<SortSeg> segs;
+  std::vector<VcfDesc> fake;
+  std::vector<SortSeg> vsegs((size_t)nv);
+  std::vector<int32_t> bk_tile_seg, ktile_seg, ktile_local, vparts((size_t)nv);
+  int64_t bk_ents = 0, nbt = 0, nkt = 0;
+  b->last2_vs.clear();
+  for (int i = 0; i < nv; ++i) {
+    const VcfDesc& d = b->L.vcfs[(size_t)vs[(size_t)i]];
+    uint32_t run = 0;
+    const int seg0 = (int)segs.size();
+    for (int p = 0; p < P2_PARTS; ++p) {
+      run = (run + 1u) & ~1u;
+      const uint32_t start = run;
+      for (int k = 0; k < P2_SUBS; ++k) { off[(size_t)i * (NC + 1) + (size_t)p * P2_SUBS + k] = run; run += cnt[(size_t)i * NC + (size_t)p * P2_SUBS + k]; }
+      const int64_t np = (int64_t)run - start;
+      if (np == 0) continue;
+      if (np > (int64_t)HB_BUCKETS * HB_MAX_RECORDS * 13 / 16) return QM_OK;   // all 256 buckets of a partition are in use: more than 6 656 records per bucket on average will not fit 8 x 1 024 (not for this path: *taken stays false)
+      SortSeg g;
+      memset(&g, 0, sizeof g);
+      g.src_off = d.off; g.koff = ps[(size_t)i].ent_off + start; g.n = np;
+      g.main_vcf = vs[(size_t)i]; g.sub_vcf = i; g.main_tile0 = d.tile0;
+      g.pad = DJ_MAX_SHIFT; g.nbk = HB_BUCKETS; g.key_base = (uint32_t)p << P2_SHIFT;
+      int64_t want = np / (128 * HB_SUBS) * 3 / 2 + 16, cap2 = 16;
+      while (cap2 < want && cap2 < HB_SUB_MAX) cap2 *= 2;
+      g.bk_cap = (int32_t)cap2; g.bk_off = bk_ents; g.bk_tile0 = (int32_t)nbt;
+      bk_ents += (int64_t)HB_BUCKETS * HB_SUBS * cap2;
+      const int64_t t = (np + BK_TILE - 1) / BK_TILE;
+      bk_tile_seg.insert(bk_tile_seg.end(), (size_t)t, (int32_t)segs.size());
+      nbt += t;
+      // the buckets of a PARTITION as the "spans" of a VCF for k_finalize: one workgroup per partition (one per VCF summed
+      // 1 536 rows by itself); k_sort_copy_rows adds a VCF's partitions up when the rows go home
+      VcfDesc f = VcfDesc();
+      f.off = 0; f.n = np; f.truth = tids[(size_t)i]; f.tile0 = 0; f.ntiles = 0; f.span0 = (int32_t)segs.size() * HB_BUCKETS; f.nspans = HB_BUCKETS; f.pad = 0;
+      fake.push_back(f);
+      segs.push_back(g);
+    }
+    off[(size_t)i * (NC + 1) + NC] = run;
+    SortSeg& vg = vsegs[(size_t)i];
+    memset(&vg, 0, sizeof vg);
+    vg.src_off = d.off; vg.n = d.n; vg.main_vcf = vs[(size_t)i]; vg.sub_vcf = seg0; vg.main_tile0 = d.tile0;
+    vparts[(size_t)i] = (int32_t)segs.size() - seg0;
+    const size_t k0 = ktile_seg.size();
+    ktile_seg.insert(ktile_seg.end(), (size_t)d.ntiles, (int32_t)i);
+    ktile_local.resize(k0 + (size_t)d.ntiles);
+    for (int t = 0; t < d.ntiles; ++t) ktile_local[k0 + (size_t)t] = t;
+    nkt += d.ntiles;
+  }
+  const int nseg = (int)segs.size();
+  if (nbt > INT32_MAX || nkt > INT32_MAX) return fail(QM_E_LIMIT, "bucket path: too many tiles");
+  // --- the arrays of the one-level path, sized for the level-2 segments (its cached tables are gone after this)
+  b->last_segs.clear(); b->bk_tiles_valid = false; b->bk_fake_valid = false;
+  int64_t cap;
+  if (rc == QM_OK) { cap = b->cap_segs; rc = regrow(&b->d_segs, &cap, (int64_t)nseg, &b->dev_bytes); b->cap_segs = (int)cap; }
+  if (rc == QM_OK) rc = regrow(&b->d_vsegs, &b->cap_vsegs, (int64_t)nv, &b->dev_bytes);
+  if (rc == QM_OK) {
+    cap = b->cap_ktiles; rc = regrow(&b->d_ktile_seg, &cap, nkt, &b->dev_bytes);
+    if (rc == QM_OK) { cap = b->cap_ktiles; rc = regrow(&b->d_ktile_local, &cap, nkt, &b->dev_bytes); }
+    if (rc == QM_OK) b->cap_ktiles = std::max(b->cap_ktiles, (int)nkt);
+  }
+  {
+    const int64_t rows = (int64_t)nseg * HB_BUCKETS;
+    int64_t c1 = b->cap_bk_rows * SPAN_HIST_WORDS, c2 = b->cap_bk_rows * 8;
+    if (rc == QM_OK) rc = regrow(&b->bk_hist, &c1, rows * SPAN_HIST_WORDS, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->bk_scal, &c2, rows * 8, &b->dev_bytes);
+    if (rc == QM_OK) b->cap_bk_rows = std::max(b->cap_bk_rows, rows);
+    if (rc == QM_OK) rc = regrow(&b->d_bk_vcfs, &b->cap_bk_vcfs, (int64_t)nseg, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->bk_ent, &b->cap_bk_ent, bk_ents, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->bk_rows, &b->cap_bk_rowdesc, rows, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->bk_cursor, &b->cap_bk_cursor, rows * HB_SUBS + nseg + 32 + 16 * 65, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->d_bk_tile_seg, &b->cap_bk_tiles, nbt, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->d_vparts, &b->cap_vparts, (int64_t)nv, &b->dev_bytes);
+    if (rc == QM_OK) rc = ensure_bucket_rows(b, nseg);
+  }
+  if (rc != QM_OK) return rc;
+  HIPCHK(hipMemcpyAsync(b->p_off, off.data(), 4 * off.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->d_segs, segs.data(), sizeof(SortSeg) * segs.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->d_vsegs, vsegs.data(), sizeof(SortSeg) * vsegs.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->d_bk_tile_seg, bk_tile_seg.data(), 4 * bk_tile_seg.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->d_ktile_seg, ktile_seg.data(), 4 * ktile_seg.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->d_ktile_local, ktile_local.data(), 4 * ktile_local.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->d_bk_vcfs, fake.data(), sizeof(VcfDesc) * fake.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->d_vparts, vparts.data(), 4 * vparts.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));   // the host tables die with this block
+  b->last2_vs = vs; b->last2_cnt = cnt; b->last2_nseg = nseg; b->last2_nbt = nbt; b->last2_nkt = nkt;
+  }   // !same_cnt
+  const int nseg = b->last2_nseg;
+  const int64_t nbt = b->last2_nbt, nkt = b->last2_nkt;
+  const size_t ncur = ((size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg + 32 + 16 * 65) * 4;
+  HIPCHK(hipMemsetAsync(b->bk_cursor, 0, ncur, st));
+  // --- level 1 scatter, then the one-level path over the partitions: rows, scatter from the level-1 entries, join, rows summed per VCF
+  launch_part_scatter(PP, (int)nt1, st);
+  BucketScatterParams S;
+  S.segs = b->d_segs; S.tile_seg = b->d_bk_tile_seg; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
+  S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
+  S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = b->p_ent;
+  HashParams H;
+  H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
+  H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.seg_base = 0;
+  launch_bucket_rows(H, nseg, st);
+  launch_bucket_scatter(S, (int)nbt, st);
+  launch_join_direct(H, nseg, DJ_MAX_SHIFT, HB_BUCKETS, st);
+  launch_finalize(bucket_rows_finalize(b), nseg, st);
+  HIPCHK(hipGetLastError());
+  std::vector<uint32_t> hfl((size_t)nseg);
+  HIPCHK(hipMemcpyAsync(hfl.data(), b->bk_vflags, 4 * hfl.size(), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  b->path_stats[QM_PATH_BUCKET_CHUNKS] += 1;
+  for (int i = 0; i < nseg; ++i)
+    if (hfl[(size_t)i] & SPANF_OVERFLOW) { b->path_stats[QM_PATH_OVERFLOW_CHUNKS] += 1; b->last2_vs.clear(); return QM_OK; }   // a bucket did not fit: the radix sort redoes the chunk
+  launch_sort_copy_rows(b->d_vsegs, nv, b->bk_roc, b->bk_rscal, b->roc, b->scalars, b->n_bins, st, global, b->d_vcfs, b->d_vparts);
+  launch_tile_counts(b->d_vsegs, b->d_ktile_seg, b->d_ktile_local, (int)nkt, b->mask_pass, b->mask_tp, b->tile_tp, b->tile_fp, st);
+  HIPCHK(hipGetLastError());
+  b->path_stats[QM_PATH_DIRECT2] += nv;
+  *taken = true;
+  return QM_OK;
+}
+
 // re-derive tile offsets + compaction for every VCF (cheap: masks only)
 static int rescan_and_compact(qm_batch* b, hipStream_t st);
 
@@ -1129,16 +1363,28 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
     HIPCHK(hipMemcpy(posor.data(), b->vcf_posor, 4 * posor.size(), hipMemcpyDeviceToHost));
     // the VCFs the bucket path takes (by size: a VCF costs it 256 workgroups and 256 rows whatever it holds, and its
     // buckets hold 8 192 records at most) in chunks of their own, the others on the radix sort
-    std::vector<int> part[2];
-    for (int v : todo) part[bucket_path_takes(b, b->L.vcfs[(size_t)v].n) ? 1 : 0].push_back(v);
-    for (int kind = 1; kind >= 0; --kind) {
+    // kind 2: too large for 256 buckets -- two levels (bucket2_chunk); 1: the bucket path; 0: the radix sort
+    std::vector<int> part[3];
+    for (int v : todo) {
+      const int64_t n = b->L.vcfs[(size_t)v].n;
+      const bool force2 = getenv("QM_BUCKET2") && atoi(getenv("QM_BUCKET2")) == 2 && bucket2_takes(b, n);
+      part[force2 ? 2 : bucket_path_takes(b, n) ? 1 : bucket2_takes(b, n) ? 2 : 0].push_back(v);
+    }
+    for (int kind = 2; kind >= 0; --kind) {
       std::vector<int> chunk;
       int64_t chunk_n = 0;
       for (size_t i = 0; i <= part[kind].size(); ++i) {
         const bool flush = i == part[kind].size() || (!chunk.empty() && chunk_n + b->L.vcfs[(size_t)part[kind][i]].n > SORT_CHUNK_RECORDS) ||
-                           (kind == 1 && chunk.size() >= 4096);   // 256 rows of 1.5 KB and >= 1 MB of bucket regions per VCF: bounded per chunk
+                           (kind >= 1 && chunk.size() >= 4096);   // 256 rows of 1.5 KB and >= 1 MB of bucket regions per VCF: bounded per chunk
         if (flush && !chunk.empty()) {
-          int rc = sort_chunk(b, chunk, st, b->last_global, posor, kind == 1);
+          int rc = QM_OK;
+          bool taken = false;
+          if (kind == 2) {
+            rc = bucket2_chunk(b, chunk, st, b->last_global, &taken);
+            if (rc == QM_OK && !taken) { b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += (int64_t)chunk.size(); rc = sort_chunk(b, chunk, st, b->last_global, posor, false); b->path_stats[QM_PATH_RADIX] -= (int64_t)chunk.size(); }
+          } else {
+            rc = sort_chunk(b, chunk, st, b->last_global, posor, kind == 1);
+          }
           if (rc != QM_OK) return rc;
           chunk.clear();
           chunk_n = 0;

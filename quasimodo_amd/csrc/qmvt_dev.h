@@ -164,7 +164,8 @@ struct SortSeg {
   int32_t main_vcf, sub_vcf;
   int32_t main_tile0, pad;   // first K1 tile of the VCF in the main batch; pad: the bucket path's shift (key >> pad = bucket)
   int32_t bk_tile0, bk_cap;  // bucket path: first scatter tile (BK_TILE records) of the segment; entries per sub-region (a power of two)
-  int32_t nbk, pad2;         // bucket path: buckets in use (those above the VCF's highest position hold nothing)
+  int32_t nbk;               // bucket path: buckets in use (those above the VCF's highest position hold nothing)
+  uint32_t key_base;         // two-level path: first key of the segment's partition (0 on the one-level path)
 };
 // bucket path (k_bucket_scatter + k_classify_hash): one workgroup per (segment, bucket of the one scatter pass)
 #ifndef QM_BK_TILE
@@ -182,6 +183,44 @@ constexpr int HB_INDEX_BITS = 21;        // a bucket entry holds the record's in
 constexpr int DJ_MAX_SHIFT = 19;         // k_join_direct: a bucket's key range (2^shift keys) as ONE bit map in LDS, 64 KB at most
 // a bucket entry (8 bytes): key - (bucket << shift) in bits 0..23, info bits 0..11 (bin + 1, PASS, IDDOT, NOKEY) in 24..35,
 // the host-decided TP-line bit in 36, the record's index inside the VCF in 37..57
+// ---- two-level bucket path (VCFs too large for 256 buckets of 8 192 records): a first scatter deals the records of a VCF to
+// the <= 32 PARTITIONS of 2^27 keys (= 256 buckets of 2^19 keys, the widest k_join_direct takes) its positions reach, into
+// regions sized exactly by a counting pass; every partition then is a segment of the one-level path, read from the level-1
+// entries instead of the columns.
+constexpr int P2_SHIFT = DJ_MAX_SHIFT + 8;    // 27
+constexpr int P2_PARTS = 32;                  // 2^32 keys / 2^27
+constexpr int P2_SUBS = 8;                    // sub-regions of a partition: tile g of the launch fills sub-region g % 8 (one per XCD), each with a cursor
+constexpr int P2_INDEX_BITS = 24;             // a level-1 entry holds the record's index inside its VCF
+constexpr uint32_t P2_DEAD = 0x1fffu;         // info of a record that takes no part (it travels so that the counting pass can count by position alone)
+// a level-1 entry (8 bytes): key & (2^27 - 1) in bits 0..26, info (12 bits + the host-decided TP-line bit) in 27..39, index in 40..63
+struct PartSeg {
+  int64_t src_off;   // first record of the VCF in the main batch
+  int64_t n;
+  int64_t ent_off;   // first level-1 entry of the VCF
+  int32_t tile0;     // first level-1 tile (BK_TILE records) of the VCF in the launch
+  int32_t main_vcf;
+};
+struct PartParams {
+  const PartSeg* segs;
+  const int32_t* tile_seg;
+  const int32_t* pos;
+  const int32_t* ref;
+  const int32_t* alt;
+  const float* qual;
+  const uint8_t* flags;
+  uint32_t* cnt;              // [n_seg][P2_PARTS * P2_SUBS] records per (partition, sub-region): the counting pass
+  const uint32_t* off;        // [n_seg][P2_PARTS * P2_SUBS + 1] where each sub-region starts (entries from ent_off): the host's prefix sums
+  uint32_t* cursor;           // [n_seg][P2_PARTS * P2_SUBS] entries written so far; zeroed before the launch
+  uint32_t* segflags;         // [n_seg] SPANF_*
+  uint64_t* ent;
+  uint32_t* mask_pass;        // main batch, as 32-bit words: the kept mask is written here, the TP mask cleared
+  uint32_t* mask_tp;
+  int32_t n_seg;
+  int32_t n_bins;
+};
+void launch_part_hist(const PartParams& P, int ntiles, hipStream_t st);
+void launch_part_scatter(const PartParams& P, int ntiles, hipStream_t st);
+
 struct BucketScatterParams {
   const SortSeg* segs;
   const int32_t* tile_seg;    // segment of every scatter tile
@@ -197,6 +236,7 @@ struct BucketScatterParams {
   int32_t n_seg;
   int32_t n_bins;
   int32_t tile_base;          // first scatter tile of this launch (the chunk is scattered in a few segment ranges)
+  const uint64_t* l1_ent;     // two-level path: the level-1 entries the segments are read from (SortSeg.koff = first entry) instead of the columns
 };
 // everything k_classify_hash needs to know about one (segment, bucket), laid out by k_bucket_rows before it runs: the
 // workgroup of a bucket lives only a few microseconds, and every dependent load on its way to the data (segment table ->
@@ -207,8 +247,8 @@ struct HashRow {
   int64_t src_off;            // first record of the VCF in the main batch
   int32_t tn;                 // how many
   uint32_t cap;               // entries per sub-region
-  uint32_t shift;             // key >> shift = bucket
-  uint32_t pad;
+  uint32_t shift;             // (key - the segment's key_base) >> shift = bucket
+  uint32_t kbase;             // first key of the bucket
 };
 struct HashParams {
   const SortSeg* segs;
@@ -325,7 +365,7 @@ void launch_synth(const SynthParams& S, int n_vcf, int64_t max_n, hipStream_t st
 void launch_classify_hash(const HashParams& P, int nseg, hipStream_t st);   // segments P.seg_base .. + nseg
 void launch_bucket_rows(const HashParams& P, int nseg, hipStream_t st);
 void launch_join_direct(const HashParams& P, int nseg, int lb, int nbk, hipStream_t st);   // segments P.seg_base .. + nseg, every bucket shift <= lb <= DJ_MAX_SHIFT
-void launch_bucket_scatter(const BucketScatterParams& P, int ntiles, hipStream_t st);   // tiles P.tile_base .. + ntiles
+void launch_bucket_scatter(const BucketScatterParams& P, int ntiles, hipStream_t st);   // tiles P.tile_base .. + ntiles; P.l1_ent: from level-1 entries
 void launch_sort_first_hist(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const int32_t* pos_col, uint32_t* hist, uint32_t* orbits,
                             hipStream_t st);
 void launch_sort_first_scatter(const SortSeg* segs, const int32_t* tile_seg, int nseg, int ntiles, const SortCols& src, int n_bins, int ext,
@@ -341,7 +381,8 @@ void launch_sort_scatter_tp(const SortSeg* segs, const int32_t* tile_seg, int nt
 void launch_tile_counts(const SortSeg* segs, const int32_t* ktile_seg, const int32_t* ktile_local, int nktiles, const uint64_t* mp,
                         const uint64_t* mt, uint32_t* tile_tp, uint32_t* tile_fp, hipStream_t st);
 void launch_sort_copy_rows(const SortSeg* segs, int nseg, const uint64_t* sub_roc, const int64_t* sub_scal, uint64_t* roc,
-                           int64_t* scal, int n_bins, hipStream_t st, uint64_t* global_add = nullptr, const VcfDesc* vcfs = nullptr);
+                           int64_t* scal, int n_bins, hipStream_t st, uint64_t* global_add = nullptr, const VcfDesc* vcfs = nullptr,
+                           const int32_t* nparts = nullptr);
 void launch_bw_probe(int mode, const uint8_t* src, uint8_t* dst, int64_t bytes, uint32_t* sink, hipStream_t st);
 void launch_overlap_pack(const int32_t* pos, const int32_t* ref, const int32_t* alt, const int32_t* set_of, int64_t n,
                          uint32_t* keys, uint32_t* vals, uint32_t* bad, hipStream_t st);

@@ -1483,6 +1483,10 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
 #ifndef BK_WAVES_PER_EU
 #define BK_WAVES_PER_EU 6
 #endif
+// L2: the segment is one partition of a large VCF (two-level path): its records come as level-1 entries (P.l1_ent + sg.koff,
+// sg.n of them, no holes) instead of columns, keys are relative to the partition (sg.key_base), the kept mask was written
+// by the first level.
+template <bool L2>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BK_WAVES_PER_EU, 8))) void k_bucket_scatter(BucketScatterParams P) {
   constexpr int PER = BK_TILE / 512;          // records per thread, in groups of four consecutive ones
   static_assert(BK_TILE % 2048 == 0 && PER >= 4, "whole 16-byte loads, 256 records per wave and group");
@@ -1509,6 +1513,37 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BK_WAVES_PE
   v4i p[PER / 4], r[PER / 4], a[PER / 4];
   v4f q[PER / 4];
   uint32_t f[PER / 4];
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  if (L2) {
+    // level-1 entries -> bucket entries: four per thread and group, two 16-byte loads (the partition's region starts on a
+    // 16-byte boundary and holds sg.n entries without holes; the array is padded past its end)
+#pragma unroll
+    for (int j = 0; j < PER / 4; ++j) {
+      const int64_t i4 = tbase + (int64_t)j * 2048 + tid * 4;
+      v4u e0 = {0u, 0u, 0u, 0u}, e1 = {0u, 0u, 0u, 0u};
+      if (i4 < sg.n) {
+        const v4u* src = reinterpret_cast<const v4u*>(P.l1_ent + sg.koff + i4);
+        e0 = __builtin_nontemporal_load(src);
+        e1 = __builtin_nontemporal_load(src + 1);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = 4 * j + u;
+        const uint32_t lo = u == 0 ? e0[0] : u == 1 ? e0[2] : u == 2 ? e1[0] : e1[2];
+        const uint32_t hi = u == 0 ? e0[1] : u == 1 ? e0[3] : u == 2 ? e1[1] : e1[3];
+        dr[k] = 0xffffffffu;
+        ent[k] = 0ull;
+        const uint32_t v27 = lo & ((1u << P2_SHIFT) - 1u);
+        const uint32_t inf13 = ((lo >> P2_SHIFT) | (hi << (32 - P2_SHIFT))) & 0x1fffu;
+        if (i4 + u < sg.n && inf13 != P2_DEAD) {
+          const uint32_t d = v27 >> shift;   // shift = DJ_MAX_SHIFT here: < 256
+          const uint32_t v = v27 - (d << shift);
+          ent[k] = (uint64_t)v | ((uint64_t)inf13 << 24) | ((uint64_t)(hi >> 8) << 37);
+          dr[k] = (d << 16) | atomicAdd(&s_cnt[d], 1u);
+        }
+      }
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < PER / 4; ++j) {   // all loads first: whole 16-byte pieces, the columns are padded past every VCF
     const int64_t i4 = tbase + (int64_t)j * 2048 + tid * 4;
@@ -1556,6 +1591,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BK_WAVES_PE
       P.mask_tp[(sg.src_off + w0) >> 5] = 0u;
     }
   }
+  }   // !L2
   if (segfl) atomicOr(&P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg], segfl);
   __syncthreads();
   // thread d: exclusive scan over the digit counts = tile-local run starts; room for the run in the bucket's sub-region
@@ -1603,6 +1639,154 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BK_WAVES_PE
     const int32_t w = s_glob[d] + idx;
     if (w < sg.bk_cap) out[((size_t)d * HB_SUBS + sub) * (size_t)sg.bk_cap + (size_t)w] = s_e[idx];   // beyond: the VCF is flagged and redone
   }
+}
+
+// ---------------------------------------------------------------------------
+// Two-level bucket path, first level (VCFs too large for 256 buckets): k_part_hist counts a VCF's records per partition of
+// 2^27 keys (and per sub-region: tile g of the launch counts for, and later fills, sub-region g % 8 -- one cursor per XCD);
+// the host turns the counts into exact regions; k_part_scatter packs every record to a level-1 entry (qmvt_dev.h) and drops
+// it into its partition's region.  EVERY record with a position in range travels, dead ones (alleles that take no part)
+// marked as such, so that the counting pass needs the position column only and the regions have no holes.  The kernel sees
+// the records in input order: it writes the kept mask and clears the TP mask, as k_bucket_scatter does on the one-level path.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_part_hist(PartParams P) {
+  // a tile of a VCF reaches a handful of partitions: sixteen replicas of every counter (one per lane & 15) keep the lanes
+  // of a wave off each other's addresses
+  constexpr int REP = 16;
+  __shared__ uint32_t s_cnt[P2_PARTS * REP];
+  const int bid = (int)blockIdx.x;
+  const int seg = P.tile_seg[bid];
+  const PartSeg sg = P.segs[seg];
+  const int sub = bid & (P2_SUBS - 1);
+  const int tid = (int)threadIdx.x;
+  s_cnt[tid] = 0u;
+  static_assert(P2_PARTS * REP == 512, "one counter per thread");
+  __syncthreads();
+  const int64_t tbase = (int64_t)(bid - sg.tile0) * BK_TILE;
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  uint32_t bad = 0;
+#pragma unroll
+  for (int j = 0; j < BK_TILE / 2048; ++j) {
+    const int64_t i4 = tbase + (int64_t)j * 2048 + tid * 4;
+    if (i4 < sg.n) {
+      const v4i p = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(P.pos + sg.src_off + i4));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (i4 + u < sg.n) {
+          const uint32_t pp = (uint32_t)p[u];
+          if (pp >= (uint32_t)QM_POS_LIMIT_DEV) bad = 1u;
+          else atomicAdd(&s_cnt[(pp >> (P2_SHIFT - 4)) * REP + (tid & (REP - 1))], 1u);
+        }
+      }
+    }
+  }
+  if (ballot64(bad != 0u) && (tid & 63) == 0) atomicOr(&P.segflags[seg], SPANF_BADPOS);
+  __syncthreads();
+  if (tid < P2_PARTS) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < REP; ++r) c += s_cnt[tid * REP + ((r + tid) & (REP - 1))];
+    if (c) atomicAdd(&P.cnt[(size_t)seg * (P2_PARTS * P2_SUBS) + tid * P2_SUBS + sub], c);
+  }
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BK_WAVES_PER_EU, 8))) void k_part_scatter(PartParams P) {
+  constexpr int PER = BK_TILE / 512;
+  __shared__ uint32_t s_cnt[P2_PARTS];
+  __shared__ uint32_t s_loc[P2_PARTS];
+  __shared__ int64_t s_glob[P2_PARTS];        // place of partition d's run in the level-1 array, minus s_loc[d]
+  __shared__ uint32_t s_total;
+  __shared__ uint64_t s_e[BK_TILE];
+  __shared__ uint8_t s_d[BK_TILE];
+  const int bid = (int)blockIdx.x;
+  const int seg = P.tile_seg[bid];
+  const PartSeg sg = P.segs[seg];
+  const int sub = bid & (P2_SUBS - 1);
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  if (tid < P2_PARTS) s_cnt[tid] = 0u;
+  __syncthreads();
+  const int64_t tbase = (int64_t)(bid - sg.tile0) * BK_TILE;
+  uint64_t ent[PER];
+  uint32_t dr[PER];   // partition << 16 | rank inside the tile's partition; 0xffffffff: position out of range (the VCF is refused)
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4i p[PER / 4], r[PER / 4], a[PER / 4];
+  v4f q[PER / 4];
+  uint32_t f[PER / 4];
+#pragma unroll
+  for (int j = 0; j < PER / 4; ++j) {
+    const int64_t i4 = tbase + (int64_t)j * 2048 + tid * 4;
+    f[j] = 0u;
+    if (i4 < sg.n) {
+      const int64_t g = sg.src_off + i4;
+      p[j] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(P.pos + g));
+      r[j] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(P.ref + g));
+      a[j] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(P.alt + g));
+      q[j] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(P.qual + g));
+      f[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(P.flags + g));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PER / 4; ++j) {
+    const int64_t i4 = tbase + (int64_t)j * 2048 + tid * 4;
+    uint32_t kept = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = 4 * j + u;
+      dr[k] = 0xffffffffu;
+      ent[k] = 0ull;
+      if (i4 + u < sg.n) {
+        uint32_t key, inf;
+        pack_record<false>(p[j][u], r[j][u], a[j][u], q[j][u], f[j] >> (8 * u), P.n_bins, key, inf);
+        if (!(inf & I_BADPOS)) {   // (the counting pass has flagged the VCF otherwise)
+          const bool live = (inf & I_LIVE) != 0u;
+          kept |= ((inf >> 16) & 1u) << u;
+          const uint32_t d = key >> P2_SHIFT;
+          const uint32_t inf13 = live ? ((inf & 0xfffu) | ((inf >> 12) & 0x1000u)) : P2_DEAD;
+          ent[k] = (uint64_t)(key & ((1u << P2_SHIFT) - 1u)) | ((uint64_t)inf13 << P2_SHIFT) | ((uint64_t)(uint32_t)(i4 + u) << 40);
+          dr[k] = (d << 16) | atomicAdd(&s_cnt[d], 1u);
+        }
+      }
+    }
+    const uint32_t wp = or_reduce8(kept << (4u * (uint32_t)(lane & 7)));
+    const int64_t w0 = i4 - 4 * (lane & 7);
+    if ((lane & 7) == 7 && w0 < ((sg.n + 255) & ~(int64_t)255)) {
+      P.mask_pass[(sg.src_off + w0) >> 5] = wp;
+      P.mask_tp[(sg.src_off + w0) >> 5] = 0u;
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {   // one wave: exclusive scan over the 32 partition counts, room for each run in its (partition, sub-region)
+    const uint32_t cnt = tid < P2_PARTS ? s_cnt[tid] : 0u;
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_up(incl, o);
+      if (lane >= o) incl += y;
+    }
+    if (tid < P2_PARTS) {
+      const uint32_t loc = incl - cnt;
+      s_loc[tid] = loc;
+      const size_t c = (size_t)seg * (P2_PARTS * P2_SUBS) + (size_t)tid * P2_SUBS + sub;
+      uint32_t g = 0;
+      if (cnt) g = atomicAdd(&P.cursor[c], cnt);
+      s_glob[tid] = sg.ent_off + (int64_t)P.off[(size_t)seg * (P2_PARTS * P2_SUBS + 1) + (size_t)tid * P2_SUBS + sub] + (int64_t)g - (int64_t)loc;
+    }
+    if (tid == P2_PARTS - 1) s_total = incl;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    if (dr[k] != 0xffffffffu) {
+      const uint32_t d = dr[k] >> 16;
+      const uint32_t lp = s_loc[d] + (dr[k] & 0xffffu);
+      s_e[lp] = ent[k];
+      s_d[lp] = (uint8_t)d;
+    }
+  }
+  __syncthreads();
+  const int total = (int)s_total;
+  for (int idx = tid; idx < total; idx += 512) P.ent[s_glob[s_d[idx]] + idx] = s_e[idx];   // the regions are exact: nothing can overflow
 }
 
 // ---------------------------------------------------------------------------
@@ -1654,8 +1838,9 @@ __global__ __launch_bounds__(HB_BUCKETS) void k_bucket_rows(HashParams P) {
   const SortSeg sg = P.segs[blockIdx.x];
   const TruthDev tr = P.truths[P.vcfs[sg.main_vcf].truth];
   const uint32_t d = threadIdx.x, shift = (uint32_t)sg.pad;
-  const uint32_t plo = (d << shift) >> 4;
-  const uint32_t phi = (((d + 1u) << shift) - 1u) >> 4;   // d + 1 = 256 with shift = 24 wraps to 0 - 1: the top of the key space
+  const uint32_t kbase = sg.key_base + (d << shift);       // (two-level path: the segment is one partition of a VCF's key space)
+  const uint32_t plo = kbase >> 4;
+  const uint32_t phi = (kbase + ((1u << shift) - 1u)) >> 4;   // the last bucket of the key space ends at 2^32 - 1: no wrap
   uint32_t ba = plo >> tr.shift, bb = (phi >> tr.shift) + 1u;
   const uint32_t lim = (uint32_t)tr.nb + 1u;
   ba = ba < lim ? ba : lim; bb = bb < lim ? bb : lim;
@@ -1667,7 +1852,7 @@ __global__ __launch_bounds__(HB_BUCKETS) void k_bucket_rows(HashParams P) {
   R.tn = hi - lo;
   R.cap = (uint32_t)sg.bk_cap;
   R.shift = shift;
-  R.pad = 0u;
+  R.kbase = kbase;
   P.rows_out[(size_t)blockIdx.x * HB_BUCKETS + d] = R;
 }
 
@@ -1780,8 +1965,8 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
   };
   fetch(0, 0);
   const uint32_t shift = R.shift;                            // >= 4: a bucket is a whole range of positions
-  const uint32_t kbase = (uint32_t)d << shift;               // every key of the bucket is >= kbase
-  const uint32_t klast = ((uint32_t)(d + 1) << shift) - 1u;  // d + 1 = 256 with shift = 24 wraps to 0 - 1: the top of the key space
+  const uint32_t kbase = R.kbase;                            // every key of the bucket is >= kbase
+  const uint32_t klast = kbase + ((1u << shift) - 1u);
   uint32_t tkey0 = 0u, tkey1 = 0u;
 #ifndef HB_SKIP_TRUTH   // (timing builds only: phases of the kernel switched off, results wrong)
   const int tn = over ? 0 : R.tn;
@@ -2119,8 +2304,8 @@ __global__ __launch_bounds__(DJ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
   }
   over |= R.shift > (uint32_t)LB ? 1u : 0u;                  // (the host never launches this instantiation for such a segment)
   const uint32_t shift = R.shift > (uint32_t)LB ? (uint32_t)LB : R.shift;   // 4 <= shift <= LB: a bucket is a whole range of positions
-  const uint32_t kbase = (uint32_t)d << shift;               // every key of the bucket is >= kbase
-  const uint32_t klast = ((uint32_t)(d + 1) << shift) - 1u;
+  const uint32_t kbase = R.kbase;                            // every key of the bucket is >= kbase
+  const uint32_t klast = kbase + ((1u << shift) - 1u);
   const int tn_all = R.tn;
   over |= tn_all > DJ_TRUTH_MAX ? 1u : 0u;
   const int tn = over ? 0 : tn_all;
@@ -2425,19 +2610,27 @@ __global__ __launch_bounds__(256) void k_tile_counts(const SortSeg* segs, const 
 }
 
 // ROC rows and scalars of the sorted scratch VCFs back under the original VCFs
+// nparts (or null = one each): two-level bucket path -- the rows of a VCF's partitions, sub_vcf .. sub_vcf + nparts - 1, are summed
+// (every count of a row is additive over disjoint ranges of positions; T' is the truth set's, the same in every part)
 __global__ __launch_bounds__(256) void k_sort_copy_rows(const SortSeg* segs, const uint64_t* sub_roc, const int64_t* sub_scal,
-                                                        uint64_t* roc, int64_t* scal, int n_bins, uint64_t* global_add, const VcfDesc* vcfs) {
+                                                        uint64_t* roc, int64_t* scal, int n_bins, uint64_t* global_add, const VcfDesc* vcfs,
+                                                        const int32_t* nparts) {
   const SortSeg sg = segs[blockIdx.x];
   const int n = 3 * n_bins;
+  const int np = nparts ? nparts[blockIdx.x] : 1;
   for (int i = (int)threadIdx.x; i < n; i += 256) {
-    const uint64_t v = sub_roc[(size_t)sg.sub_vcf * n + i];
+    uint64_t v = 0;
+    for (int q = 0; q < np; ++q) v += sub_roc[(size_t)(sg.sub_vcf + q) * n + i];
     roc[(size_t)sg.main_vcf * n + i] = v;
     // bucket path: the rows join the per-truth sums only here, once the host knows no bucket overflowed
     if (global_add && v) atomicAdd(reinterpret_cast<unsigned long long*>(global_add) + (size_t)vcfs[sg.main_vcf].truth * n + i, (unsigned long long)v);
   }
   if (threadIdx.x < 8) {
-    int64_t v = sub_scal[(size_t)sg.sub_vcf * 8 + threadIdx.x];
+    int64_t v = 0;
+    for (int q = 0; q < np; ++q) v += sub_scal[(size_t)(sg.sub_vcf + q) * 8 + threadIdx.x];
     if (threadIdx.x == 5) v = 0;   // QM_S_SORTED: the original was not
+    if (threadIdx.x == 6) v = sg.n;   // QM_S_NREC
+    if (threadIdx.x == 7 && np > 0) v = sub_scal[(size_t)sg.sub_vcf * 8 + 7];   // QM_S_TRUTH
     scal[(size_t)sg.main_vcf * 8 + threadIdx.x] = v;
   }
 }
@@ -2580,8 +2773,8 @@ void launch_tile_counts(const SortSeg* segs, const int32_t* ktile_seg, const int
                        tile_tp, tile_fp);
 }
 void launch_sort_copy_rows(const SortSeg* segs, int nseg, const uint64_t* sub_roc, const int64_t* sub_scal, uint64_t* roc,
-                           int64_t* scal, int n_bins, hipStream_t st, uint64_t* global_add, const VcfDesc* vcfs) {
-  if (nseg > 0) hipLaunchKernelGGL(k_sort_copy_rows, dim3(nseg), dim3(256), 0, st, segs, sub_roc, sub_scal, roc, scal, n_bins, global_add, vcfs);
+                           int64_t* scal, int n_bins, hipStream_t st, uint64_t* global_add, const VcfDesc* vcfs, const int32_t* nparts) {
+  if (nseg > 0) hipLaunchKernelGGL(k_sort_copy_rows, dim3(nseg), dim3(256), 0, st, segs, sub_roc, sub_scal, roc, scal, n_bins, global_add, vcfs, nparts);
 }
 void launch_classify_hash(const HashParams& P, int nseg, hipStream_t st) {
   if (nseg > 0) hipLaunchKernelGGL(k_classify_hash, dim3(HB_BUCKETS, nseg), dim3(HB_THREADS), 0, st, P);
@@ -2598,7 +2791,15 @@ void launch_bucket_rows(const HashParams& P, int nseg, hipStream_t st) {
   if (nseg > 0) hipLaunchKernelGGL(k_bucket_rows, dim3(nseg), dim3(HB_BUCKETS), 0, st, P);
 }
 void launch_bucket_scatter(const BucketScatterParams& P, int ntiles, hipStream_t st) {
-  if (ntiles > 0) hipLaunchKernelGGL(k_bucket_scatter, dim3(ntiles), dim3(512), 0, st, P);
+  if (ntiles <= 0) return;
+  if (P.l1_ent) hipLaunchKernelGGL((k_bucket_scatter<true>), dim3(ntiles), dim3(512), 0, st, P);
+  else hipLaunchKernelGGL((k_bucket_scatter<false>), dim3(ntiles), dim3(512), 0, st, P);
+}
+void launch_part_hist(const PartParams& P, int ntiles, hipStream_t st) {
+  if (ntiles > 0) hipLaunchKernelGGL(k_part_hist, dim3(ntiles), dim3(512), 0, st, P);
+}
+void launch_part_scatter(const PartParams& P, int ntiles, hipStream_t st) {
+  if (ntiles > 0) hipLaunchKernelGGL(k_part_scatter, dim3(ntiles), dim3(512), 0, st, P);
 }
 void launch_overlap_pack(const int32_t* pos, const int32_t* ref, const int32_t* alt, const int32_t* set_of, int64_t n,
                          uint32_t* keys, uint32_t* vals, uint32_t* bad, hipStream_t st) {

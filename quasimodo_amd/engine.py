@@ -284,10 +284,10 @@ class Batch:
 
     def path_stats(self):
         """qm_batch_path_stats: where the VCFs the last finish found out of order went"""
-        out = np.zeros(8, np.int64)
+        out = np.zeros(9, np.int64)
         self._ck(self._L.qm_batch_path_stats(self._h, _p(out)))
         return dict(zip(("unsorted", "bucket_direct", "bucket_hashed", "radix", "radix_after_overflow", "bucket_chunks", "overflow_chunks",
-                         "radix_chunks"), (int(x) for x in out)))
+                         "radix_chunks", "bucket_two_level"), (int(x) for x in out)))
 
     @property
     def device_bytes(self):

@@ -361,3 +361,45 @@ def test_vector_scan_equals_the_line_by_line_rules(qmlib):
     few = b"chr\t7\t.\tA\tG\t50\tPASS\tDP=1\tGT\t.\tA\tG;x\n"
     sv = vcfio.scan_vcf(many + few + b"chr\t8\t.\tA\tG\t50\tPASS\tDP=1\n")
     assert list(sv.line_kind[:3]) == [2, 2, 0]      # QM_LINE_DATA_HOST twice: the text decides, on the host path
+
+
+def test_bgzf_blocks_are_what_htslib_indexes(qmlib, tmp_path):
+    """qm_bgzf_write (the *.vcf.gz the rules declare, rules/vis_eval_vcf.smk:29,36): tabix / htslib address a BGZF file by
+    virtual offsets = (start of a block in the file) << 16 | (offset inside its inflated data), so every block must be a
+    complete gzip member of at most 64 KiB whose 'BC' extra field holds its size - 1, inflating to at most 64 KiB, and the
+    file must end with the 28-byte EOF member.  Walked block by block here, as bgzf_read_block does."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(3)
+    lines = [b"##fileformat=VCFv4.2", b"#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO"]
+    for p in range(1, 20001):
+        lines.append(b"chr1\t%d\t.\t%s\t%s\t%d\tPASS\tDP=%d" % (p * 7, b"ACGT"[p % 4:p % 4 + 1], b"CGTA"[p % 4:p % 4 + 1], int(rng.integers(0, 300)), int(rng.integers(1, 10**6))))
+    data = b"\n".join(lines) + b"\n"
+    assert len(data) > 5 * 0xff00
+    out = tmp_path / "x.vcf.gz"
+    assert qmlib.qm_bgzf_write(str(out).encode(), data, len(data), -1) == 0
+    raw = out.read_bytes()
+    off, got, nblocks, voffsets = 0, [], 0, []
+    while off < len(raw):
+        magic, cm, flg, _, _, _, xlen = struct.unpack_from("<HBBIBBH", raw, off)
+        assert (magic, cm, flg) == (0x8b1f, 8, 4) and xlen == 6
+        si1, si2, slen, bsize = struct.unpack_from("<BBHH", raw, off + 12)
+        assert (si1, si2, slen) == (66, 67, 2)
+        size = bsize + 1
+        assert 28 <= size <= 0x10000 and off + size <= len(raw)
+        body = raw[off + 18:off + size - 8]
+        crc, isize = struct.unpack_from("<II", raw, off + size - 8)
+        inflated = zlib.decompress(body, -15)
+        assert len(inflated) == isize <= 0x10000 and zlib.crc32(inflated) == crc
+        voffsets.append((off << 16, isize))
+        got.append(inflated)
+        off += size
+        nblocks += 1
+    assert b"".join(got) == data and got[-1] == b"" and nblocks == (len(data) + 0xfeff) // 0xff00 + 1
+    # the virtual offset of any byte: block start << 16 | offset in block -- what a .tbi written by `tabix -p vcf` holds
+    pos = data.index(b"chr1\t70007\t")
+    blk, inner = divmod(pos, 0xff00)
+    v = voffsets[blk][0] | inner
+    start = v >> 16
+    bsz = struct.unpack_from("<H", raw, start + 16)[0] + 1
+    assert zlib.decompress(raw[start + 18:start + bsz - 8], -15)[v & 0xffff:].startswith(b"chr1\t70007\t")
