@@ -1481,6 +1481,15 @@ extern "C" int qm_batch_get_global(qm_batch* b, uint64_t* out) {
   HIPCHK(hipMemcpy(out, b->last_global, (size_t)b->n_truth * 3 * (size_t)b->n_bins * 8, hipMemcpyDeviceToHost));
   return QM_OK;
 }
+// dst[i] += src[i] for device arrays (qm_extract_files_ex adds the per-truth sums of its groups into the caller's buffer)
+int qm_device_add_u64(qm_ctx* c, uint64_t* dst, const uint64_t* src, int64_t n) {
+  if (!c || !dst || !src || n < 0) return fail(QM_E_INVAL, "qm_device_add_u64: bad arguments");
+  HIPCHK(hipSetDevice(c->dev));
+  launch_add_u64(dst, src, n, c->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return QM_OK;
+}
 extern "C" int qm_batch_path_stats(qm_batch* b, int64_t* out) {
   NEED_FINISHED(b, "qm_batch_path_stats");
   if (!out) return fail(QM_E_INVAL, "qm_batch_path_stats: NULL");

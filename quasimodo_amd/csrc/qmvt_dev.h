@@ -384,6 +384,7 @@ void launch_sort_copy_rows(const SortSeg* segs, int nseg, const uint64_t* sub_ro
                            int64_t* scal, int n_bins, hipStream_t st, uint64_t* global_add = nullptr, const VcfDesc* vcfs = nullptr,
                            const int32_t* nparts = nullptr);
 void launch_bw_probe(int mode, const uint8_t* src, uint8_t* dst, int64_t bytes, uint32_t* sink, hipStream_t st);
+void launch_add_u64(uint64_t* dst, const uint64_t* src, int64_t n, hipStream_t st);
 void launch_overlap_pack(const int32_t* pos, const int32_t* ref, const int32_t* alt, const int32_t* set_of, int64_t n,
                          uint32_t* keys, uint32_t* vals, uint32_t* bad, hipStream_t st);
 void launch_overlap_count(const uint32_t* keys, const uint32_t* vals, int64_t n, unsigned long long* regions, hipStream_t st);

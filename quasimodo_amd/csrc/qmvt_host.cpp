@@ -24,6 +24,7 @@
 #include <fcntl.h>
 #include <sys/uio.h>
 #include <unistd.h>
+#include <sched.h>
 #include <zlib.h>
 
 #include "../../include/qmvt.h"
@@ -478,8 +479,14 @@ static void scan_chunk(const uint8_t* text, ScanChunk& c, bool count_only, int64
 }
 
 static int host_threads() {
-  const char* e = getenv("QM_HOST_THREADS");
-  int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+  // QM_HOST_THREADS says it; otherwise the CPUs this process may run on (its affinity mask: a container's share of a
+  // large host), at most 32 -- more threads than that gain nothing for the memory traffic of tokenising and writing
+  // (profiles/r03_e2e_threads.log)
+  if (const char* e = getenv("QM_HOST_THREADS")) { const int n = atoi(e); return n < 1 ? 1 : n > 256 ? 256 : n; }
+  int n = 0;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+  if (n < 1) n = (int)std::thread::hardware_concurrency();
   if (n < 1) n = 1;
   return n > 32 ? 32 : n;
 }

@@ -156,6 +156,27 @@ __device__ __forceinline__ void pack_record_fast(int p, int r, int a, float q, u
   inf = live ? (b1 | g) : 0u;
 }
 
+// The allele-extended counterpart (any valid allele code takes part, include/qmvt.h): the same key and info as
+// pack_record<true> for a record whose position is in range.  A code is valid iff it is < 4 or in [0x08000000, 0x80000000),
+// i.e. iff ((c >> 27) - 1) < 15 for the latter; the nibble of a pair that is not two single bases is allele_nib's fold.
+__device__ __forceinline__ void pack_record_fast_ext(int p, int r, int a, float q, uint32_t f4x4, float nbm1f, const uint32_t* flut,
+                                                     uint32_t& key, uint32_t& inf) {
+  const uint32_t ur = (uint32_t)r, ua = (uint32_t)a;
+  const bool single = (ur | ua) < 4u;
+  const bool longs = ((ur < 4u) | (((ur >> 27) - 1u) < 15u)) & ((ua < 4u) | (((ua >> 27) - 1u) < 15u));
+  const bool live = (((uint32_t)p >> 28) == 0u) & (single | longs);
+  uint32_t h = ur ^ __builtin_amdgcn_alignbit(ua, ua, 19);   // rotl(a, 13)
+  h ^= h >> 16;
+  h ^= h >> 8;
+  h ^= h >> 4;
+  const uint32_t nib = single ? ((ur << 2) | ua) : (h & 15u);
+  key = ((uint32_t)p << 4) | (live ? nib : 0u);
+  const float c = fminf(fmaxf(q, -1.0f), nbm1f);            // NaN -> -1
+  const uint32_t b1 = (uint32_t)((int)floorf(c) + 1);
+  const uint32_t g = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(flut) + f4x4);
+  inf = live ? (b1 | g) : 0u;
+}
+
 struct Cols {  // bases of one VCF: the five columns, or the packed pair
   const int32_t* pos;
   const int32_t* ref;
@@ -219,10 +240,22 @@ __device__ __forceinline__ void unpack_raw(const Raw4<false>& R, int nb, In4& X,
     return;
   }
 #endif
+#ifndef QM_NO_FAST_PACK_EXT
+  if (EXT) {
+    const float nbm1f = (float)(nb - 1);
+    pack_record_fast_ext(R.p.x, R.r.x, R.a.x, R.q.x, (R.f << 2) & 0x3cu, nbm1f, flut, X.key[0], X.inf[0]);
+    pack_record_fast_ext(R.p.y, R.r.y, R.a.y, R.q.y, (R.f >> 6) & 0x3cu, nbm1f, flut, X.key[1], X.inf[1]);
+    pack_record_fast_ext(R.p.z, R.r.z, R.a.z, R.q.z, (R.f >> 14) & 0x3cu, nbm1f, flut, X.key[2], X.inf[2]);
+    pack_record_fast_ext(R.p.w, R.r.w, R.a.w, R.q.w, (R.f >> 22) & 0x3cu, nbm1f, flut, X.key[3], X.inf[3]);
+    X.posor = (uint32_t)R.p.x | (uint32_t)R.p.y | (uint32_t)R.p.z | (uint32_t)R.p.w;   // anything at or above bit 28: out of range (SPANF_BADPOS)
+  } else
+#endif
+  {
   pack_record<EXT>(R.p.x, R.r.x, R.a.x, R.q.x, R.f, nb, X.key[0], X.inf[0]);
   pack_record<EXT>(R.p.y, R.r.y, R.a.y, R.q.y, R.f >> 8, nb, X.key[1], X.inf[1]);
   pack_record<EXT>(R.p.z, R.r.z, R.a.z, R.q.z, R.f >> 16, nb, X.key[2], X.inf[2]);
   pack_record<EXT>(R.p.w, R.r.w, R.a.w, R.q.w, R.f >> 24, nb, X.key[3], X.inf[3]);
+  }
   if (EXT) {
     X.r[0] = R.r.x; X.r[1] = R.r.y; X.r[2] = R.r.z; X.r[3] = R.r.w;
     X.a[0] = R.a.x; X.a[1] = R.a.y; X.a[2] = R.a.z; X.a[3] = R.a.w;
@@ -2800,6 +2833,13 @@ void launch_part_hist(const PartParams& P, int ntiles, hipStream_t st) {
 }
 void launch_part_scatter(const PartParams& P, int ntiles, hipStream_t st) {
   if (ntiles > 0) hipLaunchKernelGGL(k_part_scatter, dim3(ntiles), dim3(512), 0, st, P);
+}
+__global__ void k_add_u64(unsigned long long* dst, const unsigned long long* src, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+void launch_add_u64(uint64_t* dst, const uint64_t* src, int64_t n, hipStream_t st) {
+  if (n > 0) hipLaunchKernelGGL(k_add_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (unsigned long long*)dst, (const unsigned long long*)src, n);
 }
 void launch_overlap_pack(const int32_t* pos, const int32_t* ref, const int32_t* alt, const int32_t* set_of, int64_t n,
                          uint32_t* keys, uint32_t* vals, uint32_t* bad, hipStream_t st) {

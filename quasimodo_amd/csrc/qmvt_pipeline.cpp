@@ -38,6 +38,7 @@ int qm_host_write_masks(const char* path, const uint8_t* text, size_t len, int64
                         const uint8_t* line_kind, const uint64_t* kept, const uint64_t* tp, const uint8_t* flags, int select);
 int qm_host_threads(void);
 void qm_set_error(const char* msg);   // qmvt_api.cpp: what qm_last_error returns
+int qm_device_add_u64(qm_ctx* ctx, uint64_t* dst, const uint64_t* src, int64_t n);   // qmvt_api.cpp: dst[i] += src[i] on the device, blocking
 
 namespace {
 
@@ -105,7 +106,7 @@ struct PinnedArena {
 // One arena per context (= per device): calls on different contexts -- a thread and a context per GPU, examples/qm_multi.c --
 // tokenise, upload and write side by side; two calls on ONE context take turns.  The table itself is never destroyed: at
 // process exit the HIP runtime may be gone before static destructors run; qm_destroy releases a context's arena.
-struct CtxArena { PinnedArena arena; std::mutex mu; };
+struct CtxArena { PinnedArena arena[2]; std::mutex mu; };
 std::map<qm_ctx*, CtxArena*>& g_arenas = *new std::map<qm_ctx*, CtxArena*>();
 std::mutex* g_arenas_mu = new std::mutex();
 CtxArena* arena_of(qm_ctx* ctx) {
@@ -154,7 +155,7 @@ void qm_pipeline_ctx_destroyed(qm_ctx* ctx) {
     auto it = g_arenas.find(ctx);
     if (it != g_arenas.end()) { a = it->second; g_arenas.erase(it); }
   }
-  if (a) { { std::lock_guard<std::mutex> g(a->mu); a->arena.release(); } delete a; }
+  if (a) { { std::lock_guard<std::mutex> g(a->mu); a->arena[0].release(); a->arena[1].release(); } delete a; }
 }
 
 extern "C" int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs, int n_bins, unsigned mode, int strict,
@@ -175,7 +176,12 @@ extern "C" int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* j
     return QM_OK;
   }
   const bool ext = (mode & QM_BATCH_ALLELES) != 0;
-  double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // map + count, truth sets (beside the former), batch layout, tokenise + host path (+ uploads beside it), engine, masks back, write, release
+  // map + count, truth sets (beside the former), batch layout, tokenise + host path (+ uploads beside it), engine, masks back,
+  // write, release -- summed over the groups of the pipeline below (stages of different groups overlap, so the sum of the
+  // phases exceeds the wall time of the call)
+  double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  std::mutex ph_mu;
+  auto add_ph = [&](int k, double dt) { std::lock_guard<std::mutex> g(ph_mu); ph[k] += dt; };
   const int nthr = qm_host_threads();
   std::vector<JobState> J((size_t)n_jobs);
   for (int j = 0; j < n_jobs; ++j) {
@@ -186,11 +192,50 @@ extern "C" int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* j
   }
   qm_dict* dict = ext ? qm_dict_create() : nullptr;
   std::vector<TruthState> T;
-  qm_batch* batch = nullptr;
+
+  // ---- groups: the VCFs CAN go through a two-stage pipeline, group after group -- while group g is on the engine and its
+  //      files are being written (a thread of its own, fanning out over the host threads), group g + 1 is mapped, tokenised
+  //      and uploaded.  Measured (round 3, 16 VCFs of 10^6 lines, profiles/r03_e2e_groups.log): 83 ms in one group, 86 / 108 /
+  //      142 ms in 2 / 4 / 6 -- every stage parallelises over FILES (one thread counts a file, one thread writes an output
+  //      file), so a stage takes as long as its slowest file however few files it holds, and smaller groups only idle
+  //      threads.  The default is therefore ONE group (QM_FILES_GROUPS / QM_FILES_GROUP_MB for experiments); what would make
+  //      groups pay is parallelism INSIDE a file in the count and in the writers.
+  struct Group {
+    std::vector<int> jobs;             // indices into `jobs`, ascending
+    qm_batch* batch = nullptr;
+    std::vector<int64_t> nrec;
+    std::vector<int32_t> tids;
+    hipStream_t copy_stream = nullptr;
+    std::vector<int64_t> scal;
+    std::vector<uint64_t> roc;
+    int rc = QM_OK;
+    std::string err;
+  };
+  std::vector<Group> G;
+  {
+    int64_t total = 0;
+    std::vector<int64_t> sz((size_t)n_jobs, 0);
+    for (int j = 0; j < n_jobs; ++j) { struct stat st; if (stat(jobs[j].vcf_path, &st) == 0) sz[(size_t)j] = (int64_t)st.st_size; total += sz[(size_t)j]; }
+    int want = 1;
+    if (const char* e = getenv("QM_FILES_GROUP_MB")) want = (int)std::min<int64_t>(8, std::max<int64_t>(1, total / (std::max<int64_t>(1, atoll(e)) << 20)));
+    if (const char* e = getenv("QM_FILES_GROUPS")) want = std::max(1, atoi(e));
+    want = std::min(want, n_jobs);
+    G.resize((size_t)want);
+    int64_t acc = 0;
+    int g = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+      while (g + 1 < want && acc >= total * (g + 1) / want && !G[(size_t)g].jobs.empty()) ++g;
+      G[(size_t)g].jobs.push_back(j);
+      acc += sz[(size_t)j];
+    }
+    while (!G.empty() && G.back().jobs.empty()) G.pop_back();
+  }
   std::thread truth_thread;   // ends with the patterns of the truth files
+  std::thread stage2;         // engine + masks + files of the group before the one being tokenised
   auto cleanup = [&]() {
+    if (stage2.joinable()) stage2.join();
     if (truth_thread.joinable()) truth_thread.join();
-    if (batch) qm_batch_destroy(batch);
+    for (auto& g : G) { if (g.batch) { qm_batch_destroy(g.batch); g.batch = nullptr; } if (g.copy_stream) { (void)hipStreamDestroy(g.copy_stream); g.copy_stream = nullptr; } }
     for (auto& t : T) { if (t.pats) qm_patterns_destroy(t.pats); if (t.tid >= 0) (void)qm_truth_release(ctx, t.tid); }
     if (dict) qm_dict_destroy(dict);
   };
@@ -255,193 +300,207 @@ extern "C" int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* j
       const int rc = qm_truth_load(ctx, tp.data(), tr.data(), ta.data(), k, &t.tid);
       if (rc != QM_OK) { truth_rc = rc; truth_msg = qm_last_error(ctx); break; }
     }
-    ph[1] = now() - tt0;
+    add_ph(1, now() - tt0);
     { std::lock_guard<std::mutex> g(pats_mu); keys_ready = true; }
     pats_cv.notify_all();
     pats_thread.join();   // (the VCFs do not wait for this thread but for pats_ready)
   });
   auto wait_patterns = [&]() { std::unique_lock<std::mutex> g(pats_mu); pats_cv.wait(g, [&] { return pats_ready; }); };
 
-  // ---- 2. ... while every VCF is mapped and its lines / data lines are counted (the batch layout needs the record counts) ----
-  double t0 = now();
-  parallel_for(n_jobs, nthr, [&](int j) {
-    JobState& s = J[(size_t)j];
-    s.vcf.open_file(jobs[j].vcf_path);
-    if (!s.vcf.ok) { s.rc = QM_E_IO; return; }
-    int64_t nl = 0, nd = 0;
-    qm_host_count_lines(s.vcf.p, s.vcf.n, &nl, &nd);
-    s.n_lines = nl; s.n_data = nd;
-  });
-  ph[0] = now() - t0;
-  { std::unique_lock<std::mutex> g(pats_mu); pats_cv.wait(g, [&] { return keys_ready; }); }   // the thread itself ends with the patterns
-  for (int j = 0; j < n_jobs; ++j)
-    if (J[(size_t)j].rc != QM_OK) { cleanup(); return fail(QM_E_IO, std::string("cannot read ") + jobs[j].vcf_path); }
-  if (truth_rc != QM_OK) { cleanup(); return fail(truth_rc, truth_msg); }
-
-  // ---- 3. batch layout for the mixed samples; column buffers for everything ----
-  t0 = now();
-  std::vector<int64_t> nrec;
-  std::vector<int32_t> tids;
-  for (int j = 0; j < n_jobs; ++j)
-    if (!jobs[j].pure) { J[(size_t)j].batch_v = (int)nrec.size(); nrec.push_back(J[(size_t)j].n_data); tids.push_back(T[(size_t)J[(size_t)j].truth].tid); }
-  if (!nrec.empty()) {
-    const int rc = qm_batch_create_ext(ctx, (int)nrec.size(), nrec.data(), tids.data(), n_bins, mode, &batch);
-    if (rc != QM_OK) { cleanup(); return rc; }
-  }
   CtxArena* const ca = arena_of(ctx);
-  std::unique_lock<std::mutex> arena_lock(ca->mu);   // one call at a time per context uses its page-locked arena
-  size_t need = 0;
-  std::vector<size_t> aoff((size_t)n_jobs);
-  for (int j = 0; j < n_jobs; ++j) {
-    aoff[(size_t)j] = need;
-    const size_t cap = (size_t)J[(size_t)j].n_lines + 1;
-    need += ((cap * 17 + 255) & ~(size_t)255) + ((((cap + 63) / 64) * 16 + 255) & ~(size_t)255);
-  }
-  uint8_t* arena = ca->arena.get(need);
-  if (!arena) { cleanup(); return fail(QM_E_NOMEM, "qm_extract_files: no memory for the column buffers"); }
-  hipStream_t copy_stream = nullptr;
-  if (hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess) { cleanup(); return fail(QM_E_HIP, "hipStreamCreate failed"); }
+  std::unique_lock<std::mutex> arena_lock(ca->mu);   // one call at a time per context uses its page-locked arenas
 
-  ph[2] = now() - t0;
-
-  // ---- 4. tokenise + host path, each VCF uploaded (asynchronously) as soon as it is ready ----
-  t0 = now();
-  const int per_file_threads = std::max(1, nthr / std::max(1, std::min(n_jobs, nthr)));
-  parallel_for(n_jobs, nthr, [&](int j) {
-    JobState& s = J[(size_t)j];
-    const size_t cap = (size_t)s.n_lines + 1;
-    uint8_t* a = arena + aoff[(size_t)j];
-    s.pos = (int32_t*)a; s.ref = s.pos + cap; s.alt = s.ref + cap; s.qual = (float*)(s.alt + cap); s.flags = (uint8_t*)(s.qual + cap);
-    s.kept = (uint64_t*)(a + ((cap * 17 + 255) & ~(size_t)255)); s.tp = s.kept + (cap + 63) / 64;
-    s.line_off.resize(cap + 1);
-    s.line_kind.resize(cap);
-    s.rc = qm_host_scan_threads(s.vcf.p, s.vcf.n, (int64_t)cap, s.line_off.data(), s.line_kind.data(), s.pos, s.ref, s.alt, s.qual, s.flags,
-                                &s.info, dict, per_file_threads > 1 ? per_file_threads : -1);   // -1: one thread, lines counted above
-    if (s.rc != QM_OK || s.info.n_data != s.n_data) {
-      // (the file changed between the count and the scan: the scan stops at the room it was given)
-      s.err = s.rc == QM_OK || s.rc == QM_E_INVAL ? "the file changed while it was being read" : "tokenising failed";
-      if (s.rc == QM_OK) s.rc = QM_E_INVAL;
-      return;
+  // ---- stage 1 of a group: map + count, batch layout, tokenise + host path + uploads ----
+  auto stage_one = [&](Group& gr, int gi) -> int {
+    const int ng = (int)gr.jobs.size();
+    double t0 = now();
+    parallel_for(ng, nthr, [&](int k) {
+      const int j = gr.jobs[(size_t)k];
+      JobState& s = J[(size_t)j];
+      s.vcf.open_file(jobs[j].vcf_path);
+      if (!s.vcf.ok) { s.rc = QM_E_IO; return; }
+      int64_t nl = 0, nd = 0;
+      qm_host_count_lines(s.vcf.p, s.vcf.n, &nl, &nd);
+      s.n_lines = nl; s.n_data = nd;
+    });
+    add_ph(0, now() - t0);
+    { std::unique_lock<std::mutex> g(pats_mu); pats_cv.wait(g, [&] { return keys_ready; }); }   // the thread itself ends with the patterns
+    for (int j : gr.jobs)
+      if (J[(size_t)j].rc != QM_OK) return fail(QM_E_IO, std::string("cannot read ") + jobs[j].vcf_path);
+    if (truth_rc != QM_OK) return fail(truth_rc, truth_msg);
+    t0 = now();
+    for (int j : gr.jobs)
+      if (!jobs[j].pure) { J[(size_t)j].batch_v = (int)gr.nrec.size(); gr.nrec.push_back(J[(size_t)j].n_data); gr.tids.push_back(T[(size_t)J[(size_t)j].truth].tid); }
+    if (!gr.nrec.empty()) {
+      const int rc = qm_batch_create_ext(ctx, (int)gr.nrec.size(), gr.nrec.data(), gr.tids.data(), n_bins, mode, &gr.batch);
+      if (rc != QM_OK) return rc;
     }
-    if (jobs[j].pure) return;
+    size_t need = 0;
+    std::vector<size_t> aoff((size_t)ng);
+    for (int k = 0; k < ng; ++k) {
+      aoff[(size_t)k] = need;
+      const size_t cap = (size_t)J[(size_t)gr.jobs[(size_t)k]].n_lines + 1;
+      need += ((cap * 17 + 255) & ~(size_t)255) + ((((cap + 63) / 64) * 16 + 255) & ~(size_t)255);
+    }
+    uint8_t* arena = ca->arena[gi & 1].get(need);   // two arenas take turns: group g - 2 has been written by now
+    if (!arena) return fail(QM_E_NOMEM, "qm_extract_files: no memory for the column buffers");
+    if (hipStreamCreateWithFlags(&gr.copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(QM_E_HIP, "hipStreamCreate failed");
+    add_ph(2, now() - t0);
+    t0 = now();
+    const int per_file_threads = std::max(1, nthr / std::max(1, std::min(ng, nthr)));
+    parallel_for(ng, nthr, [&](int k) {
+      const int j = gr.jobs[(size_t)k];
+      JobState& s = J[(size_t)j];
+      const size_t cap = (size_t)s.n_lines + 1;
+      uint8_t* a = arena + aoff[(size_t)k];
+      s.pos = (int32_t*)a; s.ref = s.pos + cap; s.alt = s.ref + cap; s.qual = (float*)(s.alt + cap); s.flags = (uint8_t*)(s.qual + cap);
+      s.kept = (uint64_t*)(a + ((cap * 17 + 255) & ~(size_t)255)); s.tp = s.kept + (cap + 63) / 64;
+      s.line_off.resize(cap + 1);
+      s.line_kind.resize(cap);
+      s.rc = qm_host_scan_threads(s.vcf.p, s.vcf.n, (int64_t)cap, s.line_off.data(), s.line_kind.data(), s.pos, s.ref, s.alt, s.qual, s.flags,
+                                  &s.info, dict, per_file_threads > 1 ? per_file_threads : -1);   // -1: one thread, lines counted above
+      if (s.rc != QM_OK || s.info.n_data != s.n_data) {
+        // (the file changed between the count and the scan: the scan stops at the room it was given)
+        s.err = s.rc == QM_OK || s.rc == QM_E_INVAL ? "the file changed while it was being read" : "tokenising failed";
+        if (s.rc == QM_OK) s.rc = QM_E_INVAL;
+        return;
+      }
+      if (jobs[j].pure) return;
+      wait_patterns();
+      const TruthState& t = T[(size_t)s.truth];
+      if (t.rc != QM_OK) { s.rc = t.rc; return; }
+      if (s.info.n_host || s.info.n_nokey_kept || t.info[1] > 0 || t.info[2] > 0) {
+        s.rc = qm_vcf_hostpath(t.pats, s.vcf.p, s.vcf.n, s.info.n_lines, s.line_off.data(), s.line_kind.data(), s.pos, s.ref, s.alt, s.flags, s.ex);
+        if (s.rc != QM_OK) s.err = "the host path (fgrep -w on the text) failed";
+      }
+      if (s.rc == QM_OK && !(strict && s.info.n_refused)) {
+        s.rc = qm_batch_upload_async(gr.batch, s.batch_v, s.pos, s.ref, s.alt, s.qual, s.flags, gr.copy_stream);
+        if (s.rc != QM_OK) s.err = qm_last_error(ctx);   // this thread's message: the caller's thread would not see it
+      }
+    });
+    int rc = QM_OK;
     wait_patterns();
-    const TruthState& t = T[(size_t)s.truth];
-    if (t.rc != QM_OK) { s.rc = t.rc; return; }
-    if (s.info.n_host || s.info.n_nokey_kept || t.info[1] > 0 || t.info[2] > 0) {
-      s.rc = qm_vcf_hostpath(t.pats, s.vcf.p, s.vcf.n, s.info.n_lines, s.line_off.data(), s.line_kind.data(), s.pos, s.ref, s.alt, s.flags, s.ex);
-      if (s.rc != QM_OK) s.err = "the host path (fgrep -w on the text) failed";
+    for (const auto& t : T) {
+      if (rc != QM_OK) break;
+      if (t.rc != QM_OK) rc = fail(t.rc, "cannot take the patterns of truth file " + t.path);
+      else if (strict && t.info[3] > 0) rc = fail(QM_E_NONCANON, t.path + ": " + std::to_string(t.info[3]) + " truth rows hold NUL or non-ASCII bytes");
     }
-    if (s.rc == QM_OK && !(strict && s.info.n_refused)) {
-      s.rc = qm_batch_upload_async(batch, s.batch_v, s.pos, s.ref, s.alt, s.qual, s.flags, copy_stream);
-      if (s.rc != QM_OK) s.err = qm_last_error(ctx);   // this thread's message: the caller's thread would not see it
+    for (int k = 0; k < ng && rc == QM_OK; ++k) {
+      const int j = gr.jobs[(size_t)k];
+      const JobState& s = J[(size_t)j];
+      if (s.rc != QM_OK) rc = fail(s.rc, std::string("tokenising / uploading failed for ") + jobs[j].vcf_path + (s.err.empty() ? "" : ": " + s.err));
+      else if (strict && s.info.n_refused)
+        rc = fail(QM_E_NONCANON, std::string(jobs[j].vcf_path) + " line " + std::to_string(s.info.first_refused_line) +
+                                     ": a kept line holds NUL or non-ASCII bytes -- the reference's answer for it depends on the locale "
+                                     "Python exports to grep; set QM_LENIENT=1 to classify it by its columns");
     }
-  });
+    if (hipStreamSynchronize(gr.copy_stream) != hipSuccess && rc == QM_OK) rc = fail(QM_E_HIP, "upload failed");
+    add_ph(3, now() - t0);
+    return rc;
+  };
+
+  // ---- stage 2 of a group (a thread of its own): the engine, the class masks back, the three files of every VCF, the rows ----
+  auto stage_two = [&](Group& gr) {
+    int rc = QM_OK;
+    double t0 = now();
+    if (gr.batch) {
+      rc = qm_batch_run(gr.batch, nullptr, nullptr);
+      if (rc == QM_OK) rc = qm_batch_finish(gr.batch, nullptr);
+      gr.scal.resize(gr.nrec.size() * QM_N_SCALARS);
+      gr.roc.resize(gr.nrec.size() * 3 * (size_t)n_bins);
+      if (rc == QM_OK) rc = qm_batch_get_scalars(gr.batch, gr.scal.data());
+      if (rc == QM_OK) rc = qm_batch_get_roc(gr.batch, gr.roc.data());
+      if (rc == QM_OK && global_dev) {
+        // the per-truth-set sums as the engine left them in HBM, row by row ADDED into the caller's layout: what a multi-GPU
+        // caller all-reduces (device to device: the counters never visit the host)
+        void* src = nullptr;
+        rc = qm_batch_global_device(gr.batch, &src);
+        const size_t roww = 3 * (size_t)n_bins;
+        for (size_t k = 0; k < T.size() && rc == QM_OK; ++k) {
+          if (slot_of_truth[k] < 0 || T[k].tid < 0) continue;
+          rc = qm_device_add_u64(ctx, (uint64_t*)global_dev + (size_t)slot_of_truth[k] * roww, (const uint64_t*)src + (size_t)T[k].tid * roww, (int64_t)roww);
+        }
+      }
+      if (rc != QM_OK) gr.err = qm_last_error(ctx);
+    }
+    add_ph(4, now() - t0);
+    t0 = now();
+    for (size_t k = 0; k < gr.jobs.size() && rc == QM_OK; ++k) {
+      const int j = gr.jobs[k];
+      JobState& s = J[(size_t)j];
+      if (jobs[j].pure) continue;
+      rc = qm_batch_get_masks(gr.batch, s.batch_v, s.kept, s.tp);
+      if (rc != QM_OK) gr.err = qm_last_error(ctx);
+    }
+    add_ph(5, now() - t0);
+    if (gr.copy_stream) { (void)hipStreamDestroy(gr.copy_stream); gr.copy_stream = nullptr; }
+    if (rc != QM_OK) { gr.rc = rc; return; }
+    t0 = now();
+    struct WTask { int j, select; const char* path; bool pure; };
+    std::vector<WTask> W;
+    for (int j : gr.jobs) {
+      if (jobs[j].pure) { W.push_back({j, 0, jobs[j].filtered_out, true}); W.push_back({j, 0, jobs[j].fp_out, true}); }   // cp filtered fp (:33-36)
+      else { W.push_back({j, 0, jobs[j].filtered_out, false}); W.push_back({j, 1, jobs[j].tp_out, false}); W.push_back({j, 2, jobs[j].fp_out, false}); }
+    }
+    std::vector<int> wrc(W.size(), QM_OK);
+    parallel_for((int)W.size(), nthr, [&](int k) {
+      const WTask& w = W[(size_t)k];
+      const JobState& s = J[(size_t)w.j];
+      // pure-strain samples never reach the device: kept = the A2 filter's verdict, which the tokenizer left in the flags
+      wrc[(size_t)k] = qm_host_write_masks(w.path, s.vcf.p, s.vcf.n, s.info.n_lines, s.line_off.data(), s.line_kind.data(),
+                                           w.pure ? nullptr : s.kept, w.pure ? nullptr : s.tp, s.flags, w.select);
+    });
+    for (size_t k = 0; k < W.size(); ++k)
+      if (wrc[k] != QM_OK) { gr.rc = wrc[k]; gr.err = std::string("cannot write ") + W[k].path; return; }
+    add_ph(6, now() - t0);
+    // per-VCF rows
+    for (int j : gr.jobs) {
+      const JobState& s = J[(size_t)j];
+      int64_t hk = 0, hk_tp = 0;
+      for (int64_t i = 0; i < s.info.n_lines; ++i) { hk += s.line_kind[(size_t)i] == QM_LINE_HEADER_KEPT || s.line_kind[(size_t)i] == QM_LINE_HEADER_KEPT_TP; hk_tp += s.line_kind[(size_t)i] == QM_LINE_HEADER_KEPT_TP; }
+      if (stats) {
+        qm_file_stats& o = stats[j];
+        memset(&o, 0, sizeof o);
+        o.n_lines = s.info.n_lines; o.n_refused = s.info.n_refused; o.header_kept = hk; o.header_kept_tp = hk_tp; o.host_decided = s.ex[0];
+        if (jobs[j].pure) {
+          int64_t np = 0;
+          for (int64_t r = 0; r < s.n_data; ++r) np += s.flags[r] & QM_F_PASS;
+          o.scalars[QM_S_NPASS] = np; o.scalars[QM_S_FP_LINES] = np; o.scalars[QM_S_SORTED] = 1; o.scalars[QM_S_NREC] = s.n_data;
+        } else {
+          memcpy(o.scalars, &gr.scal[(size_t)s.batch_v * QM_N_SCALARS], sizeof o.scalars);
+          // R keys a line by the TEXT of POS / REF / ALT; for lines without a comparable key the device counted distinct
+          // (carried pos, ref, alt) instead: swap those for the text keys (qm_vcf_hostpath)
+          o.scalars[QM_S_FP_R] += s.ex[4] - s.ex[2];
+          o.scalars[QM_S_TP_R] += s.ex[3];
+          o.genomediff = T[(size_t)s.truth].counts[0];
+        }
+      }
+      if (roc_out) {
+        uint64_t* dst = roc_out + (size_t)j * 3 * (size_t)n_bins;
+        if (jobs[j].pure) memset(dst, 0, sizeof(uint64_t) * 3 * (size_t)n_bins);
+        else memcpy(dst, &gr.roc[(size_t)s.batch_v * 3 * (size_t)n_bins], sizeof(uint64_t) * 3 * (size_t)n_bins);
+      }
+    }
+    // the group is done: its batch, its mappings and its line tables go while the next group is at work
+    t0 = now();
+    if (gr.batch) { qm_batch_destroy(gr.batch); gr.batch = nullptr; }
+    parallel_for((int)gr.jobs.size(), nthr, [&](int k) { JobState tmp = std::move(J[(size_t)gr.jobs[(size_t)k]]); (void)tmp; });   // unmap / free in parallel
+    add_ph(7, now() - t0);
+  };
+
   int rc = QM_OK;
-  wait_patterns();
-  for (const auto& t : T) {
-    if (rc != QM_OK) break;
-    if (t.rc != QM_OK) rc = fail(t.rc, "cannot take the patterns of truth file " + t.path);
-    else if (strict && t.info[3] > 0) rc = fail(QM_E_NONCANON, t.path + ": " + std::to_string(t.info[3]) + " truth rows hold NUL or non-ASCII bytes");
+  std::string msg;
+  for (size_t g = 0; g < G.size() && rc == QM_OK; ++g) {
+    rc = stage_one(G[g], (int)g);
+    if (rc != QM_OK) msg = qm_last_error(ctx);
+    if (stage2.joinable()) stage2.join();          // group g - 1 is written (and its arena free for group g + 1)
+    if (g > 0 && rc == QM_OK && G[g - 1].rc != QM_OK) { rc = G[g - 1].rc; msg = G[g - 1].err; }
+    if (rc == QM_OK) stage2 = std::thread(stage_two, std::ref(G[g]));
   }
-  for (int j = 0; j < n_jobs && rc == QM_OK; ++j) {
-    const JobState& s = J[(size_t)j];
-    if (s.rc != QM_OK) rc = fail(s.rc, std::string("tokenising / uploading failed for ") + jobs[j].vcf_path + (s.err.empty() ? "" : ": " + s.err));
-    else if (strict && s.info.n_refused)
-      rc = fail(QM_E_NONCANON, std::string(jobs[j].vcf_path) + " line " + std::to_string(s.info.first_refused_line) +
-                                   ": a kept line holds NUL or non-ASCII bytes -- the reference's answer for it depends on the locale "
-                                   "Python exports to grep; set QM_LENIENT=1 to classify it by its columns");
-  }
-  if (hipStreamSynchronize(copy_stream) != hipSuccess && rc == QM_OK) rc = fail(QM_E_HIP, "upload failed");
-  ph[3] = now() - t0;
-
-  // ---- 5. the engine: one batch for every mixed-sample VCF of the call ----
-  t0 = now();
-  std::vector<int64_t> scal;
-  std::vector<uint64_t> roc;
-  if (rc == QM_OK && batch) {
-    rc = qm_batch_run(batch, nullptr, nullptr);
-    if (rc == QM_OK) rc = qm_batch_finish(batch, nullptr);
-    scal.resize(nrec.size() * QM_N_SCALARS);
-    roc.resize(nrec.size() * 3 * (size_t)n_bins);
-    if (rc == QM_OK) rc = qm_batch_get_scalars(batch, scal.data());
-    if (rc == QM_OK) rc = qm_batch_get_roc(batch, roc.data());
-    if (rc == QM_OK && global_dev) {
-      // the per-truth-set sums as the engine left them in HBM, row by row into the caller's layout: what a multi-GPU caller
-      // all-reduces (device to device: the counters never visit the host)
-      void* src = nullptr;
-      rc = qm_batch_global_device(batch, &src);
-      const size_t rowb = 3 * (size_t)n_bins * sizeof(uint64_t);
-      for (size_t k = 0; k < T.size() && rc == QM_OK; ++k) {
-        if (slot_of_truth[k] < 0 || T[k].tid < 0) continue;
-        if (hipMemcpy((uint8_t*)global_dev + (size_t)slot_of_truth[k] * rowb, (const uint8_t*)src + (size_t)T[k].tid * rowb, rowb,
-                      hipMemcpyDeviceToDevice) != hipSuccess)
-          rc = fail(QM_E_HIP, "qm_extract_files_ex: copying the per-truth sums failed");
-      }
-    }
-  }
-  ph[4] = now() - t0;
-  t0 = now();
-  for (int j = 0; j < n_jobs && rc == QM_OK; ++j) {
-    JobState& s = J[(size_t)j];
-    if (jobs[j].pure) continue;
-    rc = qm_batch_get_masks(batch, s.batch_v, s.kept, s.tp);
-  }
-  ph[5] = now() - t0;
-  (void)hipStreamDestroy(copy_stream);
-  if (rc != QM_OK) { cleanup(); return rc; }
-
-  // ---- 6. the output files: filtered / tp / fp of every VCF, each a task of its own ----
-  t0 = now();
-  struct WTask { int j, select; const char* path; bool pure; };
-  std::vector<WTask> W;
-  for (int j = 0; j < n_jobs; ++j) {
-    if (jobs[j].pure) { W.push_back({j, 0, jobs[j].filtered_out, true}); W.push_back({j, 0, jobs[j].fp_out, true}); }   // cp filtered fp (:33-36)
-    else { W.push_back({j, 0, jobs[j].filtered_out, false}); W.push_back({j, 1, jobs[j].tp_out, false}); W.push_back({j, 2, jobs[j].fp_out, false}); }
-  }
-  std::vector<int> wrc(W.size(), QM_OK);
-  parallel_for((int)W.size(), nthr, [&](int k) {
-    const WTask& w = W[(size_t)k];
-    const JobState& s = J[(size_t)w.j];
-    // pure-strain samples never reach the device: kept = the A2 filter's verdict, which the tokenizer left in the flags
-    wrc[(size_t)k] = qm_host_write_masks(w.path, s.vcf.p, s.vcf.n, s.info.n_lines, s.line_off.data(), s.line_kind.data(),
-                                         w.pure ? nullptr : s.kept, w.pure ? nullptr : s.tp, s.flags, w.select);
-  });
-  for (size_t k = 0; k < W.size(); ++k)
-    if (wrc[k] != QM_OK) { const std::string p = W[k].path; cleanup(); return fail(wrc[k], "cannot write " + p); }
-  ph[6] = now() - t0;
-
-  // ---- 7. per-VCF rows ----
-  for (int j = 0; j < n_jobs; ++j) {
-    const JobState& s = J[(size_t)j];
-    int64_t hk = 0, hk_tp = 0;
-    for (int64_t i = 0; i < s.info.n_lines; ++i) { hk += s.line_kind[(size_t)i] == QM_LINE_HEADER_KEPT || s.line_kind[(size_t)i] == QM_LINE_HEADER_KEPT_TP; hk_tp += s.line_kind[(size_t)i] == QM_LINE_HEADER_KEPT_TP; }
-    if (stats) {
-      qm_file_stats& o = stats[j];
-      memset(&o, 0, sizeof o);
-      o.n_lines = s.info.n_lines; o.n_refused = s.info.n_refused; o.header_kept = hk; o.header_kept_tp = hk_tp; o.host_decided = s.ex[0];
-      if (jobs[j].pure) {
-        int64_t np = 0;
-        for (int64_t r = 0; r < s.n_data; ++r) np += s.flags[r] & QM_F_PASS;
-        o.scalars[QM_S_NPASS] = np; o.scalars[QM_S_FP_LINES] = np; o.scalars[QM_S_SORTED] = 1; o.scalars[QM_S_NREC] = s.n_data;
-      } else {
-        memcpy(o.scalars, &scal[(size_t)s.batch_v * QM_N_SCALARS], sizeof o.scalars);
-        // R keys a line by the TEXT of POS / REF / ALT; for lines without a comparable key the device counted distinct
-        // (carried pos, ref, alt) instead: swap those for the text keys (qm_vcf_hostpath)
-        o.scalars[QM_S_FP_R] += s.ex[4] - s.ex[2];
-        o.scalars[QM_S_TP_R] += s.ex[3];
-        o.genomediff = T[(size_t)s.truth].counts[0];
-      }
-    }
-    if (roc_out) {
-      uint64_t* dst = roc_out + (size_t)j * 3 * (size_t)n_bins;
-      if (jobs[j].pure) memset(dst, 0, sizeof(uint64_t) * 3 * (size_t)n_bins);
-      else memcpy(dst, &roc[(size_t)s.batch_v * 3 * (size_t)n_bins], sizeof(uint64_t) * 3 * (size_t)n_bins);
-    }
-  }
-  t0 = now();
+  if (stage2.joinable()) stage2.join();
+  if (rc == QM_OK) for (auto& g : G) if (g.rc != QM_OK) { rc = g.rc; msg = g.err; break; }
   cleanup();
-  parallel_for(n_jobs, nthr, [&](int j) { JobState tmp = std::move(J[(size_t)j]); (void)tmp; });   // unmap / free in parallel
-  ph[7] = now() - t0;
+  if (rc != QM_OK) return fail(rc, msg);
   if (phase_seconds) memcpy(phase_seconds, ph, sizeof ph);
   return QM_OK;
 }
