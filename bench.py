@@ -69,6 +69,9 @@ def main():
                     help="also time shuffled VCFs of configs[3]'s shape (10 M records on a 50 Mb reference: the two-level bucket path) on this many VCFs at N=1, config 2; 0 disables")
     ap.add_argument("--alleles-vcfs", type=int, default=int(os.environ.get("QM_BENCH_ALLELES_VCFS", "1000")),
                     help="also time the allele-extended variant (config 4's record shape) on this many VCFs at N=1, config 2; 0 disables")
+    ap.add_argument("--alloc-reps", type=int, default=int(os.environ.get("QM_BENCH_ALLOC_REPS", "3")),
+                    help="re-create the timed batch this many times after the timed region and report k_classify's time for each "
+                         "(roofline.alloc_spread: the kernel moves by several per cent with where a batch lands in memory); N=1, config 2; 0 disables")
     ap.add_argument("--check-vcfs", type=int, default=2, help="VCFs of this rank's batch checked against the oracle after the timed region (N > 1 and configs 3 / 4)")
     args = ap.parse_args()
     P = dict(PRESETS[args.config])
@@ -272,6 +275,23 @@ def main():
         except Exception as e:   # never fatal
             out["roofline"]["measured_error"] = str(e)[:120]
     side = rank == 0 and world == 1
+    if side and args.config == 2 and not custom and not args.shuffled and args.alloc_reps > 0:
+        # The same workload in fresh allocations, outside the timed region: within one allocation k_classify is steady to a per
+        # cent, from one allocation to the next it moves by several (profiles/r03_alloc_pmc.log: the same requests, 5-9 % more
+        # memory latency) -- the headline above is ONE draw of this spread.
+        spread = [round(tm["classify_ms"], 4)]
+        for _ in range(args.alloc_reps):
+            b2 = eng.batch([P["records"]] * n_vcf, [tids[0]] * n_vcf, n_bins=args.bins)
+            b2.synth(P["genome"], P["truth"], tseeds[0], P["seed"])
+            b2.run(); b2.finish()
+            b2.set_timing(True)
+            for _ in range(5):
+                b2.run()
+            b2.finish()
+            spread.append(round(b2.timings()["classify_ms"], 4))
+            b2.close()
+        out["roofline"]["alloc_spread"] = {"k_classify_ms": spread, "min": min(spread), "max": max(spread),
+                                           "note": "first entry = the timed batch; the others = the same batch created again (5 runs each)"}
     if side and args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(batch, P, tseeds, alleles, args.bins, max(1, min(n_vcf, args.cpu_sample // P["records"])))
     if side and args.config == 2 and not custom and args.shell_sample > 0:
