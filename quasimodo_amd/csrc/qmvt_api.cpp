@@ -369,6 +369,10 @@ struct qm_batch {
   uint32_t *bk_hist = nullptr, *bk_scal = nullptr;
   VcfDesc* d_bk_vcfs = nullptr;
   int64_t cap_bk_rows = 0, cap_bk_vcfs = 0;
+  uint64_t* bk_xent = nullptr;      // allele-extended batches: the second stream's regions (16-byte entries), its cursors and row descriptors
+  uint32_t* bk_xcursor = nullptr;
+  HashRowX* bk_xrows = nullptr;
+  int64_t cap_bk_xent = 0, cap_bk_xcursor = 0, cap_bk_xrows = 0;
   uint64_t* bk_ent = nullptr;       // the bucket regions: [segment][256][8][SortSeg.bk_cap] packed records
   uint32_t* bk_cursor = nullptr;    // [segment][256][8] fill counts, then one flag word per segment
   int32_t* d_bk_tile_seg = nullptr;
@@ -450,7 +454,7 @@ static void batch_free(qm_batch* b) {
   (void)hipSetDevice(b->ctx->dev);
   if (b->sub) { batch_free(b->sub); b->sub = nullptr; }
   void* ptrs[] = {b->pkey, b->pinf, b->pos, b->ref, b->alt, b->qual, b->flags, b->mask_pass, b->mask_tp, b->idx, b->tile_tp, b->tile_fp,
-                  b->tile_tp_off, b->tile_fp_off, b->span_hist, b->span_scal, b->vcf_flags, b->vcf_posor, b->bk_hist, b->bk_scal, b->d_bk_vcfs, b->bk_ent, b->bk_cursor, b->d_bk_tile_seg, b->bk_rows, b->bk_roc, b->bk_rscal, b->bk_vflags, b->p_segs, b->p_tile_seg, b->p_cnt, b->p_off, b->p_cursor, b->p_flags, b->p_ent, b->d_vsegs, b->d_vparts, b->rs_roc, b->rs_scal, b->rs_flags, b->roc, b->global_acc,
+                  b->tile_tp_off, b->tile_fp_off, b->span_hist, b->span_scal, b->vcf_flags, b->vcf_posor, b->bk_hist, b->bk_scal, b->d_bk_vcfs, b->bk_ent, b->bk_cursor, b->d_bk_tile_seg, b->bk_rows, b->bk_xent, b->bk_xcursor, b->bk_xrows, b->bk_roc, b->bk_rscal, b->bk_vflags, b->p_segs, b->p_tile_seg, b->p_cnt, b->p_off, b->p_cursor, b->p_flags, b->p_ent, b->d_vsegs, b->d_vparts, b->rs_roc, b->rs_scal, b->rs_flags, b->roc, b->global_acc,
                   b->scalars, b->d_vcfs, b->d_spans, b->d_tile_vcf, b->cls_scratch, b->sk[0], b->sk[1], b->sv[0],
                   b->sv[1], b->si[0], b->si[1], b->shist, b->sorbits, b->d_segs, b->d_tile_seg, b->d_ktile_seg, b->d_ktile_local};
   for (void* p : ptrs) (void)hipFree(p);
@@ -828,7 +832,7 @@ static int regrow(T** p, int64_t* cap, int64_t need, int64_t* bytes) {
 // x 1 024 entries at five eighths full and for the 21 index bits of an entry.  QM_SORT_PATH=radix keeps everything on the sort,
 // QM_BUCKET_MIN moves the lower limit.
 static bool bucket_path_takes(const qm_batch* b, int64_t n) {
-  if (b->ext) return false;
+  if (b->ext) if (const char* e = getenv("QM_BUCKET_EXT")) if (atoi(e) == 0) return false;   // allele-extended batches on the radix sort only
   if (const char* e = getenv("QM_SORT_PATH")) if (strcmp(e, "radix") == 0) return false;
   int64_t lo = HB_MIN_RECORDS;
   if (const char* e = getenv("QM_BUCKET_MIN")) lo = atoll(e);   // tests and tools/gpu_fuzz.py send their small VCFs through the buckets too
@@ -950,12 +954,28 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   // The bucket path (k_classify_hash): ONE scatter pass, no sort.  For batches of the default mode whose VCFs are small enough
   // for 256 buckets of at most HB_MAX_RECORDS records; QM_SORT_PATH=radix keeps everything on the radix sort.
   bool try_buckets = buckets;   // the caller chose the chunk's VCFs by size (bucket_path_takes)
+  int lb_all = 0, nbk_all = 1;
+  for (int i = 0; i < nseg; ++i) { lb_all = std::max(lb_all, (int)segs[(size_t)i].pad); nbk_all = std::max(nbk_all, std::min(nbk_used[(size_t)i], (int)HB_BUCKETS)); }
+  const bool direct = lb_all <= DJ_MAX_SHIFT && !join_hash_forced();
+  // allele-extended batches: two entry streams and two joins per bucket (k_join_direct for the single-base records, k_join_ext
+  // for the others), both of which need the bucket's key range to fit the bit maps; wider key ranges take the radix sort
+  const bool xstream = b->ext;
+  if (xstream && !direct) try_buckets = false;
+  const int out_stride = xstream ? 2 * HB_BUCKETS : HB_BUCKETS;
+  if (xstream) nbk_all = HB_BUCKETS;   // every row of a segment is written (the rows of the second stream follow at a fixed distance)
+  if (rc == QM_OK && !try_buckets && buckets) rc = ensure_sub(b, vs, tids);
   if (rc == QM_OK && try_buckets) {
     const int64_t rows = (int64_t)nseg * HB_BUCKETS;   // cap_bk_rows counts rows for both arrays
+    const int64_t orows = (int64_t)nseg * out_stride;
     int64_t c1 = b->cap_bk_rows * SPAN_HIST_WORDS, c2 = b->cap_bk_rows * 8;
-    rc = regrow(&b->bk_hist, &c1, rows * SPAN_HIST_WORDS, &b->dev_bytes);
-    if (rc == QM_OK) rc = regrow(&b->bk_scal, &c2, rows * 8, &b->dev_bytes);
-    if (rc == QM_OK) b->cap_bk_rows = std::max(b->cap_bk_rows, rows);
+    rc = regrow(&b->bk_hist, &c1, orows * SPAN_HIST_WORDS, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->bk_scal, &c2, orows * 8, &b->dev_bytes);
+    if (rc == QM_OK) b->cap_bk_rows = std::max(b->cap_bk_rows, orows);
+    if (rc == QM_OK && xstream) {
+      rc = regrow(&b->bk_xent, &b->cap_bk_xent, 2 * bk_ents, &b->dev_bytes);
+      if (rc == QM_OK) rc = regrow(&b->bk_xcursor, &b->cap_bk_xcursor, rows * HB_SUBS, &b->dev_bytes);
+      if (rc == QM_OK) rc = regrow(&b->bk_xrows, &b->cap_bk_xrows, rows, &b->dev_bytes);
+    }
     if (rc == QM_OK) rc = regrow(&b->d_bk_vcfs, &b->cap_bk_vcfs, (int64_t)nseg, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_ent, &b->cap_bk_ent, bk_ents, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_rows, &b->cap_bk_rowdesc, rows, &b->dev_bytes);
@@ -993,7 +1013,8 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
       for (int i = 0; i < nseg; ++i) {
         VcfDesc& f = fake[(size_t)i];
         f = VcfDesc();
-        f.off = 0; f.n = segs[(size_t)i].n; f.truth = tids[(size_t)i]; f.tile0 = 0; f.ntiles = 0; f.span0 = i * HB_BUCKETS; f.nspans = std::min(nbk_used[(size_t)i], (int)HB_BUCKETS); f.pad = 0;
+        f.off = 0; f.n = segs[(size_t)i].n; f.truth = tids[(size_t)i]; f.tile0 = 0; f.ntiles = 0; f.span0 = i * out_stride;
+        f.nspans = xstream ? out_stride : std::min(nbk_used[(size_t)i], (int)HB_BUCKETS); f.pad = 0;
       }
       HIPCHK(hipMemcpyAsync(b->d_bk_vcfs, fake.data(), sizeof(VcfDesc) * fake.size(), hipMemcpyHostToDevice, st));
       HIPCHK(hipStreamSynchronize(st));
@@ -1005,15 +1026,15 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     S.segs = b->d_segs; S.tile_seg = b->d_bk_tile_seg; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
     S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
     S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = nullptr;
+    S.xent = xstream ? b->bk_xent : nullptr; S.xcursor = xstream ? b->bk_xcursor : nullptr; S.ext = xstream ? 1 : 0;
+    if (xstream) HIPCHK(hipMemsetAsync(b->bk_xcursor, 0, (size_t)nseg * HB_BUCKETS * HB_SUBS * 4, st));
     HashParams H;
     H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
     H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.seg_base = 0;
+    H.xrows = xstream ? b->bk_xrows : nullptr; H.xent = b->bk_xent; H.xcursor = b->bk_xcursor; H.out_stride = out_stride; H.ext = xstream ? 1 : 0;
     launch_bucket_rows(H, nseg, st);
     // The scatter streams (memory-bound, its SIMDs half idle), the join issues instructions (and hardly waits for memory): in a
     // few segment ranges, the join of one range on the second stream beside the scatter of the next, they fill each other's gaps.
-    int lb_all = 0, nbk_all = 1;
-    for (int i = 0; i < nseg; ++i) { lb_all = std::max(lb_all, (int)segs[(size_t)i].pad); nbk_all = std::max(nbk_all, std::min(nbk_used[(size_t)i], (int)HB_BUCKETS)); }
-    const bool direct = lb_all <= DJ_MAX_SHIFT && !join_hash_forced();
     // k_classify_hash issues instructions where the scatter waits for memory: a few segment ranges, the join of one on the second
     // stream beside the scatter of the next, fill each other's gaps (- 7 %).  k_join_direct is bound by the latency of a
     // workgroup's serial steps and wants every LDS slot of the chip: beside a scatter it only loses (3.06 ms in one piece
@@ -1044,6 +1065,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
         // tables of k_classify_hash otherwise (QM_JOIN=hash: always)
         if (direct) launch_join_direct(H, i1 - i0, lb_all, nbk_all, aux);
         else launch_classify_hash(H, i1 - i0, aux);
+        if (xstream && !getenv("QM_XJ_SKIP")) launch_join_ext(H, i1 - i0, nbk_all, aux);   // (QM_XJ_SKIP: debugging only, results wrong)
       }
       i0 = i1;
     }
@@ -1311,10 +1333,11 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   BucketScatterParams S;
   S.segs = b->d_segs; S.tile_seg = b->d_bk_tile_seg; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
   S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
-  S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = b->p_ent;
+  S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = b->p_ent; S.xent = nullptr; S.xcursor = nullptr; S.ext = 0;
   HashParams H;
   H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
   H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.seg_base = 0;
+  H.xrows = nullptr; H.xent = nullptr; H.xcursor = nullptr; H.out_stride = HB_BUCKETS; H.ext = 0;
   launch_bucket_rows(H, nseg, st);
   launch_bucket_scatter(S, (int)nbt, st);
   launch_join_direct(H, nseg, DJ_MAX_SHIFT, HB_BUCKETS, st);

@@ -237,6 +237,11 @@ struct BucketScatterParams {
   int32_t n_bins;
   int32_t tile_base;          // first scatter tile of this launch (the chunk is scattered in a few segment ranges)
   const uint64_t* l1_ent;     // two-level path: the level-1 entries the segments are read from (SortSeg.koff = first entry) instead of the columns
+  // allele-extended batches: records whose REF / ALT are not two single bases go to a second stream of 16-byte entries (the
+  // ordinary entry with the position's first key, then REF | ALT << 32), regions [n_seg][256][8][bk_cap] with cursors of their own
+  uint64_t* xent;
+  uint32_t* xcursor;
+  int32_t ext;
 };
 // everything k_classify_hash needs to know about one (segment, bucket), laid out by k_bucket_rows before it runs: the
 // workgroup of a bucket lives only a few microseconds, and every dependent load on its way to the data (segment table ->
@@ -250,10 +255,29 @@ struct HashRow {
   uint32_t shift;             // (key - the segment's key_base) >> shift = bucket
   uint32_t kbase;             // first key of the bucket
 };
+// the same for the second stream of an allele-extended batch (k_join_ext): the truth side is the extended table
+struct HashRowX {
+  const uint64_t* ent;        // the bucket's [8][cap] 16-byte entries
+  const uint32_t* xkeys;      // the truth entries of the bucket's positions: keys, REF codes, ALT codes (sorted by key, REF, ALT)
+  const int32_t* xref;
+  const int32_t* xalt;
+  int64_t src_off;
+  int32_t tn;
+  uint32_t cap;
+  uint32_t shift;
+  uint32_t kbase;
+};
+constexpr int XJ_TRUTH_MAX = 1024;   // staged truth entries per bucket
+constexpr int XJ_LIST_MAX = 1024;    // records of a bucket that need the exact comparison (positions claimed more than once, keyless records)
 struct HashParams {
   const SortSeg* segs;
   const HashRow* rows;        // [n_seg * 256]
   HashRow* rows_out;          // the same, for k_bucket_rows
+  HashRowX* xrows;            // allele-extended batches: [n_seg * 256] descriptors of the second stream (null otherwise)
+  const uint64_t* xent;
+  const uint32_t* xcursor;
+  int32_t out_stride;         // rows of histograms / scalars per segment: 256, or 512 when the second stream's rows follow the first's
+  int32_t ext;
   const uint64_t* ent;
   const uint32_t* cursor;
   const TruthDev* truths;
@@ -364,6 +388,7 @@ void launch_masks_to_cls(const uint64_t* mp, const uint64_t* mt, int64_t off, in
 void launch_synth(const SynthParams& S, int n_vcf, int64_t max_n, hipStream_t st);
 void launch_classify_hash(const HashParams& P, int nseg, hipStream_t st);   // segments P.seg_base .. + nseg
 void launch_bucket_rows(const HashParams& P, int nseg, hipStream_t st);
+void launch_join_ext(const HashParams& P, int nseg, int nbk, hipStream_t st);     // the second stream of an allele-extended batch
 void launch_join_direct(const HashParams& P, int nseg, int lb, int nbk, hipStream_t st);   // segments P.seg_base .. + nseg, every bucket shift <= lb <= DJ_MAX_SHIFT
 void launch_bucket_scatter(const BucketScatterParams& P, int ntiles, hipStream_t st);   // tiles P.tile_base .. + ntiles; P.l1_ent: from level-1 entries
 void launch_sort_first_hist(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const int32_t* pos_col, uint32_t* hist, uint32_t* orbits,

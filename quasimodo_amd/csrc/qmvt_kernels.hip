@@ -1519,8 +1519,11 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
 // L2: the segment is one partition of a large VCF (two-level path): its records come as level-1 entries (P.l1_ent + sg.koff,
 // sg.n of them, no holes) instead of columns, keys are relative to the partition (sg.key_base), the kept mask was written
 // by the first level.
-template <bool L2>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BK_WAVES_PER_EU, 8))) void k_bucket_scatter(BucketScatterParams P) {
+// EXT (allele-extended batches): every record with valid allele codes is live; those whose REF / ALT are not two single bases
+// leave in a second stream of 16-byte entries (the ordinary entry with the position's first key, then the two codes), written
+// straight to their bucket's second region -- k_join_ext joins them exactly, k_join_direct the single-base ones.
+template <bool L2, bool EXT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : BK_WAVES_PER_EU, 8))) void k_bucket_scatter(BucketScatterParams P) {
   constexpr int PER = BK_TILE / 512;          // records per thread, in groups of four consecutive ones
   static_assert(BK_TILE % 2048 == 0 && PER >= 4, "whole 16-byte loads, 256 records per wave and group");
   __shared__ uint32_t s_cnt[256];             // records of digit d in the tile (running during the ranking)
@@ -1529,17 +1532,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BK_WAVES_PE
   __shared__ uint32_t s_scan[5];
   __shared__ uint64_t s_e[BK_TILE];
   __shared__ uint8_t s_d[BK_TILE];
+  __shared__ uint32_t s_cntx[EXT ? 256 : 1];     // second stream: records of digit d in the tile, then where its run starts in the sub-region
   const int bid = (int)blockIdx.x + P.tile_base;
   const int seg = P.tile_seg[bid];
   const SortSeg sg = P.segs[seg];
   const int sub = bid & (HB_SUBS - 1);
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < 256) s_cnt[tid] = 0u;
+  if (tid < 256) { s_cnt[tid] = 0u; if (EXT) s_cntx[tid] = 0u; }
   __syncthreads();
   const int64_t tbase = (int64_t)(bid - sg.bk_tile0) * BK_TILE;
   const uint32_t shift = (uint32_t)sg.pad;
   uint64_t ent[PER];
   uint32_t dr[PER];   // digit << 16 | rank inside the tile's digit; 0xffffffff: the record is not live
+  uint32_t drx[EXT ? PER : 1];   // the same for the second stream (the entry itself is rebuilt from ent[] and the columns when it is stored)
   uint32_t segfl = 0;
   typedef int v4i __attribute__((ext_vector_type(4)));
   typedef float v4f __attribute__((ext_vector_type(4)));
@@ -1598,20 +1603,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BK_WAVES_PE
     for (int u = 0; u < 4; ++u) {
       const int k = 4 * j + u;
       dr[k] = 0xffffffffu;
+      if (EXT) drx[k] = 0xffffffffu;
       ent[k] = 0ull;
       if (i4 + u < sg.n) {
         uint32_t key, inf;
-        pack_record<false>(p[j][u], r[j][u], a[j][u], q[j][u], f[j] >> (8 * u), P.n_bins, key, inf);
+        pack_record<EXT>(p[j][u], r[j][u], a[j][u], q[j][u], f[j] >> (8 * u), P.n_bins, key, inf);
         segfl |= (inf & I_BADPOS) ? SPANF_BADPOS : 0u;
         if (inf & I_LIVE) {
           kept |= ((inf >> 16) & 1u) << u;
           const uint32_t d = key >> shift;
           if (d >= (uint32_t)HB_BUCKETS) {
             segfl |= SPANF_OVERFLOW;   // a position above what the optimistic pass saw of this VCF: the radix sort redoes it
-          } else {
+          } else if (!EXT || (uint32_t)(r[j][u] | a[j][u]) < 4u) {
             const uint32_t v = key - (d << shift);   // < 2^24: shift <= 24
             ent[k] = (uint64_t)v | ((uint64_t)((inf & 0xfffu) | ((inf >> 12) & 0x1000u)) << 24) | ((uint64_t)(uint32_t)(i4 + u) << 37);
             dr[k] = (d << 16) | atomicAdd(&s_cnt[d], 1u);
+          } else {   // not two single bases: the second stream (the key's nibble is a hash there: the entry carries the position's first key)
+            const uint32_t v = (key & ~15u) - (d << shift);
+            ent[k] = (uint64_t)v | ((uint64_t)((inf & 0xfffu) | ((inf >> 12) & 0x1000u)) << 24) | ((uint64_t)(uint32_t)(i4 + u) << 37);
+            drx[k] = (d << 16) | atomicAdd(&s_cntx[d], 1u);
           }
         }
       }
@@ -1653,8 +1663,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BK_WAVES_PE
     }
     s_glob[tid] = (int32_t)g - (int32_t)loc;
     if (tid == 255) s_scan[4] = loc + cnt;
+  } else if (EXT) {   // the other four waves: room for the second stream's runs (no reordering in LDS: each entry is stored where it belongs)
+    const int d = tid - 256;
+    const uint32_t cx = s_cntx[d];
+    uint32_t g = 0;
+    if (cx) {
+      g = atomicAdd(&P.xcursor[((size_t)seg * HB_BUCKETS + d) * HB_SUBS + sub], cx);
+      if (g + cx > (uint32_t)sg.bk_cap) atomicOr(&P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg], SPANF_OVERFLOW);
+    }
+    s_cntx[d] = g;
   }
   __syncthreads();
+  if (EXT) {
+    typedef unsigned long long v2ull __attribute__((ext_vector_type(2)));
+    v2ull* xout = reinterpret_cast<v2ull*>(P.xent) + sg.bk_off;   // (the second stream's regions are laid out like the first's)
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      if (drx[k] != 0xffffffffu) {
+        const uint32_t d = drx[k] >> 16;
+        const uint32_t w = s_cntx[d] + (drx[k] & 0xffffu);
+        if (w < (uint32_t)sg.bk_cap) {
+          v2ull e;
+          e.x = ent[k];
+          e.y = (unsigned long long)(uint32_t)r[k >> 2][k & 3] | ((unsigned long long)(uint32_t)a[k >> 2][k & 3] << 32);
+          xout[((size_t)d * HB_SUBS + sub) * (size_t)sg.bk_cap + (size_t)w] = e;
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     if (dr[k] != 0xffffffffu) {
@@ -1887,6 +1923,21 @@ __global__ __launch_bounds__(HB_BUCKETS) void k_bucket_rows(HashParams P) {
   R.shift = shift;
   R.kbase = kbase;
   P.rows_out[(size_t)blockIdx.x * HB_BUCKETS + d] = R;
+  if (P.xrows) {   // allele-extended batch: the second stream joins against the extended truth table
+    uint32_t xa = plo >> tr.xshift, xb = (phi >> tr.xshift) + 1u;
+    const uint32_t xlim = (uint32_t)tr.xnb + 1u;
+    xa = xa < xlim ? xa : xlim; xb = xb < xlim ? xb : xlim;
+    const int xlo = tr.xtidx[xa], xhi = tr.xtidx[xb];
+    HashRowX X;
+    X.ent = P.xent + 2 * (sg.bk_off + (size_t)d * HB_SUBS * (size_t)sg.bk_cap);
+    X.xkeys = tr.xkeys + xlo; X.xref = tr.xref + xlo; X.xalt = tr.xalt + xlo;
+    X.src_off = sg.src_off;
+    X.tn = xhi - xlo;
+    X.cap = (uint32_t)sg.bk_cap;
+    X.shift = shift;
+    X.kbase = kbase;
+    P.xrows[(size_t)blockIdx.x * HB_BUCKETS + d] = X;
+  }
 }
 
 constexpr int HB_THREADS = 512;
@@ -2329,10 +2380,11 @@ __global__ __launch_bounds__(DJ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
     nsub[k] = c < cap ? c : cap;
     nrec += nsub[k];
   }
-  uint32_t* oh = P.row_hist + row * SPAN_HIST_WORDS;
+  const size_t orow = (size_t)seg_id * (size_t)P.out_stride + (size_t)d;   // where the bucket's row goes (allele-extended batches: the second stream's rows follow)
+  uint32_t* oh = P.row_hist + orow * SPAN_HIST_WORDS;
   if (nrec == 0u) {   // an empty bucket: a row of zeros, nothing else
     if (tid < 3 * 128) oh[tid] = 0u;
-    if (tid < 8) P.row_scal[row * 8 + tid] = tid == 5 ? segfl : 0u;
+    if (tid < 8) P.row_scal[orow * 8 + tid] = tid == 5 ? segfl : 0u;
     return;
   }
   over |= R.shift > (uint32_t)LB ? 1u : 0u;                  // (the host never launches this instantiation for such a segment)
@@ -2576,7 +2628,7 @@ __global__ __launch_bounds__(DJ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
     oh[256 + tid] = s_hu[tid];
   }
   if (tid == 0) {
-    uint32_t* sc = P.row_scal + row * 8;
+    uint32_t* sc = P.row_scal + orow * 8;
     const uint32_t fl = s_c[4];
     sc[0] = s_c[0]; sc[1] = s_c[1]; sc[2] = s_c[0] - s_c[1]; sc[3] = s_c[3];
     sc[4] = s_c[9] - s_c[5] + s_c[2];   // distinct kept keys outside the truth set: bits of the map minus the truth bits, plus the keyless ones
@@ -2585,6 +2637,262 @@ __global__ __launch_bounds__(DJ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
   DJ_TICK(11);
   __syncthreads();
   DJ_FLUSH();
+}
+
+// ---------------------------------------------------------------------------
+// k_join_ext -- the second stream of an allele-extended batch: the records of a bucket whose REF / ALT are not two single bases
+// (16-byte entries: the ordinary entry with the position's first key, then the two allele codes), joined EXACTLY on
+// (position, REF, ALT) against the extended truth table.  Their 32-bit key cannot stand for them (its nibble is a hash), but a
+// bucket has at most 2^15 positions and such records rarely share one, so three bit maps over POSITIONS carry the common case:
+//   * P: an extended truth entry sits at this position.  Records there are parked in a ring of their wave and compared with
+//     that position's truth entries (bisection of the sorted slice, then REF and ALT) 64 at a time; exact hits are marked in a
+//     bit per entry, their truth entry's state and the input-order TP bit follow.
+//   * S / S2: a kept record outside the truth set sits here / more than one does.  A record on a position only it claims is a
+//     distinct key by construction; the records on positions claimed more than once (true repeats, multi-allelic sites) and
+//     the keyless ones go to a list and are compared all against all -- exact, and free of the races a hash set of 12-byte
+//     keys would have.
+// Histograms, counts, scalars: a row like k_join_direct's (every count of the two streams is additive: a key belongs to one).
+// 512 threads, 51 KB of LDS; what does not fit (1 024 truth entries, 1 024 listed records) flags the VCF for the radix sort.
+// ---------------------------------------------------------------------------
+constexpr int XJ_THREADS = 512;
+constexpr int XJ_TRIPS = HB_MAX_RECORDS / XJ_THREADS;   // one entry per thread and trip
+__global__ __launch_bounds__(XJ_THREADS) void k_join_ext(HashParams P) {
+  constexpr int MAPW = (1 << (DJ_MAX_SHIFT - 4)) / 32;       // 2^15 positions
+  __shared__ uint32_t s_p[MAPW], s_s[MAPW], s_s2[MAPW];
+  __shared__ uint32_t s_xk[XJ_TRUTH_MAX], s_xr[XJ_TRUTH_MAX], s_xa[XJ_TRUTH_MAX], s_ts[XJ_TRUTH_MAX];
+  __shared__ uint32_t s_tf[XJ_TRUTH_MAX / 32];
+  __shared__ uint32_t s_hit[HB_MAX_RECORDS / 32];            // entry e of the bucket hit a truth entry exactly
+  __shared__ uint32_t s_lp[XJ_LIST_MAX], s_lr[XJ_LIST_MAX], s_la[XJ_LIST_MAX];
+  __shared__ __attribute__((aligned(16))) uint4 s_ring[(XJ_THREADS / 64) * 64];
+  __shared__ uint32_t s_ringe[(XJ_THREADS / 64) * 64];
+  __shared__ uint32_t s_htp[130], s_hfp[130], s_hu[128];
+  __shared__ uint32_t s_c[10];   // kept, TP lines, distinct kept keys outside the truth set, matched truth entries, flags, -, listed records, top-bin TP, top-bin FP, -
+  const int tid = (int)threadIdx.x;
+  const int d = (int)blockIdx.x;
+  const int seg_id = (int)blockIdx.y + P.seg_base;
+  const size_t row = (size_t)seg_id * HB_BUCKETS + (size_t)d;
+  const HashRowX R = P.xrows[row];
+  const uint32_t* cur = P.xcursor + row * HB_SUBS;
+  const size_t orow = (size_t)seg_id * (size_t)P.out_stride + (size_t)HB_BUCKETS + (size_t)d;   // the second stream's rows follow the first's
+  for (int i = tid; i < MAPW; i += XJ_THREADS) { s_p[i] = 0u; s_s[i] = 0u; s_s2[i] = 0u; }
+  s_ts[tid] = 0u; s_ts[tid + XJ_THREADS] = 0u;
+  if (tid < XJ_TRUTH_MAX / 32) s_tf[tid] = 0u;
+  if (tid < HB_MAX_RECORDS / 32) s_hit[tid] = 0u;
+  if (tid < 130) { s_htp[tid] = 0u; s_hfp[tid] = 0u; }
+  if (tid < 128) s_hu[tid] = 0u;
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(1))) v4u* gv4p;
+  const gv4p g_ent = (gv4p)R.ent;
+  const uint32_t cap = R.cap;
+  uint32_t nsub[HB_SUBS], pre[HB_SUBS + 1];   // wave-uniform
+  uint32_t over = 0;
+  pre[0] = 0;
+#pragma unroll
+  for (int k = 0; k < HB_SUBS; ++k) {
+    const uint32_t c = cur[k];
+    over |= c > cap ? 1u : 0u;
+    nsub[k] = c < cap ? c : cap;
+    pre[k + 1] = pre[k] + nsub[k];
+  }
+  const uint32_t nrec = pre[HB_SUBS];
+  uint32_t* oh = P.row_hist + orow * SPAN_HIST_WORDS;
+  if (nrec == 0u) {
+    if (tid < 3 * 128) oh[tid] = 0u;
+    if (tid < 8) P.row_scal[orow * 8 + tid] = 0u;
+    return;
+  }
+  over |= R.shift > (uint32_t)DJ_MAX_SHIFT ? 1u : 0u;
+  const uint32_t kbase = R.kbase;
+  const int tn_all = R.tn;
+  over |= tn_all > XJ_TRUTH_MAX ? 1u : 0u;
+  const int tn = over ? 0 : tn_all;
+  if (tid < 10) s_c[tid] = tid == 4 ? (over ? SPANF_OVERFLOW : 0u) : 0u;
+  const int ntrips = over ? 0 : (int)((nrec + XJ_THREADS - 1) / XJ_THREADS);
+  // where entry e of the bucket lies: the sub-regions one after the other
+  auto entry_at = [&](uint32_t e) -> gv4p {
+    uint32_t k = 0;
+#pragma unroll
+    for (int q = 1; q < HB_SUBS; ++q) k += e >= pre[q] ? 1u : 0u;
+    uint32_t b0 = 0;
+#pragma unroll
+    for (int q = 0; q < HB_SUBS; ++q) b0 = k == (uint32_t)q ? pre[q] : b0;
+    return g_ent + ((size_t)k * cap + (size_t)(e - b0));
+  };
+  // ---- the truth entries of the bucket's positions: the sorted slice as it is; a bit per position that holds an extended one ----
+  {
+    const gu32p gk = (gu32p)R.xkeys;
+    const gi32p gr = (gi32p)R.xref, ga = (gi32p)R.xalt;
+    const uint32_t klast = kbase + ((1u << (R.shift > (uint32_t)DJ_MAX_SHIFT ? (uint32_t)DJ_MAX_SHIFT : R.shift)) - 1u);
+    uint32_t k0 = 0, r0 = 0, a0 = 0, k1 = 0, r1 = 0, a1 = 0;
+    if (tid < tn) { k0 = gk[tid]; r0 = (uint32_t)gr[tid]; a0 = (uint32_t)ga[tid]; }
+    if (tid + XJ_THREADS < tn) { k1 = gk[tid + XJ_THREADS]; r1 = (uint32_t)gr[tid + XJ_THREADS]; a1 = (uint32_t)ga[tid + XJ_THREADS]; }
+    __syncthreads();   // the maps are clear
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = tid + h * XJ_THREADS;
+      const uint32_t k = h ? k1 : k0, r = h ? r1 : r0, a = h ? a1 : a0;
+      if (j < tn) {
+        s_xk[j] = k; s_xr[j] = r; s_xa[j] = a;
+        if (k >= kbase && k <= klast && (r | a) >= 4u) { const uint32_t pr = (k - kbase) >> 4; atomicOr(&s_p[pr >> 5], 1u << (pr & 31u)); }
+      }
+    }
+  }
+  __syncthreads();
+  const int nb = P.n_bins;
+  int ttop = 0;
+  if (tn > 0) ttop = 1 << (31 - __clz(tn));
+  unsigned long long* mtp = reinterpret_cast<unsigned long long*>(P.mask_tp);
+  uint32_t xs[XJ_TRIPS];   // per trip: position inside the bucket (15 bits) | info << 15 | valid << 28
+  // ---- pass 1: records on a position with a truth entry are compared with it ----
+  {
+    uint4* ring = s_ring + (tid >> 6) * 64;
+    uint32_t* ringe = s_ringe + (tid >> 6) * 64;
+    const uint32_t lane = (uint32_t)tid & 63u;
+    uint32_t nring = 0;   // wave-uniform
+    auto drain = [&]() {
+      if (lane < nring) {
+        const uint4 q = ring[lane];
+        const uint32_t e = ringe[lane];
+        const uint32_t pr = (q.x & 0xffffffu) >> 4;
+        const uint32_t inf = (q.x >> 24) | ((q.y & 0x1fu) << 8);
+        const uint32_t b1 = inf & I_BIN1;
+        const bool kept = (inf & I_PASS) != 0u;
+        bool hit = false;
+        if (((s_p[pr >> 5] >> (pr & 31u)) & 1u) && !(inf & I_NOKEY)) {
+          const uint32_t key0 = kbase + (pr << 4);
+          int j = lds_lower_bound(s_xk, tn, ttop, key0);
+          for (; j < tn && (s_xk[j] >> 4) == (key0 >> 4); ++j)
+            if (s_xr[j] == q.z && s_xa[j] == q.w) { hit = true; break; }
+          if (hit) {
+            atomicOr(&s_hit[e >> 5], 1u << (e & 31u));
+            if ((inf & I_IDDOT) && b1) atomicMax(&s_ts[j], b1);
+            if (kept) atomicOr(&s_tf[j >> 5], 1u << (j & 31));
+          }
+        }
+        if (kept && ((hit && (inf & I_IDDOT)) || (inf & 0x1000u))) {
+          const int64_t o = R.src_off + (int64_t)(q.y >> 5);
+          atomicOr(mtp + (o >> 6), 1ull << (o & 63));
+        }
+      }
+      nring = 0;
+    };
+#pragma unroll
+    for (int t = 0; t < XJ_TRIPS; ++t) {
+      xs[t] = 0u;
+      if (t < ntrips) {   // wave-uniform
+        const uint32_t e = (uint32_t)t * XJ_THREADS + (uint32_t)tid;
+        const bool valid = e < nrec;
+        v4u q = {0u, 0u, 0u, 0u};
+        if (valid) q = __builtin_nontemporal_load(entry_at(e));
+        const uint32_t pr = (q[0] & 0xffffffu) >> 4;
+        const uint32_t inf = (q[0] >> 24) | ((q[1] & 0x1fu) << 8);
+        xs[t] = pr | (inf << 15) | (valid ? 1u << 28 : 0u);
+        const bool park = valid && ((((s_p[pr >> 5] >> (pr & 31u)) & 1u) && !(inf & I_NOKEY)) || ((inf & I_PASS) && (inf & 0x1000u)));
+        const uint64_t m = ballot64(park);
+        const uint32_t cnt = (uint32_t)popc64(m);
+        if (nring + cnt > 64u) drain();
+        if (park) {
+          const uint32_t at = nring + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          ring[at] = make_uint4(q[0], q[1], q[2], q[3]);
+          ringe[at] = e;
+        }
+        nring += cnt;
+      }
+    }
+    if (nring) drain();
+  }
+  __syncthreads();
+  // ---- pass 2: histograms and counts (the hit bits are final); kept records outside the truth set claim their position ----
+  uint32_t n_pass = 0, n_tp = 0, top_tp = 0, top_fp = 0;
+  uint32_t fpm = 0, nkm = 0;   // bit t: the record of trip t is a kept key outside the truth set / the same without a comparable key
+#pragma unroll
+  for (int t = 0; t < XJ_TRIPS; ++t) {
+    const uint32_t x = xs[t];
+    if ((x >> 28) & 1u) {
+      const uint32_t e = (uint32_t)t * XJ_THREADS + (uint32_t)tid;
+      const uint32_t pr = x & 0x7fffu, inf = (x >> 15) & 0x1fffu;
+      const uint32_t hit = (s_hit[e >> 5] >> (e & 31u)) & 1u;
+      const uint32_t kept = (inf >> 9) & 1u, keyed = ~(inf >> 11) & 1u;
+      const uint32_t tpl = (hit & (inf >> 10)) | ((inf >> 12) & 1u);
+      const uint32_t b1 = inf & I_BIN1;
+      const uint32_t top = b1 == (uint32_t)nb ? 1u : 0u;
+      top_tp += top & tpl;
+      top_fp += top & ~tpl;
+      if (!top) atomicAdd(tpl ? &s_htp[b1 >> 1] : &s_hfp[b1 >> 1], 1u << (16u * (b1 & 1u)));
+      n_pass += kept;
+      n_tp += kept & tpl;
+      if (kept & ~hit & keyed & 1u) {
+        fpm |= 1u << t;
+        const uint32_t bit = 1u << (pr & 31u);
+        if (atomicOr(&s_s[pr >> 5], bit) & bit) atomicOr(&s_s2[pr >> 5], bit);
+      }
+      nkm |= (kept & ~hit & ~keyed & 1u) << t;
+    }
+  }
+  __syncthreads();
+  // ---- pass 3: a record alone on its position is a distinct key; the others, and the keyless ones, are listed ----
+  uint32_t fpr = 0;
+#pragma unroll
+  for (int t = 0; t < XJ_TRIPS; ++t) {
+    const uint32_t pr = xs[t] & 0x7fffu;
+    const bool mine = (fpm >> t) & 1u;
+    const bool shared = mine && ((s_s2[pr >> 5] >> (pr & 31u)) & 1u);
+    const bool list = shared || ((nkm >> t) & 1u);
+    fpr += (mine && !shared) ? 1u : 0u;
+    if (ballot64(list)) {   // rare
+      const uint32_t at = wave_reserve(&s_c[6], list);
+      if (list) {
+        if (at >= (uint32_t)XJ_LIST_MAX) atomicOr(&s_c[4], SPANF_OVERFLOW);
+        else {
+          const v4u q = *entry_at((uint32_t)t * XJ_THREADS + (uint32_t)tid);   // the allele codes again (the entry is still in L2)
+          s_lp[at] = pr | (((nkm >> t) & 1u) << 31);
+          s_lr[at] = q[2]; s_la[at] = q[3];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const uint32_t m = s_c[6] < (uint32_t)XJ_LIST_MAX ? s_c[6] : (uint32_t)XJ_LIST_MAX;
+    for (uint32_t i = (uint32_t)tid; i < m; i += XJ_THREADS) {   // all against all: the first of equal records counts
+      const uint32_t lp = s_lp[i], lr = s_lr[i], la = s_la[i];
+      bool dup = false;
+      for (uint32_t j = 0; j < i && !dup; ++j) dup = s_lp[j] == lp && s_lr[j] == lr && s_la[j] == la;
+      fpr += dup ? 0u : 1u;
+    }
+  }
+  n_pass = wave_sum(n_pass); n_tp = wave_sum(n_tp); fpr = wave_sum(fpr);
+  if (ballot64((top_tp | top_fp) != 0u)) { top_tp = wave_sum(top_tp); top_fp = wave_sum(top_fp); }
+  uint32_t tpr = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int j = tid + h * XJ_THREADS;
+    if (j < tn) {
+      const uint32_t mx = s_ts[j];
+      if (mx) atomicAdd(&s_hu[(mx - 1u) >> 1], 1u << (16u * ((mx - 1u) & 1u)));
+      tpr += (s_tf[j >> 5] >> (j & 31)) & 1u;
+    }
+  }
+  tpr = wave_sum(tpr);
+  if ((tid & 63) == 0) {
+    atomicAdd(&s_c[0], n_pass); atomicAdd(&s_c[1], n_tp); atomicAdd(&s_c[2], fpr);
+    if (tpr) atomicAdd(&s_c[3], tpr);
+    if (top_tp) atomicAdd(&s_c[7], top_tp);
+    if (top_fp) atomicAdd(&s_c[8], top_fp);
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const uint32_t ttp = s_c[7], tfp = s_c[8];
+    const int b0 = 2 * tid, b1 = 2 * tid + 1;
+    auto get = [&](const uint32_t* t, int slot) { return (t[slot >> 1] >> (16 * (slot & 1))) & 0xffffu; };
+    oh[tid] = (get(s_htp, 1 + b0) + (b0 == nb - 1 ? ttp : 0u)) | ((get(s_htp, 1 + b1) + (b1 == nb - 1 ? ttp : 0u)) << 16);
+    oh[128 + tid] = (get(s_hfp, 1 + b0) + (b0 == nb - 1 ? tfp : 0u)) | ((get(s_hfp, 1 + b1) + (b1 == nb - 1 ? tfp : 0u)) << 16);
+    oh[256 + tid] = s_hu[tid];
+  }
+  if (tid == 0) {
+    uint32_t* sc = P.row_scal + orow * 8;
+    sc[0] = s_c[0]; sc[1] = s_c[1]; sc[2] = s_c[0] - s_c[1]; sc[3] = s_c[3]; sc[4] = s_c[2]; sc[5] = s_c[4]; sc[6] = 0u; sc[7] = 0u;
+  }
 }
 
 // TP bits of the sorted scratch VCFs back to input order: only the records that ARE true positives
@@ -2820,13 +3128,17 @@ void launch_join_direct(const HashParams& P, int nseg, int lb, int nbk, hipStrea
   if (lb <= 16) hipLaunchKernelGGL((k_join_direct<16>), dim3(nbk, nseg), dim3(DJ_THREADS), pad, st, P);
   else hipLaunchKernelGGL((k_join_direct<DJ_MAX_SHIFT>), dim3(nbk, nseg), dim3(DJ_THREADS), pad, st, P);
 }
+void launch_join_ext(const HashParams& P, int nseg, int nbk, hipStream_t st) {
+  if (nseg > 0) hipLaunchKernelGGL(k_join_ext, dim3(nbk, nseg), dim3(XJ_THREADS), 0, st, P);
+}
 void launch_bucket_rows(const HashParams& P, int nseg, hipStream_t st) {
   if (nseg > 0) hipLaunchKernelGGL(k_bucket_rows, dim3(nseg), dim3(HB_BUCKETS), 0, st, P);
 }
 void launch_bucket_scatter(const BucketScatterParams& P, int ntiles, hipStream_t st) {
   if (ntiles <= 0) return;
-  if (P.l1_ent) hipLaunchKernelGGL((k_bucket_scatter<true>), dim3(ntiles), dim3(512), 0, st, P);
-  else hipLaunchKernelGGL((k_bucket_scatter<false>), dim3(ntiles), dim3(512), 0, st, P);
+  if (P.l1_ent) hipLaunchKernelGGL((k_bucket_scatter<true, false>), dim3(ntiles), dim3(512), 0, st, P);
+  else if (P.ext) hipLaunchKernelGGL((k_bucket_scatter<false, true>), dim3(ntiles), dim3(512), 0, st, P);
+  else hipLaunchKernelGGL((k_bucket_scatter<false, false>), dim3(ntiles), dim3(512), 0, st, P);
 }
 void launch_part_hist(const PartParams& P, int ntiles, hipStream_t st) {
   if (ntiles > 0) hipLaunchKernelGGL(k_part_hist, dim3(ntiles), dim3(512), 0, st, P);
