@@ -69,6 +69,8 @@ def main():
                     help="also time shuffled VCFs of configs[3]'s shape (10 M records on a 50 Mb reference: the two-level bucket path) on this many VCFs at N=1, config 2; 0 disables")
     ap.add_argument("--alleles-vcfs", type=int, default=int(os.environ.get("QM_BENCH_ALLELES_VCFS", "1000")),
                     help="also time the allele-extended variant (config 4's record shape) on this many VCFs at N=1, config 2; 0 disables")
+    ap.add_argument("--shuffled-alleles-vcfs", type=int, default=int(os.environ.get("QM_BENCH_SHUFFLED_ALLELES_VCFS", "256")),
+                    help="also time shuffled allele-extended VCFs (config 4's record shape: two entry streams, k_join_direct + k_join_ext) on this many VCFs at N=1, config 2; 0 disables")
     ap.add_argument("--alloc-reps", type=int, default=int(os.environ.get("QM_BENCH_ALLOC_REPS", "3")),
                     help="re-create the timed batch this many times after the timed region and report k_classify's time for each "
                          "(roofline.alloc_spread: the kernel moves by several per cent with where a batch lands in memory); N=1, config 2; 0 disables")
@@ -305,6 +307,8 @@ def main():
         out["shuffled_config3_variant"] = shuffled_config3_variant(eng, args.bins, args.shuffled3_vcfs)
     if side and args.config == 2 and not custom and not args.shuffled and args.alleles_vcfs > 0:
         out["alleles_variant"] = alleles_variant(eng, P, args.bins, min(args.alleles_vcfs, n_vcf))
+    if side and args.config == 2 and not custom and not args.shuffled and args.shuffled_alleles_vcfs > 0:
+        out["shuffled_alleles_variant"] = shuffled_alleles_variant(eng, P, args.bins, min(args.shuffled_alleles_vcfs, n_vcf))
     if rank == 0:
         print(json.dumps(out))
     batch.close()
@@ -437,6 +441,37 @@ def alleles_variant(eng, P, bins, nv):
             "ms_per_step": dt / steps * 1e3, "classify_ms": tm["classify_ms"], "classify_GBps": alg / tm["classify_ms"] / 1e6,
             "indel_pct": pct, "equals_oracle_on_vcf0": ok,
             "note": "k_classify<false,true>: allele codes staged in LDS beside the keys, (key, ref, alt) equality"}
+
+
+def shuffled_alleles_variant(eng, P, bins, nv):
+    """BASELINE configs[4]'s record shape (30 % of the records with variable-length alleles) with the records permuted: the bucket
+    path with two entry streams -- single-base records through k_join_direct, the others (16-byte entries with their allele
+    codes) through k_join_ext, exact on (position, REF, ALT).  A side measurement; the counters must equal the sorted run's."""
+    import numpy as np
+    import torch
+    pct, tseed = 30, 5
+    tid = eng.truth_synth(P["genome"], P["truth"], tseed, indel_pct=pct)
+    rows = {}
+    for shuffled in (False, True):
+        b = eng.batch([P["records"]] * nv, [tid] * nv, n_bins=bins, alleles=True)
+        b.synth(P["genome"], P["truth"], tseed, 5000, shuffled=shuffled, indel_pct=pct)
+        b.run(); b.finish()
+        if shuffled:
+            torch.cuda.synchronize()
+            steps = 3
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                b.run()
+                b.finish()
+            dt = time.perf_counter() - t0
+            paths = b.path_stats()
+        rows[shuffled] = (b.roc(), b.scalars()[:, :5].copy())
+        b.close()
+    eng.truth_release(tid)
+    ok = bool(np.array_equal(rows[True][0], rows[False][0]) and np.array_equal(rows[True][1], rows[False][1]))
+    return {"value": nv * float(P["records"]) * steps / dt, "unit": "classifications/s", "vcfs": nv, "steps": steps, "ms_per_step": dt / steps * 1e3,
+            "indel_pct": pct, "equals_sorted_variant": ok, "paths": paths,
+            "note": "allele-extended VCFs permuted: one scatter into two entry streams per bucket, k_join_direct (single-base records) + k_join_ext (the others)"}
 
 
 def shell_baseline(batch, P, n_sample, tseed):

@@ -154,7 +154,8 @@ def test_config5_shape_generated_on_device(engine, oracle):
     b.close()
 
 
-def test_alleles_mode_unsorted_vcfs_take_the_radix_sort_path(engine, oracle):
+def test_alleles_mode_unsorted_vcfs_small_and_large(engine, oracle):
+    """unsorted VCFs of an allele-extended batch: the small ones on the radix sort, 70 001 records on the bucket path (two streams)"""
     rng = np.random.default_rng(11)
     L = 40000
     truth = ext_truth(rng, 3000, L)
@@ -195,3 +196,49 @@ def test_alleles_mode_gives_up_on_overlong_runs(engine):
     alt = ((13 << 26) | (np.arange(n) % 7)).astype(np.int32)
     res, _ = engine.classify_batch([(pos, np.zeros(n, np.int32), alt, np.full(n, 50, np.float32), np.full(n, 3, np.uint8))], [tid], alleles=True)
     assert res[0]["scalars"]["FP_R"] == 7 and res[0]["scalars"]["fp_lines"] == n
+
+
+def test_alleles_mode_unsorted_vcfs_on_the_bucket_path(engine, oracle):
+    """Allele-extended VCFs out of order take the bucket path with TWO entry streams: single-base records through k_join_direct,
+    the others -- 16-byte entries with their allele codes -- through k_join_ext (exact on position, REF, ALT).  Synthetic config-5
+    VCFs against the sorted run, and an adversarial VCF (multi-allelic positions: many different and repeated alleles on one
+    position, on truth positions and off them, keyless and non-'.' records) against the oracle."""
+    from oracle.synth import synth_truth_keys
+    L, T, N, pct = 2_000_000, 50_000, 400_000, 30
+    tid = engine.truth_synth(L, T, 5, indel_pct=pct)
+    rows = {}
+    for shuffled in (False, True):
+        b = engine.batch([N] * 5, [tid] * 5, alleles=True)
+        b.synth(L, T, 5, 5000, shuffled=shuffled, indel_pct=pct)
+        b.run(); b.finish()
+        rows[shuffled] = (b.roc(), b.scalars()[:, :5].copy())
+        if shuffled:
+            ps = b.path_stats()
+            assert ps["unsorted"] == 5 and ps["bucket_direct"] == 5 and ps["radix"] == 0 and ps["radix_after_overflow"] == 0
+            cols = b.columns(3)
+            cls, oroc, sc = oracle.classify_columns(*cols, *synth_truth_keys(L, T, 5, pct), ext=True)
+            assert np.array_equal(b.cls(3), cls) and np.array_equal(rows[True][0][3], oroc)
+            idx = b.idx(3)
+            assert np.array_equal(idx[:sc["tp_lines"]], np.nonzero(cls == 3)[0]) and np.array_equal(idx[N - sc["fp_lines"]:], np.nonzero(cls == 1)[0])
+        b.close()
+    assert np.array_equal(rows[True][0], rows[False][0]) and np.array_equal(rows[True][1], rows[False][1])
+    engine.truth_release(tid)
+    # adversarial: 60 000 records on 20 000 positions, a third of them multi-allelic with a handful of alleles each
+    rng = np.random.default_rng(77)
+    Lp = 300_000
+    truth = ext_truth(rng, 6000, Lp)
+    tid2 = engine.truth_load(*truth)
+    c = ext_columns(rng, 60_000, Lp, truth)
+    pos, ref, alt, qual, flags = (a.copy() for a in c)
+    hot = rng.choice(pos, 300)
+    m = rng.random(len(pos)) < 0.3
+    pos[m] = rng.choice(hot, int(m.sum()))
+    alt[m] = np.where(rng.random(int(m.sum())) < 0.7, ((3 << 26) | rng.integers(0, 6, int(m.sum()))), alt[m]).astype(np.int32)
+    o = rng.permutation(len(pos))
+    cols = tuple(np.ascontiguousarray(a[o]) for a in (pos, ref, alt, qual, flags))
+    res, _ = engine.classify_batch([cols], [tid2], alleles=True)
+    cls, roc, sc = oracle.classify_columns(*cols, *truth, ext=True)
+    assert np.array_equal(res[0]["cls"], cls) and np.array_equal(res[0]["roc"], roc)
+    for k in ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R", "truth_unique"):
+        assert res[0]["scalars"][k] == sc[k], k
+    engine.truth_release(tid2)
