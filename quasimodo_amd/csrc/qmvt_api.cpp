@@ -447,7 +447,26 @@ struct qm_batch {
   uint32_t* d_summary = nullptr;
   // where the unsorted VCFs of the last qm_batch_finish went (qm_batch_path_stats)
   int64_t path_stats[QM_N_PATH_STATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // What a finish found stays known while the columns stay the same (only qm_batch_upload* / qm_batch_synth write them): a VCF found out
+  // of order is not streamed by the optimistic pass again, and qm_batch_finish queues its bucket path behind the run without first
+  // waiting for the flags (a host round trip of ~ 0.15 ms per step).  QM_MEMO=0: off.
+  std::vector<uint8_t> known;         // per VCF: 1 = out of order, as the last finish found it
+  std::vector<uint32_t> known_posor;  // its position bits (vcf_posor of that finish)
+  int n_known = 0;
+  bool known_dirty = false;           // the device copy is stale
+  uint8_t* d_known = nullptr;
+  bool run_used_known = false;        // the run in flight was launched with d_known
 };
+
+static bool memo_on() {
+  static const bool on = !getenv("QM_MEMO") || atoi(getenv("QM_MEMO")) != 0;
+  return on;
+}
+static void forget_known(qm_batch* b, int v) {   // v < 0: every VCF
+  if (b->known.empty() || b->n_known == 0) return;
+  if (v < 0) { std::fill(b->known.begin(), b->known.end(), (uint8_t)0); b->n_known = 0; b->known_dirty = true; return; }
+  if (b->known[(size_t)v]) { b->known[(size_t)v] = 0; --b->n_known; b->known_dirty = true; }
+}
 
 static void batch_free(qm_batch* b) {
   if (!b) return;
@@ -456,7 +475,7 @@ static void batch_free(qm_batch* b) {
   void* ptrs[] = {b->pkey, b->pinf, b->pos, b->ref, b->alt, b->qual, b->flags, b->mask_pass, b->mask_tp, b->idx, b->tile_tp, b->tile_fp,
                   b->tile_tp_off, b->tile_fp_off, b->span_hist, b->span_scal, b->vcf_flags, b->vcf_posor, b->bk_hist, b->bk_scal, b->d_bk_vcfs, b->bk_ent, b->bk_cursor, b->d_bk_tile_seg, b->bk_rows, b->bk_xent, b->bk_xcursor, b->bk_xrows, b->bk_roc, b->bk_rscal, b->bk_vflags, b->p_segs, b->p_tile_seg, b->p_cnt, b->p_off, b->p_cursor, b->p_flags, b->p_ent, b->d_vsegs, b->d_vparts, b->rs_roc, b->rs_scal, b->rs_flags, b->roc, b->global_acc,
                   b->scalars, b->d_vcfs, b->d_spans, b->d_tile_vcf, b->cls_scratch, b->sk[0], b->sk[1], b->sv[0],
-                  b->sv[1], b->si[0], b->si[1], b->shist, b->sorbits, b->d_segs, b->d_tile_seg, b->d_ktile_seg, b->d_ktile_local};
+                  b->sv[1], b->si[0], b->si[1], b->shist, b->sorbits, b->d_segs, b->d_tile_seg, b->d_ktile_seg, b->d_ktile_local, b->d_known};
   for (void* p : ptrs) (void)hipFree(p);
   if (b->h_summary) (void)hipHostFree(b->h_summary);
   for (auto& r : b->ev) for (auto& e : r) if (e) (void)hipEventDestroy(e);
@@ -594,6 +613,7 @@ extern "C" int qm_batch_upload(qm_batch* b, int v, const int32_t* pos, const int
   HIPCHK(hipMemcpy(b->qual + d.off, qual, n * 4, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(b->flags + d.off, flags, n, hipMemcpyHostToDevice));
   b->ran = b->finished = false;
+  forget_known(b, v);
   return QM_OK;
 }
 
@@ -614,6 +634,7 @@ extern "C" int qm_batch_upload_async(qm_batch* b, int v, const int32_t* pos, con
   HIPCHK(hipMemcpyAsync(b->qual + d.off, qual, n * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->flags + d.off, flags, n, hipMemcpyHostToDevice, st));
   b->ran = b->finished = false;
+  forget_known(b, v);
   return QM_OK;
 }
 
@@ -663,6 +684,7 @@ extern "C" int qm_batch_synth(qm_batch* b, const qm_synth_cfg* cfg) {
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(b->ctx->stream));
   b->ran = b->finished = false;
+  forget_known(b, -1);
   return QM_OK;
 }
 
@@ -678,6 +700,7 @@ static ClassifyParams classify_params(qm_batch* b) {
   P.ext = b->ext ? 1 : 0;
   P.span_base = 0;
   P.zero_acc = nullptr; P.zero_words = 0;
+  P.known = nullptr;
   return P;
 }
 static FinalizeParams finalize_params(qm_batch* b, uint64_t* global) {
@@ -688,6 +711,7 @@ static FinalizeParams finalize_params(qm_batch* b, uint64_t* global) {
   F.vcf_base = 0;
   F.flag_summary = nullptr;
   F.parts = 3;
+  F.known = nullptr;
   return F;
 }
 static CompactParams compact_params(qm_batch* b) {
@@ -732,6 +756,14 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
   // tile offsets exist.  The second stream starts behind everything queued on the main one so far (an earlier run's
   // compaction reads the masks this run rewrites) and the main stream ends behind the last compaction.
   hipStream_t aux = nch > 1 ? c->aux : st;
+  // VCFs an earlier finish found out of order, columns unchanged since: their spans return at once (qm_batch: known)
+  const bool use_known = memo_on() && b->n_known > 0;
+  if (use_known && (b->known_dirty || !b->d_known)) {
+    if (!b->d_known) { DALLOC(b->d_known, (size_t)b->n_vcf); b->dev_bytes += b->n_vcf; }
+    HIPCHK(hipMemcpy(b->d_known, b->known.data(), (size_t)b->n_vcf, hipMemcpyHostToDevice));
+    b->known_dirty = false;
+  }
+  b->run_used_known = use_known;
   if (nch > 1) {
     HIPCHK(hipEventRecord(b->ev_sync[qm_batch::MAX_CHUNKS], st));
     HIPCHK(hipStreamWaitEvent(aux, b->ev_sync[qm_batch::MAX_CHUNKS], 0));
@@ -745,12 +777,14 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
       if (ck.s1 > ck.s0) { P.zero_acc = g; P.zero_words = (int32_t)(gbytes / 8); }
       else HIPCHK(hipMemsetAsync(g, 0, gbytes, st));   // a batch of empty VCFs launches nothing
     }
+    if (use_known) P.known = b->d_known;
     if (T) HIPCHK(hipEventRecord(e5[0], st));
     launch_classify(P, ck.s1 - ck.s0, st);
     if (T) HIPCHK(hipEventRecord(e5[1], st));
     FinalizeParams F = finalize_params(b, g);
     F.vcf_base = ck.v0;
     F.flag_summary = b->d_summary;
+    if (use_known) F.known = b->d_known;
     // In one piece (the default), the compaction waits only for what it needs of k_finalize -- per-VCF flags and tile offsets --
     // and the rows (ROC, scalars, per-truth sums: 96 MB of span histograms to sum) go to the second stream beside it.
     const bool split = finalize_split_on() && nch == 1 && b->ev_sync[0] != nullptr;
@@ -1065,7 +1099,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
         // tables of k_classify_hash otherwise (QM_JOIN=hash: always)
         if (direct) launch_join_direct(H, i1 - i0, lb_all, nbk_all, aux);
         else launch_classify_hash(H, i1 - i0, aux);
-        if (xstream && !getenv("QM_XJ_SKIP")) launch_join_ext(H, i1 - i0, nbk_all, aux);   // (QM_XJ_SKIP: debugging only, results wrong)
+        if (xstream) launch_join_ext(H, i1 - i0, nbk_all, aux);
       }
       i0 = i1;
     }
@@ -1360,63 +1394,88 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
 // re-derive tile offsets + compaction for every VCF (cheap: masks only)
 static int rescan_and_compact(qm_batch* b, hipStream_t st);
 
+// The VCFs found out of order, redone: by size on the two-level bucket path (kind 2), the bucket path (1) or the radix sort (0),
+// in chunks of <= 2^28 records.  posor[v]: the position bits the optimistic pass saw in VCF v.
+static int redo_unsorted(qm_batch* b, const std::vector<int>& todo, const std::vector<uint32_t>& posor, hipStream_t st) {
+  // the VCFs the bucket path takes (by size: a VCF costs it 256 workgroups and 256 rows whatever it holds, and its
+  // buckets hold 8 192 records at most) in chunks of their own, the others on the radix sort
+  std::vector<int> part[3];
+  for (int v : todo) {
+    const int64_t n = b->L.vcfs[(size_t)v].n;
+    const bool force2 = getenv("QM_BUCKET2") && atoi(getenv("QM_BUCKET2")) == 2 && bucket2_takes(b, n);
+    part[force2 ? 2 : bucket_path_takes(b, n) ? 1 : bucket2_takes(b, n) ? 2 : 0].push_back(v);
+  }
+  for (int kind = 2; kind >= 0; --kind) {
+    std::vector<int> chunk;
+    int64_t chunk_n = 0;
+    for (size_t i = 0; i <= part[kind].size(); ++i) {
+      const bool flush = i == part[kind].size() || (!chunk.empty() && chunk_n + b->L.vcfs[(size_t)part[kind][i]].n > SORT_CHUNK_RECORDS) ||
+                         (kind >= 1 && chunk.size() >= 4096);   // 256 rows of 1.5 KB and >= 1 MB of bucket regions per VCF: bounded per chunk
+      if (flush && !chunk.empty()) {
+        int rc = QM_OK;
+        bool taken = false;
+        if (kind == 2) {
+          rc = bucket2_chunk(b, chunk, st, b->last_global, &taken);
+          if (rc == QM_OK && !taken) { b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += (int64_t)chunk.size(); rc = sort_chunk(b, chunk, st, b->last_global, posor, false); b->path_stats[QM_PATH_RADIX] -= (int64_t)chunk.size(); }
+        } else {
+          rc = sort_chunk(b, chunk, st, b->last_global, posor, kind == 1);
+        }
+        if (rc != QM_OK) return rc;
+        chunk.clear();
+        chunk_n = 0;
+      }
+      if (i < part[kind].size()) { chunk.push_back(part[kind][i]); chunk_n += b->L.vcfs[(size_t)part[kind][i]].n; }
+    }
+  }
+  return QM_OK;
+}
+
 extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
   if (!b || !b->ran) return fail(QM_E_STATE, "qm_batch_finish: nothing was run");
   qm_ctx* c = b->ctx;
   HIPCHK(hipSetDevice(c->dev));
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
-  HIPCHK(hipStreamSynchronize(st));
-  if (b->finished) return QM_OK;
-  if (b->h_summary && *reinterpret_cast<volatile uint32_t*>(b->h_summary) == 0u) {   // no VCF of the run carries a flag: nothing to read back
-    b->finished = true;
-    return QM_OK;
-  }
-  std::vector<uint32_t> fl((size_t)b->n_vcf), posor((size_t)b->n_vcf);
-  HIPCHK(hipMemcpy(fl.data(), b->vcf_flags, 4 * fl.size(), hipMemcpyDeviceToHost));
-  std::vector<int> todo;
-  for (int v = 0; v < b->n_vcf; ++v) {
-    if (fl[(size_t)v] & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", v);
-    if (fl[(size_t)v] & SPANF_RUNLIMIT)
-      return fail(QM_E_LIMIT, "VCF %d repeats one position more than %d times between equal alleles (allele-extended de-duplication limit)", v, 1 << 14);
-    if (fl[(size_t)v] & SPANF_UNSORTED) todo.push_back(v);
-  }
+  if (b->finished) { HIPCHK(hipStreamSynchronize(st)); return QM_OK; }
   for (auto& x : b->path_stats) x = 0;
-  b->path_stats[QM_PATH_UNSORTED] = (int64_t)todo.size();
-  if (!todo.empty()) {
-    HIPCHK(hipMemcpy(posor.data(), b->vcf_posor, 4 * posor.size(), hipMemcpyDeviceToHost));
-    // the VCFs the bucket path takes (by size: a VCF costs it 256 workgroups and 256 rows whatever it holds, and its
-    // buckets hold 8 192 records at most) in chunks of their own, the others on the radix sort
-    // kind 2: too large for 256 buckets -- two levels (bucket2_chunk); 1: the bucket path; 0: the radix sort
-    std::vector<int> part[3];
-    for (int v : todo) {
-      const int64_t n = b->L.vcfs[(size_t)v].n;
-      const bool force2 = getenv("QM_BUCKET2") && atoi(getenv("QM_BUCKET2")) == 2 && bucket2_takes(b, n);
-      part[force2 ? 2 : bucket_path_takes(b, n) ? 1 : bucket2_takes(b, n) ? 2 : 0].push_back(v);
+  std::vector<uint32_t> posor((size_t)b->n_vcf, 0u);
+  bool redone = false;
+  if (b->run_used_known) {
+    // the VCFs known to be out of order: their bucket path goes onto the stream behind the run, before anything is waited for
+    std::vector<int> kn;
+    for (int v = 0; v < b->n_vcf; ++v) if (b->known[(size_t)v]) { kn.push_back(v); posor[(size_t)v] = b->known_posor[(size_t)v]; }
+    b->path_stats[QM_PATH_UNSORTED] += (int64_t)kn.size();
+    const int rc = redo_unsorted(b, kn, posor, st);
+    if (rc != QM_OK) { forget_known(b, -1); return rc; }
+    redone = !kn.empty();
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  std::vector<int> todo;
+  if (!b->h_summary || *reinterpret_cast<volatile uint32_t*>(b->h_summary) != 0u) {   // else: no VCF of the run carries a flag nobody knew of
+    std::vector<uint32_t> fl((size_t)b->n_vcf);
+    HIPCHK(hipMemcpy(fl.data(), b->vcf_flags, 4 * fl.size(), hipMemcpyDeviceToHost));
+    for (int v = 0; v < b->n_vcf; ++v) {
+      if (fl[(size_t)v] & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", v);
+      if (fl[(size_t)v] & SPANF_RUNLIMIT)
+        return fail(QM_E_LIMIT, "VCF %d repeats one position more than %d times between equal alleles (allele-extended de-duplication limit)", v, 1 << 14);
+      if ((fl[(size_t)v] & SPANF_UNSORTED) && !(b->run_used_known && b->known[(size_t)v])) todo.push_back(v);
     }
-    for (int kind = 2; kind >= 0; --kind) {
-      std::vector<int> chunk;
-      int64_t chunk_n = 0;
-      for (size_t i = 0; i <= part[kind].size(); ++i) {
-        const bool flush = i == part[kind].size() || (!chunk.empty() && chunk_n + b->L.vcfs[(size_t)part[kind][i]].n > SORT_CHUNK_RECORDS) ||
-                           (kind >= 1 && chunk.size() >= 4096);   // 256 rows of 1.5 KB and >= 1 MB of bucket regions per VCF: bounded per chunk
-        if (flush && !chunk.empty()) {
-          int rc = QM_OK;
-          bool taken = false;
-          if (kind == 2) {
-            rc = bucket2_chunk(b, chunk, st, b->last_global, &taken);
-            if (rc == QM_OK && !taken) { b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += (int64_t)chunk.size(); rc = sort_chunk(b, chunk, st, b->last_global, posor, false); b->path_stats[QM_PATH_RADIX] -= (int64_t)chunk.size(); }
-          } else {
-            rc = sort_chunk(b, chunk, st, b->last_global, posor, kind == 1);
-          }
-          if (rc != QM_OK) return rc;
-          chunk.clear();
-          chunk_n = 0;
-        }
-        if (i < part[kind].size()) { chunk.push_back(part[kind][i]); chunk_n += b->L.vcfs[(size_t)part[kind][i]].n; }
-      }
+    if (!todo.empty()) {
+      std::vector<uint32_t> po((size_t)b->n_vcf);
+      HIPCHK(hipMemcpy(po.data(), b->vcf_posor, 4 * po.size(), hipMemcpyDeviceToHost));
+      for (int v : todo) posor[(size_t)v] = po[(size_t)v];
+      b->path_stats[QM_PATH_UNSORTED] += (int64_t)todo.size();
+      const int rc = redo_unsorted(b, todo, posor, st);
+      if (rc != QM_OK) return rc;
+      redone = true;
     }
-    int rc = rescan_and_compact(b, st);
+  }
+  if (redone) {
+    const int rc = rescan_and_compact(b, st);
     if (rc != QM_OK) return rc;
+  }
+  if (memo_on() && !todo.empty()) {
+    if (b->known.empty()) { b->known.assign((size_t)b->n_vcf, (uint8_t)0); b->known_posor.assign((size_t)b->n_vcf, 0u); }
+    for (int v : todo) if (!b->known[(size_t)v]) { b->known[(size_t)v] = 1; b->known_posor[(size_t)v] = posor[(size_t)v]; ++b->n_known; b->known_dirty = true; }
   }
   b->finished = true;
   return QM_OK;

@@ -115,6 +115,8 @@ struct ClassifyParams {
   int32_t span_base;   // first span of this launch (the batch is run in a few span ranges so that compaction overlaps classification)
   uint64_t* zero_acc;  // or null: the per-truth sums k_finalize adds to, cleared by the first wave of this launch (saves a memset node per run)
   int32_t zero_words;
+  const uint8_t* known;   // or null: known[v] != 0 = an earlier run of this batch found VCF v out of order and its columns have not changed since:
+                          // its spans return at once (their rows still say so) and qm_batch_finish sends it down the bucket path without asking
 };
 
 struct FinalizeParams {
@@ -136,6 +138,7 @@ struct FinalizeParams {
   int32_t vcf_base;      // first VCF of this launch
   uint32_t* flag_summary; // or null: host-mapped word, set to 1 if any VCF of the launch carries a flag
   int32_t parts;          // 1 = flags and tile offsets (what k_compact needs), 2 = ROC / scalars / per-truth sums, 3 = both
+  const uint8_t* known;   // or null (ClassifyParams.known): a VCF known to be out of order does not raise the summary for being out of order
 };
 
 struct CompactParams {

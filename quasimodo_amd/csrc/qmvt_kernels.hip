@@ -734,6 +734,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
   if (lane < 16) lds[L_FLUT + lane] = flag_info((uint32_t)lane);
   if (P.zero_acc && blockIdx.x == 0)
     for (int i = lane; i < P.zero_words; i += 64) P.zero_acc[i] = 0ull;
+  if (!PACKED && P.known && P.known[sp.vcf]) return;   // found out of order by an earlier run of the same columns: the span's rows still say so
   Acc A = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
   uint32_t acc_pass = 0, acc_tp = 0;  // wave-uniform
   uint32_t acc_tpr = 0;               // per lane, reduced at the end
@@ -1016,7 +1017,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
       if (P.vcf_posor) P.vcf_posor[v] = s_or;
       const uint32_t out = fl & (SPANF_UNSORTED | SPANF_BADPOS | SPANF_RUNLIMIT | SPANF_OVERFLOW);
       P.vcf_flags[v] = out;
-      if (out && P.flag_summary) __hip_atomic_store(P.flag_summary, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-mapped: tells qm_batch_finish that the per-VCF flags are worth a copy
+      if (out && P.flag_summary && !(out == SPANF_UNSORTED && P.known && P.known[v])) __hip_atomic_store(P.flag_summary, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-mapped: tells qm_batch_finish that the per-VCF flags are worth a copy
     }
   }
   if (!offsets) return;

@@ -769,3 +769,56 @@ def test_synthetic_workload_is_what_the_specification_says(engine, shuffled, pct
             assert np.array_equal(g, w), (v, k)
     b.close()
     engine.truth_release(tid)
+
+
+@pytest.mark.parametrize("memo", ["1", "0"], ids=["memo", "no-memo"])
+def test_a_batch_remembers_which_vcfs_were_out_of_order_until_their_columns_change(engine, oracle, monkeypatch, memo):
+    """What a finish found stays known to the batch while the columns stay the same: on the next run the VCFs found out of order
+    are not streamed by the optimistic pass and their bucket path (or radix sort) is queued without first waiting for the flags.
+    The answers must be the ones of a fresh batch -- after a plain repeat, and after uploads that turn an unsorted VCF into a
+    sorted one, a sorted one into an unsorted one, and replace an unsorted one by another unsorted one (QM_MEMO=0: the same
+    without the memory)."""
+    monkeypatch.setenv("QM_MEMO", memo)
+    rng = np.random.default_rng(31)
+    L = 500_000
+    truth = random_truth(rng, 20_000, L)
+    tid = engine.truth_load(*truth)
+    sizes = [40_000, 3_000, 50_000, 20_000, 0, 70_000]
+    order = [False, False, True, True, True, False]      # sorted?
+    cols = [random_columns(rng, n, L, truth, sorted_=s) for n, s in zip(sizes, order)]
+    b = engine.batch(sizes, [tid] * len(sizes))
+
+    def check_all(n_unsorted):
+        roc, sc = b.roc(), b.scalars()
+        want = np.zeros((3, 256), np.uint64)
+        for v, c in enumerate(cols):
+            cls, oroc, osc = oracle.classify_columns(*c, *truth)
+            assert np.array_equal(b.cls(v), cls), v
+            assert np.array_equal(roc[v], oroc), v
+            assert [int(x) for x in sc[v, :5]] == [osc[k] for k in ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R")], v
+            idx = b.idx(v)
+            assert np.array_equal(idx[:osc["tp_lines"]], np.nonzero(cls == 3)[0]) and np.array_equal(idx[len(cls) - osc["fp_lines"]:], np.nonzero(cls == 1)[0])
+            want += oroc
+        assert np.array_equal(b.global_counts()[tid], want)
+        assert b.path_stats()["unsorted"] == n_unsorted
+
+    for v, c in enumerate(cols):
+        b.upload(v, *c)
+    for _ in range(3):                 # the first finish finds them, the others know
+        b.run(); b.finish()
+        check_all(3)
+    cols[0] = random_columns(rng, sizes[0], L, truth, sorted_=True)    # unsorted -> sorted
+    cols[2] = random_columns(rng, sizes[2], L, truth, sorted_=False)   # sorted -> unsorted
+    cols[5] = random_columns(rng, sizes[5], L, truth, sorted_=False)   # unsorted -> other unsorted records
+    for v in (0, 2, 5):
+        b.upload(v, *cols[v])
+    for _ in range(2):
+        b.run(); b.finish()
+        check_all(3)
+    cols[1] = random_columns(rng, sizes[1], L, truth, sorted_=True)    # the last small one in order too: only the two large ones remain
+    b.upload(1, *cols[1])
+    for _ in range(2):
+        b.run(); b.finish()
+        check_all(2)
+    b.close()
+    engine.truth_release(tid)
