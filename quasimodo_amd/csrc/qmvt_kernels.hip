@@ -2332,13 +2332,15 @@ constexpr int DJ_THREADS = 512;
 constexpr int DJ_TRUTH_MAX = 1024;   // staged truth keys per bucket (whole cells of the coarse position index)
 constexpr int DJ_NK_LOG2 = 7;        // exact set of the kept records without a comparable key
 constexpr uint32_t DJ_RING = 64;     // parked records per wave
+constexpr int DJ_CI_LOG2 = 10;       // coarse index over the staged truth keys: one entry per 2^10 keys (64 positions)
 template <int LB>
 __global__ __launch_bounds__(DJ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_join_direct(HashParams P) {
   constexpr int PER = 16;                                // records per thread at most: four trips of four
   constexpr int BM_WORDS = LB >= 7 ? (1 << (LB - 5)) : 4;
   static_assert(HB_MAX_RECORDS <= DJ_THREADS * PER && BM_WORDS % 4 == 0, "table sizes");
   __shared__ __attribute__((aligned(16))) uint32_t s_bm[BM_WORDS];   // bit v: key kbase + v is a truth key, or (second pass) a kept key outside the truth set
-  __shared__ uint32_t s_tk[DJ_TRUTH_MAX];            // the staged truth keys, sorted (absolute keys)
+  __shared__ uint32_t s_tk[DJ_TRUTH_MAX + 2];        // the staged truth keys, sorted (absolute keys); two more so that a look-up may read past its key
+  __shared__ uint16_t s_ci[LB > DJ_CI_LOG2 ? 1 << (LB - DJ_CI_LOG2) : 1];   // per block of 2^DJ_CI_LOG2 keys: index of its first staged truth key (written for blocks that hold one)
   __shared__ uint32_t s_ts[DJ_TRUTH_MAX];            // per staged key: best bin + 1 of a '.'-ID match
   __shared__ uint32_t s_tf[DJ_TRUTH_MAX / 32];       // matched by a kept record (ID ignored)
   __shared__ uint32_t s_htp[130], s_hfp[130];        // TP / FP histograms: slot = bin + 1 (slot 0 swallows records without a bin), two u16 slots per dword
@@ -2395,24 +2397,58 @@ __global__ __launch_bounds__(DJ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
   const int tn_all = R.tn;
   over |= tn_all > DJ_TRUTH_MAX ? 1u : 0u;
   const int tn = over ? 0 : tn_all;
-  const uint32_t lcap = 31u - (uint32_t)__clz(cap);            // cap is a power of two >= 4
-  const uint32_t nslots = (HB_SUBS * cap) >> 2;
-  const int ntrips = (int)((nslots + DJ_THREADS - 1) / DJ_THREADS) < PER / 4 ? (int)((nslots + DJ_THREADS - 1) / DJ_THREADS) : PER / 4;
+  // The threads walk the FILLED part of the bucket's sub-regions, four consecutive entries (32 bytes) of one sub-region at a time:
+  // quad q of the bucket is quad q - qoff[k] of sub-region k.  (The regions are about half full; walking their whole capacity
+  // cost every record two slots' worth of instructions, and this kernel is bound by instruction issue: 71 % VALU busy.)
+  uint32_t qoff[HB_SUBS + 1];   // wave-uniform
+  qoff[0] = 0u;
+#pragma unroll
+  for (int k = 0; k < HB_SUBS; ++k) qoff[k + 1] = qoff[k] + ((nsub[k] + 3u) >> 2);
+  const uint32_t nquads = qoff[HB_SUBS];
+  over |= nquads > (uint32_t)(DJ_THREADS * PER / 4) ? 1u : 0u;   // (a bucket filled to its last entries with ragged sub-regions: the fallback's)
+  const int ntrips_dense = (int)((nquads + DJ_THREADS - 1) / DJ_THREADS) < PER / 4 ? (int)((nquads + DJ_THREADS - 1) / DJ_THREADS) : PER / 4;
+#ifndef DJ_SPARSE_WALK
+  const int ntrips = ntrips_dense;
+#endif
   // every trip of the thread is in flight before anything else happens: with two workgroups per CU nothing hides a memory
   // round trip (3 000+ cycles under load), and a workgroup that fetched trip by trip paid one per trip
   v4u ea[PER / 4], eb[PER / 4];
   uint32_t nv[PER / 4];      // valid entries of the trip's four
   const v4u z4 = {0u, 0u, 0u, 0u};
+#ifdef DJ_SPARSE_WALK   // (A/B builds: the walk over the regions' whole capacity)
+  const uint32_t lcap_ = 31u - (uint32_t)__clz(cap);
+  const uint32_t nslots_ = (HB_SUBS * cap) >> 2;
+  const int ntrips_ = (int)((nslots_ + DJ_THREADS - 1) / DJ_THREADS) < PER / 4 ? (int)((nslots_ + DJ_THREADS - 1) / DJ_THREADS) : PER / 4;
+#define ntrips ntrips_
+#endif
   auto fetch = [&](int g, int buf) {
+#ifdef DJ_SPARSE_WALK
     const uint32_t slot = (uint32_t)g * DJ_THREADS + (uint32_t)tid;
-    const uint32_t e0 = slot << 2, sb = e0 >> lcap, w = e0 & (cap - 1u);
-    uint32_t n = 0;
+    const uint32_t e0 = slot << 2, sb = e0 >> lcap_, w_ = e0 & (cap - 1u);
+    uint32_t n_ = 0;
 #pragma unroll
-    for (int k = 0; k < HB_SUBS; ++k) n = sb == (uint32_t)k ? nsub[k] : n;
+    for (int k = 0; k < HB_SUBS; ++k) n_ = sb == (uint32_t)k ? nsub[k] : n_;
     ea[buf] = z4; eb[buf] = z4; nv[buf] = 0u;
-    if (slot < nslots && w < n && !over) {
+    if (slot < nslots_ && w_ < n_ && !over) {
+      nv[buf] = n_ - w_ < 4u ? n_ - w_ : 4u;
+      const gv4p src = g_ent + (e0 >> 1);
+      ea[buf] = __builtin_nontemporal_load(src);
+      eb[buf] = __builtin_nontemporal_load(src + 1);
+    }
+    return;
+#endif
+    const uint32_t q = (uint32_t)g * DJ_THREADS + (uint32_t)tid;
+    uint32_t base = 0u, n = nsub[0], reg = 0u;
+#pragma unroll
+    for (int k = 1; k < HB_SUBS; ++k) {
+      const bool ge = q >= qoff[k];
+      base = ge ? qoff[k] : base; n = ge ? nsub[k] : n; reg = ge ? (uint32_t)k * cap : reg;
+    }
+    const uint32_t w = (q - base) << 2;
+    ea[buf] = z4; eb[buf] = z4; nv[buf] = 0u;
+    if (g < ntrips && q < nquads && !over) {
       nv[buf] = n - w < 4u ? n - w : 4u;
-      const gv4p src = g_ent + (e0 >> 1);   // two entries per 16 bytes
+      const gv4p src = g_ent + ((reg + w) >> 1);   // two entries per 16 bytes
       ea[buf] = __builtin_nontemporal_load(src);
       eb[buf] = __builtin_nontemporal_load(src + 1);
     }
@@ -2420,9 +2456,11 @@ __global__ __launch_bounds__(DJ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
   DJ_TICK(1);
 #pragma unroll
   for (int g = 0; g < PER / 4; ++g) fetch(g, g);   // (trips beyond the bucket's capacity load nothing)
-  uint32_t tkey0 = 0xffffffffu, tkey1 = 0xffffffffu;
+  uint32_t tkey0 = 0xffffffffu, tkey1 = 0xffffffffu, tprev0 = 0u, tprev1 = 0u;   // (tprev: the key in front, for the coarse index; 0 is below every bucket's first key that matters)
   if (tid < tn) tkey0 = g_tkeys[tid];
   if (tid + DJ_THREADS < tn) tkey1 = g_tkeys[tid + DJ_THREADS];
+  if (tid > 0 && tid < tn) tprev0 = g_tkeys[tid - 1];
+  if (tid + DJ_THREADS < tn) tprev1 = g_tkeys[tid + DJ_THREADS - 1];
   const int nw4 = (int)(((1u << shift) + 127u) >> 7);        // 16-byte pieces of the map in use
   if (tid < 10) s_c[tid] = tid == 4 ? (segfl | (over ? SPANF_OVERFLOW : 0u)) : 0u;
   DJ_TICK(2);
@@ -2438,6 +2476,11 @@ __global__ __launch_bounds__(DJ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
       const bool in = j < tn && k >= kbase && k <= klast;
       if (j < tn) s_tk[j] = k;
       if (in) atomicOr(&s_bm[(k - kbase) >> 5], 1u << ((k - kbase) & 31u));
+      {   // the first key of its block of 2^DJ_CI_LOG2 keys names itself in the coarse index (the slice is sorted)
+        const uint32_t kp = h ? tprev1 : tprev0;
+        const bool pin = j > 0 && kp >= kbase;                      // (kp <= k <= klast)
+        if (in && (!pin || ((kp - kbase) >> DJ_CI_LOG2) != ((k - kbase) >> DJ_CI_LOG2))) s_ci[(k - kbase) >> DJ_CI_LOG2] = (uint16_t)j;
+      }
       nin += (uint32_t)popc64(ballot64(in));
     }
     if ((tid & 63) == 0 && nin) atomicAdd(&s_c[5], nin);
@@ -2462,7 +2505,12 @@ __global__ __launch_bounds__(DJ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
     const bool kept = (inf & I_PASS) != 0u;
     const bool hit = ((s_bm[v >> 5] >> (v & 31u)) & 1u) && !(inf & I_NOKEY);
     if (hit) {
-      const int j = lds_lower_bound(s_tk, tn, ttop, kbase + v);   // the key IS there
+      // the key IS among the staged ones: at or behind the first key of its block (most blocks hold one or two)
+      int j = (int)s_ci[v >> DJ_CI_LOG2];
+      {
+        const uint32_t k0 = s_tk[j], k1 = s_tk[j + 1];
+        if (k0 != kbase + v) j = k1 == kbase + v ? j + 1 : lds_lower_bound(s_tk, tn, ttop, kbase + v);
+      }
       if ((inf & I_IDDOT) && b1) atomicMax(&s_ts[j], b1);
       if (kept) atomicOr(&s_tf[j >> 5], 1u << (j & 31));
     }
@@ -2478,10 +2526,12 @@ __global__ __launch_bounds__(DJ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
     const uint32_t lane = (uint32_t)tid & 63u;
     uint32_t head = 0, tail = 0;                                   // wave-uniform
     auto drain = [&](uint32_t n) {                                 // the first n <= 64 parked records, one per lane
+#ifndef DJ_NO_DRAIN   // (timing builds only)
       if (lane < n) {
         const uint2 e = ring[(head + lane) & (DJ_RING - 1u)];
         settle(e.x, e.y);
       }
+#endif
       head += n;
     };
     // the map reads of all the thread's records first, in flight together (as the compiler orders the loop below, every read
@@ -2496,7 +2546,11 @@ __global__ __launch_bounds__(DJ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
         for (int u = 0; u < 4; ++u) {
           const uint32_t elo_ = u == 0 ? ea[g][0] : u == 1 ? ea[g][2] : u == 2 ? eb[g][0] : eb[g][2];
           vq[4 * g + u] = elo_ & 0xffffffu;
-          w[4 * g + u] = s_bm[vq[4 * g + u] >> 5];
+          w[4 * g + u] = 0u;
+        }
+        if (g < ntrips) {                                          // wave-uniform
+#pragma unroll
+          for (int u = 0; u < 4; ++u) w[4 * g + u] = s_bm[vq[4 * g + u] >> 5];
         }
       }
 #pragma unroll
@@ -2562,8 +2616,15 @@ __global__ __launch_bounds__(DJ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
   __syncthreads();   // every read of a truth bit is done: the map now also takes the kept keys outside the truth set
 #ifndef DJ_NO_PASS2
 #pragma unroll
-  for (int k = 0; k < PER; ++k)
-    if ((cand >> k) & 1u) atomicOr(&s_bm[vq[k] >> 5], 1u << (vq[k] & 31u));   // no return value: ds_or_b32
+  for (int g = 0; g < PER / 4; ++g) {
+    if (g < ntrips) {                                              // wave-uniform
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = 4 * g + u;
+        if ((cand >> k) & 1u) atomicOr(&s_bm[vq[k] >> 5], 1u << (vq[k] & 31u));   // no return value: ds_or_b32
+      }
+    }
+  }
 #endif
   uint32_t fpr_nk = 0;
   if (ballot64(candnk != 0u)) {   // rare: keyless records are keys of their own, in an exact set, every insertion reserved
@@ -2638,6 +2699,9 @@ __global__ __launch_bounds__(DJ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
   DJ_TICK(11);
   __syncthreads();
   DJ_FLUSH();
+#ifdef DJ_SPARSE_WALK
+#undef ntrips
+#endif
 }
 
 // ---------------------------------------------------------------------------
