@@ -458,9 +458,9 @@ struct qm_batch {
   bool run_used_known = false;        // the run in flight was launched with d_known
 };
 
-static bool memo_on() {
-  static const bool on = !getenv("QM_MEMO") || atoi(getenv("QM_MEMO")) != 0;
-  return on;
+static bool memo_on() {   // read at every run / finish: bench.py times a batch with and without its memory in one process
+  const char* e = getenv("QM_MEMO");
+  return !e || atoi(e) != 0;
 }
 static void forget_known(qm_batch* b, int v) {   // v < 0: every VCF
   if (b->known.empty() || b->n_known == 0) return;

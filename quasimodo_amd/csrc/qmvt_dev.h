@@ -271,7 +271,10 @@ struct HashRowX {
   uint32_t kbase;
 };
 constexpr int XJ_TRUTH_MAX = 1024;   // staged truth entries per bucket
-constexpr int XJ_LIST_MAX = 1024;    // records of a bucket that need the exact comparison (positions claimed more than once, keyless records)
+#ifndef XJ_LIST_MAX_
+#define XJ_LIST_MAX_ 1024
+#endif
+constexpr int XJ_LIST_MAX = XJ_LIST_MAX_;    // records of a bucket that need the exact comparison (positions claimed more than once, keyless records)
 struct HashParams {
   const SortSeg* segs;
   const HashRow* rows;        // [n_seg * 256]

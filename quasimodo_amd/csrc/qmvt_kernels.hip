@@ -1961,11 +1961,24 @@ __device__ __forceinline__ uint32_t wave_reserve(uint32_t* ctr, bool want) {
 #define HB_TICK(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(hb_prof + (i), (uint32_t)((t_ - hb_t) >> 4)); hb_t = t_; } } while (0)
 // the same kept in LDS and flushed once, at the end of the workgroup, into one of 64 replicas (k_join_direct: twelve atomics of
 // every workgroup on the same twelve words doubled the kernel's time and with it every share)
-#define DJ_TICK(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); s_prof[i] = (uint32_t)((t_ - hb_t) >> 4); hb_t = t_; } } while (0)
-#define DJ_FLUSH() do { if (threadIdx.x < 16) atomicAdd(hb_prof + 16 * (1 + (blockIdx.x & 63)) + threadIdx.x, threadIdx.x == 0 ? 1u : s_prof[threadIdx.x]); } while (0)
+#define LDS_TICK(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); s_prof[i] = (uint32_t)((t_ - hb_t) >> 4); hb_t = t_; } } while (0)
+#define LDS_FLUSH() do { if (threadIdx.x < 16) atomicAdd(hb_prof + 16 * (1 + (blockIdx.x & 63)) + threadIdx.x, threadIdx.x == 0 ? 1u : s_prof[threadIdx.x]); } while (0)
+#ifdef XJ_PROFILE   // the clocks of k_join_ext instead of k_join_direct's (they share the counters)
+#define DJ_TICK(i) do { } while (0)
+#define DJ_FLUSH() do { } while (0)
+#define XJ_TICK(i) LDS_TICK(i)
+#define XJ_FLUSH() LDS_FLUSH()
+#else
+#define DJ_TICK(i) LDS_TICK(i)
+#define DJ_FLUSH() LDS_FLUSH()
+#define XJ_TICK(i) do { } while (0)
+#define XJ_FLUSH() do { } while (0)
+#endif
 #else
 #define DJ_TICK(i) do { } while (0)
 #define DJ_FLUSH() do { } while (0)
+#define XJ_TICK(i) do { } while (0)
+#define XJ_FLUSH() do { } while (0)
 #define HB_TICK(i) do { } while (0)
 #endif
 // Waves of a bucket's workgroup meet at three barriers only and walk their records independently in between: versions that
@@ -2717,7 +2730,7 @@ __global__ __launch_bounds__(DJ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
 //     the keyless ones go to a list and are compared all against all -- exact, and free of the races a hash set of 12-byte
 //     keys would have.
 // Histograms, counts, scalars: a row like k_join_direct's (every count of the two streams is additive: a key belongs to one).
-// 512 threads, 51 KB of LDS; what does not fit (1 024 truth entries, 1 024 listed records) flags the VCF for the radix sort.
+// 512 threads, 43 KB of LDS (three workgroups per CU); what does not fit (1 024 truth entries, 1 024 listed records) flags the VCF for the radix sort.
 // ---------------------------------------------------------------------------
 constexpr int XJ_THREADS = 512;
 constexpr int XJ_TRIPS = HB_MAX_RECORDS / XJ_THREADS;   // one entry per thread and trip
@@ -2727,15 +2740,25 @@ __global__ __launch_bounds__(XJ_THREADS) void k_join_ext(HashParams P) {
   __shared__ uint32_t s_xk[XJ_TRUTH_MAX], s_xr[XJ_TRUTH_MAX], s_xa[XJ_TRUTH_MAX], s_ts[XJ_TRUTH_MAX];
   __shared__ uint32_t s_tf[XJ_TRUTH_MAX / 32];
   __shared__ uint32_t s_hit[HB_MAX_RECORDS / 32];            // entry e of the bucket hit a truth entry exactly
-  __shared__ uint32_t s_lp[XJ_LIST_MAX], s_lr[XJ_LIST_MAX], s_la[XJ_LIST_MAX];
-  __shared__ __attribute__((aligned(16))) uint4 s_ring[(XJ_THREADS / 64) * 64];
-  __shared__ uint32_t s_ringe[(XJ_THREADS / 64) * 64];
+  // the waves' rings (pass 1) and the list (pass 3) take turns in one array: with both, the workgroup's 52.7 KB came to two per
+  // CU as the hardware allots LDS, and the kernel's time follows the number of workgroups in flight (0.79 -> 0.58 ms)
+  static_assert(3 * XJ_LIST_MAX >= 5 * XJ_THREADS, "the rings fit the list's room");
+  __shared__ __attribute__((aligned(16))) uint32_t s_un[3 * XJ_LIST_MAX];
+  uint32_t* const s_lp = s_un; uint32_t* const s_lr = s_un + XJ_LIST_MAX; uint32_t* const s_la = s_un + 2 * XJ_LIST_MAX;
+  uint4* const s_ring = reinterpret_cast<uint4*>(s_un);        // [(XJ_THREADS / 64) * 64]
+  uint32_t* const s_ringe = s_un + 4 * XJ_THREADS;             // [(XJ_THREADS / 64) * 64]
   __shared__ uint32_t s_htp[130], s_hfp[130], s_hu[128];
   __shared__ uint32_t s_c[10];   // kept, TP lines, distinct kept keys outside the truth set, matched truth entries, flags, -, listed records, top-bin TP, top-bin FP, -
   const int tid = (int)threadIdx.x;
   const int d = (int)blockIdx.x;
   const int seg_id = (int)blockIdx.y + P.seg_base;
   const size_t row = (size_t)seg_id * HB_BUCKETS + (size_t)d;
+#ifdef HB_PROFILE
+  uint32_t* hb_prof = const_cast<uint32_t*>(P.cursor) + (size_t)P.n_seg * HB_BUCKETS * HB_SUBS + (size_t)P.n_seg;
+  unsigned long long hb_t = __builtin_amdgcn_s_memtime();
+  __shared__ uint32_t s_prof[16];
+  if (threadIdx.x < 16) s_prof[threadIdx.x] = 0u;
+#endif
   const HashRowX R = P.xrows[row];
   const uint32_t* cur = P.xcursor + row * HB_SUBS;
   const size_t orow = (size_t)seg_id * (size_t)P.out_stride + (size_t)HB_BUCKETS + (size_t)d;   // the second stream's rows follow the first's
@@ -2783,6 +2806,18 @@ __global__ __launch_bounds__(XJ_THREADS) void k_join_ext(HashParams P) {
     for (int q = 0; q < HB_SUBS; ++q) b0 = k == (uint32_t)q ? pre[q] : b0;
     return g_ent + ((size_t)k * cap + (size_t)(e - b0));
   };
+  // the first four trips' entries (all of them but for the fullest buckets) are asked for before anything else: they arrive while
+  // the truth slice is staged (asked for when pass 1 wanted them, a workgroup spent half its life waiting for them)
+  v4u q4[4];
+  auto ask = [&](int t0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      q4[u] = v4u{0u, 0u, 0u, 0u};
+      const uint32_t e = (uint32_t)(t0 + u) * XJ_THREADS + (uint32_t)tid;
+      if (t0 + u < ntrips && e < nrec) q4[u] = __builtin_nontemporal_load(entry_at(e));
+    }
+  };
+  ask(0);
   // ---- the truth entries of the bucket's positions: the sorted slice as it is; a bit per position that holds an extended one ----
   {
     const gu32p gk = (gu32p)R.xkeys;
@@ -2791,7 +2826,9 @@ __global__ __launch_bounds__(XJ_THREADS) void k_join_ext(HashParams P) {
     uint32_t k0 = 0, r0 = 0, a0 = 0, k1 = 0, r1 = 0, a1 = 0;
     if (tid < tn) { k0 = gk[tid]; r0 = (uint32_t)gr[tid]; a0 = (uint32_t)ga[tid]; }
     if (tid + XJ_THREADS < tn) { k1 = gk[tid + XJ_THREADS]; r1 = (uint32_t)gr[tid + XJ_THREADS]; a1 = (uint32_t)ga[tid + XJ_THREADS]; }
+    XJ_TICK(1);
     __syncthreads();   // the maps are clear
+    XJ_TICK(2);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int j = tid + h * XJ_THREADS;
@@ -2802,7 +2839,9 @@ __global__ __launch_bounds__(XJ_THREADS) void k_join_ext(HashParams P) {
       }
     }
   }
+  XJ_TICK(3);
   __syncthreads();
+  XJ_TICK(4);
   const int nb = P.n_bins;
   int ttop = 0;
   if (tn > 0) ttop = 1 << (31 - __clz(tn));
@@ -2841,14 +2880,18 @@ __global__ __launch_bounds__(XJ_THREADS) void k_join_ext(HashParams P) {
       }
       nring = 0;
     };
+    // four trips' entries are in flight together (trip by trip, every trip paid a memory round trip of its own)
 #pragma unroll
-    for (int t = 0; t < XJ_TRIPS; ++t) {
+    for (int t0 = 0; t0 < XJ_TRIPS; t0 += 4) {
+      if (t0 > 0 && t0 < ntrips) ask(t0);   // wave-uniform
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u;
       xs[t] = 0u;
       if (t < ntrips) {   // wave-uniform
         const uint32_t e = (uint32_t)t * XJ_THREADS + (uint32_t)tid;
         const bool valid = e < nrec;
-        v4u q = {0u, 0u, 0u, 0u};
-        if (valid) q = __builtin_nontemporal_load(entry_at(e));
+        const v4u q = q4[u];
         const uint32_t pr = (q[0] & 0xffffffu) >> 4;
         const uint32_t inf = (q[0] >> 24) | ((q[1] & 0x1fu) << 8);
         xs[t] = pr | (inf << 15) | (valid ? 1u << 28 : 0u);
@@ -2863,17 +2906,20 @@ __global__ __launch_bounds__(XJ_THREADS) void k_join_ext(HashParams P) {
         }
         nring += cnt;
       }
+      }
     }
     if (nring) drain();
   }
+  XJ_TICK(5);
   __syncthreads();
+  XJ_TICK(6);
   // ---- pass 2: histograms and counts (the hit bits are final); kept records outside the truth set claim their position ----
   uint32_t n_pass = 0, n_tp = 0, top_tp = 0, top_fp = 0;
   uint32_t fpm = 0, nkm = 0;   // bit t: the record of trip t is a kept key outside the truth set / the same without a comparable key
 #pragma unroll
   for (int t = 0; t < XJ_TRIPS; ++t) {
     const uint32_t x = xs[t];
-    if ((x >> 28) & 1u) {
+    if (t < ntrips && ((x >> 28) & 1u)) {
       const uint32_t e = (uint32_t)t * XJ_THREADS + (uint32_t)tid;
       const uint32_t pr = x & 0x7fffu, inf = (x >> 15) & 0x1fffu;
       const uint32_t hit = (s_hit[e >> 5] >> (e & 31u)) & 1u;
@@ -2894,11 +2940,14 @@ __global__ __launch_bounds__(XJ_THREADS) void k_join_ext(HashParams P) {
       nkm |= (kept & ~hit & ~keyed & 1u) << t;
     }
   }
+  XJ_TICK(7);
   __syncthreads();
+  XJ_TICK(8);
   // ---- pass 3: a record alone on its position is a distinct key; the others, and the keyless ones, are listed ----
   uint32_t fpr = 0;
 #pragma unroll
   for (int t = 0; t < XJ_TRIPS; ++t) {
+    if (t >= ntrips) break;   // wave-uniform
     const uint32_t pr = xs[t] & 0x7fffu;
     const bool mine = (fpm >> t) & 1u;
     const bool shared = mine && ((s_s2[pr >> 5] >> (pr & 31u)) & 1u);
@@ -2916,7 +2965,9 @@ __global__ __launch_bounds__(XJ_THREADS) void k_join_ext(HashParams P) {
       }
     }
   }
+  XJ_TICK(9);
   __syncthreads();
+  XJ_TICK(10);
   {
     const uint32_t m = s_c[6] < (uint32_t)XJ_LIST_MAX ? s_c[6] : (uint32_t)XJ_LIST_MAX;
     for (uint32_t i = (uint32_t)tid; i < m; i += XJ_THREADS) {   // all against all: the first of equal records counts
@@ -2958,6 +3009,11 @@ __global__ __launch_bounds__(XJ_THREADS) void k_join_ext(HashParams P) {
     uint32_t* sc = P.row_scal + orow * 8;
     sc[0] = s_c[0]; sc[1] = s_c[1]; sc[2] = s_c[0] - s_c[1]; sc[3] = s_c[3]; sc[4] = s_c[2]; sc[5] = s_c[4]; sc[6] = 0u; sc[7] = 0u;
   }
+  XJ_TICK(11);
+#ifdef XJ_PROFILE
+  __syncthreads();
+#endif
+  XJ_FLUSH();
 }
 
 // TP bits of the sorted scratch VCFs back to input order: only the records that ARE true positives
