@@ -10,6 +10,7 @@ cp "$(st ${TAG}shufx)" profiles/${R}_kernel_stats_shuffled_alleles.csv
 cp gpurun_out/${R}_pmc_per_launch.json profiles/${R}_pmc_per_launch.json
 cp gpurun_out/traffic.json profiles/traffic.json
 cp gpurun_out/${TAG}_pmc_shuffled.json profiles/${R}_pmc_shuffled.json
+cp gpurun_out/${TAG}_pmc_shuffled_alleles.json profiles/${R}_pmc_shuffled_alleles.json
 cp gpurun_out/${TAG}_shuffled_ext.log profiles/${R}_shuffled_ext.log
 cp gpurun_out/${TAG}_e2e.log profiles/${R}_e2e_files.log
 tail -1 gpurun_out/${TAG}_bench.json > profiles/${R}_bench_1gpu.json

@@ -12,6 +12,7 @@ mkdir -p gpurun_out/trace_${TAG}shuf3 gpurun_out/trace_${TAG}alle
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/trace_${TAG}shuf3 -- python3 $ROOT/tools/join_ab.py 16 10000000 50000000 1000000 > $ROOT/gpurun_out/${TAG}_trace_shuf3.log 2>&1)
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/trace_${TAG}alle -- python3 $ROOT/tools/run_once.py 256 6 0 30 > $ROOT/gpurun_out/${TAG}_trace_alle.log 2>&1)
 bash tools/pmc_shuffled.sh $TAG "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "VALUBusy SALUBusy VALUUtilization LdsUtil MemUnitStalled" "FETCH_SIZE" "WRITE_SIZE" > gpurun_out/${TAG}_pmc_shuffled.json 2> gpurun_out/${TAG}_pmc_shuffled.err
+PCT=30 bash tools/pmc_shuffled.sh $TAG "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "VALUBusy SALUBusy VALUUtilization LdsUtil MemUnitStalled" "FETCH_SIZE" "WRITE_SIZE" > gpurun_out/${TAG}_pmc_shuffled_alleles.json 2> gpurun_out/${TAG}_pmc_shuffled_alleles.err
 mkdir -p gpurun_out/trace_${TAG}shufx
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/trace_${TAG}shufx -- python3 $ROOT/tools/shuffled_ext.py 256 > $ROOT/gpurun_out/${TAG}_trace_shufx.log 2>&1)
 python3 tools/shuffled_ext.py 256 > gpurun_out/${TAG}_shuffled_ext.log 2>&1
