@@ -52,6 +52,7 @@ extern "C" {
 #define QM_E_IO (-7)
 #define QM_E_NONCANON (-8)  /* text input the engine refuses to guess about (strict mode) */
 #define QM_E_LIMIT (-9)     /* allele-extended batch: too many records at one position */
+#define QM_E_UNSORTED (-10) /* qm_bgzf_write_tbi: sequences not in blocks or positions stepping backwards (tabix refuses such a VCF too) */
 
 /* ---- allele-extended mode (QM_BATCH_ALLELES) ---------------------------------------------
  * BASELINE.json configs[4] (mixed SNP + indel, variable-length alleles).  The reference drops
@@ -380,6 +381,14 @@ int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs, int n_
  * most 64 KiB with a 'BC' extra field + the EOF member; zcat and tabix / htslib read it.  level -1 = zlib's default (6,
  * bgzip's default).  Atomic. */
 int qm_bgzf_write(const char* path, const uint8_t* data, size_t len, int level);
+
+/* `bgzip -c x.vcf > x.vcf.gz && tabix -p vcf x.vcf.gz` (rules/vis_eval_vcf.smk:36-37, 51-52, 67-68, 82-83): <path> as
+ * qm_bgzf_write writes it and <path>.tbi, the tabix index of its data lines (sequence = column 1, begin = POS - 1, end =
+ * begin + len(REF) or INFO's END=; bins of the UCSC scheme with a 16 kb linear index over BGZF virtual offsets; htslib's
+ * pseudo-bin 37450 per sequence; itself BGZF-compressed).  QM_E_UNSORTED when the sequences do not come in blocks or a
+ * position steps backwards -- `tabix` stops on such a file as well --, QM_E_RANGE for coordinates beyond 2^29, QM_E_INVAL
+ * for a data line without CHROM / POS; nothing is written then.  Atomic per file. */
+int qm_bgzf_write_tbi(const char* path, const uint8_t* data, size_t len, int level);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,8 @@ _SO = os.environ.get("QM_LIBQMVT") or os.path.join(_CSRC, "libqmvt.so")   # over
 QM_N_SCALARS = 8
 SCALAR_NAMES = ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R", "sorted", "n_records", "truth_unique")
 ERRORS = {-1: "QM_E_INVAL", -2: "QM_E_NODEVICE", -3: "QM_E_HIP", -4: "QM_E_NOMEM", -5: "QM_E_RANGE",
-          -6: "QM_E_STATE", -7: "QM_E_IO", -8: "QM_E_NONCANON", -9: "QM_E_LIMIT"}
+          -6: "QM_E_STATE", -7: "QM_E_IO", -8: "QM_E_NONCANON", -9: "QM_E_LIMIT", -10: "QM_E_UNSORTED"}
+QM_E_UNSORTED = -10
 QM_BATCH_ALLELES = 1
 QM_ABI_VERSION = 3
 
@@ -24,7 +25,7 @@ EXPORTS = (
     "qm_truth_size_ext", "qm_truth_synth_ext", "qm_batch_create_ext", "qm_classify_batch_ext",
     "qm_dict_create", "qm_dict_destroy", "qm_dict_size", "qm_allele_code", "qm_allele_spell", "qm_vcf_scan_ext", "qm_truth_scan_ext",
     "qm_bench_synth", "qm_truth_release", "qm_batch_n_truth",
-    "qm_bw_probe", "qm_bgzf_write", "qm_extract_files", "qm_extract_files_ex", "qm_batch_global_device", "qm_batch_path_stats", "qm_batch_upload_async", "qm_batch_get_masks", "qm_patterns_create", "qm_patterns_destroy", "qm_patterns_info", "qm_vcf_hostpath",
+    "qm_bw_probe", "qm_bgzf_write", "qm_bgzf_write_tbi", "qm_extract_files", "qm_extract_files_ex", "qm_batch_global_device", "qm_batch_path_stats", "qm_batch_upload_async", "qm_batch_get_masks", "qm_patterns_create", "qm_patterns_destroy", "qm_patterns_info", "qm_vcf_hostpath",
 )
 
 
@@ -159,6 +160,7 @@ def lib():
     L.qm_batch_upload_async.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
     L.qm_batch_get_masks.argtypes = [vp, i32, vp, vp]
     L.qm_bgzf_write.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, i32]
+    L.qm_bgzf_write_tbi.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, i32]
     L.qm_bw_probe.argtypes = [vp, i64, i32, C.POINTER(C.c_double)]
     L.qm_patterns_create.argtypes = [C.c_char_p, C.c_size_t, i32, i32]
     L.qm_patterns_create.restype = vp

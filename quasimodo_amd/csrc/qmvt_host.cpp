@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -1021,23 +1022,171 @@ size_t bgzf_block(const uint8_t* in, size_t n, int level, uint8_t* out /* >= 0x1
 
 }  // namespace
 
-extern "C" int qm_bgzf_write(const char* path, const uint8_t* data, size_t len, int level) {
-  if (!path || (!data && len) || level < -1 || level > 9) return QM_E_INVAL;
-  static std::atomic<unsigned> serial{0};
-  const std::string tmp = std::string(path) + ".tmp." + std::to_string((long)getpid()) + "." + std::to_string(serial.fetch_add(1));
-  FILE* fh = fopen(tmp.c_str(), "wb");
-  if (!fh) return QM_E_IO;
+// ---------------------------------------------------------------------------
+// Tabix index of a BGZF-compressed VCF (`tabix -p vcf`, rules/vis_eval_vcf.smk:37,52,68,83; format: the tabix paper's
+// supplement / htslib's tbx.c + hts.c, restated): UCSC binning with a 16 kb linear index (min_shift 14, 5 levels) over
+// BGZF virtual offsets (compressed offset of the block << 16 | offset inside the block).  Per data line: sequence = column 1,
+// begin = POS - 1, end = begin + len(REF), or INFO's END= when that lies behind begin.  Records of one bin that follow each
+// other make one chunk [offset of the first, offset behind the last); a window of the linear index holds the offset of the
+// first record that overlaps it, empty windows take their successor's.  Every sequence also carries htslib's pseudo-bin
+// 37450 (file range of its records; record count).  The index itself is BGZF-compressed.
+// Like tabix, the writer refuses a VCF whose sequences do not come in blocks or whose positions step backwards.
+// ---------------------------------------------------------------------------
+namespace {
+
+inline uint32_t tbi_reg2bin(int64_t beg, int64_t end) {
+  int l, s = 14;
+  int64_t t = ((1 << 15) - 1) / 7;
+  for (--end, l = 5; l > 0; --l, s += 3, t -= (int64_t)1 << (3 * l))
+    if ((beg >> s) == (end >> s)) return (uint32_t)(t + (beg >> s));
+  return 0;
+}
+
+struct TbiRef {
+  std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins;
+  std::vector<uint64_t> lin;
+  uint64_t off_beg = 0, off_end = 0, n = 0;
+};
+
+void put32(std::vector<uint8_t>& o, uint32_t v) { for (int k = 0; k < 4; ++k) o.push_back((uint8_t)(v >> (8 * k))); }
+void put64(std::vector<uint8_t>& o, uint64_t v) { for (int k = 0; k < 8; ++k) o.push_back((uint8_t)(v >> (8 * k))); }
+
+// the index of `data` as it lies in a BGZF file cut into members of 0xff00 input bytes whose compressed offsets are coff[]
+// (coff[number of members] = where the EOF member starts).  QM_OK, QM_E_UNSORTED, QM_E_RANGE (a coordinate tabix cannot bin).
+int tbi_build(const uint8_t* data, size_t len, const std::vector<uint64_t>& coff, std::vector<uint8_t>& out) {
+  auto voff = [&](size_t u) { return (coff[u / 0xff00] << 16) | (uint64_t)(u % 0xff00); };
+  std::vector<std::string> names;
+  std::vector<TbiRef> refs;
+  std::string last_name;
+  int tid = -1;
+  int64_t last_beg = -1;
+  uint32_t last_bin = 0xffffffffu;
+  size_t b = 0;
+  while (b < len) {
+    const uint8_t* nl = (const uint8_t*)memchr(data + b, '\n', len - b);
+    const size_t e = nl ? (size_t)(nl - data) : len;          // line = [b, e), the record ends behind its newline
+    const size_t next = nl ? e + 1 : len;
+    if (e > b && data[b] != '#') {
+      Span f[8] = {};
+      const int nf = split_head(data + b, e - b, f, 8);
+      if (nf < 2 || f[0].n == 0) return QM_E_INVAL;            // tabix: "failed to parse" a line without its columns
+      int64_t pos = 0;
+      {
+        size_t k = 0;
+        for (; k < f[1].n && f[1].p[k] >= '0' && f[1].p[k] <= '9' && pos < ((int64_t)1 << 40); ++k) pos = pos * 10 + (f[1].p[k] - '0');
+        if (k == 0) return QM_E_INVAL;
+      }
+      const int64_t beg = pos - 1;
+      int64_t end = beg + (nf >= 4 && f[3].n ? (int64_t)f[3].n : 1);
+      if (nf >= 8) {   // INFO: END= at its start or behind a ';'
+        const uint8_t* s = f[7].p;
+        const size_t n = f[7].n;
+        for (size_t k = 0; k + 4 <= n; ++k) {
+          if ((k == 0 || s[k - 1] == ';') && memcmp(s + k, "END=", 4) == 0) {
+            int64_t v = 0;
+            size_t q = k + 4;
+            for (; q < n && s[q] >= '0' && s[q] <= '9' && v < ((int64_t)1 << 40); ++q) v = v * 10 + (s[q] - '0');
+            if (q > k + 4 && (q == n || s[q] == ';') && v > beg) end = v;
+            break;
+          }
+        }
+      }
+      if (beg < 0 || end > ((int64_t)1 << 29)) return QM_E_RANGE;   // 2^(14 + 3 * 5): the reach of this binning scheme
+      const std::string name((const char*)f[0].p, f[0].n);
+      if (tid < 0 || name != last_name) {
+        for (const auto& nm : names) if (nm == name) return QM_E_UNSORTED;   // "chromosome blocks not continuous"
+        names.push_back(name); refs.emplace_back();
+        tid = (int)names.size() - 1; last_name = name; last_beg = -1; last_bin = 0xffffffffu;
+        refs[(size_t)tid].off_beg = voff(b);
+      }
+      if (beg < last_beg) return QM_E_UNSORTED;                                // "unsorted positions"
+      last_beg = beg;
+      TbiRef& R = refs[(size_t)tid];
+      const uint64_t o0 = voff(b), o1 = voff(next);
+      const uint32_t bin = tbi_reg2bin(beg, end);
+      if (bin == last_bin) R.bins[bin].back().second = o1;
+      else { R.bins[bin].emplace_back(o0, o1); last_bin = bin; }
+      const size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
+      if (R.lin.size() < w1 + 1) R.lin.resize(w1 + 1, ~0ull);
+      for (size_t w = w0; w <= w1; ++w) if (R.lin[w] == ~0ull) R.lin[w] = o0;
+      R.off_end = o1; R.n += 1;
+    }
+    b = next;
+  }
+  out.clear();
+  const uint8_t magic[4] = {'T', 'B', 'I', 1};
+  out.insert(out.end(), magic, magic + 4);
+  put32(out, (uint32_t)names.size());
+  put32(out, 2u);          // format: VCF
+  put32(out, 1u); put32(out, 2u); put32(out, 0u);   // sequence, begin, end columns
+  put32(out, (uint32_t)'#'); put32(out, 0u);        // comment character, lines to skip
+  size_t l_nm = 0;
+  for (const auto& nm : names) l_nm += nm.size() + 1;
+  put32(out, (uint32_t)l_nm);
+  for (const auto& nm : names) { out.insert(out.end(), nm.begin(), nm.end()); out.push_back(0); }
+  for (TbiRef& R : refs) {
+    for (size_t w = R.lin.size(); w-- > 1;) if (R.lin[w - 1] == ~0ull) R.lin[w - 1] = R.lin[w];
+    put32(out, (uint32_t)R.bins.size() + 1u);
+    for (const auto& kv : R.bins) {
+      put32(out, kv.first); put32(out, (uint32_t)kv.second.size());
+      for (const auto& c : kv.second) { put64(out, c.first); put64(out, c.second); }
+    }
+    put32(out, 37450u); put32(out, 2u);               // htslib's pseudo-bin: the file range of the records, their number
+    put64(out, R.off_beg); put64(out, R.off_end); put64(out, R.n); put64(out, 0ull);
+    put32(out, (uint32_t)R.lin.size());
+    for (uint64_t v : R.lin) put64(out, v);
+  }
+  put64(out, 0ull);        // records without coordinates
+  return QM_OK;
+}
+
+// `data` as a series of BGZF members + the EOF member into a file; coff (optional) receives the members' offsets
+bool bgzf_stream(FILE* fh, const uint8_t* data, size_t len, int level, std::vector<uint64_t>* coff) {
   std::vector<uint8_t> blk(0x10000);
-  bool ok = true;
-  for (size_t off = 0; off < len && ok; off += 0xff00) {
+  uint64_t at = 0;
+  for (size_t off = 0; off < len; off += 0xff00) {
     const size_t n = std::min<size_t>(0xff00, len - off);
     const size_t m = bgzf_block(data + off, n, level, blk.data());
-    ok = m > 0 && fwrite(blk.data(), 1, m, fh) == m;
+    if (coff) coff->push_back(at);
+    if (m == 0 || fwrite(blk.data(), 1, m, fh) != m) return false;
+    at += m;
   }
-  ok = ok && fwrite(kBgzfEof, 1, sizeof kBgzfEof, fh) == sizeof kBgzfEof;
+  if (coff) coff->push_back(at);
+  return fwrite(kBgzfEof, 1, sizeof kBgzfEof, fh) == sizeof kBgzfEof;
+}
+
+int bgzf_file(const std::string& path, const uint8_t* data, size_t len, int level, std::vector<uint64_t>* coff) {
+  static std::atomic<unsigned> serial{0};
+  const std::string tmp = path + ".tmp." + std::to_string((long)getpid()) + "." + std::to_string(serial.fetch_add(1));
+  FILE* fh = fopen(tmp.c_str(), "wb");
+  if (!fh) return QM_E_IO;
+  bool ok = bgzf_stream(fh, data, len, level, coff);
   ok = (fclose(fh) == 0) && ok;
   if (!ok) { remove(tmp.c_str()); return QM_E_IO; }
-  if (rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return QM_E_IO; }
+  if (rename(tmp.c_str(), path.c_str()) != 0) { remove(tmp.c_str()); return QM_E_IO; }
+  return QM_OK;
+}
+
+}  // namespace
+
+extern "C" int qm_bgzf_write(const char* path, const uint8_t* data, size_t len, int level) {
+  if (!path || (!data && len) || level < -1 || level > 9) return QM_E_INVAL;
+  return bgzf_file(path, data, len, level, nullptr);
+}
+
+// bgzip + tabix -p vcf in one call: <path> and <path>.tbi.  The index is built (and the order of the VCF checked) before
+// anything is written: QM_E_UNSORTED leaves no file behind.
+extern "C" int qm_bgzf_write_tbi(const char* path, const uint8_t* data, size_t len, int level) {
+  if (!path || (!data && len) || level < -1 || level > 9) return QM_E_INVAL;
+  const std::string gz(path), tmp = gz + ".tbitmp." + std::to_string((long)getpid());
+  std::vector<uint64_t> coff;
+  int rc = bgzf_file(tmp, data, len, level, &coff);   // (the compressed sizes are what the virtual offsets are made of)
+  if (rc != QM_OK) return rc;
+  std::vector<uint8_t> idx;
+  rc = tbi_build(data, len, coff, idx);
+  if (rc == QM_OK) rc = bgzf_file(gz + ".tbi", idx.data(), idx.size(), level, nullptr);
+  if (rc != QM_OK) { remove(tmp.c_str()); return rc; }
+  if (rename(tmp.c_str(), gz.c_str()) != 0) { remove(tmp.c_str()); return QM_E_IO; }
   return QM_OK;
 }
 

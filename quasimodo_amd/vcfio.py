@@ -2,12 +2,13 @@
 All heavy lifting is in libqmvt.so (quasimodo_amd/csrc/qmvt_host.cpp)."""
 import ctypes as C
 import os
+import sys
 from dataclasses import dataclass
 
 import numpy as np
 
 from . import _lib
-from ._lib import QmvtError, VcfCols, check
+from ._lib import QM_E_UNSORTED, QmvtError, VcfCols, check
 
 
 def _p(a):
@@ -192,21 +193,35 @@ def awk_flavour_default() -> int:
     return AWK_MAWK_LITERAL if v == "mawk-literal" else AWK_POSIX
 
 
-def bgzip(src_path, dst_path=None, level=-1) -> str:
-    """`bgzip -c src > dst` (rules/vis_eval_vcf.smk:36,51,67,82) without the tool: BGZF members + EOF block."""
+def bgzip(src_path, dst_path=None, level=-1, tbi=False) -> str:
+    """`bgzip -c src > dst` (rules/vis_eval_vcf.smk:36,51,67,82) without the tool: BGZF members + EOF block.
+    tbi=True: also `tabix -p vcf dst` (:37,52,68,83) -> dst + ".tbi"; a VCF whose sequences do not come in blocks or whose
+    positions step backwards raises QmvtError(QM_E_UNSORTED) and nothing is written -- tabix stops on such a file too.
+    tbi="if-sorted": such a VCF gets its .gz and no index (a note goes to stderr)."""
     dst_path = dst_path or src_path + ".gz"
     with open(src_path, "rb") as fh:
         data = fh.read()
-    rc = _lib.lib().qm_bgzf_write(os.fsencode(dst_path), data, len(data), int(level))
+    L = _lib.lib()
+    if tbi:
+        rc = L.qm_bgzf_write_tbi(os.fsencode(dst_path), data, len(data), int(level))
+        if rc == QM_E_UNSORTED and tbi == "if-sorted":
+            sys.stderr.write("%s: not sorted by sequence block and position -- no .tbi (tabix refuses it too)\n" % dst_path)
+            if os.path.exists(dst_path + ".tbi"):
+                os.remove(dst_path + ".tbi")      # an index of an earlier run would describe other bytes
+            rc = L.qm_bgzf_write(os.fsencode(dst_path), data, len(data), int(level))
+        elif rc == QM_E_UNSORTED:
+            raise QmvtError(rc, "%s: sequences not in blocks or positions stepping backwards: no tabix index can describe it" % src_path)
+    else:
+        rc = L.qm_bgzf_write(os.fsencode(dst_path), data, len(data), int(level))
     if rc < 0:
         raise QmvtError(rc, "cannot write %s" % dst_path)
     return dst_path
 
 
-def split_variants(vcf_path, out_path, kind, flavour=None, bgz=False) -> int:
+def split_variants(vcf_path, out_path, kind, flavour=None, bgz=False, tbi=False) -> int:
     """`extract_snp` / `extract_indel` / `extract_nucmer_*` (rules/vis_eval_vcf.smk:25-86) without
     awk: kind "xsnp" or "xindel"; returns the number of lines written.  bgz=True also writes the rules' second
-    declared output, <out_path>.gz (BGZF, what `bgzip -c` makes of it)."""
+    declared output, <out_path>.gz (BGZF, what `bgzip -c` makes of it); tbi (with bgz): and its tabix index, see `bgzip`."""
     if kind not in ("xsnp", "xindel"):
         raise ValueError("kind must be xsnp or xindel")
     with open(vcf_path, "rb") as fh:
@@ -217,5 +232,5 @@ def split_variants(vcf_path, out_path, kind, flavour=None, bgz=False) -> int:
     if rc < 0:
         raise QmvtError(rc, "cannot write %s" % out_path)
     if bgz:
-        bgzip(out_path)
+        bgzip(out_path, tbi=tbi)
     return int(n.value)

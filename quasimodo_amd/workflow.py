@@ -105,11 +105,11 @@ def run_hcmv_variantcall(data_dir, outpath, callers=None, engine=None, dryrun=Fa
     from .vcfio import split_variants
     for kind in ("xsnp", "xindel"):                                      # extract_snp / extract_indel / extract_nucmer_*:
         for j in jobs:                                                   # both declared outputs, *.vcf and its bgzip
-            split_variants(j.vcf_file, j.vcf_file[:-4] + ".%s.vcf" % kind, kind, bgz=True)
+            split_variants(j.vcf_file, j.vcf_file[:-4] + ".%s.vcf" % kind, kind, bgz=True, tbi="if-sorted")
         for mix in ("TM", "TA"):
             t = os.path.join(snp_dir, "nucmer", "%s.maskrepeat.variants.vcf" % mix)
             if os.path.exists(t):
-                split_variants(t, os.path.join(snp_dir, "nucmer", "%s.maskrepeat.%s.vcf" % (mix, kind)), kind, bgz=True)
+                split_variants(t, os.path.join(snp_dir, "nucmer", "%s.maskrepeat.%s.vcf" % (mix, kind)), kind, bgz=True, tbi="if-sorted")
     mixed = [s for s in samples if not s.endswith(("-1-0", "-0-1"))]
     cmp_callers = [c for c in FP_COMPARED if c in callers]
     tables = os.path.join(results, "final_tables")

@@ -403,3 +403,189 @@ def test_bgzf_blocks_are_what_htslib_indexes(qmlib, tmp_path):
     start = v >> 16
     bsz = struct.unpack_from("<H", raw, start + 16)[0] + 1
     assert zlib.decompress(raw[start + 18:start + bsz - 8], -15)[v & 0xffff:].startswith(b"chr1\t70007\t")
+
+
+class _Bgzf:
+    """A BGZF file as htslib addresses it: members located by their BC field, a virtual offset = member start << 16 | offset
+    in its inflated bytes."""
+
+    def __init__(self, raw):
+        import struct
+        import zlib
+        self.blocks = {}          # member start -> (inflated bytes, start of the next member)
+        off = 0
+        while off < len(raw):
+            assert raw[off:off + 4] == b"\x1f\x8b\x08\x04"
+            size = struct.unpack_from("<H", raw, off + 16)[0] + 1
+            self.blocks[off] = (zlib.decompress(raw[off + 18:off + size - 8], -15), off + size)
+            off += size
+
+    def read_lines(self, vbeg, vend):
+        """the whole lines between two virtual offsets, with the virtual offset each starts at"""
+        coff, inner = vbeg >> 16, vbeg & 0xffff
+        out, cur, cur_v = [], b"", vbeg
+        while coff in self.blocks and (coff << 16 | inner) < vend:
+            data, nxt = self.blocks[coff]
+            if inner >= len(data):
+                coff, inner = nxt, 0
+                continue
+            stop = len(data) if (vend >> 16) != coff else min(len(data), vend & 0xffff)
+            nl = data.find(b"\n", inner, stop)
+            if not cur:
+                cur_v = coff << 16 | inner
+            if nl < 0:
+                cur += data[inner:stop]
+                inner = stop
+                if stop < len(data):
+                    break
+            else:
+                out.append((cur_v, cur + data[inner:nl + 1]))
+                cur = b""
+                inner = nl + 1
+        assert not cur, "a chunk ends inside a line"
+        return out
+
+
+def _reg2bin(beg, end):       # SAM specification, section 5.3 (min_shift 14, depth 5)
+    end -= 1
+    if beg >> 14 == end >> 14: return ((1 << 15) - 1) // 7 + (beg >> 14)
+    if beg >> 17 == end >> 17: return ((1 << 12) - 1) // 7 + (beg >> 17)
+    if beg >> 20 == end >> 20: return ((1 << 9) - 1) // 7 + (beg >> 20)
+    if beg >> 23 == end >> 23: return ((1 << 6) - 1) // 7 + (beg >> 23)
+    if beg >> 26 == end >> 26: return ((1 << 3) - 1) // 7 + (beg >> 26)
+    return 0
+
+
+def _reg2bins(beg, end):
+    end -= 1
+    bins = [0]
+    for shift, first in ((26, 1), (23, 9), (20, 73), (17, 585), (14, 4681)):
+        bins += list(range(first + (beg >> shift), first + (end >> shift) + 1))
+    return bins
+
+
+def _parse_tbi(raw):
+    import gzip
+    import struct
+    b = gzip.decompress(raw)
+    assert b[:4] == b"TBI\x01"
+    n_ref, fmt, cs, cb, ce, meta, skip, l_nm = struct.unpack_from("<8i", b, 4)
+    assert (fmt, cs, cb, ce, meta, skip) == (2, 1, 2, 0, ord("#"), 0)
+    names = b[36:36 + l_nm].split(b"\0")[:-1]
+    assert len(names) == n_ref
+    off = 36 + l_nm
+    refs = []
+    for _ in range(n_ref):
+        n_bin, = struct.unpack_from("<i", b, off); off += 4
+        bins = {}
+        for _ in range(n_bin):
+            bn, n_chunk = struct.unpack_from("<Ii", b, off); off += 8
+            assert bn not in bins
+            bins[bn] = [struct.unpack_from("<QQ", b, off + 16 * k) for k in range(n_chunk)]
+            off += 16 * n_chunk
+        n_intv, = struct.unpack_from("<i", b, off); off += 4
+        lin = list(struct.unpack_from("<%dQ" % n_intv, b, off)); off += 8 * n_intv
+        refs.append((bins, lin))
+    assert off == len(b) or (off + 8 == len(b) and struct.unpack_from("<Q", b, off)[0] == 0)
+    return names, refs
+
+
+def test_tabix_index_beside_the_bgzf_output(qmlib, tmp_path):
+    """qm_bgzf_write_tbi = `bgzip -c` + `tabix -p vcf` (rules/vis_eval_vcf.smk:36-37): the .tbi is read back by a reader written
+    from the format description (not from the writer) -- header, names, bins, chunks, linear index, pseudo-bin --, every chunk
+    must hold whole records of its bin only, every record must be in exactly one chunk, and region queries answered the way
+    tabix answers them (bins of the region, linear index as the lower bound, records filtered by overlap) must return what a
+    scan of the text returns.  Three sequences, several BGZF members, records with long REF alleles and INFO END= reaching
+    over bin and window borders; a VCF out of order is refused and leaves no file."""
+    import gzip
+    rng = np.random.default_rng(11)
+    lines = [b"##fileformat=VCFv4.2", b"#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO"]
+    recs = []      # (chrom, beg, end, line)
+    for chrom, n, span in ((b"chrA", 9000, 3_000_000), (b"ctg-2", 40, 200_000_000), (b"z", 3000, 70_000)):
+        pos = np.sort(rng.integers(1, span, n))
+        for p in pos:
+            kind = rng.integers(0, 20)
+            ref, info = b"ACGT"[int(p) % 4:int(p) % 4 + 1], b"DP=%d" % int(rng.integers(1, 99))
+            end = int(p) - 1 + 1
+            if kind == 0:
+                ref = b"ACGT" * int(rng.integers(2, 6000)); end = int(p) - 1 + len(ref)
+            elif kind == 1:
+                e = int(p) + int(rng.integers(0, 100_000)); info = b"SVTYPE=DEL;END=%d;X=1" % e; end = e if e > int(p) - 1 else end
+            elif kind == 2:
+                e = int(p) + int(rng.integers(20_000, 40_000)); info = b"END=%d" % e; end = e
+            elif kind == 3:
+                info = b"BEND=5;AEND=7"           # not an END key
+            line = b"%s\t%d\t.\t%s\tG\t50\tPASS\t%s\n" % (chrom, int(p), ref, info)
+            lines.append(line[:-1])
+            recs.append((chrom, int(p) - 1, end, line))
+    data = b"\n".join(lines) + b"\n"
+    assert len(data) > 6 * 0xff00
+    out = tmp_path / "x.vcf.gz"
+    assert qmlib.qm_bgzf_write_tbi(str(out).encode(), data, len(data), -1) == 0
+    raw = out.read_bytes()
+    assert gzip.decompress(raw) == data
+    plain = tmp_path / "y.vcf.gz"
+    assert qmlib.qm_bgzf_write(str(plain).encode(), data, len(data), -1) == 0 and plain.read_bytes() == raw   # the same .gz as without the index
+    names, refs = _parse_tbi((tmp_path / "x.vcf.gz.tbi").read_bytes())
+    assert names == [b"chrA", b"ctg-2", b"z"]
+    bg = _Bgzf(raw)
+    first_v = {}
+    for tid, (bins, lin) in enumerate(refs):
+        mine = [r for r in recs if r[0] == names[tid]]
+        by_line = {r[3]: r for r in mine}
+        assert len(by_line) == len(mine)
+        seen = []
+        for bn, chunks in bins.items():
+            if bn == 37450:
+                assert len(chunks) == 2 and chunks[1] == (len(mine), 0)
+                got = bg.read_lines(*chunks[0])
+                assert [l for _, l in got] == [r[3] for r in mine]
+                continue
+            for cb, ce in chunks:
+                assert cb < ce
+                for v, l in bg.read_lines(cb, ce):
+                    r = by_line[l]
+                    assert _reg2bin(r[1], r[2]) == bn
+                    seen.append(l)
+                    first_v[l] = v
+        assert sorted(seen) == sorted(r[3] for r in mine)            # every record in exactly one chunk
+        # the linear index: the first record overlapping each 16 kb window, holes filled from behind
+        want = {}
+        for r in mine:
+            for w in range(r[1] >> 14, ((r[2] - 1) >> 14) + 1):
+                want.setdefault(w, first_v[r[3]])
+        assert len(lin) == max(want) + 1
+        for w in range(len(lin) - 1, -1, -1):
+            assert lin[w] == (want[w] if w in want else lin[w + 1])
+        # region queries the way tabix answers them
+        span = max(r[2] for r in mine)
+        for _ in range(60):
+            qb = int(rng.integers(0, span)); qe = qb + int(rng.integers(1, 1 << int(rng.integers(1, 22))))
+            lo = lin[min(qb >> 14, len(lin) - 1)] if (qb >> 14) < len(lin) else lin[-1]
+            hits = []
+            for bn in _reg2bins(qb, qe):
+                for cb, ce in bins.get(bn, []):
+                    if ce > lo:
+                        for v, l in bg.read_lines(cb, ce):
+                            r = by_line[l]
+                            if r[1] < qe and r[2] > qb:
+                                hits.append((v, l))
+            assert [l for _, l in sorted(set(hits))] == [r[3] for r in mine if r[1] < qe and r[2] > qb]
+    # out of order: refused like tabix refuses it, and nothing is left behind
+    for bad in (b"c1\t10\t.\tA\tC\t9\t.\t.\nc1\t9\t.\tA\tC\t9\t.\t.\n", b"c1\t1\t.\tA\tC\t9\t.\t.\nc2\t1\t.\tA\tC\t9\t.\t.\nc1\t2\t.\tA\tC\t9\t.\t.\n"):
+        o2 = tmp_path / "bad.vcf.gz"
+        assert qmlib.qm_bgzf_write_tbi(str(o2).encode(), bad, len(bad), -1) == -10
+        assert not o2.exists() and not (tmp_path / "bad.vcf.gz.tbi").exists()
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["x.vcf.gz", "x.vcf.gz.tbi", "y.vcf.gz"]
+    # the Python entry points
+    from quasimodo_amd.vcfio import bgzip
+    from quasimodo_amd._lib import QmvtError
+    src = tmp_path / "s.vcf"
+    src.write_bytes(data)
+    bgzip(str(src), tbi=True)
+    assert (tmp_path / "s.vcf.gz.tbi").read_bytes() == (tmp_path / "x.vcf.gz.tbi").read_bytes()
+    src.write_bytes(b"c1\t10\t.\tA\tC\t9\t.\t.\nc1\t9\t.\tA\tC\t9\t.\t.\n")
+    with pytest.raises(QmvtError):
+        bgzip(str(src), tbi=True)
+    bgzip(str(src), tbi="if-sorted")
+    assert (tmp_path / "s.vcf.gz").exists() and not (tmp_path / "s.vcf.gz.tbi").exists()

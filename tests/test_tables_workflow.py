@@ -142,6 +142,8 @@ def test_hcmv_variantcall_workflow(engine, oracle, tmp_path):
         gz = open(str(plain) + ".gz", "rb").read()
         assert gz[:4] == b"\x1f\x8b\x08\x04" and gz[12:16] == b"BC\x02\x00" and gz.endswith(eof)
         assert gzip.decompress(gz) == plain.read_bytes()
+        tbi = gzip.decompress(open(str(plain) + ".gz.tbi", "rb").read())      # ... and its `tabix -p vcf` (vis_eval_vcf.smk:37,52,68,83)
+        assert tbi[:4] == b"TBI\x01" and tbi[8:12] == (2).to_bytes(4, "little")
     # FP overlap regions against the oracle's restatement of snpcaller_fp_compare.R
     table = (results / "final_tables" / "snpcaller_fp_snp_compare.txt").read_text().splitlines()[1:]
     got = {}
