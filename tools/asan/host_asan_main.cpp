@@ -68,6 +68,11 @@ static void exercise(const std::vector<uint8_t>& t, qm_dict* dict, const char* o
       qm_vcf_split_write(o.c_str(), text, len, mode, fl, &n);
       ++g_calls;
     }
+  {   // bgzip + tabix index: any return code is fine (mutated files are out of order or lack columns), no fault is
+    const std::string o = std::string(outdir) + "/t.vcf.gz";
+    (void)qm_bgzf_write_tbi(o.c_str(), text, len, 1);
+    ++g_calls;
+  }
   free(text);
 }
 
