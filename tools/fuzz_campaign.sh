@@ -1,0 +1,14 @@
+#!/bin/bash
+# a long randomised parity hunt over every variant of the unsorted path: bash tools/fuzz_campaign.sh [rounds per variant]
+N=${1:-600}
+OUT=gpurun_out/fuzz_campaign.log; : > $OUT
+run() { echo "== $*" >> $OUT; env "$@" python3 tools/gpu_fuzz.py $N $SEED 2>&1 | tail -1 >> $OUT; }
+SEED=101 run QM_X=0
+SEED=102 run QM_BUCKET2=2
+SEED=103 run QM_JOIN=hash
+SEED=104 run QM_SORT_PATH=radix
+SEED=105 run QM_BUCKET_EXT=0
+SEED=106 run QM_MEMO=0
+SEED=107 run QM_BUCKET_PARTS=4
+SEED=108 run QM_PIPE_CHUNKS=3 QM_PIPE_MIN_SPANS=1
+cat $OUT
