@@ -768,9 +768,17 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
     HIPCHK(hipEventRecord(b->ev_sync[qm_batch::MAX_CHUNKS], st));
     HIPCHK(hipStreamWaitEvent(aux, b->ev_sync[qm_batch::MAX_CHUNKS], 0));
   }
+  // every VCF known to be out of order: the optimistic pass, its k_finalize and its compaction would find and write what the
+  // earlier run left (flags, position bits, rows nobody reads) -- only the per-truth sums are cleared
+  const bool all_known = use_known && b->n_known == b->n_vcf;
   for (int k = 0; k < nch; ++k) {
     const qm_batch::Chunk& ck = b->chunks[(size_t)k];
     hipEvent_t* e5 = ev + 2 + 5 * k;
+    if (all_known) {
+      if (k == 0) HIPCHK(hipMemsetAsync(g, 0, gbytes, st));
+      if (T) for (int q = 0; q < 5; ++q) HIPCHK(hipEventRecord(e5[q], st));
+      continue;
+    }
     ClassifyParams P = classify_params(b);
     P.span_base = ck.s0;
     if (k == 0) {   // k_finalize, behind this launch, adds to the per-truth sums: the first wave of the launch clears them
@@ -808,7 +816,8 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
     launch_compact(K, ck.s1 - ck.s0, aux);
     if (T) HIPCHK(hipEventRecord(e5[4], aux));
   }
-  if (nch > 1) {
+  if (all_known) {
+  } else if (nch > 1) {
     HIPCHK(hipEventRecord(b->ev_sync[qm_batch::MAX_CHUNKS + 1], aux));
     HIPCHK(hipStreamWaitEvent(st, b->ev_sync[qm_batch::MAX_CHUNKS + 1], 0));
   } else if (b->ev_sync[0] != nullptr && finalize_split_on()) {

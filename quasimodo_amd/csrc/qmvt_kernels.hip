@@ -1534,12 +1534,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   __shared__ uint64_t s_e[BK_TILE];
   __shared__ uint8_t s_d[BK_TILE];
   __shared__ uint32_t s_cntx[EXT ? 256 : 1];     // second stream: records of digit d in the tile, then where its run starts in the sub-region
+  __shared__ uint32_t s_flut[16];                // flag_info of the sixteen flag nibbles (pack_record_fast)
   const int bid = (int)blockIdx.x + P.tile_base;
   const int seg = P.tile_seg[bid];
   const SortSeg sg = P.segs[seg];
   const int sub = bid & (HB_SUBS - 1);
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < 256) { s_cnt[tid] = 0u; if (EXT) s_cntx[tid] = 0u; }
+  if (!L2 && tid >= 256 && tid < 272) s_flut[tid - 256] = flag_info((uint32_t)(tid - 256));
   __syncthreads();
   const int64_t tbase = (int64_t)(bid - sg.bk_tile0) * BK_TILE;
   const uint32_t shift = (uint32_t)sg.pad;
@@ -1596,6 +1598,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
       f[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(P.flags + g));
     }
   }
+  const float nbm1f = (float)(P.n_bins - 1);
 #pragma unroll
   for (int j = 0; j < PER / 4; ++j) {
     const int64_t i4 = tbase + (int64_t)j * 2048 + tid * 4;
@@ -1608,8 +1611,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
       ent[k] = 0ull;
       if (i4 + u < sg.n) {
         uint32_t key, inf;
+#ifdef BK_SLOW_PACK   // (A/B builds: the general packer)
         pack_record<EXT>(p[j][u], r[j][u], a[j][u], q[j][u], f[j] >> (8 * u), P.n_bins, key, inf);
         segfl |= (inf & I_BADPOS) ? SPANF_BADPOS : 0u;
+#else
+        const uint32_t f4x4 = ((f[j] >> (8 * u)) & 15u) << 2;
+        if (EXT) pack_record_fast_ext(p[j][u], r[j][u], a[j][u], q[j][u], f4x4, nbm1f, s_flut, key, inf);
+        else pack_record_fast(p[j][u], r[j][u], a[j][u], q[j][u], f4x4, nbm1f, s_flut, key, inf);
+        segfl |= ((uint32_t)p[j][u] >> 28) ? SPANF_BADPOS : 0u;
+#endif
         if (inf & I_LIVE) {
           kept |= ((inf >> 16) & 1u) << u;
           const uint32_t d = key >> shift;
@@ -1773,8 +1783,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BK_WAVES_PE
   const PartSeg sg = P.segs[seg];
   const int sub = bid & (P2_SUBS - 1);
   const int tid = (int)threadIdx.x, lane = tid & 63;
+  __shared__ uint32_t s_flut[16];             // flag_info of the sixteen flag nibbles (pack_record_fast)
   if (tid < P2_PARTS) s_cnt[tid] = 0u;
+  if (tid >= 64 && tid < 80) s_flut[tid - 64] = flag_info((uint32_t)(tid - 64));
   __syncthreads();
+  const float nbm1f = (float)(P.n_bins - 1);
   const int64_t tbase = (int64_t)(bid - sg.tile0) * BK_TILE;
   uint64_t ent[PER];
   uint32_t dr[PER];   // partition << 16 | rank inside the tile's partition; 0xffffffff: position out of range (the VCF is refused)
@@ -1807,8 +1820,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BK_WAVES_PE
       ent[k] = 0ull;
       if (i4 + u < sg.n) {
         uint32_t key, inf;
+#ifdef BK_SLOW_PACK
         pack_record<false>(p[j][u], r[j][u], a[j][u], q[j][u], f[j] >> (8 * u), P.n_bins, key, inf);
         if (!(inf & I_BADPOS)) {   // (the counting pass has flagged the VCF otherwise)
+#else
+        pack_record_fast(p[j][u], r[j][u], a[j][u], q[j][u], ((f[j] >> (8 * u)) & 15u) << 2, nbm1f, s_flut, key, inf);
+        if (!((uint32_t)p[j][u] >> 28)) {   // (the counting pass has flagged the VCF otherwise)
+#endif
           const bool live = (inf & I_LIVE) != 0u;
           kept |= ((inf >> 16) & 1u) << u;
           const uint32_t d = key >> P2_SHIFT;
