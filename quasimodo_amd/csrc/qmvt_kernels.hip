@@ -1517,6 +1517,13 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
 #ifndef BK_WAVES_PER_EU
 #define BK_WAVES_PER_EU 6
 #endif
+#if defined(HB_PROFILE) && defined(BKS_PROFILE)   // phase clocks of the scatter (instead of the joins': they share the counters)
+#define BKS_TICK(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); s_prof[i] = (uint32_t)((t_ - hb_t) >> 4); hb_t = t_; } } while (0)
+#define BKS_FLUSH() do { if (threadIdx.x < 16) atomicAdd(hb_prof + 16 * (1 + (blockIdx.x & 63)) + threadIdx.x, threadIdx.x == 0 ? 1u : s_prof[threadIdx.x]); } while (0)
+#else
+#define BKS_TICK(i) do { } while (0)
+#define BKS_FLUSH() do { } while (0)
+#endif
 // L2: the segment is one partition of a large VCF (two-level path): its records come as level-1 entries (P.l1_ent + sg.koff,
 // sg.n of them, no holes) instead of columns, keys are relative to the partition (sg.key_base), the kept mask was written
 // by the first level.
@@ -1540,9 +1547,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   const SortSeg sg = P.segs[seg];
   const int sub = bid & (HB_SUBS - 1);
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#if defined(HB_PROFILE) && defined(BKS_PROFILE)
+  uint32_t* hb_prof = P.cursor + (size_t)P.n_seg * HB_BUCKETS * HB_SUBS + (size_t)P.n_seg;
+  unsigned long long hb_t = __builtin_amdgcn_s_memtime();
+  __shared__ uint32_t s_prof[16];
+  if (threadIdx.x < 16) s_prof[threadIdx.x] = 0u;
+#endif
   if (tid < 256) { s_cnt[tid] = 0u; if (EXT) s_cntx[tid] = 0u; }
   if (!L2 && tid >= 256 && tid < 272) s_flut[tid - 256] = flag_info((uint32_t)(tid - 256));
   __syncthreads();
+  BKS_TICK(1);
   const int64_t tbase = (int64_t)(bid - sg.bk_tile0) * BK_TILE;
   const uint32_t shift = (uint32_t)sg.pad;
   uint64_t ent[PER];
@@ -1598,6 +1612,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
       f[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(P.flags + g));
     }
   }
+  BKS_TICK(2);
   const float nbm1f = (float)(P.n_bins - 1);
 #pragma unroll
   for (int j = 0; j < PER / 4; ++j) {
@@ -1647,7 +1662,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   }
   }   // !L2
   if (segfl) atomicOr(&P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg], segfl);
+  BKS_TICK(3);
   __syncthreads();
+  BKS_TICK(4);
   // thread d: exclusive scan over the digit counts = tile-local run starts; room for the run in the bucket's sub-region
   uint32_t cnt = 0, incl = 0;
   if (tid < 256) {
@@ -1661,30 +1678,43 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
     if (lane == 63) s_scan[wave] = incl;
   }
   __syncthreads();
+  // The room for the runs is asked for (one returning atomic per digit in use) and not waited for: reordering the tile in LDS
+  // needs the tile-local run starts only, so the cursors' round trip (5 000 of a workgroup's 42 000 cycles by its phase clocks,
+  // -DHB_PROFILE -DBKS_PROFILE) passes behind it.  (Same-box A/B against waiting on the spot: 1.39 ms either way -- the kernel is
+  // bound by what the memory system does with its mix of streamed reads and scattered 100-byte writes, not by any wait of its own.)
+  uint32_t g = 0, loc = 0;
   if (tid < 256) {
     uint32_t woff = 0;
 #pragma unroll
     for (int w = 0; w < 3; ++w) woff += w < wave ? s_scan[w] : 0u;
-    const uint32_t loc = woff + incl - cnt;
+    loc = woff + incl - cnt;
     s_loc[tid] = loc;
-    uint32_t g = 0;
-    if (cnt) {
-      g = atomicAdd(&P.cursor[((size_t)seg * HB_BUCKETS + tid) * HB_SUBS + sub], cnt);
-      if (g + cnt > (uint32_t)sg.bk_cap) atomicOr(&P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg], SPANF_OVERFLOW);
-    }
-    s_glob[tid] = (int32_t)g - (int32_t)loc;
+    if (cnt) g = atomicAdd(&P.cursor[((size_t)seg * HB_BUCKETS + tid) * HB_SUBS + sub], cnt);
     if (tid == 255) s_scan[4] = loc + cnt;
   } else if (EXT) {   // the other four waves: room for the second stream's runs (no reordering in LDS: each entry is stored where it belongs)
-    const int d = tid - 256;
-    const uint32_t cx = s_cntx[d];
-    uint32_t g = 0;
-    if (cx) {
-      g = atomicAdd(&P.xcursor[((size_t)seg * HB_BUCKETS + d) * HB_SUBS + sub], cx);
-      if (g + cx > (uint32_t)sg.bk_cap) atomicOr(&P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg], SPANF_OVERFLOW);
-    }
-    s_cntx[d] = g;
+    cnt = s_cntx[tid - 256];
+    if (cnt) g = atomicAdd(&P.xcursor[((size_t)seg * HB_BUCKETS + (tid - 256)) * HB_SUBS + sub], cnt);
   }
+  BKS_TICK(5);
   __syncthreads();
+  BKS_TICK(6);
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    if (dr[k] != 0xffffffffu) {
+      const uint32_t d = dr[k] >> 16;
+      const uint32_t lp = s_loc[d] + (dr[k] & 0xffffu);
+      s_e[lp] = ent[k];
+      s_d[lp] = (uint8_t)d;
+    }
+  }
+  if (tid < 256 || EXT) {
+    if (cnt && g + cnt > (uint32_t)sg.bk_cap) atomicOr(&P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg], SPANF_OVERFLOW);
+    if (tid < 256) s_glob[tid] = (int32_t)g - (int32_t)loc;
+    else s_cntx[tid - 256] = g;
+  }
+  BKS_TICK(7);
+  __syncthreads();
+  BKS_TICK(8);
   if (EXT) {
     typedef unsigned long long v2ull __attribute__((ext_vector_type(2)));
     v2ull* xout = reinterpret_cast<v2ull*>(P.xent) + sg.bk_off;   // (the second stream's regions are laid out like the first's)
@@ -1702,16 +1732,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
       }
     }
   }
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    if (dr[k] != 0xffffffffu) {
-      const uint32_t d = dr[k] >> 16;
-      const uint32_t lp = s_loc[d] + (dr[k] & 0xffffu);
-      s_e[lp] = ent[k];
-      s_d[lp] = (uint8_t)d;
-    }
-  }
-  __syncthreads();
   const int total = (int)s_scan[4];
   uint64_t* out = P.ent + sg.bk_off;
   for (int idx = tid; idx < total; idx += 512) {
@@ -1719,6 +1739,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
     const int32_t w = s_glob[d] + idx;
     if (w < sg.bk_cap) out[((size_t)d * HB_SUBS + sub) * (size_t)sg.bk_cap + (size_t)w] = s_e[idx];   // beyond: the VCF is flagged and redone
   }
+  BKS_TICK(9);
+#if defined(HB_PROFILE) && defined(BKS_PROFILE)
+  __syncthreads();
+#endif
+  BKS_FLUSH();
 }
 
 // ---------------------------------------------------------------------------
@@ -1981,7 +2006,12 @@ __device__ __forceinline__ uint32_t wave_reserve(uint32_t* ctr, bool want) {
 // every workgroup on the same twelve words doubled the kernel's time and with it every share)
 #define LDS_TICK(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); s_prof[i] = (uint32_t)((t_ - hb_t) >> 4); hb_t = t_; } } while (0)
 #define LDS_FLUSH() do { if (threadIdx.x < 16) atomicAdd(hb_prof + 16 * (1 + (blockIdx.x & 63)) + threadIdx.x, threadIdx.x == 0 ? 1u : s_prof[threadIdx.x]); } while (0)
-#ifdef XJ_PROFILE   // the clocks of k_join_ext instead of k_join_direct's (they share the counters)
+#if defined(BKS_PROFILE)
+#define DJ_TICK(i) do { } while (0)
+#define DJ_FLUSH() do { } while (0)
+#define XJ_TICK(i) do { } while (0)
+#define XJ_FLUSH() do { } while (0)
+#elif defined(XJ_PROFILE)   // the clocks of k_join_ext instead of k_join_direct's (they share the counters)
 #define DJ_TICK(i) do { } while (0)
 #define DJ_FLUSH() do { } while (0)
 #define XJ_TICK(i) LDS_TICK(i)
