@@ -734,9 +734,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
   if (lane < 16) lds[L_FLUT + lane] = flag_info((uint32_t)lane);
   if (P.zero_acc && blockIdx.x == 0)
     for (int i = lane; i < P.zero_words; i += 64) P.zero_acc[i] = 0ull;
-#ifndef K1_NO_KNOWN   // (A/B builds)
   if (!PACKED && P.known && P.known[sp.vcf]) return;   // found out of order by an earlier run of the same columns: the span's rows still say so
-#endif
   Acc A = {0u, 0u, 0u, 0u, 0u, 0u, 0u};
   uint32_t acc_pass = 0, acc_tp = 0;  // wave-uniform
   uint32_t acc_tpr = 0;               // per lane, reduced at the end
