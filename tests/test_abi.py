@@ -117,3 +117,18 @@ def test_multi_device_c_program_shards_sum_to_the_single_batch(qmlib, tmp_path):
     d = json.loads(r.stdout)
     assert d["devices"] == 2 and d["vcfs"] == 10 and d["equals_one_batch"] is True
     assert d["kept"] == d["tp_lines"] + d["fp_lines"] and d["roc_tp_at_20"] == d["tp_lines"]
+
+
+
+def test_traffic_json_names_the_current_device_code():
+    """bench.py quotes profiles/traffic.json (PMC bytes per k_classify launch) only for the device code it was measured on:
+    a kernel edit after the last PMC pass would silently turn `roofline.traffic` into null in the driver's bench line."""
+    import json
+    import quasimodo_amd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t = json.load(open(os.path.join(root, "profiles", "traffic.json")))
+    assert isinstance(t.get("kernels_build"), str) and len(t["kernels_build"]) == 16 and t["hbm_bytes_per_launch"] > 0
+    if t["kernels_build"] != quasimodo_amd.kernel_source_id():   # (a warning, not a failure: kernels are edited between PMC passes)
+        import warnings
+        warnings.warn("profiles/traffic.json was measured on device code %s, the tree holds %s: bench.py will print roofline.traffic = null "
+                      "until tools/final_profiles.sh has run on the GPU again" % (t["kernels_build"], quasimodo_amd.kernel_source_id()))
