@@ -11,5 +11,5 @@ for spec in "$@"; do
 done
 for rep in 1 2; do for spec in "$@"; do
   TAG=${spec%%=*}
-  echo -n "$TAG: "; QM_LIBQMVT=/tmp/abm/$TAG/libqmvt.so python3 $GRAFT_REPO_ROOT/tools/run_once.py ${NV:-1000} 8 2>&1 | grep classify
+  echo -n "$TAG: "; QM_LIBQMVT=/tmp/abm/$TAG/libqmvt.so python3 $GRAFT_REPO_ROOT/tools/run_once.py ${NV:-1000} 8 ${RARGS:-} 2>&1 | grep classify
 done; done
