@@ -121,7 +121,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # QM_BENCH_FORCE_PG=1: the process group and the collective also at N = 1 (a one-GPU box can at least show that RCCL
+    # initialises on this device and all-reduces the engine's buffer on the bench's stream)
+    force_pg = world == 1 and os.environ.get("QM_BENCH_FORCE_PG") == "1"
+    if force_pg:
+        os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1 or force_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("QM_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; gloo only for the rehearsal
         if backend == "nccl":
@@ -159,11 +164,11 @@ def main():
     def step():
         batch.run(stream=stream.cuda_stream, global_dev=glob.data_ptr())
         batch.finish(stream=stream.cuda_stream)          # per-VCF flags read back; the radix-sort path of unsorted VCFs completes here
-        if world > 1:
+        if world > 1 or force_pg:
             dist.all_reduce(glob, op=dist.ReduceOp.SUM)   # the path's only collective
 
     def fence():
-        if world > 1:
+        if world > 1 or force_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -313,7 +318,7 @@ def main():
         print(json.dumps(out))
     batch.close()
     eng.close()
-    if world > 1:
+    if world > 1 or force_pg:
         dist.destroy_process_group()
 
 

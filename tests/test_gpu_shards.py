@@ -93,6 +93,38 @@ def test_product_multi_gpu_entry_point_two_ranks_on_this_gpu(tmp_path, qmlib):
     assert np.array_equal(res["counters"], want) and want.sum() > 0
 
 
+def test_product_multi_gpu_entry_point_one_rank_over_rccl(tmp_path, qmlib):
+    """The same entry point with the backend the product uses, "nccl" (= RCCL on ROCm), at the only world size one card allows:
+    the child initialises the process group on its device, all-reduces the DEVICE buffer the engine filled and gathers nothing.
+    What two ranks add to this is RCCL's transport between GPUs, which no one-GPU box can show."""
+    from quasimodo_amd.extract import Job
+    from quasimodo_amd.multigpu import extract_many_sharded, truth_key
+    cases = [c for c in golden_cases() if c["family"] == "hcmv"][:12]
+    jobs, exps = [], []
+    for e in cases:
+        vcf, truth, exp = read_case(e)
+        root = tmp_path / e["family"] / e["mode"]
+        vp = root / e["vcf"][len("input/"):]
+        tp = root / e["truth"][len("input/"):]
+        vp.parent.mkdir(parents=True, exist_ok=True)
+        tp.parent.mkdir(parents=True, exist_ok=True)
+        vp.write_bytes(vcf)
+        tp.write_bytes(truth)
+        jobs.append(Job(str(vp), str(tp), e["mode"], str(root / e["outdir"]), e["caller"]))
+        exps.append((e, exp))
+    jobs, res = extract_many_sharded(jobs, 1, backend="nccl", strict=True, timeout=600)
+    for job, (e, exp) in zip(jobs, exps):
+        assert open(job.fp_out, "rb").read() == exp["fp"], case_id(e)
+        if not e["pure"]:
+            assert open(job.tp_out, "rb").read() == exp["tp"], case_id(e)
+    keys = res["truth_keys"]
+    want = np.zeros((max(len(keys), 1), 3, 256), np.int64)
+    for j in jobs:
+        if j.stats.get("roc") is not None:
+            want[keys.index(truth_key(j))] += np.asarray(j.stats["roc"]).astype(np.int64)
+    assert np.array_equal(res["counters"], want) and want.sum() > 0
+
+
 def test_workflows_on_two_ranks_of_this_gpu_write_what_one_gpu_writes(tmp_path, qmlib, engine):
     """run_hcmv_variantcall / run_vareval with gpus=2 and the HIP engine on both ranks (one card, gloo for the collective
     since RCCL refuses two ranks on one GPU): the VCFs dealt by sample, the FP overlap by the rank that holds the sample, the
