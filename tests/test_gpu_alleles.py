@@ -242,3 +242,38 @@ def test_alleles_mode_unsorted_vcfs_on_the_bucket_path(engine, oracle):
     for k in ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R", "truth_unique"):
         assert res[0]["scalars"][k] == sc[k], k
     engine.truth_release(tid2)
+
+
+def test_alleles_mode_bucket_limits_send_the_chunk_to_the_radix_sort(engine, oracle):
+    """What does not fit a bucket of the second stream -- here more than 1 024 records on positions that several kept records
+    outside the truth set claim (multi-allelic sites packed into one bucket's position range) -- flags the VCF, nothing of the
+    chunk joins the per-truth sums, and the radix sort redoes it: the answers are the oracle's, the statistics say so."""
+    rng = np.random.default_rng(123)
+    Lp = 4_000_000                       # 123 buckets of 2^15 positions
+    truth = ext_truth(rng, 3000, Lp)
+    tid = engine.truth_load(*truth)
+    n = 60_000
+    pos, ref, alt, qual, flags = (a.copy() for a in ext_columns(rng, n, Lp, truth))
+    # 4 000 records on 1 300 positions inside ONE bucket, three different long alleles each: every one of them is listed
+    hot = 70_000 + rng.choice(20_000, 1300, replace=False)
+    m = rng.choice(n, 4000, replace=False)
+    pos[m] = rng.choice(hot, 4000).astype(np.int32)
+    alt[m] = ((3 << 26) | rng.integers(0, 64, 4000)).astype(np.int32)
+    ref[m] = 0
+    flags[m] = 3
+    qual[m] = 60
+    o = rng.permutation(n)
+    cols = tuple(np.ascontiguousarray(a[o]) for a in (pos, ref, alt, qual, flags))
+    b = engine.batch([n], [tid], alleles=True)
+    b.upload(0, *cols)
+    b.run(); b.finish()
+    ps = b.path_stats()
+    assert ps["unsorted"] == 1 and ps["overflow_chunks"] == 1 and ps["radix_after_overflow"] == 1 and ps["bucket_direct"] == 0
+    cls, roc, sc = oracle.classify_columns(*cols, *truth, ext=True)
+    assert np.array_equal(b.cls(0), cls) and np.array_equal(b.roc()[0], roc)
+    assert [int(x) for x in b.scalars()[0, :5]] == [sc[k] for k in ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R")]
+    assert np.array_equal(b.global_counts()[tid], roc.astype(np.uint64))
+    b.run(); b.finish()                  # and again, now known to be out of order
+    assert np.array_equal(b.cls(0), cls) and np.array_equal(b.roc()[0], roc) and np.array_equal(b.global_counts()[tid], roc.astype(np.uint64))
+    b.close()
+    engine.truth_release(tid)
