@@ -71,6 +71,8 @@ def main():
                     help="also time the allele-extended variant (config 4's record shape) on this many VCFs at N=1, config 2; 0 disables")
     ap.add_argument("--shuffled-alleles-vcfs", type=int, default=int(os.environ.get("QM_BENCH_SHUFFLED_ALLELES_VCFS", "256")),
                     help="also time shuffled allele-extended VCFs (config 4's record shape: two entry streams, k_join_direct + k_join_ext) on this many VCFs at N=1, config 2; 0 disables")
+    ap.add_argument("--shuffled4-vcfs", type=int, default=int(os.environ.get("QM_BENCH_SHUFFLED4_VCFS", "48")),
+                    help="also time shuffled VCFs of configs[4]'s shape (2 M records on a 10 Mb reference, 30 % variable-length alleles, three truth sets: partitions of buckets) on this many VCFs at N=1, config 2; 0 disables")
     ap.add_argument("--alloc-reps", type=int, default=int(os.environ.get("QM_BENCH_ALLOC_REPS", "3")),
                     help="re-create the timed batch this many times after the timed region and report k_classify's time for each "
                          "(roofline.alloc_spread: the kernel moves by several per cent with where a batch lands in memory); N=1, config 2; 0 disables")
@@ -314,6 +316,8 @@ def main():
         out["alleles_variant"] = alleles_variant(eng, P, args.bins, min(args.alleles_vcfs, n_vcf))
     if side and args.config == 2 and not custom and not args.shuffled and args.shuffled_alleles_vcfs > 0:
         out["shuffled_alleles_variant"] = shuffled_alleles_variant(eng, P, args.bins, min(args.shuffled_alleles_vcfs, n_vcf))
+    if side and args.config == 2 and not custom and not args.shuffled and args.shuffled4_vcfs > 0:
+        out["shuffled_config4_variant"] = shuffled_config4_variant(eng, args.bins, args.shuffled4_vcfs)
     if rank == 0:
         print(json.dumps(out))
     batch.close()
@@ -491,6 +495,34 @@ def shuffled_alleles_variant(eng, P, bins, nv):
     return {"value": nv * float(P["records"]) / dt, "unit": "classifications/s", "vcfs": nv, "steps": steps, "ms_per_step": dt * 1e3, "ms_per_step_unseen": dt0 * 1e3,
             "indel_pct": pct, "equals_sorted_variant": ok, "paths": paths,
             "note": "allele-extended VCFs permuted: one scatter into two entry streams per bucket, k_join_direct (single-base records) + k_join_ext (the others)"}
+
+
+def shuffled_config4_variant(eng, bins, nv):
+    """configs[4]'s VCF shape (2 M records on a 10 Mb reference, 30 % of them with variable-length alleles, VCF v against truth
+    set v mod 3) with the records permuted: too many records and too wide a key range for 256 buckets, so every partition of 2^27
+    keys is a segment of the one-level scatter that reads its VCF's columns and keeps its own key range; two entry streams and two
+    joins per bucket.  A side measurement; the counters must equal those of the same VCFs in position order."""
+    import numpy as np
+    P4 = PRESETS[4]
+    tids = [eng.truth_synth(P4["genome"], P4["truth"], ts, indel_pct=P4["indel_pct"]) for ts in P4["truth_seeds"]]
+    rows = {}
+    for shuffled in (False, True):
+        b = eng.batch([P4["records"]] * nv, [tids[v % len(tids)] for v in range(nv)], n_bins=bins, alleles=True)
+        b.synth(P4["genome"], P4["truth"], None, P4["seed"], shuffled=shuffled, indel_pct=P4["indel_pct"])
+        b.run(); b.finish()
+        if shuffled:
+            steps = 3
+            dt, dt0 = _timed_with_and_without_memory(b, steps)
+            paths = b.path_stats()
+        rows[shuffled] = (b.roc(), b.scalars()[:, :5].copy())
+        b.close()
+    for t in tids:
+        eng.truth_release(t)
+    ok = bool(np.array_equal(rows[True][0], rows[False][0]) and np.array_equal(rows[True][1], rows[False][1]))
+    return {"value": nv * float(P4["records"]) / dt, "unit": "classifications/s", "vcfs": nv, "records_per_vcf": P4["records"], "steps": steps,
+            "ms_per_step": dt * 1e3, "ms_per_step_unseen": dt0 * 1e3, "indel_pct": P4["indel_pct"], "equals_sorted_variant": ok, "paths": paths,
+            "note": "2 M-record allele-extended VCFs on a 10 Mb reference permuted: two partitions of 2^27 keys per VCF, each a segment of the one-level "
+                    "scatter reading the VCF's columns (SortSeg.part); k_join_direct + k_join_ext per bucket; `paths` counts them as bucket_two_level"}
 
 
 def shell_baseline(batch, P, n_sample, tseed):

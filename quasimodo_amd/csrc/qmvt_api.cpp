@@ -1400,6 +1400,140 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   return QM_OK;
 }
 
+// ---- allele-extended VCFs too large or too wide for 256 buckets: partitions of the key space, each read from the columns ----
+// The one-level path needs <= 8 192 records and <= 2^19 keys per bucket: configs[4]'s VCFs (2 M records on a 10 Mb genome) have
+// neither.  The two-level path's first scatter packs level-1 entries that have no room for allele codes, so for these batches
+// every PARTITION of 2^27 keys (256 buckets of 2^19) is a segment of the one-level scatter that reads ALL of its VCF's columns
+// and keeps the records of its own key range (SortSeg.part): P partitions cost P reads of the columns (two for a 10 Mb genome:
+// about what the two-level path's counting pass and first scatter cost) and nothing else is new -- bucket rows, the two joins,
+// the rows per segment and their sum per VCF are the one-level and two-level paths'.
+constexpr int PX_MAX_PARTS = 4;
+static int ext_parts_of(uint32_t posor) { return (int)((((uint64_t)posor << 4) | 15u) >> P2_SHIFT) + 1; }
+static bool bucketx_takes(const qm_batch* b, int64_t n, uint32_t posor) {
+  if (!b->ext) return false;
+  if (const char* e = getenv("QM_BUCKET_EXT")) if (atoi(e) == 0) return false;
+  if (const char* e = getenv("QM_SORT_PATH")) if (strcmp(e, "radix") == 0) return false;
+  if (join_hash_forced()) return false;
+  if (n < HB_MIN_RECORDS || n > ((int64_t)1 << HB_INDEX_BITS)) return false;
+  const int parts = ext_parts_of(posor);
+  if (parts > PX_MAX_PARTS) return false;
+  if (const char* e = getenv("QM_BUCKETX")) { if (atoi(e) == 0) return false; if (atoi(e) == 2) return true; }   // 2: every unsorted VCF of an allele-extended batch (tests, fuzz)
+  return parts > 1 || !bucket_path_takes(b, n);
+}
+
+static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, const std::vector<uint32_t>& posor, bool* taken) {
+  *taken = false;
+  const int nv = (int)vs.size();
+  std::vector<SortSeg> segs, vsegs((size_t)nv);
+  std::vector<VcfDesc> fake;
+  std::vector<int32_t> bk_tile_seg, ktile_seg, ktile_local, vparts((size_t)nv);
+  int64_t bk_ents = 0, nbt = 0, nkt = 0;
+  const int out_stride = 2 * HB_BUCKETS;
+  for (int i = 0; i < nv; ++i) {
+    const VcfDesc& d = b->L.vcfs[(size_t)vs[(size_t)i]];
+    const uint32_t kor = (posor[(size_t)vs[(size_t)i]] << 4) | 15u;
+    const int parts = ext_parts_of(posor[(size_t)vs[(size_t)i]]);
+    const int seg0 = (int)segs.size();
+    for (int p = 0; p < parts; ++p) {
+      SortSeg g;
+      memset(&g, 0, sizeof g);
+      g.src_off = d.off; g.n = d.n; g.main_vcf = vs[(size_t)i]; g.sub_vcf = i; g.main_tile0 = d.tile0;
+      g.pad = DJ_MAX_SHIFT; g.key_base = (uint32_t)p << P2_SHIFT; g.part = p + 1 == parts ? 2 : 1;
+      g.nbk = p + 1 == parts ? std::min<int>(HB_BUCKETS, (int)((kor - g.key_base) >> DJ_MAX_SHIFT) + 1) : HB_BUCKETS;
+      int64_t want = d.n / (128 * HB_SUBS) * 3 / 2 + 16, cap2 = 16;   // (how the records spread over the partitions is not known: room as for all of them)
+      while (cap2 < want && cap2 < HB_SUB_MAX) cap2 *= 2;
+      g.bk_cap = (int32_t)cap2; g.bk_off = bk_ents; g.bk_tile0 = (int32_t)nbt;
+      bk_ents += (int64_t)HB_BUCKETS * HB_SUBS * cap2;
+      const int64_t t = (d.n + BK_TILE - 1) / BK_TILE;
+      bk_tile_seg.insert(bk_tile_seg.end(), (size_t)t, (int32_t)segs.size());
+      nbt += t;
+      VcfDesc f = VcfDesc();   // the two streams' rows of a partition as the "spans" of a VCF for k_finalize
+      f.off = 0; f.n = d.n; f.truth = d.truth; f.tile0 = 0; f.ntiles = 0; f.span0 = (int32_t)segs.size() * out_stride; f.nspans = out_stride; f.pad = 0;
+      fake.push_back(f);
+      segs.push_back(g);
+    }
+    SortSeg& vg = vsegs[(size_t)i];
+    memset(&vg, 0, sizeof vg);
+    vg.src_off = d.off; vg.n = d.n; vg.main_vcf = vs[(size_t)i]; vg.sub_vcf = seg0; vg.main_tile0 = d.tile0;
+    vparts[(size_t)i] = parts;
+    const size_t k0 = ktile_seg.size();
+    ktile_seg.insert(ktile_seg.end(), (size_t)d.ntiles, (int32_t)i);
+    ktile_local.resize(k0 + (size_t)d.ntiles);
+    for (int t = 0; t < d.ntiles; ++t) ktile_local[k0 + (size_t)t] = t;
+    nkt += d.ntiles;
+  }
+  const int nseg = (int)segs.size();
+  if (nbt > INT32_MAX || nkt > INT32_MAX) return fail(QM_E_LIMIT, "bucket path: too many tiles");
+  // the arrays of the one-level path, sized for these segments (its cached tables, and the two-level path's, are gone after this)
+  b->last_segs.clear(); b->bk_tiles_valid = false; b->bk_fake_valid = false; b->last2_vs.clear();
+  int rc = QM_OK;
+  int64_t cap;
+  { cap = b->cap_segs; rc = regrow(&b->d_segs, &cap, (int64_t)nseg, &b->dev_bytes); b->cap_segs = (int)cap; }
+  if (rc == QM_OK) rc = regrow(&b->d_vsegs, &b->cap_vsegs, (int64_t)nv, &b->dev_bytes);
+  if (rc == QM_OK) {
+    cap = b->cap_ktiles; rc = regrow(&b->d_ktile_seg, &cap, nkt, &b->dev_bytes);
+    if (rc == QM_OK) { cap = b->cap_ktiles; rc = regrow(&b->d_ktile_local, &cap, nkt, &b->dev_bytes); }
+    if (rc == QM_OK) b->cap_ktiles = std::max(b->cap_ktiles, (int)nkt);
+  }
+  {
+    const int64_t rows = (int64_t)nseg * HB_BUCKETS, orows = (int64_t)nseg * out_stride;
+    int64_t c1 = b->cap_bk_rows * SPAN_HIST_WORDS, c2 = b->cap_bk_rows * 8;
+    if (rc == QM_OK) rc = regrow(&b->bk_hist, &c1, orows * SPAN_HIST_WORDS, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->bk_scal, &c2, orows * 8, &b->dev_bytes);
+    if (rc == QM_OK) b->cap_bk_rows = std::max(b->cap_bk_rows, orows);
+    if (rc == QM_OK) rc = regrow(&b->bk_xent, &b->cap_bk_xent, 2 * bk_ents, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->bk_xcursor, &b->cap_bk_xcursor, rows * HB_SUBS, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->bk_xrows, &b->cap_bk_xrows, rows, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->d_bk_vcfs, &b->cap_bk_vcfs, (int64_t)nseg, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->bk_ent, &b->cap_bk_ent, bk_ents, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->bk_rows, &b->cap_bk_rowdesc, rows, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->bk_cursor, &b->cap_bk_cursor, rows * HB_SUBS + nseg + 32 + 16 * 65, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->d_bk_tile_seg, &b->cap_bk_tiles, nbt, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->d_vparts, &b->cap_vparts, (int64_t)nv, &b->dev_bytes);
+    if (rc == QM_OK) rc = ensure_bucket_rows(b, nseg);
+  }
+  if (rc != QM_OK) return rc;
+  HIPCHK(hipMemcpyAsync(b->d_segs, segs.data(), sizeof(SortSeg) * segs.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->d_vsegs, vsegs.data(), sizeof(SortSeg) * vsegs.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->d_bk_tile_seg, bk_tile_seg.data(), 4 * bk_tile_seg.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->d_ktile_seg, ktile_seg.data(), 4 * ktile_seg.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->d_ktile_local, ktile_local.data(), 4 * ktile_local.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->d_bk_vcfs, fake.data(), sizeof(VcfDesc) * fake.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(b->d_vparts, vparts.data(), 4 * vparts.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));   // the host tables die with this call
+  const size_t ncur = ((size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg + 32 + 16 * 65) * 4;
+  HIPCHK(hipMemsetAsync(b->bk_cursor, 0, ncur, st));
+  HIPCHK(hipMemsetAsync(b->bk_xcursor, 0, (size_t)nseg * HB_BUCKETS * HB_SUBS * 4, st));
+  BucketScatterParams S;
+  S.segs = b->d_segs; S.tile_seg = b->d_bk_tile_seg; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
+  S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
+  S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = nullptr; S.xent = b->bk_xent; S.xcursor = b->bk_xcursor; S.ext = 1;
+  HashParams H;
+  H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
+  H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.seg_base = 0;
+  H.xrows = b->bk_xrows; H.xent = b->bk_xent; H.xcursor = b->bk_xcursor; H.out_stride = out_stride; H.ext = 1;
+  launch_bucket_rows(H, nseg, st);
+  launch_bucket_scatter(S, (int)nbt, st);
+  launch_join_direct(H, nseg, DJ_MAX_SHIFT, HB_BUCKETS, st);
+  launch_join_ext(H, nseg, HB_BUCKETS, st);
+  launch_finalize(bucket_rows_finalize(b), nseg, st);
+  HIPCHK(hipGetLastError());
+  std::vector<uint32_t> hfl((size_t)nseg);
+  HIPCHK(hipMemcpyAsync(hfl.data(), b->bk_vflags, 4 * hfl.size(), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  b->path_stats[QM_PATH_BUCKET_CHUNKS] += 1;
+  for (int i = 0; i < nseg; ++i) {
+    if (hfl[(size_t)i] & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", segs[(size_t)i].main_vcf);
+    if (hfl[(size_t)i] & SPANF_OVERFLOW) { b->path_stats[QM_PATH_OVERFLOW_CHUNKS] += 1; return QM_OK; }   // a bucket did not fit: the radix sort redoes the chunk
+  }
+  launch_sort_copy_rows(b->d_vsegs, nv, b->bk_roc, b->bk_rscal, b->roc, b->scalars, b->n_bins, st, global, b->d_vcfs, b->d_vparts);
+  launch_tile_counts(b->d_vsegs, b->d_ktile_seg, b->d_ktile_local, (int)nkt, b->mask_pass, b->mask_tp, b->tile_tp, b->tile_fp, st);
+  HIPCHK(hipGetLastError());
+  b->path_stats[QM_PATH_DIRECT2] += nv;
+  *taken = true;
+  return QM_OK;
+}
+
 // re-derive tile offsets + compaction for every VCF (cheap: masks only)
 static int rescan_and_compact(qm_batch* b, hipStream_t st);
 
@@ -1408,22 +1542,27 @@ static int rescan_and_compact(qm_batch* b, hipStream_t st);
 static int redo_unsorted(qm_batch* b, const std::vector<int>& todo, const std::vector<uint32_t>& posor, hipStream_t st) {
   // the VCFs the bucket path takes (by size: a VCF costs it 256 workgroups and 256 rows whatever it holds, and its
   // buckets hold 8 192 records at most) in chunks of their own, the others on the radix sort
-  std::vector<int> part[3];
+  // kind 3: allele-extended VCFs in partitions read from the columns (bucketx_chunk)
+  std::vector<int> part[4];
   for (int v : todo) {
     const int64_t n = b->L.vcfs[(size_t)v].n;
     const bool force2 = getenv("QM_BUCKET2") && atoi(getenv("QM_BUCKET2")) == 2 && bucket2_takes(b, n);
-    part[force2 ? 2 : bucket_path_takes(b, n) ? 1 : bucket2_takes(b, n) ? 2 : 0].push_back(v);
+    part[bucketx_takes(b, n, posor[(size_t)v]) ? 3 : force2 ? 2 : bucket_path_takes(b, n) ? 1 : bucket2_takes(b, n) ? 2 : 0].push_back(v);
   }
-  for (int kind = 2; kind >= 0; --kind) {
+  for (int kind = 3; kind >= 0; --kind) {
     std::vector<int> chunk;
     int64_t chunk_n = 0;
     for (size_t i = 0; i <= part[kind].size(); ++i) {
-      const bool flush = i == part[kind].size() || (!chunk.empty() && chunk_n + b->L.vcfs[(size_t)part[kind][i]].n > SORT_CHUNK_RECORDS) ||
-                         (kind >= 1 && chunk.size() >= 4096);   // 256 rows of 1.5 KB and >= 1 MB of bucket regions per VCF: bounded per chunk
+      const int64_t wgt = i < part[kind].size() ? b->L.vcfs[(size_t)part[kind][i]].n * (kind == 3 ? ext_parts_of(posor[(size_t)part[kind][i]]) : 1) : 0;   // (a partition reads its whole VCF)
+      const bool flush = i == part[kind].size() || (!chunk.empty() && chunk_n + wgt > SORT_CHUNK_RECORDS) ||
+                         (kind >= 1 && chunk.size() >= (size_t)(kind == 3 ? 4096 / PX_MAX_PARTS : 4096));   // 256 rows of 1.5 KB and >= 1 MB of bucket regions per VCF: bounded per chunk
       if (flush && !chunk.empty()) {
         int rc = QM_OK;
         bool taken = false;
-        if (kind == 2) {
+        if (kind == 3) {
+          rc = bucketx_chunk(b, chunk, st, b->last_global, posor, &taken);
+          if (rc == QM_OK && !taken) { b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += (int64_t)chunk.size(); rc = sort_chunk(b, chunk, st, b->last_global, posor, false); b->path_stats[QM_PATH_RADIX] -= (int64_t)chunk.size(); }
+        } else if (kind == 2) {
           rc = bucket2_chunk(b, chunk, st, b->last_global, &taken);
           if (rc == QM_OK && !taken) { b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += (int64_t)chunk.size(); rc = sort_chunk(b, chunk, st, b->last_global, posor, false); b->path_stats[QM_PATH_RADIX] -= (int64_t)chunk.size(); }
         } else {
@@ -1433,7 +1572,7 @@ static int redo_unsorted(qm_batch* b, const std::vector<int>& todo, const std::v
         chunk.clear();
         chunk_n = 0;
       }
-      if (i < part[kind].size()) { chunk.push_back(part[kind][i]); chunk_n += b->L.vcfs[(size_t)part[kind][i]].n; }
+      if (i < part[kind].size()) { chunk.push_back(part[kind][i]); chunk_n += wgt; }
     }
   }
   return QM_OK;

@@ -169,6 +169,9 @@ struct SortSeg {
   int32_t bk_tile0, bk_cap;  // bucket path: first scatter tile (BK_TILE records) of the segment; entries per sub-region (a power of two)
   int32_t nbk;               // bucket path: buckets in use (those above the VCF's highest position hold nothing)
   uint32_t key_base;         // two-level path: first key of the segment's partition (0 on the one-level path)
+  int32_t part;              // one-level scatter over a PARTITION of a VCF's key range, read from the columns (allele-extended VCFs too
+                             // large or too wide for 256 buckets): 0 = the whole VCF; 1 = keys outside [key_base, key_base + 256 << pad)
+                             // belong to another segment of the same VCF; 2 = the VCF's last partition: keys above it flag the VCF
 };
 // bucket path (k_bucket_scatter + k_classify_hash): one workgroup per (segment, bucket of the one scatter pass)
 #ifndef QM_BK_TILE

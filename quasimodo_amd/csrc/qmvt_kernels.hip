@@ -1637,15 +1637,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
 #endif
         if (inf & I_LIVE) {
           kept |= ((inf >> 16) & 1u) << u;
-          const uint32_t d = key >> shift;
-          if (d >= (uint32_t)HB_BUCKETS) {
+          const uint32_t rel = key - sg.key_base;   // (key_base = 0 unless the segment is a partition of its VCF)
+          const uint32_t d = rel >> shift;
+          if (sg.part != 0 && (key < sg.key_base || (sg.part == 1 && d >= (uint32_t)HB_BUCKETS))) {
+            // another partition of the same VCF takes this record (every partition reads all of the VCF's columns)
+          } else if (d >= (uint32_t)HB_BUCKETS) {
             segfl |= SPANF_OVERFLOW;   // a position above what the optimistic pass saw of this VCF: the radix sort redoes it
           } else if (!EXT || (uint32_t)(r[j][u] | a[j][u]) < 4u) {
-            const uint32_t v = key - (d << shift);   // < 2^24: shift <= 24
+            const uint32_t v = rel - (d << shift);   // < 2^24: shift <= 24
             ent[k] = (uint64_t)v | ((uint64_t)((inf & 0xfffu) | ((inf >> 12) & 0x1000u)) << 24) | ((uint64_t)(uint32_t)(i4 + u) << 37);
             dr[k] = (d << 16) | atomicAdd(&s_cnt[d], 1u);
           } else {   // not two single bases: the second stream (the key's nibble is a hash there: the entry carries the position's first key)
-            const uint32_t v = (key & ~15u) - (d << shift);
+            const uint32_t v = (rel & ~15u) - (d << shift);
             ent[k] = (uint64_t)v | ((uint64_t)((inf & 0xfffu) | ((inf >> 12) & 0x1000u)) << 24) | ((uint64_t)(uint32_t)(i4 + u) << 37);
             drx[k] = (d << 16) | atomicAdd(&s_cntx[d], 1u);
           }

@@ -277,3 +277,35 @@ def test_alleles_mode_bucket_limits_send_the_chunk_to_the_radix_sort(engine, ora
     assert np.array_equal(b.cls(0), cls) and np.array_equal(b.roc()[0], roc) and np.array_equal(b.global_counts()[tid], roc.astype(np.uint64))
     b.close()
     engine.truth_release(tid)
+
+
+def test_alleles_mode_unsorted_vcfs_of_configs4_shape_take_partitions_of_buckets(engine, oracle):
+    """BASELINE configs[4]'s VCFs -- 2 M records on a 10 Mb reference, 30 % with variable-length alleles -- out of order: too many
+    records and too wide a key range for 256 buckets, so every partition of 2^27 keys is a segment of the one-level scatter that
+    reads its VCF's columns and keeps its own key range (SortSeg.part), two streams and two joins per bucket as before.  Against
+    the sorted run (all VCFs) and the oracle (one VCF); no radix sort."""
+    from oracle.synth import synth_truth_keys
+    L, T, N, pct = 10_000_000, 200_000, 2_000_000, 30
+    tids = [engine.truth_synth(L, T, s, indel_pct=pct) for s in (5, 6)]
+    nv = 4
+    rows = {}
+    for shuffled in (False, True):
+        b = engine.batch([N] * nv, [tids[v % 2] for v in range(nv)], alleles=True)
+        b.synth(L, T, None, 5000, shuffled=shuffled, indel_pct=pct)
+        for rep in range(2 if shuffled else 1):       # (the second run: the batch knows its VCFs are out of order)
+            b.run(); b.finish()
+            if shuffled:
+                ps = b.path_stats()
+                assert ps["unsorted"] == nv and ps["bucket_two_level"] == nv and ps["radix"] == 0 and ps["radix_after_overflow"] == 0, ps
+        rows[shuffled] = (b.roc(), b.scalars()[:, :5].copy(), b.global_counts())
+        if shuffled:
+            cols = b.columns(1)
+            cls, oroc, sc = oracle.classify_columns(*cols, *synth_truth_keys(L, T, 6, pct), ext=True)
+            assert np.array_equal(b.cls(1), cls) and np.array_equal(rows[True][0][1], oroc)
+            idx = b.idx(1)
+            assert np.array_equal(idx[:sc["tp_lines"]], np.nonzero(cls == 3)[0]) and np.array_equal(idx[N - sc["fp_lines"]:], np.nonzero(cls == 1)[0])
+        b.close()
+    for k in range(3):
+        assert np.array_equal(rows[True][k], rows[False][k]), k
+    for t in tids:
+        engine.truth_release(t)

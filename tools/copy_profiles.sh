@@ -7,6 +7,7 @@ cp "$(st ${TAG}shuf)" profiles/${R}_kernel_stats_shuffled.csv
 cp "$(st ${TAG}shuf3)" profiles/${R}_kernel_stats_shuffled_config3.csv
 cp "$(st ${TAG}alle)" profiles/${R}_kernel_stats_alleles.csv
 cp "$(st ${TAG}shufx)" profiles/${R}_kernel_stats_shuffled_alleles.csv
+cp "$(st ${TAG}shufx4)" profiles/${R}_kernel_stats_shuffled_config4.csv
 cp gpurun_out/${R}_pmc_per_launch.json profiles/${R}_pmc_per_launch.json
 cp gpurun_out/traffic.json profiles/traffic.json
 cp gpurun_out/${TAG}_pmc_shuffled.json profiles/${R}_pmc_shuffled.json

@@ -16,6 +16,9 @@ PCT=30 bash tools/pmc_shuffled.sh $TAG "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES S
 mkdir -p gpurun_out/trace_${TAG}shufx
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/trace_${TAG}shufx -- python3 $ROOT/tools/shuffled_ext.py 256 > $ROOT/gpurun_out/${TAG}_trace_shufx.log 2>&1)
 python3 tools/shuffled_ext.py 256 > gpurun_out/${TAG}_shuffled_ext.log 2>&1
+mkdir -p gpurun_out/trace_${TAG}shufx4
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/trace_${TAG}shufx4 -- python3 $ROOT/tools/shuffled_ext.py 64 2000000 10000000 200000 > $ROOT/gpurun_out/${TAG}_trace_shufx4.log 2>&1)
+python3 tools/shuffled_ext.py 64 2000000 10000000 200000 >> gpurun_out/${TAG}_shuffled_ext.log 2>&1
 python3 tools/e2e_files_bench.py 16 > gpurun_out/${TAG}_e2e.log 2>&1
 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 tail -c 600 gpurun_out/${TAG}_bench.json

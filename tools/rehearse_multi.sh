@@ -12,4 +12,4 @@ python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127
 # and the collective over RCCL itself at the only world size one card allows (QM_BENCH_FORCE_PG=1: process group "nccl" on the
 # device, the all-reduce of the engine's buffer inside every step)
 unset QM_BENCH_SAME_DEVICE QM_BENCH_BACKEND
-QM_BENCH_FORCE_PG=1 python3 bench.py --steps 10 --warmup 3 --cpu-sample 0 --shell-sample 0 --shuffled-vcfs 0 --shuffled3-vcfs 0 --shuffled-alleles-vcfs 0 --alleles-vcfs 0 --alloc-reps 0 2>/dev/null | tail -1
+QM_BENCH_FORCE_PG=1 python3 bench.py --steps 10 --warmup 3 --cpu-sample 0 --shell-sample 0 --shuffled-vcfs 0 --shuffled3-vcfs 0 --shuffled-alleles-vcfs 0 --shuffled4-vcfs 0 --alleles-vcfs 0 --alloc-reps 0 2>/dev/null | tail -1
