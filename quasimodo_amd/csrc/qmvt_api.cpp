@@ -450,6 +450,11 @@ struct qm_batch {
   // What a finish found stays known while the columns stay the same (only qm_batch_upload* / qm_batch_synth write them): a VCF found out
   // of order is not streamed by the optimistic pass again, and qm_batch_finish queues its bucket path behind the run without first
   // waiting for the flags (a host round trip of ~ 0.15 ms per step).  QM_MEMO=0: off.
+  std::vector<int> lastx_vs;          // bucketx_chunk: the chunk whose tables are on the device (a batch run again)
+  std::vector<uint32_t> lastx_por;
+  std::vector<int> lastx_seg_vcf;     // VCF of every segment
+  int lastx_nseg = 0;
+  int64_t lastx_nbt = 0, lastx_nkt = 0;
   std::vector<uint8_t> known;         // per VCF: 1 = out of order, as the last finish found it
   std::vector<uint32_t> known_posor;  // its position bits (vcf_posor of that finish)
   int n_known = 0;
@@ -1030,7 +1035,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     }
   }
   if (rc != QM_OK) return rc;
-  b->last2_vs.clear();   // (the two-level path keeps its tables in the same arrays)
+  b->last2_vs.clear(); b->lastx_vs.clear();   // (the two-level path and the partitions path keep their tables in the same arrays)
   const bool same_tables = b->last_segs.size() == segs.size() && memcmp(b->last_segs.data(), segs.data(), sizeof(SortSeg) * segs.size()) == 0;
   if (!same_tables || (try_buckets && !b->bk_tiles_valid)) {
     build_tile_maps();
@@ -1332,7 +1337,7 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   const int nseg = (int)segs.size();
   if (nbt > INT32_MAX || nkt > INT32_MAX) return fail(QM_E_LIMIT, "bucket path: too many tiles");
   // --- the arrays of the one-level path, sized for the level-2 segments (its cached tables are gone after this)
-  b->last_segs.clear(); b->bk_tiles_valid = false; b->bk_fake_valid = false;
+  b->last_segs.clear(); b->bk_tiles_valid = false; b->bk_fake_valid = false; b->lastx_vs.clear();
   int64_t cap;
   if (rc == QM_OK) { cap = b->cap_segs; rc = regrow(&b->d_segs, &cap, (int64_t)nseg, &b->dev_bytes); b->cap_segs = (int)cap; }
   if (rc == QM_OK) rc = regrow(&b->d_vsegs, &b->cap_vsegs, (int64_t)nv, &b->dev_bytes);
@@ -1424,11 +1429,18 @@ static bool bucketx_takes(const qm_batch* b, int64_t n, uint32_t posor) {
 static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, const std::vector<uint32_t>& posor, bool* taken) {
   *taken = false;
   const int nv = (int)vs.size();
+  std::vector<uint32_t> por((size_t)nv);
+  for (int i = 0; i < nv; ++i) por[(size_t)i] = posor[(size_t)vs[(size_t)i]];
+  const bool same = !b->lastx_vs.empty() && b->lastx_vs == vs && b->lastx_por == por;   // the tables of this chunk are still on the device
+  int nseg = b->lastx_nseg;
+  int64_t nbt = b->lastx_nbt, nkt = b->lastx_nkt;
+  const int out_stride = 2 * HB_BUCKETS;
+  if (!same) {
+  nbt = 0; nkt = 0;
   std::vector<SortSeg> segs, vsegs((size_t)nv);
   std::vector<VcfDesc> fake;
   std::vector<int32_t> bk_tile_seg, ktile_seg, ktile_local, vparts((size_t)nv);
-  int64_t bk_ents = 0, nbt = 0, nkt = 0;
-  const int out_stride = 2 * HB_BUCKETS;
+  int64_t bk_ents = 0;
   for (int i = 0; i < nv; ++i) {
     const VcfDesc& d = b->L.vcfs[(size_t)vs[(size_t)i]];
     const uint32_t kor = (posor[(size_t)vs[(size_t)i]] << 4) | 15u;
@@ -1462,10 +1474,10 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
     for (int t = 0; t < d.ntiles; ++t) ktile_local[k0 + (size_t)t] = t;
     nkt += d.ntiles;
   }
-  const int nseg = (int)segs.size();
+  nseg = (int)segs.size();
   if (nbt > INT32_MAX || nkt > INT32_MAX) return fail(QM_E_LIMIT, "bucket path: too many tiles");
   // the arrays of the one-level path, sized for these segments (its cached tables, and the two-level path's, are gone after this)
-  b->last_segs.clear(); b->bk_tiles_valid = false; b->bk_fake_valid = false; b->last2_vs.clear();
+  b->last_segs.clear(); b->bk_tiles_valid = false; b->bk_fake_valid = false; b->last2_vs.clear(); b->lastx_vs.clear();
   int rc = QM_OK;
   int64_t cap;
   { cap = b->cap_segs; rc = regrow(&b->d_segs, &cap, (int64_t)nseg, &b->dev_bytes); b->cap_segs = (int)cap; }
@@ -1500,7 +1512,11 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   HIPCHK(hipMemcpyAsync(b->d_ktile_local, ktile_local.data(), 4 * ktile_local.size(), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->d_bk_vcfs, fake.data(), sizeof(VcfDesc) * fake.size(), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->d_vparts, vparts.data(), 4 * vparts.size(), hipMemcpyHostToDevice, st));
-  HIPCHK(hipStreamSynchronize(st));   // the host tables die with this call
+  HIPCHK(hipStreamSynchronize(st));   // the host tables die with this block
+  b->lastx_vs = vs; b->lastx_por = por; b->lastx_nseg = nseg; b->lastx_nbt = nbt; b->lastx_nkt = nkt;
+  b->lastx_seg_vcf.resize((size_t)nseg);
+  for (int i = 0; i < nseg; ++i) b->lastx_seg_vcf[(size_t)i] = segs[(size_t)i].main_vcf;
+  }   // !same
   const size_t ncur = ((size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg + 32 + 16 * 65) * 4;
   HIPCHK(hipMemsetAsync(b->bk_cursor, 0, ncur, st));
   HIPCHK(hipMemsetAsync(b->bk_xcursor, 0, (size_t)nseg * HB_BUCKETS * HB_SUBS * 4, st));
@@ -1523,8 +1539,8 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   HIPCHK(hipStreamSynchronize(st));
   b->path_stats[QM_PATH_BUCKET_CHUNKS] += 1;
   for (int i = 0; i < nseg; ++i) {
-    if (hfl[(size_t)i] & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", segs[(size_t)i].main_vcf);
-    if (hfl[(size_t)i] & SPANF_OVERFLOW) { b->path_stats[QM_PATH_OVERFLOW_CHUNKS] += 1; return QM_OK; }   // a bucket did not fit: the radix sort redoes the chunk
+    if (hfl[(size_t)i] & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", b->lastx_seg_vcf[(size_t)i]);
+    if (hfl[(size_t)i] & SPANF_OVERFLOW) { b->path_stats[QM_PATH_OVERFLOW_CHUNKS] += 1; b->lastx_vs.clear(); return QM_OK; }   // a bucket did not fit: the radix sort redoes the chunk
   }
   launch_sort_copy_rows(b->d_vsegs, nv, b->bk_roc, b->bk_rscal, b->roc, b->scalars, b->n_bins, st, global, b->d_vcfs, b->d_vparts);
   launch_tile_counts(b->d_vsegs, b->d_ktile_seg, b->d_ktile_local, (int)nkt, b->mask_pass, b->mask_tp, b->tile_tp, b->tile_fp, st);
