@@ -1074,7 +1074,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     S.segs = b->d_segs; S.tile_seg = b->d_bk_tile_seg; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
     S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
     S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = nullptr;
-    S.xent = xstream ? b->bk_xent : nullptr; S.xcursor = xstream ? b->bk_xcursor : nullptr; S.ext = xstream ? 1 : 0;
+    S.xent = xstream ? b->bk_xent : nullptr; S.xcursor = xstream ? b->bk_xcursor : nullptr; S.ext = xstream ? 1 : 0; S.pairs = 0;
     if (xstream) HIPCHK(hipMemsetAsync(b->bk_xcursor, 0, (size_t)nseg * HB_BUCKETS * HB_SUBS * 4, st));
     HashParams H;
     H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
@@ -1381,7 +1381,7 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   BucketScatterParams S;
   S.segs = b->d_segs; S.tile_seg = b->d_bk_tile_seg; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
   S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
-  S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = b->p_ent; S.xent = nullptr; S.xcursor = nullptr; S.ext = 0;
+  S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = b->p_ent; S.xent = nullptr; S.xcursor = nullptr; S.ext = 0; S.pairs = 0;
   HashParams H;
   H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
   H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.seg_base = 0;
@@ -1409,9 +1409,10 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
 // The one-level path needs <= 8 192 records and <= 2^19 keys per bucket: configs[4]'s VCFs (2 M records on a 10 Mb genome) have
 // neither.  The two-level path's first scatter packs level-1 entries that have no room for allele codes, so for these batches
 // every PARTITION of 2^27 keys (256 buckets of 2^19) is a segment of the one-level scatter that reads ALL of its VCF's columns
-// and keeps the records of its own key range (SortSeg.part): P partitions cost P reads of the columns (two for a 10 Mb genome:
-// about what the two-level path's counting pass and first scatter cost) and nothing else is new -- bucket rows, the two joins,
-// the rows per segment and their sum per VCF are the one-level and two-level paths'.
+// and keeps the records of its own key range (SortSeg.part).  Two neighbouring partitions share one pass (the 512-digit
+// instantiation of the scatter: the first one's tiles fill both), so a 10 Mb genome costs ONE read of the columns, four partitions
+// two; nothing else is new -- bucket rows, the two joins, the rows per segment and their sum per VCF are the one-level and
+// two-level paths'.
 constexpr int PX_MAX_PARTS = 4;
 static int ext_parts_of(uint32_t posor) { return (int)((((uint64_t)posor << 4) | 15u) >> P2_SHIFT) + 1; }
 static bool bucketx_takes(const qm_batch* b, int64_t n, uint32_t posor) {
@@ -1450,13 +1451,18 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
       SortSeg g;
       memset(&g, 0, sizeof g);
       g.src_off = d.off; g.n = d.n; g.main_vcf = vs[(size_t)i]; g.sub_vcf = i; g.main_tile0 = d.tile0;
-      g.pad = DJ_MAX_SHIFT; g.key_base = (uint32_t)p << P2_SHIFT; g.part = p + 1 == parts ? 2 : 1;
+      g.pad = DJ_MAX_SHIFT; g.key_base = (uint32_t)p << P2_SHIFT;
+      // two neighbouring partitions share ONE pass over the columns: the tiles belong to the first of the pair, whose 512 digits
+      // reach into the second one's cursors, regions and rows (same capacity, laid out one behind the other)
+      const bool lead = (p & 1) == 0 && p + 1 < parts, follow = (p & 1) == 1;
+      const bool pair_last = lead ? p + 2 == parts : p + 1 == parts;
+      g.part = (pair_last ? 2 : 1) | (lead ? 4 : 0);
       g.nbk = p + 1 == parts ? std::min<int>(HB_BUCKETS, (int)((kor - g.key_base) >> DJ_MAX_SHIFT) + 1) : HB_BUCKETS;
       int64_t want = d.n / (128 * HB_SUBS) * 3 / 2 + 16, cap2 = 16;   // (how the records spread over the partitions is not known: room as for all of them)
       while (cap2 < want && cap2 < HB_SUB_MAX) cap2 *= 2;
       g.bk_cap = (int32_t)cap2; g.bk_off = bk_ents; g.bk_tile0 = (int32_t)nbt;
       bk_ents += (int64_t)HB_BUCKETS * HB_SUBS * cap2;
-      const int64_t t = (d.n + BK_TILE - 1) / BK_TILE;
+      const int64_t t = follow ? 0 : (d.n + BK_TILE - 1) / BK_TILE;   // (the second of a pair has no tiles of its own)
       bk_tile_seg.insert(bk_tile_seg.end(), (size_t)t, (int32_t)segs.size());
       nbt += t;
       VcfDesc f = VcfDesc();   // the two streams' rows of a partition as the "spans" of a VCF for k_finalize
@@ -1523,7 +1529,7 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   BucketScatterParams S;
   S.segs = b->d_segs; S.tile_seg = b->d_bk_tile_seg; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
   S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
-  S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = nullptr; S.xent = b->bk_xent; S.xcursor = b->bk_xcursor; S.ext = 1;
+  S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = nullptr; S.xent = b->bk_xent; S.xcursor = b->bk_xcursor; S.ext = 1; S.pairs = 1;   // (tiles of single partitions run through the 512-digit instantiation as well)
   HashParams H;
   H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
   H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.seg_base = 0;

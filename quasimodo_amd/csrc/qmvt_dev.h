@@ -171,7 +171,8 @@ struct SortSeg {
   uint32_t key_base;         // two-level path: first key of the segment's partition (0 on the one-level path)
   int32_t part;              // one-level scatter over a PARTITION of a VCF's key range, read from the columns (allele-extended VCFs too
                              // large or too wide for 256 buckets): 0 = the whole VCF; 1 = keys outside [key_base, key_base + 256 << pad)
-                             // belong to another segment of the same VCF; 2 = the VCF's last partition: keys above it flag the VCF
+                             // belong to another segment of the same VCF; 2 = the VCF's last partition: keys above it flag the VCF;
+                             // + 4: the segment's tiles fill the buckets of the NEXT segment too (two partitions, 512 buckets, one read)
 };
 // bucket path (k_bucket_scatter + k_classify_hash): one workgroup per (segment, bucket of the one scatter pass)
 #ifndef QM_BK_TILE
@@ -248,6 +249,7 @@ struct BucketScatterParams {
   uint64_t* xent;
   uint32_t* xcursor;
   int32_t ext;
+  int32_t pairs;              // the launch holds tiles whose segment stands for two partitions (SortSeg.part & 4): the 512-digit instantiation
 };
 // everything k_classify_hash needs to know about one (segment, bucket), laid out by k_bucket_rows before it runs: the
 // workgroup of a bucket lives only a few microseconds, and every dependent load on its way to the data (segment table ->

@@ -24,6 +24,7 @@
 // Reference stages replaced (file:line in /root/reference):
 //   fgrep -wf / -wvf            program/extract_TP_FP_SNPs.py:50-57
 //   R intersect/setdiff/length  scripts/caller_performance_compare.R:94-96
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -1530,17 +1531,21 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
 // EXT (allele-extended batches): every record with valid allele codes is live; those whose REF / ALT are not two single bases
 // leave in a second stream of 16-byte entries (the ordinary entry with the position's first key, then the two codes), written
 // straight to their bucket's second region -- k_join_ext joins them exactly, k_join_direct the single-base ones.
-template <bool L2, bool EXT>
+// NB = 512 (allele-extended VCFs in partitions, SortSeg.part & 4): the tile's segment stands for TWO neighbouring partitions of its
+// VCF -- 512 buckets whose cursors, regions and rows lie one behind the other -- so that the columns are read once for both.
+template <bool L2, bool EXT, int NB = 256>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : BK_WAVES_PER_EU, 8))) void k_bucket_scatter(BucketScatterParams P) {
   constexpr int PER = BK_TILE / 512;          // records per thread, in groups of four consecutive ones
   static_assert(BK_TILE % 2048 == 0 && PER >= 4, "whole 16-byte loads, 256 records per wave and group");
-  __shared__ uint32_t s_cnt[256];             // records of digit d in the tile (running during the ranking)
-  __shared__ uint32_t s_loc[256];             // tile-local start of digit d's run
-  __shared__ int32_t s_glob[256];             // place of digit d's run in its sub-region, minus s_loc[d]
-  __shared__ uint32_t s_scan[5];
+  static_assert(NB == 256 || (NB == 512 && !L2), "one digit per thread at most");
+  typedef typename std::conditional<NB == 256, uint8_t, uint16_t>::type digit_t;
+  __shared__ uint32_t s_cnt[NB];              // records of digit d in the tile (running during the ranking)
+  __shared__ uint32_t s_loc[NB];              // tile-local start of digit d's run
+  __shared__ int32_t s_glob[NB];              // place of digit d's run in its sub-region, minus s_loc[d]
+  __shared__ uint32_t s_scan[NB / 64 + 1];
   __shared__ uint64_t s_e[BK_TILE];
-  __shared__ uint8_t s_d[BK_TILE];
-  __shared__ uint32_t s_cntx[EXT ? 256 : 1];     // second stream: records of digit d in the tile, then where its run starts in the sub-region
+  __shared__ digit_t s_d[BK_TILE];
+  __shared__ uint32_t s_cntx[EXT ? NB : 1];      // second stream: records of digit d in the tile, then where its run starts in the sub-region
   __shared__ uint32_t s_flut[16];                // flag_info of the sixteen flag nibbles (pack_record_fast)
   const int bid = (int)blockIdx.x + P.tile_base;
   const int seg = P.tile_seg[bid];
@@ -1553,8 +1558,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   __shared__ uint32_t s_prof[16];
   if (threadIdx.x < 16) s_prof[threadIdx.x] = 0u;
 #endif
-  if (tid < 256) { s_cnt[tid] = 0u; if (EXT) s_cntx[tid] = 0u; }
+  if (tid < NB) { s_cnt[tid] = 0u; if (EXT) s_cntx[tid] = 0u; }
   if (!L2 && tid >= 256 && tid < 272) s_flut[tid - 256] = flag_info((uint32_t)(tid - 256));
+  const uint32_t dlim = NB == 512 && (sg.part & 4) ? 512u : (uint32_t)HB_BUCKETS;   // buckets this tile's segment stands for
   __syncthreads();
   BKS_TICK(1);
   const int64_t tbase = (int64_t)(bid - sg.bk_tile0) * BK_TILE;
@@ -1639,9 +1645,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
           kept |= ((inf >> 16) & 1u) << u;
           const uint32_t rel = key - sg.key_base;   // (key_base = 0 unless the segment is a partition of its VCF)
           const uint32_t d = rel >> shift;
-          if (sg.part != 0 && (key < sg.key_base || (sg.part == 1 && d >= (uint32_t)HB_BUCKETS))) {
-            // another partition of the same VCF takes this record (every partition reads all of the VCF's columns)
-          } else if (d >= (uint32_t)HB_BUCKETS) {
+          if (sg.part != 0 && (key < sg.key_base || ((sg.part & 3) == 1 && d >= dlim))) {
+            // another partition of the same VCF takes this record (every partition, or pair of partitions, reads all of the VCF's columns)
+          } else if (d >= dlim) {
             segfl |= SPANF_OVERFLOW;   // a position above what the optimistic pass saw of this VCF: the radix sort redoes it
           } else if (!EXT || (uint32_t)(r[j][u] | a[j][u]) < 4u) {
             const uint32_t v = rel - (d << shift);   // < 2^24: shift <= 24
@@ -1670,7 +1676,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   BKS_TICK(4);
   // thread d: exclusive scan over the digit counts = tile-local run starts; room for the run in the bucket's sub-region
   uint32_t cnt = 0, incl = 0;
-  if (tid < 256) {
+  if (tid < NB) {
     cnt = s_cnt[tid];
     incl = cnt;
 #pragma unroll
@@ -1686,14 +1692,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   // -DHB_PROFILE -DBKS_PROFILE) passes behind it.  (Same-box A/B against waiting on the spot: 1.39 ms either way -- the kernel is
   // bound by what the memory system does with its mix of streamed reads and scattered 100-byte writes, not by any wait of its own.)
   uint32_t g = 0, loc = 0;
-  if (tid < 256) {
+  uint32_t cntx2 = 0, gx2 = 0;   // NB = 512: the thread of digit d reserves for both streams
+  if (tid < NB) {
     uint32_t woff = 0;
 #pragma unroll
-    for (int w = 0; w < 3; ++w) woff += w < wave ? s_scan[w] : 0u;
+    for (int w = 0; w < NB / 64 - 1; ++w) woff += w < wave ? s_scan[w] : 0u;
     loc = woff + incl - cnt;
     s_loc[tid] = loc;
-    if (cnt) g = atomicAdd(&P.cursor[((size_t)seg * HB_BUCKETS + tid) * HB_SUBS + sub], cnt);
-    if (tid == 255) s_scan[4] = loc + cnt;
+    if (cnt) g = atomicAdd(&P.cursor[((size_t)seg * HB_BUCKETS + tid) * HB_SUBS + sub], cnt);   // (digits 256..511: the next partition's cursors follow)
+    if (tid == NB - 1) s_scan[NB / 64] = loc + cnt;
+    if (EXT && NB == 512) {
+      cntx2 = s_cntx[tid];
+      if (cntx2) gx2 = atomicAdd(&P.xcursor[((size_t)seg * HB_BUCKETS + tid) * HB_SUBS + sub], cntx2);
+    }
   } else if (EXT) {   // the other four waves: room for the second stream's runs (no reordering in LDS: each entry is stored where it belongs)
     cnt = s_cntx[tid - 256];
     if (cnt) g = atomicAdd(&P.xcursor[((size_t)seg * HB_BUCKETS + (tid - 256)) * HB_SUBS + sub], cnt);
@@ -1707,13 +1718,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
       const uint32_t d = dr[k] >> 16;
       const uint32_t lp = s_loc[d] + (dr[k] & 0xffffu);
       s_e[lp] = ent[k];
-      s_d[lp] = (uint8_t)d;
+      s_d[lp] = (digit_t)d;
     }
   }
-  if (tid < 256 || EXT) {
+  if (tid < NB || EXT) {
     if (cnt && g + cnt > (uint32_t)sg.bk_cap) atomicOr(&P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg], SPANF_OVERFLOW);
-    if (tid < 256) s_glob[tid] = (int32_t)g - (int32_t)loc;
+    if (tid < NB) s_glob[tid] = (int32_t)g - (int32_t)loc;
     else s_cntx[tid - 256] = g;
+    if (EXT && NB == 512) {
+      if (cntx2 && gx2 + cntx2 > (uint32_t)sg.bk_cap) atomicOr(&P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg], SPANF_OVERFLOW);
+      s_cntx[tid] = gx2;
+    }
   }
   BKS_TICK(7);
   __syncthreads();
@@ -1735,7 +1750,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
       }
     }
   }
-  const int total = (int)s_scan[4];
+  const int total = (int)s_scan[NB / 64];
   uint64_t* out = P.ent + sg.bk_off;
   for (int idx = tid; idx < total; idx += 512) {
     const uint32_t d = s_d[idx];
@@ -3309,6 +3324,7 @@ void launch_bucket_rows(const HashParams& P, int nseg, hipStream_t st) {
 void launch_bucket_scatter(const BucketScatterParams& P, int ntiles, hipStream_t st) {
   if (ntiles <= 0) return;
   if (P.l1_ent) hipLaunchKernelGGL((k_bucket_scatter<true, false>), dim3(ntiles), dim3(512), 0, st, P);
+  else if (P.ext && P.pairs) hipLaunchKernelGGL((k_bucket_scatter<false, true, 512>), dim3(ntiles), dim3(512), 0, st, P);
   else if (P.ext) hipLaunchKernelGGL((k_bucket_scatter<false, true>), dim3(ntiles), dim3(512), 0, st, P);
   else hipLaunchKernelGGL((k_bucket_scatter<false, false>), dim3(ntiles), dim3(512), 0, st, P);
 }
