@@ -11,4 +11,5 @@ SEED=105 run QM_BUCKET_EXT=0
 SEED=106 run QM_MEMO=0
 SEED=107 run QM_BUCKET_PARTS=4
 SEED=108 run QM_PIPE_CHUNKS=3 QM_PIPE_MIN_SPANS=1
+SEED=109 run QM_BUCKETX=2
 cat $OUT
