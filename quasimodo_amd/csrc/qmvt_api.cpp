@@ -1405,7 +1405,8 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   return QM_OK;
 }
 
-// ---- allele-extended VCFs too large or too wide for 256 buckets: partitions of the key space, each read from the columns ----
+// ---- VCFs too large or too wide for 256 buckets (allele-extended ones; default-mode ones on references of 8.4 ... 16.8 M positions):
+//      partitions of the key space, read from the columns ----
 // The one-level path needs <= 8 192 records and <= 2^19 keys per bucket: configs[4]'s VCFs (2 M records on a 10 Mb genome) have
 // neither.  The two-level path's first scatter packs level-1 entries that have no room for allele codes, so for these batches
 // every PARTITION of 2^27 keys (256 buckets of 2^19) is a segment of the one-level scatter that reads ALL of its VCF's columns
@@ -1416,15 +1417,17 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
 constexpr int PX_MAX_PARTS = 4;
 static int ext_parts_of(uint32_t posor) { return (int)((((uint64_t)posor << 4) | 15u) >> P2_SHIFT) + 1; }
 static bool bucketx_takes(const qm_batch* b, int64_t n, uint32_t posor) {
-  if (!b->ext) return false;
-  if (const char* e = getenv("QM_BUCKET_EXT")) if (atoi(e) == 0) return false;
+  if (b->ext) if (const char* e = getenv("QM_BUCKET_EXT")) if (atoi(e) == 0) return false;
   if (const char* e = getenv("QM_SORT_PATH")) if (strcmp(e, "radix") == 0) return false;
   if (join_hash_forced()) return false;
   if (n < HB_MIN_RECORDS || n > ((int64_t)1 << HB_INDEX_BITS)) return false;
   const int parts = ext_parts_of(posor);
   if (parts > PX_MAX_PARTS) return false;
-  if (const char* e = getenv("QM_BUCKETX")) { if (atoi(e) == 0) return false; if (atoi(e) == 2) return true; }   // 2: every unsorted VCF of an allele-extended batch (tests, fuzz)
-  return parts > 1 || !bucket_path_takes(b, n);
+  if (const char* e = getenv("QM_BUCKETX")) { if (atoi(e) == 0) return false; if (atoi(e) == 2) return true; }   // 2: every unsorted VCF that fits (tests, fuzz)
+  if (b->ext) return parts > 1 || !bucket_path_takes(b, n);
+  // default mode: a reference of 8.4 ... 16.8 M positions is ONE pair of partitions = one pass of the 512-digit scatter and the
+  // bit-map join, where the one-level path would need the hashed join (bucket key ranges of 2^20) and larger VCFs two levels
+  return parts == 2;
 }
 
 static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, const std::vector<uint32_t>& posor, bool* taken) {
@@ -1435,7 +1438,8 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   const bool same = !b->lastx_vs.empty() && b->lastx_vs == vs && b->lastx_por == por;   // the tables of this chunk are still on the device
   int nseg = b->lastx_nseg;
   int64_t nbt = b->lastx_nbt, nkt = b->lastx_nkt;
-  const int out_stride = 2 * HB_BUCKETS;
+  const bool xs = b->ext;                                  // two entry streams (allele-extended batches)
+  const int out_stride = xs ? 2 * HB_BUCKETS : HB_BUCKETS;
   if (!same) {
   nbt = 0; nkt = 0;
   std::vector<SortSeg> segs, vsegs((size_t)nv);
@@ -1499,9 +1503,9 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
     if (rc == QM_OK) rc = regrow(&b->bk_hist, &c1, orows * SPAN_HIST_WORDS, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_scal, &c2, orows * 8, &b->dev_bytes);
     if (rc == QM_OK) b->cap_bk_rows = std::max(b->cap_bk_rows, orows);
-    if (rc == QM_OK) rc = regrow(&b->bk_xent, &b->cap_bk_xent, 2 * bk_ents, &b->dev_bytes);
-    if (rc == QM_OK) rc = regrow(&b->bk_xcursor, &b->cap_bk_xcursor, rows * HB_SUBS, &b->dev_bytes);
-    if (rc == QM_OK) rc = regrow(&b->bk_xrows, &b->cap_bk_xrows, rows, &b->dev_bytes);
+    if (rc == QM_OK && xs) rc = regrow(&b->bk_xent, &b->cap_bk_xent, 2 * bk_ents, &b->dev_bytes);
+    if (rc == QM_OK && xs) rc = regrow(&b->bk_xcursor, &b->cap_bk_xcursor, rows * HB_SUBS, &b->dev_bytes);
+    if (rc == QM_OK && xs) rc = regrow(&b->bk_xrows, &b->cap_bk_xrows, rows, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->d_bk_vcfs, &b->cap_bk_vcfs, (int64_t)nseg, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_ent, &b->cap_bk_ent, bk_ents, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_rows, &b->cap_bk_rowdesc, rows, &b->dev_bytes);
@@ -1525,19 +1529,20 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   }   // !same
   const size_t ncur = ((size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg + 32 + 16 * 65) * 4;
   HIPCHK(hipMemsetAsync(b->bk_cursor, 0, ncur, st));
-  HIPCHK(hipMemsetAsync(b->bk_xcursor, 0, (size_t)nseg * HB_BUCKETS * HB_SUBS * 4, st));
+  if (xs) HIPCHK(hipMemsetAsync(b->bk_xcursor, 0, (size_t)nseg * HB_BUCKETS * HB_SUBS * 4, st));
   BucketScatterParams S;
   S.segs = b->d_segs; S.tile_seg = b->d_bk_tile_seg; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
   S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
-  S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = nullptr; S.xent = b->bk_xent; S.xcursor = b->bk_xcursor; S.ext = 1; S.pairs = 1;   // (tiles of single partitions run through the 512-digit instantiation as well)
+  S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = nullptr; S.xent = xs ? b->bk_xent : nullptr; S.xcursor = xs ? b->bk_xcursor : nullptr; S.ext = xs ? 1 : 0;
+  S.pairs = 1;   // (tiles of single partitions run through the 512-digit instantiation as well)
   HashParams H;
   H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
   H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.seg_base = 0;
-  H.xrows = b->bk_xrows; H.xent = b->bk_xent; H.xcursor = b->bk_xcursor; H.out_stride = out_stride; H.ext = 1;
+  H.xrows = xs ? b->bk_xrows : nullptr; H.xent = b->bk_xent; H.xcursor = b->bk_xcursor; H.out_stride = out_stride; H.ext = xs ? 1 : 0;
   launch_bucket_rows(H, nseg, st);
   launch_bucket_scatter(S, (int)nbt, st);
   launch_join_direct(H, nseg, DJ_MAX_SHIFT, HB_BUCKETS, st);
-  launch_join_ext(H, nseg, HB_BUCKETS, st);
+  if (xs) launch_join_ext(H, nseg, HB_BUCKETS, st);
   launch_finalize(bucket_rows_finalize(b), nseg, st);
   HIPCHK(hipGetLastError());
   std::vector<uint32_t> hfl((size_t)nseg);

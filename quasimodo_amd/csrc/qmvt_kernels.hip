@@ -3325,6 +3325,7 @@ void launch_bucket_scatter(const BucketScatterParams& P, int ntiles, hipStream_t
   if (ntiles <= 0) return;
   if (P.l1_ent) hipLaunchKernelGGL((k_bucket_scatter<true, false>), dim3(ntiles), dim3(512), 0, st, P);
   else if (P.ext && P.pairs) hipLaunchKernelGGL((k_bucket_scatter<false, true, 512>), dim3(ntiles), dim3(512), 0, st, P);
+  else if (P.pairs) hipLaunchKernelGGL((k_bucket_scatter<false, false, 512>), dim3(ntiles), dim3(512), 0, st, P);
   else if (P.ext) hipLaunchKernelGGL((k_bucket_scatter<false, true>), dim3(ntiles), dim3(512), 0, st, P);
   else hipLaunchKernelGGL((k_bucket_scatter<false, false>), dim3(ntiles), dim3(512), 0, st, P);
 }

@@ -822,3 +822,28 @@ def test_a_batch_remembers_which_vcfs_were_out_of_order_until_their_columns_chan
         check_all(2)
     b.close()
     engine.truth_release(tid)
+
+
+def test_unsorted_vcfs_on_a_reference_of_ten_million_positions_take_a_pair_of_partitions(engine, oracle):
+    """Default mode, 1 M records on a 10 Mb reference, out of order: the key range needs buckets of 2^20 keys on the one-level path
+    (the hashed join); as ONE pair of partitions of 2^27 keys it is one pass of the 512-digit scatter and the bit-map join.  Against
+    the sorted run and, for one VCF, the oracle."""
+    from oracle.synth import synth_truth_keys
+    L, T, N = 10_000_000, 100_000, 1_000_000
+    tid = engine.truth_synth(L, T, 9)
+    rows = {}
+    for shuffled in (False, True):
+        b = engine.batch([N] * 3, [tid] * 3)
+        b.synth(L, T, 9, 7000, shuffled=shuffled)
+        for _ in range(2 if shuffled else 1):
+            b.run(); b.finish()
+        rows[shuffled] = (b.roc(), b.scalars()[:, :5].copy(), b.global_counts())
+        if shuffled:
+            ps = b.path_stats()
+            assert ps["unsorted"] == 3 and ps["bucket_two_level"] == 3 and ps["bucket_hashed"] == 0 and ps["radix"] == 0, ps
+            cls, oroc, sc = oracle.classify_columns(*b.columns(2), *synth_truth_keys(L, T, 9))
+            assert np.array_equal(b.cls(2), cls) and np.array_equal(rows[True][0][2], oroc)
+        b.close()
+    for k in range(3):
+        assert np.array_equal(rows[True][k], rows[False][k]), k
+    engine.truth_release(tid)
