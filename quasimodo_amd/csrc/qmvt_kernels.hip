@@ -3013,7 +3013,7 @@ __global__ __launch_bounds__(XJ_THREADS) void k_join_ext(HashParams P) {
   uint32_t fpr = 0;
 #pragma unroll
   for (int t = 0; t < XJ_TRIPS; ++t) {
-    if (t >= ntrips) break;   // wave-uniform
+    if (t < ntrips) {   // wave-uniform
     const uint32_t pr = xs[t] & 0x7fffu;
     const bool mine = (fpm >> t) & 1u;
     const bool shared = mine && ((s_s2[pr >> 5] >> (pr & 31u)) & 1u);
@@ -3029,6 +3029,7 @@ __global__ __launch_bounds__(XJ_THREADS) void k_join_ext(HashParams P) {
           s_lr[at] = q[2]; s_la[at] = q[3];
         }
       }
+    }
     }
   }
   XJ_TICK(9);
