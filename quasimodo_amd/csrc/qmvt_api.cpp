@@ -526,6 +526,8 @@ static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int
   A_(b->roc, (size_t)n_vcf * 3 * (size_t)n_bins) A_(b->global_acc, nt * 3 * (size_t)n_bins) A_(b->scalars, (size_t)n_vcf * 8)
   A_(b->d_vcfs, (size_t)n_vcf) A_(b->d_spans, b->cap_spans) A_(b->d_tile_vcf, b->cap_tiles) A_(b->cls_scratch, (size_t)L.max_n)
 #undef A_
+  if (rc == QM_OK && getenv("QM_DEBUG_PTRS"))   // where the batch landed (tools/alloc_probe.py: the step varies with it)
+    fprintf(stderr, "qmvt: batch pos %p flags %p mask_pass %p mask_tp %p idx %p\n", (void*)b->pos, (void*)b->flags, (void*)b->mask_pass, (void*)b->mask_tp, (void*)b->idx);
   if (rc == QM_OK) rc = upload_layout(b);
   if (rc == QM_OK) {
     // ranges of whole VCFs with about equal numbers of spans; small batches stay in one piece

@@ -1026,7 +1026,14 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
   // per thread in registers, the 256 thread totals with wave shuffles -- two barriers per 1 024 tiles
   {
     const int lane = tid & 63, wave = tid >> 6;
-    uint32_t carry_t = 0, carry_f = 0;
+    // the FP run ends at the back of the VCF's region: its offsets start at n - (FP lines of the VCF), so that a wave of
+    // k_compact finds the place of its tile's entries with one load
+    uint32_t fsum = 0;
+    for (int i = tid; i < vd.ntiles; i += 256) fsum += P.tile_fp[vd.tile0 + i];
+    fsum = wave_sum(fsum);
+    if (lane == 0) s_scan[8 + wave] = fsum;
+    __syncthreads();
+    uint32_t carry_t = 0, carry_f = (uint32_t)vd.n - (s_scan[8] + s_scan[9] + s_scan[10] + s_scan[11]);
     for (int base = 0; base < vd.ntiles; base += 1024) {
       const int t0 = base + tid * 4;
       uint32_t xt[4], xf[4];
@@ -1066,111 +1073,255 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
 
 // ---------------------------------------------------------------------------
 // k_compact: class masks -> compacted line-index lists (prefix-sum compaction).
-// One wave per span (the same spans as k_classify: <= SPAN_TILES tiles of one VCF).
-// The span's mask words are fetched with a few coalesced vector loads (lane l holds
-// words l, l + 64, ...) and broadcast from registers; per word a lane tests its bit,
-// ranks itself with popc(word & lanemask_lt) on top of a running offset and appends
-// its VCF-relative line index to a ring in LDS.  Whenever 256 entries are ready the
-// wave drains them with ONE 16-byte-per-lane store, aligned to 1 KiB of the output --
-// dword stores are issue-bound on gfx950, dwordx4 stores are not.  Only the ragged head
-// and tail of a span's run fall back to masked dword stores.
 // idx region of VCF v (vd.n entries at vd.off): TP line indices ascending from the
-// front, FP ascending, ending at the back.
+// front, FP ascending, ending at the back.  Stage replaced: the shell '>' redirections
+// of program/extract_TP_FP_SNPs.py:50-53.
+//
+// Round 4: one wave per TILE (1 024 records), K3_WAVES tiles of a span per workgroup.
+// * What bounded the kernel of rounds 1-3 (one wave per span of 16 tiles, a ring per list)
+//   was not its instruction stream: with the stores switched off it took 0.42 ms, with
+//   ONLY the stores 0.82 ms (tools/probe/store_shape.hip: waves that each write 60 KB, 1 KiB
+//   at a time with work in between, reach 5.1-5.4 TB/s; waves that write 4 KB and leave
+//   reach 6.4-6.5).  Short waves keep the chip's write front compact: what is being
+//   written at any one time is a few tens of MB of neighbouring lines instead of 5 000
+//   separate streams.
+// * A lane takes EIGHT records of a pass of 512: one byte of the TP mask and of kept & ~TP
+//   (byte loads, 64 B per wave-instruction).  One DPP prefix sum over the lanes' popcounts
+//   (TP and FP counts packed into one register) gives every lane the place of its first
+//   entry of either list; a 256-entry table in LDS (mask byte -> the positions of its set
+//   bits, one per byte) turns the lane's byte into its <= 8 entries, and the lane stores all
+//   eight slots UNCONDITIONALLY, highest slot first: a slot beyond the lane's count lands on
+//   a place a LATER lane owns (or beyond the list), and that lane's own store of the place
+//   is issued after it -- slot j of a later lane starts at a higher address, so it reaches
+//   the same place with a SMALLER j -- and the LDS keeps a wave's stores in order.  No
+//   per-entry branch, execution mask or rank: two instructions per slot.  (Lanes without an
+//   entry sit the eight stores out: their first slot IS the next lane's.)  Both passes of
+//   the FP list are stored before the TP list, which lies behind it in the wave's buffer.
+// * The tile's two runs leave LDS with 16-byte-per-lane stores.  A run starts wherever the
+//   tile's offset says: it is laid out in LDS with the same 16-byte phase as in the output,
+//   so every lane moves one aligned quad; the <= 3 entries in front of the first whole quad
+//   and behind the last one (of both lists: <= 12) leave with ONE masked dword store.
+// * Workgroups are dealt round-robin to the 8 XCDs: the block index is mapped so that every
+//   XCD owns a contiguous range of tiles, and the 128-byte lines two neighbouring tiles
+//   share meet in ONE L2 instead of reaching HBM as two partial writes.
+// k_finalize leaves tile_tp_off / tile_fp_off as places inside the VCF's region (the FP
+// offsets already shifted to the back), so a wave needs its span descriptor and then one
+// round trip (offsets and mask bytes together).
 // ---------------------------------------------------------------------------
-constexpr int K3_WORDS = SPAN_TILES * K1_TILE / 64;   // mask words per span
-constexpr int K3_REGS = (K3_WORDS + 63) / 64;
-constexpr int K3_RING = 512;                          // entries per ring (two rings per wave)
+#ifndef K3_TILES
+#define K3_TILES 4                              // tiles per wave: its stores overlap the next tile's work, and it leaves before the write front widens
+#endif
+#ifndef K3_WAVES
+#define K3_WAVES 4                              // waves per workgroup; the table is loaded once per workgroup
+#endif
+static_assert(SPAN_TILES % (K3_WAVES * K3_TILES) == 0, "a workgroup's tiles lie in one span");
+constexpr int K3_PASS = 512;                    // records per pass: 8 per lane
+static_assert(K1_TILE == 2 * K3_PASS, "a tile is two passes");
+constexpr int K3_NPASS = 2 * K3_TILES;
+constexpr int K3_BUF = 256 + K3_PASS + 16;      // entries per list: the carried partial chunk, one pass, the slack the unconditional stores run into
 
-struct Ring {
-  uint32_t* buf;    // LDS, K3_RING entries; slot of global output index g is g & (K3_RING - 1)
-  int32_t* out;     // the VCF's index region
-  uint32_t first;   // first output index this span owns
-  uint32_t drained; // next output index to drain (multiple of 256 once past the head)
-  uint32_t end;     // output index after the last appended entry
-};
-
-__device__ __forceinline__ void ring_drain_full(Ring& R, int lane) {
-  // R.drained is a multiple of 256 here: the 256 entries sit contiguously in the ring
-  const uint4 v = *reinterpret_cast<const uint4*>(&R.buf[(R.drained & (K3_RING - 1)) + 4 * lane]);
-  // the index lists are written once and read by nobody on the device: non-temporal stores (+4 %)
-  typedef int v4i __attribute__((ext_vector_type(4)));
-  v4i w; w.x = (int)v.x; w.y = (int)v.y; w.z = (int)v.z; w.w = (int)v.w;
-  __builtin_nontemporal_store(w, reinterpret_cast<v4i*>(&R.out[R.drained + 4 * lane]));
-  R.drained += 256;
-}
-// entries [lo, hi) of the 256-chunk starting at `chunk` (the ragged head or tail of the span's run)
-__device__ __forceinline__ void ring_drain_part(Ring& R, uint32_t chunk, uint32_t lo, uint32_t hi, int lane) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const uint32_t g = chunk + 64u * k + lane;
-    if (g >= lo && g < hi) R.out[g] = (int32_t)R.buf[g & (K3_RING - 1)];
-  }
-}
-
-__global__ __launch_bounds__(64) void k_compact(CompactParams P) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_ring[2][K3_RING];
-  const int lane = (int)threadIdx.x;
-  const SpanDesc sp = P.spans[(int)blockIdx.x + P.span_base];
-  // VCFs found out of order by this run are redone by the sort path: their masks and counts are not meaningful yet
-  if (P.skip_unsorted && (P.vcf_flags[sp.vcf] & SPANF_UNSORTED)) return;
-  const VcfDesc vd = P.vcfs[sp.vcf];
-  const int sb = (int)(sp.begin - vd.off);
-  const int se = (int)(sp.end - vd.off);
-  const int nwords = (se - sb + 63) >> 6;
-  const uint64_t* mp = P.mask_pass + ((vd.off + sb) >> 6);
-  const uint64_t* mt = P.mask_tp + ((vd.off + sb) >> 6);
-  uint64_t rp[K3_REGS], rt[K3_REGS];
-#pragma unroll
-  for (int i = 0; i < K3_REGS; ++i) {
-    const int w = i * 64 + lane;
-    rp[i] = w < nwords ? mp[w] : 0ull;   // cached on purpose: non-temporal mask accesses measured slightly slower
-    rt[i] = w < nwords ? mt[w] : 0ull;
-  }
-  // total FP lines of the VCF = offset of its last tile + that tile's count
-  const int lastt = vd.tile0 + vd.ntiles - 1;
-  const uint32_t fp_total = P.tile_fp_off[lastt] + P.tile_fp[lastt];
-  Ring T, F;
-  T.buf = s_ring[0]; F.buf = s_ring[1];
-  T.out = F.out = P.idx + vd.off;
-  T.first = T.end = P.tile_tp_off[sp.tile0];
-  F.first = F.end = ((uint32_t)vd.n - fp_total) + P.tile_fp_off[sp.tile0];
-  T.drained = T.first & ~255u;
-  F.drained = F.first & ~255u;
-#pragma unroll
-  for (int i = 0; i < K3_REGS; ++i) {
-    const int wn = nwords - i * 64 < 64 ? nwords - i * 64 : 64;
-    for (int j = 0; j < wn; ++j) {
-      const uint32_t plo = __builtin_amdgcn_readlane((uint32_t)rp[i], j), phi = __builtin_amdgcn_readlane((uint32_t)(rp[i] >> 32), j);
-      const uint32_t tlo = __builtin_amdgcn_readlane((uint32_t)rt[i], j), thi = __builtin_amdgcn_readlane((uint32_t)(rt[i] >> 32), j);
-      const uint64_t wt = ((uint64_t)thi << 32) | tlo;
-      const uint64_t wf = (((uint64_t)phi << 32) | plo) & ~wt;
-      const uint32_t rel = (uint32_t)(sb + (i * 64 + j) * 64 + lane);
-      // the word IS the execution mask (inverse ballot: no per-lane bit test) and mbcnt ranks the lane inside it
-      if (__builtin_amdgcn_inverse_ballot_w64(wt))
-        T.buf[(T.end + __builtin_amdgcn_mbcnt_hi((uint32_t)(wt >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wt, 0u))) & (K3_RING - 1)] = rel;
-      if (__builtin_amdgcn_inverse_ballot_w64(wf))
-        F.buf[(F.end + __builtin_amdgcn_mbcnt_hi((uint32_t)(wf >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wf, 0u))) & (K3_RING - 1)] = rel;
-      T.end += (uint32_t)__popcll(wt);
-      F.end += (uint32_t)__popcll(wf);
-      // drain complete 256-entry chunks (wave-uniform conditions)
-      if (F.end - F.drained >= 256u) {
-        __syncthreads();
-        if (F.drained < F.first) { ring_drain_part(F, F.drained, F.first, F.drained + 256u, lane); F.drained += 256u; }
-        else ring_drain_full(F, lane);
-        __syncthreads();
-      }
-      if (T.end - T.drained >= 256u) {
-        __syncthreads();
-        if (T.drained < T.first) { ring_drain_part(T, T.drained, T.first, T.drained + 256u, lane); T.drained += 256u; }
-        else ring_drain_full(T, lane);
-        __syncthreads();
-      }
+// mask byte -> positions of its set bits, ascending, one per byte (64 bits per entry)
+struct K3Lut {
+  uint32_t w[512];
+  constexpr K3Lut() : w() {
+    for (int v = 0; v < 256; ++v) {
+      uint64_t l = 0;
+      int n = 0;
+      for (int b = 0; b < 8; ++b)
+        if ((v >> b) & 1) { l |= (uint64_t)b << (8 * n); ++n; }
+      w[2 * v] = (uint32_t)l;
+      w[2 * v + 1] = (uint32_t)(l >> 32);
     }
   }
+};
+__device__ const K3Lut k3_lut = K3Lut();
+
+typedef volatile uint32_t __attribute__((address_space(3)))* k3_ldsp;   // explicit: a generic pointer here turns every access into flat_*
+typedef int k3_v4i __attribute__((ext_vector_type(4)));
+typedef volatile k3_v4i __attribute__((address_space(3)))* k3_lds4p;
+
+// base | byte K of l in one instruction (SDWA operand select; the compiler finds it for bytes 0 and 3 only)
+template <int K> __device__ __forceinline__ uint32_t k3_or_byte(uint32_t base, uint32_t l) {
+  uint32_t r;
+  if (K == 0) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(l), "v"(base));
+  if (K == 1) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(l), "v"(base));
+  if (K == 2) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(l), "v"(base));
+  if (K == 3) asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(l), "v"(base));
+  return r;
+}
+// the lane's <= 8 entries of one list: slot j at a + j, highest first, all eight whatever the count (see above)
+__device__ __forceinline__ void k3_emit(k3_ldsp buf, const uint32_t* lut, uint32_t a, uint32_t m, uint32_t base) {
+  if (m) {
+    const uint2 l = *reinterpret_cast<const uint2*>(&lut[2 * m]);
+    k3_ldsp d = buf + a;
+    d[7] = k3_or_byte<3>(base, l.y);
+    d[6] = k3_or_byte<2>(base, l.y);
+    d[5] = k3_or_byte<1>(base, l.y);
+    d[4] = k3_or_byte<0>(base, l.y);
+    d[3] = k3_or_byte<3>(base, l.x);
+    d[2] = k3_or_byte<2>(base, l.x);
+    d[1] = k3_or_byte<1>(base, l.x);
+    d[0] = k3_or_byte<0>(base, l.x);
+  }
+}
+// inclusive prefix sum over the wave (DPP only), the wave's total to everybody through `tot`
+__device__ __forceinline__ uint32_t k3_scan(uint32_t c, uint32_t& tot) {
+  uint32_t x = c;
+#define K3_DPP_ADD(ctrl, rmask) x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rmask, 0xf, false)
+  K3_DPP_ADD(0x111, 0xf);   // row_shr:1
+  K3_DPP_ADD(0x112, 0xf);   // row_shr:2
+  K3_DPP_ADD(0x114, 0xf);   // row_shr:4
+  K3_DPP_ADD(0x118, 0xf);   // row_shr:8: inclusive inside every row of 16
+  K3_DPP_ADD(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+  K3_DPP_ADD(0x143, 0xc);   // row_bcast:31 into rows 2 and 3
+#undef K3_DPP_ADD
+  tot = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+  return x;
+}
+
+struct K3List {
+  k3_ldsp buf;              // LDS, K3_BUF entries; buf[i] is entry g0 + i of the VCF's region
+  int32_t* out;             // the VCF's index region
+  uint32_t first;           // first entry this wave owns
+  uint32_t g0;              // entry of buf[0]: a multiple of 256
+  uint32_t n;               // entries in buf (those below `first` in the wave's first chunk belong to the wave before: never stored)
+};
+__device__ __forceinline__ void k3_store4(int32_t* p, k3_v4i w) {
+#ifdef K3_ABL_NOSTORE
+  asm volatile("" :: "v"(w));
+#elif defined(K3_NT_STORE)
+  __builtin_nontemporal_store(w, reinterpret_cast<k3_v4i*>(p));
+#else
+  *reinterpret_cast<k3_v4i*>(p) = w;
+#endif
+}
+// entries [lo, hi) of the chunk that starts at buf index c0 (a multiple of 256; entry g0 + c0): whole quads with one
+// 16-byte store per lane, the <= 3 + 3 entries around them with one masked dword store
+__device__ __forceinline__ void k3_store_part(const K3List& X, uint32_t c0, uint32_t lo, uint32_t hi, int lane) {
+  const uint32_t b = X.g0 + c0;                     // entry of the chunk's first slot
+  const uint32_t q = b + 4u * (uint32_t)lane;       // the lane's quad
+  if (q >= lo && q + 4u <= hi) k3_store4(X.out + q, *reinterpret_cast<k3_lds4p>(X.buf + (c0 + 4u * lane)));
+  if (lane < 6) {
+    // lanes 0..2: entries in front of the first whole quad; 3..5: behind the last one
+    const uint32_t lo4 = (lo + 3u) & ~3u, hi4 = hi & ~3u;
+    uint32_t i = lane < 3 ? lo + (uint32_t)lane : hi4 + (uint32_t)(lane - 3);
+    const bool ok = lane < 3 ? (i < lo4 && i < hi) : (i < hi && i >= lo && i >= lo4);
+#ifndef K3_ABL_NOSTORE
+    if (ok) X.out[i] = (int32_t)X.buf[i - X.g0];
+#endif
+  }
+}
+// complete 256-entry chunks leave; the partial chunk behind them moves to the front (everything here is wave-uniform)
+__device__ __forceinline__ void k3_drain(K3List& X, int lane) {
+  const uint32_t nfull = X.n >> 8;
+  if (!nfull) return;
+  for (uint32_t c = 0; c < nfull; ++c) {
+    const uint32_t gc = X.g0 + 256u * c;
+    if (gc < X.first) k3_store_part(X, 256u * c, X.first, gc + 256u, lane);   // the wave's first chunk starts in its predecessor's entries
+    else k3_store4(X.out + gc + 4u * lane, *reinterpret_cast<k3_lds4p>(X.buf + (256u * c + 4u * lane)));
+  }
+  const k3_v4i v = *reinterpret_cast<k3_lds4p>(X.buf + (256u * nfull + 4u * lane));
+  *reinterpret_cast<k3_lds4p>(X.buf + 4u * lane) = v;
+  X.g0 += 256u * nfull;
+  X.n &= 255u;
+}
+
+__device__ __forceinline__ int k3_block() {
+#if defined(K3_NO_XCD_MAP)
+  return (int)blockIdx.x;
+#elif defined(K3_XCD_RUN)
+  // runs of K3_XCD_RUN consecutive workgroups per XCD, the eight XCDs side by side in one window of 8 runs
+  const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+  const int g0 = (j / K3_XCD_RUN) * (8 * K3_XCD_RUN);   // a window is permuted inside itself; the grid's ragged last window keeps its launch order
+  return g0 + 8 * K3_XCD_RUN <= (int)gridDim.x ? g0 + xcd * K3_XCD_RUN + (j % K3_XCD_RUN) : (int)blockIdx.x;
+#else
+  const int nblk = (int)gridDim.x, xcd = (int)blockIdx.x & 7, jx = (int)blockIdx.x >> 3;
+  const int per = nblk >> 3, rem = nblk & 7;
+  return xcd * per + (xcd < rem ? xcd : rem) + jx;
+#endif
+}
+
+__global__ __launch_bounds__(64 * K3_WAVES) void k_compact(CompactParams P) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_buf[K3_WAVES][2][K3_BUF];
+  __shared__ __attribute__((aligned(16))) uint32_t s_lut[512];
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int BPS = SPAN_TILES / (K3_WAVES * K3_TILES);   // workgroups per span
+  constexpr int NLUT = (256 + 64 * K3_WAVES - 1) / (64 * K3_WAVES);
+  const int L = k3_block();
+  const SpanDesc sp = P.spans[L / BPS + P.span_base];
+  // everything the wave needs is asked for at once, behind the span descriptor: the table, the VCF's flags, the two offsets of
+  // its first tile, the mask bytes of all its passes
+  uint2 lut[NLUT];
+#pragma unroll
+  for (int k = 0; k < NLUT; ++k) {
+    const int i = tid + k * 64 * K3_WAVES;
+    lut[k] = reinterpret_cast<const uint2*>(k3_lut.w)[i < 256 ? i : 0];
+  }
+  const int tl = ((L % BPS) * K3_WAVES + wave) * K3_TILES;     // the wave's first tile inside the span
+  const int rb = (int)(sp.begin - sp.voff) + tl * K1_TILE;     // its first record inside the VCF (a multiple of K1_TILE)
+  const bool live = (int64_t)sp.voff + rb < sp.end;
+  const int t = live ? sp.tile0 + tl : sp.tile0;
+  const uint32_t vflags = P.vcf_flags[sp.vcf];
+  const uint32_t aT = P.tile_tp_off[t], aF = P.tile_fp_off[t];
+  // mask bytes of the wave's tiles: whole 64-bit words of the VCF (bits beyond its last record are clear), nothing beyond the
+  // span (the next span's bytes belong to another wave)
+  const int re = (int)(sp.end - sp.voff);                      // the span's end inside the VCF
+  const int nb = live ? ((((re < rb + K3_TILES * K1_TILE ? re : rb + K3_TILES * K1_TILE) - rb) + 63) >> 6) * 8 : 0;
+  const uint8_t* mp = reinterpret_cast<const uint8_t*>(P.mask_pass) + ((sp.voff + rb) >> 3);
+  const uint8_t* mt = reinterpret_cast<const uint8_t*>(P.mask_tp) + ((sp.voff + rb) >> 3);
+  uint32_t mk[K3_NPASS], mq[K3_NPASS];
+#pragma unroll
+  for (int u = 0; u < K3_NPASS; ++u) {
+    const int b = u * 64 + lane;
+    mk[u] = b < nb ? mp[b] : 0u;
+    mq[u] = b < nb ? mt[b] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < NLUT; ++k) {
+    const int i = tid + k * 64 * K3_WAVES;
+    if (i < 256) *reinterpret_cast<uint2*>(&s_lut[2 * i]) = lut[k];
+  }
+  asm volatile("" :: "s"(aT), "s"(aF), "s"(vflags));   // here, not behind the barrier where the compiler would sink these loads to
   __syncthreads();
-  // ragged tails (fewer than 256 entries left in each ring)
-  if (F.end > F.drained) ring_drain_part(F, F.drained, F.first > F.drained ? F.first : F.drained, F.end, lane);
-  if (T.end > T.drained) ring_drain_part(T, T.drained, T.first > T.drained ? T.first : T.drained, T.end, lane);
+  // VCFs found out of order by this run are redone by the sort path: their masks and counts are not meaningful yet
+  if (!live || (P.skip_unsorted && (vflags & SPANF_UNSORTED))) return;
+  const int npass = (nb + 63) >> 6;
+  K3List T, F;
+  T.buf = (k3_ldsp)s_buf[wave][0]; F.buf = (k3_ldsp)s_buf[wave][1];
+  T.out = F.out = P.idx + sp.voff;
+  T.first = aT; F.first = aF;
+  T.g0 = T.first & ~255u; T.n = T.first - T.g0;
+  F.g0 = F.first & ~255u; F.n = F.first - F.g0;
+#pragma unroll
+  for (int u = 0; u < K3_NPASS; ++u) {
+    if (u >= npass) break;
+    const uint32_t wt = mq[u], wf = mk[u] & ~mq[u];
+    // one prefix sum for both lists: FP count in the low half, TP count in the high half (a pass holds 512 records)
+    const uint32_t c = (uint32_t)__popc(wf) | ((uint32_t)__popc(wt) << 16);
+    uint32_t tot;
+    const uint32_t ex = k3_scan(c, tot) - c;
+    const uint32_t base = (uint32_t)(rb + u * K3_PASS + 8 * lane);
+#ifndef K3_ABL_NOEMIT
+    if (tot & 0xffffu) k3_emit(F.buf, s_lut, F.n + (ex & 0xffffu), wf, base);
+    if (tot >> 16) k3_emit(T.buf, s_lut, T.n + (ex >> 16), wt, base);
+#endif
+    F.n += tot & 0xffffu;
+    T.n += tot >> 16;
+    asm volatile("" ::: "memory");
+    k3_drain(F, lane);
+    k3_drain(T, lane);
+    asm volatile("" ::: "memory");
+  }
+  // what is left: less than a chunk per list
+  {
+    const uint32_t lo = F.first > F.g0 ? F.first : F.g0;
+    if (F.g0 + F.n > lo) k3_store_part(F, 0u, lo, F.g0 + F.n, lane);
+  }
+  {
+    const uint32_t lo = T.first > T.g0 ? T.first : T.g0;
+    if (T.g0 + T.n > lo) k3_store_part(T, 0u, lo, T.g0 + T.n, lane);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -3252,7 +3403,7 @@ void launch_finalize(const FinalizeParams& P, int n_vcf, hipStream_t st) {
   if (n_vcf > 0) hipLaunchKernelGGL(k_finalize, dim3(n_vcf), dim3(256), 0, st, P);
 }
 void launch_compact(const CompactParams& P, int n_spans, hipStream_t st) {
-  if (n_spans > 0) hipLaunchKernelGGL(k_compact, dim3(n_spans), dim3(64), 0, st, P);
+  if (n_spans > 0) hipLaunchKernelGGL(k_compact, dim3(n_spans * (SPAN_TILES / (K3_WAVES * K3_TILES))), dim3(64 * K3_WAVES), 0, st, P);
 }
 void launch_masks_to_cls(const uint64_t* mp, const uint64_t* mt, int64_t off, int64_t n, uint8_t* cls, hipStream_t st) {
   if (n > 0) hipLaunchKernelGGL(k_masks_to_cls, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mp, mt, off, n, cls);

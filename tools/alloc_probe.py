@@ -8,7 +8,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import quasimodo_amd as q
 eng = q.Engine(0)
 tid = eng.truth_synth(5_000_000, 100_000, 3)
+hold = []
 for rep in range(int(os.environ.get("REPS", "6"))):
+    if os.environ.get("PERTURB"):   # something of another size in front of every batch: the allocator hands out other places
+        import torch
+        hold.append(torch.empty((rep + 1) * int(os.environ["PERTURB"]) * (1 << 20), dtype=torch.uint8, device="cuda"))
     b = eng.batch([1_000_000] * 1000, [tid] * 1000)
     b.synth(5_000_000, 100_000, 3, 3000)
     b.set_timing(True)
