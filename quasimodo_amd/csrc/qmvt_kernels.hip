@@ -1189,10 +1189,12 @@ struct K3List {
 __device__ __forceinline__ void k3_store4(int32_t* p, k3_v4i w) {
 #ifdef K3_ABL_NOSTORE
   asm volatile("" :: "v"(w));
-#elif defined(K3_NT_STORE)
-  __builtin_nontemporal_store(w, reinterpret_cast<k3_v4i*>(p));
-#else
+#elif defined(K3_PLAIN_STORE)
   *reinterpret_cast<k3_v4i*>(p) = w;
+#else
+  // non-temporal: nobody reads the lists on the device, and plain stores leave their dirty lines to be written back while the next
+  // step's k_classify streams (same-box A/B over 5 processes each: k_compact alike, k_classify + 0.19 ms with plain stores)
+  __builtin_nontemporal_store(w, reinterpret_cast<k3_v4i*>(p));
 #endif
 }
 // entries [lo, hi) of the chunk that starts at buf index c0 (a multiple of 256; entry g0 + c0): whole quads with one
@@ -1712,6 +1714,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   if (tid < NB) { s_cnt[tid] = 0u; if (EXT) s_cntx[tid] = 0u; }
   if (!L2 && tid >= 256 && tid < 272) s_flut[tid - 256] = flag_info((uint32_t)(tid - 256));
   const uint32_t dlim = NB == 512 && (sg.part & 4) ? 512u : (uint32_t)HB_BUCKETS;   // buckets this tile's segment stands for
+  // a whole VCF in one segment (part 0): the host joins and sums only the sg.nbk buckets up to the highest position the optimistic
+  // pass SAW -- and that pass leaves a span at its first tile out of order, so later tiles can hold higher positions: a record
+  // beyond the estimate flags the VCF (the radix sort redoes it) instead of landing in a bucket nobody looks at
+  const uint32_t olim = sg.part == 0 ? (uint32_t)sg.nbk : dlim;
   __syncthreads();
   BKS_TICK(1);
   const int64_t tbase = (int64_t)(bid - sg.bk_tile0) * BK_TILE;
@@ -1798,7 +1804,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
           const uint32_t d = rel >> shift;
           if (sg.part != 0 && (key < sg.key_base || ((sg.part & 3) == 1 && d >= dlim))) {
             // another partition of the same VCF takes this record (every partition, or pair of partitions, reads all of the VCF's columns)
-          } else if (d >= dlim) {
+          } else if (d >= olim) {
             segfl |= SPANF_OVERFLOW;   // a position above what the optimistic pass saw of this VCF: the radix sort redoes it
           } else if (!EXT || (uint32_t)(r[j][u] | a[j][u]) < 4u) {
             const uint32_t v = rel - (d << shift);   // < 2^24: shift <= 24

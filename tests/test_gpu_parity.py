@@ -847,3 +847,47 @@ def test_unsorted_vcfs_on_a_reference_of_ten_million_positions_take_a_pair_of_pa
     for k in range(3):
         assert np.array_equal(rows[True][k], rows[False][k]), k
     engine.truth_release(tid)
+
+
+def test_positions_above_what_the_optimistic_pass_saw(engine, oracle):
+    """The optimistic pass leaves a span at its first tile out of order, so the OR of the positions it saw can miss the highest
+    ones; the bucket path sizes its join by that OR.  A shuffled VCF (every span is left after its first tile) whose first tiles
+    hold no position with bit 21 or above 0x5fffff -- an OR of 0x5fffff: 192 buckets of 256 -- while a quarter of the other
+    records lie at 0x600000 and above (buckets 192..255): those records must be classified (by the radix sort, after the scatter
+    flags the VCF), not dropped (the join was trimmed to the buckets below the estimate and nothing noticed).
+    Run twice: the batch's memory of the VCF carries the same estimate forward."""
+    rng = np.random.default_rng(4242)
+    n, span = 40000, 16384
+    seen = np.zeros(n, bool)
+    for s0 in range(0, n, span):
+        seen[s0:s0 + 1024] = True   # the first tile of every span: all the optimistic pass sees of a shuffled VCF
+    lo = rng.choice(np.concatenate([np.arange(1, 0x200000), np.arange(0x400000, 0x600000)]), size=n - n // 4, replace=False)
+    hi = rng.choice(np.arange(0x600000, 0x800000), size=n // 4, replace=False)
+    pos = np.empty(n, np.int32)
+    pos[seen] = lo[:seen.sum()]                                  # shuffled: every first tile is out of order
+    rest = np.concatenate([lo[seen.sum():], hi])
+    rng.shuffle(rest)
+    pos[~seen] = rest
+    ref = rng.integers(0, 4, n).astype(np.int32)
+    alt = ((ref + 1 + rng.integers(0, 3, n)) & 3).astype(np.int32)
+    qual = rng.integers(0, 256, n).astype(np.float32)
+    flags = (2 | (qual >= 20)).astype(np.uint8)
+    take = rng.random(n) < 0.3                                   # truth: a third of the records' keys, high positions included
+    tp_, tr_, ta_ = pos[take], ref[take], alt[take]
+    o = np.lexsort((ta_, tr_, tp_))
+    truth = (tp_[o], tr_[o], ta_[o])
+    assert (truth[0] >= 0x600000).sum() > 100
+    tid = engine.truth_load(*truth)
+    cols = (pos, ref, alt, qual, flags)
+    b = engine.batch([n], [tid])
+    b.upload(0, *cols)
+    from quasimodo_amd.engine import SCALAR_NAMES
+    for _ in range(2):
+        b.run()
+        b.finish()
+        sc = dict(zip(SCALAR_NAMES, b.scalars()[0].tolist()))
+        reg = b.idx(0)
+        res = {"cls": b.cls(0), "roc": b.roc()[0], "scalars": sc, "tp_idx": reg[:sc["tp_lines"]].copy(), "fp_idx": reg[n - sc["fp_lines"]:].copy()}
+        check_vcf(oracle, res, cols, truth, expect_sorted=False)
+        assert b.path_stats()["radix_after_overflow"] == 1
+    b.close()
