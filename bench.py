@@ -185,7 +185,17 @@ def main():
     dt = time.perf_counter() - t0
     tm = batch.timings()
     batch.set_timing(False)
+    per_rank = None
     if world > 1:
+        # every rank's own figures, so that a scaling curve can tell an unbalanced or slow rank from the fabric: its wall clock over
+        # the K steps (each ends in the all-reduce, so the ranks' walls agree unless one is late to the closing barrier) and its
+        # own kernels' time per step by HIP events (no collective in it)
+        mine = torch.tensor([dt / args.steps * 1e3, tm["total_ms"], tm["classify_ms"], tm["compact_ms"]], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rows = np.array([e.cpu().numpy() for e in every])
+        per_rank = {k: {"min": float(rows[:, i].min()), "max": float(rows[:, i].max()), "all": [float(x) for x in rows[:, i]]}
+                    for i, k in enumerate(("ms_per_step", "kernels_ms", "classify_ms", "compact_ms"))}
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -271,6 +281,7 @@ def main():
                      # SURVEY 8d's own formula over the WHOLE step: 18.2 B x classifications/s / peak
                      "step_frac": alg_bytes / step_s / 1e9 / HBM_PEAK_GBS},
         "kernels_ms": tm,
+        "per_rank": per_rank,     # N > 1: min / max / all over the ranks of ms_per_step and of each rank's own kernel time
         "device_bytes": batch.device_bytes,
     }
 

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define QM_ABI_VERSION 3
+#define QM_ABI_VERSION 4
 
 #define QM_OK 0
 #define QM_E_INVAL (-1)     /* bad argument */
@@ -100,6 +100,12 @@ typedef struct qm_batch qm_batch;
 
 /* ---- lifecycle ------------------------------------------------------------ */
 int qm_abi_version(void);
+/* Which sources this library was built from: first 16 hex digits of the sha256 over the device code's sources
+ * (qmvt_kernels.hip, qmvt_dev.h: what a kernel profile belongs to) / over every source of the library, taken by the Makefile
+ * at build time.  "unknown" for a build that did not go through it (A/B builds).  The host package compares them with the
+ * sources in the tree, so that a stale binary is rebuilt -- and can never be quoted with another build's profile. */
+const char* qm_kernels_id(void);
+const char* qm_build_id(void);
 /* One context per process and GPU.  device_id indexes HIP devices (cuda:N in torch). */
 int qm_init(int device_id, qm_ctx** out);
 void qm_destroy(qm_ctx* ctx);

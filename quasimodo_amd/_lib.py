@@ -13,11 +13,11 @@ ERRORS = {-1: "QM_E_INVAL", -2: "QM_E_NODEVICE", -3: "QM_E_HIP", -4: "QM_E_NOMEM
           -6: "QM_E_STATE", -7: "QM_E_IO", -8: "QM_E_NONCANON", -9: "QM_E_LIMIT", -10: "QM_E_UNSORTED"}
 QM_E_UNSORTED = -10
 QM_BATCH_ALLELES = 1
-QM_ABI_VERSION = 3
+QM_ABI_VERSION = 4
 
 # every symbol include/qmvt.h declares
 EXPORTS = (
-    "qm_abi_version", "qm_init", "qm_destroy", "qm_last_error", "qm_truth_load", "qm_truth_size", "qm_truth_count",
+    "qm_abi_version", "qm_kernels_id", "qm_build_id", "qm_init", "qm_destroy", "qm_last_error", "qm_truth_load", "qm_truth_size", "qm_truth_count",
     "qm_classify_batch", "qm_batch_create", "qm_batch_destroy", "qm_batch_upload", "qm_truth_synth", "qm_batch_synth",
     "qm_batch_run", "qm_batch_finish", "qm_batch_set_timing", "qm_batch_timings", "qm_batch_get_cls", "qm_batch_get_idx",
     "qm_batch_get_roc", "qm_batch_get_scalars", "qm_batch_get_global", "qm_batch_get_columns", "qm_batch_device_bytes",
@@ -65,24 +65,61 @@ def library_path():
     return _SO
 
 
-def kernel_source_id():
-    """sha256 (first 16 hex digits) of the device code's sources: what a profile of the kernels belongs to (profiles/traffic.json
-    carries the id of the build its PMC passes ran on; bench.py quotes that traffic only for the same id)."""
+_KSRC = ("qmvt_kernels.hip", "qmvt_dev.h")
+_ASRC = _KSRC + ("qmvt_api.cpp", "qmvt_host.cpp", "qmvt_pipeline.cpp", os.path.join("..", "..", "include", "qmvt.h"), "Makefile")
+
+
+def _sha16(files):
     import hashlib
     h = hashlib.sha256()
-    for f in ("qmvt_kernels.hip", "qmvt_dev.h"):
+    for f in files:
         with open(os.path.join(_CSRC, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
 
 
+def source_kernels_id():
+    """sha256 (first 16 hex digits) of the device code's SOURCES in the tree (the Makefile compiles the same figure in)."""
+    return _sha16(_KSRC)
+
+
+def source_build_id():
+    """The same over every source of the library."""
+    return _sha16(_ASRC)
+
+
+def embedded_ids(path=None):
+    """(kernels id, build id) compiled into a libqmvt.so, read from the file without loading it; (None, None) when the file
+    or the marker is missing."""
+    import re
+    try:
+        with open(path or _SO, "rb") as fh:
+            m = re.search(rb"@\(#\)qmvt-ids kernels=([0-9a-z]+) build=([0-9a-z]+);", fh.read())
+    except OSError:
+        return None, None
+    return (m.group(1).decode(), m.group(2).decode()) if m else (None, None)
+
+
+def kernel_source_id():
+    """The id of the device code of the LOADED library (qm_kernels_id: compiled in at build time): what a profile of the
+    kernels belongs to.  profiles/traffic.json carries the id of the build its PMC passes ran on; bench.py quotes that
+    traffic only for the same id.  "unknown" for builds that did not go through the Makefile (QM_LIBQMVT A/B builds)."""
+    L = lib()
+    return L.qm_kernels_id().decode()
+
+
 def build_library(force=False):
-    """Compile libqmvt.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".cpp", ".h"))]
-    srcs.append(os.path.join(_HERE, "..", "include", "qmvt.h"))
-    stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    """Compile libqmvt.so for gfx950 with hipcc (cross-compiles without a GPU).  Rebuilt whenever the ids compiled into the
+    binary differ from the sources in the tree (content, not time stamps: a stale binary that travelled with the tree is
+    replaced), when it is missing, or on request."""
+    default = os.path.join(_CSRC, "libqmvt.so")
+    stale = force or not os.path.exists(default) or embedded_ids(default) != (source_kernels_id(), source_build_id())
     if stale:
+        if _lib is not None and _SO == default:
+            raise QmvtError(-6, "libqmvt.so is stale but already loaded in this process; rebuild before importing the engine")
         subprocess.check_call(["make", "-s", "-C", _CSRC, "libqmvt.so"])
+        if embedded_ids(default) != (source_kernels_id(), source_build_id()):
+            raise QmvtError(-7, "libqmvt.so does not carry the ids of the sources it was just built from")
     return _SO
 
 
@@ -100,6 +137,8 @@ def lib():
     L = C.CDLL(_SO)
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
     L.qm_abi_version.restype = i32
+    L.qm_kernels_id.restype = C.c_char_p
+    L.qm_build_id.restype = C.c_char_p
     L.qm_last_error.restype = C.c_char_p
     L.qm_last_error.argtypes = [vp]
     L.qm_init.argtypes = [i32, C.POINTER(vp)]

@@ -86,6 +86,16 @@ static int dalloc(T** p, size_t count) {
   } while (0)
 
 extern "C" int qm_abi_version(void) { return QM_ABI_VERSION; }
+#ifndef QM_KERNELS_ID
+#define QM_KERNELS_ID "unknown"
+#endif
+#ifndef QM_BUILD_ID
+#define QM_BUILD_ID "unknown"
+#endif
+// also findable in the file without loading it (quasimodo_amd/_lib.py: embedded_ids)
+extern "C" const char qm_build_marker[] = "@(#)qmvt-ids kernels=" QM_KERNELS_ID " build=" QM_BUILD_ID ";";
+extern "C" const char* qm_kernels_id(void) { return QM_KERNELS_ID; }
+extern "C" const char* qm_build_id(void) { return QM_BUILD_ID; }
 extern "C" const char* qm_last_error(qm_ctx*) { return g_err.c_str(); }
 
 extern "C" int qm_init(int device_id, qm_ctx** out) {

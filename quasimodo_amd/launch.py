@@ -27,7 +27,7 @@ class RankFailure(RuntimeError):
 
 def free_port():
     """A port nobody listens on right now.  (Another process can still take it before the children bind:
-    callers that see the rendezvous fail may simply retry -- spawn_ranks does, once.)"""
+    spawn_ranks then starts the ranks once more on another port.)"""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     p = s.getsockname()[1]
@@ -56,13 +56,30 @@ def _tail(path, n=3000):
         return ""
 
 
+def _port_was_taken(e):
+    s = str(e)
+    return "EADDRINUSE" in s or "Address already in use" in s or "address already in use" in s
+
+
 def spawn_ranks(cmd, world, timeout=None, env=None, port=None, poll=0.05):
     """Runs `cmd` (argv list) once per rank.  Returns rank 0's standard output (str).
-    Raises RankFailure when a rank exits non-zero or the time limit (default QM_RANK_TIMEOUT, 3600 s) passes."""
+    Raises RankFailure when a rank exits non-zero or the time limit (default QM_RANK_TIMEOUT, 3600 s) passes.
+    When the port was probed here (port=None) and the ranks fail because somebody took it between the probe and their
+    bind, they are started once more on a fresh port; a second failure is raised like any other."""
     if world < 1:
         raise ValueError("world must be >= 1")
     timeout = DEFAULT_TIMEOUT if timeout is None else timeout
-    port = port or free_port()
+    if port is None:
+        try:
+            return _spawn_once(cmd, world, timeout, env, free_port(), poll)
+        except RankFailure as e:
+            if not _port_was_taken(e):
+                raise
+        return _spawn_once(cmd, world, timeout, env, free_port(), poll)
+    return _spawn_once(cmd, world, timeout, env, port, poll)
+
+
+def _spawn_once(cmd, world, timeout, env, port, poll):
     with tempfile.TemporaryDirectory(prefix="qmvt_ranks_") as tmp:
         outs = [os.path.join(tmp, "rank%d.out" % r) for r in range(world)]
         errs = [os.path.join(tmp, "rank%d.err" % r) for r in range(world)]

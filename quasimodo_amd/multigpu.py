@@ -6,12 +6,14 @@ per GPU, VCFs dealt by longest-processing-time-first on their size (`sharding.lp
 GROUPS of VCFs where something needs them together: the FP overlap of rules/compare_FP.smk:5-8 compares
 the callers of ONE sample, so the workflows deal by sample and every rank computes the overlap of its own
 samples with no exchange -- every rank runs the ordinary batch path (`extract_many` -> qm_extract_files_ex)
-on its share and writes its own files.  The only exchange is ONE all-reduce of the per-truth-file confusion
-counters [n_truth][3][n_bins], on the device buffer the engine filled (RCCL over xGMI: torch.distributed
-backend "nccl"; "gloo" in the CPU tests), plus a gather of the per-VCF rows to rank 0 for the tables.
+on its share and writes its own files.  The only exchange between the ranks is ONE all-reduce of the per-truth-file
+confusion counters [n_truth][3][n_bins], on the device buffer the engine filled (RCCL over xGMI: torch.distributed
+backend "nccl"; "gloo" in the CPU tests) -- nothing else: no gather, no barrier.  The per-VCF rows never travel between
+ranks: every rank leaves them in a result file of its own, the way rank 0 always handed its result to the parent.
 
-The parent never touches a GPU: it writes the job list to a spec file and starts one child per
-rank (`python -m quasimodo_amd.multigpu <spec>`, quasimodo_amd.launch.spawn_ranks); children rendezvous on 127.0.0.1.
+The parent never touches a GPU: it writes the job list to a spec file, starts one child per rank
+(`python -m quasimodo_amd.multigpu <spec>`, quasimodo_amd.launch.spawn_ranks; children rendezvous on 127.0.0.1) and, when
+all of them have left with status 0, puts the ranks' rows together.
 """
 import datetime
 import importlib
@@ -108,11 +110,11 @@ def _resolve(name):
 
 def run_rank(jobs, rank, world, backend="nccl", body=None, n_bins=256, alleles=None, strict=None, same_device=False,
              groups=None, post=None, post_args=None):
-    """What one rank does.  Returns, on rank 0, {"stats": [per job], "counters": int64 [n_truth][3][n_bins] summed over ALL
-    ranks, "truth_keys": [...], "shards": [[job index, ...] per rank], "extras": [per rank]}; None on the other ranks.
-    torch.distributed must be initialised by the caller (world > 1)."""
+    """What one rank does: its share of the jobs, then the all-reduce.  Returns {"rows": [(job index, stats), ...] of ITS jobs,
+    "extra": the post hook's result} and, on rank 0, also "counters" (int64 [n_truth][3][n_bins] summed over ALL ranks),
+    "truth_keys" and "shards" ([[job index, ...] per rank]); `merge_ranks` puts the ranks' values together.
+    torch.distributed must be initialised by the caller: the all-reduce runs whenever a process group exists."""
     import torch
-    import torch.distributed as dist
     body = _resolve(body)
     shards = plan_shards(jobs, world, groups)
     mine = shards[rank]
@@ -136,20 +138,51 @@ def run_rank(jobs, rank, world, backend="nccl", body=None, n_bins=256, alleles=N
             t = t.to(torch.device("cuda", device))
     elif backend != "nccl" and t.is_cuda:
         t = t.cpu()                            # rehearsals on one card: gloo sums host tensors
+    ops0 = _collectives_so_far()
     allreduce_counters(t)                      # the path's single collective
-    rows = (list(zip(mine, local)), res.get("extra"))
-    if world > 1:
-        gathered = [None] * world if rank == 0 else None
-        dist.gather_object(rows, gathered, dst=0)
-    else:
-        gathered = [rows]
-    if rank != 0:
+    out = {"rows": list(zip(mine, local)), "extra": res.get("extra"), "collective": _collective_record(ops0)}
+    if rank == 0:
+        out.update(counters=t.cpu().numpy(), truth_keys=keys, shards=shards)
+    return out
+
+
+def _collectives_so_far():
+    """How many collectives the default process group has issued (its sequence number), or None without a group / the counter."""
+    try:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return None
+        return int(dist.distributed_c10d._get_default_group()._get_sequence_number_for_group())
+    except Exception:
         return None
-    stats = [None] * len(jobs)
-    for part, _ in gathered:
-        for i, st in part:
+
+
+def _collective_record(ops_before):
+    """What the run's one exchange was: backend, world size and how far the process group's collective counter moved over it
+    (1: the all-reduce and nothing else) -- the evidence a one-GPU test has that the sum really went through RCCL."""
+    try:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return None
+        now = _collectives_so_far()
+        return {"backend": str(dist.get_backend()), "world": int(dist.get_world_size()), "ops_before": ops_before, "ops_after": now}
+    except Exception:
+        return None
+
+
+def merge_ranks(n_jobs, parts):
+    """The ranks' results (run_rank's return values, rank order) as ONE: {"stats": [per job], "counters", "truth_keys",
+    "shards", "extras": [per rank]}."""
+    stats = [None] * n_jobs
+    for part in parts:
+        for i, st in part["rows"]:
             stats[i] = st
-    return {"stats": stats, "counters": t.cpu().numpy(), "truth_keys": keys, "shards": shards, "extras": [e for _, e in gathered]}
+    missing = [i for i, st in enumerate(stats) if st is None]
+    if missing:
+        raise RuntimeError("no rank returned a row for job(s) %s" % missing[:8])
+    r0 = parts[0]
+    return {"stats": stats, "counters": r0["counters"], "truth_keys": r0["truth_keys"], "shards": r0["shards"],
+            "extras": [part.get("extra") for part in parts], "collectives": [part.get("collective") for part in parts]}
 
 
 def extract_many_sharded(jobs, gpus, backend="nccl", body=None, n_bins=256, alleles=None, strict=None, same_device=False,
@@ -176,14 +209,14 @@ def extract_many_sharded(jobs, gpus, backend="nccl", body=None, n_bins=256, alle
             pickle.dump(spec, fh)
         cmd = [sys.executable, "-m", "quasimodo_amd.multigpu", sp]
         try:
-            spawn_ranks(cmd, gpus, timeout=timeout)
+            spawn_ranks(cmd, gpus, timeout=timeout)   # (starts the ranks once more when their port was taken under them)
         except RankFailure as e:
-            if "EADDRINUSE" in str(e) or "Address already in use" in str(e):   # the port was taken between the probe and the bind
-                spawn_ranks(cmd, gpus, timeout=timeout)
-            else:
-                raise RuntimeError(str(e)) from None
-        with open(spec["result"], "rb") as fh:
-            res = pickle.load(fh)
+            raise RuntimeError(str(e)) from None
+        parts = []
+        for r in range(gpus):   # every rank has left with status 0: its file is complete (written under another name, then renamed)
+            with open("%s.%d" % (spec["result"], r), "rb") as fh:
+                parts.append(pickle.load(fh))
+        res = merge_ranks(len(jobs), parts)
     for j, st in zip(jobs, res["stats"]):
         j.stats = st
         if st.get("pure_strain"):
@@ -214,11 +247,12 @@ def _main(argv):
         res = run_rank(jobs, rank, world, backend=backend, body=spec["body"], n_bins=spec["n_bins"],
                        alleles=spec["alleles"], strict=spec["strict"], same_device=spec["same_device"], groups=spec.get("groups"),
                        post=spec.get("post"), post_args=spec.get("post_args"))
-        if rank == 0:
-            with open(spec["result"] + ".tmp", "wb") as fh:
-                pickle.dump(res, fh)
-            os.replace(spec["result"] + ".tmp", spec["result"])
-        dist.barrier()
+        if res.get("collective") is not None:
+            res["collective"]["ops_at_exit"] = _collectives_so_far()   # nothing follows the all-reduce: still 1
+        mine = "%s.%d" % (spec["result"], rank)   # the rows go to the parent, not to another rank
+        with open(mine + ".tmp", "wb") as fh:
+            pickle.dump(res, fh)
+        os.replace(mine + ".tmp", mine)
     finally:
         dist.destroy_process_group()
     return 0

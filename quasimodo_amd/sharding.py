@@ -21,8 +21,9 @@ def lpt_shards(n_records, world):
 
 def allreduce_counters(counters, group=None):
     """In-place sum over ranks of the [n_truth][3][n_bins] counter tensor (int64).  This is the
-    path's single collective."""
+    path's single collective.  It runs whenever a process group exists, a group of one rank included (the sum
+    of one term: the same call on the same fabric library, which is what a one-GPU box can test of it)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(counters, op=dist.ReduceOp.SUM, group=group)
     return counters

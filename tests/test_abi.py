@@ -22,7 +22,22 @@ def test_header_symbols_exported(qmlib):
     for n in names:
         assert hasattr(qmlib, n), "libqmvt.so does not export %s" % n
     assert sorted(_lib.EXPORTS) == names
-    assert qmlib.qm_abi_version() == 3
+    assert qmlib.qm_abi_version() == 4
+
+
+def test_the_library_says_which_sources_it_was_built_from(qmlib, tmp_path):
+    """qm_kernels_id / qm_build_id = the sha256 ids of the sources in the tree, taken by the Makefile at build time: what
+    `build()` compares (content, not time stamps) and what a PMC profile is keyed on (a stale binary could
+    carry a fresh id).  The ids are also readable from the file without loading it; a file without them is never 'up to date'."""
+    from quasimodo_amd import _lib
+    qmlib.qm_kernels_id.restype = C.c_char_p
+    qmlib.qm_build_id.restype = C.c_char_p
+    assert qmlib.qm_kernels_id().decode() == _lib.source_kernels_id() == _lib.kernel_source_id()
+    assert qmlib.qm_build_id().decode() == _lib.source_build_id()
+    assert _lib.embedded_ids() == (_lib.source_kernels_id(), _lib.source_build_id())
+    other = tmp_path / "libqmvt.so"
+    other.write_bytes(b"\x7fELF nothing of ours")
+    assert _lib.embedded_ids(str(other)) == (None, None) and _lib.embedded_ids(str(tmp_path / "missing.so")) == (None, None)
 
 
 def test_no_cpu_fallback_without_device(qmlib):

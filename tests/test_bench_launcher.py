@@ -67,3 +67,27 @@ def test_spawn_ranks_env_and_relay(tmp_path):
     with pytest.raises(RankFailure) as ei:
         spawn_ranks([sys.executable, str(script)], 4, timeout=60, env=dict(os.environ, BREAK="1"))
     assert ei.value.bad == [2] and ei.value.returncodes[2] == 3
+
+
+def test_spawn_ranks_starts_once_more_when_the_port_was_taken(tmp_path):
+    """The probed port can be taken before the children bind (the docstring promised a retry nobody made):
+    ranks that fail with "Address already in use" are started once more on another port; any other failure, and a second
+    one, is raised."""
+    from quasimodo_amd.launch import RankFailure, spawn_ranks
+    flag = tmp_path / "seen"
+    prog = ("import os, sys\n"
+            "flag = %r\n"
+            "if os.environ['RANK'] == '0' and not os.path.exists(flag):\n"
+            "    open(flag, 'w').write(os.environ['MASTER_PORT'])\n"
+            "    sys.stderr.write('RuntimeError: The server socket has failed to listen on any local network address. "
+            "port: 1, useIpv6: false, code: -98, name: EADDRINUSE, message: address already in use\\n')\n"
+            "    sys.exit(1)\n"
+            "print('port', os.environ['MASTER_PORT'])\n") % str(flag)
+    out = spawn_ranks([sys.executable, "-c", prog], 2, timeout=60)
+    assert out.startswith("port ") and out.split()[1] != flag.read_text()          # the second start used another port
+    always = "import sys; sys.stderr.write('EADDRINUSE\\n'); sys.exit(1)"
+    with pytest.raises(RankFailure):
+        spawn_ranks([sys.executable, "-c", always], 2, timeout=60)
+    flag.unlink()
+    with pytest.raises(RankFailure):                                                  # a port the caller chose is not replaced
+        spawn_ranks([sys.executable, "-c", prog], 2, timeout=60, port=29871)

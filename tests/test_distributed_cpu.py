@@ -60,6 +60,11 @@ def test_sharded_extract_gloo_world2(tmp_path, monkeypatch, oracle, qmlib):
             want[keys.index(truth_key(j))] += j.stats["roc"].astype(np.int64)
     assert np.array_equal(res["counters"], want) and want.sum() > 0
     assert len(keys) == len({truth_key(j) for j, (e, _) in zip(jobs, exps) if not e["pure"]})
+    # ONE collective per rank and run: the all-reduce.  The rows came through the ranks' result files (no gather, no barrier)
+    assert len(res["collectives"]) == 2
+    for col in res["collectives"]:
+        assert col["backend"] == "gloo" and col["world"] == 2
+        assert col["ops_after"] - col["ops_before"] == 1 and col["ops_at_exit"] == 1, col
 
 
 def test_sharded_extract_reports_a_failing_rank(tmp_path, monkeypatch, qmlib):

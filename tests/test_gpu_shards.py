@@ -95,8 +95,9 @@ def test_product_multi_gpu_entry_point_two_ranks_on_this_gpu(tmp_path, qmlib):
 
 def test_product_multi_gpu_entry_point_one_rank_over_rccl(tmp_path, qmlib):
     """The same entry point with the backend the product uses, "nccl" (= RCCL on ROCm), at the only world size one card allows:
-    the child initialises the process group on its device, all-reduces the DEVICE buffer the engine filled and gathers nothing.
-    What two ranks add to this is RCCL's transport between GPUs, which no one-GPU box can show."""
+    the child initialises the process group on its device and all-reduces the DEVICE buffer the engine filled -- the call is
+    issued at every world size (sharding.allreduce_counters) -- and exchanges nothing else: the rows reach the parent through
+    the rank's own result file.  What two ranks add to this is RCCL's transport between GPUs, which no one-GPU box can show."""
     from quasimodo_amd.extract import Job
     from quasimodo_amd.multigpu import extract_many_sharded, truth_key
     cases = [c for c in golden_cases() if c["family"] == "hcmv"][:12]
@@ -123,6 +124,11 @@ def test_product_multi_gpu_entry_point_one_rank_over_rccl(tmp_path, qmlib):
         if j.stats.get("roc") is not None:
             want[keys.index(truth_key(j))] += np.asarray(j.stats["roc"]).astype(np.int64)
     assert np.array_equal(res["counters"], want) and want.sum() > 0
+    # the product's ONE collective really went through RCCL: the process group of the child is "nccl", and its collective
+    # counter moved by exactly one over the all-reduce and stood at one when the rank left (no gather, no barrier)
+    (col,) = res["collectives"]
+    assert col["backend"] == "nccl" and col["world"] == 1
+    assert col["ops_after"] - col["ops_before"] == 1 and col["ops_at_exit"] == col["ops_after"] == 1, col
 
 
 def test_workflows_on_two_ranks_of_this_gpu_write_what_one_gpu_writes(tmp_path, qmlib, engine):
