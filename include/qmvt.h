@@ -232,6 +232,9 @@ enum {
   QM_N_PATH_STATS = 9
 };
 int qm_batch_path_stats(qm_batch* b, int64_t* out /*[QM_N_PATH_STATS]*/);
+/* The same counters summed over every qm_batch_finish of every batch of the context since qm_init, the batches that
+ * qm_extract_files / qm_classify_batch make for themselves included: callers take the difference around a call. */
+int qm_path_stats_total(qm_ctx* ctx, int64_t* out /*[QM_N_PATH_STATS]*/);
 /* Device address of the per-truth sums of the last run ([qm_batch_n_truth(b)][3][n_bins] uint64; the caller's global_dev when
  * qm_batch_run was given one): valid until the batch runs again or is destroyed.  For callers that hand the counters to a
  * collective without a trip through the host. */

@@ -24,17 +24,25 @@ def _extract(a):
         jobs = [Job(v, a.truth, "custom", a.custom, lab) for v, lab in zip(vcfs, labels)]
     else:
         jobs = [Job(v, a.truth, "hcmv") for v in vcfs]
-    extract_many(jobs, alleles=True if a.alleles else None, gpus=a.gpus)
-    cols = ("n_records", "n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R", "genomediff", "truth_unique", "pure_strain")
+    if a.gpus and a.gpus > 1:
+        from .multigpu import extract_many_sharded
+        jobs, res = extract_many_sharded(jobs, int(a.gpus), alleles=True if a.alleles else None)
+        paths = res.get("paths")
+    else:
+        extract_many(jobs, alleles=True if a.alleles else None)
+        paths = extract_many.last_paths
+    cols = ("n_records", "n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R", "genomediff", "truth_unique", "pure_strain", "sorted")
     print("\t".join(("vcf",) + cols))
     out = []
     for j in jobs:
-        row = {k: (int(j.stats[k]) if k != "pure_strain" else bool(j.stats[k])) for k in cols}
+        row = {k: (int(j.stats.get(k, 1)) if k != "pure_strain" else bool(j.stats[k])) for k in cols}
         print("\t".join([j.vcf_file] + [str(row[k]) for k in cols]))
         out.append(dict(vcf=j.vcf_file, filtered=j.filtered_out, tp=j.tp_out, fp=j.fp_out, **row))
     if a.json:
+        # unsorted_paths: where the VCFs that were not in position order went (include/qmvt.h QM_PATH_*): the bucket paths, or the
+        # several times slower radix sort behind them ("radix", "radix_after_overflow")
         with open(a.json, "w") as fh:
-            json.dump(out, fh, indent=1)
+            json.dump({"rows": out, "unsorted_paths": paths}, fh, indent=1)
     return 0
 
 
@@ -55,7 +63,7 @@ def main(argv=None):
     e.add_argument("--alleles", action="store_true", help="allele-extended mode: indels / MNPs matched exactly (off by default)")
     e.add_argument("--gpus", type=int, default=1, help="deal the VCFs to this many GPUs of the node: one process per GPU, one all-reduce "
                                                        "of the confusion counters (RCCL), rows gathered on rank 0")
-    e.add_argument("--json", default=None, help="also write the rows as JSON")
+    e.add_argument("--json", default=None, help="also write {rows, unsorted_paths: where VCFs that were out of order went} as JSON")
     e.add_argument("vcf", nargs="+")
     e.set_defaults(fn=_extract)
     s = sub.add_parser("split", help="the extract_snp / extract_indel rules (rules/vis_eval_vcf.smk:25-86)")

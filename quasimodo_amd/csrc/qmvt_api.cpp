@@ -69,6 +69,7 @@ struct qm_ctx {
   std::vector<Truth> truths;
   TruthDev* d_truths = nullptr;  // device copy of the descriptors
   int d_truths_cap = 0;
+  int64_t path_total[QM_N_PATH_STATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // qm_path_stats_total: every finish of every batch of this context
 };
 
 template <typename T>
@@ -1664,6 +1665,7 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
     if (b->known.empty()) { b->known.assign((size_t)b->n_vcf, (uint8_t)0); b->known_posor.assign((size_t)b->n_vcf, 0u); }
     for (int v : todo) if (!b->known[(size_t)v]) { b->known[(size_t)v] = 1; b->known_posor[(size_t)v] = posor[(size_t)v]; ++b->n_known; b->known_dirty = true; }
   }
+  for (int k = 0; k < QM_N_PATH_STATS; ++k) c->path_total[k] += b->path_stats[k];
   b->finished = true;
   return QM_OK;
 }
@@ -1759,6 +1761,12 @@ int qm_device_add_u64(qm_ctx* c, uint64_t* dst, const uint64_t* src, int64_t n) 
   HIPCHK(hipStreamSynchronize(c->stream));
   return QM_OK;
 }
+extern "C" int qm_path_stats_total(qm_ctx* c, int64_t* out) {
+  if (!c || !out) return fail(QM_E_INVAL, "qm_path_stats_total: NULL");
+  memcpy(out, c->path_total, sizeof c->path_total);
+  return QM_OK;
+}
+
 extern "C" int qm_batch_path_stats(qm_batch* b, int64_t* out) {
   NEED_FINISHED(b, "qm_batch_path_stats");
   if (!out) return fail(QM_E_INVAL, "qm_batch_path_stats: NULL");

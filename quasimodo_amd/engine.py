@@ -7,6 +7,10 @@ import numpy as np
 from . import _lib
 from ._lib import SCALAR_NAMES, QmvtError, SynthCfg, check
 
+# include/qmvt.h QM_PATH_*: where the VCFs a finish found out of order went
+PATH_NAMES = ("unsorted", "bucket_direct", "bucket_hashed", "radix", "radix_after_overflow", "bucket_chunks", "overflow_chunks",
+              "radix_chunks", "bucket_two_level")
+
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
@@ -163,6 +167,13 @@ class Engine:
         phases = dict(zip(("map_count", "truth_beside", "batch_layout", "tokenise_upload", "engine", "masks_back", "write", "release"), list(ph)))
         return rows, phases
 
+    def path_stats_total(self):
+        """qm_path_stats_total: where the VCFs found out of order went, summed over every batch this context has finished
+        (PATH_NAMES); take the difference around a call."""
+        out = np.zeros(len(PATH_NAMES), np.int64)
+        check(self._L.qm_path_stats_total(self._h, _p(out)), self._h)
+        return dict(zip(PATH_NAMES, (int(x) for x in out)))
+
     def bw_probe(self, nbytes=4 << 30, reps=5):
         """qm_bw_probe: GB/s this GPU streams read-only, copying (read + written) and write-only"""
         out = (C.c_double * 3)()
@@ -284,10 +295,9 @@ class Batch:
 
     def path_stats(self):
         """qm_batch_path_stats: where the VCFs the last finish found out of order went"""
-        out = np.zeros(9, np.int64)
+        out = np.zeros(len(PATH_NAMES), np.int64)
         self._ck(self._L.qm_batch_path_stats(self._h, _p(out)))
-        return dict(zip(("unsorted", "bucket_direct", "bucket_hashed", "radix", "radix_after_overflow", "bucket_chunks", "overflow_chunks",
-                         "radix_chunks", "bucket_two_level"), (int(x) for x in out)))
+        return dict(zip(PATH_NAMES, (int(x) for x in out)))
 
     @property
     def device_bytes(self):

@@ -107,12 +107,16 @@ def extract_many(jobs, engine=None, strict=None, n_bins=256, alleles=None, gpus=
                 os.makedirs(os.path.dirname(job.tp_out) or ".", exist_ok=True)
         fj = [dict(vcf=j.vcf_file, truth=None if p else j.snp_file, mode=j.mode, pure=p, filtered=j.filtered_out,
                    tp=None if p else j.tp_out, fp=j.fp_out) for j, p in zip(jobs, pure)]
+        extract_many.last_paths = None
         if engine is None:
             rows = _pure_only(fj, strict)
         else:
+            before = engine.path_stats_total()
             rows, phases = engine.extract_files(fj, n_bins=n_bins, alleles=alleles, strict=strict, truth_slots=truth_slots, n_slots=n_slots,
                                                 global_dev=global_dev)
             extract_many.last_phases = phases
+            # where the VCFs found out of order went (bucket paths / radix sort: a silent fall onto the slow path shows here)
+            extract_many.last_paths = {k: v - before[k] for k, v in engine.path_stats_total().items()}
     finally:
         if own and engine is not None:
             engine.close()
@@ -126,6 +130,7 @@ def extract_many(jobs, engine=None, strict=None, n_bins=256, alleles=None, gpus=
 
 
 extract_many.last_phases = None
+extract_many.last_paths = None
 
 
 def _pure_only(file_jobs, strict):

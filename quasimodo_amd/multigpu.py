@@ -96,7 +96,7 @@ def default_body(jobs, indices, device, opts):
             eng.close()
     if counters is not None:
         torch.cuda.synchronize(dev)
-    return {"stats": [j.stats for j in jobs], "counters": counters, "extra": extra}
+    return {"stats": [j.stats for j in jobs], "counters": counters, "extra": extra, "paths": extract_many.last_paths if jobs else None}
 
 
 def _resolve(name):
@@ -140,7 +140,7 @@ def run_rank(jobs, rank, world, backend="nccl", body=None, n_bins=256, alleles=N
         t = t.cpu()                            # rehearsals on one card: gloo sums host tensors
     ops0 = _collectives_so_far()
     allreduce_counters(t)                      # the path's single collective
-    out = {"rows": list(zip(mine, local)), "extra": res.get("extra"), "collective": _collective_record(ops0)}
+    out = {"rows": list(zip(mine, local)), "extra": res.get("extra"), "collective": _collective_record(ops0), "paths": res.get("paths")}
     if rank == 0:
         out.update(counters=t.cpu().numpy(), truth_keys=keys, shards=shards)
     return out
@@ -181,7 +181,11 @@ def merge_ranks(n_jobs, parts):
     if missing:
         raise RuntimeError("no rank returned a row for job(s) %s" % missing[:8])
     r0 = parts[0]
-    return {"stats": stats, "counters": r0["counters"], "truth_keys": r0["truth_keys"], "shards": r0["shards"],
+    paths = None
+    for part in parts:   # where the VCFs found out of order went, summed over the ranks
+        if part.get("paths"):
+            paths = {k: (paths or {}).get(k, 0) + v for k, v in part["paths"].items()}
+    return {"paths": paths, "stats": stats, "counters": r0["counters"], "truth_keys": r0["truth_keys"], "shards": r0["shards"],
             "extras": [part.get("extra") for part in parts], "collectives": [part.get("collective") for part in parts]}
 
 

@@ -26,6 +26,75 @@ class WorkflowError(RuntimeError):
     pass
 
 
+def ensure_bundle(data_dir):
+    """rules/load_config.smk:28-31: when data/snp is absent, the bundle data/snp.tar.gz is unpacked beside it (the reference
+    shells `tar -xzvf data/snp.tar.gz -C data/`).  Returns data_dir; raises when neither exists."""
+    data_dir = data_dir.rstrip("/")
+    if os.path.isdir(data_dir):
+        return data_dir
+    tarball = data_dir + ".tar.gz"
+    if not os.path.exists(tarball):
+        raise WorkflowError("neither %s nor %s exists" % (data_dir, tarball))
+    import tarfile
+    parent = os.path.dirname(data_dir) or "."
+    with tarfile.open(tarball, "r:gz") as tf:
+        try:
+            tf.extractall(parent, filter="data")   # (members that would leave `parent` are refused)
+        except TypeError:                           # a Python without extraction filters
+            root = os.path.realpath(parent)
+            for m in tf.getmembers():
+                if not os.path.realpath(os.path.join(parent, m.name)).startswith(root + os.sep) or m.issym() or m.islnk():
+                    raise WorkflowError("%s: member %s would be written outside %s" % (tarball, m.name, parent))
+            tf.extractall(parent)
+    if not os.path.isdir(data_dir):
+        raise WorkflowError("%s does not hold a directory %s" % (tarball, os.path.basename(data_dir)))
+    return data_dir
+
+
+def load_yaml(path):
+    import yaml
+    with open(path) as fh:
+        return yaml.safe_load(fh) or {}
+
+
+class PathNotGiven(WorkflowError):
+    """eval_variant_custom.smk:6-17 / :24-28 (same messages)."""
+
+
+def vareval_settings(vcfs=None, refs=None, outpath=None, labels=None, config=None, cd=None, wd=None):
+    """What `run_benchmark.py vareval` runs on: the command line where it says something, config/customize_data.yaml where it
+    does not (run_benchmark.py:153-166: only vcfs / refs / outpath travel from the command line, made absolute against the
+    caller's directory; rules/load_config_custom.smk:3 + eval_variant_custom.smk:3-17,24-34 take the rest, and whatever the
+    command line left out, from the config file, relative to the workflow's directory).
+    One deliberate difference: the reference DROPS `-l/--labels` given on the command line (run_benchmark.py:157-165,
+    `else: continue`) and always uses the config file's; here a command-line value wins.
+    vcfs / refs / labels: comma-separated strings or None; config: the YAML as a dict.
+    Returns {"vcfs": [...], "refs": [...] or None, "outpath": str, "labels": [...] or None}."""
+    config = config or {}
+    cd = cd or os.getcwd()
+    wd = wd or cd
+
+    def items(val, base):
+        return [os.path.join(base, x.strip()) for x in val.split(",")]
+
+    def pick(name, cli):
+        if cli is not None:
+            return cli, cd
+        v = config.get(name)
+        return (v, wd) if isinstance(v, str) else (None, wd)
+
+    r, rbase = pick("refs", refs)
+    o, obase = pick("outpath", outpath)
+    if o is None:
+        raise PathNotGiven("The reference genome files or output directory are not specified.")
+    v, vbase = pick("vcfs", vcfs)
+    if v is None:
+        raise PathNotGiven("The VCF files from SNP calling are not specified.")
+    lab = labels if labels is not None else config.get("labels")
+    return {"vcfs": items(v, vbase), "refs": items(r, rbase) if r is not None else None, "outpath": os.path.join(obase, o.rstrip("/")),
+            "labels": [x for x in lab.split(",")] if isinstance(lab, str) and lab else None}
+
+
 def _fp_keys(path):
     """snpcaller_fp_compare.R:36-47: pos/ref/alt of the data rows with single-base alleles."""
     with open(path, "rb") as fh:
@@ -66,18 +135,20 @@ def hcmv_rank_post(engine, jobs, indices, args):
 def run_hcmv_variantcall(data_dir, outpath, callers=None, engine=None, dryrun=False, gpus=None, _body=None, _backend="nccl",
                          _same_device=False):
     """data_dir: the unpacked bundle (data/snp): vcf/{caller}/{sample}.{ref}.{caller}.vcf and
-    nucmer/{TM,TA}.maskrepeat.variants.vcf (rules/load_config.smk:28-36).
+    nucmer/{TM,TA}.maskrepeat.variants.vcf (rules/load_config.smk:28-36); when it is absent and <data_dir>.tar.gz exists,
+    that is unpacked first (:28-31).
     gpus > 1: one process per GPU (quasimodo_amd.multigpu); the VCFs are dealt by SAMPLE (longest first), so the four
     compared callers of a sample meet on one rank and the FP overlap needs no exchange; every rank writes its own files,
     the confusion counters go through the one all-reduce, the rows come to this process for the three tables."""
     callers = list(callers or SNPCALLERS)
+    data_dir = ensure_bundle(data_dir)
     results = os.path.join(outpath.rstrip("/"), "results")
     snp_dir = os.path.join(results, "snp")
     call_dir = os.path.join(snp_dir, "callers")
     samples = sorted(s for s in (os.path.basename(p).split(".")[0] for p in glob.glob(os.path.join(data_dir, "vcf", "clc", "*.clc.vcf")))
                      if s in SAMPLE_REF)
     if not samples:
-        raise WorkflowError("no bundled VCFs under %s/vcf/clc (data/snp.tar.gz not unpacked?)" % data_dir)
+        raise WorkflowError("no bundled VCFs under %s/vcf/clc" % data_dir)
     plan = []
     for s in samples:
         for c in callers:

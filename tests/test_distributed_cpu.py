@@ -151,3 +151,80 @@ def test_lpt_shards_properties():
         assert sorted(i for s in sh for i in s) == list(range(50)) and all(s == sorted(s) for s in sh)
         loads = [int(n[s].sum()) for s in sh]
         assert max(loads) - min(loads) <= int(n.max())
+
+
+def test_the_bundle_is_unpacked_when_data_snp_is_absent(tmp_path, monkeypatch, oracle, qmlib):
+    """rules/load_config.smk:28-31: `data/snp` missing, `data/snp.tar.gz` there -> unpacked beside it, then the run as ever.
+    The tables of the run from the tarball are byte-identical to those of the run from the directory (per-rank body injected:
+    product host code, the oracle as the device)."""
+    import tarfile
+    from quasimodo_amd import workflow
+    monkeypatch.setenv("PYTHONPATH", os.path.join(ROOT, "tests") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    explicit = tmp_path / "explicit" / "data" / "snp"
+    _bundle(explicit)
+    packed = tmp_path / "packed" / "data"
+    packed.mkdir(parents=True)
+    with tarfile.open(packed / "snp.tar.gz", "w:gz") as tf:
+        tf.add(str(explicit), arcname="snp")
+    t = {}
+    for name, data in (("explicit", explicit), ("packed", packed / "snp")):
+        out = tmp_path / ("out_" + name)
+        jobs = workflow.run_hcmv_variantcall(str(data), str(out), gpus=1, _body="sharded_cpu_classify:body", _backend="gloo")
+        assert len(jobs) == 60
+        t[name] = {n: (out / "results" / "final_tables" / n).read_bytes() for n in ("caller_performance.tsv", "snpcaller_fp_snp_compare.txt")}
+    assert t["explicit"] == t["packed"] and (packed / "snp" / "vcf" / "clc").is_dir()
+    # neither the directory nor the tarball; a tarball that would write outside its directory
+    with pytest.raises(workflow.WorkflowError):
+        workflow.ensure_bundle(str(tmp_path / "nowhere" / "snp"))
+    evil = tmp_path / "evil"
+    evil.mkdir()
+    (tmp_path / "x.txt").write_text("x")
+    with tarfile.open(evil / "snp.tar.gz", "w:gz") as tf:
+        tf.add(str(tmp_path / "x.txt"), arcname="../escaped.txt")
+    with pytest.raises(Exception):
+        workflow.ensure_bundle(str(evil / "snp"))
+    assert not (tmp_path / "escaped.txt").exists()
+
+
+def test_vareval_from_the_config_file_alone(tmp_path, monkeypatch, oracle, qmlib):
+    """run_benchmark.py:153-166 + rules/load_config_custom.smk:3 + eval_variant_custom.smk:3-34: what the command line leaves out
+    comes from config/customize_data.yaml (paths relative to the workflow's directory; command-line paths relative to the
+    caller's).  A YAML-only run writes the table of the run with everything on the command line."""
+    import yaml
+    from quasimodo_amd import workflow
+    monkeypatch.setenv("PYTHONPATH", os.path.join(ROOT, "tests") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    wd = tmp_path / "wd"
+    cd = tmp_path / "elsewhere"
+    (wd / "in").mkdir(parents=True)
+    cd.mkdir()
+    cs = [e for e in golden_cases() if e["family"] == "custom"]
+    names = []
+    for e in cs:
+        vcf, truth, _ = read_case(e)
+        (wd / "in" / os.path.basename(e["vcf"])).write_bytes(vcf)
+        names.append("in/" + os.path.basename(e["vcf"]))
+    cfg = {"outpath": "out_yaml/", "vcfs": ", ".join(names), "refs": "ref/g1.fa,ref/g2.fa", "labels": None, "novenn": False, "threads": 6}
+    (wd / "customize_data.yaml").write_text(yaml.safe_dump(cfg))
+    st = workflow.vareval_settings(config=workflow.load_yaml(str(wd / "customize_data.yaml")), cd=str(cd), wd=str(wd))
+    assert st["vcfs"] == [str(wd / n) for n in names] and st["outpath"] == str(wd / "out_yaml") and st["labels"] is None
+    assert st["refs"] == [str(wd / "ref/g1.fa"), str(wd / "ref/g2.fa")]
+    # the command line wins, relative to the caller's directory; labels from the file when the command line has none
+    st2 = workflow.vareval_settings(vcfs="a.vcf, b.vcf", outpath="o", config=dict(cfg, labels="x,y"), cd=str(cd), wd=str(wd))
+    assert st2["vcfs"] == [str(cd / "a.vcf"), str(cd / "b.vcf")] and st2["outpath"] == str(cd / "o") and st2["labels"] == ["x", "y"]
+    assert workflow.vareval_settings(vcfs="a.vcf", outpath="o", labels="k", config=dict(cfg, labels="x"), cd=str(cd), wd=str(wd))["labels"] == ["k"]
+    # the reference's two complaints (eval_variant_custom.smk:14-17, 27-28)
+    with pytest.raises(workflow.PathNotGiven, match="reference genome files or output directory"):
+        workflow.vareval_settings(vcfs="a.vcf", config={"outpath": None}, cd=str(cd), wd=str(wd))
+    with pytest.raises(workflow.PathNotGiven, match="VCF files from SNP calling"):
+        workflow.vareval_settings(outpath="o", config={"vcfs": None}, cd=str(cd), wd=str(wd))
+    # the two runs
+    snps_rel = os.path.join("results", "snp", "nucmer", "g1_g2.maskrepeat.snps")
+    t = {}
+    for name, s in (("yaml", st), ("explicit", workflow.vareval_settings(vcfs=",".join(str(wd / n) for n in names), refs="g1.fa,g2.fa",
+                                                                       outpath=str(tmp_path / "out_explicit"), config={}, cd=str(cd), wd=str(wd)))):
+        snps = os.path.join(s["outpath"], snps_rel)
+        os.makedirs(os.path.dirname(snps))
+        open(snps, "wb").write(truth)
+        workflow.run_vareval(s["vcfs"], snps, s["outpath"], labels=s["labels"], gpus=1, _body="sharded_cpu_classify:body", _backend="gloo")
+        t[name] = open(os.path.join(s["outpath"], "results", "final_tables", "snpcall_benchmark.txt"), "rb").read()
+    assert t["yaml"] == t["explicit"] and len(t["yaml"].splitlines()) == 1 + len(cs)

@@ -184,6 +184,56 @@ def test_vareval_workflow(engine, oracle, tmp_path):
         assert job.filtered_out.endswith("results/snp/callers/%s.filtered.vcf" % e["caller"])
 
 
+@pytest.mark.gpu
+def test_run_benchmark_cli_vareval_from_a_config_file_hcmv_from_the_tarball(tmp_path):
+    """The reference's command lines on the HIP engine: `vareval` with nothing but a config file (run_benchmark.py:153-166,
+    rules/load_config_custom.smk:3), `hcmv -e variantcall` on a data directory that exists only as snp.tar.gz
+    (rules/load_config.smk:28-31); --json says where VCFs that were out of order went."""
+    import json
+    import subprocess
+    import sys
+    import tarfile
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cs = [e for e in golden_cases() if e["family"] == "custom"]
+    names = []
+    for e in cs:
+        vcf, truth, exp = read_case(e)
+        (tmp_path / os.path.basename(e["vcf"])).write_bytes(vcf)
+        names.append(str(tmp_path / os.path.basename(e["vcf"])))
+    out = tmp_path / "o"
+    snps = out / "results" / "snp" / "nucmer" / "g1_g2.maskrepeat.snps"
+    snps.parent.mkdir(parents=True)
+    snps.write_bytes(truth)
+    cfg = tmp_path / "customize_data.yaml"
+    cfg.write_text(yaml.safe_dump({"outpath": str(out), "vcfs": ",".join(names), "refs": "x/g1.fa,x/g2.fa", "labels": None}))
+    js = tmp_path / "run.json"
+    r = subprocess.run([sys.executable, os.path.join(root, "run_benchmark.py"), "vareval", "--config", str(cfg), "--json", str(js)],
+                       cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = (out / "results" / "final_tables" / "snpcall_benchmark.txt").read_text().splitlines()
+    assert len(lines) == 1 + len(cs)
+    doc = json.load(open(js))
+    assert doc["command"] == "vareval" and len(doc["rows"]) == len(cs) and doc["unsorted_paths"]["radix_after_overflow"] == 0
+    for e, row in zip(cs, doc["rows"]):
+        _, _, exp = read_case(e)
+        assert open(row["fp"], "rb").read() == exp["fp"] and open(row["tp"], "rb").read() == exp["tp"]
+    # without a config file and without arguments: the reference's complaint, a non-zero exit
+    r = subprocess.run([sys.executable, os.path.join(root, "run_benchmark.py"), "vareval", "-o", "o2"], cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode != 0 and "VCF files from SNP calling are not specified" in r.stdout
+    # hcmv from the tarball
+    data = tmp_path / "data"
+    _build_bundle(str(tmp_path / "stage" / "snp"))
+    data.mkdir()
+    with tarfile.open(data / "snp.tar.gz", "w:gz") as tf:
+        tf.add(str(tmp_path / "stage" / "snp"), arcname="snp")
+    r = subprocess.run([sys.executable, os.path.join(root, "run_benchmark.py"), "hcmv", "-e", "variantcall", "--data", str(data / "snp"), "-o", str(tmp_path / "h"),
+                        "--json", str(tmp_path / "h.json")], cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert len((tmp_path / "h" / "results" / "final_tables" / "caller_performance.tsv").read_text().splitlines()) == 61
+    assert len(json.load(open(tmp_path / "h.json"))["rows"]) == 60
+
+
 def test_module_cli_split_and_argument_errors(tmp_path):
     """`python -m quasimodo_amd` -- the parts that need no GPU"""
     import subprocess
@@ -222,7 +272,11 @@ def test_module_cli_extract(tmp_path):
     r = subprocess.run([sys.executable, "-m", "quasimodo_amd", "extract", "--truth", os.path.join(g, cases[0]["truth"]), "--json", str(js)] + sel,
                        cwd=root, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    rows = json.load(open(js))
+    doc = json.load(open(js))
+    rows = doc["rows"]
+    # where VCFs that were out of order went (qm_path_stats_total): every counter there, nothing on the radix sort after an overflow
+    assert set(doc["unsorted_paths"]) >= {"unsorted", "bucket_direct", "radix", "radix_after_overflow"} and doc["unsorted_paths"]["radix_after_overflow"] == 0
+    assert doc["unsorted_paths"]["unsorted"] == sum(1 for row in rows if not row["sorted"])
     assert len(rows) == len(sel) and r.stdout.count("\n") == len(sel) + 1
     for row, c in zip(rows, same_truth):
         _, _, exp = read_case(c)
