@@ -279,6 +279,13 @@ typedef struct qm_vcf_cols {
   int64_t n_refused;    /* kinds 5 and 6 */
   int64_t first_refused_line; /* 1-based, 0 = none */
   int64_t n_nokey_kept; /* kept data lines without a comparable key (QM_F_NOKEY): qm_vcf_hostpath counts their keys as text */
+  /* (ABI 4) kept data lines that hold '#', ' or ": the reference's counting step reads <x>.filtered.vcf with R's read.table
+   * (scripts/caller_performance_compare.R:29-39, custom_snp_benchmark.R:45-48: comment.char = "#", quote = "\"'"), which cuts a
+   * line at a '#', lets a quote swallow tabs and newlines up to the next one, and turns a file it then cannot parse into an
+   * EMPTY one (tryCatch -> NA row).  The three output files are unaffected (they are the shell pipeline's bytes); the R-path
+   * counts (QM_S_TP_R / FP_R / NPASS) assume lines split at their tabs alone.  Strict table writers refuse such a file. */
+  int64_t n_r_hostile;
+  int64_t first_r_hostile_line; /* 1-based, 0 = none */
 } qm_vcf_cols;
 typedef struct qm_dict qm_dict;
 int64_t qm_vcf_count_lines(const uint8_t* text, size_t len);
@@ -373,6 +380,7 @@ typedef struct qm_file_stats {
   int64_t n_lines, n_refused, genomediff;
   int64_t header_kept, header_kept_tp;   /* '#' lines that pass the A2 filter (awk emits them among the kept lines too) */
   int64_t host_decided;                  /* lines decided by the host path */
+  int64_t r_hostile;                     /* (ABI 4) qm_vcf_cols.n_r_hostile: kept lines R's read.table would not read as tab-split text */
 } qm_file_stats;
 int qm_extract_files(qm_ctx* ctx, int n_jobs, const qm_file_job* jobs, int n_bins, unsigned mode, int strict,
                      qm_file_stats* stats, uint64_t* roc, double* phase_seconds);

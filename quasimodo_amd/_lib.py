@@ -53,12 +53,12 @@ class FileJob(C.Structure):
 
 class FileStats(C.Structure):
     _fields_ = [("scalars", C.c_int64 * QM_N_SCALARS), ("n_lines", C.c_int64), ("n_refused", C.c_int64), ("genomediff", C.c_int64),
-                ("header_kept", C.c_int64), ("header_kept_tp", C.c_int64), ("host_decided", C.c_int64)]
+                ("header_kept", C.c_int64), ("header_kept_tp", C.c_int64), ("host_decided", C.c_int64), ("r_hostile", C.c_int64)]
 
 
 class VcfCols(C.Structure):
     _fields_ = [("n_lines", C.c_int64), ("n_data", C.c_int64), ("n_host", C.c_int64), ("n_refused", C.c_int64),
-                ("first_refused_line", C.c_int64), ("n_nokey_kept", C.c_int64)]
+                ("first_refused_line", C.c_int64), ("n_nokey_kept", C.c_int64), ("n_r_hostile", C.c_int64), ("first_r_hostile_line", C.c_int64)]
 
 
 def library_path():

@@ -1761,6 +1761,14 @@ int qm_device_add_u64(qm_ctx* c, uint64_t* dst, const uint64_t* src, int64_t n) 
   HIPCHK(hipStreamSynchronize(c->stream));
   return QM_OK;
 }
+// bytes of a device buffer cleared on the context's device (qm_extract_files_ex: the caller's per-truth-file sums)
+int qm_device_zero(qm_ctx* c, void* dst, size_t bytes) {
+  if (!c || (!dst && bytes)) return fail(QM_E_INVAL, "qm_device_zero: bad arguments");
+  HIPCHK(hipSetDevice(c->dev));
+  if (bytes) HIPCHK(hipMemsetAsync(dst, 0, bytes, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return QM_OK;
+}
 extern "C" int qm_path_stats_total(qm_ctx* c, int64_t* out) {
   if (!c || !out) return fail(QM_E_INVAL, "qm_path_stats_total: NULL");
   memcpy(out, c->path_total, sizeof c->path_total);

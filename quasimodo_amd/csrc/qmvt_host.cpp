@@ -275,41 +275,53 @@ struct LineIndex {
   size_t n;        // length without the newline
   int ntab;        // all tabs of the line
   bool dirty;      // NUL or non-ASCII byte
+  bool punct;      // a byte in 0x20..0x27 (space ! " # $ % & '): the line MAY hold one of the three that R's read.table reads its own way
   uint32_t tab[LINE_MAXT];
 };
 #define QM_INDEX_TABS(mt, off) while (mt) { const uint32_t i_ = (uint32_t)__builtin_ctz(mt); mt &= mt - 1u; if (nt < LINE_MAXT) L.tab[nt] = (off) + i_; ++nt; }
-inline void index_line_tail(const uint8_t* s, const uint8_t* p, const uint8_t* lim, int nt, bool dirty, LineIndex& L) {
+inline void index_line_tail(const uint8_t* s, const uint8_t* p, const uint8_t* lim, int nt, bool dirty, bool punct, LineIndex& L) {
   for (; p < lim && *p != '\n'; ++p) {
     if (*p == '\t') { if (nt < LINE_MAXT) L.tab[nt] = (uint32_t)(p - s); ++nt; }
     dirty = dirty || *p == 0 || *p >= 0x80;
+    punct = punct || (*p & 0xf8) == 0x20;
   }
-  L.n = (size_t)(p - s); L.ntab = nt; L.dirty = dirty;
+  L.n = (size_t)(p - s); L.ntab = nt; L.dirty = dirty; L.punct = punct;
+}
+// '#' anywhere, or a quote character: R's read.table (comment.char = "#", quote = "\"'") does not split such a line at its tabs alone
+inline bool r_hostile_line(const uint8_t* s, size_t n) {
+  for (size_t i = 0; i < n; ++i)
+    if (s[i] == '#' || s[i] == '\'' || s[i] == '"') return true;
+  return false;
 }
 #if defined(__x86_64__)
 __attribute__((target("avx2"))) void index_line_avx2(const uint8_t* s, const uint8_t* lim, LineIndex& L) {
   const uint8_t* p = s;
   int nt = 0;
-  bool dirty = false;
+  bool dirty = false, punct = false;
   const __m256i vt = _mm256_set1_epi8('\t'), vn = _mm256_set1_epi8('\n'), vz = _mm256_setzero_si256();
+  const __m256i vf8 = _mm256_set1_epi8((char)0xf8), v20 = _mm256_set1_epi8(0x20);
   while (p + 32 <= lim) {
     const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(p));
     uint32_t mt = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(x, vt));
     const uint32_t mn = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(x, vn));
     uint32_t md = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(x, vz)) | (uint32_t)_mm256_movemask_epi8(x);   // zero bytes | high bits
+    uint32_t mq = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_and_si256(x, vf8), v20));              // 0x20..0x27
     const uint32_t off = (uint32_t)(p - s);
     if (mn) {
       const uint32_t e = (uint32_t)__builtin_ctz(mn), below = e ? (0xffffffffu >> (32u - e)) : 0u;
-      mt &= below; md &= below;
+      mt &= below; md &= below; mq &= below;
       dirty = dirty || md != 0;
+      punct = punct || mq != 0;
       QM_INDEX_TABS(mt, off)
-      L.n = (size_t)off + e; L.ntab = nt; L.dirty = dirty;
+      L.n = (size_t)off + e; L.ntab = nt; L.dirty = dirty; L.punct = punct;
       return;
     }
     dirty = dirty || md != 0;
+    punct = punct || mq != 0;
     QM_INDEX_TABS(mt, off)
     p += 32;
   }
-  index_line_tail(s, p, lim, nt, dirty, L);
+  index_line_tail(s, p, lim, nt, dirty, punct, L);
 }
 #endif
 inline void index_line(const uint8_t* s, const uint8_t* lim, LineIndex& L) {   // lim: end of the chunk (whole lines; inside the mapping)
@@ -317,29 +329,33 @@ inline void index_line(const uint8_t* s, const uint8_t* lim, LineIndex& L) {   /
   if (cpu_has_avx2()) { index_line_avx2(s, lim, L); return; }
   const uint8_t* p = s;
   int nt = 0;
-  bool dirty = false;
+  bool dirty = false, punct = false;
   const __m128i vt = _mm_set1_epi8('\t'), vn = _mm_set1_epi8('\n'), vz = _mm_setzero_si128();
+  const __m128i vf8 = _mm_set1_epi8((char)0xf8), v20 = _mm_set1_epi8(0x20);
   while (p + 16 <= lim) {
     const __m128i x = _mm_loadu_si128(reinterpret_cast<const __m128i*>(p));
     uint32_t mt = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, vt));
     const uint32_t mn = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, vn));
     uint32_t md = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(x, vz)) | (uint32_t)_mm_movemask_epi8(x);   // zero bytes | high bits
+    uint32_t mq = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_and_si128(x, vf8), v20));              // 0x20..0x27
     const uint32_t off = (uint32_t)(p - s);
     if (mn) {
       const uint32_t e = (uint32_t)__builtin_ctz(mn), below = (1u << e) - 1u;
-      mt &= below; md &= below;
+      mt &= below; md &= below; mq &= below;
       dirty = dirty || md != 0;
+      punct = punct || mq != 0;
       QM_INDEX_TABS(mt, off)
-      L.n = (size_t)off + e; L.ntab = nt; L.dirty = dirty;
+      L.n = (size_t)off + e; L.ntab = nt; L.dirty = dirty; L.punct = punct;
       return;
     }
     dirty = dirty || md != 0;
+    punct = punct || mq != 0;
     QM_INDEX_TABS(mt, off)
     p += 16;
   }
-  index_line_tail(s, p, lim, nt, dirty, L);
+  index_line_tail(s, p, lim, nt, dirty, punct, L);
 #else
-  index_line_tail(s, s, lim, 0, false, L);
+  index_line_tail(s, s, lim, 0, false, false, L);
 #endif
 }
 #undef QM_INDEX_TABS
@@ -378,6 +394,7 @@ struct ScanChunk {
   int64_t nl = 0, nd = 0;          // lines / data lines in the chunk
   int64_t l0 = 0, d0 = 0;          // global index of its first line / data line
   int64_t nhost = 0, nref = 0, first_ref = 0, nnokey = 0;   // host-path lines; refused lines, 1-based global line of the first; kept NOKEY lines
+  int64_t nrq = 0, first_rq = 0;   // kept data lines holding '#', ' or ": R's read.table does not read them the way the counts assume; the first one's line
   int32_t last_pos = 0;            // last canonical POS seen in the chunk (0 if none)
   int64_t lead_nokey = 0;          // data lines before the chunk's first canonical POS
   bool any_pos = false;
@@ -454,6 +471,7 @@ static void scan_chunk(const uint8_t* text, ScanChunk& c, bool count_only, int64
           kind = QM_LINE_DATA_HOST; ++c.nhost;
         }
         if (pass && !cpos) ++c.nnokey;
+        if (pass && L.punct && r_hostile_line(s, n)) { ++c.nrq; if (!c.first_rq) c.first_rq = gl + 1; }
         line_kind[gl] = kind;
         if (pos) {
           pos[gd] = p;
@@ -536,14 +554,15 @@ int qm_host_scan_threads(const uint8_t* text, size_t len, int64_t cap_lines, int
   run(false);
   for (auto& c : ch) if (c.overflow) return QM_E_INVAL;
   if (counted) { nl = ch[0].nl; nd = ch[0].nd; }
-  int64_t nhost = 0, nref = 0, first_ref = 0, nnokey = 0;
+  int64_t nhost = 0, nref = 0, first_ref = 0, nnokey = 0, nrq = 0, first_rq = 0;
   int32_t carry = 0;
   for (auto& c : ch) {
     if (pos && carry != 0)
       for (int64_t i = 0; i < c.lead_nokey; ++i) pos[c.d0 + i] = carry;   // leading records had no position of their own
     if (c.any_pos) carry = c.last_pos;
-    nhost += c.nhost; nref += c.nref; nnokey += c.nnokey;
+    nhost += c.nhost; nref += c.nref; nnokey += c.nnokey; nrq += c.nrq;
     if (!first_ref && c.first_ref) first_ref = c.first_ref;
+    if (!first_rq && c.first_rq) first_rq = c.first_rq;
   }
   line_off[nl] = (int64_t)len;
   info->n_lines = nl;
@@ -552,6 +571,8 @@ int qm_host_scan_threads(const uint8_t* text, size_t len, int64_t cap_lines, int
   info->n_refused = nref;
   info->first_refused_line = first_ref;
   info->n_nokey_kept = nnokey;
+  info->n_r_hostile = nrq;
+  info->first_r_hostile_line = first_rq;
   return QM_OK;
 }
 
@@ -1178,15 +1199,21 @@ extern "C" int qm_bgzf_write(const char* path, const uint8_t* data, size_t len, 
 // anything is written: QM_E_UNSORTED leaves no file behind.
 extern "C" int qm_bgzf_write_tbi(const char* path, const uint8_t* data, size_t len, int level) {
   if (!path || (!data && len) || level < -1 || level > 9) return QM_E_INVAL;
-  const std::string gz(path), tmp = gz + ".tbitmp." + std::to_string((long)getpid());
+  // both files are complete under names of their own (process id + a serial number: two threads may write the same path) before
+  // either appears: the .gz first, then its index -- a reader never finds an index beside an older or missing .gz; if the
+  // second rename fails, the index that no longer belongs to the new .gz is removed
+  static std::atomic<unsigned> serial{0};
+  const std::string gz(path), tag = "." + std::to_string((long)getpid()) + "." + std::to_string(serial.fetch_add(1));
+  const std::string tmp = gz + ".tbitmp" + tag, tmpi = gz + ".tbi.tbitmp" + tag;
   std::vector<uint64_t> coff;
   int rc = bgzf_file(tmp, data, len, level, &coff);   // (the compressed sizes are what the virtual offsets are made of)
   if (rc != QM_OK) return rc;
   std::vector<uint8_t> idx;
   rc = tbi_build(data, len, coff, idx);
-  if (rc == QM_OK) rc = bgzf_file(gz + ".tbi", idx.data(), idx.size(), level, nullptr);
-  if (rc != QM_OK) { remove(tmp.c_str()); return rc; }
-  if (rename(tmp.c_str(), gz.c_str()) != 0) { remove(tmp.c_str()); return QM_E_IO; }
+  if (rc == QM_OK) rc = bgzf_file(tmpi, idx.data(), idx.size(), level, nullptr);
+  if (rc != QM_OK) { remove(tmp.c_str()); remove(tmpi.c_str()); return rc; }
+  if (rename(tmp.c_str(), gz.c_str()) != 0) { remove(tmp.c_str()); remove(tmpi.c_str()); return QM_E_IO; }
+  if (rename(tmpi.c_str(), (gz + ".tbi").c_str()) != 0) { remove(tmpi.c_str()); remove((gz + ".tbi").c_str()); return QM_E_IO; }
   return QM_OK;
 }
 

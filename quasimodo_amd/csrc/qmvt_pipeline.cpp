@@ -39,6 +39,7 @@ int qm_host_write_masks(const char* path, const uint8_t* text, size_t len, int64
 int qm_host_threads(void);
 void qm_set_error(const char* msg);   // qmvt_api.cpp: what qm_last_error returns
 int qm_device_add_u64(qm_ctx* ctx, uint64_t* dst, const uint64_t* src, int64_t n);   // qmvt_api.cpp: dst[i] += src[i] on the device, blocking
+int qm_device_zero(qm_ctx* ctx, void* dst, size_t bytes);                              // qmvt_api.cpp: on the context's device, blocking
 
 namespace {
 
@@ -170,7 +171,7 @@ extern "C" int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* j
     return fail(QM_E_INVAL, "qm_extract_files: bad arguments");
   if (global_dev && (n_slots < 1 || (n_jobs && !truth_slot))) return fail(QM_E_INVAL, "qm_extract_files_ex: global_dev needs truth_slot and n_slots >= 1");
   const size_t gbytes = global_dev ? (size_t)n_slots * 3 * (size_t)n_bins * sizeof(uint64_t) : 0;
-  if (global_dev && hipMemset(global_dev, 0, gbytes) != hipSuccess) return fail(QM_E_HIP, "qm_extract_files_ex: cannot clear global_dev");
+  if (global_dev) { const int rc0 = qm_device_zero(ctx, global_dev, gbytes); if (rc0 != QM_OK) return rc0; }   // (on the context's device, whatever the caller's thread had current)
   if (n_jobs == 0) {   // nothing to do is not an error (a rank of a sharded run may hold no VCF)
     if (phase_seconds) memset(phase_seconds, 0, 8 * sizeof(double));
     return QM_OK;
@@ -230,6 +231,11 @@ extern "C" int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* j
     }
     while (!G.empty() && G.back().jobs.empty()) G.pop_back();
   }
+  // The context is not made for two threads: with more than one group (QM_FILES_GROUPS / QM_FILES_GROUP_MB; experimental, the
+  // default is one) stage one of group g + 1 runs beside stage two of group g, so whatever touches the context's streams and
+  // truth tables -- batch creation there, run / finish / row read-back here -- takes turns.  (The uploads of the tokenizer
+  // threads write their own batch through a stream of its own.)
+  std::mutex engine_mu;
   std::thread truth_thread;   // ends with the patterns of the truth files
   std::thread stage2;         // engine + masks + files of the group before the one being tokenised
   auto cleanup = [&]() {
@@ -332,6 +338,7 @@ extern "C" int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* j
     for (int j : gr.jobs)
       if (!jobs[j].pure) { J[(size_t)j].batch_v = (int)gr.nrec.size(); gr.nrec.push_back(J[(size_t)j].n_data); gr.tids.push_back(T[(size_t)J[(size_t)j].truth].tid); }
     if (!gr.nrec.empty()) {
+      std::lock_guard<std::mutex> eg(engine_mu);
       const int rc = qm_batch_create_ext(ctx, (int)gr.nrec.size(), gr.nrec.data(), gr.tids.data(), n_bins, mode, &gr.batch);
       if (rc != QM_OK) return rc;
     }
@@ -404,6 +411,7 @@ extern "C" int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* j
     int rc = QM_OK;
     double t0 = now();
     if (gr.batch) {
+      std::lock_guard<std::mutex> eg(engine_mu);
       rc = qm_batch_run(gr.batch, nullptr, nullptr);
       if (rc == QM_OK) rc = qm_batch_finish(gr.batch, nullptr);
       gr.scal.resize(gr.nrec.size() * QM_N_SCALARS);
@@ -461,7 +469,7 @@ extern "C" int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* j
       if (stats) {
         qm_file_stats& o = stats[j];
         memset(&o, 0, sizeof o);
-        o.n_lines = s.info.n_lines; o.n_refused = s.info.n_refused; o.header_kept = hk; o.header_kept_tp = hk_tp; o.host_decided = s.ex[0];
+        o.n_lines = s.info.n_lines; o.n_refused = s.info.n_refused; o.header_kept = hk; o.header_kept_tp = hk_tp; o.host_decided = s.ex[0]; o.r_hostile = s.info.n_r_hostile;
         if (jobs[j].pure) {
           int64_t np = 0;
           for (int64_t r = 0; r < s.n_data; ++r) np += s.flags[r] & QM_F_PASS;

@@ -162,7 +162,8 @@ class Engine:
         for k in range(n):
             r = dict(zip(SCALAR_NAMES, list(st[k].scalars)))
             r.update(n_lines=st[k].n_lines, n_refused=st[k].n_refused, genomediff=st[k].genomediff,
-                     header_kept=(st[k].header_kept, st[k].header_kept_tp), host_decided=st[k].host_decided, roc=roc[k].copy())
+                     header_kept=(st[k].header_kept, st[k].header_kept_tp), host_decided=st[k].host_decided, r_hostile=st[k].r_hostile,
+                     roc=roc[k].copy())
             rows.append(r)
         phases = dict(zip(("map_count", "truth_beside", "batch_layout", "tokenise_upload", "engine", "masks_back", "write", "release"), list(ph)))
         return rows, phases

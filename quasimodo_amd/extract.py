@@ -148,7 +148,8 @@ def _pure_only(file_jobs, strict):
         sv.write(j["fp"], cls, 0)
         npass = int(cls.sum())
         r = dict(zip(SCALAR_NAMES, (npass, 0, npass, 0, 0, 1, sv.n_records, 0)))
-        r.update(n_lines=sv.n_lines, n_refused=sv.n_refused, genomediff=0, header_kept=sv.header_kept, host_decided=0, roc=None)
+        r.update(n_lines=sv.n_lines, n_refused=sv.n_refused, genomediff=0, header_kept=sv.header_kept, host_decided=0, roc=None,
+                 r_hostile=sv.n_r_hostile)
         rows.append(r)
     return rows
 

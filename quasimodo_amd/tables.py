@@ -9,8 +9,47 @@ The counts come from the engine (Job.stats); only the three ratios are computed 
 round(x, 3) (R 3.5.1: x * 10^3 in long double, nearbyint, / 10^3).  Raw counts are written next to
 the rounded columns so that a tie-rounding difference between R versions is visible."""
 import math
+import os
 
 import numpy as np
+
+
+class RTableError(RuntimeError):
+    """An input that R's read.table would not read the way the engine's counts assume."""
+
+
+def r_hostile_rows(path):
+    """How many non-comment rows of a truth file hold '#', ' or " (see check_r_readable): R reads the truth files with the
+    same read.table call (caller_performance_compare.R:29-39 through make_snp_vector, custom_snp_benchmark.R:23-24)."""
+    n = 0
+    with open(path, "rb") as fh:
+        for ln in fh:
+            if ln[:1] != b"#" and (b"#" in ln or b"'" in ln or b'"' in ln):
+                n += 1
+    return n
+
+
+def check_r_readable(rows, strict=None):
+    """A6 / A6c are RESTATED from the R text (no R in this image: parity unpinned), and the restatement reads a file as lines
+    split at tabs.  R's read.table -- comment.char = "#", the default quote = "\"'", eight colClasses recycled over the
+    columns of the first five lines (scripts/caller_performance_compare.R:29-39, custom_snp_benchmark.R:23-24,45-48,
+    snpcaller_fp_compare.R:36-39) -- does not: a '#' ANYWHERE in a data line cuts the line there (fewer fields than the first
+    lines had: read.table stops, the tryCatch turns the WHOLE FILE into an empty vector and the row into NA, :37-40,101-108;
+    only a '#' inside the last column is harmless), a ' or " opens a string that swallows tabs and newlines up to the next
+    one (balanced inside one field: the quotes are dropped, also from POS; otherwise fields shift or the file fails the same
+    way).  The engine counts what the reference's shell pipeline kept (those bytes are pinned); it does not guess what R makes
+    of such a line.  strict (default: QM_LENIENT unset): refuse to write a row for a file with such kept lines or truth rows;
+    lenient: write the tab-split counts.  rows: iterable of (name, stats)."""
+    if strict is None:
+        strict = os.environ.get("QM_LENIENT", "0") in ("", "0")
+    bad = [(name, int(st.get("r_hostile") or 0), int(st.get("truth_r_hostile") or 0)) for name, st in rows
+           if (st.get("r_hostile") or 0) or (st.get("truth_r_hostile") or 0)]
+    if bad and strict:
+        raise RTableError("R's read.table (comment.char = \"#\", quote = \"\\\"'\") would not read these files as tab-split lines, so the "
+                          "counts of the table are not what the reference's R scripts would write: "
+                          + "; ".join("%s (%d kept line(s), %d truth row(s) with '#', ' or \")" % b for b in bad[:5])
+                          + ".  QM_LENIENT=1 writes the tab-split counts.")
+    return bad
 
 CALLER_MAP = {"bcftools": "BCFtools", "clc": "CLC", "freebayes": "FreeBayes", "gatk": "GATK", "lofreq": "LoFreq",
               "varscan": "VarScan2"}  # caller_performance_compare.R:24-27
@@ -61,8 +100,10 @@ def performance_row(stats):
     return gd, n, tp, fp, p, r, f1
 
 
-def write_caller_performance(path, rows):
+def write_caller_performance(path, rows, strict=None):
     """rows: iterable of (caller_lower, sample, stats)."""
+    rows = list(rows)
+    check_r_readable([("%s/%s" % (c, smp), st) for c, smp, st in rows], strict)
     with open(path, "w") as fh:
         fh.write("\t".join(["caller", "mixture", "genomediff", "calleridentify", "TP", "FP", "Precision", "Recall", "F1"]) + "\n")
         for caller, sample, stats in rows:
@@ -70,8 +111,10 @@ def write_caller_performance(path, rows):
             fh.write("\t".join([CALLER_MAP.get(caller, caller), sample] + [r_str(v) for v in vals]) + "\n")
 
 
-def write_snpcall_benchmark(path, rows):
+def write_snpcall_benchmark(path, rows, strict=None):
     """rows: iterable of (label, stats).  custom_snp_benchmark.R:30-95."""
+    rows = list(rows)
+    check_r_readable(rows, strict)
     with open(path, "w") as fh:
         fh.write("\t".join(["caller", "genomediff", "calleridentify", "TP", "FP", "precision", "recall", "f1"]) + "\n")
         for label, stats in rows:

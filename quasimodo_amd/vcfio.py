@@ -33,6 +33,8 @@ class ScannedVcf:
     n_refused: int
     first_refused_line: int
     n_nokey_kept: int      # kept lines without a comparable key (POS not a canonical decimal)
+    n_r_hostile: int = 0   # kept lines holding '#', ' or ": R's read.table does not read them as tab-split text (include/qmvt.h)
+    first_r_hostile_line: int = 0
 
     @property
     def n_records(self):
@@ -120,7 +122,8 @@ def scan_vcf(text: bytes, alleles: "AlleleDict | None" = None) -> ScannedVcf:
     n, d = int(info.n_lines), int(info.n_data)
     # views, not copies: the spare tail of each buffer is a line or two
     return ScannedVcf(text, n, line_off[:n + 1], kind[:n], pos[:d], ref[:d], alt[:d], qual[:d], flags[:d],
-                      int(info.n_host), int(info.n_refused), int(info.first_refused_line), int(info.n_nokey_kept))
+                      int(info.n_host), int(info.n_refused), int(info.first_refused_line), int(info.n_nokey_kept),
+                      int(info.n_r_hostile), int(info.first_r_hostile_line))
 
 
 class Patterns:

@@ -12,7 +12,7 @@ import shutil
 
 from .engine import Engine
 from .extract import Job, extract_many, is_pure_strain
-from .tables import write_caller_performance, write_fp_overlap, write_snpcall_benchmark, write_weighted_roc
+from .tables import r_hostile_rows, write_caller_performance, write_fp_overlap, write_snpcall_benchmark, write_weighted_roc
 from .vcfio import scan_vcf
 
 SAMPLE_REF = {  # rules/load_config.smk:20-23
@@ -101,6 +101,18 @@ def _fp_keys(path):
         sv = scan_vcf(fh.read())
     keep = (sv.ref < 4) & (sv.alt < 4) & ((sv.flags & 4) == 0)
     return sv.pos[keep], sv.ref[keep], sv.alt[keep]
+
+
+def _flag_truth_rows(jobs):
+    """stats["truth_r_hostile"]: rows of the job's truth file that R's read.table would not read as tab-split text
+    (tables.check_r_readable); pure-strain samples never read theirs."""
+    seen = {}
+    for j in jobs:
+        if j.stats is None or j.stats.get("pure_strain"):
+            continue
+        if j.snp_file not in seen:
+            seen[j.snp_file] = r_hostile_rows(j.snp_file)
+        j.stats["truth_r_hostile"] = seen[j.snp_file]
 
 
 def fp_overlap_tables(engine, fp_files_by_sample, callers):
@@ -193,6 +205,7 @@ def run_hcmv_variantcall(data_dir, outpath, callers=None, engine=None, dryrun=Fa
                                          post="quasimodo_amd.workflow:hcmv_rank_post",
                                          post_args=dict(meta=meta, cmp_callers=cmp_callers, snp_dir=snp_dir))
         os.makedirs(tables, exist_ok=True)
+        _flag_truth_rows(jobs)
         write_caller_performance(os.path.join(tables, "caller_performance.tsv"), [(c, s, j.stats) for (c, s), j in zip(meta, jobs)])
         _write_snp_rocs(meta, jobs, snp_dir)
         if mixed and len(cmp_callers) >= 2:
@@ -211,6 +224,7 @@ def run_hcmv_variantcall(data_dir, outpath, callers=None, engine=None, dryrun=Fa
     try:
         extract_many(jobs, engine=engine)                                # extractTP, one batch
         os.makedirs(os.path.join(results, "final_tables"), exist_ok=True)
+        _flag_truth_rows(jobs)
         write_caller_performance(os.path.join(results, "final_tables", "caller_performance.tsv"),
                                  [(c, s, j.stats) for (c, s), j in zip(meta, jobs)])
         _write_snp_rocs(meta, jobs, snp_dir)
@@ -301,6 +315,7 @@ def run_vareval(vcfs, snps_file, outpath, labels=None, engine=None, dryrun=False
     else:
         extract_many(jobs, engine=engine)
     os.makedirs(os.path.join(results, "final_tables"), exist_ok=True)
+    _flag_truth_rows(jobs)
     write_snpcall_benchmark(os.path.join(results, "final_tables", "snpcall_benchmark.txt"),
                             [(lab, j.stats) for lab, j in zip(labels, jobs)])
     return jobs

@@ -52,6 +52,48 @@ def test_weighted_roc_layout(qmlib, tmp_path):
     assert rows[-1][:5] == ["0", "4", "9", "5", "4"] and len(rows) == 31
 
 
+def test_lines_r_read_table_would_not_split_at_tabs_are_counted_and_refused(qmlib, tmp_path, monkeypatch):
+    """A6 / A6c are restated from the R text (unpinned: no R here).  R reads <x>.filtered.vcf and the truth file with
+    read.table(sep = "\\t", comment.char = "#") and the default quote = "\\"'" (scripts/caller_performance_compare.R:29-39):
+    a '#' inside a data line cuts it, a quote swallows tabs and newlines -- a file R cannot parse then counts as EMPTY (tryCatch,
+    :37-40,101-108).  Hand-derived fixture: the tokenizer counts the KEPT lines holding '#', ' or " (headers and lines the A2
+    filter drops do not matter to R: comment / not in the file), the strict table writers refuse the file, QM_LENIENT=1 writes
+    the tab-split counts."""
+    from quasimodo_amd.tables import RTableError, check_r_readable, r_hostile_rows, write_caller_performance, write_snpcall_benchmark
+    from quasimodo_amd.vcfio import scan_vcf
+    text = (b'##INFO=<ID=DP,Number=1,Type=Integer,Description="Raw depth">\n'      # header: a comment to R, quotes and all
+            b"#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n"
+            b"c\t100\t.\tA\tG\t50\tPASS\tDP=9\n"                             # plain kept line
+            b'c\t200\t.\tA\tG\t50\tPASS\tDP=9;NOTE="x"\n'                    # kept, balanced quotes in the last column: R drops the quotes only
+            b"c\t300\trs#7\tC\tT\t60\tPASS\tDP=1\n"                          # kept, '#' in column 3: R sees 3 fields -> the whole file fails
+            b"c\t400\t.\tC\tT\t70\tit's\tDP=1\n"                             # kept, a lone apostrophe: swallows what follows
+            b"c\t500\t.\tC\tT\t7\tq'#\"\tDP=1\n"                            # QUAL 7: not kept -> not in the filtered file
+            b"c\t600\t.\tCA\tT\t90\t'\tDP=1\n")                              # not single-base: not kept
+    sv = scan_vcf(text)
+    assert int((sv.flags & 1).sum()) == 4 and sv.n_r_hostile == 3 and sv.first_r_hostile_line == 4
+    assert scan_vcf(b"c\t1\t.\tA\tG\t50\tPASS\tDP=9 %&$! x\n").n_r_hostile == 0   # the coarse vector test (bytes 0x20..0x27) is not the answer
+    long = b"c\t1\t.\tA\tG\t50\tPASS\t" + b"D" * 70 + b"'\n"                      # beyond the first 32-byte step of the line index
+    assert scan_vcf(long * 3).n_r_hostile == 3
+    truth = tmp_path / "t.vcf"
+    truth.write_bytes(b"##x=\"y\"\nc\t100\t.\tA\tG\t30\tPASS\tDP=30;ORIG=a'b\nc\t200\t.\tA\tG\t30\tPASS\tDP=30\n")
+    assert r_hostile_rows(str(truth)) == 1
+    ok = {"n_pass": 6, "TP_R": 2, "FP_R": 2, "genomediff": 4, "pure_strain": False, "r_hostile": 0}
+    bad = dict(ok, r_hostile=3)
+    badt = dict(ok, truth_r_hostile=1)
+    monkeypatch.delenv("QM_LENIENT", raising=False)
+    assert check_r_readable([("a", ok)]) == []
+    for st in (bad, badt):
+        with pytest.raises(RTableError, match="read.table"):
+            write_caller_performance(str(tmp_path / "cp.tsv"), [("lofreq", "TA-1-10", ok), ("varscan", "TA-1-10", st)])
+        with pytest.raises(RTableError):
+            write_snpcall_benchmark(str(tmp_path / "sb.txt"), [("lab", st)])
+    assert not (tmp_path / "cp.tsv").exists() and not (tmp_path / "sb.txt").exists()      # refused before anything is written
+    monkeypatch.setenv("QM_LENIENT", "1")
+    write_caller_performance(str(tmp_path / "cp.tsv"), [("lofreq", "TA-1-10", bad)])
+    assert (tmp_path / "cp.tsv").read_text().splitlines()[1] == "LoFreq\tTA-1-10\t4\t6\t2\t2\t0.333\t0.5\t0.4"
+    assert check_r_readable([("x", bad)]) == [("x", 3, 0)]
+
+
 def test_lpt_shards(qmlib):
     from quasimodo_amd.sharding import lpt_shards
     n = [10, 1, 1, 1, 9, 8, 2, 2]
