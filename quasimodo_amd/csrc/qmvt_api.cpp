@@ -737,6 +737,8 @@ static CompactParams compact_params(qm_batch* b) {
   C.vcfs = b->d_vcfs; C.spans = b->d_spans; C.mask_pass = b->mask_pass; C.mask_tp = b->mask_tp;
   C.tile_fp = b->tile_fp; C.tile_tp_off = b->tile_tp_off; C.tile_fp_off = b->tile_fp_off; C.idx = b->idx;
   C.vcf_flags = b->vcf_flags; C.skip_unsorted = 1; C.span_base = 0;
+  C.nwin = 8;
+  if (const char* e = getenv("QM_K3_WINDOWS")) { const int w = atoi(e); if (w == 1 || w == 2 || w == 4 || w == 8) C.nwin = w; }   // (experiments)
   return C;
 }
 

@@ -633,8 +633,8 @@ __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, con
   // natural-order mask words: 8 lanes x 4 records = one 32-bit word; parked in LDS, the tile stores them at once
   if (!(ablate & 4)) {
     const uint32_t sh = 4u * (uint32_t)(lane & 7);
-    const uint32_t wp = or_reduce8(pass << sh);
-    const uint32_t wt = or_reduce8(tp << sh);
+    const uint32_t wp = (ablate & 16) ? pass << sh : or_reduce8(pass << sh);   // (16: the DPP reductions priced alone)
+    const uint32_t wt = (ablate & 16) ? tp << sh : or_reduce8(tp << sh);
     if ((lane & 7) == 7) {
       lds[L_MASK + mslot + (lane >> 3)] = wp;
       lds[L_MASK + 32 * mask_tiles<EXT>() + mslot + (lane >> 3)] = wt;
@@ -873,8 +873,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           uint32_t* dst = (half ? mtp32 : mpass32) + (b0 >> 5);
+          if (ablate & 64) dst = reinterpret_cast<uint32_t*>(half ? P.mask_tp : P.mask_pass) + ((int)(blockIdx.x & 1023) << 10);   // (64: the same stores into 4 MB that stay in L2 -- is it the HBM traffic or the store itself?)
           const int src = L_MASK + half * 32 * MT;
           for (int w = 4 * lane; w < 32 * MT; w += 256) {
+            if (ablate & 32) { asm volatile("" :: "v"(lds[src + w])); continue; }   // (32: the masks' global stores priced alone)
             if (w + 3 < nd) *reinterpret_cast<uint4*>(dst + w) = *reinterpret_cast<const uint4*>(&lds[src + w]);
             else for (int k = 0; k < 4; ++k) if (w + k < nd) dst[w + k] = lds[src + w + k];
           }
@@ -1228,19 +1230,14 @@ __device__ __forceinline__ void k3_drain(K3List& X, int lane) {
   X.n &= 255u;
 }
 
-__device__ __forceinline__ int k3_block() {
-#if defined(K3_NO_XCD_MAP)
-  return (int)blockIdx.x;
-#elif defined(K3_XCD_RUN)
-  // runs of K3_XCD_RUN consecutive workgroups per XCD, the eight XCDs side by side in one window of 8 runs
-  const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
-  const int g0 = (j / K3_XCD_RUN) * (8 * K3_XCD_RUN);   // a window is permuted inside itself; the grid's ragged last window keeps its launch order
-  return g0 + 8 * K3_XCD_RUN <= (int)gridDim.x ? g0 + xcd * K3_XCD_RUN + (j % K3_XCD_RUN) : (int)blockIdx.x;
-#else
-  const int nblk = (int)gridDim.x, xcd = (int)blockIdx.x & 7, jx = (int)blockIdx.x >> 3;
-  const int per = nblk >> 3, rem = nblk & 7;
-  return xcd * per + (xcd < rem ? xcd : rem) + jx;
-#endif
+// Workgroups go round-robin to the 8 XCDs (blockIdx & 7).  nwin = 8: every XCD owns a contiguous eighth of the grid (the lines
+// two neighbouring waves share meet in ONE L2, and every XCD writes one compact window); 4 / 2: two / four XCDs share a window,
+// interleaved inside it; 1: launch order.  A permutation of the grid for any size (the last grid % 8 blocks keep their place).
+__device__ __forceinline__ int k3_block(int nwin) {
+  const int b = (int)blockIdx.x, gm = (int)gridDim.x & ~7;
+  if (nwin <= 1 || b >= gm) return b;
+  const int xcd = b & 7, j = b >> 3, share = 8 / nwin;   // XCDs per window
+  return (xcd % nwin) * (gm / nwin) + j * share + xcd / nwin;
 }
 
 __global__ __launch_bounds__(64 * K3_WAVES) void k_compact(CompactParams P) {
@@ -1250,7 +1247,7 @@ __global__ __launch_bounds__(64 * K3_WAVES) void k_compact(CompactParams P) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int BPS = SPAN_TILES / (K3_WAVES * K3_TILES);   // workgroups per span
   constexpr int NLUT = (256 + 64 * K3_WAVES - 1) / (64 * K3_WAVES);
-  const int L = k3_block();
+  const int L = k3_block(P.nwin);
   const SpanDesc sp = P.spans[L / BPS + P.span_base];
   // everything the wave needs is asked for at once, behind the span descriptor: the table, the VCF's flags, the two offsets of
   // its first tile, the mask bytes of all its passes

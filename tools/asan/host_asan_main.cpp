@@ -21,6 +21,19 @@ static std::vector<uint8_t> slurp(const char* p) {
 
 static long g_calls = 0;
 
+// internal to the library (qmvt_pipeline.cpp calls it): the writer from the device's class masks
+int qm_host_write_masks(const char* path, const uint8_t* text, size_t len, int64_t n_lines, const int64_t* line_off,
+                        const uint8_t* line_kind, const uint64_t* kept, const uint64_t* tp, const uint8_t* flags, int select);
+static std::vector<uint8_t> slurp(const std::string& p) {
+  std::vector<uint8_t> v;
+  FILE* f = fopen(p.c_str(), "rb");
+  if (!f) return v;
+  uint8_t b[65536]; size_t n;
+  while ((n = fread(b, 1, sizeof b, f)) > 0) v.insert(v.end(), b, b + n);
+  fclose(f);
+  return v;
+}
+
 static void exercise(const std::vector<uint8_t>& t, qm_dict* dict, const char* outdir) {
   // exact-size heap copy: any read past the end trips the sanitizer
   uint8_t* text = (uint8_t*)malloc(t.size() ? t.size() : 1);
@@ -39,6 +52,29 @@ static void exercise(const std::vector<uint8_t>& t, qm_dict* dict, const char* o
     for (int sel = 0; sel < 3; ++sel) {
       const std::string o = std::string(outdir) + "/w.vcf";
       qm_vcf_write(o.c_str(), text, len, info.n_lines, off.data(), kind.data(), cls.data(), sel);
+    }
+    {
+      // the writer from class MASKS (64 lines at a time where every '#' line precedes the data) against the line-by-line writer
+      // from class BYTES, on a pseudo-random classification of this file's records: the same bytes, all three files
+      std::vector<uint8_t> c2((size_t)cap, 0);
+      std::vector<uint64_t> kept((size_t)(info.n_data + 63) / 64 + 1, 0), tpm(kept.size(), 0);
+      uint64_t x = 0x9e3779b97f4a7c15ull + (uint64_t)len;
+      for (int64_t r = 0; r < info.n_data; ++r) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        const unsigned m = (unsigned)(x >> 33) % 100;
+        const uint8_t c = m < 10 ? 0 : m < 25 ? 3 : m < 30 ? 2 : 1;   // (2: the TP bit without the kept bit selects nothing)
+        c2[(size_t)r] = c;
+        if (c & 1) kept[(size_t)(r >> 6)] |= 1ull << (r & 63);
+        if (c & 2) tpm[(size_t)(r >> 6)] |= 1ull << (r & 63);
+      }
+      if (len % 3 == 0) for (int64_t r = 0; r < info.n_data; ++r) { c2[(size_t)r] = 3; kept[(size_t)(r >> 6)] |= 1ull << (r & 63); tpm[(size_t)(r >> 6)] |= 1ull << (r & 63); }   // long runs too
+      for (int sel = 0; sel < 3; ++sel) {
+        const std::string a = std::string(outdir) + "/wa.vcf", b = std::string(outdir) + "/wb.vcf";
+        const int ra = qm_vcf_write(a.c_str(), text, len, info.n_lines, off.data(), kind.data(), c2.data(), sel);
+        const int rb = qm_host_write_masks(b.c_str(), text, len, info.n_lines, off.data(), kind.data(), kept.data(), tpm.data(), flags.data(), sel);
+        if (ra != rb || (ra == QM_OK && slurp(a) != slurp(b))) { fprintf(stderr, "writer mismatch: masks vs bytes, select %d, %zu bytes of text\n", sel, len); exit(1); }
+        g_calls += 2;
+      }
     }
     int64_t counts[5];
     std::vector<int32_t> tpos((size_t)cap), tref((size_t)cap), talt((size_t)cap);
