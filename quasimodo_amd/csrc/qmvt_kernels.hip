@@ -350,8 +350,9 @@ constexpr int L_TCNT = L_FLUT + 16;                     // [2][SPAN_TILES] TP / 
 #define QM_MASK_TILES 8
 #endif
 #ifndef QM_MASK_TILES_X
-#define QM_MASK_TILES_X 2
-#endif
+#define QM_MASK_TILES_X 4   // round 4: 4 tiles (8.4 KB of LDS, 19 waves per CU instead of 20) against 2: k_classify<false, true> 3.54 -> 3.51 ms per 1 000 VCFs
+#endif                      // (same-box medians of 4 processes each); 8 tiles (9.4 KB, 17 waves): 3.72
+
 // The kept / TP mask words wait in LDS for MASK_TILES tiles and leave as ONE 16-byte-per-lane store per mask (1 KiB
 // contiguous for 8 tiles): a 256-byte store per tile in the middle of the read stream cost 8 % of the kernel.
 template <bool EXT> __device__ __forceinline__ constexpr int mask_tiles() { return EXT ? QM_MASK_TILES_X : QM_MASK_TILES; }
