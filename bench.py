@@ -282,6 +282,7 @@ def main():
                      "step_frac": alg_bytes / step_s / 1e9 / HBM_PEAK_GBS},
         "kernels_ms": tm,
         "per_rank": per_rank,     # N > 1: min / max / all over the ranks of ms_per_step and of each rank's own kernel time
+        "compact_form": batch.compact_form(),   # which form of k_compact this batch settled on during the warm-up and what each took
         "device_bytes": batch.device_bytes,
     }
 

@@ -72,12 +72,26 @@ struct qm_ctx {
   int64_t path_total[QM_N_PATH_STATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // qm_path_stats_total: every finish of every batch of this context
 };
 
+// QM_ALLOC_CONTIG=<MB>: arrays of at least that many MB are asked for as physically contiguous memory (hipDeviceMallocContiguous;
+// plain hipMalloc when the driver cannot give it).  An experiment knob (k_compact's two modes follow WHERE the index
+// lists landed in physical memory); 0 / unset = plain hipMalloc.
+static size_t alloc_contig_bytes() {
+  static const size_t v = [] { const char* e = getenv("QM_ALLOC_CONTIG"); return e && atoll(e) > 0 ? (size_t)atoll(e) << 20 : (size_t)0; }();
+  return v;
+}
 template <typename T>
 static int dalloc(T** p, size_t count) {
   *p = nullptr;
   if (count == 0) count = 1;
-  hipError_t e = hipMalloc((void**)p, count * sizeof(T));
-  if (e != hipSuccess) return fail(QM_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+  const size_t bytes = count * sizeof(T);
+  if (alloc_contig_bytes() && bytes >= alloc_contig_bytes()) {
+    if (hipExtMallocWithFlags((void**)p, bytes, hipDeviceMallocContiguous) == hipSuccess) return QM_OK;
+    (void)hipGetLastError();
+    *p = nullptr;
+    if (getenv("QM_DEBUG_PTRS")) fprintf(stderr, "qmvt: no contiguous %zu MB, plain hipMalloc\n", bytes >> 20);
+  }
+  hipError_t e = hipMalloc((void**)p, bytes);
+  if (e != hipSuccess) return fail(QM_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
   return QM_OK;
 }
 #define DALLOC(p, n)                 \
@@ -374,7 +388,7 @@ struct qm_batch {
   // outputs / workspace
   uint64_t *mask_pass = nullptr, *mask_tp = nullptr;
   int32_t* idx = nullptr;
-  uint32_t *tile_tp = nullptr, *tile_fp = nullptr, *tile_tp_off = nullptr, *tile_fp_off = nullptr;
+  uint32_t *tile_tp = nullptr, *tile_fp = nullptr, *tile_tp_off = nullptr, *tile_fp_off = nullptr, *vcf_tot = nullptr;
   uint32_t *span_hist = nullptr, *span_scal = nullptr, *vcf_flags = nullptr, *vcf_posor = nullptr;
   // bucket path of the unsorted VCFs: one "span" row per (segment, bucket), fake VCF descriptors for k_finalize
   uint32_t *bk_hist = nullptr, *bk_scal = nullptr;
@@ -438,6 +452,16 @@ struct qm_batch {
   struct Chunk { int v0, v1, s0, s1; };
   std::vector<Chunk> chunks;
   hipEvent_t ev_sync[MAX_CHUNKS + 2] = {};   // ordering between the two streams (no timing)
+  // k_compact's two forms, tried on this batch's first runs and the faster kept: which one wins depends on where the
+  // batch's index lists landed in physical memory, which nobody chooses.  Run 0 is left out (the first touch of a batch's memory
+  // is slower than every later one), runs 1..4 alternate the forms, the smaller of a form's two times counts.
+  // k3_state: 0 = trying (k3_run: the next run's number), 2 = decided (k3_form), 3 = not tuned (small batch, QM_K3_TUNE=0 or an
+  // explicit QM_K3_OWN / QM_K3_WINDOWS)
+  static constexpr int K3_TRIES = 5;
+  int k3_state = 3, k3_form = 0, k3_run = 0;
+  bool k3_pending = false;                   // the last run recorded k3_ev around its compaction
+  hipEvent_t k3_ev[2] = {};
+  float k3_ms[2] = {0.f, 0.f};
   // timing
   bool timing = false;
   static constexpr int EV_RING = 32;   // per-kernel events of the latest runs
@@ -489,13 +513,14 @@ static void batch_free(qm_batch* b) {
   (void)hipSetDevice(b->ctx->dev);
   if (b->sub) { batch_free(b->sub); b->sub = nullptr; }
   void* ptrs[] = {b->pkey, b->pinf, b->pos, b->ref, b->alt, b->qual, b->flags, b->mask_pass, b->mask_tp, b->idx, b->tile_tp, b->tile_fp,
-                  b->tile_tp_off, b->tile_fp_off, b->span_hist, b->span_scal, b->vcf_flags, b->vcf_posor, b->bk_hist, b->bk_scal, b->d_bk_vcfs, b->bk_ent, b->bk_cursor, b->d_bk_tile_seg, b->bk_rows, b->bk_xent, b->bk_xcursor, b->bk_xrows, b->bk_roc, b->bk_rscal, b->bk_vflags, b->p_segs, b->p_tile_seg, b->p_cnt, b->p_off, b->p_cursor, b->p_flags, b->p_ent, b->d_vsegs, b->d_vparts, b->rs_roc, b->rs_scal, b->rs_flags, b->roc, b->global_acc,
+                  b->tile_tp_off, b->tile_fp_off, b->vcf_tot, b->span_hist, b->span_scal, b->vcf_flags, b->vcf_posor, b->bk_hist, b->bk_scal, b->d_bk_vcfs, b->bk_ent, b->bk_cursor, b->d_bk_tile_seg, b->bk_rows, b->bk_xent, b->bk_xcursor, b->bk_xrows, b->bk_roc, b->bk_rscal, b->bk_vflags, b->p_segs, b->p_tile_seg, b->p_cnt, b->p_off, b->p_cursor, b->p_flags, b->p_ent, b->d_vsegs, b->d_vparts, b->rs_roc, b->rs_scal, b->rs_flags, b->roc, b->global_acc,
                   b->scalars, b->d_vcfs, b->d_spans, b->d_tile_vcf, b->cls_scratch, b->sk[0], b->sk[1], b->sv[0],
                   b->sv[1], b->si[0], b->si[1], b->shist, b->sorbits, b->d_segs, b->d_tile_seg, b->d_ktile_seg, b->d_ktile_local, b->d_known};
   for (void* p : ptrs) (void)hipFree(p);
   if (b->h_summary) (void)hipHostFree(b->h_summary);
   for (auto& r : b->ev) for (auto& e : r) if (e) (void)hipEventDestroy(e);
   for (auto& e : b->ev_sync) if (e) (void)hipEventDestroy(e);
+  for (auto& e : b->k3_ev) if (e) (void)hipEventDestroy(e);
   delete b;
 }
 
@@ -532,7 +557,7 @@ static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int
   }
   else { A_(b->pos, np) A_(b->ref, np) A_(b->alt, np) A_(b->qual, np) A_(b->flags, np) }
   A_(b->mask_pass, np / 64 + 64) A_(b->mask_tp, np / 64 + 64) A_(b->idx, np)
-  A_(b->tile_tp, b->cap_tiles) A_(b->tile_fp, b->cap_tiles) A_(b->tile_tp_off, b->cap_tiles) A_(b->tile_fp_off, b->cap_tiles)
+  A_(b->tile_tp, b->cap_tiles) A_(b->tile_fp, b->cap_tiles) A_(b->tile_tp_off, b->cap_tiles + SPAN_TILES) A_(b->tile_fp_off, b->cap_tiles + SPAN_TILES) A_(b->vcf_tot, (size_t)n_vcf * 2)
   A_(b->span_hist, b->cap_spans * SPAN_HIST_WORDS) A_(b->span_scal, b->cap_spans * 8) A_(b->vcf_flags, (size_t)n_vcf) A_(b->vcf_posor, (size_t)n_vcf)
   A_(b->roc, (size_t)n_vcf * 3 * (size_t)n_bins) A_(b->global_acc, nt * 3 * (size_t)n_bins) A_(b->scalars, (size_t)n_vcf * 8)
   A_(b->d_vcfs, (size_t)n_vcf) A_(b->d_spans, b->cap_spans) A_(b->d_tile_vcf, b->cap_tiles) A_(b->cls_scratch, (size_t)L.max_n)
@@ -562,6 +587,11 @@ static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int
     b->chunks.back().v1 = n_vcf; b->chunks.back().s1 = ns;
     for (auto& e : b->ev_sync) {
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rc = fail(QM_E_HIP, "hipEventCreate failed"); break; }
+    }
+    const char* tune = getenv("QM_K3_TUNE");
+    if (rc == QM_OK && ns >= 4096 && !(tune && !strcmp(tune, "0")) && !getenv("QM_K3_OWN") && !getenv("QM_K3_WINDOWS") && b->chunks.size() == 1) {
+      if (hipEventCreate(&b->k3_ev[0]) == hipSuccess && hipEventCreate(&b->k3_ev[1]) == hipSuccess) b->k3_state = 0;
+      else (void)hipGetLastError();
     }
   }
   if (rc == QM_OK && !packed) {
@@ -724,7 +754,7 @@ static ClassifyParams classify_params(qm_batch* b) {
 static FinalizeParams finalize_params(qm_batch* b, uint64_t* global) {
   FinalizeParams F;
   F.vcfs = b->d_vcfs; F.truths = b->ctx->d_truths; F.span_hist = b->span_hist; F.span_scal = b->span_scal;
-  F.tile_tp = b->tile_tp; F.tile_fp = b->tile_fp; F.tile_tp_off = b->tile_tp_off; F.tile_fp_off = b->tile_fp_off;
+  F.tile_tp = b->tile_tp; F.tile_fp = b->tile_fp; F.tile_tp_off = b->tile_tp_off; F.tile_fp_off = b->tile_fp_off; F.vcf_tot = b->vcf_tot;
   F.roc = b->roc; F.scalars = b->scalars; F.vcf_flags = b->vcf_flags; F.vcf_posor = b->vcf_posor; F.global_acc = global; F.n_bins = b->n_bins; F.ext = b->ext ? 1 : 0;
   F.vcf_base = 0;
   F.flag_summary = nullptr;
@@ -732,13 +762,17 @@ static FinalizeParams finalize_params(qm_batch* b, uint64_t* global) {
   F.known = nullptr;
   return F;
 }
+// the two forms of k_compact: 0 = a wave stores its own entries, every XCD a contiguous eighth of the tiles; 1 = whole 1 KiB chunks
+// (completed from the tiles behind a wave's own), tiles in launch order
+static void k3_set_form(CompactParams& C, int form) { C.own_chunks = form ? 1 : 0; C.nwin = form ? 1 : 8; }
 static CompactParams compact_params(qm_batch* b) {
   CompactParams C;
   C.vcfs = b->d_vcfs; C.spans = b->d_spans; C.mask_pass = b->mask_pass; C.mask_tp = b->mask_tp;
-  C.tile_fp = b->tile_fp; C.tile_tp_off = b->tile_tp_off; C.tile_fp_off = b->tile_fp_off; C.idx = b->idx;
+  C.tile_fp = b->tile_fp; C.tile_tp_off = b->tile_tp_off; C.tile_fp_off = b->tile_fp_off; C.vcf_tot = b->vcf_tot; C.idx = b->idx;
   C.vcf_flags = b->vcf_flags; C.skip_unsorted = 1; C.span_base = 0;
-  C.nwin = 8;
+  k3_set_form(C, b->k3_state == 0 ? ((b->k3_run & 1) ^ 1) : b->k3_state == 2 ? b->k3_form : 1);   // trying: chunks, entries, chunks, entries, chunks; untuned batches: the form that does not depend on luck
   if (const char* e = getenv("QM_K3_WINDOWS")) { const int w = atoi(e); if (w == 1 || w == 2 || w == 4 || w == 8) C.nwin = w; }   // (experiments)
+  if (const char* e = getenv("QM_K3_OWN")) C.own_chunks = !strcmp(e, "chunks") ? 1 : 0;
   return C;
 }
 
@@ -833,7 +867,10 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
       HIPCHK(hipStreamWaitEvent(aux, b->ev_sync[k], 0));
     }
     if (T) HIPCHK(hipEventRecord(e5[3], aux));
+    const bool k3_try = nch == 1 && b->k3_state == 0 && b->k3_ev[0] != nullptr;
+    if (k3_try) HIPCHK(hipEventRecord(b->k3_ev[0], aux));
     launch_compact(K, ck.s1 - ck.s0, aux);
+    if (k3_try) { HIPCHK(hipEventRecord(b->k3_ev[1], aux)); b->k3_pending = true; }
     if (T) HIPCHK(hipEventRecord(e5[4], aux));
   }
   if (all_known) {
@@ -946,6 +983,7 @@ static FinalizeParams bucket_rows_finalize(qm_batch* b) {
   FinalizeParams F = finalize_params(b, nullptr);   // the rows join the per-truth sums only once no bucket is known to have overflowed
   F.vcfs = b->d_bk_vcfs; F.span_hist = b->bk_hist; F.span_scal = b->bk_scal; F.vcf_posor = nullptr;
   F.roc = b->bk_roc; F.scalars = b->bk_rscal; F.vcf_flags = b->bk_vflags;
+  F.vcf_tot = nullptr;   // (these "VCFs" are rows of buckets: no tiles, no lists -- and not the main batch's numbering)
   return F;
 }
 
@@ -1668,6 +1706,18 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
     for (int v : todo) if (!b->known[(size_t)v]) { b->known[(size_t)v] = 1; b->known_posor[(size_t)v] = posor[(size_t)v]; ++b->n_known; b->known_dirty = true; }
   }
   for (int k = 0; k < QM_N_PATH_STATS; ++k) c->path_total[k] += b->path_stats[k];
+  if (b->k3_pending && b->k3_state == 0) {   // the stream is idle: the run's compaction has its time
+    b->k3_pending = false;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, b->k3_ev[0], b->k3_ev[1]) == hipSuccess) {
+      const int form = (b->k3_run & 1) ^ 1;
+      if (b->k3_run > 0) b->k3_ms[form] = b->k3_ms[form] > 0.f && b->k3_ms[form] < ms ? b->k3_ms[form] : ms;
+      if (++b->k3_run == qm_batch::K3_TRIES) { b->k3_form = b->k3_ms[1] < b->k3_ms[0] ? 1 : 0; b->k3_state = 2; }
+    } else {
+      (void)hipGetLastError();
+      b->k3_state = 3;
+    }
+  }
   b->finished = true;
   return QM_OK;
 }
@@ -1774,6 +1824,13 @@ int qm_device_zero(qm_ctx* c, void* dst, size_t bytes) {
 extern "C" int qm_path_stats_total(qm_ctx* c, int64_t* out) {
   if (!c || !out) return fail(QM_E_INVAL, "qm_path_stats_total: NULL");
   memcpy(out, c->path_total, sizeof c->path_total);
+  return QM_OK;
+}
+
+extern "C" int qm_batch_compact_form(qm_batch* b, int32_t* state, float* ms2) {
+  if (!b || !state) return fail(QM_E_INVAL, "qm_batch_compact_form: NULL");
+  state[0] = b->k3_state == 0 ? ((b->k3_run & 1) ^ 1) : b->k3_state; state[1] = b->k3_state == 2 ? b->k3_form : b->k3_state == 0 ? ((b->k3_run & 1) ^ 1) : 1;
+  if (ms2) { ms2[0] = b->k3_ms[0]; ms2[1] = b->k3_ms[1]; }
   return QM_OK;
 }
 

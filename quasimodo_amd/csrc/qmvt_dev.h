@@ -128,6 +128,7 @@ struct FinalizeParams {
   const uint32_t* tile_fp;
   uint32_t* tile_tp_off;
   uint32_t* tile_fp_off;
+  uint32_t* vcf_tot;  // [n_vcf][2]: TP lines, FP lines of the VCF (where k_compact's lists end)
   uint64_t* roc;      // [n_vcf][3][n_bins]
   int64_t* scalars;   // [n_vcf][8]
   uint32_t* vcf_flags;
@@ -149,10 +150,12 @@ struct CompactParams {
   const uint32_t* tile_fp;
   const uint32_t* tile_tp_off;
   const uint32_t* tile_fp_off;
+  const uint32_t* vcf_tot;     // [n_vcf][2] (k_finalize)
   int32_t* idx;
   const uint32_t* vcf_flags;   // written by k_finalize of the same run
   int32_t skip_unsorted;       // 1: leave VCFs flagged unsorted alone (they are redone); 0: compact everything
   int32_t span_base;           // first span of this launch
+  int32_t own_chunks;          // 0: a wave stores its own entries (shared chunks leave in two pieces); 1: whole chunks, completed from the tiles behind (k3_own)
   int32_t nwin;                // block -> tile mapping: 8 = every XCD owns a contiguous eighth of the launch, 4 / 2 = XCDs share windows, 1 = launch order
 };
 

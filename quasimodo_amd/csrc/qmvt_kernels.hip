@@ -1036,7 +1036,9 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
     fsum = wave_sum(fsum);
     if (lane == 0) s_scan[8 + wave] = fsum;
     __syncthreads();
-    uint32_t carry_t = 0, carry_f = (uint32_t)vd.n - (s_scan[8] + s_scan[9] + s_scan[10] + s_scan[11]);
+    const uint32_t fp_total = s_scan[8] + s_scan[9] + s_scan[10] + s_scan[11];
+    uint32_t carry_t = 0, carry_f = (uint32_t)vd.n - fp_total;
+    if (tid == 0 && P.vcf_tot) P.vcf_tot[2 * v + 1] = fp_total;
     for (int base = 0; base < vd.ntiles; base += 1024) {
       const int t0 = base + tid * 4;
       uint32_t xt[4], xf[4];
@@ -1071,6 +1073,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
       carry_t += bt; carry_f += bf;
       __syncthreads();
     }
+    if (tid == 0 && P.vcf_tot) P.vcf_tot[2 * v] = carry_t;   // TP lines of the VCF (k_compact: where the TP list ends)
   }
 }
 
@@ -1121,6 +1124,19 @@ static_assert(SPAN_TILES % (K3_WAVES * K3_TILES) == 0, "a workgroup's tiles lie 
 constexpr int K3_PASS = 512;                    // records per pass: 8 per lane
 static_assert(K1_TILE == 2 * K3_PASS, "a tile is two passes");
 constexpr int K3_NPASS = 2 * K3_TILES;
+// A wave stores whole chunks of a list; the chunk that BEGINS among its entries is completed from the tiles behind its own.
+// FP list (dense): 256 entries = the 1 KiB of one store instruction.  TP list (a few per cent of the records): 64 entries = two
+// 128-byte lines, so that completing a chunk does not take a wave through six more passes.
+#ifndef K3_FCH_LOG
+#define K3_FCH_LOG 8
+#endif
+#ifndef K3_TCH_LOG
+#define K3_TCH_LOG 6
+#endif
+static_assert(K3_FCH_LOG >= 4 && K3_FCH_LOG <= 8 && K3_TCH_LOG >= 4 && K3_TCH_LOG <= 8, "a chunk is whole 64-byte pieces, at most one store instruction");
+#ifndef K3_EXTRA
+#define K3_EXTRA 2                              // passes behind the wave's own whose mask bytes are loaded up front (see k_compact)
+#endif
 constexpr int K3_BUF = 256 + K3_PASS + 16;      // entries per list: the carried partial chunk, one pass, the slack the unconditional stores run into
 
 // mask byte -> positions of its set bits, ascending, one per byte (64 bits per entry)
@@ -1185,9 +1201,9 @@ __device__ __forceinline__ uint32_t k3_scan(uint32_t c, uint32_t& tot) {
 struct K3List {
   k3_ldsp buf;              // LDS, K3_BUF entries; buf[i] is entry g0 + i of the VCF's region
   int32_t* out;             // the VCF's index region
-  uint32_t first;           // first entry this wave owns
+  uint32_t lo, hi;          // the wave STORES the entries [lo, hi) of the list: whole 1 KiB chunks, except where the list itself begins or ends
   uint32_t g0;              // entry of buf[0]: a multiple of 256
-  uint32_t n;               // entries in buf (those below `first` in the wave's first chunk belong to the wave before: never stored)
+  uint32_t n;               // entries in buf (the first wave-offset & 255 of them are not there: below lo, never stored)
 };
 __device__ __forceinline__ void k3_store4(int32_t* p, k3_v4i w) {
 #ifdef K3_ABL_NOSTORE
@@ -1201,7 +1217,8 @@ __device__ __forceinline__ void k3_store4(int32_t* p, k3_v4i w) {
 #endif
 }
 // entries [lo, hi) of the chunk that starts at buf index c0 (a multiple of 256; entry g0 + c0): whole quads with one
-// 16-byte store per lane, the <= 3 + 3 entries around them with one masked dword store
+// 16-byte store per lane, the <= 3 + 3 entries around them with one masked dword store.  Only where a LIST begins or ends
+// (twice per VCF and list): every other chunk leaves whole.
 __device__ __forceinline__ void k3_store_part(const K3List& X, uint32_t c0, uint32_t lo, uint32_t hi, int lane) {
   const uint32_t b = X.g0 + c0;                     // entry of the chunk's first slot
   const uint32_t q = b + 4u * (uint32_t)lane;       // the lane's quad
@@ -1216,19 +1233,41 @@ __device__ __forceinline__ void k3_store_part(const K3List& X, uint32_t c0, uint
 #endif
   }
 }
-// complete 256-entry chunks leave; the partial chunk behind them moves to the front (everything here is wave-uniform)
+// Complete chunks of 2^CL entries leave -- those the wave owns --, the partial chunk behind them moves to the front (all
+// wave-uniform).  What leaves is a run of whole chunks, i.e. of whole 64-byte pieces of HBM: 256-entry windows of it with one
+// 16-byte store per lane; only where the LIST begins or ends inside (twice per VCF) does a window carry ragged ends.
+template <int CL>
 __device__ __forceinline__ void k3_drain(K3List& X, int lane) {
-  const uint32_t nfull = X.n >> 8;
+  const uint32_t nfull = X.n >> CL;
   if (!nfull) return;
-  for (uint32_t c = 0; c < nfull; ++c) {
-    const uint32_t gc = X.g0 + 256u * c;
-    if (gc < X.first) k3_store_part(X, 256u * c, X.first, gc + 256u, lane);   // the wave's first chunk starts in its predecessor's entries
-    else k3_store4(X.out + gc + 4u * lane, *reinterpret_cast<k3_lds4p>(X.buf + (256u * c + 4u * lane)));
+  const uint32_t top = X.g0 + (nfull << CL);                                   // entries [g0, top) are complete chunks
+  const uint32_t s0 = X.lo > X.g0 ? X.lo : X.g0, e0 = X.hi < top ? X.hi : top;   // ... of which the wave stores [s0, e0)
+  for (uint32_t w = X.g0; w < e0; w += 256u) {
+    if (w + 256u <= s0) continue;
+    if (s0 <= w && w + 256u <= e0) k3_store4(X.out + w + 4u * lane, *reinterpret_cast<k3_lds4p>(X.buf + ((w - X.g0) + 4u * lane)));
+    else k3_store_part(X, w - X.g0, s0 > w ? s0 : w, e0 < w + 256u ? e0 : w + 256u, lane);
   }
-  const k3_v4i v = *reinterpret_cast<k3_lds4p>(X.buf + (256u * nfull + 4u * lane));
-  *reinterpret_cast<k3_lds4p>(X.buf + 4u * lane) = v;
-  X.g0 += 256u * nfull;
-  X.n &= 255u;
+  const uint32_t left = X.n - (nfull << CL);                                    // < 2^CL <= 256
+  if (4u * (uint32_t)lane < left) {
+    const k3_v4i v = *reinterpret_cast<k3_lds4p>(X.buf + ((nfull << CL) + 4u * lane));
+    *reinterpret_cast<k3_lds4p>(X.buf + 4u * lane) = v;
+  }
+  X.g0 = top;
+  X.n = left;
+}
+// [lo, hi) of a wave whose own tiles hold the entries [a, a2) of a list that spans [l0, l1).
+// chunks = false (the default): its own entries, [a, a2) -- the 1 KiB chunk two neighbouring waves share leaves in two pieces.
+// chunks = true: the chunks that BEGIN among its entries, whole (the first wave of a VCF, first = true, also takes the list's
+// ragged head): the wave completes its last chunk from the tiles behind its own.  No partial store is left but at the lists'
+// ends -- on physically contiguous batches that alone is worth 1.07 -> 0.78 ms -- for one or two more passes per wave.
+template <int CL>
+__device__ __forceinline__ void k3_own(K3List& X, uint32_t a, uint32_t a2, uint32_t l0, uint32_t l1, bool first, bool chunks) {
+  constexpr uint32_t M = (1u << CL) - 1u;
+  const uint32_t up = (a + M) & ~M, up2 = (a2 + M) & ~M;
+  X.lo = !chunks ? a : first ? l0 : (up < l1 ? up : l1);
+  X.hi = !chunks ? a2 : (up2 < l1 ? up2 : l1);
+  X.g0 = a & ~M;
+  X.n = a - X.g0;
 }
 
 // Workgroups go round-robin to the 8 XCDs (blockIdx & 7).  nwin = 8: every XCD owns a contiguous eighth of the grid (the lines
@@ -1248,10 +1287,11 @@ __global__ __launch_bounds__(64 * K3_WAVES) void k_compact(CompactParams P) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int BPS = SPAN_TILES / (K3_WAVES * K3_TILES);   // workgroups per span
   constexpr int NLUT = (256 + 64 * K3_WAVES - 1) / (64 * K3_WAVES);
+  constexpr int NPRE = K3_NPASS + K3_EXTRA;                 // passes whose mask bytes are asked for at the start
   const int L = k3_block(P.nwin);
   const SpanDesc sp = P.spans[L / BPS + P.span_base];
-  // everything the wave needs is asked for at once, behind the span descriptor: the table, the VCF's flags, the two offsets of
-  // its first tile, the mask bytes of all its passes
+  // everything the wave needs is asked for at once, behind the span descriptor: the table, the VCF's flags and list sizes, the
+  // offsets of its first tile and of its successor's, the mask bytes of its passes and of the first few behind them
   uint2 lut[NLUT];
 #pragma unroll
   for (int k = 0; k < NLUT; ++k) {
@@ -1262,17 +1302,18 @@ __global__ __launch_bounds__(64 * K3_WAVES) void k_compact(CompactParams P) {
   const int rb = (int)(sp.begin - sp.voff) + tl * K1_TILE;     // its first record inside the VCF (a multiple of K1_TILE)
   const bool live = (int64_t)sp.voff + rb < sp.end;
   const int t = live ? sp.tile0 + tl : sp.tile0;
+  const bool has_next = live && rb + K3_TILES * K1_TILE < sp.vn;   // another wave of the same VCF follows
   const uint32_t vflags = P.vcf_flags[sp.vcf];
+  const uint32_t tp_total = P.vcf_tot[2 * sp.vcf], fp_total = P.vcf_tot[2 * sp.vcf + 1];
   const uint32_t aT = P.tile_tp_off[t], aF = P.tile_fp_off[t];
-  // mask bytes of the wave's tiles: whole 64-bit words of the VCF (bits beyond its last record are clear), nothing beyond the
-  // span (the next span's bytes belong to another wave)
-  const int re = (int)(sp.end - sp.voff);                      // the span's end inside the VCF
-  const int nb = live ? ((((re < rb + K3_TILES * K1_TILE ? re : rb + K3_TILES * K1_TILE) - rb) + 63) >> 6) * 8 : 0;
+  const uint32_t aT2 = has_next ? P.tile_tp_off[t + K3_TILES] : tp_total, aF2 = has_next ? P.tile_fp_off[t + K3_TILES] : (uint32_t)sp.vn;
+  // mask bytes from the wave's first record to the end of the VCF: whole 64-bit words (bits beyond the last record are clear)
+  const int nb = live ? (((sp.vn - rb) + 63) >> 6) * 8 : 0;
   const uint8_t* mp = reinterpret_cast<const uint8_t*>(P.mask_pass) + ((sp.voff + rb) >> 3);
   const uint8_t* mt = reinterpret_cast<const uint8_t*>(P.mask_tp) + ((sp.voff + rb) >> 3);
-  uint32_t mk[K3_NPASS], mq[K3_NPASS];
+  uint32_t mk[NPRE], mq[NPRE];
 #pragma unroll
-  for (int u = 0; u < K3_NPASS; ++u) {
+  for (int u = 0; u < NPRE; ++u) {
     const int b = u * 64 + lane;
     mk[u] = b < nb ? mp[b] : 0u;
     mq[u] = b < nb ? mt[b] : 0u;
@@ -1282,45 +1323,68 @@ __global__ __launch_bounds__(64 * K3_WAVES) void k_compact(CompactParams P) {
     const int i = tid + k * 64 * K3_WAVES;
     if (i < 256) *reinterpret_cast<uint2*>(&s_lut[2 * i]) = lut[k];
   }
-  asm volatile("" :: "s"(aT), "s"(aF), "s"(vflags));   // here, not behind the barrier where the compiler would sink these loads to
+  asm volatile("" :: "s"(aT), "s"(aF), "s"(aT2), "s"(aF2), "s"(vflags), "s"(tp_total), "s"(fp_total));   // here, not behind the barrier where the compiler would sink these loads to
   __syncthreads();
   // VCFs found out of order by this run are redone by the sort path: their masks and counts are not meaningful yet
   if (!live || (P.skip_unsorted && (vflags & SPANF_UNSORTED))) return;
-  const int npass = (nb + 63) >> 6;
   K3List T, F;
   T.buf = (k3_ldsp)s_buf[wave][0]; F.buf = (k3_ldsp)s_buf[wave][1];
   T.out = F.out = P.idx + sp.voff;
-  T.first = aT; F.first = aF;
-  T.g0 = T.first & ~255u; T.n = T.first - T.g0;
-  F.g0 = F.first & ~255u; F.n = F.first - F.g0;
-#pragma unroll
-  for (int u = 0; u < K3_NPASS; ++u) {
-    if (u >= npass) break;
-    const uint32_t wt = mq[u], wf = mk[u] & ~mq[u];
-    // one prefix sum for both lists: FP count in the low half, TP count in the high half (a pass holds 512 records)
+  k3_own<K3_TCH_LOG>(T, aT, aT2, 0u, tp_total, rb == 0, P.own_chunks != 0);
+  k3_own<K3_FCH_LOG>(F, aF, aF2, (uint32_t)sp.vn - fp_total, (uint32_t)sp.vn, rb == 0, P.own_chunks != 0);
+  if (T.lo >= T.hi && F.lo >= F.hi) return;                    // no chunk of either list begins among this wave's entries
+  const int npass_vcf = (nb + 63) >> 6;                        // passes from here to the end of the VCF
+  const int npass_own = npass_vcf < K3_NPASS ? npass_vcf : K3_NPASS;
+  // One pass: a prefix sum for both lists (FP count in the low half, TP count in the high half: a pass holds 512 records), the
+  // entries of the lists that still want them, complete chunks out
+  auto pass = [&](uint32_t kb, uint32_t tb, int p, bool wantF, bool wantT) {
+    const uint32_t wt = tb, wf = kb & ~tb;
     const uint32_t c = (uint32_t)__popc(wf) | ((uint32_t)__popc(wt) << 16);
     uint32_t tot;
     const uint32_t ex = k3_scan(c, tot) - c;
-    const uint32_t base = (uint32_t)(rb + u * K3_PASS + 8 * lane);
+    const uint32_t base = (uint32_t)(rb + p * K3_PASS + 8 * lane);
 #ifndef K3_ABL_NOEMIT
-    if (tot & 0xffffu) k3_emit(F.buf, s_lut, F.n + (ex & 0xffffu), wf, base);
-    if (tot >> 16) k3_emit(T.buf, s_lut, T.n + (ex >> 16), wt, base);
+    if (wantF && (tot & 0xffffu)) k3_emit(F.buf, s_lut, F.n + (ex & 0xffffu), wf, base);
+    if (wantT && (tot >> 16)) k3_emit(T.buf, s_lut, T.n + (ex >> 16), wt, base);
 #endif
-    F.n += tot & 0xffffu;
-    T.n += tot >> 16;
     asm volatile("" ::: "memory");
-    k3_drain(F, lane);
-    k3_drain(T, lane);
+    if (wantF) { F.n += tot & 0xffffu; k3_drain<K3_FCH_LOG>(F, lane); }
+    if (wantT) { T.n += tot >> 16; k3_drain<K3_TCH_LOG>(T, lane); }
     asm volatile("" ::: "memory");
+  };
+#pragma unroll
+  for (int u = 0; u < K3_NPASS; ++u) {
+    if (u >= npass_own) break;
+    pass(mk[u], mq[u], u, true, true);
   }
-  // what is left: less than a chunk per list
+  // The wave's last chunk of a list is completed from the tiles BEHIND its own (the successor leaves the entries in front of its
+  // first chunk boundary alone): passes go on, for the list that still misses entries, until its chunk is whole or the VCF ends.
+  // Dense lists want one more pass at most; a list of a few entries per pass a few more -- the first K3_EXTRA are already here.
+  int p = npass_own;
+  bool wantF = F.g0 + F.n < F.hi, wantT = T.g0 + T.n < T.hi;
+#pragma unroll
+  for (int u = K3_NPASS; u < NPRE; ++u) {
+    if (p == u && u < npass_vcf && (wantF || wantT)) {
+      pass(mk[u], mq[u], u, wantF, wantT);
+      wantF = wantF && F.g0 + F.n < F.hi; wantT = wantT && T.g0 + T.n < T.hi;
+      ++p;
+    }
+  }
+  while (p < npass_vcf && (wantF || wantT)) {      // a list sparse enough to need still more: its bytes one pass at a time
+    const int b = p * 64 + lane;
+    const uint32_t kb = b < nb ? mp[b] : 0u, tb = b < nb ? mt[b] : 0u;
+    pass(kb, tb, p, wantF, wantT);
+    wantF = wantF && F.g0 + F.n < F.hi; wantT = wantT && T.g0 + T.n < T.hi;
+    ++p;
+  }
+  // what is left below hi: only where the list ends (its last, ragged chunk)
   {
-    const uint32_t lo = F.first > F.g0 ? F.first : F.g0;
-    if (F.g0 + F.n > lo) k3_store_part(F, 0u, lo, F.g0 + F.n, lane);
+    const uint32_t l = F.lo > F.g0 ? F.lo : F.g0, h = F.hi < F.g0 + F.n ? F.hi : F.g0 + F.n;
+    if (h > l) k3_store_part(F, 0u, l, h, lane);
   }
   {
-    const uint32_t lo = T.first > T.g0 ? T.first : T.g0;
-    if (T.g0 + T.n > lo) k3_store_part(T, 0u, lo, T.g0 + T.n, lane);
+    const uint32_t l = T.lo > T.g0 ? T.lo : T.g0, h = T.hi < T.g0 + T.n ? T.hi : T.g0 + T.n;
+    if (h > l) k3_store_part(T, 0u, l, h, lane);
   }
 }
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # every profile of a round in one GPU call: bash tools/final_profiles.sh <tag>   (outputs under gpurun_out/, copied to profiles/ by hand)
-TAG=${1:-r03f}
+TAG=${1:-r04f}
 ROOT=$PWD
 export TMPDIR=/tmp
 bash tools/prof_trace.sh $TAG --steps 5 --warmup 2 > gpurun_out/${TAG}_trace.log 2>&1
@@ -20,5 +20,8 @@ mkdir -p gpurun_out/trace_${TAG}shufx4
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/trace_${TAG}shufx4 -- python3 $ROOT/tools/shuffled_ext.py 64 2000000 10000000 200000 > $ROOT/gpurun_out/${TAG}_trace_shufx4.log 2>&1)
 python3 tools/shuffled_ext.py 64 2000000 10000000 200000 >> gpurun_out/${TAG}_shuffled_ext.log 2>&1
 python3 tools/e2e_files_bench.py 16 > gpurun_out/${TAG}_e2e.log 2>&1
+# round 4: what bounds k_compact (PMC of the new kernel; its block -> tile mapping against where a batch landed in memory)
+bash tools/pmc_compact.sh $TAG > gpurun_out/${TAG}_pmc_compact.log 2>&1
+REPS=6 python3 tools/compact_map_probe.py > gpurun_out/${TAG}_compact_map_probe.log 2>&1
 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 tail -c 600 gpurun_out/${TAG}_bench.json

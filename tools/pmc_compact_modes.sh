@@ -8,7 +8,7 @@ TAG=${1:-x}; ROUNDS=${2:-6}; shift; shift
 CNT=${@:-FETCH_SIZE}
 OUT=$ROOT/gpurun_out/pmc_modes_$TAG; mkdir -p $OUT
 for r in $(seq 1 $ROUNDS); do
-  (cd /tmp && rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $OUT/r$r -- python3 $ROOT/tools/run_once.py 1000 3 > $OUT/log$r.txt 2>&1) || true
+  (cd /tmp && timeout -k 10 150 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $OUT/r$r -- python3 $ROOT/tools/run_once.py 1000 3 > $OUT/log$r.txt 2>&1) || echo "round $r failed (see $OUT/log$r.txt)"
 done
 python3 - $OUT <<'PY'
 import csv, glob, collections, sys, os

@@ -18,14 +18,16 @@ __global__ void kr(const v4u* src, int64_t per_wave16, unsigned* sink) {
   for (int64_t j = threadIdx.x; j < per_wave16; j += 64) a ^= __builtin_nontemporal_load(base + j);
   if ((a.x ^ a.y ^ a.z ^ a.w) == 0x12345678u) *sink = 1;
 }
-int main() {
+int main(int argc, char**) {
   const int64_t bytes = 4ll << 30;
   hipEvent_t a, e; (void)hipEventCreate(&a); (void)hipEventCreate(&e);
   unsigned* sink; (void)hipMalloc(&sink, 4);
   std::vector<void*> junk;
   for (int rep = 0; rep < 10; ++rep) {
     v4u* d = nullptr;
-    if (hipMalloc(&d, bytes) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    const bool contig = argc > 1 && rep % 2 == 1;   // any argument: every other allocation physically contiguous (hipDeviceMallocContiguous)
+    if ((contig ? hipExtMallocWithFlags((void**)&d, bytes, hipDeviceMallocContiguous) : hipMalloc(&d, bytes)) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    printf("%s ", contig ? "contiguous" : "plain     ");
     (void)hipMemset(d, 1, bytes);
     float best_w = 1e9f, best_r = 1e9f, worst_w = 0.f;
     for (int pw : {4096}) {

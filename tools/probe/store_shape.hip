@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 struct Cfg {
   int64_t per_wave;   // bytes of the main stream per wave (multiple of 1 KiB)
@@ -41,6 +42,22 @@ __global__ void k(v4u* dst, v4u* dst2, Cfg c, int nblocks) {
     x.y += 1;
   }
 }
+// k_compact's traffic in the small: every wave first READS `rd` bytes per lane-group from a separate buffer (its mask bytes: 64 B per
+// wave-instruction, at its own place), then writes its piece, 1 KiB per instruction -- do a few reads among the writes change the rate?
+template <int FL>
+__global__ void krw(v4u* dst, const unsigned char* src, int64_t piece, int nrd, int idle) {
+  const int lane = threadIdx.x & 63;
+  const int64_t b = blockIdx.x;
+  unsigned acc = 0;
+  for (int r = 0; r < nrd; ++r) acc += src[(b * nrd + r) * 64 + lane];          // nrd x 64 B, contiguous per wave
+  v4u x = {(unsigned)b, acc, 2, (unsigned)lane};
+  v4u* base = dst + b * (piece / 16);
+  for (int64_t j = 0; j < piece / 1024; ++j) {
+    st<FL>(base + j * 64 + lane, x);
+    for (int s2 = 0; s2 < idle; ++s2) __builtin_amdgcn_s_sleep(1);
+    x.y += 1;
+  }
+}
 // persistent, strided: the grid fills the chip once; wave g writes pieces g, g + G, g + 2G, ... of `piece` bytes each (G = all
 // waves of the grid), so that what the chip writes at any one time is ONE window of G pieces that moves through the buffer
 template <int FL>
@@ -60,7 +77,10 @@ __global__ void kp(v4u* dst, int64_t piece, int64_t npieces, int idle, int xmap)
 int main() {
   const int64_t bytes = 4ll << 30;
   v4u *d, *d2;
-  hipMalloc(&d, bytes); hipMalloc(&d2, bytes / 4);
+  if (getenv("STORE_CONTIG")) {   // physically contiguous memory (hipDeviceMallocContiguous): linear physical addresses
+    if (hipExtMallocWithFlags((void**)&d, bytes, hipDeviceMallocContiguous) != hipSuccess || hipExtMallocWithFlags((void**)&d2, bytes / 4, hipDeviceMallocContiguous) != hipSuccess) { printf("no contiguous memory\n"); return 1; }
+    printf("physically contiguous buffers\n");
+  } else { hipMalloc(&d, bytes); hipMalloc(&d2, bytes / 4); }
   hipMemset(d, 1, bytes); hipMemset(d2, 1, bytes / 4);
   hipEvent_t a, e; hipEventCreate(&a); hipEventCreate(&e);
   auto run = [&](const char* name, Cfg c) {
@@ -117,6 +137,27 @@ int main() {
            best, (double)bytes / best / 1e6);
     fflush(stdout);
   };
+  {
+    unsigned char* src; hipMalloc(&src, 1ll << 30); hipMemset(src, 1, 1ll << 30);
+    auto runrw = [&](const char* name, int64_t piece, int nrd, int idle, int fl) {
+      const int nblocks = (int)(bytes / piece);
+      float best = 1e9f;
+      for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(a);
+        if (fl == 0) hipLaunchKernelGGL(krw<0>, dim3(nblocks), dim3(64), 0, 0, d, src, piece, nrd, idle);
+        else hipLaunchKernelGGL(krw<1>, dim3(nblocks), dim3(64), 0, 0, d, src, piece, nrd, idle);
+        hipEventRecord(e); hipEventSynchronize(e);
+        float ms; hipEventElapsedTime(&ms, a, e);
+        if (rep && ms < best) best = ms;
+      }
+      printf("%-28s piece=%6lld reads=%2d x 64 B idle=%3d fl=%d : %.3f ms %7.1f GB/s written (+ %.0f MB read)\n", name, (long long)piece, nrd, idle, fl, best,
+             (double)bytes / best / 1e6, (double)nblocks * nrd * 64 / 1e6);
+      fflush(stdout);
+    };
+    for (int nrd : {0, 1, 4, 16}) runrw("read then write", 16384, nrd, 0, 0);
+    for (int nrd : {0, 4, 16}) runrw("read then write, idle 8", 16384, nrd, 8, 0);
+    for (int nrd : {0, 2, 8}) runrw("read then write 4K", 4096, nrd, 0, 0);
+  }
   for (int fl = 0; fl < 2; ++fl)
     for (int xmap = 0; xmap < 2; ++xmap) {
       runp("persistent 8 WG/CU x 4 waves", 2048, 256, 4096, 0, fl, xmap);
