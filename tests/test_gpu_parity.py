@@ -891,3 +891,72 @@ def test_positions_above_what_the_optimistic_pass_saw(engine, oracle):
         check_vcf(oracle, res, cols, truth, expect_sorted=False)
         assert b.path_stats()["radix_after_overflow"] == 1
     b.close()
+
+
+@pytest.mark.parametrize("form", ["entries", "chunks"])
+@pytest.mark.parametrize("windows", ["8", "1"])
+def test_both_forms_of_the_compaction_on_lists_of_every_density(engine, oracle, monkeypatch, form, windows):
+    """k_compact stores a list either entry range by entry range (a wave its own entries) or chunk by chunk (a wave the 1 KiB
+    chunks that begin among its entries, completed from the tiles BEHIND its own -- however far it has to go for them), with the
+    tiles dealt to the XCDs in eighths or in launch order.  The lists are the same: dense and sparse, empty, one
+    entry, everything TP, a handful of kept records at the far ends of a long VCF, ragged sizes."""
+    monkeypatch.setenv("QM_K3_OWN", form)
+    monkeypatch.setenv("QM_K3_WINDOWS", windows)
+    rng = np.random.default_rng(77)
+    L = 400000
+    truth = random_truth(rng, 30000, L)
+    tid = engine.truth_load(*truth)
+    cols = [random_columns(rng, n, L, truth, sorted_=True) for n in (0, 1, 255, 256, 257, 1023, 1025, 4095, 4097, 20000, 70001)]
+
+    def plain(n, keep, hit):   # n sorted records on distinct positions; keep / hit: boolean arrays (kept by the filter; carries a truth key)
+        pos = (np.arange(n, dtype=np.int64) * 3 + 5).astype(np.int32)
+        ref = np.zeros(n, np.int32)
+        alt = np.where(hit, 1, 2).astype(np.int32)
+        qual = np.where(keep, 50, 3).astype(np.float32)
+        return pos, ref, alt, qual, (2 | keep).astype(np.uint8)
+
+    n = 90000
+    tpos = (np.arange(n, dtype=np.int64) * 3 + 5).astype(np.int32)
+    truth2 = (tpos, np.zeros(n, np.int32), np.ones(n, np.int32))          # every position with ALT = C: a record hits iff its ALT is C
+    tid2 = engine.truth_load(*truth2)
+    e = np.zeros(n, bool)
+    far = e.copy(); far[[3, n - 2]] = True
+    few = e.copy(); few[rng.choice(n, 40, replace=False)] = True
+    shapes = [plain(n, ~e, ~e),            # everything kept, everything TP: the FP list is empty
+              plain(n, ~e, e),             # everything kept, nothing TP
+              plain(n, e, e),              # nothing kept: both lists empty
+              plain(n, far, far),          # two TP lines, at the two ends of the VCF: the wave that owns their chunk walks to the end
+              plain(n, ~e, few),           # a dense FP list, forty TP lines somewhere
+              plain(n, few, e),            # forty FP lines, nothing else
+              plain(n, rng.random(n) < 0.5, rng.random(n) < 0.5)]
+    res, _ = engine.classify_batch(cols + shapes, [tid] * len(cols) + [tid2] * len(shapes))
+    for r, c in zip(res, cols):
+        check_vcf(oracle, r, c, truth)
+    for r, c in zip(res[len(cols):], shapes):
+        check_vcf(oracle, r, c, truth2, expect_sorted=True)
+
+
+def test_a_batch_settles_on_a_form_of_the_compaction(engine, oracle):
+    """A batch that fills the chip alternates k_compact's two forms over its first five runs (the first is not counted) and keeps
+    the faster (qm_batch_compact_form); whatever it tries or keeps, the lists are those of the oracle."""
+    b = engine.batch([1_000_000] * 80, [engine.truth_synth(5_000_000, 100_000, 3)] * 80)      # 80 x 62 spans >= 4 096
+    b.synth(5_000_000, 100_000, 3, 3000)
+    seen = []
+    for run in range(6):
+        seen.append(b.compact_form())
+        b.run()
+        b.finish()
+    st = b.compact_form()
+    assert [s["state"] for s in seen[:5]] == ["trying chunks", "trying entries", "trying chunks", "trying entries", "trying chunks"]
+    assert seen[5]["state"] == "decided" and st["state"] == "decided" and st["entries_ms"] > 0 and st["chunks_ms"] > 0
+    assert st["form"] == ("chunks" if st["chunks_ms"] < st["entries_ms"] else "entries")
+    from oracle.synth import synth_truth_keys
+    from quasimodo_amd.engine import SCALAR_NAMES
+    tk = synth_truth_keys(5_000_000, 100_000, 3)
+    for v in (0, 79):
+        cols = b.columns(v)
+        sc = dict(zip(SCALAR_NAMES, b.scalars()[v].tolist()))
+        reg = b.idx(v)
+        res = {"cls": b.cls(v), "roc": b.roc()[v], "scalars": sc, "tp_idx": reg[:sc["tp_lines"]].copy(), "fp_idx": reg[1_000_000 - sc["fp_lines"]:].copy()}
+        check_vcf(oracle, res, cols, tk, expect_sorted=True)
+    b.close()
