@@ -22,6 +22,6 @@ python3 tools/shuffled_ext.py 64 2000000 10000000 200000 >> gpurun_out/${TAG}_sh
 python3 tools/e2e_files_bench.py 16 > gpurun_out/${TAG}_e2e.log 2>&1
 # round 4: what bounds k_compact (PMC of the new kernel; its block -> tile mapping against where a batch landed in memory)
 bash tools/pmc_compact.sh $TAG > gpurun_out/${TAG}_pmc_compact.log 2>&1
-REPS=6 python3 tools/compact_map_probe.py > gpurun_out/${TAG}_compact_map_probe.log 2>&1
+(echo "== plain hipMalloc"; REPS=6 python3 tools/compact_map_probe.py; echo "== physically contiguous batches (QM_ALLOC_CONTIG=64)"; QM_ALLOC_CONTIG=64 REPS=2 python3 tools/compact_map_probe.py) > gpurun_out/${TAG}_compact_map_probe.log 2>&1
 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 tail -c 600 gpurun_out/${TAG}_bench.json
