@@ -1974,7 +1974,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   for (int idx = tid; idx < total; idx += 512) {
     const uint32_t d = s_d[idx];
     const int32_t w = s_glob[d] + idx;
+#ifdef BK_ABL_NOSTORE   // (timing builds: the entries' stores switched off -- what do the 8 bytes per record cost inside 17 bytes of reads?)
+    if (w < sg.bk_cap) asm volatile("" :: "v"(s_e[idx]));
+#elif defined(BK_ABL_L2STORE)   // (the same stores, same shape, wrapped into 2 MB that stay in L2: the instructions without the HBM traffic)
+    if (w < sg.bk_cap) out[(((size_t)d * HB_SUBS + sub) * (size_t)sg.bk_cap + (size_t)w) & 0x3ffffu] = s_e[idx];
+#else
     if (w < sg.bk_cap) out[((size_t)d * HB_SUBS + sub) * (size_t)sg.bk_cap + (size_t)w] = s_e[idx];   // beyond: the VCF is flagged and redone
+#endif
   }
   BKS_TICK(9);
 #if defined(HB_PROFILE) && defined(BKS_PROFILE)

@@ -40,6 +40,40 @@ def test_the_library_says_which_sources_it_was_built_from(qmlib, tmp_path):
     assert _lib.embedded_ids(str(other)) == (None, None) and _lib.embedded_ids(str(tmp_path / "missing.so")) == (None, None)
 
 
+def test_caller_allocated_structs_have_the_headers_size_everywhere(qmlib):
+    """qm_vcf_cols / qm_file_stats / qm_file_job / qm_bench_result are allocated by the CALLER and filled by the library: a binding
+    that declares fewer fields than the header lets the library write past its allocation (round 4: the stub of INTEGRATION.md was
+    two fields short of a grown qm_vcf_cols for a few hours -- a heap corruption that showed as a crash at interpreter exit).
+    The header's field counts against the package's ctypes structures and against the stub in INTEGRATION.md."""
+    from quasimodo_amd import _lib
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "qmvt.h")).read(), flags=re.S)
+
+    def c_size(name):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, re.S).group(1)
+        size = 0
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            m = re.match(r"(const char\*|int64_t|uint64_t|int32_t|uint32_t|int|double|float)\s+(.*)$", decl, re.S)
+            assert m, decl
+            width = {"const char*": 8, "int64_t": 8, "uint64_t": 8, "double": 8, "int32_t": 4, "uint32_t": 4, "int": 4, "float": 4}[m.group(1)]
+            for var in m.group(2).split(","):
+                arr = re.search(r"\[(\w+)\]", var)
+                n = 1 if not arr else (int(arr.group(1)) if arr.group(1).isdigit() else {"QM_N_SCALARS": 8}[arr.group(1)])
+                size += width * n
+        return size
+
+    assert C.sizeof(_lib.VcfCols) == c_size("qm_vcf_cols") == 64
+    assert C.sizeof(_lib.FileStats) == c_size("qm_file_stats") == 120
+    assert C.sizeof(_lib.SynthCfg) == c_size("qm_synth_cfg")
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = md[md.index("## The binding itself"):]
+    fields = re.search(r"class Info\(C\.Structure\): _fields_ = \[\(k, C\.c_int64\) for k in \((.*?)\)\]", stub, re.S).group(1)
+    assert 8 * len(re.findall(r'"\w+"', fields)) == c_size("qm_vcf_cols")
+    assert "qm_abi_version() == %d" % _lib.QM_ABI_VERSION in stub
+
+
 def test_no_cpu_fallback_without_device(qmlib):
     """On a box without a GPU qm_init must fail with QM_E_NODEVICE; on a GPU box it succeeds."""
     import torch
