@@ -413,6 +413,24 @@ int qm_bgzf_write(const char* path, const uint8_t* data, size_t len, int level);
  * for a data line without CHROM / POS; nothing is written then.  Atomic per file. */
 int qm_bgzf_write_tbi(const char* path, const uint8_t* data, size_t len, int level);
 
+/* ---- truth-set builder ------------------------------------------------------------------------------
+ * `mummer2vcf.py -s <table> [--input-header] [-n] [-t SNP|INDEL] [--output-header] -g <ref.fa>` of rules/genome_diff.smk:22-24
+ * (program/mummer2vcf.py:69-357): a MUMmer `show-snps -T` table and the reference FASTA in, the truth VCF out (SNVs of one
+ * position collapsed into a multi-allelic ALT, runs of insertions / deletions merged and anchored on the base in front of them,
+ * rows ordered by contig and position).  Restated from the reference's text -- Biopython is not in the build image, the
+ * reference cannot run there: parity unpinned, hand-derived cases only.  table / fasta: the files' bytes; reference_name: what
+ * `##reference=` shall say (the path given to -g); file_date: "YYYYMMDD" for `##fileDate=` or NULL for today; *out: the VCF,
+ * malloc'ed, to be released with qm_free.  QM_E_INVAL: a row with fewer than 12 columns or a P1 that is no integer, an indel on
+ * a contig the FASTA does not hold; QM_E_RANGE: an indel beyond its contig's end. */
+#define QM_M2V_NO_NS 1u          /* -n */
+#define QM_M2V_OUTPUT_HEADER 2u  /* --output-header */
+#define QM_M2V_INPUT_HEADER 4u   /* --input-header: the table's first four lines are its header */
+#define QM_M2V_ONLY_SNP 8u       /* -t SNP */
+#define QM_M2V_ONLY_INDEL 16u    /* -t INDEL */
+int qm_mummer2vcf(const uint8_t* table, size_t table_len, const uint8_t* fasta, size_t fasta_len, const char* reference_name,
+                  unsigned flags, const char* file_date, uint8_t** out, size_t* out_len);
+void qm_free(void* p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,7 @@ EXPORTS = (
     "qm_dict_create", "qm_dict_destroy", "qm_dict_size", "qm_allele_code", "qm_allele_spell", "qm_vcf_scan_ext", "qm_truth_scan_ext",
     "qm_bench_synth", "qm_truth_release", "qm_batch_n_truth",
     "qm_bw_probe", "qm_bgzf_write", "qm_bgzf_write_tbi", "qm_extract_files", "qm_extract_files_ex", "qm_batch_global_device", "qm_batch_path_stats", "qm_path_stats_total", "qm_batch_compact_form", "qm_batch_upload_async", "qm_batch_get_masks", "qm_patterns_create", "qm_patterns_destroy", "qm_patterns_info", "qm_vcf_hostpath",
+    "qm_mummer2vcf", "qm_free",
 )
 
 
@@ -197,6 +198,9 @@ def lib():
     L.qm_batch_global_device.argtypes = [vp, C.POINTER(vp)]
     L.qm_batch_path_stats.argtypes = [vp, vp]
     L.qm_path_stats_total.argtypes = [vp, vp]
+    L.qm_mummer2vcf.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_uint, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.qm_free.argtypes = [vp]
+    L.qm_free.restype = None
     L.qm_batch_compact_form.argtypes = [vp, vp, vp]
     L.qm_batch_upload_async.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
     L.qm_batch_get_masks.argtypes = [vp, i32, vp, vp]

@@ -15,8 +15,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <map>
 #include <mutex>
+#include <set>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -1333,3 +1335,227 @@ extern "C" int qm_vcf_split_write(const char* path, const uint8_t* text, size_t 
   if (n_written) *n_written = nw;
   return QM_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Truth-set builder: MUMmer `show-snps -CTHlr` table -> truth VCF, what rules/genome_diff.smk:22-24
+// runs as `mummer2vcf.py -s <table> --output-header -n -g <ref.fa>`.  Restated from the text of the reference's
+// program/mummer2vcf.py (Biopython is not in the build image, so the reference itself cannot run: PARITY UNPINNED, hand-derived
+// cases only; quasimodo_amd/mummer2vcf.py holds the same restatement in Python and the tests compare the two on random tables):
+//   * one VCF row per table row: CHROM = reference tag (column 11), POS = P1 (column 1), REF / ALT = the two SUB columns, QUAL 30,
+//     FILTER PASS, INFO DP=30;REF1=..;REF2=..                                                            (mummer2vcf.py:69-85)
+//   * -n: rows with an N / n in REF or ALT are dropped                                                   (:88-100)
+//   * single-base, dot-free REF and ALT -> SNV, anything else INDEL                                      (:103-118)
+//   * SNVs ordered by position (stable); a row at the position of the row before it folds its ALT into the kept row's comma
+//     list (no duplicates)                                                                               (:122-144, :242-252)
+//   * indels keep input order; a row continues the one before it when it is an insertion at the same position or a deletion at
+//     the next position: inserted bases are appended to every allele (another query position) or add an alternative allele whose
+//     last character is replaced (the same query position); deleted bases are appended to REF           (:147-185)
+//   * every indel row gets the reference base in front of it as anchor and its POS moves one to the left (:188-210)
+//   * rows ordered by POS as TEXT, then (stable) by (CHROM, POS as a number): SNVs in front of indels at equal keys; INFO gains
+//     ;ORIG=<query tag>:<P2>;TYPE=SNV|INDEL; eight columns                                               (:277-313)
+//   * --output-header: VCFv4.2 header with the contigs that carry variants, in FASTA order               (:320-357)
+// ---------------------------------------------------------------------------
+namespace {
+
+struct M2vRow {
+  std::string chrom, ref, alt, info, orig;
+  long long pos = 0;
+  bool snv = false;
+};
+
+// text -> lines the way Python's universal-newlines text mode hands them out (\n, \r\n and a lone \r end a line)
+void m2v_lines(const uint8_t* t, size_t n, std::vector<std::string>& out) {
+  size_t b = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (t[i] == '\n' || t[i] == '\r') {
+      out.emplace_back((const char*)t + b, i - b);
+      if (t[i] == '\r' && i + 1 < n && t[i + 1] == '\n') ++i;
+      b = i + 1;
+    }
+  }
+  if (b < n) out.emplace_back((const char*)t + b, n - b);
+}
+std::vector<std::string> m2v_split(const std::string& s, char sep) {
+  std::vector<std::string> v;
+  size_t b = 0;
+  for (;;) {
+    const size_t e = s.find(sep, b);
+    if (e == std::string::npos) { v.push_back(s.substr(b)); break; }
+    v.push_back(s.substr(b, e - b));
+    b = e + 1;
+  }
+  return v;
+}
+std::string m2v_join(const std::vector<std::string>& v, const char* sep) {
+  std::string o;
+  for (size_t i = 0; i < v.size(); ++i) { if (i) o += sep; o += v[i]; }
+  return o;
+}
+bool m2v_int(const std::string& s, long long* out) {   // a decimal integer with an optional sign, blanks around it allowed (Python's int())
+  size_t b = 0, e = s.size();
+  while (b < e && (s[b] == ' ' || s[b] == '\t')) ++b;
+  while (e > b && (s[e - 1] == ' ' || s[e - 1] == '\t')) --e;
+  if (b == e) return false;
+  bool neg = false;
+  if (s[b] == '+' || s[b] == '-') { neg = s[b] == '-'; ++b; }
+  if (b == e || e - b > 18) return false;
+  long long v = 0;
+  for (size_t i = b; i < e; ++i) { if (s[i] < '0' || s[i] > '9') return false; v = v * 10 + (s[i] - '0'); }
+  *out = neg ? -v : v;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int qm_mummer2vcf(const uint8_t* table, size_t table_len, const uint8_t* fasta, size_t fasta_len, const char* reference_name,
+                             unsigned flags, const char* file_date, uint8_t** out, size_t* out_len) {
+  if (!out || !out_len || (!table && table_len) || (!fasta && fasta_len) || (flags & ~31u) || ((flags & 8u) && (flags & 16u))) return QM_E_INVAL;
+  *out = nullptr; *out_len = 0;
+  const bool no_ns = flags & 1u, header = flags & 2u, in_header = flags & 4u, only_snp = flags & 8u, only_indel = flags & 16u;
+  // ---- the FASTA: first word of every '>' line -> its sequence, in file order (a name seen again keeps its place, takes the new sequence)
+  std::vector<std::pair<std::string, std::string>> seqs;
+  std::map<std::string, size_t> seq_of;
+  {
+    std::vector<std::string> L;
+    if (fasta_len) m2v_lines(fasta, fasta_len, L);
+    long cur = -1;
+    auto strip = [](const std::string& s) {
+      size_t b = 0, e = s.size();
+      auto ws = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\f' || c == '\v'; };
+      while (b < e && ws(s[b])) ++b;
+      while (e > b && ws(s[e - 1])) --e;
+      return s.substr(b, e - b);
+    };
+    for (const std::string& ln : L) {
+      if (!ln.empty() && ln[0] == '>') {
+        const std::string h = strip(ln.substr(1));
+        size_t e = 0;
+        while (e < h.size() && !(h[e] == ' ' || h[e] == '\t' || h[e] == '\f' || h[e] == '\v')) ++e;
+        const std::string name = h.substr(0, e);
+        auto it = seq_of.find(name);
+        if (it == seq_of.end()) { seq_of[name] = seqs.size(); cur = (long)seqs.size(); seqs.emplace_back(name, std::string()); }
+        else { cur = (long)it->second; seqs[(size_t)cur].second.clear(); }
+      } else if (cur >= 0) {
+        seqs[(size_t)cur].second += strip(ln);
+      }
+    }
+  }
+  // ---- the table
+  std::vector<M2vRow> snvs, indels;
+  {
+    std::vector<std::string> L;
+    if (table_len) m2v_lines(table, table_len, L);
+    for (size_t i = in_header ? 4 : 0; i < L.size(); ++i) {
+      std::string ln = L[i];
+      if (ln.empty()) continue;
+      while (!ln.empty() && (ln.back() == '\n' || ln.back() == '\r' || ln.back() == '\b')) ln.pop_back();
+      const std::vector<std::string> c = m2v_split(ln, '\t');
+      if (c.size() < 12) return QM_E_INVAL;
+      M2vRow r;
+      if (!m2v_int(c[0], &r.pos)) return QM_E_INVAL;
+      r.ref = c[1]; r.alt = c[2]; r.chrom = c[10];
+      if (no_ns && (r.ref.find_first_of("Nn") != std::string::npos || r.alt.find_first_of("Nn") != std::string::npos)) continue;
+      r.snv = r.ref.size() == 1 && r.ref != "." && r.alt.size() == 1 && r.alt != ".";
+      r.info = "DP=30;REF1=" + c[10] + ";REF2=" + c[11];
+      r.orig = c[11] + ":" + c[3];
+      (r.snv ? snvs : indels).push_back(std::move(r));
+    }
+  }
+  // ---- SNVs: by position (stable), rows at the position of the row before them folded into it
+  {
+    std::stable_sort(snvs.begin(), snvs.end(), [](const M2vRow& a, const M2vRow& b) { return a.pos < b.pos; });
+    std::vector<M2vRow> o;
+    long long prev = 0;
+    bool have = false;
+    for (M2vRow& r : snvs) {
+      if (have && !o.empty() && r.pos == prev) {
+        std::vector<std::string> alts = m2v_split(o.back().alt, ',');
+        if (std::find(alts.begin(), alts.end(), r.alt) == alts.end()) { alts.push_back(r.alt); o.back().alt = m2v_join(alts, ","); }
+      } else {
+        o.push_back(r);
+      }
+      prev = r.pos; have = true;
+    }
+    snvs.swap(o);
+  }
+  // ---- indels: runs merged in input order, then the anchor base
+  if (!indels.empty()) {
+    std::vector<M2vRow> o;
+    long long prev_pos = 0;
+    std::string prev_orig;
+    bool have = false;
+    for (M2vRow& r : indels) {
+      const bool cont = have && !o.empty() && ((r.pos == prev_pos && r.ref == ".") || (r.pos == prev_pos + 1 && r.alt == "."));
+      if (cont) {
+        M2vRow& last = o.back();
+        if (r.ref == ".") {
+          if (r.orig != prev_orig) {
+            std::vector<std::string> alts = m2v_split(last.alt, ',');
+            for (std::string& a : alts) a += r.alt;
+            last.alt = m2v_join(alts, ",");
+          } else {
+            last.alt = last.alt + "," + last.alt.substr(0, last.alt.size() - 1) + r.alt;
+          }
+        } else if (r.alt == ".") {
+          last.ref += r.ref;
+        }
+      } else {
+        o.push_back(r);
+      }
+      prev_pos = r.pos; prev_orig = r.orig; have = true;
+    }
+    for (M2vRow& r : o) {
+      auto it = seq_of.find(r.chrom);
+      if (it == seq_of.end()) return QM_E_INVAL;              // (the reference: KeyError)
+      const std::string& sq = seqs[it->second].second;
+      long long i = r.pos - 2;                                // the base in front of the variant; Python's index: -1 wraps to the last base
+      if (i < 0) i += (long long)sq.size();
+      if (i < 0 || i >= (long long)sq.size()) return QM_E_RANGE;
+      const std::string base(1, sq[(size_t)i]);
+      if (r.ref == ".") {
+        std::vector<std::string> alts = m2v_split(r.alt, ',');
+        for (std::string& a : alts) a = base + a;
+        r.ref = base; r.alt = m2v_join(alts, ",");
+      } else if (r.alt == ".") {
+        r.ref = base + r.ref; r.alt = base;
+      }
+      r.pos -= 1;
+    }
+    indels.swap(o);
+  }
+  // ---- order: POS as text, then (stable) (CHROM, POS); the type filter between the two as in the reference
+  std::vector<const M2vRow*> all;
+  for (const M2vRow& r : snvs) all.push_back(&r);
+  for (const M2vRow& r : indels) all.push_back(&r);
+  std::stable_sort(all.begin(), all.end(), [](const M2vRow* a, const M2vRow* b) { return std::to_string(a->pos) < std::to_string(b->pos); });
+  if (only_snp || only_indel) {
+    std::vector<const M2vRow*> f;
+    for (const M2vRow* r : all) if (r->snv == (bool)only_snp) f.push_back(r);
+    all.swap(f);
+  }
+  std::stable_sort(all.begin(), all.end(), [](const M2vRow* a, const M2vRow* b) { return a->chrom != b->chrom ? a->chrom < b->chrom : a->pos < b->pos; });
+  std::string o;
+  if (header) {
+    char date[16] = "";
+    if (file_date) snprintf(date, sizeof date, "%.8s", file_date);
+    else { const time_t now = time(nullptr); struct tm tmv; localtime_r(&now, &tmv); strftime(date, sizeof date, "%Y%m%d", &tmv); }
+    o += "##fileformat=VCFv4.2\n##fileDate=" + std::string(date) + "\n##source=mummer2vcf.py\n##reference=" + std::string(reference_name ? reference_name : "None") + "\n";
+    std::set<std::string> used;
+    for (const M2vRow* r : all) used.insert(r->chrom);
+    for (const auto& sq : seqs) if (used.count(sq.first)) o += "##contig=<ID=" + sq.first + ",length=" + std::to_string(sq.second.size()) + ">\n";
+    o += "##INFO=<ID=DP,Number=1,Type=Integer,Description=\"Total depth of quality bases\">\n"
+         "##INFO=<ID=REF1,Number=1,Type=String,Description=\"The name of the 1st reference sequence\">\n"
+         "##INFO=<ID=REF2,Number=1,Type=String,Description=\"The name of the 2nd reference sequence\">\n"
+         "##INFO=<ID=ORIG,Number=1,Type=String,Description=\"The original position of variant at 2nd reference sequence\">\n"
+         "##INFO=<ID=TYPE,Number=1,Type=String,Description=\"Indicates that the variant is an INDEL or SNV.\">\n"
+         "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n";
+  }
+  for (const M2vRow* r : all)
+    o += r->chrom + "\t" + std::to_string(r->pos) + "\t.\t" + r->ref + "\t" + r->alt + "\t30\tPASS\t" + r->info + ";ORIG=" + r->orig + ";TYPE=" + (r->snv ? "SNV" : "INDEL") + "\n";
+  uint8_t* buf = (uint8_t*)malloc(o.size() ? o.size() : 1);
+  if (!buf) return QM_E_NOMEM;
+  memcpy(buf, o.data(), o.size());
+  *out = buf; *out_len = o.size();
+  return QM_OK;
+}
+extern "C" void qm_free(void* p) { free(p); }

@@ -20,7 +20,11 @@ as `mummer2vcf.py -s <table> --output-header -n -g <ref.fa>`) without Biopython:
   * --output-header: VCFv4.2 header with the contigs that carry variants, in FASTA order  (:320-357)
 
 The reference cannot be executed in the build image (Bio is not installed), so parity is pinned
-by hand-derived cases only (tests/test_mummer2vcf.py)."""
+by hand-derived cases only (tests/test_mummer2vcf.py).
+
+`convert` / the command line go through the library (`qm_mummer2vcf`, csrc/qmvt_host.cpp: SURVEY.md 8f-2 asks for the
+builder in C++); `convert_py` below is the same restatement in Python, kept as the second opinion the tests compare the
+library with on random tables."""
 import sys
 from time import strftime
 
@@ -104,8 +108,38 @@ def _anchor(rows, seqs):
     return rows
 
 
-def convert(table_lines, reference=None, no_ns=False, vtype="ALL", output_header=False, input_header=False):
-    """Returns the VCF as a list of lines (no newline)."""
+def convert(table_lines, reference=None, no_ns=False, vtype="ALL", output_header=False, input_header=False, file_date=None):
+    """Returns the VCF as a list of lines (no newline).  table_lines: the table's lines (str or bytes, with their newlines) or its
+    whole text; reference: path of the FASTA.  The work is the library's (qm_mummer2vcf)."""
+    import ctypes as C
+    from . import _lib
+    L = _lib.lib()
+    if isinstance(table_lines, (bytes, str)):
+        text = table_lines
+    else:
+        table_lines = list(table_lines)
+        text = (b"" if table_lines and isinstance(table_lines[0], bytes) else "").join(table_lines)
+    if isinstance(text, str):
+        text = text.encode("utf-8", "surrogateescape")
+    fasta = b""
+    if reference:
+        with open(reference, "rb") as fh:
+            fasta = fh.read()
+    flags = (1 if no_ns else 0) | (2 if output_header else 0) | (4 if input_header else 0) | {"ALL": 0, "SNP": 8, "INDEL": 16}[vtype]
+    out, n = C.c_void_p(), C.c_size_t()
+    rc = L.qm_mummer2vcf(text, len(text), fasta, len(fasta), None if reference is None else str(reference).encode(), flags,
+                         None if file_date is None else file_date.encode(), C.byref(out), C.byref(n))
+    if rc != 0:
+        raise _lib.QmvtError(rc, "qm_mummer2vcf: a row with fewer than 12 columns, a position that is no integer, or an indel outside the reference sequences")
+    try:
+        data = C.string_at(out, n.value)
+    finally:
+        L.qm_free(out)
+    return data.decode("utf-8", "surrogateescape").split("\n")[:-1] if data else []
+
+
+def convert_py(table_lines, reference=None, no_ns=False, vtype="ALL", output_header=False, input_header=False):
+    """The same in Python (the restatement the library's is checked against).  Returns the VCF as a list of lines."""
     lines = list(table_lines)
     if input_header:
         lines = lines[4:]
@@ -148,8 +182,8 @@ def main(argv=None):
     a = p.parse_args(argv)
     if a.output_header and not a.reference:
         sys.exit("ERROR: --add-vcf-header requires --reference as well\n\n")
-    with open(a.snps) as fh:
-        out = convert(fh, reference=a.reference, no_ns=a.no_Ns, vtype=a.type, output_header=a.output_header,
+    with open(a.snps, "rb") as fh:
+        out = convert(fh.read(), reference=a.reference, no_ns=a.no_Ns, vtype=a.type, output_header=a.output_header,
                       input_header=a.input_header)
     for line in out:
         sys.stdout.write(line + "\n")

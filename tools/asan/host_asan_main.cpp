@@ -97,6 +97,21 @@ static void exercise(const std::vector<uint8_t>& t, qm_dict* dict, const char* o
     }
     g_calls += 6;
   }
+  // the truth-set builder on whatever this file is (as the table AND as the FASTA): refusals are fine, reads past the end are not
+  for (unsigned fl : {0u, 1u, 2u, 3u, 4u, 9u, 18u, 7u}) {
+    uint8_t* o = nullptr; size_t on = 0;
+    const int rc = qm_mummer2vcf(text, len, text, len, "ref.fa", fl, "20261004", &o, &on);
+    if (rc == QM_OK) qm_free(o);
+    ++g_calls;
+  }
+  {
+    static const char tab[] = "5\t.\tA\t50\t5\t100\t20\t30\t1\t1\tc\tq\n5\t.\tC\t50\t5\t100\t20\t30\t1\t1\tc\tq\r\n1\tA\t.\t9\t5\t100\t20\t30\t1\t1\tc\tq\n2\tC\tG\t9\t5\t100\t20\t30\t1\t1\tc\tq";
+    static const char fa[] = ">c x\nACGT\nAC\n>d\n";
+    uint8_t* o = nullptr; size_t on = 0;
+    if (qm_mummer2vcf((const uint8_t*)tab, sizeof tab - 1, (const uint8_t*)fa, sizeof fa - 1, nullptr, 3u, nullptr, &o, &on) != QM_OK || on == 0) { fprintf(stderr, "qm_mummer2vcf failed on its own example\n"); exit(1); }
+    qm_free(o);
+    ++g_calls;
+  }
   for (int mode = 0; mode < 2; ++mode)
     for (int fl = 0; fl < 2; ++fl) {
       int64_t n = 0;
