@@ -1978,6 +1978,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
     if (w < sg.bk_cap) asm volatile("" :: "v"(s_e[idx]));
 #elif defined(BK_ABL_L2STORE)   // (the same stores, same shape, wrapped into 2 MB that stay in L2: the instructions without the HBM traffic)
     if (w < sg.bk_cap) out[(((size_t)d * HB_SUBS + sub) * (size_t)sg.bk_cap + (size_t)w) & 0x3ffffu] = s_e[idx];
+#elif defined(BK_NT_STORE)      // (A/B: streaming stores for the entries)
+    if (w < sg.bk_cap) __builtin_nontemporal_store(s_e[idx], &out[((size_t)d * HB_SUBS + sub) * (size_t)sg.bk_cap + (size_t)w]);
 #else
     if (w < sg.bk_cap) out[((size_t)d * HB_SUBS + sub) * (size_t)sg.bk_cap + (size_t)w] = s_e[idx];   // beyond: the VCF is flagged and redone
 #endif
