@@ -385,6 +385,7 @@ struct qm_batch {
   int32_t *pos = nullptr, *ref = nullptr, *alt = nullptr;
   float* qual = nullptr;
   uint8_t* flags = nullptr;
+  char* col_slab = nullptr;   // QM_COL_SLAB (experiment): the five columns in one allocation, column k shifted by k x that many bytes
   // outputs / workspace
   uint64_t *mask_pass = nullptr, *mask_tp = nullptr;
   int32_t* idx = nullptr;
@@ -512,6 +513,7 @@ static void batch_free(qm_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->ctx->dev);
   if (b->sub) { batch_free(b->sub); b->sub = nullptr; }
+  if (b->col_slab) { (void)hipFree(b->col_slab); b->pos = b->ref = b->alt = nullptr; b->qual = nullptr; b->flags = nullptr; }
   void* ptrs[] = {b->pkey, b->pinf, b->pos, b->ref, b->alt, b->qual, b->flags, b->mask_pass, b->mask_tp, b->idx, b->tile_tp, b->tile_fp,
                   b->tile_tp_off, b->tile_fp_off, b->vcf_tot, b->span_hist, b->span_scal, b->vcf_flags, b->vcf_posor, b->bk_hist, b->bk_scal, b->d_bk_vcfs, b->bk_ent, b->bk_cursor, b->d_bk_tile_seg, b->bk_rows, b->bk_xent, b->bk_xcursor, b->bk_xrows, b->bk_roc, b->bk_rscal, b->bk_vflags, b->p_segs, b->p_tile_seg, b->p_cnt, b->p_off, b->p_cursor, b->p_flags, b->p_ent, b->d_vsegs, b->d_vparts, b->rs_roc, b->rs_scal, b->rs_flags, b->roc, b->global_acc,
                   b->scalars, b->d_vcfs, b->d_spans, b->d_tile_vcf, b->cls_scratch, b->sk[0], b->sk[1], b->sv[0],
@@ -554,6 +556,18 @@ static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int
   if (packed) {
     A_(b->pkey, np) A_(b->pinf, np)
     if (packed_alleles) { A_(b->ref, np) A_(b->alt, np) }   // sorted copies of the allele codes
+  }
+  else if (const char* e = getenv("QM_COL_SLAB")) {
+    const size_t skew = (size_t)atoll(e), pitch = ((np * 4 + (2u << 20) - 1) >> 21 << 21);
+    rc = dalloc(&b->col_slab, 5 * pitch + 5 * skew);
+    if (rc == QM_OK) {
+      b->dev_bytes += (int64_t)(5 * pitch + 5 * skew);
+      b->pos = reinterpret_cast<int32_t*>(b->col_slab);
+      b->ref = reinterpret_cast<int32_t*>(b->col_slab + pitch + skew);
+      b->alt = reinterpret_cast<int32_t*>(b->col_slab + 2 * (pitch + skew));
+      b->qual = reinterpret_cast<float*>(b->col_slab + 3 * (pitch + skew));
+      b->flags = reinterpret_cast<uint8_t*>(b->col_slab + 4 * (pitch + skew));
+    }
   }
   else { A_(b->pos, np) A_(b->ref, np) A_(b->alt, np) A_(b->qual, np) A_(b->flags, np) }
   A_(b->mask_pass, np / 64 + 64) A_(b->mask_tp, np / 64 + 64) A_(b->idx, np)

@@ -452,8 +452,12 @@ __device__ __forceinline__ void stage_round(uint32_t* lds, In4& X, int i0, int t
     uint4 rv, av;
     rv.x = (uint32_t)X.r[0]; rv.y = (uint32_t)X.r[1]; rv.z = (uint32_t)X.r[2]; rv.w = (uint32_t)X.r[3];
     av.x = (uint32_t)X.a[0]; av.y = (uint32_t)X.a[1]; av.z = (uint32_t)X.a[2]; av.w = (uint32_t)X.a[3];
+#ifndef K1X_ABL_NOSTAGE   // (timing builds: what do the two stores cost?  results are wrong without them)
     *reinterpret_cast<uint4*>(&lds[L_XRREF + lane * 4]) = rv;
     *reinterpret_cast<uint4*>(&lds[L_XRALT + lane * 4]) = av;
+#else
+    asm volatile("" :: "v"(rv.x), "v"(rv.y), "v"(rv.z), "v"(rv.w), "v"(av.x), "v"(av.y), "v"(av.z), "v"(av.w));
+#endif
   }
   if (lane < 8) lds[L_HITS + lane] = 0;
 }
@@ -700,6 +704,12 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #ifndef K1_PREFETCH
 #define K1_PREFETCH 1
 #endif
+#ifndef K1_MAP
+#define K1_MAP 0
+#endif
+#ifndef K1_MAP_STRIDE
+#define K1_MAP_STRIDE 61
+#endif
 #ifndef K1_WAVES_PER_EU
 #define K1_WAVES_PER_EU 5   // the register allocator is told to stay within 96 VGPRs (5 waves per SIMD)
 #endif
@@ -715,7 +725,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
   __shared__ __attribute__((aligned(16))) uint32_t lds[(EXT ? L_TOTAL_X : L_TOTAL) + K1_LDS_PAD];
 
   const int lane = (int)threadIdx.x;
-  const int span_id = (int)blockIdx.x + P.span_base;
+#if K1_MAP == 1     // (A/B) every XCD a contiguous eighth of the spans
+  const int nblk_ = (int)gridDim.x, x_ = (int)blockIdx.x & 7, j_ = (int)blockIdx.x >> 3, per_ = nblk_ >> 3;
+  const int bid_ = j_ < per_ ? x_ * per_ + j_ : (int)blockIdx.x;
+#elif K1_MAP == 2   // (A/B) neighbours in the launch order far apart in memory
+  const int nblk_ = (int)gridDim.x, full_ = nblk_ / K1_MAP_STRIDE * K1_MAP_STRIDE;
+  const int bid_ = (int)blockIdx.x < full_ ? ((int)blockIdx.x % K1_MAP_STRIDE) * (full_ / K1_MAP_STRIDE) + (int)blockIdx.x / K1_MAP_STRIDE : (int)blockIdx.x;
+#else
+  const int bid_ = (int)blockIdx.x;
+#endif
+  const int span_id = bid_ + P.span_base;
   const SpanDesc sp = P.spans[span_id];
   const TruthG tr = truth_global<EXT>(P.truths[sp.truth]);
   Cols C;
@@ -878,7 +897,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
           const int src = L_MASK + half * 32 * MT;
           for (int w = 4 * lane; w < 32 * MT; w += 256) {
             if (ablate & 32) { asm volatile("" :: "v"(lds[src + w])); continue; }   // (32: the masks' global stores priced alone)
-            if (w + 3 < nd) *reinterpret_cast<uint4*>(dst + w) = *reinterpret_cast<const uint4*>(&lds[src + w]);
+#if defined(QM_ABLATE_SUPPORT)
+            const bool mask_nt = (ablate & 128) == 0;   // (128: cached instead of streaming stores for the mask words)
+#elif defined(K1_MASK_PLAIN)
+            constexpr bool mask_nt = false;             // (A/B)
+#else
+            constexpr bool mask_nt = true;   // streaming: 0.8 % of the kernel on every one of 14 allocations (profiles/r04_classify_mask_nt.log)
+#endif
+            if (w + 3 < nd) {
+              typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+              if (mask_nt) __builtin_nontemporal_store(*reinterpret_cast<const v4u_*>(&lds[src + w]), reinterpret_cast<v4u_*>(dst + w));
+              else *reinterpret_cast<uint4*>(dst + w) = *reinterpret_cast<const uint4*>(&lds[src + w]);
+            }
             else for (int k = 0; k < 4; ++k) if (w + k < nd) dst[w + k] = lds[src + w + k];
           }
         }
@@ -922,9 +952,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
   uint32_t* oh = P.span_hist + (size_t)span_id * SPAN_HIST_WORDS;
   for (int i = lane; i < 128; i += 64) {
     const int b0 = 2 * i, b1 = 2 * i + 1;
-    oh[i] = (hist_get(lds, L_HTP, 1 + b0) + (b0 == nb - 1 ? top_tp : 0u)) | ((hist_get(lds, L_HTP, 1 + b1) + (b1 == nb - 1 ? top_tp : 0u)) << 16);
-    oh[128 + i] = (hist_get(lds, L_HFP, 1 + b0) + (b0 == nb - 1 ? top_fp : 0u)) | ((hist_get(lds, L_HFP, 1 + b1) + (b1 == nb - 1 ? top_fp : 0u)) << 16);
-    oh[256 + i] = hist_get(lds, L_HU, b0) | (hist_get(lds, L_HU, b1) << 16);
+#if defined(QM_ABLATE_SUPPORT)   // debug builds: QM_ABLATE=256
+#define K1_HST(p, x) do { if (ablate & 256) __builtin_nontemporal_store((uint32_t)(x), (p)); else *(p) = (x); } while (0)
+#elif defined(K1_HIST_NT)   // (A/B) streaming stores for the span's histograms
+#define K1_HST(p, x) __builtin_nontemporal_store((uint32_t)(x), (p))
+#else
+#define K1_HST(p, x) (*(p) = (x))
+#endif
+    K1_HST(&oh[i], (hist_get(lds, L_HTP, 1 + b0) + (b0 == nb - 1 ? top_tp : 0u)) | ((hist_get(lds, L_HTP, 1 + b1) + (b1 == nb - 1 ? top_tp : 0u)) << 16));
+    K1_HST(&oh[128 + i], (hist_get(lds, L_HFP, 1 + b0) + (b0 == nb - 1 ? top_fp : 0u)) | ((hist_get(lds, L_HFP, 1 + b1) + (b1 == nb - 1 ? top_fp : 0u)) << 16));
+    K1_HST(&oh[256 + i], hist_get(lds, L_HU, b0) | (hist_get(lds, L_HU, b1) << 16));
+#undef K1_HST
   }
   {   // the span's tile counts: lanes 0..15 TP, 16..31 FP (tiles never reached on an unsorted VCF hold nothing anyone reads)
     const int nt_span = (sp_end - (int)(sp.begin - sp.voff) + K1_TILE - 1) / K1_TILE;
