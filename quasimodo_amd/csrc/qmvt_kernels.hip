@@ -725,7 +725,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
   __shared__ __attribute__((aligned(16))) uint32_t lds[(EXT ? L_TOTAL_X : L_TOTAL) + K1_LDS_PAD];
 
   const int lane = (int)threadIdx.x;
-#if K1_MAP == 1     // (A/B) every XCD a contiguous eighth of the spans
+#if defined(QM_ABLATE_SUPPORT)   // debug builds: QM_ABLATE bits 9-10 pick the span order per launch (0 linear, 1 an eighth per XCD, 2 / 3 neighbours 61 / 1 021 apart)
+  int bid_ = (int)blockIdx.x;
+  {
+    const int mode_ = (P.ablate >> 9) & 3, nblk_ = (int)gridDim.x;
+    if (mode_ == 1) { const int x_ = bid_ & 7, j_ = bid_ >> 3, per_ = nblk_ >> 3; if (j_ < per_) bid_ = x_ * per_ + j_; }
+    else if (mode_ >= 2) { const int st_ = mode_ == 2 ? 61 : 1021, full_ = nblk_ / st_ * st_; if (bid_ < full_) bid_ = (bid_ % st_) * (full_ / st_) + bid_ / st_; }
+  }
+#elif K1_MAP == 1     // (A/B) every XCD a contiguous eighth of the spans
   const int nblk_ = (int)gridDim.x, x_ = (int)blockIdx.x & 7, j_ = (int)blockIdx.x >> 3, per_ = nblk_ >> 3;
   const int bid_ = j_ < per_ ? x_ * per_ + j_ : (int)blockIdx.x;
 #elif K1_MAP == 2   // (A/B) neighbours in the launch order far apart in memory
