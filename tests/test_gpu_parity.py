@@ -960,3 +960,17 @@ def test_a_batch_settles_on_a_form_of_the_compaction(engine, oracle):
         res = {"cls": b.cls(v), "roc": b.roc()[v], "scalars": sc, "tp_idx": reg[:sc["tp_lines"]].copy(), "fp_idx": reg[1_000_000 - sc["fp_lines"]:].copy()}
         check_vcf(oracle, res, cols, tk, expect_sorted=True)
     b.close()
+
+
+def test_columns_in_one_slab_give_the_same_answers(engine, oracle, monkeypatch):
+    """QM_COL_SLAB (DESIGN 4.1's placement probe): the five record columns as pieces of one allocation, shifted against each
+    other -- sorted and shuffled VCFs of ragged sizes against the oracle"""
+    monkeypatch.setenv("QM_COL_SLAB", "1280")
+    rng = np.random.default_rng(4242)
+    L = 60000
+    truth = random_truth(rng, 3000, L)
+    tid = engine.truth_load(*truth)
+    cols = [random_columns(rng, n, L, truth, sorted_=(i % 3 != 2)) for i, n in enumerate([0, 1, 255, 257, 2049, 5000, 16385, 40000])]
+    res, _ = engine.classify_batch(cols, [tid] * len(cols))
+    for r, c in zip(res, cols):
+        check_vcf(oracle, r, c, truth)
