@@ -17,4 +17,5 @@ SEED=110 run QM_K3_OWN=entries QM_K3_WINDOWS=8
 SEED=111 run QM_K3_OWN=chunks QM_K3_WINDOWS=1
 SEED=112 run QM_K3_OWN=chunks QM_K3_WINDOWS=8 QM_BUCKET2=2
 SEED=113 run QM_K3_OWN=entries QM_K3_WINDOWS=1 QM_SORT_PATH=radix
+SEED=114 run QM_COL_SLAB=1280                                   # the columns as pieces of one allocation
 cat $OUT
