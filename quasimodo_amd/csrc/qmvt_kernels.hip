@@ -900,6 +900,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           uint32_t* dst = (half ? mtp32 : mpass32) + (b0 >> 5);
+#ifdef QM_ABLATE_SUPPORT
+          if (half && (ablate & 2048)) dst = mpass32 + (b0 >> 5) + 32 * MT;   // (2048: the TP words right behind the batch's kept words instead of in their own array -- timing only: they land on the next batch's)
+#endif
           if (ablate & 64) dst = reinterpret_cast<uint32_t*>(half ? P.mask_tp : P.mask_pass) + ((int)(blockIdx.x & 1023) << 10);   // (64: the same stores into 4 MB that stay in L2 -- is it the HBM traffic or the store itself?)
           const int src = L_MASK + half * 32 * MT;
           for (int w = 4 * lane; w < 32 * MT; w += 256) {
