@@ -385,6 +385,9 @@ struct qm_batch {
   int32_t *pos = nullptr, *ref = nullptr, *alt = nullptr;
   float* qual = nullptr;
   uint8_t* flags = nullptr;
+#ifdef K1_IL_PROBE
+  uint8_t* il = nullptr;      // probe builds: the round-interleaved copy of the columns (QM_IL_PROBE=1; made at the first launch that asks for it)
+#endif
   char* col_slab = nullptr;   // QM_COL_SLAB (experiment): the five columns in one allocation, column k shifted by k x that many bytes
   // outputs / workspace
   uint64_t *mask_pass = nullptr, *mask_tp = nullptr;
@@ -513,6 +516,9 @@ static void batch_free(qm_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->ctx->dev);
   if (b->sub) { batch_free(b->sub); b->sub = nullptr; }
+#ifdef K1_IL_PROBE
+  (void)hipFree(b->il);
+#endif
   if (b->col_slab) { (void)hipFree(b->col_slab); b->pos = b->ref = b->alt = nullptr; b->qual = nullptr; b->flags = nullptr; }
   void* ptrs[] = {b->pkey, b->pinf, b->pos, b->ref, b->alt, b->qual, b->flags, b->mask_pass, b->mask_tp, b->idx, b->tile_tp, b->tile_fp,
                   b->tile_tp_off, b->tile_fp_off, b->vcf_tot, b->span_hist, b->span_scal, b->vcf_flags, b->vcf_posor, b->bk_hist, b->bk_scal, b->d_bk_vcfs, b->bk_ent, b->bk_cursor, b->d_bk_tile_seg, b->bk_rows, b->bk_xent, b->bk_xcursor, b->bk_xrows, b->bk_roc, b->bk_rscal, b->bk_vflags, b->p_segs, b->p_tile_seg, b->p_cnt, b->p_off, b->p_cursor, b->p_flags, b->p_ent, b->d_vsegs, b->d_vparts, b->rs_roc, b->rs_scal, b->rs_flags, b->roc, b->global_acc,
@@ -759,6 +765,17 @@ static ClassifyParams classify_params(qm_batch* b) {
   P.span_hist = b->span_hist; P.span_scal = b->span_scal; P.n_bins = b->n_bins;
   const char* ab = getenv("QM_ABLATE");
   P.ablate = ab ? atoi(ab) : 0;
+#ifdef K1_IL_PROBE
+  P.il = nullptr;
+  if (const char* e = getenv("QM_IL_PROBE")) if (atoi(e) && b->pos) {
+    const int64_t n_rounds = b->L.n_pad / 256;   // (n_pad = whole rounds + one tile)
+    if (!b->il) {
+      if (dalloc(&b->il, (size_t)n_rounds * 4352 + 8192) == QM_OK) launch_repack_il(b->pos, b->ref, b->alt, b->qual, b->flags, b->il, n_rounds, b->ctx->stream);
+      (void)hipStreamSynchronize(b->ctx->stream);
+    }
+    P.il = b->il;
+  }
+#endif
   P.ext = b->ext ? 1 : 0;
   P.span_base = 0;
   P.zero_acc = nullptr; P.zero_words = 0;

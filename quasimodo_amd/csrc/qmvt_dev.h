@@ -117,6 +117,9 @@ struct ClassifyParams {
   int32_t zero_words;
   const uint8_t* known;   // or null: known[v] != 0 = an earlier run of this batch found VCF v out of order and its columns have not changed since:
                           // its spans return at once (their rows still say so) and qm_batch_finish sends it down the bucket path without asking
+#ifdef K1_IL_PROBE
+  const uint8_t* il;      // probe builds: or null; a copy of the five columns with every 256-record round in 4 352 contiguous bytes
+#endif
 };
 
 struct FinalizeParams {
@@ -397,6 +400,9 @@ __host__ __device__ inline void synth_record(int64_t L, int64_t N, int64_t T, ui
 
 // ---- launchers ---------------------------------------------------------------
 void launch_classify(const ClassifyParams& P, int n_spans, hipStream_t st);
+#ifdef K1_IL_PROBE
+void launch_repack_il(const int32_t* pos, const int32_t* ref, const int32_t* alt, const float* qual, const uint8_t* flags, uint8_t* il, int64_t n_rounds, hipStream_t st);
+#endif
 void launch_finalize(const FinalizeParams& P, int n_vcf, hipStream_t st);
 void launch_compact(const CompactParams& P, int n_spans, hipStream_t st);
 void launch_masks_to_cls(const uint64_t* mp, const uint64_t* mt, int64_t off, int64_t n, uint8_t* cls, hipStream_t st);

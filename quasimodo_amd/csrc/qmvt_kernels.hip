@@ -186,6 +186,9 @@ struct Cols {  // bases of one VCF: the five columns, or the packed pair
   const uint8_t* flags;
   const uint32_t* pkey;
   const uint32_t* pinf;
+#ifdef K1_IL_PROBE
+  const uint8_t* il;   // or null: the VCF's first round in the round-interleaved copy
+#endif
 };
 
 template <bool PACKED> struct Raw4;   // one round's loads, still in flight
@@ -198,6 +201,21 @@ __device__ __forceinline__ void load_raw(const Cols& C, int idx, Raw4<false>& R)
   // outputs in L2 (same-box A/B: +3.5 % on this kernel, k_finalize 10 % faster)
   typedef int v4i __attribute__((ext_vector_type(4)));
   typedef float v4f __attribute__((ext_vector_type(4)));
+#ifdef K1_IL_PROBE
+  if (C.il) {   // wave-uniform; idx = first record of the round + 4 x lane
+    const uint8_t* t = C.il + (int64_t)(idx >> 8) * 4352 + (idx & 255) * 4;
+    const v4i vp = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(t));
+    const v4i vr = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(t + 1024));
+    const v4i va = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(t + 2048));
+    const v4f vq = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(t + 3072));
+    R.p = make_int4(vp.x, vp.y, vp.z, vp.w);
+    R.r = make_int4(vr.x, vr.y, vr.z, vr.w);
+    R.a = make_int4(va.x, va.y, va.z, va.w);
+    R.q = make_float4(vq.x, vq.y, vq.z, vq.w);
+    R.f = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(C.il + (int64_t)(idx >> 8) * 4352 + 4096 + (idx & 255)));
+    return;
+  }
+#endif
   const v4i vp = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(C.pos + idx));
   const v4i vr = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(C.ref + idx));
   const v4i va = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(C.alt + idx));
@@ -747,6 +765,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
   Cols C;
   C.pos = P.pos + sp.voff; C.ref = P.ref + sp.voff; C.alt = P.alt + sp.voff; C.qual = P.qual + sp.voff; C.flags = P.flags + sp.voff;
   C.pkey = P.pkey + sp.voff; C.pinf = P.pinf + sp.voff;
+#ifdef K1_IL_PROBE
+  C.il = P.il ? P.il + (sp.voff >> 8) * 4352 : nullptr;
+#endif
   uint32_t* const mpass32 = reinterpret_cast<uint32_t*>(P.mask_pass + (sp.voff >> 6));
   uint32_t* const mtp32 = reinterpret_cast<uint32_t*>(P.mask_tp + (sp.voff >> 6));
   const int vn = sp.vn;
@@ -3516,6 +3537,21 @@ void launch_bw_probe(int mode, const uint8_t* src, uint8_t* dst, int64_t bytes, 
   else if (mode == 1) hipLaunchKernelGGL((k_bw_probe<1>), grid, block, 0, st, (const uint4*)src, (uint4*)dst, n16, sink);
   else hipLaunchKernelGGL((k_bw_probe<2>), grid, block, 0, st, (const uint4*)src, (uint4*)dst, n16, sink);
 }
+#ifdef K1_IL_PROBE
+__global__ __launch_bounds__(256) void k_repack_il(const int32_t* pos, const int32_t* ref, const int32_t* alt, const float* qual, const uint8_t* flags, uint8_t* il) {
+  const int64_t r = blockIdx.x;
+  const int t = (int)threadIdx.x;
+  uint8_t* o = il + r * 4352;
+  reinterpret_cast<int32_t*>(o)[t] = pos[r * 256 + t];
+  reinterpret_cast<int32_t*>(o + 1024)[t] = ref[r * 256 + t];
+  reinterpret_cast<int32_t*>(o + 2048)[t] = alt[r * 256 + t];
+  reinterpret_cast<float*>(o + 3072)[t] = qual[r * 256 + t];
+  o[4096 + t] = flags[r * 256 + t];
+}
+void launch_repack_il(const int32_t* pos, const int32_t* ref, const int32_t* alt, const float* qual, const uint8_t* flags, uint8_t* il, int64_t n_rounds, hipStream_t st) {
+  if (n_rounds > 0) hipLaunchKernelGGL(k_repack_il, dim3((unsigned)n_rounds), dim3(256), 0, st, pos, ref, alt, qual, flags, il);
+}
+#endif
 void launch_classify(const ClassifyParams& P, int n_spans, hipStream_t st) {   // spans P.span_base .. + n_spans
   if (n_spans <= 0) return;
   if (P.pkey && P.ext) hipLaunchKernelGGL((k_classify<true, true>), dim3(n_spans), dim3(64), 0, st, P);
