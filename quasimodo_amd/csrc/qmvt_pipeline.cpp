@@ -13,6 +13,7 @@
 
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -44,6 +45,12 @@ int qm_device_zero(qm_ctx* ctx, void* dst, size_t bytes);                       
 namespace {
 
 double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// user + system seconds of the whole process so far (QM_FILES_TRACE: what a phase cost in CPU time, the currency of a box with a CPU quota)
+double cpu_now() {
+  struct rusage u;
+  if (getrusage(RUSAGE_SELF, &u) != 0) return 0.0;
+  return (double)u.ru_utime.tv_sec + (double)u.ru_stime.tv_sec + 1e-6 * ((double)u.ru_utime.tv_usec + (double)u.ru_stime.tv_usec);
+}
 
 struct Mapped {
   const uint8_t* p = nullptr;
@@ -180,9 +187,10 @@ extern "C" int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* j
   // map + count, truth sets (beside the former), batch layout, tokenise + host path (+ uploads beside it), engine, masks back,
   // write, release -- summed over the groups of the pipeline below (stages of different groups overlap, so the sum of the
   // phases exceeds the wall time of the call)
-  double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, phc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::mutex ph_mu;
-  auto add_ph = [&](int k, double dt) { std::lock_guard<std::mutex> g(ph_mu); ph[k] += dt; };
+  const bool trace = getenv("QM_FILES_TRACE") != nullptr;
+  auto add_ph = [&](int k, double dt, double dc = 0.0) { std::lock_guard<std::mutex> g(ph_mu); ph[k] += dt; phc[k] += dc; };
   const int nthr = qm_host_threads();
   std::vector<JobState> J((size_t)n_jobs);
   for (int j = 0; j < n_jobs; ++j) {
@@ -279,7 +287,7 @@ extern "C" int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* j
   std::condition_variable pats_cv;
   bool pats_ready = false, keys_ready = false;
   truth_thread = std::thread([&]() {
-    const double tt0 = now();
+    const double tt0 = now(), tc0 = trace ? cpu_now() : 0.0;
     parallel_for((int)T.size(), std::max(1, nthr / 4), [&](int k) {
       TruthState& t = T[(size_t)k];
       t.file.open_file(t.path.c_str());
@@ -306,7 +314,7 @@ extern "C" int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* j
       const int rc = qm_truth_load(ctx, tp.data(), tr.data(), ta.data(), k, &t.tid);
       if (rc != QM_OK) { truth_rc = rc; truth_msg = qm_last_error(ctx); break; }
     }
-    add_ph(1, now() - tt0);
+    add_ph(1, now() - tt0, trace ? cpu_now() - tc0 : 0.0);
     { std::lock_guard<std::mutex> g(pats_mu); keys_ready = true; }
     pats_cv.notify_all();
     pats_thread.join();   // (the VCFs do not wait for this thread but for pats_ready)
@@ -319,7 +327,7 @@ extern "C" int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* j
   // ---- stage 1 of a group: map + count, batch layout, tokenise + host path + uploads ----
   auto stage_one = [&](Group& gr, int gi) -> int {
     const int ng = (int)gr.jobs.size();
-    double t0 = now();
+    double t0 = now(), c0 = trace ? cpu_now() : 0.0;
     parallel_for(ng, nthr, [&](int k) {
       const int j = gr.jobs[(size_t)k];
       JobState& s = J[(size_t)j];
@@ -329,12 +337,12 @@ extern "C" int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* j
       qm_host_count_lines(s.vcf.p, s.vcf.n, &nl, &nd);
       s.n_lines = nl; s.n_data = nd;
     });
-    add_ph(0, now() - t0);
+    add_ph(0, now() - t0, trace ? cpu_now() - c0 : 0.0);
     { std::unique_lock<std::mutex> g(pats_mu); pats_cv.wait(g, [&] { return keys_ready; }); }   // the thread itself ends with the patterns
     for (int j : gr.jobs)
       if (J[(size_t)j].rc != QM_OK) return fail(QM_E_IO, std::string("cannot read ") + jobs[j].vcf_path);
     if (truth_rc != QM_OK) return fail(truth_rc, truth_msg);
-    t0 = now();
+    t0 = now(); c0 = trace ? cpu_now() : 0.0;
     for (int j : gr.jobs)
       if (!jobs[j].pure) { J[(size_t)j].batch_v = (int)gr.nrec.size(); gr.nrec.push_back(J[(size_t)j].n_data); gr.tids.push_back(T[(size_t)J[(size_t)j].truth].tid); }
     if (!gr.nrec.empty()) {
@@ -352,8 +360,8 @@ extern "C" int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* j
     uint8_t* arena = ca->arena[gi & 1].get(need);   // two arenas take turns: group g - 2 has been written by now
     if (!arena) return fail(QM_E_NOMEM, "qm_extract_files: no memory for the column buffers");
     if (hipStreamCreateWithFlags(&gr.copy_stream, hipStreamNonBlocking) != hipSuccess) return fail(QM_E_HIP, "hipStreamCreate failed");
-    add_ph(2, now() - t0);
-    t0 = now();
+    add_ph(2, now() - t0, trace ? cpu_now() - c0 : 0.0);
+    t0 = now(); c0 = trace ? cpu_now() : 0.0;
     const int per_file_threads = std::max(1, nthr / std::max(1, std::min(ng, nthr)));
     parallel_for(ng, nthr, [&](int k) {
       const int j = gr.jobs[(size_t)k];
@@ -402,14 +410,14 @@ extern "C" int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* j
                                      "Python exports to grep; set QM_LENIENT=1 to classify it by its columns");
     }
     if (hipStreamSynchronize(gr.copy_stream) != hipSuccess && rc == QM_OK) rc = fail(QM_E_HIP, "upload failed");
-    add_ph(3, now() - t0);
+    add_ph(3, now() - t0, trace ? cpu_now() - c0 : 0.0);
     return rc;
   };
 
   // ---- stage 2 of a group (a thread of its own): the engine, the class masks back, the three files of every VCF, the rows ----
   auto stage_two = [&](Group& gr) {
     int rc = QM_OK;
-    double t0 = now();
+    double t0 = now(), c0 = trace ? cpu_now() : 0.0;
     if (gr.batch) {
       std::lock_guard<std::mutex> eg(engine_mu);
       rc = qm_batch_run(gr.batch, nullptr, nullptr);
@@ -431,8 +439,8 @@ extern "C" int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* j
       }
       if (rc != QM_OK) gr.err = qm_last_error(ctx);
     }
-    add_ph(4, now() - t0);
-    t0 = now();
+    add_ph(4, now() - t0, trace ? cpu_now() - c0 : 0.0);
+    t0 = now(); c0 = trace ? cpu_now() : 0.0;
     for (size_t k = 0; k < gr.jobs.size() && rc == QM_OK; ++k) {
       const int j = gr.jobs[k];
       JobState& s = J[(size_t)j];
@@ -440,10 +448,10 @@ extern "C" int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* j
       rc = qm_batch_get_masks(gr.batch, s.batch_v, s.kept, s.tp);
       if (rc != QM_OK) gr.err = qm_last_error(ctx);
     }
-    add_ph(5, now() - t0);
+    add_ph(5, now() - t0, trace ? cpu_now() - c0 : 0.0);
     if (gr.copy_stream) { (void)hipStreamDestroy(gr.copy_stream); gr.copy_stream = nullptr; }
     if (rc != QM_OK) { gr.rc = rc; return; }
-    t0 = now();
+    t0 = now(); c0 = trace ? cpu_now() : 0.0;
     struct WTask { int j, select; const char* path; bool pure; };
     std::vector<WTask> W;
     for (int j : gr.jobs) {
@@ -460,7 +468,7 @@ extern "C" int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* j
     });
     for (size_t k = 0; k < W.size(); ++k)
       if (wrc[k] != QM_OK) { gr.rc = wrc[k]; gr.err = std::string("cannot write ") + W[k].path; return; }
-    add_ph(6, now() - t0);
+    add_ph(6, now() - t0, trace ? cpu_now() - c0 : 0.0);
     // per-VCF rows
     for (int j : gr.jobs) {
       const JobState& s = J[(size_t)j];
@@ -490,12 +498,12 @@ extern "C" int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* j
       }
     }
     // the group is done: its batch, its mappings and its line tables go while the next group is at work
-    t0 = now();
+    t0 = now(); c0 = trace ? cpu_now() : 0.0;
     if (gr.batch) { qm_batch_destroy(gr.batch); gr.batch = nullptr; }
     const double t1 = now();
     parallel_for((int)gr.jobs.size(), nthr, [&](int k) { JobState tmp = std::move(J[(size_t)gr.jobs[(size_t)k]]); (void)tmp; });   // unmap / free in parallel
     if (getenv("QM_FILES_TRACE")) fprintf(stderr, "release: batch destroy %.2f ms, unmap + free %.2f ms\n", (t1 - t0) * 1e3, (now() - t1) * 1e3);
-    add_ph(7, now() - t0);
+    add_ph(7, now() - t0, trace ? cpu_now() - c0 : 0.0);
   };
 
   int rc = QM_OK;
@@ -512,5 +520,8 @@ extern "C" int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* j
   cleanup();
   if (rc != QM_OK) return fail(rc, msg);
   if (phase_seconds) memcpy(phase_seconds, ph, sizeof ph);
+  if (trace)   // (process-wide CPU time between a phase's two clock readings: phases that run beside each other share it)
+    fprintf(stderr, "cpu seconds: map_count %.3f truth_beside %.3f batch_layout %.3f tokenise_upload %.3f engine %.3f masks_back %.3f write %.3f release %.3f\n",
+            phc[0], phc[1], phc[2], phc[3], phc[4], phc[5], phc[6], phc[7]);
   return QM_OK;
 }
