@@ -1707,9 +1707,12 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
     if (rc != QM_OK) { forget_known(b, -1); return rc; }
     redone = !kn.empty();
   }
-  HIPCHK(hipStreamSynchronize(st));
+  // every VCF known to be out of order: the run launched no optimistic pass, nothing can have raised a flag, and the rescan below
+  // goes onto the stream behind the bucket path without a round trip through the host in between
+  const bool nothing_ran = b->run_used_known && b->n_known == b->n_vcf && b->h_summary != nullptr;
+  if (!nothing_ran) HIPCHK(hipStreamSynchronize(st));
   std::vector<int> todo;
-  if (!b->h_summary || *reinterpret_cast<volatile uint32_t*>(b->h_summary) != 0u) {   // else: no VCF of the run carries a flag nobody knew of
+  if (!nothing_ran && (!b->h_summary || *reinterpret_cast<volatile uint32_t*>(b->h_summary) != 0u)) {   // else: no VCF of the run carries a flag nobody knew of
     std::vector<uint32_t> fl((size_t)b->n_vcf);
     HIPCHK(hipMemcpy(fl.data(), b->vcf_flags, 4 * fl.size(), hipMemcpyDeviceToHost));
     for (int v = 0; v < b->n_vcf; ++v) {
@@ -1731,6 +1734,8 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
   if (redone) {
     const int rc = rescan_and_compact(b, st);
     if (rc != QM_OK) return rc;
+  } else if (nothing_ran) {
+    HIPCHK(hipStreamSynchronize(st));
   }
   if (memo_on() && !todo.empty()) {
     if (b->known.empty()) { b->known.assign((size_t)b->n_vcf, (uint8_t)0); b->known_posor.assign((size_t)b->n_vcf, 0u); }
