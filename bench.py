@@ -21,7 +21,9 @@ would be redone through the radix sort here), plus, for N > 1, the one RCCL all-
 confusion counters.  VCFs shard over ranks with no data-path collective (weak scaling: per-GPU work fixed).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k_classify), timed with HIP events on its own
-stream inside the timed region; `roofline.step_frac` is SURVEY 8d's formula over the whole step.  `cpu_baseline` is
+stream inside the timed region; `roofline.step_frac` is SURVEY 8d's formula over the whole step of the timed batch, and
+`roofline.step_frac_median` / `_min` / `_max` the same over that batch and `--alloc-reps` re-creations of it (the step moves
+by several per cent with where a batch lands in physical memory: the median is the figure of record).  `cpu_baseline` is
 the oracle (a C restatement of the reference's awk/fgrep semantics) timed on this box's host cores on a bounded
 sample of the same VCFs -- a reported baseline, not the target.
 """
@@ -272,7 +274,10 @@ def main():
         "data": "synthetic (generated on device; VCF seeds %d+v, truth seed%s %s)" % (P["seed"], "s" if len(tseeds) > 1 else "", ",".join(map(str, tseeds))),
         "config": {"workload": workload, "baseline_config_index": args.config,
                    "vcfs_per_gpu": n_vcf, "records_per_vcf": P["records"], "parallelism": "vcf-shard x%d" % world,
-                   "collective": "1 all-reduce of [%d x 3 x %d] int64 per step" % (batch.n_truth, args.bins) if world > 1 else "none",
+                   "collective": ("1 all-reduce of [%d x 3 x %d] int64 per step" % (batch.n_truth, args.bins)
+                                  + (" (QM_BENCH_FORCE_PG: a process group of one rank)" if force_pg else "")) if world > 1 or force_pg else "none",
+                   # VCFs of this rank's batch compared with the oracle after the timed region: class bits, ROC row, scalars and both
+                   # index lists (oracle_check), plus what the cpu_baseline leg verifies while it times the oracle (filled in below)
                    "vcfs_checked_against_oracle_per_rank": checked},
         "roofline": {"bound": "hbm", "kernel": roof_kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_build": traffic_build, "traffic_note": traffic_note,
@@ -282,7 +287,6 @@ def main():
                      "step_frac": alg_bytes / step_s / 1e9 / HBM_PEAK_GBS},
         "kernels_ms": tm,
         "per_rank": per_rank,     # N > 1: min / max / all over the ranks of ms_per_step and of each rank's own kernel time
-        "compact_form": batch.compact_form(),   # which form of k_compact this batch settled on during the warm-up and what each took
         "device_bytes": batch.device_bytes,
     }
 
@@ -297,24 +301,38 @@ def main():
             out["roofline"]["measured_error"] = str(e)[:120]
     side = rank == 0 and world == 1
     if side and args.config == 2 and not custom and not args.shuffled and args.alloc_reps > 0:
-        # The same workload in fresh allocations, outside the timed region: within one allocation k_classify is steady to a per
+        # The same workload in fresh allocations, outside the timed region: within one allocation the step is steady to a per
         # cent, from one allocation to the next it moves by several (profiles/r03_alloc_pmc.log: the same requests, 5-9 % more
-        # memory latency) -- the headline above is ONE draw of this spread.
+        # memory latency) -- the headline above is ONE draw of this spread, so the line also carries the WHOLE step (wall clock
+        # over back-to-back steps, as the timed region measures it) of every allocation and the median of them: the figure of record.
         spread = [round(tm["classify_ms"], 4)]
+        steps_ms = [round(step_s * 1e3, 4)]
         for _ in range(args.alloc_reps):
             b2 = eng.batch([P["records"]] * n_vcf, [tids[0]] * n_vcf, n_bins=args.bins)
             b2.synth(P["genome"], P["truth"], tseeds[0], P["seed"])
-            b2.run(); b2.finish()
+            for _ in range(2):
+                b2.run(); b2.finish()
+            steps_ms.append(round(_timed_steps(b2, max(5, min(args.steps, 10))) * 1e3, 4))
             b2.set_timing(True)
             for _ in range(5):
                 b2.run()
             b2.finish()
             spread.append(round(b2.timings()["classify_ms"], 4))
             b2.close()
-        out["roofline"]["alloc_spread"] = {"k_classify_ms": spread, "min": min(spread), "max": max(spread),
-                                           "note": "first entry = the timed batch; the others = the same batch created again (5 runs each)"}
+        frac_of = lambda ms: alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        med = float(np.median(steps_ms))
+        out["roofline"]["alloc_spread"] = {"k_classify_ms": spread, "min": min(spread), "max": max(spread), "step_ms": steps_ms,
+                                           "note": "first entry = the timed batch; the others = the same batch created again (k_classify: 5 runs each; "
+                                                   "step: wall clock over back-to-back steps)"}
+        out["roofline"].update(step_frac_median=frac_of(med), step_frac_min=frac_of(max(steps_ms)), step_frac_max=frac_of(min(steps_ms)),
+                               step_ms_median=med, value_at_median_allocation=total_records / (med * 1e-3))
     if side and args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(batch, P, tseeds, alleles, args.bins, max(1, min(n_vcf, args.cpu_sample // P["records"])))
+        ck = out["cpu_baseline"].pop("checked")
+        out["config"]["vcfs_checked_against_oracle_per_rank"] = max(checked, ck["roc_rows"])
+        out["config"]["oracle_checks"] = dict(ck, full_vcfs=checked,
+                                              note="roc_rows: VCFs whose [3][n_bins] ROC row equals the oracle's; class_bits_vcfs: VCFs whose per-record "
+                                                   "class bits equal the oracle's; full_vcfs: class bits + ROC row + scalars + both index lists (oracle_check)")
     if side and args.config == 2 and not custom and args.shell_sample > 0:
         try:
             out["cpu_baseline_shell"] = shell_baseline(batch, P, min(args.shell_sample, n_vcf), tseeds[0])
@@ -382,7 +400,8 @@ def _timed_steps(b, steps):
 def _timed_with_and_without_memory(b, steps):
     """A batch remembers which VCFs a finish found out of order while its columns stay the same: `ms_per_step` is
     the repeated run, `ms_per_step_unseen` the same run with that memory switched off (QM_MEMO=0: optimistic pass over every
-    VCF, flags read back, then the bucket path -- what a batch pays when it is run for the first time)."""
+    VCF, flags read back, then the bucket path -- what a batch pays when it is run for the first time).  The variants report
+    the FIRST-SEEN figure as their `value` (`value_repeated_run` beside it)."""
     dt = _timed_steps(b, steps)
     old = os.environ.get("QM_MEMO")
     os.environ["QM_MEMO"] = "0"
@@ -414,7 +433,7 @@ def shuffled_variant(eng, tid, P, bins, nv, tseed, sorted_roc):
     ok = bool(np.array_equal(b.roc(), sorted_roc[:nv])) and int(b.scalars()[:, 5].sum()) == 0
     paths = b.path_stats()
     b.close()
-    return {"value": nv * float(P["records"]) / dt, "unit": "classifications/s", "vcfs": nv, "steps": steps,
+    return {"value": nv * float(P["records"]) / dt0, "value_repeated_run": nv * float(P["records"]) / dt, "unit": "classifications/s", "vcfs": nv, "steps": steps,
             "ms_per_step": dt * 1e3, "ms_per_step_unseen": dt0 * 1e3, "roc_equals_sorted_variant": ok, "paths": paths,
             "note": "records permuted: optimistic pass (stops early) + bucket path (one scatter pass into 256 position buckets per VCF, k_join_direct: one bit per "
                     "key of the bucket in LDS, no sort and no hashing inside a bucket, TP bits straight into the input-order mask); `paths` says where the VCFs went"}
@@ -442,7 +461,7 @@ def shuffled_config3_variant(eng, bins, nv):
         b.close()
     eng.truth_release(tid)
     ok = bool(np.array_equal(rocs[True][0], rocs[False][0]) and np.array_equal(rocs[True][1], rocs[False][1]))
-    return {"value": nv * float(P3["records"]) / dt, "unit": "classifications/s", "vcfs": nv, "records_per_vcf": P3["records"], "steps": steps,
+    return {"value": nv * float(P3["records"]) / dt0, "value_repeated_run": nv * float(P3["records"]) / dt, "unit": "classifications/s", "vcfs": nv, "records_per_vcf": P3["records"], "steps": steps,
             "ms_per_step": dt * 1e3, "ms_per_step_unseen": dt0 * 1e3, "equals_sorted_variant": ok, "paths": paths,
             "note": "10 M-record VCFs permuted: k_part_hist + k_part_scatter (level 1: partitions of 2^27 keys, exact regions), then k_bucket_scatter from the "
                     "level-1 entries and k_join_direct per partition"}
@@ -504,7 +523,7 @@ def shuffled_alleles_variant(eng, P, bins, nv):
         b.close()
     eng.truth_release(tid)
     ok = bool(np.array_equal(rows[True][0], rows[False][0]) and np.array_equal(rows[True][1], rows[False][1]))
-    return {"value": nv * float(P["records"]) / dt, "unit": "classifications/s", "vcfs": nv, "steps": steps, "ms_per_step": dt * 1e3, "ms_per_step_unseen": dt0 * 1e3,
+    return {"value": nv * float(P["records"]) / dt0, "value_repeated_run": nv * float(P["records"]) / dt, "unit": "classifications/s", "vcfs": nv, "steps": steps, "ms_per_step": dt * 1e3, "ms_per_step_unseen": dt0 * 1e3,
             "indel_pct": pct, "equals_sorted_variant": ok, "paths": paths,
             "note": "allele-extended VCFs permuted: one scatter into two entry streams per bucket, k_join_direct (single-base records) + k_join_ext (the others)"}
 
@@ -531,7 +550,7 @@ def shuffled_config4_variant(eng, bins, nv):
     for t in tids:
         eng.truth_release(t)
     ok = bool(np.array_equal(rows[True][0], rows[False][0]) and np.array_equal(rows[True][1], rows[False][1]))
-    return {"value": nv * float(P4["records"]) / dt, "unit": "classifications/s", "vcfs": nv, "records_per_vcf": P4["records"], "steps": steps,
+    return {"value": nv * float(P4["records"]) / dt0, "value_repeated_run": nv * float(P4["records"]) / dt, "unit": "classifications/s", "vcfs": nv, "records_per_vcf": P4["records"], "steps": steps,
             "ms_per_step": dt * 1e3, "ms_per_step_unseen": dt0 * 1e3, "indel_pct": P4["indel_pct"], "equals_sorted_variant": ok, "paths": paths,
             "note": "2 M-record allele-extended VCFs on a 10 Mb reference permuted: two partitions of 2^27 keys per VCF, each a segment of the one-level "
                     "scatter reading the VCF's columns (SortSeg.part); k_join_direct + k_join_ext per bucket; `paths` counts them as bucket_two_level"}
@@ -585,14 +604,49 @@ def shell_baseline(batch, P, n_sample, tseed):
             a.wait(); b.wait()
         dt = time.perf_counter() - t0
         mb = os.path.getsize(paths[0]) / 1e6
+        nl = lambda q: sum(1 for ln in open(q, "rb") if not ln.startswith(b"#"))
         for v, p in enumerate(paths):
-            nl = lambda q: sum(1 for ln in open(q, "rb") if not ln.startswith(b"#"))
             assert nl(p + ".filtered") == scal[v][0] and nl(p + ".tp") == scal[v][1] and nl(p + ".fp") == scal[v][2], \
                 "shell pipeline and GPU disagree on VCF %d" % v
+        # SURVEY 8d's second form: the same five commands with one VCF per host core.  The texts are rendered once: job k reads
+        # the text of VCF k mod n_sample (the reads are the same work whichever VCF) and writes outputs of its own.  One job is
+        # ~9 processes (3 bash, 3 grep header, 5 awk / grep stages), and the box allows 1 024 of ours at once: jobs <= 48.
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        quota = None
+        try:
+            q_, per_ = open("/sys/fs/cgroup/cpu.max").read().split()
+            quota = None if q_ == "max" else float(q_) / float(per_)
+        except Exception:
+            pass
+        jobs = max(1, min(cores, 48, int(os.environ.get("QM_BENCH_SHELL_JOBS", "48"))))
+
+        def one(k):
+            p = paths[k % n_sample]
+            o = os.path.join(w, "job%d" % k)
+            f = flt % p
+            subprocess.run(["bash", "-c", '(grep -E "^#" %s;%s) > %s.filtered' % (p, f, o)], check=True)
+            a = subprocess.Popen(["bash", "-c", '(grep -E "^#" %s;grep -F -wf <(%s) <(%s)) > %s.tp' % (p, gs, f, o)])
+            b = subprocess.Popen(["bash", "-c", '(grep -E "^#" %s;grep -F -wvf <(%s) <(%s)) > %s.fp' % (p, gs, f, o)])
+            a.wait(); b.wait()
+            return o
+
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(jobs) as ex:
+            t0 = time.perf_counter()
+            outs = list(ex.map(one, range(jobs)))
+            dtp = time.perf_counter() - t0
+        for k, o in enumerate(outs):
+            v = k % n_sample
+            assert nl(o + ".filtered") == scal[v][0] and nl(o + ".tp") == scal[v][1] and nl(o + ".fp") == scal[v][2], \
+                "parallel shell pipeline and GPU disagree on job %d" % k
     n = float(n_sample) * P["records"]
     return {"value": n / dt, "unit": "classifications/s", "cores": 3, "kind": "reference-mechanism",
             "sample": "first %d VCFs as text (%.0f MB each), awk filter + fgrep -wf/-wvf as extract_TP_FP_SNPs.py:24-57, VCFs serial, "
                       "<= 3 concurrent pipelines per VCF, %.1f s; line counts equal the GPU's" % (n_sample, mb, dt),
+            "all_cores": {"value": float(jobs) * P["records"] / dtp, "unit": "classifications/s", "jobs": jobs, "cores": cores, "cpu_quota": quota,
+                          "seconds": dtp,
+                          "sample": "%d VCF jobs at once, one per host core (capped at 48: a job is ~9 processes), each the same five commands on the "
+                                    "text of VCF k mod %d with outputs of its own; line counts of every job equal the GPU's" % (jobs, n_sample)},
             "awk": awkv}
 
 
@@ -613,7 +667,8 @@ def cpu_baseline(batch, P, tseeds, alleles, bins, n_sample):
     n = float(sum(len(c[0]) for c in cols))
     out = {"value": n / dt, "unit": "classifications/s", "cores": 1, "kind": "port",
            "sample": "first %d VCFs of the batch (%d records), oracle/qm_oracle.c classify_columns, 1 thread, %.1f s"
-                     % (n_sample, int(n), dt)}
+                     % (n_sample, int(n), dt),
+           "checked": {"roc_rows": len(res), "class_bits_vcfs": 1}}
     # the same sample with one oracle call in flight per host core (ctypes drops the GIL during the call)
     from concurrent.futures import ThreadPoolExecutor
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define QM_ABI_VERSION 4
+#define QM_ABI_VERSION 5
 
 #define QM_OK 0
 #define QM_E_INVAL (-1)     /* bad argument */
@@ -235,12 +235,6 @@ int qm_batch_path_stats(qm_batch* b, int64_t* out /*[QM_N_PATH_STATS]*/);
 /* The same counters summed over every qm_batch_finish of every batch of the context since qm_init, the batches that
  * qm_extract_files / qm_classify_batch make for themselves included: callers take the difference around a call. */
 int qm_path_stats_total(qm_ctx* ctx, int64_t* out /*[QM_N_PATH_STATS]*/);
-/* k_compact has two forms (a wave stores its own entries, the XCDs on contiguous eighths of the tiles / a wave stores whole
- * 1 KiB chunks, tiles in launch order); which one is faster follows where the batch's index lists landed in physical memory,
- * so a batch that fills the chip alternates them over its first five runs (the very first is not counted: first touch) and
- * keeps the faster (QM_K3_TUNE=0: never; the second form then).  state[0]: 0 / 1 = the run that tries form 0 / 1 is next, 2 = decided, 3 = not tuned; state[1]: the form the
- * next run uses; ms2 (or NULL): the compaction's time with either form, 0 until tried. */
-int qm_batch_compact_form(qm_batch* b, int32_t* state /*[2]*/, float* ms2 /*[2]*/);
 /* Device address of the per-truth sums of the last run ([qm_batch_n_truth(b)][3][n_bins] uint64; the caller's global_dev when
  * qm_batch_run was given one): valid until the batch runs again or is destroyed.  For callers that hand the counters to a
  * collective without a trip through the host. */

@@ -35,7 +35,8 @@ def _extract(a):
     print("\t".join(("vcf",) + cols))
     out = []
     for j in jobs:
-        row = {k: (int(j.stats.get(k, 1)) if k != "pure_strain" else bool(j.stats[k])) for k in cols}
+        # ("sorted" is absent from a pure-strain row -- nothing was classified --; every other column must be there)
+        row = {k: bool(j.stats[k]) if k == "pure_strain" else int(j.stats.get(k, 1)) if k == "sorted" else int(j.stats[k]) for k in cols}
         print("\t".join([j.vcf_file] + [str(row[k]) for k in cols]))
         out.append(dict(vcf=j.vcf_file, filtered=j.filtered_out, tp=j.tp_out, fp=j.fp_out, **row))
     if a.json:
@@ -62,7 +63,7 @@ def main(argv=None):
     e.add_argument("--labels", default=None, help="comma-separated output labels for --custom")
     e.add_argument("--alleles", action="store_true", help="allele-extended mode: indels / MNPs matched exactly (off by default)")
     e.add_argument("--gpus", type=int, default=1, help="deal the VCFs to this many GPUs of the node: one process per GPU, one all-reduce "
-                                                       "of the confusion counters (RCCL), rows gathered on rank 0")
+                                                       "of the confusion counters (RCCL); the per-VCF rows reach the parent through the ranks' result files")
     e.add_argument("--json", default=None, help="also write {rows, unsorted_paths: where VCFs that were out of order went} as JSON")
     e.add_argument("vcf", nargs="+")
     e.set_defaults(fn=_extract)

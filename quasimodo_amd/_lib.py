@@ -13,7 +13,7 @@ ERRORS = {-1: "QM_E_INVAL", -2: "QM_E_NODEVICE", -3: "QM_E_HIP", -4: "QM_E_NOMEM
           -6: "QM_E_STATE", -7: "QM_E_IO", -8: "QM_E_NONCANON", -9: "QM_E_LIMIT", -10: "QM_E_UNSORTED"}
 QM_E_UNSORTED = -10
 QM_BATCH_ALLELES = 1
-QM_ABI_VERSION = 4
+QM_ABI_VERSION = 5
 
 # every symbol include/qmvt.h declares
 EXPORTS = (
@@ -25,7 +25,7 @@ EXPORTS = (
     "qm_truth_size_ext", "qm_truth_synth_ext", "qm_batch_create_ext", "qm_classify_batch_ext",
     "qm_dict_create", "qm_dict_destroy", "qm_dict_size", "qm_allele_code", "qm_allele_spell", "qm_vcf_scan_ext", "qm_truth_scan_ext",
     "qm_bench_synth", "qm_truth_release", "qm_batch_n_truth",
-    "qm_bw_probe", "qm_bgzf_write", "qm_bgzf_write_tbi", "qm_extract_files", "qm_extract_files_ex", "qm_batch_global_device", "qm_batch_path_stats", "qm_path_stats_total", "qm_batch_compact_form", "qm_batch_upload_async", "qm_batch_get_masks", "qm_patterns_create", "qm_patterns_destroy", "qm_patterns_info", "qm_vcf_hostpath",
+    "qm_bw_probe", "qm_bgzf_write", "qm_bgzf_write_tbi", "qm_extract_files", "qm_extract_files_ex", "qm_batch_global_device", "qm_batch_path_stats", "qm_path_stats_total", "qm_batch_upload_async", "qm_batch_get_masks", "qm_patterns_create", "qm_patterns_destroy", "qm_patterns_info", "qm_vcf_hostpath",
     "qm_mummer2vcf", "qm_free",
 )
 
@@ -201,7 +201,6 @@ def lib():
     L.qm_mummer2vcf.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_uint, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.qm_free.argtypes = [vp]
     L.qm_free.restype = None
-    L.qm_batch_compact_form.argtypes = [vp, vp, vp]
     L.qm_batch_upload_async.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
     L.qm_batch_get_masks.argtypes = [vp, i32, vp, vp]
     L.qm_bgzf_write.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, i32]

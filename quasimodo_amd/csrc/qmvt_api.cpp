@@ -456,16 +456,6 @@ struct qm_batch {
   struct Chunk { int v0, v1, s0, s1; };
   std::vector<Chunk> chunks;
   hipEvent_t ev_sync[MAX_CHUNKS + 2] = {};   // ordering between the two streams (no timing)
-  // k_compact's two forms, tried on this batch's first runs and the faster kept: which one wins depends on where the
-  // batch's index lists landed in physical memory, which nobody chooses.  Run 0 is left out (the first touch of a batch's memory
-  // is slower than every later one), runs 1..4 alternate the forms, the smaller of a form's two times counts.
-  // k3_state: 0 = trying (k3_run: the next run's number), 2 = decided (k3_form), 3 = not tuned (small batch, QM_K3_TUNE=0 or an
-  // explicit QM_K3_OWN / QM_K3_WINDOWS)
-  static constexpr int K3_TRIES = 5;
-  int k3_state = 3, k3_form = 0, k3_run = 0;
-  bool k3_pending = false;                   // the last run recorded k3_ev around its compaction
-  hipEvent_t k3_ev[2] = {};
-  float k3_ms[2] = {0.f, 0.f};
   // timing
   bool timing = false;
   static constexpr int EV_RING = 32;   // per-kernel events of the latest runs
@@ -528,7 +518,6 @@ static void batch_free(qm_batch* b) {
   if (b->h_summary) (void)hipHostFree(b->h_summary);
   for (auto& r : b->ev) for (auto& e : r) if (e) (void)hipEventDestroy(e);
   for (auto& e : b->ev_sync) if (e) (void)hipEventDestroy(e);
-  for (auto& e : b->k3_ev) if (e) (void)hipEventDestroy(e);
   delete b;
 }
 
@@ -607,11 +596,6 @@ static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int
     b->chunks.back().v1 = n_vcf; b->chunks.back().s1 = ns;
     for (auto& e : b->ev_sync) {
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rc = fail(QM_E_HIP, "hipEventCreate failed"); break; }
-    }
-    const char* tune = getenv("QM_K3_TUNE");
-    if (rc == QM_OK && ns >= 4096 && !(tune && !strcmp(tune, "0")) && !getenv("QM_K3_OWN") && !getenv("QM_K3_WINDOWS") && b->chunks.size() == 1) {
-      if (hipEventCreate(&b->k3_ev[0]) == hipSuccess && hipEventCreate(&b->k3_ev[1]) == hipSuccess) b->k3_state = 0;
-      else (void)hipGetLastError();
     }
   }
   if (rc == QM_OK && !packed) {
@@ -793,17 +777,11 @@ static FinalizeParams finalize_params(qm_batch* b, uint64_t* global) {
   F.known = nullptr;
   return F;
 }
-// the two forms of k_compact: 0 = a wave stores its own entries, every XCD a contiguous eighth of the tiles; 1 = whole 1 KiB chunks
-// (completed from the tiles behind a wave's own), tiles in launch order
-static void k3_set_form(CompactParams& C, int form) { C.own_chunks = form ? 1 : 0; C.nwin = form ? 1 : 8; }
 static CompactParams compact_params(qm_batch* b) {
   CompactParams C;
   C.vcfs = b->d_vcfs; C.spans = b->d_spans; C.mask_pass = b->mask_pass; C.mask_tp = b->mask_tp;
   C.tile_fp = b->tile_fp; C.tile_tp_off = b->tile_tp_off; C.tile_fp_off = b->tile_fp_off; C.vcf_tot = b->vcf_tot; C.idx = b->idx;
   C.vcf_flags = b->vcf_flags; C.skip_unsorted = 1; C.span_base = 0;
-  k3_set_form(C, b->k3_state == 0 ? ((b->k3_run & 1) ^ 1) : b->k3_state == 2 ? b->k3_form : 1);   // trying: chunks, entries, chunks, entries, chunks; untuned batches: the form that does not depend on luck
-  if (const char* e = getenv("QM_K3_WINDOWS")) { const int w = atoi(e); if (w == 1 || w == 2 || w == 4 || w == 8) C.nwin = w; }   // (experiments)
-  if (const char* e = getenv("QM_K3_OWN")) C.own_chunks = !strcmp(e, "chunks") ? 1 : 0;
   return C;
 }
 
@@ -898,10 +876,7 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
       HIPCHK(hipStreamWaitEvent(aux, b->ev_sync[k], 0));
     }
     if (T) HIPCHK(hipEventRecord(e5[3], aux));
-    const bool k3_try = nch == 1 && b->k3_state == 0 && b->k3_ev[0] != nullptr;
-    if (k3_try) HIPCHK(hipEventRecord(b->k3_ev[0], aux));
     launch_compact(K, ck.s1 - ck.s0, aux);
-    if (k3_try) { HIPCHK(hipEventRecord(b->k3_ev[1], aux)); b->k3_pending = true; }
     if (T) HIPCHK(hipEventRecord(e5[4], aux));
   }
   if (all_known) {
@@ -1742,18 +1717,6 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
     for (int v : todo) if (!b->known[(size_t)v]) { b->known[(size_t)v] = 1; b->known_posor[(size_t)v] = posor[(size_t)v]; ++b->n_known; b->known_dirty = true; }
   }
   for (int k = 0; k < QM_N_PATH_STATS; ++k) c->path_total[k] += b->path_stats[k];
-  if (b->k3_pending && b->k3_state == 0) {   // the stream is idle: the run's compaction has its time
-    b->k3_pending = false;
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, b->k3_ev[0], b->k3_ev[1]) == hipSuccess) {
-      const int form = (b->k3_run & 1) ^ 1;
-      if (b->k3_run > 0) b->k3_ms[form] = b->k3_ms[form] > 0.f && b->k3_ms[form] < ms ? b->k3_ms[form] : ms;
-      if (++b->k3_run == qm_batch::K3_TRIES) { b->k3_form = b->k3_ms[1] < b->k3_ms[0] ? 1 : 0; b->k3_state = 2; }
-    } else {
-      (void)hipGetLastError();
-      b->k3_state = 3;
-    }
-  }
   b->finished = true;
   return QM_OK;
 }
@@ -1860,13 +1823,6 @@ int qm_device_zero(qm_ctx* c, void* dst, size_t bytes) {
 extern "C" int qm_path_stats_total(qm_ctx* c, int64_t* out) {
   if (!c || !out) return fail(QM_E_INVAL, "qm_path_stats_total: NULL");
   memcpy(out, c->path_total, sizeof c->path_total);
-  return QM_OK;
-}
-
-extern "C" int qm_batch_compact_form(qm_batch* b, int32_t* state, float* ms2) {
-  if (!b || !state) return fail(QM_E_INVAL, "qm_batch_compact_form: NULL");
-  state[0] = b->k3_state == 0 ? ((b->k3_run & 1) ^ 1) : b->k3_state; state[1] = b->k3_state == 2 ? b->k3_form : b->k3_state == 0 ? ((b->k3_run & 1) ^ 1) : 1;
-  if (ms2) { ms2[0] = b->k3_ms[0]; ms2[1] = b->k3_ms[1]; }
   return QM_OK;
 }
 

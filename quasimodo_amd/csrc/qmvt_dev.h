@@ -158,8 +158,6 @@ struct CompactParams {
   const uint32_t* vcf_flags;   // written by k_finalize of the same run
   int32_t skip_unsorted;       // 1: leave VCFs flagged unsorted alone (they are redone); 0: compact everything
   int32_t span_base;           // first span of this launch
-  int32_t own_chunks;          // 0: a wave stores its own entries (shared chunks leave in two pieces); 1: whole chunks, completed from the tiles behind (k3_own)
-  int32_t nwin;                // block -> tile mapping: 8 = every XCD owns a contiguous eighth of the launch, 4 / 2 = XCDs share windows, 1 = launch order
 };
 
 // one unsorted VCF inside a sort chunk

@@ -289,11 +289,18 @@ inline void index_line_tail(const uint8_t* s, const uint8_t* p, const uint8_t* l
   }
   L.n = (size_t)(p - s); L.ntab = nt; L.dirty = dirty; L.punct = punct;
 }
-// '#' anywhere, or a quote character: R's read.table (comment.char = "#", quote = "\"'") does not split such a line at its tabs alone
+// a quote character anywhere, or a '#' in front of the last column: R's read.table (comment.char = "#", quote = "\"'") does not split
+// such a line at its tabs alone.  (A '#' INSIDE the last column only shortens that column: the field count stays, and the
+// counting scripts never read it.)
 inline bool r_hostile_line(const uint8_t* s, size_t n) {
-  for (size_t i = 0; i < n; ++i)
-    if (s[i] == '#' || s[i] == '\'' || s[i] == '"') return true;
-  return false;
+  size_t hash = n;                       // first '#'
+  size_t last_tab = 0; bool any_tab = false;
+  for (size_t i = 0; i < n; ++i) {
+    if (s[i] == '\'' || s[i] == '"') return true;
+    if (s[i] == '#' && hash == n) hash = i;
+    if (s[i] == '\t') { last_tab = i; any_tab = true; }
+  }
+  return hash < n && !(any_tab && hash > last_tab);
 }
 #if defined(__x86_64__)
 __attribute__((target("avx2"))) void index_line_avx2(const uint8_t* s, const uint8_t* lim, LineIndex& L) {

@@ -1193,9 +1193,9 @@ static_assert(SPAN_TILES % (K3_WAVES * K3_TILES) == 0, "a workgroup's tiles lie 
 constexpr int K3_PASS = 512;                    // records per pass: 8 per lane
 static_assert(K1_TILE == 2 * K3_PASS, "a tile is two passes");
 constexpr int K3_NPASS = 2 * K3_TILES;
-// A wave stores whole chunks of a list; the chunk that BEGINS among its entries is completed from the tiles behind its own.
-// FP list (dense): 256 entries = the 1 KiB of one store instruction.  TP list (a few per cent of the records): 64 entries = two
-// 128-byte lines, so that completing a chunk does not take a wave through six more passes.
+// A wave stores whole chunks of a list: the chunk that BEGINS among its entries is completed from the ONE tile behind its own
+// (k3_own).  FP list (dense): 256 entries = the 1 KiB of one store instruction.  TP list (a few per cent of the records): 64
+// entries = two 128-byte lines.
 #ifndef K3_FCH_LOG
 #define K3_FCH_LOG 8
 #endif
@@ -1203,9 +1203,8 @@ constexpr int K3_NPASS = 2 * K3_TILES;
 #define K3_TCH_LOG 6
 #endif
 static_assert(K3_FCH_LOG >= 4 && K3_FCH_LOG <= 8 && K3_TCH_LOG >= 4 && K3_TCH_LOG <= 8, "a chunk is whole 64-byte pieces, at most one store instruction");
-#ifndef K3_EXTRA
-#define K3_EXTRA 2                              // passes behind the wave's own whose mask bytes are loaded up front (see k_compact)
-#endif
+constexpr int K3_EXTRA = 2;                     // passes behind the wave's own whose mask bytes it also reads: ONE tile (k3_own's reach)
+static_assert(K3_EXTRA * K3_PASS == K1_TILE, "a wave reaches exactly one tile beyond its own");
 constexpr int K3_BUF = 256 + K3_PASS + 16;      // entries per list: the carried partial chunk, one pass, the slack the unconditional stores run into
 
 // mask byte -> positions of its set bits, ascending, one per byte (64 bits per entry)
@@ -1324,29 +1323,32 @@ __device__ __forceinline__ void k3_drain(K3List& X, int lane) {
   X.g0 = top;
   X.n = left;
 }
-// [lo, hi) of a wave whose own tiles hold the entries [a, a2) of a list that spans [l0, l1).
-// chunks = false (the default): its own entries, [a, a2) -- the 1 KiB chunk two neighbouring waves share leaves in two pieces.
-// chunks = true: the chunks that BEGIN among its entries, whole (the first wave of a VCF, first = true, also takes the list's
-// ragged head): the wave completes its last chunk from the tiles behind its own.  No partial store is left but at the lists'
-// ends -- on physically contiguous batches that alone is worth 1.07 -> 0.78 ms -- for one or two more passes per wave.
+// [lo, hi) of a wave whose own tiles hold the entries [a, a2) of a list that spans [l0, l1): no partial store is left but
+// where a list begins or ends, or where it is so sparse that a chunk does not end within a tile (on physically contiguous
+// batches whole chunks alone are worth 1.07 -> 0.78 ms; same-box medians of 8 processes against waves that store exactly
+// their own entries: 0.726 against 0.766 ms, spread 0.72-0.76 against 0.75-0.80, profiles/r05_compact_form_ab.log).
+//   * The wave OWNS the chunks that begin among its entries (the list's ragged head included, wherever its first entry lies)
+//     and completes the last of them from the tile behind its own, never further: `reach` is the list's offset behind that
+//     tile, so the wave's work is bounded whatever the list holds (a sparse TP list made the first version walk to the end
+//     of its VCF: ADVICE round 4).
+//   * What an owner leaves -- entries of its last chunk beyond its reach -- is stored by the wave whose tiles hold them: the
+//     wave in front (first entry `aprev`, reach `rnext` = the offset behind THIS wave's first tile) owns the chunk that
+//     holds `a` exactly when that chunk begins at or behind `aprev`; an owner further back reaches nothing of this wave.
+// Every wave derives both ends from tile offsets alone, so neighbours agree without talking: every entry leaves exactly once.
 template <int CL>
-__device__ __forceinline__ void k3_own(K3List& X, uint32_t a, uint32_t a2, uint32_t l0, uint32_t l1, bool first, bool chunks) {
-  constexpr uint32_t M = (1u << CL) - 1u;
+__device__ __forceinline__ void k3_own(K3List& X, uint32_t a, uint32_t a2, uint32_t aprev, uint32_t rnext, uint32_t reach, uint32_t l0, uint32_t l1) {
+  constexpr uint32_t M = (1u << CL) - 1u, C = 1u << CL;
+  const uint32_t s = a & ~M;                                   // the chunk that holds entry a
   const uint32_t up = (a + M) & ~M, up2 = (a2 + M) & ~M;
-  X.lo = !chunks ? a : first ? l0 : (up < l1 ? up : l1);
-  X.hi = !chunks ? a2 : (up2 < l1 ? up2 : l1);
-  X.g0 = a & ~M;
-  X.n = a - X.g0;
-}
-
-// Workgroups go round-robin to the 8 XCDs (blockIdx & 7).  nwin = 8: every XCD owns a contiguous eighth of the grid (the lines
-// two neighbouring waves share meet in ONE L2, and every XCD writes one compact window); 4 / 2: two / four XCDs share a window,
-// interleaved inside it; 1: launch order.  A permutation of the grid for any size (the last grid % 8 blocks keep their place).
-__device__ __forceinline__ int k3_block(int nwin) {
-  const int b = (int)blockIdx.x, gm = (int)gridDim.x & ~7;
-  if (nwin <= 1 || b >= gm) return b;
-  const int xcd = b & 7, j = b >> 3, share = 8 / nwin;   // XCDs per window
-  return (xcd % nwin) * (gm / nwin) + j * share + xcd / nwin;
+  const bool head = a == l0;                                   // nothing of the list lies in front of this wave (its ragged first chunk begins here, if anywhere)
+  const bool begins = up < a2 || (head && a2 > a);             // a chunk begins among the wave's entries
+  const uint32_t sb = s > l0 ? s : l0;                         // first entry of the chunk that holds a
+  const bool inherited = !head && s != a && sb >= aprev && sb < a;   // ... which the wave in front owns, and stores as far as it reaches
+  X.lo = inherited ? (s + C < rnext ? s + C : rnext) : a;
+  const uint32_t end = up2 < reach ? up2 : reach;
+  X.hi = begins ? (end < l1 ? end : l1) : a2;
+  X.g0 = s;
+  X.n = a - s;
 }
 
 __global__ __launch_bounds__(64 * K3_WAVES) void k_compact(CompactParams P) {
@@ -1357,10 +1359,10 @@ __global__ __launch_bounds__(64 * K3_WAVES) void k_compact(CompactParams P) {
   constexpr int BPS = SPAN_TILES / (K3_WAVES * K3_TILES);   // workgroups per span
   constexpr int NLUT = (256 + 64 * K3_WAVES - 1) / (64 * K3_WAVES);
   constexpr int NPRE = K3_NPASS + K3_EXTRA;                 // passes whose mask bytes are asked for at the start
-  const int L = k3_block(P.nwin);
+  const int L = (int)blockIdx.x;   // launch order (an XCD-contiguous tile order was measured with the other ownership form only; not kept)
   const SpanDesc sp = P.spans[L / BPS + P.span_base];
   // everything the wave needs is asked for at once, behind the span descriptor: the table, the VCF's flags and list sizes, the
-  // offsets of its first tile and of its successor's, the mask bytes of its passes and of the first few behind them
+  // offsets of its first tile, of its neighbours' and of the tiles behind them, the mask bytes of its passes and of the tile behind
   uint2 lut[NLUT];
 #pragma unroll
   for (int k = 0; k < NLUT; ++k) {
@@ -1372,10 +1374,16 @@ __global__ __launch_bounds__(64 * K3_WAVES) void k_compact(CompactParams P) {
   const bool live = (int64_t)sp.voff + rb < sp.end;
   const int t = live ? sp.tile0 + tl : sp.tile0;
   const bool has_next = live && rb + K3_TILES * K1_TILE < sp.vn;   // another wave of the same VCF follows
+  const bool has_t1 = live && rb + K1_TILE < sp.vn;                // the VCF has a tile behind the wave's first one
+  const bool has_reach = live && rb + (K3_TILES + 1) * K1_TILE < sp.vn;   // ... and one behind the successor's first one
+  const bool first = rb == 0;
   const uint32_t vflags = P.vcf_flags[sp.vcf];
   const uint32_t tp_total = P.vcf_tot[2 * sp.vcf], fp_total = P.vcf_tot[2 * sp.vcf + 1];
   const uint32_t aT = P.tile_tp_off[t], aF = P.tile_fp_off[t];
   const uint32_t aT2 = has_next ? P.tile_tp_off[t + K3_TILES] : tp_total, aF2 = has_next ? P.tile_fp_off[t + K3_TILES] : (uint32_t)sp.vn;
+  const uint32_t pT = first || !live ? 0u : P.tile_tp_off[t - K3_TILES], pF = first || !live ? 0u : P.tile_fp_off[t - K3_TILES];
+  const uint32_t nT = has_t1 ? P.tile_tp_off[t + 1] : tp_total, nF = has_t1 ? P.tile_fp_off[t + 1] : (uint32_t)sp.vn;
+  const uint32_t rT = has_reach ? P.tile_tp_off[t + K3_TILES + 1] : tp_total, rF = has_reach ? P.tile_fp_off[t + K3_TILES + 1] : (uint32_t)sp.vn;
   // mask bytes from the wave's first record to the end of the VCF: whole 64-bit words (bits beyond the last record are clear)
   const int nb = live ? (((sp.vn - rb) + 63) >> 6) * 8 : 0;
   const uint8_t* mp = reinterpret_cast<const uint8_t*>(P.mask_pass) + ((sp.voff + rb) >> 3);
@@ -1393,15 +1401,16 @@ __global__ __launch_bounds__(64 * K3_WAVES) void k_compact(CompactParams P) {
     if (i < 256) *reinterpret_cast<uint2*>(&s_lut[2 * i]) = lut[k];
   }
   asm volatile("" :: "s"(aT), "s"(aF), "s"(aT2), "s"(aF2), "s"(vflags), "s"(tp_total), "s"(fp_total));   // here, not behind the barrier where the compiler would sink these loads to
+  asm volatile("" :: "s"(pT), "s"(pF), "s"(nT), "s"(nF), "s"(rT), "s"(rF));
   __syncthreads();
   // VCFs found out of order by this run are redone by the sort path: their masks and counts are not meaningful yet
   if (!live || (P.skip_unsorted && (vflags & SPANF_UNSORTED))) return;
   K3List T, F;
   T.buf = (k3_ldsp)s_buf[wave][0]; F.buf = (k3_ldsp)s_buf[wave][1];
   T.out = F.out = P.idx + sp.voff;
-  k3_own<K3_TCH_LOG>(T, aT, aT2, 0u, tp_total, rb == 0, P.own_chunks != 0);
-  k3_own<K3_FCH_LOG>(F, aF, aF2, (uint32_t)sp.vn - fp_total, (uint32_t)sp.vn, rb == 0, P.own_chunks != 0);
-  if (T.lo >= T.hi && F.lo >= F.hi) return;                    // no chunk of either list begins among this wave's entries
+  k3_own<K3_TCH_LOG>(T, aT, aT2, pT, nT, rT, 0u, tp_total);
+  k3_own<K3_FCH_LOG>(F, aF, aF2, pF, nF, rF, (uint32_t)sp.vn - fp_total, (uint32_t)sp.vn);
+  if (T.lo >= T.hi && F.lo >= F.hi) return;                    // nothing of either list is this wave's to store
   const int npass_vcf = (nb + 63) >> 6;                        // passes from here to the end of the VCF
   const int npass_own = npass_vcf < K3_NPASS ? npass_vcf : K3_NPASS;
   // One pass: a prefix sum for both lists (FP count in the low half, TP count in the high half: a pass holds 512 records), the
@@ -1426,9 +1435,8 @@ __global__ __launch_bounds__(64 * K3_WAVES) void k_compact(CompactParams P) {
     if (u >= npass_own) break;
     pass(mk[u], mq[u], u, true, true);
   }
-  // The wave's last chunk of a list is completed from the tiles BEHIND its own (the successor leaves the entries in front of its
-  // first chunk boundary alone): passes go on, for the list that still misses entries, until its chunk is whole or the VCF ends.
-  // Dense lists want one more pass at most; a list of a few entries per pass a few more -- the first K3_EXTRA are already here.
+  // The wave's last chunk of a list is completed from the tile BEHIND its own (the successor leaves the entries in front of
+  // its first chunk boundary alone, as far as this wave reaches: k3_own), whose mask bytes are already here.
   int p = npass_own;
   bool wantF = F.g0 + F.n < F.hi, wantT = T.g0 + T.n < T.hi;
 #pragma unroll
@@ -1439,14 +1447,7 @@ __global__ __launch_bounds__(64 * K3_WAVES) void k_compact(CompactParams P) {
       ++p;
     }
   }
-  while (p < npass_vcf && (wantF || wantT)) {      // a list sparse enough to need still more: its bytes one pass at a time
-    const int b = p * 64 + lane;
-    const uint32_t kb = b < nb ? mp[b] : 0u, tb = b < nb ? mt[b] : 0u;
-    pass(kb, tb, p, wantF, wantT);
-    wantF = wantF && F.g0 + F.n < F.hi; wantT = wantT && T.g0 + T.n < T.hi;
-    ++p;
-  }
-  // what is left below hi: only where the list ends (its last, ragged chunk)
+  // what is left below hi: where the list ends, or the wave's reach did (a ragged chunk)
   {
     const uint32_t l = F.lo > F.g0 ? F.lo : F.g0, h = F.hi < F.g0 + F.n ? F.hi : F.g0 + F.n;
     if (h > l) k3_store_part(F, 0u, l, h, lane);

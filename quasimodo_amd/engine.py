@@ -294,14 +294,6 @@ class Batch:
         self._ck(self._L.qm_batch_get_columns(self._h, int(v), _p(pos), _p(ref), _p(alt), _p(qual), _p(flags)))
         return pos, ref, alt, qual, flags
 
-    def compact_form(self):
-        """qm_batch_compact_form: which form of k_compact the batch uses / is trying, and the time of either once tried"""
-        st = np.zeros(2, np.int32)
-        ms = np.zeros(2, np.float32)
-        self._ck(self._L.qm_batch_compact_form(self._h, _p(st), _p(ms)))
-        return {"state": ("trying entries", "trying chunks", "decided", "not tuned")[int(st[0])], "form": ("entries", "chunks")[int(st[1])],
-                "entries_ms": float(ms[0]), "chunks_ms": float(ms[1])}
-
     def path_stats(self):
         """qm_batch_path_stats: where the VCFs the last finish found out of order went"""
         out = np.zeros(len(PATH_NAMES), np.int64)

@@ -140,6 +140,10 @@ def run_rank(jobs, rank, world, backend="nccl", body=None, n_bins=256, alleles=N
         t = t.cpu()                            # rehearsals on one card: gloo sums host tensors
     ops0 = _collectives_so_far()
     allreduce_counters(t)                      # the path's single collective
+    if t.is_cuda:
+        # RCCL only ENQUEUES the sum on the device.  Every rank waits for its own copy here -- a local wait, not a collective --
+        # so that no rank tears its communicator down (destroy_process_group at exit) while a peer's sum is still in flight.
+        torch.cuda.synchronize(t.device)
     out = {"rows": list(zip(mine, local)), "extra": res.get("extra"), "collective": _collective_record(ops0), "paths": res.get("paths")}
     if rank == 0:
         out.update(counters=t.cpu().numpy(), truth_keys=keys, shards=shards)

@@ -22,7 +22,7 @@ def test_header_symbols_exported(qmlib):
     for n in names:
         assert hasattr(qmlib, n), "libqmvt.so does not export %s" % n
     assert sorted(_lib.EXPORTS) == names
-    assert qmlib.qm_abi_version() == 4
+    assert qmlib.qm_abi_version() == 5
 
 
 def test_the_library_says_which_sources_it_was_built_from(qmlib, tmp_path):

@@ -893,15 +893,11 @@ def test_positions_above_what_the_optimistic_pass_saw(engine, oracle):
     b.close()
 
 
-@pytest.mark.parametrize("form", ["entries", "chunks"])
-@pytest.mark.parametrize("windows", ["8", "1"])
-def test_both_forms_of_the_compaction_on_lists_of_every_density(engine, oracle, monkeypatch, form, windows):
-    """k_compact stores a list either entry range by entry range (a wave its own entries) or chunk by chunk (a wave the 1 KiB
-    chunks that begin among its entries, completed from the tiles BEHIND its own -- however far it has to go for them), with the
-    tiles dealt to the XCDs in eighths or in launch order.  The lists are the same: dense and sparse, empty, one
-    entry, everything TP, a handful of kept records at the far ends of a long VCF, ragged sizes."""
-    monkeypatch.setenv("QM_K3_OWN", form)
-    monkeypatch.setenv("QM_K3_WINDOWS", windows)
+def test_the_compaction_on_lists_of_every_density(engine, oracle):
+    """k_compact stores a list chunk by chunk: a wave the chunks that begin among its entries, completed from the ONE tile behind
+    its own; what lies beyond that reach is stored by the wave whose tiles hold it.  The lists must come out whole
+    whatever they hold: dense and sparse, empty, one entry, everything TP, a handful of kept records at the far ends of a long
+    VCF (chunks that no wave completes), TP lines in one half only, ragged sizes."""
     rng = np.random.default_rng(77)
     L = 400000
     truth = random_truth(rng, 30000, L)
@@ -922,10 +918,15 @@ def test_both_forms_of_the_compaction_on_lists_of_every_density(engine, oracle, 
     e = np.zeros(n, bool)
     far = e.copy(); far[[3, n - 2]] = True
     few = e.copy(); few[rng.choice(n, 40, replace=False)] = True
+    half = e.copy(); half[: n // 2] = rng.random(n // 2) < 0.3          # a dense list that stops: the chunk at its end is never whole
+    thin = rng.random(n) < 0.004                                          # a few entries per tile: chunks span many waves
+    edge = e.copy(); edge[np.arange(0, n, 1024)] = True; edge[np.arange(1023, n, 1024)] = True   # the first and last record of every tile
     shapes = [plain(n, ~e, ~e),            # everything kept, everything TP: the FP list is empty
               plain(n, ~e, e),             # everything kept, nothing TP
               plain(n, e, e),              # nothing kept: both lists empty
-              plain(n, far, far),          # two TP lines, at the two ends of the VCF: the wave that owns their chunk walks to the end
+              plain(n, far, far),          # two TP lines, at the two ends of the VCF: the chunk that holds them is nobody's to complete
+              plain(n, ~e, half), plain(n, half, e), plain(n, ~e, thin), plain(n, thin, thin), plain(n, thin, e),
+              plain(n, ~e, edge), plain(n, edge, edge), plain(n, edge, e),
               plain(n, ~e, few),           # a dense FP list, forty TP lines somewhere
               plain(n, few, e),            # forty FP lines, nothing else
               plain(n, rng.random(n) < 0.5, rng.random(n) < 0.5)]
@@ -934,32 +935,6 @@ def test_both_forms_of_the_compaction_on_lists_of_every_density(engine, oracle, 
         check_vcf(oracle, r, c, truth)
     for r, c in zip(res[len(cols):], shapes):
         check_vcf(oracle, r, c, truth2, expect_sorted=True)
-
-
-def test_a_batch_settles_on_a_form_of_the_compaction(engine, oracle):
-    """A batch that fills the chip alternates k_compact's two forms over its first five runs (the first is not counted) and keeps
-    the faster (qm_batch_compact_form); whatever it tries or keeps, the lists are those of the oracle."""
-    b = engine.batch([1_000_000] * 80, [engine.truth_synth(5_000_000, 100_000, 3)] * 80)      # 80 x 62 spans >= 4 096
-    b.synth(5_000_000, 100_000, 3, 3000)
-    seen = []
-    for run in range(6):
-        seen.append(b.compact_form())
-        b.run()
-        b.finish()
-    st = b.compact_form()
-    assert [s["state"] for s in seen[:5]] == ["trying chunks", "trying entries", "trying chunks", "trying entries", "trying chunks"]
-    assert seen[5]["state"] == "decided" and st["state"] == "decided" and st["entries_ms"] > 0 and st["chunks_ms"] > 0
-    assert st["form"] == ("chunks" if st["chunks_ms"] < st["entries_ms"] else "entries")
-    from oracle.synth import synth_truth_keys
-    from quasimodo_amd.engine import SCALAR_NAMES
-    tk = synth_truth_keys(5_000_000, 100_000, 3)
-    for v in (0, 79):
-        cols = b.columns(v)
-        sc = dict(zip(SCALAR_NAMES, b.scalars()[v].tolist()))
-        reg = b.idx(v)
-        res = {"cls": b.cls(v), "roc": b.roc()[v], "scalars": sc, "tp_idx": reg[:sc["tp_lines"]].copy(), "fp_idx": reg[1_000_000 - sc["fp_lines"]:].copy()}
-        check_vcf(oracle, res, cols, tk, expect_sorted=True)
-    b.close()
 
 
 def test_columns_in_one_slab_give_the_same_answers(engine, oracle, monkeypatch):

@@ -52,13 +52,14 @@ def test_weighted_roc_layout(qmlib, tmp_path):
     assert rows[-1][:5] == ["0", "4", "9", "5", "4"] and len(rows) == 31
 
 
-def test_lines_r_read_table_would_not_split_at_tabs_are_counted_and_refused(qmlib, tmp_path, monkeypatch):
+def test_lines_r_read_table_would_not_split_at_tabs_are_counted_and_written_as_r_would(qmlib, tmp_path, monkeypatch, capsys):
     """A6 / A6c are restated from the R text (unpinned: no R here).  R reads <x>.filtered.vcf and the truth file with
     read.table(sep = "\\t", comment.char = "#") and the default quote = "\\"'" (scripts/caller_performance_compare.R:29-39):
-    a '#' inside a data line cuts it, a quote swallows tabs and newlines -- a file R cannot parse then counts as EMPTY (tryCatch,
-    :37-40,101-108).  Hand-derived fixture: the tokenizer counts the KEPT lines holding '#', ' or " (headers and lines the A2
-    filter drops do not matter to R: comment / not in the file), the strict table writers refuse the file, QM_LENIENT=1 writes
-    the tab-split counts."""
+    a '#' in front of the last column cuts the line, a quote swallows tabs and newlines -- a file R cannot parse then counts as
+    EMPTY (tryCatch, :37-40,101-108) and every other file is still counted.  Hand-derived fixture: the tokenizer counts the
+    KEPT lines holding ' or ", or a '#' in front of the last column (headers and lines the A2 filter drops do not matter to R:
+    comment / not in the file); the strict table writers write such a file's row as R's empty vector and warn, strict =
+    "refuse" raises before anything is written, QM_LENIENT=1 writes the tab-split counts."""
     from quasimodo_amd.tables import RTableError, check_r_readable, r_hostile_rows, write_caller_performance, write_snpcall_benchmark
     from quasimodo_amd.vcfio import scan_vcf
     text = (b'##INFO=<ID=DP,Number=1,Type=Integer,Description="Raw depth">\n'      # header: a comment to R, quotes and all
@@ -67,16 +68,19 @@ def test_lines_r_read_table_would_not_split_at_tabs_are_counted_and_refused(qmli
             b'c\t200\t.\tA\tG\t50\tPASS\tDP=9;NOTE="x"\n'                    # kept, balanced quotes in the last column: R drops the quotes only
             b"c\t300\trs#7\tC\tT\t60\tPASS\tDP=1\n"                          # kept, '#' in column 3: R sees 3 fields -> the whole file fails
             b"c\t400\t.\tC\tT\t70\tit's\tDP=1\n"                             # kept, a lone apostrophe: swallows what follows
+            b"c\t450\t.\tC\tT\t70\tPASS\tDP=1;X=#5\n"                        # kept, '#' inside the LAST column: R loses the tail of a column nobody reads
             b"c\t500\t.\tC\tT\t7\tq'#\"\tDP=1\n"                            # QUAL 7: not kept -> not in the filtered file
             b"c\t600\t.\tCA\tT\t90\t'\tDP=1\n")                              # not single-base: not kept
     sv = scan_vcf(text)
-    assert int((sv.flags & 1).sum()) == 4 and sv.n_r_hostile == 3 and sv.first_r_hostile_line == 4
+    assert int((sv.flags & 1).sum()) == 5 and sv.n_r_hostile == 3 and sv.first_r_hostile_line == 4
     assert scan_vcf(b"c\t1\t.\tA\tG\t50\tPASS\tDP=9 %&$! x\n").n_r_hostile == 0   # the coarse vector test (bytes 0x20..0x27) is not the answer
+    assert scan_vcf(b"c#1\t1\t.\tA\tG\t50\tPASS\tDP=9\n").n_r_hostile == 1 and scan_vcf(b"c\t1\t.\tA\tG\t50\tPASS\tDP=9#\n").n_r_hostile == 0
     long = b"c\t1\t.\tA\tG\t50\tPASS\t" + b"D" * 70 + b"'\n"                      # beyond the first 32-byte step of the line index
     assert scan_vcf(long * 3).n_r_hostile == 3
     truth = tmp_path / "t.vcf"
-    truth.write_bytes(b"##x=\"y\"\nc\t100\t.\tA\tG\t30\tPASS\tDP=30;ORIG=a'b\nc\t200\t.\tA\tG\t30\tPASS\tDP=30\n")
-    assert r_hostile_rows(str(truth)) == 1
+    truth.write_bytes(b"##x=\"y\"\nc\t100\t.\tA\tG\t30\tPASS\tDP=30;ORIG=a'b\nc\t200\t.\tA\tG\t30\tPASS\tDP=30\nc\t300\t.\tA\tG\t30\tPASS\tDP=30;K=#1\n"
+                      b"c\t400\tid#\tA\tG\t30\tPASS\tDP=30\n")
+    assert r_hostile_rows(str(truth)) == 2
     ok = {"n_pass": 6, "TP_R": 2, "FP_R": 2, "genomediff": 4, "pure_strain": False, "r_hostile": 0}
     bad = dict(ok, r_hostile=3)
     badt = dict(ok, truth_r_hostile=1)
@@ -84,10 +88,18 @@ def test_lines_r_read_table_would_not_split_at_tabs_are_counted_and_refused(qmli
     assert check_r_readable([("a", ok)]) == []
     for st in (bad, badt):
         with pytest.raises(RTableError, match="read.table"):
-            write_caller_performance(str(tmp_path / "cp.tsv"), [("lofreq", "TA-1-10", ok), ("varscan", "TA-1-10", st)])
+            write_caller_performance(str(tmp_path / "cp.tsv"), [("lofreq", "TA-1-10", ok), ("varscan", "TA-1-10", st)], strict="refuse")
         with pytest.raises(RTableError):
-            write_snpcall_benchmark(str(tmp_path / "sb.txt"), [("lab", st)])
+            write_snpcall_benchmark(str(tmp_path / "sb.txt"), [("lab", st)], strict="refuse")
     assert not (tmp_path / "cp.tsv").exists() and not (tmp_path / "sb.txt").exists()      # refused before anything is written
+    # the default: the reference's per-file tryCatch -- the unreadable file is an empty vector, every other row is written
+    write_caller_performance(str(tmp_path / "cp.tsv"), [("lofreq", "TA-1-10", ok), ("varscan", "TA-1-10", bad), ("clc", "TA-1-10", badt)])
+    assert "varscan/TA-1-10" in capsys.readouterr().err
+    assert (tmp_path / "cp.tsv").read_text().splitlines()[1:] == ["LoFreq\tTA-1-10\t4\t6\t2\t2\t0.333\t0.5\t0.4",
+                                                                   "VarScan2\tTA-1-10\t4\t0\t0\t0\tNA\tNA\tNA",        # :101-108
+                                                                   "CLC\tTA-1-10\t0\t6\t0\t4\t0\tNaN\tNaN"]            # an empty truth vector: :84-99
+    write_snpcall_benchmark(str(tmp_path / "sb.txt"), [("lab", bad), ("lab2", ok)])
+    assert (tmp_path / "sb.txt").read_text().splitlines()[1:] == ["lab\t4\t0\t0\t0\tNA\tNA\tNA", "lab2\t4\t6\t2\t2\t0.333\t0.5\t0.4"]
     monkeypatch.setenv("QM_LENIENT", "1")
     write_caller_performance(str(tmp_path / "cp.tsv"), [("lofreq", "TA-1-10", bad)])
     assert (tmp_path / "cp.tsv").read_text().splitlines()[1] == "LoFreq\tTA-1-10\t4\t6\t2\t2\t0.333\t0.5\t0.4"

@@ -13,9 +13,7 @@ SEED=107 run QM_BUCKET_PARTS=4
 SEED=108 run QM_PIPE_CHUNKS=3 QM_PIPE_MIN_SPANS=1
 SEED=109 run QM_BUCKETX=2
 # round 4: both forms of the compaction, with the tiles in eighths and in launch order (fuzzed batches are too small to tune themselves)
-SEED=110 run QM_K3_OWN=entries QM_K3_WINDOWS=8
-SEED=111 run QM_K3_OWN=chunks QM_K3_WINDOWS=1
-SEED=112 run QM_K3_OWN=chunks QM_K3_WINDOWS=8 QM_BUCKET2=2
-SEED=113 run QM_K3_OWN=entries QM_K3_WINDOWS=1 QM_SORT_PATH=radix
+SEED=112 run QM_BUCKET2=2
+SEED=113 run QM_SORT_PATH=radix
 SEED=114 run QM_COL_SLAB=1280                                   # the columns as pieces of one allocation
 cat $OUT
