@@ -1197,7 +1197,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
       for (int r = 1; r <= 64; ++r) for (int i = 0; i < 16; ++i) sum[i] += pj[16 * r + i];
       if (sum[0] > 0) {
         fprintf(stderr, "dj profile: wgs %.0f;", sum[0]);
-        for (int i = 1; i < 12; ++i) fprintf(stderr, " p%d %.0f", i, sum[i] * 16.0 / sum[0]);
+        for (int i = 1; i < 14; ++i) fprintf(stderr, " p%d %.0f", i, sum[i] * 16.0 / sum[0]);
         fprintf(stderr, " (ticks per workgroup)\n");
       }
     }

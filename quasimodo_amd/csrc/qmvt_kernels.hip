@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "qmvt_dev.h"
 
@@ -3081,6 +3082,390 @@ __global__ __launch_bounds__(DJ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
 }
 
 // ---------------------------------------------------------------------------
+// k_join_lean -- k_join_direct's join of one bucket, rewritten (round 5).
+//
+// What bounded k_join_direct (profiles/r04_pmc_shuffled.json: 123 vector and about as many scalar instructions per record -- a CU
+// issues one of either per clock --, the memory unit stalled 0.5 % of the time; and, once those are gone, tools/ab_shuffled.sh with
+// -DLJ_*: the LIFE of a workgroup -- three dependent memory round trips, five barriers -- with only two workgroups per CU,
+// because one bit per KEY of a bucket is 64 KB of LDS):
+//   * Maps over POSITIONS, not keys: a bucket has at most 2^15 positions, and kept records rarely share one.  W holds two bits
+//     per position -- T (low half of a word, sixteen positions per word): a truth key sits here; S1 (high half): a kept record
+//     sits here -- so ONE returning ds_or per record both marks the record's position and brings back "a truth key sits
+//     here" and "somebody was here before me"; the latter sets the position's bit in S2.  8 + 4 KB instead of 64: four
+//     workgroups per CU hide each other's round trips.
+//   * Distinct kept keys, exactly: a position claimed once is one key (popcount(S1) - popcount(S2)); the records of positions
+//     claimed more than once (a second look, behind a barrier, at S2: repeats, multi-allelic sites, a random record on a
+//     truth position) go through a small exact set.  FP_R = that count - TP_R (the kept keys that are truth keys).
+//   * ONE pass over the records without a branch or an execution mask per record except the histogram's: a wave owns one of
+//     the bucket's eight sub-regions (wave w = sub-region w: a record's address is its lane's, no select chains); slots
+//     beyond the cursor are ZERO entries, inert everywhere (not kept, no bin, no ID '.').  One histogram add per record
+//     (all records by bin): the TP histogram is added to by the hits only, the FP histogram is the difference.
+//   * The records that need a closer look -- on a truth position (8 %), on a position claimed twice (a few per cent) -- are
+//     compacted ONCE per wave (one prefix sum, sixteen masked 8-byte LDS stores) and settled 64 at a time with every lane
+//     busy: exact key through the coarse index, best bin / matched-by-kept state, TP histogram, the input-order TP bit (one
+//     32-bit atomic OR), the exact set.
+//   * Records without a comparable key and host-decided TP lines are rare: a wave that holds one (one OR over its entries'
+//     flag words tells) runs the same pass with two extra masks.
+// Same rows, flags and limits as k_join_direct (QM_JOIN=direct still launches it).
+// ---------------------------------------------------------------------------
+constexpr int LJ_THREADS = 512;
+constexpr int LJ_SET_LOG2 = 11;      // exact set of the keys on positions claimed more than once, and of the kept records without a comparable key
+constexpr uint32_t LJ_RING = 128;    // compacted records per wave and round
+constexpr uint32_t LJ_NOKEY_TAG = 1u << 24;   // (a key inside a bucket is below 2^24)
+#ifndef LJ_WAVES
+#define LJ_WAVES 8
+#endif
+template <int LB>
+__global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_WAVES, 8))) void k_join_lean(HashParams P) {
+  constexpr int PER = 16;                                // records per thread at most: four trips of four
+  constexpr int W_WORDS = LB >= 10 ? (1 << (LB - 8)) : 4;    // sixteen positions per word: T in bits 0..15, S1 in 16..31
+  constexpr int W2_WORDS = LB >= 11 ? (1 << (LB - 9)) : 4;   // S2: a bit per position
+  constexpr int CI_N = LB > DJ_CI_LOG2 ? 1 << (LB - DJ_CI_LOG2) : 1;
+  static_assert(HB_SUB_MAX == 64 * PER && HB_SUBS * 64 == LJ_THREADS && W_WORDS % 4 == 0 && W2_WORDS % 4 == 0, "a wave per sub-region");
+  __shared__ __attribute__((aligned(16))) uint32_t s_W[W_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_W2[W2_WORDS];
+  __shared__ uint32_t s_tk[DJ_TRUTH_MAX + 2];        // the staged truth keys, sorted (absolute keys), 0xffffffff behind the last
+  __shared__ uint16_t s_ci[CI_N];                    // per block of 2^DJ_CI_LOG2 keys: index of its first staged truth key (written for blocks that hold one)
+  __shared__ uint32_t s_ts[DJ_TRUTH_MAX];            // per staged key: best bin + 1 of a '.'-ID match
+  __shared__ uint32_t s_tf[DJ_TRUTH_MAX / 32];       // matched by a kept record (ID ignored)
+  __shared__ uint32_t s_ha[258];                     // every record by bin + 1 (slot 0: no bin; the top bin is counted in registers)
+  __shared__ uint32_t s_htp[130];                    // TP records by bin + 1, two u16 slots per dword
+  __shared__ uint32_t s_hu[128];                     // distinct-truth-key histogram, two u16 bins per dword
+  __shared__ uint32_t s_set[1 << LJ_SET_LOG2];
+  __shared__ __attribute__((aligned(8))) uint2 s_ring[(LJ_THREADS / 64) * LJ_RING];
+  __shared__ uint32_t s_c[8];                        // kept, TP lines, fresh keys of the exact set, matched truth keys, flags, top-bin records, set inserts, S1 - S2 bits
+  const int tid = (int)threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int d = (int)blockIdx.x;
+  const int seg_id = (int)blockIdx.y + P.seg_base;
+  const size_t row = (size_t)seg_id * HB_BUCKETS + (size_t)d;
+#ifdef HB_PROFILE
+  uint32_t* hb_prof = const_cast<uint32_t*>(P.cursor) + (size_t)P.n_seg * HB_BUCKETS * HB_SUBS + (size_t)P.n_seg;
+  unsigned long long hb_t = __builtin_amdgcn_s_memtime();
+  __shared__ uint32_t s_prof[16];
+  if (threadIdx.x < 16) s_prof[threadIdx.x] = 0u;
+#endif
+  const HashRow R = P.rows[row];
+  const uint32_t* cur = P.cursor + row * HB_SUBS;
+  const uint32_t segfl = d == 0 ? P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg_id] : 0u;   // the segment's flags travel in its first row
+  // maps, truth state and histograms are cleared while the descriptor and the cursors are on their way
+  for (int i = tid; i < W_WORDS / 4; i += LJ_THREADS) *reinterpret_cast<uint4*>(&s_W[4 * i]) = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = tid; i < W2_WORDS / 4; i += LJ_THREADS) *reinterpret_cast<uint4*>(&s_W2[4 * i]) = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = tid; i < (1 << LJ_SET_LOG2) / 4; i += LJ_THREADS) *reinterpret_cast<uint4*>(&s_set[4 * i]) = make_uint4(HB_EMPTY, HB_EMPTY, HB_EMPTY, HB_EMPTY);
+  s_ts[tid] = 0u; s_ts[tid + LJ_THREADS] = 0u;
+  if (tid < DJ_TRUTH_MAX / 32) s_tf[tid] = 0u;
+  if (tid < 258) s_ha[tid] = 0u;
+  if (tid < 130) s_htp[tid] = 0u;
+  if (tid < 128) s_hu[tid] = 0u;
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(1))) v4u* gv4p;
+  const gu32p g_tkeys = (gu32p)R.tkeys;
+  const uint32_t cap = R.cap;
+  uint32_t nrec = 0, over = 0, nw = 0;     // wave-uniform (scalar loads); nw: entries of this wave's sub-region
+#pragma unroll
+  for (int k = 0; k < HB_SUBS; ++k) {
+    const uint32_t c = cur[k];
+    over |= c > cap ? 1u : 0u;
+    const uint32_t n = c < cap ? c : cap;
+    nrec += n;
+    nw = wave == k ? n : nw;
+  }
+  const size_t orow = (size_t)seg_id * (size_t)P.out_stride + (size_t)d;   // where the bucket's row goes (allele-extended batches: the second stream's rows follow)
+  uint32_t* oh = P.row_hist + orow * SPAN_HIST_WORDS;
+  if (nrec == 0u) {   // an empty bucket: a row of zeros, nothing else
+    if (tid < 3 * 128) oh[tid] = 0u;
+    if (tid < 8) P.row_scal[orow * 8 + tid] = tid == 5 ? segfl : 0u;
+    return;
+  }
+  over |= (R.shift > (uint32_t)LB || cap > (uint32_t)HB_SUB_MAX) ? 1u : 0u;   // (the host never launches this instantiation for such a segment)
+  const uint32_t shift = R.shift > (uint32_t)LB ? (uint32_t)LB : R.shift;   // 4 <= shift <= LB: a bucket is a whole range of positions
+  const uint32_t kbase = R.kbase;                            // every key of the bucket is >= kbase
+  const uint32_t klast = kbase + ((1u << shift) - 1u);
+  const int tn_all = R.tn;
+  over |= tn_all > DJ_TRUTH_MAX ? 1u : 0u;
+  const int tn = over ? 0 : tn_all;
+  if (over) nw = 0u;
+  // every trip of the thread is in flight before anything else happens.  Lane l of wave w takes the quads l, l + 64, ... of
+  // sub-region w: four consecutive entries, 32 bytes.
+  const gv4p wbase = (gv4p)R.ent + (size_t)wave * (cap >> 1);     // two entries per 16 bytes (cap is even: a power of two)
+  v4u ea[PER / 4], eb[PER / 4];
+  const v4u z4 = {0u, 0u, 0u, 0u};
+  const int ntrips = (int)((nw + 255u) >> 8);                       // wave-uniform
+#pragma unroll
+  for (int g = 0; g < PER / 4; ++g) {
+    const uint32_t q = (uint32_t)g * 64u + (uint32_t)lane;
+    ea[g] = z4; eb[g] = z4;
+    if (4u * q < nw) {
+      ea[g] = __builtin_nontemporal_load(wbase + 2u * q);
+      eb[g] = __builtin_nontemporal_load(wbase + 2u * q + 1u);
+    }
+  }
+  uint32_t tkey0 = 0xffffffffu, tkey1 = 0xffffffffu, tprev0 = 0u, tprev1 = 0u;   // (tprev: the key in front, for the coarse index; 0 is below every bucket's first key that matters)
+  if (tid < tn) tkey0 = g_tkeys[tid];
+  if (tid + LJ_THREADS < tn) tkey1 = g_tkeys[tid + LJ_THREADS];
+  if (tid > 0 && tid < tn) tprev0 = g_tkeys[tid - 1];
+  if (tid + LJ_THREADS < tn) tprev1 = g_tkeys[tid + LJ_THREADS - 1];
+  const int nw4 = (int)(((1u << shift) + 1023u) >> 10);      // 16-byte pieces of W in use (64 positions each); S2 has half as many
+  if (tid < 8) s_c[tid] = tid == 4 ? (segfl | (over ? SPANF_OVERFLOW : 0u)) : 0u;
+  DJ_TICK(1);
+  __syncthreads();
+  DJ_TICK(2);
+  // ---- the truth keys of the bucket's positions: the sorted slice as it is (its keys outside the bucket match nothing), a bit per position inside ----
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int j = tid + h * LJ_THREADS;
+    const uint32_t k = h ? tkey1 : tkey0;
+    const bool in = j < tn && k >= kbase && k <= klast;
+    if (j < tn) s_tk[j] = k;
+    if (in) atomicOr(&s_W[(k - kbase) >> 8], 1u << (((k - kbase) >> 4) & 15u));
+    const uint32_t kp = h ? tprev1 : tprev0;
+    const bool pin = j > 0 && kp >= kbase;                    // (kp <= k <= klast)
+    // the first key of its block of 2^DJ_CI_LOG2 keys names itself in the coarse index (the slice is sorted)
+    if (in && (!pin || ((kp - kbase) >> DJ_CI_LOG2) != ((k - kbase) >> DJ_CI_LOG2))) s_ci[(k - kbase) >> DJ_CI_LOG2] = (uint16_t)j;
+  }
+  if (tid < 2) s_tk[tn + tid] = 0xffffffffu;                 // behind the last staged key: a look-up may read past its key
+  DJ_TICK(3);
+  __syncthreads();
+  DJ_TICK(4);
+  const uint32_t nb = (uint32_t)P.n_bins;
+  int ttop = 0;                                              // largest power of two <= tn
+  if (tn > 0) ttop = 1 << (31 - __clz(tn));
+  uint32_t n_tp = 0, fresh = 0;
+  uint32_t hitm = 0, keptm = 0, top = 0, nkm = 0;            // bit k: record k sits on a truth position (or is a host-decided TP line) / is kept / (rare) is kept without a key
+  // the partly filled quad at the end of the sub-region: what lies behind the cursor there is left over from an earlier run
+#pragma unroll
+  for (int g = 0; g < PER / 4; ++g) {
+    if (nw > (uint32_t)g * 256u && nw < (uint32_t)(g + 1) * 256u) {   // wave-uniform
+      const int left = (int)nw - 4 * (g * 64 + lane);         // entries of the lane's quad in front of the cursor
+      if (left < 4) { eb[g][2] = 0u; eb[g][3] = 0u; }
+      if (left < 3) { eb[g][0] = 0u; eb[g][1] = 0u; }
+      if (left < 2) { ea[g][2] = 0u; ea[g][3] = 0u; }
+      if (left < 1) { ea[g][0] = 0u; ea[g][1] = 0u; }
+    }
+  }
+  uint32_t orall = 0;
+#pragma unroll
+  for (int g = 0; g < PER / 4; ++g) orall |= ea[g][1] | ea[g][3] | eb[g][1] | eb[g][3];
+#ifdef LJ_NO_CAREFUL   // (timing builds only)
+  const bool careful = false;
+#else
+  const bool careful = ballot64((orall & 0x18u) != 0u) != 0ull;   // a record without a key or a host-decided TP line somewhere in the wave
+#endif
+  const bool run = !(s_c[4] & SPANF_OVERFLOW);
+  auto pass = [&](auto tag) {
+    constexpr bool CAREFUL = decltype(tag)::value;
+#pragma unroll
+    for (int g = 0; g < PER / 4; ++g) {
+      if (g < ntrips) {                                        // wave-uniform
+        uint32_t old[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                          // the four returning ORs of the trip first, in flight together
+          const int k = 4 * g + u;
+          const uint32_t elo = u == 0 ? ea[g][0] : u == 1 ? ea[g][2] : u == 2 ? eb[g][0] : eb[g][2];
+          const uint32_t ehi = u == 0 ? ea[g][1] : u == 1 ? ea[g][3] : u == 2 ? eb[g][1] : eb[g][3];
+          uint32_t kb = (ehi >> 1) & 1u;                       // PASS: every entry is a live record, so this is `kept`
+          keptm |= kb << k;
+          if (CAREFUL) {
+            const uint32_t nokey = (ehi >> 3) & 1u;
+            nkm |= (kb & nokey) << k;
+            kb &= ~nokey;
+          }
+          old[u] = atomicOr(&s_W[(elo >> 8) & (uint32_t)(W_WORDS - 1)], kb << (16u + ((elo >> 4) & 15u)));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = 4 * g + u;
+          const uint32_t elo = u == 0 ? ea[g][0] : u == 1 ? ea[g][2] : u == 2 ? eb[g][0] : eb[g][2];
+          const uint32_t ehi = u == 0 ? ea[g][1] : u == 1 ? ea[g][3] : u == 2 ? eb[g][1] : eb[g][3];
+          const uint32_t o = old[u] >> ((elo >> 4) & 15u);
+          uint32_t hit = o & 1u;
+          uint32_t kb = (ehi >> 1) & 1u;
+          if (CAREFUL) {
+            const uint32_t nokey = (ehi >> 3) & 1u;
+            hit = (hit & ~nokey) | ((ehi >> 4) & 1u);          // a TP line by the host's decision is settled too (kept or not: the TP histogram counts it)
+            kb &= ~nokey;
+          }
+          hitm |= hit << k;
+#ifdef LJ_W2_PLAIN
+          atomicOr(&s_W2[(elo >> 9) & (uint32_t)(W2_WORDS - 1)], ((o >> 16) & kb) << ((elo >> 4) & 31u));   // somebody kept was here before: no return value
+#else
+          if ((o >> 16) & kb) atomicOr(&s_W2[(elo >> 9) & (uint32_t)(W2_WORDS - 1)], 1u << ((elo >> 4) & 31u));   // somebody kept was here before (rare: the few lanes it is true for)
+#endif
+          const uint32_t b1 = (elo >> 24) | ((ehi & 1u) << 8);
+          // the saturated top bin, where real QUALs pile up, is counted in a register (the lanes of a wave would serialise on its one address)
+          const bool istop = b1 == nb;
+          top += istop ? 1u : 0u;
+#ifndef LJ_NO_HIST
+          if (!istop) atomicAdd(&s_ha[b1], 1u);
+#endif
+        }
+      }
+    }
+  };
+  DJ_TICK(5);
+  if (run) { if (careful) pass(std::true_type()); else pass(std::false_type()); }
+  DJ_TICK(6);
+  __syncthreads();   // every kept record has marked its position: S2 says which positions were claimed more than once
+  DJ_TICK(7);
+  if (run) {
+    // ---- the second look: kept records (with a key) on positions claimed more than once ----
+    uint32_t collm = 0;
+#pragma unroll
+    for (int g = 0; g < PER / 4; ++g) {
+      if (g < ntrips) {                                        // wave-uniform
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t elo = u == 0 ? ea[g][0] : u == 1 ? ea[g][2] : u == 2 ? eb[g][0] : eb[g][2];
+          collm |= ((s_W2[(elo >> 9) & (uint32_t)(W2_WORDS - 1)] >> ((elo >> 4) & 31u)) & 1u) << (4 * g + u);
+        }
+      }
+    }
+    // the lane's slots in front of the cursor (a zero entry may sit on a truth position: it is not to be settled)
+    uint32_t vmask = 0;
+#pragma unroll
+    for (int g = 0; g < PER / 4; ++g) {
+      const int left = (int)nw - 4 * (g * 64 + lane);
+      vmask |= (left >= 4 ? 15u : left <= 0 ? 0u : (1u << left) - 1u) << (4 * g);
+    }
+    DJ_TICK(8);
+    const uint32_t postm = ((hitm & vmask) | (collm & keptm & ~nkm) | nkm);   // hits, keys to be counted exactly, keyless kept records
+#ifndef LJ_NO_SETTLE
+    // ---- one compaction per wave: a prefix sum over the lanes' counts, sixteen masked 8-byte stores; then 64 at a time ----
+    uint2* const ring = s_ring + (size_t)wave * LJ_RING;
+    uint32_t* const mtp = reinterpret_cast<uint32_t*>(P.mask_tp);
+    const uint32_t cnt = (uint32_t)__popc(postm);
+    uint32_t tot;
+    const uint32_t excl = k3_scan(cnt, tot) - cnt;
+    for (uint32_t w0 = 0; w0 < tot; w0 += LJ_RING) {           // (one round unless a wave holds more than LJ_RING such records)
+      uint32_t slot = excl - w0;                                // may wrap below zero: unsigned compare keeps it out
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const int g = k >> 2, u = k & 3;
+        const uint32_t elo = u == 0 ? ea[g][0] : u == 1 ? ea[g][2] : u == 2 ? eb[g][0] : eb[g][2];
+        const uint32_t ehi = u == 0 ? ea[g][1] : u == 1 ? ea[g][3] : u == 2 ? eb[g][1] : eb[g][3];
+        const bool mine = (postm >> k) & 1u;
+        if (mine && slot < LJ_RING) ring[slot] = make_uint2(elo, ehi);
+        slot += mine ? 1u : 0u;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's own stores, read back by other lanes of the same wave
+      const uint32_t n = tot - w0 < LJ_RING ? tot - w0 : LJ_RING;
+      for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+        const bool act = i0 + (uint32_t)lane < n;
+        uint2 e = make_uint2(0u, 0u);
+        if (act) e = ring[i0 + (uint32_t)lane];
+        const uint32_t elo = e.x, ehi = e.y;
+        const uint32_t v = elo & 0xffffffu, key = kbase + v;
+        const uint32_t b1 = (elo >> 24) | ((ehi & 1u) << 8);
+        const bool kept = (ehi & 2u) != 0u, iddot = (ehi & 4u) != 0u, nokey = (ehi & 8u) != 0u;
+        bool hit = act && !nokey && ((s_W[(v >> 8) & (uint32_t)(W_WORDS - 1)] >> ((v >> 4) & 15u)) & 1u);
+        if (hit) {
+          // a truth key sits on the record's position: is it the record's key?  At or behind the first key of its block
+          int j = (int)s_ci[v >> DJ_CI_LOG2];
+          const uint32_t k0 = s_tk[j], k1 = s_tk[j + 1];
+          if (k0 != key) {
+            if (k1 == key) j = j + 1;
+            else if (k1 < key) { j = lds_lower_bound(s_tk, tn, ttop, key); hit = j < tn && s_tk[j] == key; }
+            else hit = false;
+          }
+          if (hit) {
+            if (iddot && b1) atomicMax(&s_ts[j], b1);
+            if (kept) atomicOr(&s_tf[j >> 5], 1u << (j & 31));
+          }
+        }
+        const bool tpl = act && ((hit && iddot) || (ehi & 0x10u));
+        if (tpl) {
+          atomicAdd(&s_htp[b1 >> 1], 1u << (16u * (b1 & 1u)));
+          if (kept) {
+            n_tp += 1u;
+            const int64_t o = R.src_off + (int64_t)(ehi >> 5);
+            atomicOr(mtp + (o >> 5), 1u << (o & 31));
+          }
+        }
+        // the exact set: a kept key on a position claimed more than once, or a kept record without a key (a key of its own)
+        const bool coll = act && kept && (nokey || ((s_W2[(v >> 9) & (uint32_t)(W2_WORDS - 1)] >> ((v >> 4) & 31u)) & 1u));
+        if (ballot64(coll)) {
+          const uint32_t at = wave_reserve(&s_c[6], coll);
+          if (coll) {
+            if (at >= (1u << LJ_SET_LOG2) / 2u) atomicOr(&s_c[4], SPANF_OVERFLOW);
+            else {
+              bool fr;
+              (void)hb_insert(s_set, LJ_SET_LOG2, nokey ? (v | LJ_NOKEY_TAG) : v, &fr);
+              fresh += fr ? 1u : 0u;
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the ring is read before the next round overwrites it
+    }
+#endif
+  }
+  DJ_TICK(9);
+  // (hipcc turns an LDS atomic add of a per-lane value on ONE address into a serial loop over the 64 lanes: DPP sums instead)
+  uint32_t n_pass = wave_sum((uint32_t)__popc(keptm));
+  n_tp = wave_sum(n_tp);
+  top = wave_sum(top);
+  fresh = wave_sum(fresh);
+  if (lane == 0) {
+    atomicAdd(&s_c[0], n_pass); atomicAdd(&s_c[1], n_tp);
+    if (fresh) atomicAdd(&s_c[2], fresh);
+    if (top) atomicAdd(&s_c[5], top);
+  }
+  // ---- bucket epilogue: positions claimed exactly once, per-entry state -> U histogram and TP_R, counters, the row ----
+  // (S1 and S2 are final since the barrier above: only the exact set and the truth state were written behind it)
+  {
+    int32_t bits = 0;
+    for (int i = tid; i < nw4; i += LJ_THREADS) {
+      const uint4 w = *reinterpret_cast<const uint4*>(&s_W[4 * i]);
+      bits += __popc(w.x >> 16) + __popc(w.y >> 16) + __popc(w.z >> 16) + __popc(w.w >> 16);
+    }
+    for (int i = tid; i < (nw4 + 1) / 2; i += LJ_THREADS) {
+      const uint4 w = *reinterpret_cast<const uint4*>(&s_W2[4 * i]);
+      bits -= __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
+    }
+    const uint32_t b = wave_sum((uint32_t)bits);
+    if (lane == 0 && b) atomicAdd(&s_c[7], b);
+  }
+  DJ_TICK(10);
+  __syncthreads();
+  DJ_TICK(11);
+  uint32_t tpr = 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int j = tid + h * LJ_THREADS;
+    if (j < tn) {
+      const uint32_t mx = s_ts[j];
+      if (mx) atomicAdd(&s_hu[(mx - 1u) >> 1], 1u << (16u * ((mx - 1u) & 1u)));
+      tpr += (s_tf[j >> 5] >> (j & 31)) & 1u;
+    }
+  }
+  tpr = wave_sum(tpr);
+  if (lane == 0 && tpr) atomicAdd(&s_c[3], tpr);
+  __syncthreads();
+  if (tid < 128) {
+    const uint32_t tall = s_c[5];
+    const int b0 = 2 * tid, b1 = 2 * tid + 1;
+    auto get = [&](const uint32_t* t, int slot) { return (t[slot >> 1] >> (16 * (slot & 1))) & 0xffffu; };
+    const uint32_t tp0 = get(s_htp, 1 + b0), tp1 = get(s_htp, 1 + b1);
+    const uint32_t all0 = s_ha[1 + b0] + (b0 == (int)nb - 1 ? tall : 0u), all1 = s_ha[1 + b1] + (b1 == (int)nb - 1 ? tall : 0u);
+    oh[tid] = tp0 | (tp1 << 16);
+    oh[128 + tid] = (all0 - tp0) | ((all1 - tp1) << 16);
+    oh[256 + tid] = s_hu[tid];
+  }
+  if (tid == 0) {
+    uint32_t* sc = P.row_scal + orow * 8;
+    const uint32_t fl = s_c[4];
+    sc[0] = s_c[0]; sc[1] = s_c[1]; sc[2] = s_c[0] - s_c[1]; sc[3] = s_c[3];
+    sc[4] = s_c[7] + s_c[2] - s_c[3];   // distinct kept keys outside the truth set: positions claimed once + the exact set's keys, minus those that are truth keys
+    sc[5] = fl; sc[6] = 0u; sc[7] = 0u;
+  }
+  DJ_TICK(12);
+#ifdef HB_PROFILE
+  __syncthreads();
+#endif
+  DJ_FLUSH();
+}
+
+// ---------------------------------------------------------------------------
 // k_join_ext -- the second stream of an allele-extended batch: the records of a bucket whose REF / ALT are not two single bases
 // (16-byte entries: the ordinary entry with the position's first key, then the two allele codes), joined EXACTLY on
 // (position, REF, ALT) against the extended truth table.  Their 32-bit key cannot stand for them (its nibble is a hash), but a
@@ -3625,6 +4010,12 @@ void launch_classify_hash(const HashParams& P, int nseg, hipStream_t st) {
 void launch_join_direct(const HashParams& P, int nseg, int lb, int nbk, hipStream_t st) {
   if (nseg <= 0) return;
   static const int pad = getenv("QM_DJ_PAD") ? atoi(getenv("QM_DJ_PAD")) : 0;   // experiment: extra (unused) dynamic LDS bounds the workgroups per CU
+  static const bool old = !(getenv("QM_JOIN") && strcmp(getenv("QM_JOIN"), "lean") == 0);   // (QM_JOIN=lean: round 5's kernel, not yet the faster one)
+  if (!old) {
+    if (lb <= 16) hipLaunchKernelGGL((k_join_lean<16>), dim3(nbk, nseg), dim3(LJ_THREADS), pad, st, P);
+    else hipLaunchKernelGGL((k_join_lean<DJ_MAX_SHIFT>), dim3(nbk, nseg), dim3(LJ_THREADS), pad, st, P);
+    return;
+  }
   if (lb <= 16) hipLaunchKernelGGL((k_join_direct<16>), dim3(nbk, nseg), dim3(DJ_THREADS), pad, st, P);
   else hipLaunchKernelGGL((k_join_direct<DJ_MAX_SHIFT>), dim3(nbk, nseg), dim3(DJ_THREADS), pad, st, P);
 }

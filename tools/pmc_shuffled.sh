@@ -16,7 +16,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"].split("(")[0]
-        if any(x in k for x in ("hash", "bucket", "sort_", "tile_counts", "join_direct", "join_ext", "k_part", "k_compact")):
+        if any(x in k for x in ("hash", "bucket", "sort_", "tile_counts", "join_direct", "join_lean", "join_ext", "k_part", "k_compact")):
             agg[k][row["Counter_Name"]] += float(row["Counter_Value"]); cnt[k][row["Counter_Name"]] += 1
 out = {k: {c: v / cnt[k][c] for c, v in sorted(d.items())} for k, d in agg.items()}
 print(json.dumps(out, indent=1))
