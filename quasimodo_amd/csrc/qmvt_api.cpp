@@ -775,6 +775,7 @@ static FinalizeParams finalize_params(qm_batch* b, uint64_t* global) {
   F.flag_summary = nullptr;
   F.parts = 3;
   F.known = nullptr;
+  F.all_hist = nullptr;
   return F;
 }
 static CompactParams compact_params(qm_batch* b) {
@@ -985,8 +986,9 @@ static int ensure_bucket_rows(qm_batch* b, int nv) {
   if (rc == QM_OK) rc = regrow(&b->bk_vflags, &b->cap_bk_vflags, (int64_t)nv, &b->dev_bytes);
   return rc;
 }
-static FinalizeParams bucket_rows_finalize(qm_batch* b) {
+static FinalizeParams bucket_rows_finalize(qm_batch* b, const uint32_t* all_hist) {
   FinalizeParams F = finalize_params(b, nullptr);   // the rows join the per-truth sums only once no bucket is known to have overflowed
+  F.all_hist = all_hist;
   F.vcfs = b->d_bk_vcfs; F.span_hist = b->bk_hist; F.span_scal = b->bk_scal; F.vcf_posor = nullptr;
   F.roc = b->bk_roc; F.scalars = b->bk_rscal; F.vcf_flags = b->bk_vflags;
   F.vcf_tot = nullptr;   // (these "VCFs" are rows of buckets: no tiles, no lists -- and not the main batch's numbering)
@@ -1086,7 +1088,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     if (rc == QM_OK) rc = regrow(&b->d_bk_vcfs, &b->cap_bk_vcfs, (int64_t)nseg, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_ent, &b->cap_bk_ent, bk_ents, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_rows, &b->cap_bk_rowdesc, rows, &b->dev_bytes);
-    if (rc == QM_OK) rc = regrow(&b->bk_cursor, &b->cap_bk_cursor, rows * HB_SUBS + nseg + 32 + 16 * 65, &b->dev_bytes);   // + 32 + 16 * 65: phase clocks of a profiling build
+    if (rc == QM_OK) rc = regrow(&b->bk_cursor, &b->cap_bk_cursor, rows * HB_SUBS + nseg + 32 + 16 * 65 + (int64_t)nseg * SEG_HIST_WORDS, &b->dev_bytes);   // + 32 + 16 * 65: phase clocks of a profiling build
     if (rc == QM_OK) rc = ensure_bucket_rows(b, nseg);
     if (rc == QM_OK && (int64_t)nbt > b->cap_bk_tiles) {
       b->bk_tiles_valid = false;
@@ -1127,18 +1129,22 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
       HIPCHK(hipStreamSynchronize(st));
       b->bk_fake_valid = true;
     }
-    const size_t ncur = ((size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg + 32 + 16 * 65) * 4;
+    const size_t nhist0 = (size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg + 32 + 16 * 65;   // the scatter's per-segment histograms lie behind the cursors, flags and phase clocks
+  const size_t ncur = (nhist0 + (size_t)nseg * SEG_HIST_WORDS) * 4;
     HIPCHK(hipMemsetAsync(b->bk_cursor, 0, ncur, st));
     BucketScatterParams S;
     S.segs = b->d_segs; S.tile_seg = b->d_bk_tile_seg; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
     S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
     S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = nullptr;
     S.xent = xstream ? b->bk_xent : nullptr; S.xcursor = xstream ? b->bk_xcursor : nullptr; S.ext = xstream ? 1 : 0; S.pairs = 0;
+    uint32_t* const seg_hist = direct && join_lean_on() ? b->bk_cursor + nhist0 : nullptr;   // k_join_lean follows: the scatter counts every record by bin
+    S.seg_hist = seg_hist;
     if (xstream) HIPCHK(hipMemsetAsync(b->bk_xcursor, 0, (size_t)nseg * HB_BUCKETS * HB_SUBS * 4, st));
     HashParams H;
     H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
     H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.seg_base = 0;
     H.xrows = xstream ? b->bk_xrows : nullptr; H.xent = b->bk_xent; H.xcursor = b->bk_xcursor; H.out_stride = out_stride; H.ext = xstream ? 1 : 0;
+    H.scatter_hist = seg_hist ? 1 : 0;
     launch_bucket_rows(H, nseg, st);
     // The scatter streams (memory-bound, its SIMDs half idle), the join issues instructions (and hardly waits for memory): in a
     // few segment ranges, the join of one range on the second stream beside the scatter of the next, they fill each other's gaps.
@@ -1180,7 +1186,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
       HIPCHK(hipEventRecord(b->ev_sync[qm_batch::MAX_CHUNKS + 1], aux));
       HIPCHK(hipStreamWaitEvent(st, b->ev_sync[qm_batch::MAX_CHUNKS + 1], 0));
     }
-    launch_finalize(bucket_rows_finalize(b), nseg, st);
+    launch_finalize(bucket_rows_finalize(b, seg_hist), nseg, st);
     HIPCHK(hipGetLastError());
     std::vector<uint32_t> hfl((size_t)nseg);
     HIPCHK(hipMemcpyAsync(hfl.data(), b->bk_vflags, 4 * hfl.size(), hipMemcpyDeviceToHost, st));
@@ -1414,7 +1420,7 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
     if (rc == QM_OK) rc = regrow(&b->d_bk_vcfs, &b->cap_bk_vcfs, (int64_t)nseg, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_ent, &b->cap_bk_ent, bk_ents, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_rows, &b->cap_bk_rowdesc, rows, &b->dev_bytes);
-    if (rc == QM_OK) rc = regrow(&b->bk_cursor, &b->cap_bk_cursor, rows * HB_SUBS + nseg + 32 + 16 * 65, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->bk_cursor, &b->cap_bk_cursor, rows * HB_SUBS + nseg + 32 + 16 * 65 + (int64_t)nseg * SEG_HIST_WORDS, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->d_bk_tile_seg, &b->cap_bk_tiles, nbt, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->d_vparts, &b->cap_vparts, (int64_t)nv, &b->dev_bytes);
     if (rc == QM_OK) rc = ensure_bucket_rows(b, nseg);
@@ -1433,7 +1439,8 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   }   // !same_cnt
   const int nseg = b->last2_nseg;
   const int64_t nbt = b->last2_nbt, nkt = b->last2_nkt;
-  const size_t ncur = ((size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg + 32 + 16 * 65) * 4;
+  const size_t nhist0 = (size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg + 32 + 16 * 65;   // the scatter's per-segment histograms lie behind the cursors, flags and phase clocks
+  const size_t ncur = (nhist0 + (size_t)nseg * SEG_HIST_WORDS) * 4;
   HIPCHK(hipMemsetAsync(b->bk_cursor, 0, ncur, st));
   // --- level 1 scatter, then the one-level path over the partitions: rows, scatter from the level-1 entries, join, rows summed per VCF
   launch_part_scatter(PP, (int)nt1, st);
@@ -1441,14 +1448,16 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   S.segs = b->d_segs; S.tile_seg = b->d_bk_tile_seg; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
   S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
   S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = b->p_ent; S.xent = nullptr; S.xcursor = nullptr; S.ext = 0; S.pairs = 0;
+  uint32_t* const seg_hist = join_lean_on() ? b->bk_cursor + nhist0 : nullptr;
+  S.seg_hist = seg_hist;
   HashParams H;
   H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
   H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.seg_base = 0;
-  H.xrows = nullptr; H.xent = nullptr; H.xcursor = nullptr; H.out_stride = HB_BUCKETS; H.ext = 0;
+  H.xrows = nullptr; H.xent = nullptr; H.xcursor = nullptr; H.out_stride = HB_BUCKETS; H.ext = 0; H.scatter_hist = seg_hist ? 1 : 0;
   launch_bucket_rows(H, nseg, st);
   launch_bucket_scatter(S, (int)nbt, st);
   launch_join_direct(H, nseg, DJ_MAX_SHIFT, HB_BUCKETS, st);
-  launch_finalize(bucket_rows_finalize(b), nseg, st);
+  launch_finalize(bucket_rows_finalize(b, seg_hist), nseg, st);
   HIPCHK(hipGetLastError());
   std::vector<uint32_t> hfl((size_t)nseg);
   HIPCHK(hipMemcpyAsync(hfl.data(), b->bk_vflags, 4 * hfl.size(), hipMemcpyDeviceToHost, st));
@@ -1568,7 +1577,7 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
     if (rc == QM_OK) rc = regrow(&b->d_bk_vcfs, &b->cap_bk_vcfs, (int64_t)nseg, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_ent, &b->cap_bk_ent, bk_ents, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_rows, &b->cap_bk_rowdesc, rows, &b->dev_bytes);
-    if (rc == QM_OK) rc = regrow(&b->bk_cursor, &b->cap_bk_cursor, rows * HB_SUBS + nseg + 32 + 16 * 65, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->bk_cursor, &b->cap_bk_cursor, rows * HB_SUBS + nseg + 32 + 16 * 65 + (int64_t)nseg * SEG_HIST_WORDS, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->d_bk_tile_seg, &b->cap_bk_tiles, nbt, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->d_vparts, &b->cap_vparts, (int64_t)nv, &b->dev_bytes);
     if (rc == QM_OK) rc = ensure_bucket_rows(b, nseg);
@@ -1586,7 +1595,8 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   b->lastx_seg_vcf.resize((size_t)nseg);
   for (int i = 0; i < nseg; ++i) b->lastx_seg_vcf[(size_t)i] = segs[(size_t)i].main_vcf;
   }   // !same
-  const size_t ncur = ((size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg + 32 + 16 * 65) * 4;
+  const size_t nhist0 = (size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg + 32 + 16 * 65;   // the scatter's per-segment histograms lie behind the cursors, flags and phase clocks
+  const size_t ncur = (nhist0 + (size_t)nseg * SEG_HIST_WORDS) * 4;
   HIPCHK(hipMemsetAsync(b->bk_cursor, 0, ncur, st));
   if (xs) HIPCHK(hipMemsetAsync(b->bk_xcursor, 0, (size_t)nseg * HB_BUCKETS * HB_SUBS * 4, st));
   BucketScatterParams S;
@@ -1594,15 +1604,17 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
   S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = nullptr; S.xent = xs ? b->bk_xent : nullptr; S.xcursor = xs ? b->bk_xcursor : nullptr; S.ext = xs ? 1 : 0;
   S.pairs = 1;   // (tiles of single partitions run through the 512-digit instantiation as well)
+  uint32_t* const seg_hist = join_lean_on() ? b->bk_cursor + nhist0 : nullptr;
+  S.seg_hist = seg_hist;
   HashParams H;
   H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
   H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.seg_base = 0;
-  H.xrows = xs ? b->bk_xrows : nullptr; H.xent = b->bk_xent; H.xcursor = b->bk_xcursor; H.out_stride = out_stride; H.ext = xs ? 1 : 0;
+  H.xrows = xs ? b->bk_xrows : nullptr; H.xent = b->bk_xent; H.xcursor = b->bk_xcursor; H.out_stride = out_stride; H.ext = xs ? 1 : 0; H.scatter_hist = seg_hist ? 1 : 0;
   launch_bucket_rows(H, nseg, st);
   launch_bucket_scatter(S, (int)nbt, st);
   launch_join_direct(H, nseg, DJ_MAX_SHIFT, HB_BUCKETS, st);
   if (xs) launch_join_ext(H, nseg, HB_BUCKETS, st);
-  launch_finalize(bucket_rows_finalize(b), nseg, st);
+  launch_finalize(bucket_rows_finalize(b, seg_hist), nseg, st);
   HIPCHK(hipGetLastError());
   std::vector<uint32_t> hfl((size_t)nseg);
   HIPCHK(hipMemcpyAsync(hfl.data(), b->bk_vflags, 4 * hfl.size(), hipMemcpyDeviceToHost, st));

@@ -143,6 +143,10 @@ struct FinalizeParams {
   uint32_t* flag_summary; // or null: host-mapped word, set to 1 if any VCF of the launch carries a flag
   int32_t parts;          // 1 = flags and tile offsets (what k_compact needs), 2 = ROC / scalars / per-truth sums, 3 = both
   const uint8_t* known;   // or null (ClassifyParams.known): a VCF known to be out of order does not raise the summary for being out of order
+  // bucket rows only, or null: [n_vcf][SEG_HIST_WORDS] every first-stream record of the "VCF" (a segment of the bucket path) by
+  // bin + 1, counted by the scatter.  The rows of the first stream (the first HB_BUCKETS rows of the VCF) then hold no FP
+  // histogram: FP = this - the sum of their TP histograms.
+  const uint32_t* all_hist;
 };
 
 struct CompactParams {
@@ -255,7 +259,13 @@ struct BucketScatterParams {
   uint32_t* xcursor;
   int32_t ext;
   int32_t pairs;              // the launch holds tiles whose segment stands for two partitions (SortSeg.part & 4): the 512-digit instantiation
+  // or null.  [n_seg][SEG_HIST_WORDS]: every record that leaves as an ordinary (first-stream) entry counted by bin + 1, per segment
+  // (zeroed with the cursors).  The scatter waits for memory with its SIMDs and its LDS half idle; k_join_lean is bound by
+  // instruction issue: the one histogram that needs no truth set is taken here, the join adds the true positives' and
+  // k_finalize takes the difference (FinalizeParams.all_hist).
+  uint32_t* seg_hist;
 };
+constexpr int SEG_HIST_WORDS = 260;   // slot = bin + 1 (slot 0: records without a bin), up to 256 bins
 // everything k_classify_hash needs to know about one (segment, bucket), laid out by k_bucket_rows before it runs: the
 // workgroup of a bucket lives only a few microseconds, and every dependent load on its way to the data (segment table ->
 // VCF -> truth set -> position index -> keys) would cost it one memory round trip with nothing else to do
@@ -304,6 +314,7 @@ struct HashParams {
   int32_t n_seg;
   int32_t n_bins;
   int32_t seg_base;           // first segment of this launch of k_classify_hash
+  int32_t scatter_hist;       // 1: the scatter counted every record by bin (BucketScatterParams.seg_hist): k_join_lean adds no histogram of its own but the true positives'
 };
 struct SortCols { const int32_t* pos; const int32_t* ref; const int32_t* alt; const float* qual; const uint8_t* flags; };
 
@@ -408,6 +419,7 @@ void launch_synth(const SynthParams& S, int n_vcf, int64_t max_n, hipStream_t st
 void launch_classify_hash(const HashParams& P, int nseg, hipStream_t st);   // segments P.seg_base .. + nseg
 void launch_bucket_rows(const HashParams& P, int nseg, hipStream_t st);
 void launch_join_ext(const HashParams& P, int nseg, int nbk, hipStream_t st);     // the second stream of an allele-extended batch
+bool join_lean_on();
 void launch_join_direct(const HashParams& P, int nseg, int lb, int nbk, hipStream_t st);   // segments P.seg_base .. + nseg, every bucket shift <= lb <= DJ_MAX_SHIFT
 void launch_bucket_scatter(const BucketScatterParams& P, int ntiles, hipStream_t st);   // tiles P.tile_base .. + ntiles; P.l1_ent: from level-1 entries
 void launch_sort_first_hist(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const int32_t* pos_col, uint32_t* hist, uint32_t* orbits,

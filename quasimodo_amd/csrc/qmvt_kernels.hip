@@ -1045,14 +1045,18 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
   // sums).  qm_batch_run launches the two apart, the rows on the second stream beside the compaction; everybody else wants both.
   const bool rows = (P.parts & 2) != 0, offsets = (P.parts & 1) != 0;
   // sum span histograms (thread = bin)
-  uint32_t h0 = 0, h1 = 0, h2 = 0;
+  uint32_t h0 = 0, h1 = 0, h2 = 0, hsub = 0;
   const int hw = tid >> 1, hs = 16 * (tid & 1);   // two u16 bins per dword
   if (rows) {
 #pragma unroll 8
     for (int s = 0; s < vd.nspans; ++s) {   // unrolled: the loads of eight spans are in flight together (10 M-record VCFs have 611 spans)
       const uint32_t* sh = P.span_hist + (size_t)(vd.span0 + s) * SPAN_HIST_WORDS;
-      h0 += (sh[hw] >> hs) & 0xffffu; h1 += (sh[128 + hw] >> hs) & 0xffffu; h2 += (sh[256 + hw] >> hs) & 0xffffu;
+      const uint32_t tp = (sh[hw] >> hs) & 0xffffu;
+      h0 += tp; h1 += (sh[128 + hw] >> hs) & 0xffffu; h2 += (sh[256 + hw] >> hs) & 0xffffu;
+      hsub += s < HB_BUCKETS ? tp : 0u;
     }
+    // bucket rows whose scatter counted every first-stream record by bin: their FP histogram is what is left of it
+    if (P.all_hist && tid < nb) h1 += P.all_hist[(size_t)v * SEG_HIST_WORDS + 1 + tid] - hsub;
   }
   // ROC = suffix sums over the bins (bins at and above n_bins are empty): shuffles inside the wave, the waves' totals through LDS
   {
@@ -1833,6 +1837,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   __shared__ digit_t s_d[BK_TILE];
   __shared__ uint32_t s_cntx[EXT ? NB : 1];      // second stream: records of digit d in the tile, then where its run starts in the sub-region
   __shared__ uint32_t s_flut[16];                // flag_info of the sixteen flag nibbles (pack_record_fast)
+  __shared__ uint32_t s_hall[NB / 256][SEG_HIST_WORDS];   // (P.seg_hist) the tile's first-stream entries by bin + 1, per segment the tile fills
   const int bid = (int)blockIdx.x + P.tile_base;
   const int seg = P.tile_seg[bid];
   const SortSeg sg = P.segs[seg];
@@ -1845,6 +1850,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   if (threadIdx.x < 16) s_prof[threadIdx.x] = 0u;
 #endif
   if (tid < NB) { s_cnt[tid] = 0u; if (EXT) s_cntx[tid] = 0u; }
+  const bool count_all = P.seg_hist != nullptr;
+  if (count_all) for (int i = tid; i < (NB / 256) * SEG_HIST_WORDS; i += 512) (&s_hall[0][0])[i] = 0u;
+  uint32_t top_all = 0, top_all2 = 0;            // records of the saturated top bin (the lanes of a wave would serialise on its one address)
+  const uint32_t nbins = (uint32_t)P.n_bins;
+  // one first-stream entry by bin + 1 (b1 <= n_bins <= 256); digit >= 256: the entry belongs to the next segment (NB = 512)
+  auto count = [&](uint32_t b1, uint32_t d) {
+    if (NB == 512 && d >= 256u) { if (b1 == nbins) ++top_all2; else atomicAdd(&s_hall[NB / 256 - 1][b1], 1u); }
+    else { if (b1 == nbins) ++top_all; else atomicAdd(&s_hall[0][b1], 1u); }
+  };
   if (!L2 && tid >= 256 && tid < 272) s_flut[tid - 256] = flag_info((uint32_t)(tid - 256));
   const uint32_t dlim = NB == 512 && (sg.part & 4) ? 512u : (uint32_t)HB_BUCKETS;   // buckets this tile's segment stands for
   // a whole VCF in one segment (part 0): the host joins and sums only the sg.nbk buckets up to the highest position the optimistic
@@ -1891,6 +1905,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
           const uint32_t v = v27 - (d << shift);
           ent[k] = (uint64_t)v | ((uint64_t)inf13 << 24) | ((uint64_t)(hi >> 8) << 37);
           dr[k] = (d << 16) | atomicAdd(&s_cnt[d], 1u);
+          if (count_all) count(inf13 & 0x1ffu, d);
         }
       }
     }
@@ -1943,6 +1958,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
             const uint32_t v = rel - (d << shift);   // < 2^24: shift <= 24
             ent[k] = (uint64_t)v | ((uint64_t)((inf & 0xfffu) | ((inf >> 12) & 0x1000u)) << 24) | ((uint64_t)(uint32_t)(i4 + u) << 37);
             dr[k] = (d << 16) | atomicAdd(&s_cnt[d], 1u);
+            if (count_all) count(inf & I_BIN1, d);
           } else {   // not two single bases: the second stream (the key's nibble is a hash there: the entry carries the position's first key)
             const uint32_t v = (rel & ~15u) - (d << shift);
             ent[k] = (uint64_t)v | ((uint64_t)((inf & 0xfffu) | ((inf >> 12) & 0x1000u)) << 24) | ((uint64_t)(uint32_t)(i4 + u) << 37);
@@ -1961,9 +1977,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   }
   }   // !L2
   if (segfl) atomicOr(&P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg], segfl);
+  if (count_all) {
+    if (ballot64(top_all != 0u)) { top_all = wave_sum(top_all); if (lane == 0) atomicAdd(&s_hall[0][nbins], top_all); }
+    if (NB == 512 && ballot64(top_all2 != 0u)) { top_all2 = wave_sum(top_all2); if (lane == 0) atomicAdd(&s_hall[NB / 256 - 1][nbins], top_all2); }
+  }
   BKS_TICK(3);
   __syncthreads();
   BKS_TICK(4);
+  if (count_all) {   // the tile's counts join its segment's (the next segment's for the digits 256..511)
+    for (int i = tid; i < (NB / 256) * SEG_HIST_WORDS; i += 512) {
+      const uint32_t c = (&s_hall[0][0])[i];
+      if (c) atomicAdd(&P.seg_hist[(size_t)(seg + i / SEG_HIST_WORDS) * SEG_HIST_WORDS + (size_t)(i % SEG_HIST_WORDS)], c);
+    }
+  }
   // thread d: exclusive scan over the digit counts = tile-local run starts; room for the run in the bucket's sub-region
   uint32_t cnt = 0, incl = 0;
   if (tid < NB) {
@@ -3113,9 +3139,10 @@ constexpr int LJ_SET_LOG2 = 11;      // exact set of the keys on positions claim
 constexpr uint32_t LJ_RING = 128;    // compacted records per wave and round
 constexpr uint32_t LJ_NOKEY_TAG = 1u << 24;   // (a key inside a bucket is below 2^24)
 #ifndef LJ_WAVES
-#define LJ_WAVES 8
+#define LJ_WAVES 6   // 80 VGPRs, three workgroups per CU: with 64 (four per CU) the kernel spills and is 4 % slower (same-box A/B)
 #endif
-template <int LB>
+// HIST = false: the scatter counted every record by bin (HashParams.scatter_hist): no histogram here but the true positives'
+template <int LB, bool HIST>
 __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_WAVES, 8))) void k_join_lean(HashParams P) {
   constexpr int PER = 16;                                // records per thread at most: four trips of four
   constexpr int W_WORDS = LB >= 10 ? (1 << (LB - 8)) : 4;    // sixteen positions per word: T in bits 0..15, S1 in 16..31
@@ -3196,10 +3223,24 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
     const uint32_t q = (uint32_t)g * 64u + (uint32_t)lane;
     ea[g] = z4; eb[g] = z4;
     if (4u * q < nw) {
+#ifdef LJ_PLAIN_LOAD
+      ea[g] = wbase[2u * q]; eb[g] = wbase[2u * q + 1u];
+#else
       ea[g] = __builtin_nontemporal_load(wbase + 2u * q);
       eb[g] = __builtin_nontemporal_load(wbase + 2u * q + 1u);
+#endif
     }
   }
+#ifdef LJ_ONLY_LOAD   // (timing builds only: what does it take to get a bucket's entries into registers, and nothing else?)
+  {
+    uint32_t x = 0;
+#pragma unroll
+    for (int g = 0; g < PER / 4; ++g) x ^= ea[g][0] ^ ea[g][1] ^ ea[g][2] ^ ea[g][3] ^ eb[g][0] ^ eb[g][1] ^ eb[g][2] ^ eb[g][3];
+    if (x == 0x12345678u) oh[tid] = x;
+    if (tid < 8) P.row_scal[orow * 8 + tid] = 0u;
+    return;
+  }
+#endif
   uint32_t tkey0 = 0xffffffffu, tkey1 = 0xffffffffu, tprev0 = 0u, tprev1 = 0u;   // (tprev: the key in front, for the coarse index; 0 is below every bucket's first key that matters)
   if (tid < tn) tkey0 = g_tkeys[tid];
   if (tid + LJ_THREADS < tn) tkey1 = g_tkeys[tid + LJ_THREADS];
@@ -3243,67 +3284,63 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
       if (left < 1) { ea[g][0] = 0u; ea[g][1] = 0u; }
     }
   }
-  uint32_t orall = 0;
+  // Records without a comparable key and host-decided TP lines are rare.  A wave that holds one (one OR over its entries' flag
+  // words tells) rewrites those entries in its registers so that the one pass below needs no mask for them: a keyless record
+  // loses its PASS bit (it marks no position and is counted as kept through nkm), which moves to bit 31 of its flag word for
+  // the settle step; host-decided TP lines are added to the records to be settled afterwards.
+  uint32_t orall = 0, tplm = 0;
 #pragma unroll
   for (int g = 0; g < PER / 4; ++g) orall |= ea[g][1] | ea[g][3] | eb[g][1] | eb[g][3];
-#ifdef LJ_NO_CAREFUL   // (timing builds only)
-  const bool careful = false;
-#else
-  const bool careful = ballot64((orall & 0x18u) != 0u) != 0ull;   // a record without a key or a host-decided TP line somewhere in the wave
+#ifndef LJ_NO_CAREFUL
+  if (ballot64((orall & 0x18u) != 0u)) {
+#pragma unroll
+    for (int g = 0; g < PER / 4; ++g) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t ehi = u == 0 ? ea[g][1] : u == 1 ? ea[g][3] : u == 2 ? eb[g][1] : eb[g][3];
+        const uint32_t nokey = (ehi >> 3) & 1u, kb = (ehi >> 1) & 1u;
+        tplm |= ((ehi >> 4) & 1u) << (4 * g + u);
+        nkm |= (kb & nokey) << (4 * g + u);
+        const uint32_t nhi = nokey ? ((ehi & ~2u) | (kb << 31)) : ehi;
+        if (u == 0) ea[g][1] = nhi; else if (u == 1) ea[g][3] = nhi; else if (u == 2) eb[g][1] = nhi; else eb[g][3] = nhi;
+      }
+    }
+  }
 #endif
   const bool run = !(s_c[4] & SPANF_OVERFLOW);
-  auto pass = [&](auto tag) {
-    constexpr bool CAREFUL = decltype(tag)::value;
+  auto pass = [&]() {
 #pragma unroll
     for (int g = 0; g < PER / 4; ++g) {
       if (g < ntrips) {                                        // wave-uniform
         uint32_t old[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {                          // the four returning ORs of the trip first, in flight together
-          const int k = 4 * g + u;
           const uint32_t elo = u == 0 ? ea[g][0] : u == 1 ? ea[g][2] : u == 2 ? eb[g][0] : eb[g][2];
           const uint32_t ehi = u == 0 ? ea[g][1] : u == 1 ? ea[g][3] : u == 2 ? eb[g][1] : eb[g][3];
-          uint32_t kb = (ehi >> 1) & 1u;                       // PASS: every entry is a live record, so this is `kept`
-          keptm |= kb << k;
-          if (CAREFUL) {
-            const uint32_t nokey = (ehi >> 3) & 1u;
-            nkm |= (kb & nokey) << k;
-            kb &= ~nokey;
-          }
+          const uint32_t kb = (ehi >> 1) & 1u;                 // PASS: every entry is a live record, so this is `kept`
+          keptm |= kb << (4 * g + u);
           old[u] = atomicOr(&s_W[(elo >> 8) & (uint32_t)(W_WORDS - 1)], kb << (16u + ((elo >> 4) & 15u)));
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int k = 4 * g + u;
           const uint32_t elo = u == 0 ? ea[g][0] : u == 1 ? ea[g][2] : u == 2 ? eb[g][0] : eb[g][2];
           const uint32_t ehi = u == 0 ? ea[g][1] : u == 1 ? ea[g][3] : u == 2 ? eb[g][1] : eb[g][3];
           const uint32_t o = old[u] >> ((elo >> 4) & 15u);
-          uint32_t hit = o & 1u;
-          uint32_t kb = (ehi >> 1) & 1u;
-          if (CAREFUL) {
-            const uint32_t nokey = (ehi >> 3) & 1u;
-            hit = (hit & ~nokey) | ((ehi >> 4) & 1u);          // a TP line by the host's decision is settled too (kept or not: the TP histogram counts it)
-            kb &= ~nokey;
+          hitm |= (o & 1u) << (4 * g + u);
+          if ((o >> 16) & (ehi >> 1) & 1u) atomicOr(&s_W2[(elo >> 9) & (uint32_t)(W2_WORDS - 1)], 1u << ((elo >> 4) & 31u));   // somebody kept was here before (rare: the few lanes it is true for)
+          if (HIST) {
+            const uint32_t b1 = (elo >> 24) | ((ehi & 1u) << 8);
+            // the saturated top bin, where real QUALs pile up, is counted in a register (the lanes of a wave would serialise on its one address)
+            const bool istop = b1 == nb;
+            top += istop ? 1u : 0u;
+            if (!istop) atomicAdd(&s_ha[b1], 1u);
           }
-          hitm |= hit << k;
-#ifdef LJ_W2_PLAIN
-          atomicOr(&s_W2[(elo >> 9) & (uint32_t)(W2_WORDS - 1)], ((o >> 16) & kb) << ((elo >> 4) & 31u));   // somebody kept was here before: no return value
-#else
-          if ((o >> 16) & kb) atomicOr(&s_W2[(elo >> 9) & (uint32_t)(W2_WORDS - 1)], 1u << ((elo >> 4) & 31u));   // somebody kept was here before (rare: the few lanes it is true for)
-#endif
-          const uint32_t b1 = (elo >> 24) | ((ehi & 1u) << 8);
-          // the saturated top bin, where real QUALs pile up, is counted in a register (the lanes of a wave would serialise on its one address)
-          const bool istop = b1 == nb;
-          top += istop ? 1u : 0u;
-#ifndef LJ_NO_HIST
-          if (!istop) atomicAdd(&s_ha[b1], 1u);
-#endif
         }
       }
     }
   };
   DJ_TICK(5);
-  if (run) { if (careful) pass(std::true_type()); else pass(std::false_type()); }
+  if (run) pass();
   DJ_TICK(6);
   __syncthreads();   // every kept record has marked its position: S2 says which positions were claimed more than once
   DJ_TICK(7);
@@ -3328,7 +3365,7 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
       vmask |= (left >= 4 ? 15u : left <= 0 ? 0u : (1u << left) - 1u) << (4 * g);
     }
     DJ_TICK(8);
-    const uint32_t postm = ((hitm & vmask) | (collm & keptm & ~nkm) | nkm);   // hits, keys to be counted exactly, keyless kept records
+    const uint32_t postm = (((hitm | tplm) & vmask) | (collm & keptm) | nkm);   // on truth positions (a keyless record there settles as no hit), host-decided TP lines, keys to be counted exactly, keyless kept records
 #ifndef LJ_NO_SETTLE
     // ---- one compaction per wave: a prefix sum over the lanes' counts, sixteen masked 8-byte stores; then 64 at a time ----
     uint2* const ring = s_ring + (size_t)wave * LJ_RING;
@@ -3356,7 +3393,7 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
         const uint32_t elo = e.x, ehi = e.y;
         const uint32_t v = elo & 0xffffffu, key = kbase + v;
         const uint32_t b1 = (elo >> 24) | ((ehi & 1u) << 8);
-        const bool kept = (ehi & 2u) != 0u, iddot = (ehi & 4u) != 0u, nokey = (ehi & 8u) != 0u;
+        const bool kept = (ehi & 0x80000002u) != 0u, iddot = (ehi & 4u) != 0u, nokey = (ehi & 8u) != 0u;   // (bit 31: a kept keyless record, see above)
         bool hit = act && !nokey && ((s_W[(v >> 8) & (uint32_t)(W_WORDS - 1)] >> ((v >> 4) & 15u)) & 1u);
         if (hit) {
           // a truth key sits on the record's position: is it the record's key?  At or behind the first key of its block
@@ -3377,7 +3414,7 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
           atomicAdd(&s_htp[b1 >> 1], 1u << (16u * (b1 & 1u)));
           if (kept) {
             n_tp += 1u;
-            const int64_t o = R.src_off + (int64_t)(ehi >> 5);
+            const int64_t o = R.src_off + (int64_t)((ehi >> 5) & 0x3ffffffu);
             atomicOr(mtp + (o >> 5), 1u << (o & 31));
           }
         }
@@ -3401,7 +3438,7 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
   }
   DJ_TICK(9);
   // (hipcc turns an LDS atomic add of a per-lane value on ONE address into a serial loop over the 64 lanes: DPP sums instead)
-  uint32_t n_pass = wave_sum((uint32_t)__popc(keptm));
+  uint32_t n_pass = wave_sum((uint32_t)__popc(keptm | nkm));
   n_tp = wave_sum(n_tp);
   top = wave_sum(top);
   fresh = wave_sum(fresh);
@@ -3448,7 +3485,7 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
     const uint32_t tp0 = get(s_htp, 1 + b0), tp1 = get(s_htp, 1 + b1);
     const uint32_t all0 = s_ha[1 + b0] + (b0 == (int)nb - 1 ? tall : 0u), all1 = s_ha[1 + b1] + (b1 == (int)nb - 1 ? tall : 0u);
     oh[tid] = tp0 | (tp1 << 16);
-    oh[128 + tid] = (all0 - tp0) | ((all1 - tp1) << 16);
+    oh[128 + tid] = HIST ? (all0 - tp0) | ((all1 - tp1) << 16) : 0u;   // (HIST = false: k_finalize takes the difference from the scatter's counts)
     oh[256 + tid] = s_hu[tid];
   }
   if (tid == 0) {
@@ -4007,13 +4044,24 @@ void launch_classify_hash(const HashParams& P, int nseg, hipStream_t st) {
 }
 // lb: log2 of the widest bucket key range among the launch's segments (SortSeg.pad), <= DJ_MAX_SHIFT
 // nbk: buckets in use at most among the launch's segments (the grid; buckets above a VCF's highest position hold nothing)
+// which bit-map join launch_join_direct launches: k_join_lean unless QM_JOIN=direct (the host side asks too: the scatter counts
+// the histogram of all records only for k_join_lean)
+bool join_lean_on() {
+  static const bool on = !(getenv("QM_JOIN") && strcmp(getenv("QM_JOIN"), "direct") == 0);
+  return on;
+}
 void launch_join_direct(const HashParams& P, int nseg, int lb, int nbk, hipStream_t st) {
   if (nseg <= 0) return;
   static const int pad = getenv("QM_DJ_PAD") ? atoi(getenv("QM_DJ_PAD")) : 0;   // experiment: extra (unused) dynamic LDS bounds the workgroups per CU
-  static const bool old = !(getenv("QM_JOIN") && strcmp(getenv("QM_JOIN"), "lean") == 0);   // (QM_JOIN=lean: round 5's kernel, not yet the faster one)
+  const bool old = !join_lean_on();   // (QM_JOIN=direct: round 3's kernel)
   if (!old) {
-    if (lb <= 16) hipLaunchKernelGGL((k_join_lean<16>), dim3(nbk, nseg), dim3(LJ_THREADS), pad, st, P);
-    else hipLaunchKernelGGL((k_join_lean<DJ_MAX_SHIFT>), dim3(nbk, nseg), dim3(LJ_THREADS), pad, st, P);
+    if (P.scatter_hist) {
+      if (lb <= 16) hipLaunchKernelGGL((k_join_lean<16, false>), dim3(nbk, nseg), dim3(LJ_THREADS), pad, st, P);
+      else hipLaunchKernelGGL((k_join_lean<DJ_MAX_SHIFT, false>), dim3(nbk, nseg), dim3(LJ_THREADS), pad, st, P);
+    } else {
+      if (lb <= 16) hipLaunchKernelGGL((k_join_lean<16, true>), dim3(nbk, nseg), dim3(LJ_THREADS), pad, st, P);
+      else hipLaunchKernelGGL((k_join_lean<DJ_MAX_SHIFT, true>), dim3(nbk, nseg), dim3(LJ_THREADS), pad, st, P);
+    }
     return;
   }
   if (lb <= 16) hipLaunchKernelGGL((k_join_direct<16>), dim3(nbk, nseg), dim3(DJ_THREADS), pad, st, P);
