@@ -1833,8 +1833,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   __shared__ uint32_t s_loc[NB];              // tile-local start of digit d's run
   __shared__ int32_t s_glob[NB];              // place of digit d's run in its sub-region, minus s_loc[d]
   __shared__ uint32_t s_scan[NB / 64 + 1];
-  __shared__ uint64_t s_e[BK_TILE];
-  __shared__ digit_t s_d[BK_TILE];
+  __shared__ __attribute__((aligned(16))) uint64_t s_e[BK_TILE + NB];   // (+ NB: a run of odd length is padded to an even one, see below)
+  __shared__ digit_t s_d[BK_TILE + NB];
   __shared__ uint32_t s_cntx[EXT ? NB : 1];      // second stream: records of digit d in the tile, then where its run starts in the sub-region
   __shared__ uint32_t s_flut[16];                // flag_info of the sixteen flag nibbles (pack_record_fast)
   __shared__ uint32_t s_hall[NB / 256][SEG_HIST_WORDS];   // (P.seg_hist) the tile's first-stream entries by bin + 1, per segment the tile fills
@@ -1990,10 +1990,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
       if (c) atomicAdd(&P.seg_hist[(size_t)(seg + i / SEG_HIST_WORDS) * SEG_HIST_WORDS + (size_t)(i % SEG_HIST_WORDS)], c);
     }
   }
-  // thread d: exclusive scan over the digit counts = tile-local run starts; room for the run in the bucket's sub-region
-  uint32_t cnt = 0, incl = 0;
+  // thread d: exclusive scan over the digit counts = tile-local run starts; room for the run in the bucket's sub-region.
+  // -DBK_PAIRS (measured, not the default): entries leave as PAIRS -- a run is reserved, laid out in LDS and stored at an even
+  // length (an odd one gets a ZERO entry behind its last: inert in every join -- not kept, no bin, no ID '.'), every sub-region
+  // fills from an even place, so a lane stores two neighbouring entries of one run with ONE 16-byte instruction (32 wave-stores
+  // per tile instead of 64; VERDICT 4 priced the store instructions at 0.17 of the kernel's 1.42 ms).  Bit-identical through
+  // every join (tests, 800 fuzz rounds), and the step takes 2.639 / 2.642 ms against 2.631 / 2.635 without (same box,
+  // profiles/r05_scatter_pairs_ab.log): the pads are 1.9 % more entries to write and to join, which eats what the
+  // instructions save.
+  uint32_t cnt = 0, incl = 0, cnt_odd = 0;
   if (tid < NB) {
     cnt = s_cnt[tid];
+#ifdef BK_PAIRS
+    cnt_odd = cnt & 1u;
+#endif
+    cnt += cnt_odd;
     incl = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -2017,6 +2028,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
     s_loc[tid] = loc;
     if (cnt) g = atomicAdd(&P.cursor[((size_t)seg * HB_BUCKETS + tid) * HB_SUBS + sub], cnt);   // (digits 256..511: the next partition's cursors follow)
     if (tid == NB - 1) s_scan[NB / 64] = loc + cnt;
+    if (cnt_odd) { s_e[loc + cnt - 1u] = 0ull; s_d[loc + cnt - 1u] = (digit_t)tid; }   // the pad (the ranks of the run's records end below it)
     if (EXT && NB == 512) {
       cntx2 = s_cntx[tid];
       if (cntx2) gx2 = atomicAdd(&P.xcursor[((size_t)seg * HB_BUCKETS + tid) * HB_SUBS + sub], cntx2);
@@ -2068,6 +2080,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   }
   const int total = (int)s_scan[NB / 64];
   uint64_t* out = P.ent + sg.bk_off;
+#ifdef BK_PAIRS
+  {
+    typedef unsigned long long v2e __attribute__((ext_vector_type(2)));
+    for (int idx = 2 * tid; idx < total; idx += 1024) {   // (total, every run's start and every run's place are even)
+      const uint32_t d = s_d[idx];
+      const int32_t w = s_glob[d] + idx;
+      if (w < sg.bk_cap) *reinterpret_cast<v2e*>(&out[((size_t)d * HB_SUBS + sub) * (size_t)sg.bk_cap + (size_t)w]) = *reinterpret_cast<const v2e*>(&s_e[idx]);   // beyond: the VCF is flagged and redone
+    }
+  }
+#else
   for (int idx = tid; idx < total; idx += 512) {
     const uint32_t d = s_d[idx];
     const int32_t w = s_glob[d] + idx;
@@ -2081,6 +2103,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
     if (w < sg.bk_cap) out[((size_t)d * HB_SUBS + sub) * (size_t)sg.bk_cap + (size_t)w] = s_e[idx];   // beyond: the VCF is flagged and redone
 #endif
   }
+#endif
   BKS_TICK(9);
 #if defined(HB_PROFILE) && defined(BKS_PROFILE)
   __syncthreads();
