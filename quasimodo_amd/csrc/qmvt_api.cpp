@@ -486,6 +486,7 @@ struct qm_batch {
   int64_t lastx_nbt = 0, lastx_nkt = 0;
   std::vector<uint8_t> known;         // per VCF: 1 = out of order, as the last finish found it
   std::vector<uint32_t> known_posor;  // its position bits (vcf_posor of that finish)
+  std::vector<uint32_t> known_nbk;    // 1 + the highest bucket its records reached on the one-level bucket path (0: not known)
   int n_known = 0;
   bool known_dirty = false;           // the device copy is stale
   uint8_t* d_known = nullptr;
@@ -497,6 +498,7 @@ static bool memo_on() {   // read at every run / finish: bench.py times a batch 
   return !e || atoi(e) != 0;
 }
 static void forget_known(qm_batch* b, int v) {   // v < 0: every VCF
+  if (!b->known_nbk.empty()) { if (v < 0) std::fill(b->known_nbk.begin(), b->known_nbk.end(), 0u); else b->known_nbk[(size_t)v] = 0u; }
   if (b->known.empty() || b->n_known == 0) return;
   if (v < 0) { std::fill(b->known.begin(), b->known.end(), (uint8_t)0); b->n_known = 0; b->known_dirty = true; return; }
   if (b->known[(size_t)v]) { b->known[(size_t)v] = 0; --b->n_known; b->known_dirty = true; }
@@ -776,6 +778,7 @@ static FinalizeParams finalize_params(qm_batch* b, uint64_t* global) {
   F.parts = 3;
   F.known = nullptr;
   F.all_hist = nullptr;
+  F.max_spans = 0;
   return F;
 }
 static CompactParams compact_params(qm_batch* b) {
@@ -1088,7 +1091,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     if (rc == QM_OK) rc = regrow(&b->d_bk_vcfs, &b->cap_bk_vcfs, (int64_t)nseg, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_ent, &b->cap_bk_ent, bk_ents, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_rows, &b->cap_bk_rowdesc, rows, &b->dev_bytes);
-    if (rc == QM_OK) rc = regrow(&b->bk_cursor, &b->cap_bk_cursor, rows * HB_SUBS + nseg + 32 + 16 * 65 + (int64_t)nseg * SEG_HIST_WORDS, &b->dev_bytes);   // + 32 + 16 * 65: phase clocks of a profiling build
+    if (rc == QM_OK) rc = regrow(&b->bk_cursor, &b->cap_bk_cursor, rows * HB_SUBS + nseg + 32 + 16 * 65 + (int64_t)nseg * (SEG_HIST_WORDS + 1), &b->dev_bytes);   // + 32 + 16 * 65: phase clocks of a profiling build
     if (rc == QM_OK) rc = ensure_bucket_rows(b, nseg);
     if (rc == QM_OK && (int64_t)nbt > b->cap_bk_tiles) {
       b->bk_tiles_valid = false;
@@ -1130,7 +1133,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
       b->bk_fake_valid = true;
     }
     const size_t nhist0 = (size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg + 32 + 16 * 65;   // the scatter's per-segment histograms lie behind the cursors, flags and phase clocks
-  const size_t ncur = (nhist0 + (size_t)nseg * SEG_HIST_WORDS) * 4;
+  const size_t ncur = (nhist0 + (size_t)nseg * (SEG_HIST_WORDS + 1)) * 4;   // (+ 1: seg_maxd behind the histograms)
     HIPCHK(hipMemsetAsync(b->bk_cursor, 0, ncur, st));
     BucketScatterParams S;
     S.segs = b->d_segs; S.tile_seg = b->d_bk_tile_seg; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
@@ -1139,6 +1142,8 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     S.xent = xstream ? b->bk_xent : nullptr; S.xcursor = xstream ? b->bk_xcursor : nullptr; S.ext = xstream ? 1 : 0; S.pairs = 0;
     uint32_t* const seg_hist = direct && join_lean_on() ? b->bk_cursor + nhist0 : nullptr;   // k_join_lean follows: the scatter counts every record by bin
     S.seg_hist = seg_hist;
+    uint32_t* const seg_maxd = b->bk_cursor + nhist0 + (size_t)nseg * SEG_HIST_WORDS;
+    S.seg_maxd = seg_maxd;
     if (xstream) HIPCHK(hipMemsetAsync(b->bk_xcursor, 0, (size_t)nseg * HB_BUCKETS * HB_SUBS * 4, st));
     HashParams H;
     H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
@@ -1152,9 +1157,11 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     // stream beside the scatter of the next, fill each other's gaps (- 7 %).  k_join_direct is bound by the latency of a
     // workgroup's serial steps and wants every LDS slot of the chip: beside a scatter it only loses (3.06 ms in one piece
     // against 3.11 - 3.22 in 2 - 8 ranges, same box)
+    int nbk_launch = nbk_all;
     int parts = nseg >= 8 && b->ev_sync[0] && !direct ? 4 : 1;
     if (const char* e = getenv("QM_BUCKET_PARTS")) parts = std::max(1, std::min({atoi(e), nseg, (int)qm_batch::MAX_CHUNKS}));
     if (!b->ev_sync[0]) parts = 1;
+    const bool tight_nbk = direct && !xstream && parts == 1 && !getenv("QM_NO_TIGHT_NBK");
     hipStream_t aux = parts > 1 ? b->ctx->aux : st;
     int i0 = 0;
     for (int p = 0; p < parts; ++p) {
@@ -1174,9 +1181,27 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
           HIPCHK(hipStreamWaitEvent(aux, b->ev_sync[p], 0));
         }
         H.seg_base = i0;
+        // The buckets above a VCF's highest position hold nothing, and a workgroup that finds its bucket empty has still held a
+        // slot of its CU for a memory round trip: 40 % of the grid on a 5 Mb genome, whose position BITS (all the optimistic pass
+        // hands over) bound the buckets in use only by 256 -- 0.09 of the step's 2.65 ms (same box).  The scatter notes the
+        // highest bucket it filled per segment (seg_maxd): a batch that ran before remembers it (known_nbk), a new one reads it
+        // back behind the scatter (one small copy and a wait: ~ 30 us for 90).
+        if (tight_nbk) {
+          bool have = memo_on() && !b->known_nbk.empty();
+          uint32_t m = 0;
+          if (have) for (int i = 0; i < nseg && have; ++i) { const uint32_t k = b->known_nbk[(size_t)vs[(size_t)i]]; have = k != 0u; m = std::max(m, k); }
+          if (!have) {
+            std::vector<uint32_t> md((size_t)nseg);
+            HIPCHK(hipMemcpyAsync(md.data(), seg_maxd, 4 * md.size(), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            m = 0;
+            for (uint32_t x : md) m = std::max(m, x);
+          }
+          nbk_launch = (int)std::min<uint32_t>(std::max(m, 1u), (uint32_t)nbk_all);
+        }
         // the join: one bit per key of the bucket in LDS where a bucket's key range allows it (k_join_direct), the hashed
         // tables of k_classify_hash otherwise (QM_JOIN=hash: always)
-        if (direct) launch_join_direct(H, i1 - i0, lb_all, nbk_all, aux);
+        if (direct) launch_join_direct(H, i1 - i0, lb_all, nbk_launch, aux);
         else launch_classify_hash(H, i1 - i0, aux);
         if (xstream) launch_join_ext(H, i1 - i0, nbk_all, aux);
       }
@@ -1186,11 +1211,23 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
       HIPCHK(hipEventRecord(b->ev_sync[qm_batch::MAX_CHUNKS + 1], aux));
       HIPCHK(hipStreamWaitEvent(st, b->ev_sync[qm_batch::MAX_CHUNKS + 1], 0));
     }
-    launch_finalize(bucket_rows_finalize(b, seg_hist), nseg, st);
+    {
+      FinalizeParams F = bucket_rows_finalize(b, seg_hist);
+      if (tight_nbk) F.max_spans = nbk_launch;   // (rows above were not written by this run)
+      launch_finalize(F, nseg, st);
+    }
     HIPCHK(hipGetLastError());
-    std::vector<uint32_t> hfl((size_t)nseg);
+    std::vector<uint32_t> hfl((size_t)nseg), hmd((size_t)nseg, 0u);
     HIPCHK(hipMemcpyAsync(hfl.data(), b->bk_vflags, 4 * hfl.size(), hipMemcpyDeviceToHost, st));
+    if (tight_nbk) HIPCHK(hipMemcpyAsync(hmd.data(), seg_maxd, 4 * hmd.size(), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));   // also makes the host tables above safe to free
+    if (tight_nbk) {
+      for (int i = 0; i < nseg; ++i) if (hmd[(size_t)i] > (uint32_t)nbk_launch) hfl[(size_t)i] |= SPANF_OVERFLOW;   // (a remembered bound that no longer holds: cannot happen while the columns stay the same)
+      if (memo_on()) {
+        if (b->known_nbk.empty()) b->known_nbk.assign((size_t)b->n_vcf, 0u);
+        for (int i = 0; i < nseg; ++i) b->known_nbk[(size_t)vs[(size_t)i]] = std::max(hmd[(size_t)i], 1u);
+      }
+    }
     if (getenv("QM_HB_PROFILE")) {   // kernels built with -DHB_PROFILE: clock ticks per phase, summed over the workgroups
       uint32_t pr[32];
       HIPCHK(hipMemcpy(pr, b->bk_cursor + (size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg, sizeof(pr), hipMemcpyDeviceToHost));
@@ -1420,7 +1457,7 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
     if (rc == QM_OK) rc = regrow(&b->d_bk_vcfs, &b->cap_bk_vcfs, (int64_t)nseg, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_ent, &b->cap_bk_ent, bk_ents, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_rows, &b->cap_bk_rowdesc, rows, &b->dev_bytes);
-    if (rc == QM_OK) rc = regrow(&b->bk_cursor, &b->cap_bk_cursor, rows * HB_SUBS + nseg + 32 + 16 * 65 + (int64_t)nseg * SEG_HIST_WORDS, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->bk_cursor, &b->cap_bk_cursor, rows * HB_SUBS + nseg + 32 + 16 * 65 + (int64_t)nseg * (SEG_HIST_WORDS + 1), &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->d_bk_tile_seg, &b->cap_bk_tiles, nbt, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->d_vparts, &b->cap_vparts, (int64_t)nv, &b->dev_bytes);
     if (rc == QM_OK) rc = ensure_bucket_rows(b, nseg);
@@ -1440,7 +1477,7 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   const int nseg = b->last2_nseg;
   const int64_t nbt = b->last2_nbt, nkt = b->last2_nkt;
   const size_t nhist0 = (size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg + 32 + 16 * 65;   // the scatter's per-segment histograms lie behind the cursors, flags and phase clocks
-  const size_t ncur = (nhist0 + (size_t)nseg * SEG_HIST_WORDS) * 4;
+  const size_t ncur = (nhist0 + (size_t)nseg * (SEG_HIST_WORDS + 1)) * 4;   // (+ 1: seg_maxd behind the histograms)
   HIPCHK(hipMemsetAsync(b->bk_cursor, 0, ncur, st));
   // --- level 1 scatter, then the one-level path over the partitions: rows, scatter from the level-1 entries, join, rows summed per VCF
   launch_part_scatter(PP, (int)nt1, st);
@@ -1449,7 +1486,7 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
   S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = b->p_ent; S.xent = nullptr; S.xcursor = nullptr; S.ext = 0; S.pairs = 0;
   uint32_t* const seg_hist = join_lean_on() ? b->bk_cursor + nhist0 : nullptr;
-  S.seg_hist = seg_hist;
+  S.seg_hist = seg_hist; S.seg_maxd = nullptr;
   HashParams H;
   H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
   H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.seg_base = 0;
@@ -1577,7 +1614,7 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
     if (rc == QM_OK) rc = regrow(&b->d_bk_vcfs, &b->cap_bk_vcfs, (int64_t)nseg, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_ent, &b->cap_bk_ent, bk_ents, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_rows, &b->cap_bk_rowdesc, rows, &b->dev_bytes);
-    if (rc == QM_OK) rc = regrow(&b->bk_cursor, &b->cap_bk_cursor, rows * HB_SUBS + nseg + 32 + 16 * 65 + (int64_t)nseg * SEG_HIST_WORDS, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->bk_cursor, &b->cap_bk_cursor, rows * HB_SUBS + nseg + 32 + 16 * 65 + (int64_t)nseg * (SEG_HIST_WORDS + 1), &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->d_bk_tile_seg, &b->cap_bk_tiles, nbt, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->d_vparts, &b->cap_vparts, (int64_t)nv, &b->dev_bytes);
     if (rc == QM_OK) rc = ensure_bucket_rows(b, nseg);
@@ -1596,7 +1633,7 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   for (int i = 0; i < nseg; ++i) b->lastx_seg_vcf[(size_t)i] = segs[(size_t)i].main_vcf;
   }   // !same
   const size_t nhist0 = (size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg + 32 + 16 * 65;   // the scatter's per-segment histograms lie behind the cursors, flags and phase clocks
-  const size_t ncur = (nhist0 + (size_t)nseg * SEG_HIST_WORDS) * 4;
+  const size_t ncur = (nhist0 + (size_t)nseg * (SEG_HIST_WORDS + 1)) * 4;   // (+ 1: seg_maxd behind the histograms)
   HIPCHK(hipMemsetAsync(b->bk_cursor, 0, ncur, st));
   if (xs) HIPCHK(hipMemsetAsync(b->bk_xcursor, 0, (size_t)nseg * HB_BUCKETS * HB_SUBS * 4, st));
   BucketScatterParams S;
@@ -1605,7 +1642,7 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = nullptr; S.xent = xs ? b->bk_xent : nullptr; S.xcursor = xs ? b->bk_xcursor : nullptr; S.ext = xs ? 1 : 0;
   S.pairs = 1;   // (tiles of single partitions run through the 512-digit instantiation as well)
   uint32_t* const seg_hist = join_lean_on() ? b->bk_cursor + nhist0 : nullptr;
-  S.seg_hist = seg_hist;
+  S.seg_hist = seg_hist; S.seg_maxd = nullptr;
   HashParams H;
   H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
   H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.seg_base = 0;

@@ -147,6 +147,7 @@ struct FinalizeParams {
   // bin + 1, counted by the scatter.  The rows of the first stream (the first HB_BUCKETS rows of the VCF) then hold no FP
   // histogram: FP = this - the sum of their TP histograms.
   const uint32_t* all_hist;
+  int32_t max_spans;      // > 0: only the first max_spans rows of every VCF were written (bucket rows: the buckets that took an entry)
 };
 
 struct CompactParams {
@@ -264,6 +265,8 @@ struct BucketScatterParams {
   // instruction issue: the one histogram that needs no truth set is taken here, the join adds the true positives' and
   // k_finalize takes the difference (FinalizeParams.all_hist).
   uint32_t* seg_hist;
+  uint32_t* seg_maxd;         // or null.  [n_seg] 1 + the highest bucket of the segment that took an entry (zeroed with the cursors): the join need not
+                              // launch a workgroup for the buckets above it (the position bits the optimistic pass saw only bound them by a power of two)
 };
 constexpr int SEG_HIST_WORDS = 260;   // slot = bin + 1 (slot 0: records without a bin), up to 256 bins
 // everything k_classify_hash needs to know about one (segment, bucket), laid out by k_bucket_rows before it runs: the

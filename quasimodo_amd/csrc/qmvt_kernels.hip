@@ -1022,7 +1022,8 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
   __shared__ uint32_t s_scan[256];
   const int v = (int)blockIdx.x + P.vcf_base;
   const int tid = (int)threadIdx.x;
-  const VcfDesc vd = P.vcfs[v];
+  VcfDesc vd = P.vcfs[v];
+  if (P.max_spans > 0 && vd.nspans > P.max_spans) vd.nspans = P.max_spans;
   const int nb = P.n_bins;
 
   // the spans' scalar rows (8 words each: five counters, the flags, the OR of the positions), every thread two or three of
@@ -1984,6 +1985,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   BKS_TICK(3);
   __syncthreads();
   BKS_TICK(4);
+  if (P.seg_maxd && tid < NB) {   // 1 + the highest bucket this tile fills, per wave: one atomic each
+    uint32_t m = s_cnt[tid] ? (uint32_t)(tid & 255) + 1u : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)m, o); m = y > m ? y : m; }
+    if (lane == 0 && m) atomicMax(&P.seg_maxd[seg + (tid >> 8)], m);   // (digits 256..511: the next segment)
+  }
   if (count_all) {   // the tile's counts join its segment's (the next segment's for the digits 256..511)
     for (int i = tid; i < (NB / 256) * SEG_HIST_WORDS; i += 512) {
       const uint32_t c = (&s_hall[0][0])[i];
@@ -4075,6 +4082,7 @@ bool join_lean_on() {
 }
 void launch_join_direct(const HashParams& P, int nseg, int lb, int nbk, hipStream_t st) {
   if (nseg <= 0) return;
+  if (const char* e = getenv("QM_NBK_PROBE")) nbk = atoi(e);   // (timing experiments only: rows beyond are not written)
   static const int pad = getenv("QM_DJ_PAD") ? atoi(getenv("QM_DJ_PAD")) : 0;   // experiment: extra (unused) dynamic LDS bounds the workgroups per CU
   const bool old = !join_lean_on();   // (QM_JOIN=direct: round 3's kernel)
   if (!old) {
