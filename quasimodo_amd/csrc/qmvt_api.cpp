@@ -614,10 +614,10 @@ static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int
   if (rc == QM_OK && !packed) {   // (the scratch batches of the sort path are finalized without it)
     void* h = nullptr;
     void* d = nullptr;
-    if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+    if (hipHostMalloc(&h, 64 + 16 * (size_t)std::max(n_vcf, 1), hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
       b->h_summary = static_cast<uint32_t*>(h);
       b->d_summary = static_cast<uint32_t*>(d);
-      *b->h_summary = 0u;
+      memset(h, 0, 64 + 16 * (size_t)std::max(n_vcf, 1));   // [16 words: the summary][n_vcf flags][n_vcf position bits][n_vcf bucket-row flags][n_vcf highest buckets]: k_finalize's host-mapped mirrors
     } else {   // not fatal: qm_batch_finish then reads the flags back every time
       if (h) (void)hipHostFree(h);
       (void)hipGetLastError();
@@ -778,7 +778,8 @@ static FinalizeParams finalize_params(qm_batch* b, uint64_t* global) {
   F.parts = 3;
   F.known = nullptr;
   F.all_hist = nullptr;
-  F.max_spans = 0;
+  F.row_cap = nullptr;
+  F.host_flags = nullptr; F.host_aux = nullptr;
   return F;
 }
 static CompactParams compact_params(qm_batch* b) {
@@ -859,6 +860,7 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
     FinalizeParams F = finalize_params(b, g);
     F.vcf_base = ck.v0;
     F.flag_summary = b->d_summary;
+    if (b->d_summary) { F.host_flags = b->d_summary + 16; F.host_aux = b->d_summary + 16 + b->n_vcf; }
     if (use_known) F.known = b->d_known;
     // In one piece (the default), the compaction waits only for what it needs of k_finalize -- per-VCF flags and tile offsets --
     // and the rows (ROC, scalars, per-truth sums: 96 MB of span histograms to sum) go to the second stream beside it.
@@ -1150,6 +1152,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.seg_base = 0;
     H.xrows = xstream ? b->bk_xrows : nullptr; H.xent = b->bk_xent; H.xcursor = b->bk_xcursor; H.out_stride = out_stride; H.ext = xstream ? 1 : 0;
     H.scatter_hist = seg_hist ? 1 : 0;
+    H.seg_maxd = nullptr;   // (set below once the launch shape is known)
     launch_bucket_rows(H, nseg, st);
     // The scatter streams (memory-bound, its SIMDs half idle), the join issues instructions (and hardly waits for memory): in a
     // few segment ranges, the join of one range on the second stream beside the scatter of the next, they fill each other's gaps.
@@ -1161,7 +1164,8 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     int parts = nseg >= 8 && b->ev_sync[0] && !direct ? 4 : 1;
     if (const char* e = getenv("QM_BUCKET_PARTS")) parts = std::max(1, std::min({atoi(e), nseg, (int)qm_batch::MAX_CHUNKS}));
     if (!b->ev_sync[0]) parts = 1;
-    const bool tight_nbk = direct && !xstream && parts == 1 && !getenv("QM_NO_TIGHT_NBK");
+    const bool tight_nbk = direct && join_lean_on() && !xstream && parts == 1 && !getenv("QM_NO_TIGHT_NBK");
+    if (tight_nbk) H.seg_maxd = seg_maxd;
     hipStream_t aux = parts > 1 ? b->ctx->aux : st;
     int i0 = 0;
     for (int p = 0; p < parts; ++p) {
@@ -1184,20 +1188,13 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
         // The buckets above a VCF's highest position hold nothing, and a workgroup that finds its bucket empty has still held a
         // slot of its CU for a memory round trip: 40 % of the grid on a 5 Mb genome, whose position BITS (all the optimistic pass
         // hands over) bound the buckets in use only by 256 -- 0.09 of the step's 2.65 ms (same box).  The scatter notes the
-        // highest bucket it filled per segment (seg_maxd): a batch that ran before remembers it (known_nbk), a new one reads it
-        // back behind the scatter (one small copy and a wait: ~ 30 us for 90).
-        if (tight_nbk) {
+        // highest bucket it filled per segment (seg_maxd): the join's workgroups above it leave at once and k_finalize sums no
+        // row of theirs -- no round trip through the host.
+        if (tight_nbk) {   // a batch that ran before remembers the highest bucket of every VCF: nothing is launched above
           bool have = memo_on() && !b->known_nbk.empty();
           uint32_t m = 0;
           if (have) for (int i = 0; i < nseg && have; ++i) { const uint32_t k = b->known_nbk[(size_t)vs[(size_t)i]]; have = k != 0u; m = std::max(m, k); }
-          if (!have) {
-            std::vector<uint32_t> md((size_t)nseg);
-            HIPCHK(hipMemcpyAsync(md.data(), seg_maxd, 4 * md.size(), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            m = 0;
-            for (uint32_t x : md) m = std::max(m, x);
-          }
-          nbk_launch = (int)std::min<uint32_t>(std::max(m, 1u), (uint32_t)nbk_all);
+          if (have) nbk_launch = (int)std::min<uint32_t>(std::max(m, 1u), (uint32_t)nbk_all);
         }
         // the join: one bit per key of the bucket in LDS where a bucket's key range allows it (k_join_direct), the hashed
         // tables of k_classify_hash otherwise (QM_JOIN=hash: always)
@@ -1211,16 +1208,24 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
       HIPCHK(hipEventRecord(b->ev_sync[qm_batch::MAX_CHUNKS + 1], aux));
       HIPCHK(hipStreamWaitEvent(st, b->ev_sync[qm_batch::MAX_CHUNKS + 1], 0));
     }
+    const bool mirrors = b->d_summary != nullptr && nseg <= b->n_vcf;   // (one segment per VCF on this path)
     {
       FinalizeParams F = bucket_rows_finalize(b, seg_hist);
-      if (tight_nbk) F.max_spans = nbk_launch;   // (rows above were not written by this run)
+      if (tight_nbk) F.row_cap = seg_maxd;   // (the rows above were not written by this run)
+      if (mirrors) { F.host_flags = b->d_summary + 16 + 2 * b->n_vcf; F.host_aux = b->d_summary + 16 + 3 * b->n_vcf; }   // (a place of their own: the run's flags may still be unread)
       launch_finalize(F, nseg, st);
     }
     HIPCHK(hipGetLastError());
     std::vector<uint32_t> hfl((size_t)nseg), hmd((size_t)nseg, 0u);
-    HIPCHK(hipMemcpyAsync(hfl.data(), b->bk_vflags, 4 * hfl.size(), hipMemcpyDeviceToHost, st));
-    if (tight_nbk) HIPCHK(hipMemcpyAsync(hmd.data(), seg_maxd, 4 * hmd.size(), hipMemcpyDeviceToHost, st));
+    if (!mirrors) {
+      HIPCHK(hipMemcpyAsync(hfl.data(), b->bk_vflags, 4 * hfl.size(), hipMemcpyDeviceToHost, st));
+      if (tight_nbk) HIPCHK(hipMemcpyAsync(hmd.data(), seg_maxd, 4 * hmd.size(), hipMemcpyDeviceToHost, st));
+    }
     HIPCHK(hipStreamSynchronize(st));   // also makes the host tables above safe to free
+    if (mirrors) {   // k_finalize's host-mapped mirrors: the flags and (row_cap) the highest buckets, no copy
+      memcpy(hfl.data(), b->h_summary + 16 + 2 * b->n_vcf, 4 * hfl.size());
+      if (tight_nbk) memcpy(hmd.data(), b->h_summary + 16 + 3 * b->n_vcf, 4 * hmd.size());
+    }
     if (tight_nbk) {
       for (int i = 0; i < nseg; ++i) if (hmd[(size_t)i] > (uint32_t)nbk_launch) hfl[(size_t)i] |= SPANF_OVERFLOW;   // (a remembered bound that no longer holds: cannot happen while the columns stay the same)
       if (memo_on()) {
@@ -1490,7 +1495,7 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   HashParams H;
   H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
   H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.seg_base = 0;
-  H.xrows = nullptr; H.xent = nullptr; H.xcursor = nullptr; H.out_stride = HB_BUCKETS; H.ext = 0; H.scatter_hist = seg_hist ? 1 : 0;
+  H.xrows = nullptr; H.xent = nullptr; H.xcursor = nullptr; H.out_stride = HB_BUCKETS; H.ext = 0; H.scatter_hist = seg_hist ? 1 : 0; H.seg_maxd = nullptr;
   launch_bucket_rows(H, nseg, st);
   launch_bucket_scatter(S, (int)nbt, st);
   launch_join_direct(H, nseg, DJ_MAX_SHIFT, HB_BUCKETS, st);
@@ -1646,7 +1651,7 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   HashParams H;
   H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
   H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.seg_base = 0;
-  H.xrows = xs ? b->bk_xrows : nullptr; H.xent = b->bk_xent; H.xcursor = b->bk_xcursor; H.out_stride = out_stride; H.ext = xs ? 1 : 0; H.scatter_hist = seg_hist ? 1 : 0;
+  H.xrows = xs ? b->bk_xrows : nullptr; H.xent = b->bk_xent; H.xcursor = b->bk_xcursor; H.out_stride = out_stride; H.ext = xs ? 1 : 0; H.scatter_hist = seg_hist ? 1 : 0; H.seg_maxd = nullptr;
   launch_bucket_rows(H, nseg, st);
   launch_bucket_scatter(S, (int)nbt, st);
   launch_join_direct(H, nseg, DJ_MAX_SHIFT, HB_BUCKETS, st);
@@ -1738,7 +1743,8 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
   std::vector<int> todo;
   if (!nothing_ran && (!b->h_summary || *reinterpret_cast<volatile uint32_t*>(b->h_summary) != 0u)) {   // else: no VCF of the run carries a flag nobody knew of
     std::vector<uint32_t> fl((size_t)b->n_vcf);
-    HIPCHK(hipMemcpy(fl.data(), b->vcf_flags, 4 * fl.size(), hipMemcpyDeviceToHost));
+    if (b->h_summary) memcpy(fl.data(), b->h_summary + 16, 4 * fl.size());   // k_finalize's host-mapped mirror: complete behind the wait above
+    else HIPCHK(hipMemcpy(fl.data(), b->vcf_flags, 4 * fl.size(), hipMemcpyDeviceToHost));
     for (int v = 0; v < b->n_vcf; ++v) {
       if (fl[(size_t)v] & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", v);
       if (fl[(size_t)v] & SPANF_RUNLIMIT)
@@ -1747,7 +1753,8 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
     }
     if (!todo.empty()) {
       std::vector<uint32_t> po((size_t)b->n_vcf);
-      HIPCHK(hipMemcpy(po.data(), b->vcf_posor, 4 * po.size(), hipMemcpyDeviceToHost));
+      if (b->h_summary) memcpy(po.data(), b->h_summary + 16 + b->n_vcf, 4 * po.size());
+      else HIPCHK(hipMemcpy(po.data(), b->vcf_posor, 4 * po.size(), hipMemcpyDeviceToHost));
       for (int v : todo) posor[(size_t)v] = po[(size_t)v];
       b->path_stats[QM_PATH_UNSORTED] += (int64_t)todo.size();
       const int rc = redo_unsorted(b, todo, posor, st);

@@ -147,7 +147,12 @@ struct FinalizeParams {
   // bin + 1, counted by the scatter.  The rows of the first stream (the first HB_BUCKETS rows of the VCF) then hold no FP
   // histogram: FP = this - the sum of their TP histograms.
   const uint32_t* all_hist;
-  int32_t max_spans;      // > 0: only the first max_spans rows of every VCF were written (bucket rows: the buckets that took an entry)
+  const uint32_t* row_cap;   // bucket rows only, or null: [n_vcf] 1 + the highest bucket of the segment that took an entry (the scatter's seg_maxd): the rows
+                             // above it were not written (k_join_lean leaves at once for them), and hold nothing
+  // or null: host-mapped mirrors [n_vcf] of vcf_flags and of vcf_posor (bucket rows: of row_cap), written beside the device copies so
+  // that the host reads them behind its wait for the stream without a copy of its own (two round trips of a first-seen step)
+  uint32_t* host_flags;
+  uint32_t* host_aux;
 };
 
 struct CompactParams {
@@ -318,6 +323,7 @@ struct HashParams {
   int32_t n_bins;
   int32_t seg_base;           // first segment of this launch of k_classify_hash
   int32_t scatter_hist;       // 1: the scatter counted every record by bin (BucketScatterParams.seg_hist): k_join_lean adds no histogram of its own but the true positives'
+  const uint32_t* seg_maxd;   // or null: BucketScatterParams.seg_maxd of the scatter in front -- the workgroups of the buckets above leave at once (k_join_lean)
 };
 struct SortCols { const int32_t* pos; const int32_t* ref; const int32_t* alt; const float* qual; const uint8_t* flags; };
 

@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
   const int v = (int)blockIdx.x + P.vcf_base;
   const int tid = (int)threadIdx.x;
   VcfDesc vd = P.vcfs[v];
-  if (P.max_spans > 0 && vd.nspans > P.max_spans) vd.nspans = P.max_spans;
+  if (P.row_cap) { const int cap = (int)P.row_cap[v] > 1 ? (int)P.row_cap[v] : 1; if (vd.nspans > cap) vd.nspans = cap; }
   const int nb = P.n_bins;
 
   // the spans' scalar rows (8 words each: five counters, the flags, the OR of the positions), every thread two or three of
@@ -1096,6 +1096,10 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
       if (P.vcf_posor) P.vcf_posor[v] = s_or;
       const uint32_t out = fl & (SPANF_UNSORTED | SPANF_BADPOS | SPANF_RUNLIMIT | SPANF_OVERFLOW);
       P.vcf_flags[v] = out;
+      if (P.host_flags) {
+        __hip_atomic_store(P.host_flags + v, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(P.host_aux + v, P.row_cap ? P.row_cap[v] : s_or, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       if (out && P.flag_summary && !(out == SPANF_UNSORTED && P.known && P.known[v])) __hip_atomic_store(P.flag_summary, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-mapped: tells qm_batch_finish that the per-VCF flags are worth a copy
     }
   }
@@ -3196,6 +3200,12 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
   const int d = (int)blockIdx.x;
   const int seg_id = (int)blockIdx.y + P.seg_base;
   const size_t row = (size_t)seg_id * HB_BUCKETS + (size_t)d;
+  // The buckets above the segment's highest position hold nothing (40 % of the grid on a 5 Mb genome: the position BITS the
+  // optimistic pass hands over bound the buckets in use only by a power of two).  The scatter noted the highest bucket it filled:
+  // the workgroups above leave behind ONE scalar load (a workgroup that waits for its descriptor and cursors to find its bucket
+  // empty holds a slot of its CU for a whole memory round trip), k_finalize sums no row of theirs (FinalizeParams.row_cap).
+  // Bucket 0 always stays: it carries the segment's flags.
+  if (P.seg_maxd && d > 0 && (uint32_t)d >= P.seg_maxd[seg_id]) return;
 #ifdef HB_PROFILE
   uint32_t* hb_prof = const_cast<uint32_t*>(P.cursor) + (size_t)P.n_seg * HB_BUCKETS * HB_SUBS + (size_t)P.n_seg;
   unsigned long long hb_t = __builtin_amdgcn_s_memtime();
