@@ -40,11 +40,19 @@ def ensure_bundle(data_dir):
     with tarfile.open(tarball, "r:gz") as tf:
         try:
             tf.extractall(parent, filter="data")   # (members that would leave `parent` are refused)
-        except TypeError:                           # a Python without extraction filters
+        except TypeError:                           # a Python without extraction filters: the same refusals by hand
             root = os.path.realpath(parent)
+            inside = lambda p: p == root or p.startswith(root + os.sep)     # ('.' and './' members of `tar -C dir .` resolve to the root itself)
             for m in tf.getmembers():
-                if not os.path.realpath(os.path.join(parent, m.name)).startswith(root + os.sep) or m.issym() or m.islnk():
+                dest = os.path.realpath(os.path.join(parent, m.name))
+                if not inside(dest):
                     raise WorkflowError("%s: member %s would be written outside %s" % (tarball, m.name, parent))
+                if m.issym() or m.islnk():          # a link is fine as long as what it points at stays inside
+                    target = m.linkname if m.islnk() else os.path.join(os.path.dirname(m.name), m.linkname)
+                    if os.path.isabs(m.linkname) or not inside(os.path.realpath(os.path.join(parent, target))):
+                        raise WorkflowError("%s: link %s points outside %s" % (tarball, m.name, parent))
+                elif not (m.isfile() or m.isdir()):
+                    raise WorkflowError("%s: member %s is neither a file, a directory nor a link" % (tarball, m.name))
             tf.extractall(parent)
     if not os.path.isdir(data_dir):
         raise WorkflowError("%s does not hold a directory %s" % (tarball, os.path.basename(data_dir)))

@@ -186,6 +186,49 @@ def test_the_bundle_is_unpacked_when_data_snp_is_absent(tmp_path, monkeypatch, o
     assert not (tmp_path / "escaped.txt").exists()
 
 
+def test_the_bundle_unpacks_on_a_python_without_extraction_filters(tmp_path, monkeypatch, qmlib):
+    """The fallback of workflow.ensure_bundle (tarfile.extractall without `filter=`): an archive made with `tar -C data .` carries a
+    '.' member that resolves to the directory itself, and links inside the tree are harmless -- the reference's `tar -xzvf`
+    (rules/load_config.smk:30) takes both; a member or a link that leaves the directory is refused."""
+    import tarfile
+    from quasimodo_amd import workflow
+    real = tarfile.TarFile.extractall
+
+    def old_python(self, path=".", members=None, **kw):
+        if "filter" in kw:
+            raise TypeError("extractall() got an unexpected keyword argument 'filter'")
+        return real(self, path, members)
+
+    monkeypatch.setattr(tarfile.TarFile, "extractall", old_python)
+    src = tmp_path / "src"
+    (src / "snp" / "vcf" / "clc").mkdir(parents=True)
+    (src / "snp" / "vcf" / "clc" / "TA-1-10.AD169.clc.vcf").write_text("#x\n")
+    os.symlink("clc", src / "snp" / "vcf" / "alias")                      # a link that stays inside
+    data = tmp_path / "data"
+    data.mkdir()
+    with tarfile.open(data / "snp.tar.gz", "w:gz") as tf:
+        tf.add(str(src), arcname=".")                                     # members '.', './snp', './snp/vcf', ...
+    assert workflow.ensure_bundle(str(data / "snp")) == str(data / "snp")
+    assert (data / "snp" / "vcf" / "clc" / "TA-1-10.AD169.clc.vcf").read_text() == "#x\n" and os.path.islink(data / "snp" / "vcf" / "alias")
+    for kind in ("member", "link"):
+        evil = tmp_path / ("evil_" + kind)
+        (evil / "s" / "snp").mkdir(parents=True)
+        (evil / "data").mkdir()
+        (tmp_path / "x.txt").write_text("x")
+        with tarfile.open(evil / "data" / "snp.tar.gz", "w:gz") as tf:
+            tf.add(str(evil / "s" / "snp"), arcname="snp")
+            if kind == "member":
+                tf.add(str(tmp_path / "x.txt"), arcname="../escaped.txt")
+            else:
+                ti = tarfile.TarInfo("snp/out")
+                ti.type = tarfile.SYMTYPE
+                ti.linkname = "../../.."
+                tf.addfile(ti)
+        with pytest.raises(workflow.WorkflowError, match="outside"):
+            workflow.ensure_bundle(str(evil / "data" / "snp"))
+        assert not (evil / "escaped.txt").exists()
+
+
 def test_vareval_from_the_config_file_alone(tmp_path, monkeypatch, oracle, qmlib):
     """run_benchmark.py:153-166 + rules/load_config_custom.smk:3 + eval_variant_custom.smk:3-34: what the command line leaves out
     comes from config/customize_data.yaml (paths relative to the workflow's directory; command-line paths relative to the
