@@ -426,6 +426,9 @@ struct qm_batch {
   std::vector<int> last2_vs;            // the chunk these tables were built for, and its counts: a batch run again with the same
   std::vector<uint32_t> last2_cnt;      // VCFs out of order keeps them on the device (as last_segs does on the one-level path)
   int last2_nseg = 0;
+  bool last2_halves = false;          // a VCF of the chunk has more than 2^24 records (BucketScatterParams.l1_half)
+  uint32_t* p_half = nullptr;
+  int64_t cap_p_half = 0;
   int64_t last2_nbt = 0, last2_nkt = 0;
   int64_t cap_p_segs = 0, cap_p_tiles = 0, cap_p_cnt = 0, cap_p_off = 0, cap_p_cursor = 0, cap_p_flags = 0, cap_p_ent = 0, cap_vsegs = 0;
   // throw-away outputs of the rescan after a sort (kept: an allocation per finish costs more than the rescan)
@@ -513,7 +516,7 @@ static void batch_free(qm_batch* b) {
 #endif
   if (b->col_slab) { (void)hipFree(b->col_slab); b->pos = b->ref = b->alt = nullptr; b->qual = nullptr; b->flags = nullptr; }
   void* ptrs[] = {b->pkey, b->pinf, b->pos, b->ref, b->alt, b->qual, b->flags, b->mask_pass, b->mask_tp, b->idx, b->tile_tp, b->tile_fp,
-                  b->tile_tp_off, b->tile_fp_off, b->vcf_tot, b->span_hist, b->span_scal, b->vcf_flags, b->vcf_posor, b->bk_hist, b->bk_scal, b->d_bk_vcfs, b->bk_ent, b->bk_cursor, b->d_bk_tile_seg, b->bk_rows, b->bk_xent, b->bk_xcursor, b->bk_xrows, b->bk_roc, b->bk_rscal, b->bk_vflags, b->p_segs, b->p_tile_seg, b->p_cnt, b->p_off, b->p_cursor, b->p_flags, b->p_ent, b->d_vsegs, b->d_vparts, b->rs_roc, b->rs_scal, b->rs_flags, b->roc, b->global_acc,
+                  b->tile_tp_off, b->tile_fp_off, b->vcf_tot, b->span_hist, b->span_scal, b->vcf_flags, b->vcf_posor, b->bk_hist, b->bk_scal, b->d_bk_vcfs, b->bk_ent, b->bk_cursor, b->d_bk_tile_seg, b->bk_rows, b->bk_xent, b->bk_xcursor, b->bk_xrows, b->bk_roc, b->bk_rscal, b->bk_vflags, b->p_segs, b->p_tile_seg, b->p_cnt, b->p_off, b->p_half, b->p_cursor, b->p_flags, b->p_ent, b->d_vsegs, b->d_vparts, b->rs_roc, b->rs_scal, b->rs_flags, b->roc, b->global_acc,
                   b->scalars, b->d_vcfs, b->d_spans, b->d_tile_vcf, b->cls_scratch, b->sk[0], b->sk[1], b->sv[0],
                   b->sv[1], b->si[0], b->si[1], b->shist, b->sorbits, b->d_segs, b->d_tile_seg, b->d_ktile_seg, b->d_ktile_local, b->d_known};
   for (void* p : ptrs) (void)hipFree(p);
@@ -1143,7 +1146,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = nullptr;
     S.xent = xstream ? b->bk_xent : nullptr; S.xcursor = xstream ? b->bk_xcursor : nullptr; S.ext = xstream ? 1 : 0; S.pairs = 0;
     uint32_t* const seg_hist = direct && join_lean_on() ? b->bk_cursor + nhist0 : nullptr;   // k_join_lean follows: the scatter counts every record by bin
-    S.seg_hist = seg_hist;
+    S.seg_hist = seg_hist; S.l1_half = nullptr;
     uint32_t* const seg_maxd = b->bk_cursor + nhist0 + (size_t)nseg * SEG_HIST_WORDS;
     S.seg_maxd = seg_maxd;
     if (xstream) HIPCHK(hipMemsetAsync(b->bk_xcursor, 0, (size_t)nseg * HB_BUCKETS * HB_SUBS * 4, st));
@@ -1331,7 +1334,7 @@ static bool bucket2_takes(const qm_batch* b, int64_t n) {
   if (const char* e = getenv("QM_SORT_PATH")) if (strcmp(e, "radix") == 0) return false;
   if (const char* e = getenv("QM_BUCKET2")) if (atoi(e) == 0) return false;
   if (join_hash_forced()) return false;
-  if (n > ((int64_t)1 << P2_INDEX_BITS)) return false;
+  if (n > (int64_t)P2_MAX_HALVES << P2_INDEX_BITS) return false;   // (VCFs above 2^24 records: in runs of 2^24, level-1 segments of their own)
   if (const char* e = getenv("QM_BUCKET2")) if (atoi(e) == 2) return n > 0;   // tests and tools/gpu_fuzz.py: every unsorted VCF takes the two levels
   return !bucket_path_takes(b, n) && n >= HB_MIN_RECORDS;
 }
@@ -1345,28 +1348,43 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   for (int i = 0; i < nv; ++i) tids[(size_t)i] = b->L.vcfs[(size_t)vs[(size_t)i]].truth;
   int rc = ensure_bucket_rows(b, nv);
   if (rc != QM_OK) return rc;
-  // --- level 1: descriptors, tile map, counting pass
-  std::vector<PartSeg> ps((size_t)nv);
+  // --- level 1: descriptors, tile map, counting pass.  A level-1 entry has 24 index bits: a VCF above 2^24 records is dealt out in
+  //     HALVES -- runs of 2^24 records, each a level-1 segment of its own (own counts, own regions, indices relative to its first
+  //     record) -- whose regions lie one behind the other inside every partition of the VCF, so that a partition still is ONE run of
+  //     entries for the second level, which adds the half's base back (BucketScatterParams.l1_half).
+  constexpr int64_t HALF = (int64_t)1 << P2_INDEX_BITS;
+  std::vector<PartSeg> ps;
+  std::vector<int> half_vcf, vcf_half0((size_t)nv + 1, 0);   // VCF (index into vs) of every half; first half of every VCF
   std::vector<int32_t> ptile;
   int64_t ent_total = 0, nt1 = 0;
   const bool build1 = b->last2_vs != vs;   // the level-1 tables depend on the chunk's VCFs only
+  bool any_halves = false;
   for (int i = 0; i < nv; ++i) {
     const VcfDesc& d = b->L.vcfs[(size_t)vs[(size_t)i]];
-    PartSeg& g = ps[(size_t)i];
-    g.src_off = d.off; g.n = d.n; g.ent_off = ent_total; g.tile0 = (int32_t)nt1; g.main_vcf = vs[(size_t)i];
-    const int64_t t = (d.n + BK_TILE - 1) / BK_TILE;
-    if (build1) ptile.insert(ptile.end(), (size_t)t, (int32_t)i);
-    nt1 += t;
+    vcf_half0[(size_t)i] = (int)ps.size();
+    const int nh = (int)std::max<int64_t>(1, (d.n + HALF - 1) / HALF);
+    any_halves = any_halves || nh > 1;
+    for (int h = 0; h < nh; ++h) {
+      PartSeg g;
+      g.src_off = d.off + (int64_t)h * HALF; g.n = std::min<int64_t>(HALF, d.n - (int64_t)h * HALF); g.ent_off = ent_total; g.tile0 = (int32_t)nt1; g.main_vcf = vs[(size_t)i];
+      const int64_t t = (g.n + BK_TILE - 1) / BK_TILE;
+      if (build1) ptile.insert(ptile.end(), (size_t)t, (int32_t)ps.size());
+      nt1 += t;
+      ps.push_back(g);
+      half_vcf.push_back(i);
+    }
     ent_total += d.n + 2 * P2_PARTS;   // every partition starts on a 16-byte boundary: at most one entry of padding each
   }
+  vcf_half0[(size_t)nv] = (int)ps.size();
+  const int nh_all = (int)ps.size();
   if (nt1 > INT32_MAX) return fail(QM_E_LIMIT, "bucket path: too many tiles");
   constexpr int NC = P2_PARTS * P2_SUBS;
-  if (rc == QM_OK) rc = regrow(&b->p_segs, &b->cap_p_segs, (int64_t)nv, &b->dev_bytes);
+  if (rc == QM_OK) rc = regrow(&b->p_segs, &b->cap_p_segs, (int64_t)nh_all, &b->dev_bytes);
   if (rc == QM_OK) rc = regrow(&b->p_tile_seg, &b->cap_p_tiles, nt1, &b->dev_bytes);
-  if (rc == QM_OK) rc = regrow(&b->p_cnt, &b->cap_p_cnt, (int64_t)nv * NC, &b->dev_bytes);
-  if (rc == QM_OK) rc = regrow(&b->p_off, &b->cap_p_off, (int64_t)nv * (NC + 1), &b->dev_bytes);
-  if (rc == QM_OK) rc = regrow(&b->p_cursor, &b->cap_p_cursor, (int64_t)nv * NC, &b->dev_bytes);
-  if (rc == QM_OK) rc = regrow(&b->p_flags, &b->cap_p_flags, (int64_t)nv, &b->dev_bytes);
+  if (rc == QM_OK) rc = regrow(&b->p_cnt, &b->cap_p_cnt, (int64_t)nh_all * NC, &b->dev_bytes);
+  if (rc == QM_OK) rc = regrow(&b->p_off, &b->cap_p_off, (int64_t)nh_all * (NC + 1), &b->dev_bytes);
+  if (rc == QM_OK) rc = regrow(&b->p_cursor, &b->cap_p_cursor, (int64_t)nh_all * NC, &b->dev_bytes);
+  if (rc == QM_OK) rc = regrow(&b->p_flags, &b->cap_p_flags, (int64_t)nh_all, &b->dev_bytes);
   if (rc == QM_OK) rc = regrow(&b->p_ent, &b->cap_p_ent, ent_total + 64, &b->dev_bytes);
   if (rc != QM_OK) return rc;
   const bool same_vs = b->last2_vs == vs;
@@ -1375,25 +1393,26 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
     HIPCHK(hipMemcpyAsync(b->p_segs, ps.data(), sizeof(PartSeg) * ps.size(), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(b->p_tile_seg, ptile.data(), 4 * ptile.size(), hipMemcpyHostToDevice, st));
   }
-  HIPCHK(hipMemsetAsync(b->p_cnt, 0, (size_t)nv * NC * 4, st));
-  HIPCHK(hipMemsetAsync(b->p_cursor, 0, (size_t)nv * NC * 4, st));
-  HIPCHK(hipMemsetAsync(b->p_flags, 0, (size_t)nv * 4, st));
+  HIPCHK(hipMemsetAsync(b->p_cnt, 0, (size_t)nh_all * NC * 4, st));
+  HIPCHK(hipMemsetAsync(b->p_cursor, 0, (size_t)nh_all * NC * 4, st));
+  HIPCHK(hipMemsetAsync(b->p_flags, 0, (size_t)nh_all * 4, st));
   PartParams PP;
   PP.segs = b->p_segs; PP.tile_seg = b->p_tile_seg; PP.pos = b->pos; PP.ref = b->ref; PP.alt = b->alt; PP.qual = b->qual; PP.flags = b->flags;
   PP.cnt = b->p_cnt; PP.off = b->p_off; PP.cursor = b->p_cursor; PP.segflags = b->p_flags; PP.ent = b->p_ent;
-  PP.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); PP.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp); PP.n_seg = nv; PP.n_bins = b->n_bins;
+  PP.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); PP.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp); PP.n_seg = nh_all; PP.n_bins = b->n_bins;
   launch_part_hist(PP, (int)nt1, st);
-  std::vector<uint32_t> cnt((size_t)nv * NC), pfl((size_t)nv);
+  std::vector<uint32_t> cnt((size_t)nh_all * NC), pfl((size_t)nh_all);
   HIPCHK(hipMemcpyAsync(cnt.data(), b->p_cnt, 4 * cnt.size(), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(pfl.data(), b->p_flags, 4 * pfl.size(), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));   // (also: the host tables above may go)
-  for (int i = 0; i < nv; ++i)
-    if (pfl[(size_t)i] & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", vs[(size_t)i]);
+  for (int hh = 0; hh < nh_all; ++hh)
+    if (pfl[(size_t)hh] & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", vs[(size_t)half_vcf[(size_t)hh]]);
   // --- exact regions; one level-2 segment per (VCF, partition in use).  The same VCFs with the same counts as last time (a batch
   //     run again): every table below is still on the device
   const bool same_cnt = same_vs && b->last2_cnt == cnt && !b->last2_cnt.empty();
   if (!same_cnt) {
-  std::vector<uint32_t> off((size_t)nv * (NC + 1));
+  std::vector<uint32_t> off((size_t)nh_all * (NC + 1));
+  std::vector<uint32_t> half_off;   // [segment][4]: where the entries of the VCF's 2nd, 3rd, 4th half begin inside the segment's run
   std::vector<SortSeg> segs;
   std::vector<VcfDesc> fake;
   std::vector<SortSeg> vsegs((size_t)nv);
@@ -1404,16 +1423,22 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
     const VcfDesc& d = b->L.vcfs[(size_t)vs[(size_t)i]];
     uint32_t run = 0;
     const int seg0 = (int)segs.size();
+    const int h0 = vcf_half0[(size_t)i], h1 = vcf_half0[(size_t)i + 1];
     for (int p = 0; p < P2_PARTS; ++p) {
       run = (run + 1u) & ~1u;
       const uint32_t start = run;
-      for (int k = 0; k < P2_SUBS; ++k) { off[(size_t)i * (NC + 1) + (size_t)p * P2_SUBS + k] = run; run += cnt[(size_t)i * NC + (size_t)p * P2_SUBS + k]; }
+      uint32_t hb[4] = {0u, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+      for (int hh = h0; hh < h1; ++hh) {   // the halves' regions of the partition one behind the other
+        hb[hh - h0] = run - start;
+        for (int k = 0; k < P2_SUBS; ++k) { off[(size_t)hh * (NC + 1) + (size_t)p * P2_SUBS + k] = run; run += cnt[(size_t)hh * NC + (size_t)p * P2_SUBS + k]; }
+      }
       const int64_t np = (int64_t)run - start;
       if (np == 0) continue;
+      half_off.insert(half_off.end(), hb, hb + 4);
       if (np > (int64_t)HB_BUCKETS * HB_MAX_RECORDS * 13 / 16) return QM_OK;   // all 256 buckets of a partition are in use: more than 6 656 records per bucket on average will not fit 8 x 1 024 (not for this path: *taken stays false)
       SortSeg g;
       memset(&g, 0, sizeof g);
-      g.src_off = d.off; g.koff = ps[(size_t)i].ent_off + start; g.n = np;
+      g.src_off = d.off; g.koff = ps[(size_t)h0].ent_off + start; g.n = np;   // (the halves of a VCF share its level-1 region)
       g.main_vcf = vs[(size_t)i]; g.sub_vcf = i; g.main_tile0 = d.tile0;
       g.pad = DJ_MAX_SHIFT; g.nbk = HB_BUCKETS; g.key_base = (uint32_t)p << P2_SHIFT;
       int64_t want = np / (128 * HB_SUBS) * 3 / 2 + 16, cap2 = 16;
@@ -1430,7 +1455,7 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
       fake.push_back(f);
       segs.push_back(g);
     }
-    off[(size_t)i * (NC + 1) + NC] = run;
+    for (int hh = h0; hh < h1; ++hh) off[(size_t)hh * (NC + 1) + NC] = run;
     SortSeg& vg = vsegs[(size_t)i];
     memset(&vg, 0, sizeof vg);
     vg.src_off = d.off; vg.n = d.n; vg.main_vcf = vs[(size_t)i]; vg.sub_vcf = seg0; vg.main_tile0 = d.tile0;
@@ -1465,9 +1490,12 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
     if (rc == QM_OK) rc = regrow(&b->bk_cursor, &b->cap_bk_cursor, rows * HB_SUBS + nseg + 32 + 16 * 65 + (int64_t)nseg * (SEG_HIST_WORDS + 1), &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->d_bk_tile_seg, &b->cap_bk_tiles, nbt, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->d_vparts, &b->cap_vparts, (int64_t)nv, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->p_half, &b->cap_p_half, (int64_t)nseg * 4, &b->dev_bytes);
     if (rc == QM_OK) rc = ensure_bucket_rows(b, nseg);
   }
   if (rc != QM_OK) return rc;
+  b->last2_halves = any_halves;
+  HIPCHK(hipMemcpyAsync(b->p_half, half_off.data(), 4 * half_off.size(), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->p_off, off.data(), 4 * off.size(), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->d_segs, segs.data(), sizeof(SortSeg) * segs.size(), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->d_vsegs, vsegs.data(), sizeof(SortSeg) * vsegs.size(), hipMemcpyHostToDevice, st));
@@ -1491,7 +1519,7 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
   S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = b->p_ent; S.xent = nullptr; S.xcursor = nullptr; S.ext = 0; S.pairs = 0;
   uint32_t* const seg_hist = join_lean_on() ? b->bk_cursor + nhist0 : nullptr;
-  S.seg_hist = seg_hist; S.seg_maxd = nullptr;
+  S.seg_hist = seg_hist; S.seg_maxd = nullptr; S.l1_half = b->last2_halves ? b->p_half : nullptr;
   HashParams H;
   H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
   H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.seg_base = 0;
@@ -1647,7 +1675,7 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = nullptr; S.xent = xs ? b->bk_xent : nullptr; S.xcursor = xs ? b->bk_xcursor : nullptr; S.ext = xs ? 1 : 0;
   S.pairs = 1;   // (tiles of single partitions run through the 512-digit instantiation as well)
   uint32_t* const seg_hist = join_lean_on() ? b->bk_cursor + nhist0 : nullptr;
-  S.seg_hist = seg_hist; S.seg_maxd = nullptr;
+  S.seg_hist = seg_hist; S.seg_maxd = nullptr; S.l1_half = nullptr;
   HashParams H;
   H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
   H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.seg_base = 0;

@@ -212,7 +212,8 @@ constexpr int DJ_MAX_SHIFT = 19;         // k_join_direct: a bucket's key range 
 constexpr int P2_SHIFT = DJ_MAX_SHIFT + 8;    // 27
 constexpr int P2_PARTS = 32;                  // 2^32 keys / 2^27
 constexpr int P2_SUBS = 8;                    // sub-regions of a partition: tile g of the launch fills sub-region g % 8 (one per XCD), each with a cursor
-constexpr int P2_INDEX_BITS = 24;             // a level-1 entry holds the record's index inside its VCF
+constexpr int P2_INDEX_BITS = 24;             // a level-1 entry holds the record's index inside its half of the VCF (the whole VCF up to 2^24 records)
+constexpr int P2_MAX_HALVES = 4;              // ... of which a VCF has at most four: 2^26 records (bit 31 of a bucket entry's second word is k_join_lean's)
 constexpr uint32_t P2_DEAD = 0x1fffu;         // info of a record that takes no part (it travels so that the counting pass can count by position alone)
 // a level-1 entry (8 bytes): key & (2^27 - 1) in bits 0..26, info (12 bits + the host-decided TP-line bit) in 27..39, index in 40..63
 struct PartSeg {
@@ -270,6 +271,10 @@ struct BucketScatterParams {
   // instruction issue: the one histogram that needs no truth set is taken here, the join adds the true positives' and
   // k_finalize takes the difference (FinalizeParams.all_hist).
   uint32_t* seg_hist;
+  // two-level path, VCFs above 2^P2_INDEX_BITS records: or null.  [n_seg][4]: a level-1 entry's index is relative to its HALF of the VCF (a run of
+  // 2^24 records, level-1 segments of their own whose entries lie one behind the other inside every partition); entry i of the
+  // segment's run belongs to half (i >= l1_half[4 seg + 1]) + (i >= l1_half[4 seg + 2]) + (i >= l1_half[4 seg + 3])
+  const uint32_t* l1_half;
   uint32_t* seg_maxd;         // or null.  [n_seg] 1 + the highest bucket of the segment that took an entry (zeroed with the cursors): the join need not
                               // launch a workgroup for the buckets above it (the position bits the optimistic pass saw only bound them by a power of two)
 };

@@ -1887,6 +1887,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   if (L2) {
     // level-1 entries -> bucket entries: four per thread and group, two 16-byte loads (the partition's region starts on a
     // 16-byte boundary and holds sg.n entries without holes; the array is padded past its end)
+    uint32_t hb1 = 0xffffffffu, hb2 = 0xffffffffu, hb3 = 0xffffffffu;   // where the entries of the VCF's 2nd, 3rd, 4th run of 2^24 records begin
+    if (P.l1_half) { hb1 = P.l1_half[4 * seg + 1]; hb2 = P.l1_half[4 * seg + 2]; hb3 = P.l1_half[4 * seg + 3]; }
 #pragma unroll
     for (int j = 0; j < PER / 4; ++j) {
       const int64_t i4 = tbase + (int64_t)j * 2048 + tid * 4;
@@ -1908,7 +1910,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
         if (i4 + u < sg.n && inf13 != P2_DEAD) {
           const uint32_t d = v27 >> shift;   // shift = DJ_MAX_SHIFT here: < 256
           const uint32_t v = v27 - (d << shift);
-          ent[k] = (uint64_t)v | ((uint64_t)inf13 << 24) | ((uint64_t)(hi >> 8) << 37);
+          const uint32_t ii = (uint32_t)(i4 + u);
+          const uint32_t half = (ii >= hb1 ? 1u : 0u) + (ii >= hb2 ? 1u : 0u) + (ii >= hb3 ? 1u : 0u);
+          ent[k] = (uint64_t)v | ((uint64_t)inf13 << 24) | ((uint64_t)((hi >> 8) + (half << P2_INDEX_BITS)) << 37);
           dr[k] = (d << 16) | atomicAdd(&s_cnt[d], 1u);
           if (count_all) count(inf13 & 0x1ffu, d);
         }

@@ -293,6 +293,42 @@ def test_config4_shape_ten_million_record_vcfs(engine, oracle):
         b.close()
 
 
+def test_shuffled_vcfs_above_the_level_one_index_stay_on_buckets(engine, oracle):
+    """Two shuffled VCFs of 32 M records: a level-1 entry of the two-level bucket path holds 24 index bits, so a
+    VCF above 16.7 M records used to fall onto the radix sort (4x slower).  It is dealt out in runs of 2^24 records now, level-1
+    segments of their own whose entries lie one behind the other inside every partition (BucketScatterParams.l1_half): the
+    shuffled run equals the sorted one, one VCF also the oracle, nothing takes the radix sort, and the step is timed."""
+    import time
+    from oracle.synth import synth_truth_keys
+    L, N, N2, T = 256_000_000, 32_000_000, 16_000_000, 1_000_000   # 0.125 records per position, 31 partitions of 2^27 keys; the 32 M-record VCFs are two runs of 2^24 records each, the third VCF one
+    tid = engine.truth_synth(L, T, 4)
+    res = {}
+    for shuffled in (False, True):
+        b = engine.batch([N, N, N2], [tid, tid, tid])
+        b.synth(L, T, 4, 4100, shuffled=shuffled)
+        b.run()
+        b.finish()
+        res[shuffled] = (b.roc(), b.scalars()[:, :5].copy())
+        if shuffled:
+            ps = b.path_stats()
+            assert ps["unsorted"] == 3 and ps["bucket_two_level"] == 3 and ps["radix"] == 0 and ps["radix_after_overflow"] == 0, ps
+            t0 = time.perf_counter()
+            for _ in range(3):
+                b.run(); b.finish()
+            rate = 3 * (2 * N + N2) / (time.perf_counter() - t0)
+            assert rate >= 4e10, rate                       # (5.0-5.5e10 measured; the radix sort: 1.5e10)
+            cols = b.columns(1)
+            cls, oroc, sc = oracle.classify_columns(*cols, *synth_truth_keys(L, T, 4))
+            assert np.array_equal(b.cls(1), cls) and np.array_equal(b.roc()[1], oroc)
+            assert [int(x) for x in b.scalars()[1][:5]] == [sc[k] for k in ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R")]
+            idx = b.idx(1)
+            assert np.array_equal(idx[:sc["tp_lines"]], np.nonzero(cls == 3)[0])
+            assert np.array_equal(idx[len(cls) - sc["fp_lines"]:], np.nonzero(cls == 1)[0])
+        b.close()
+    engine.truth_release(tid)
+    assert np.array_equal(res[True][0], res[False][0]) and np.array_equal(res[True][1], res[False][1])
+
+
 def test_config5_shape_mixed_snp_indel_three_truth_sets(engine, oracle):
     """BASELINE configs[4] under the reference's semantics: 70 % SNP / 30 % indel records, three truth sets
     (VCF v uses truth v mod 3).  The reference drops every indel at the A2 filter

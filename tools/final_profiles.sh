@@ -1,8 +1,10 @@
 #!/bin/bash
-# every profile of a round in one GPU call: bash tools/final_profiles.sh <tag>   (outputs under gpurun_out/, copied to profiles/ by hand)
-TAG=${1:-r04f}
+# every profile of a round in two GPU calls (20 minutes each at most): bash tools/final_profiles.sh <tag> 1 ; ... <tag> 2
+# (outputs under gpurun_out/, copied to profiles/ by tools/copy_profiles.sh)
+TAG=${1:-r05f}; PART=${2:-1}
 ROOT=$PWD
 export TMPDIR=/tmp
+if [ "$PART" = "1" ]; then
 bash tools/prof_trace.sh $TAG --steps 5 --warmup 2 > gpurun_out/${TAG}_trace.log 2>&1
 bash tools/prof_pmc.sh $TAG 1000 > gpurun_out/${TAG}_pmc.log 2>&1
 python3 tools/pmc_to_profiles.py gpurun_out/pmc_$TAG 1000 ${TAG%%f*} > gpurun_out/${TAG}_traffic.log 2>&1   # profiles/<round>_pmc_per_launch.json, profiles/traffic.json (with the device code's id)
@@ -11,6 +13,9 @@ bash tools/prof_trace.sh ${TAG}shuf --shuffled --vcfs 256 --steps 4 --warmup 1 >
 mkdir -p gpurun_out/trace_${TAG}shuf3 gpurun_out/trace_${TAG}alle
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/trace_${TAG}shuf3 -- python3 $ROOT/tools/join_ab.py 16 10000000 50000000 1000000 > $ROOT/gpurun_out/${TAG}_trace_shuf3.log 2>&1)
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/trace_${TAG}alle -- python3 $ROOT/tools/run_once.py 256 6 0 30 > $ROOT/gpurun_out/${TAG}_trace_alle.log 2>&1)
+echo part 1 done
+exit 0
+fi
 bash tools/pmc_shuffled.sh $TAG "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "VALUBusy SALUBusy VALUUtilization LdsUtil MemUnitStalled" "FETCH_SIZE" "WRITE_SIZE" > gpurun_out/${TAG}_pmc_shuffled.json 2> gpurun_out/${TAG}_pmc_shuffled.err
 PCT=30 bash tools/pmc_shuffled.sh $TAG "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "VALUBusy SALUBusy VALUUtilization LdsUtil MemUnitStalled" "FETCH_SIZE" "WRITE_SIZE" > gpurun_out/${TAG}_pmc_shuffled_alleles.json 2> gpurun_out/${TAG}_pmc_shuffled_alleles.err
 mkdir -p gpurun_out/trace_${TAG}shufx
@@ -20,8 +25,6 @@ mkdir -p gpurun_out/trace_${TAG}shufx4
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/trace_${TAG}shufx4 -- python3 $ROOT/tools/shuffled_ext.py 64 2000000 10000000 200000 > $ROOT/gpurun_out/${TAG}_trace_shufx4.log 2>&1)
 python3 tools/shuffled_ext.py 64 2000000 10000000 200000 >> gpurun_out/${TAG}_shuffled_ext.log 2>&1
 python3 tools/e2e_files_bench.py 16 > gpurun_out/${TAG}_e2e.log 2>&1
-# round 4: what bounds k_compact (PMC of the new kernel; its block -> tile mapping against where a batch landed in memory)
 bash tools/pmc_compact.sh $TAG > gpurun_out/${TAG}_pmc_compact.log 2>&1
-(echo "== plain hipMalloc"; REPS=6 python3 tools/compact_map_probe.py; echo "== physically contiguous batches (QM_ALLOC_CONTIG=64)"; QM_ALLOC_CONTIG=64 REPS=2 python3 tools/compact_map_probe.py) > gpurun_out/${TAG}_compact_map_probe.log 2>&1
 python3 bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 tail -c 600 gpurun_out/${TAG}_bench.json
