@@ -1167,7 +1167,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     int parts = nseg >= 8 && b->ev_sync[0] && !direct ? 4 : 1;
     if (const char* e = getenv("QM_BUCKET_PARTS")) parts = std::max(1, std::min({atoi(e), nseg, (int)qm_batch::MAX_CHUNKS}));
     if (!b->ev_sync[0]) parts = 1;
-    const bool tight_nbk = direct && join_lean_on() && !xstream && parts == 1 && !getenv("QM_NO_TIGHT_NBK");
+    const bool tight_nbk = direct && join_lean_on() && parts == 1 && !getenv("QM_NO_TIGHT_NBK");
     if (tight_nbk) H.seg_maxd = seg_maxd;
     hipStream_t aux = parts > 1 ? b->ctx->aux : st;
     int i0 = 0;
@@ -1197,7 +1197,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
           bool have = memo_on() && !b->known_nbk.empty();
           uint32_t m = 0;
           if (have) for (int i = 0; i < nseg && have; ++i) { const uint32_t k = b->known_nbk[(size_t)vs[(size_t)i]]; have = k != 0u; m = std::max(m, k); }
-          if (have) nbk_launch = (int)std::min<uint32_t>(std::max(m, 1u), (uint32_t)nbk_all);
+          if (have && !xstream) nbk_launch = (int)std::min<uint32_t>(std::max(m, 1u), (uint32_t)nbk_all);   // (two streams: every bucket is launched, the rows of the second follow at a fixed distance)
         }
         // the join: one bit per key of the bucket in LDS where a bucket's key range allows it (k_join_direct), the hashed
         // tables of k_classify_hash otherwise (QM_JOIN=hash: always)
@@ -1519,15 +1519,22 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
   S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = b->p_ent; S.xent = nullptr; S.xcursor = nullptr; S.ext = 0; S.pairs = 0;
   uint32_t* const seg_hist = join_lean_on() ? b->bk_cursor + nhist0 : nullptr;
-  S.seg_hist = seg_hist; S.seg_maxd = nullptr; S.l1_half = b->last2_halves ? b->p_half : nullptr;
+  // (no look at the highest bucket here: every partition but a VCF's last fills its 256 buckets, and the look costs the scatter more than
+  // the few empty workgroups cost the join -- 2.81 against 2.71 ms per 16 x 10 M records)
+  uint32_t* const seg_maxd = getenv("QM_TIGHT_NBK_ALL") && join_lean_on() ? b->bk_cursor + nhist0 + (size_t)nseg * SEG_HIST_WORDS : nullptr;
+  S.seg_hist = seg_hist; S.seg_maxd = seg_maxd; S.l1_half = b->last2_halves ? b->p_half : nullptr;
   HashParams H;
   H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
   H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.seg_base = 0;
-  H.xrows = nullptr; H.xent = nullptr; H.xcursor = nullptr; H.out_stride = HB_BUCKETS; H.ext = 0; H.scatter_hist = seg_hist ? 1 : 0; H.seg_maxd = nullptr;
+  H.xrows = nullptr; H.xent = nullptr; H.xcursor = nullptr; H.out_stride = HB_BUCKETS; H.ext = 0; H.scatter_hist = seg_hist ? 1 : 0; H.seg_maxd = seg_maxd;
   launch_bucket_rows(H, nseg, st);
   launch_bucket_scatter(S, (int)nbt, st);
   launch_join_direct(H, nseg, DJ_MAX_SHIFT, HB_BUCKETS, st);
-  launch_finalize(bucket_rows_finalize(b, seg_hist), nseg, st);
+  {
+    FinalizeParams F = bucket_rows_finalize(b, seg_hist);
+    F.row_cap = seg_maxd;
+    launch_finalize(F, nseg, st);
+  }
   HIPCHK(hipGetLastError());
   std::vector<uint32_t> hfl((size_t)nseg);
   HIPCHK(hipMemcpyAsync(hfl.data(), b->bk_vflags, 4 * hfl.size(), hipMemcpyDeviceToHost, st));
@@ -1675,16 +1682,21 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = nullptr; S.xent = xs ? b->bk_xent : nullptr; S.xcursor = xs ? b->bk_xcursor : nullptr; S.ext = xs ? 1 : 0;
   S.pairs = 1;   // (tiles of single partitions run through the 512-digit instantiation as well)
   uint32_t* const seg_hist = join_lean_on() ? b->bk_cursor + nhist0 : nullptr;
-  S.seg_hist = seg_hist; S.seg_maxd = nullptr; S.l1_half = nullptr;
+  uint32_t* const seg_maxd = getenv("QM_TIGHT_NBK_ALL") && join_lean_on() ? b->bk_cursor + nhist0 + (size_t)nseg * SEG_HIST_WORDS : nullptr;   // (as on the two-level path: 2.08 against 2.02 ms per 64 x 2 M)
+  S.seg_hist = seg_hist; S.seg_maxd = seg_maxd; S.l1_half = nullptr;
   HashParams H;
   H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
   H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.seg_base = 0;
-  H.xrows = xs ? b->bk_xrows : nullptr; H.xent = b->bk_xent; H.xcursor = b->bk_xcursor; H.out_stride = out_stride; H.ext = xs ? 1 : 0; H.scatter_hist = seg_hist ? 1 : 0; H.seg_maxd = nullptr;
+  H.xrows = xs ? b->bk_xrows : nullptr; H.xent = b->bk_xent; H.xcursor = b->bk_xcursor; H.out_stride = out_stride; H.ext = xs ? 1 : 0; H.scatter_hist = seg_hist ? 1 : 0; H.seg_maxd = seg_maxd;
   launch_bucket_rows(H, nseg, st);
   launch_bucket_scatter(S, (int)nbt, st);
   launch_join_direct(H, nseg, DJ_MAX_SHIFT, HB_BUCKETS, st);
   if (xs) launch_join_ext(H, nseg, HB_BUCKETS, st);
-  launch_finalize(bucket_rows_finalize(b, seg_hist), nseg, st);
+  {
+    FinalizeParams F = bucket_rows_finalize(b, seg_hist);
+    F.row_cap = seg_maxd;
+    launch_finalize(F, nseg, st);
+  }
   HIPCHK(hipGetLastError());
   std::vector<uint32_t> hfl((size_t)nseg);
   HIPCHK(hipMemcpyAsync(hfl.data(), b->bk_vflags, 4 * hfl.size(), hipMemcpyDeviceToHost, st));
@@ -1816,6 +1828,7 @@ static int rescan_and_compact(qm_batch* b, hipStream_t st) {
   }
   FinalizeParams F = finalize_params(b, nullptr);
   F.roc = b->rs_roc; F.scalars = b->rs_scal; F.vcf_flags = b->rs_flags; F.vcf_posor = nullptr;
+  F.parts = 1;   // the tile offsets only: the rows it would sum are thrown away (611 span rows per 10 M-record VCF: 0.3 ms for sixteen of them)
   launch_finalize(F, b->n_vcf, st);
   CompactParams CP = compact_params(b);
   CP.skip_unsorted = 0;   // the flags still say 'unsorted' for the VCFs just redone: compact them too

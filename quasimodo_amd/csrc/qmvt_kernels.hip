@@ -1022,8 +1022,9 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
   __shared__ uint32_t s_scan[256];
   const int v = (int)blockIdx.x + P.vcf_base;
   const int tid = (int)threadIdx.x;
-  VcfDesc vd = P.vcfs[v];
-  if (P.row_cap) { const int cap = (int)P.row_cap[v] > 1 ? (int)P.row_cap[v] : 1; if (vd.nspans > cap) vd.nspans = cap; }
+  const VcfDesc vd = P.vcfs[v];
+  // bucket rows: the rows of the buckets above the segment's highest (of either stream: row s belongs to bucket s & 255) were not written
+  const int row_cap = P.row_cap ? ((int)P.row_cap[v] > 1 ? (int)P.row_cap[v] : 1) : HB_BUCKETS;
   const int nb = P.n_bins;
 
   // the spans' scalar rows (8 words each: five counters, the flags, the OR of the positions), every thread two or three of
@@ -1036,6 +1037,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
   if (tid == 6) s_or = 0u;
   __syncthreads();
   for (int i = tid; i < vd.nspans * 8; i += 256) {
+    if (P.row_cap && ((i >> 3) & (HB_BUCKETS - 1)) >= row_cap) continue;
     const uint32_t x = P.span_scal[(size_t)vd.span0 * 8 + i];
     const int k = i & 7;
     if (k < 5) { if (x) atomicAdd(&s_sc[k], (unsigned long long)x); }
@@ -1051,6 +1053,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
   if (rows) {
 #pragma unroll 8
     for (int s = 0; s < vd.nspans; ++s) {   // unrolled: the loads of eight spans are in flight together (10 M-record VCFs have 611 spans)
+      if (P.row_cap && (s & (HB_BUCKETS - 1)) >= row_cap) continue;
       const uint32_t* sh = P.span_hist + (size_t)(vd.span0 + s) * SPAN_HIST_WORDS;
       const uint32_t tp = (sh[hw] >> hs) & 0xffffu;
       h0 += tp; h1 += (sh[128 + hw] >> hs) & 0xffffu; h2 += (sh[256 + hw] >> hs) & 0xffffu;
@@ -1994,10 +1997,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   __syncthreads();
   BKS_TICK(4);
   if (P.seg_maxd && tid < NB) {   // 1 + the highest bucket this tile fills, per wave: one atomic each
-    uint32_t m = s_cnt[tid] ? (uint32_t)(tid & 255) + 1u : 0u;
+    uint32_t m = (s_cnt[tid] || (EXT && s_cntx[tid])) ? (uint32_t)(tid & 255) + 1u : 0u;   // (either stream)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)m, o); m = y > m ? y : m; }
-    if (lane == 0 && m) atomicMax(&P.seg_maxd[seg + (tid >> 8)], m);   // (digits 256..511: the next segment)
+    // (digits 256..511: the next segment.)  A look first: hundreds of tiles of one segment are in flight together, and atomics on ONE
+    // word queue up at the memory side -- unchecked they doubled the second level's scatter (0.64 -> 1.13 ms per 1.6e8 records);
+    // a stale value only costs an atomic that changes nothing
+    if (lane == 0 && m > __hip_atomic_load(&P.seg_maxd[seg + (tid >> 8)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&P.seg_maxd[seg + (tid >> 8)], m);
   }
   if (count_all) {   // the tile's counts join its segment's (the next segment's for the digits 256..511)
     for (int i = tid; i < (NB / 256) * SEG_HIST_WORDS; i += 512) {
@@ -3582,6 +3588,7 @@ __global__ __launch_bounds__(XJ_THREADS) void k_join_ext(HashParams P) {
   const int d = (int)blockIdx.x;
   const int seg_id = (int)blockIdx.y + P.seg_base;
   const size_t row = (size_t)seg_id * HB_BUCKETS + (size_t)d;
+  if (P.seg_maxd && d > 0 && (uint32_t)d >= P.seg_maxd[seg_id]) return;   // no entry of either stream above the segment's highest bucket (k_join_lean)
 #ifdef HB_PROFILE
   uint32_t* hb_prof = const_cast<uint32_t*>(P.cursor) + (size_t)P.n_seg * HB_BUCKETS * HB_SUBS + (size_t)P.n_seg;
   unsigned long long hb_t = __builtin_amdgcn_s_memtime();
