@@ -3411,8 +3411,11 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
     uint32_t vmask = 0;
 #pragma unroll
     for (int g = 0; g < PER / 4; ++g) {
-      const int left = (int)nw - 4 * (g * 64 + lane);
-      vmask |= (left >= 4 ? 15u : left <= 0 ? 0u : (1u << left) - 1u) << (4 * g);
+      if (nw >= (uint32_t)(g + 1) * 256u) vmask |= 15u << (4 * g);             // wave-uniform: the whole trip lies in front of the cursor
+      else if (nw > (uint32_t)g * 256u) {
+        const int left = (int)nw - 4 * (g * 64 + lane);
+        vmask |= (left >= 4 ? 15u : left <= 0 ? 0u : (1u << left) - 1u) << (4 * g);
+      }
     }
     DJ_TICK(8);
     const uint32_t postm = (((hitm | tplm) & vmask) | (collm & keptm) | nkm);   // on truth positions (a keyless record there settles as no hit), host-decided TP lines, keys to be counted exactly, keyless kept records
@@ -3488,14 +3491,14 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
   }
   DJ_TICK(9);
   // (hipcc turns an LDS atomic add of a per-lane value on ONE address into a serial loop over the 64 lanes: DPP sums instead)
-  uint32_t n_pass = wave_sum((uint32_t)__popc(keptm | nkm));
-  n_tp = wave_sum(n_tp);
-  top = wave_sum(top);
-  fresh = wave_sum(fresh);
+  // one sum for two counts (a wave holds <= 1 024 records: 16 bits each), one for the rarer third
+  const uint32_t packed = wave_sum((uint32_t)__popc(keptm | nkm) | (n_tp << 16));
+  if (ballot64(fresh != 0u)) fresh = wave_sum(fresh);
+  if (HIST) top = wave_sum(top);
   if (lane == 0) {
-    atomicAdd(&s_c[0], n_pass); atomicAdd(&s_c[1], n_tp);
+    atomicAdd(&s_c[0], packed & 0xffffu); atomicAdd(&s_c[1], packed >> 16);
     if (fresh) atomicAdd(&s_c[2], fresh);
-    if (top) atomicAdd(&s_c[5], top);
+    if (HIST && top) atomicAdd(&s_c[5], top);
   }
   // ---- bucket epilogue: positions claimed exactly once, per-entry state -> U histogram and TP_R, counters, the row ----
   // (S1 and S2 are final since the barrier above: only the exact set and the truth state were written behind it)
