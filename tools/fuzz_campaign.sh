@@ -12,8 +12,12 @@ SEED=106 run QM_MEMO=0
 SEED=107 run QM_BUCKET_PARTS=4
 SEED=108 run QM_PIPE_CHUNKS=3 QM_PIPE_MIN_SPANS=1
 SEED=109 run QM_BUCKETX=2
-# round 4: both forms of the compaction, with the tiles in eighths and in launch order (fuzzed batches are too small to tune themselves)
-SEED=112 run QM_BUCKET2=2
-SEED=113 run QM_SORT_PATH=radix
+# round 5: round 3's join and the hashed one behind the new scatter (zero entries, the scatter's histogram off for them), the join without the look at the highest bucket
+SEED=110 run QM_JOIN=direct
+SEED=111 run QM_JOIN=direct QM_BUCKET2=2
+SEED=112 run QM_BUCKET2=2 QM_MEMO=0
+SEED=113 run QM_NO_TIGHT_NBK=1
+SEED=115 run QM_TIGHT_NBK_ALL=1 QM_BUCKET2=2
+SEED=116 run QM_TIGHT_NBK_ALL=1 QM_BUCKETX=2
 SEED=114 run QM_COL_SLAB=1280                                   # the columns as pieces of one allocation
 cat $OUT
