@@ -4106,7 +4106,6 @@ bool join_lean_on() {
 }
 void launch_join_direct(const HashParams& P, int nseg, int lb, int nbk, hipStream_t st) {
   if (nseg <= 0) return;
-  if (const char* e = getenv("QM_NBK_PROBE")) nbk = atoi(e);   // (timing experiments only: rows beyond are not written)
   static const int pad = getenv("QM_DJ_PAD") ? atoi(getenv("QM_DJ_PAD")) : 0;   // experiment: extra (unused) dynamic LDS bounds the workgroups per CU
   const bool old = !join_lean_on();   // (QM_JOIN=direct: round 3's kernel)
   if (!old) {
