@@ -1047,18 +1047,30 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
   // P.parts: bit 0 = the part the compaction waits for (per-VCF flags, tile offsets), bit 1 = the rows (ROC, scalars, per-truth
   // sums).  qm_batch_run launches the two apart, the rows on the second stream beside the compaction; everybody else wants both.
   const bool rows = (P.parts & 2) != 0, offsets = (P.parts & 1) != 0;
-  // sum span histograms (thread = bin)
+  // sum span histograms.  A row is three histograms of 128 words (two u16 bins per word): thread t takes word t & 127 of the rows
+  // t >> 7, t >> 7 + 2, ... -- every word is read once (thread = bin read every word twice) and a VCF's rows are walked by two
+  // halves of the workgroup side by side, which is what matters for the few hundred workgroups this kernel has: the loop is bound
+  // by its round trips (512 rows of a two-stream bucket segment took 160 us) -- and the halves meet in LDS: thread = bin from there on.
+  __shared__ uint32_t s_part[2][4][256];
   uint32_t h0 = 0, h1 = 0, h2 = 0, hsub = 0;
-  const int hw = tid >> 1, hs = 16 * (tid & 1);   // two u16 bins per dword
   if (rows) {
+    const int w = tid & 127, g = tid >> 7;
+    uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0, c0 = 0, c1 = 0, u0 = 0, u1 = 0;
 #pragma unroll 8
-    for (int s = 0; s < vd.nspans; ++s) {   // unrolled: the loads of eight spans are in flight together (10 M-record VCFs have 611 spans)
+    for (int s = g; s < vd.nspans; s += 2) {   // unrolled: the loads of eight spans are in flight together (10 M-record VCFs have 611 spans)
       if (P.row_cap && (s & (HB_BUCKETS - 1)) >= row_cap) continue;
       const uint32_t* sh = P.span_hist + (size_t)(vd.span0 + s) * SPAN_HIST_WORDS;
-      const uint32_t tp = (sh[hw] >> hs) & 0xffffu;
-      h0 += tp; h1 += (sh[128 + hw] >> hs) & 0xffffu; h2 += (sh[256 + hw] >> hs) & 0xffffu;
-      hsub += s < HB_BUCKETS ? tp : 0u;
+      const uint32_t x = sh[w], y = sh[128 + w], z = sh[256 + w];
+      a0 += x & 0xffffu; a1 += x >> 16; b0 += y & 0xffffu; b1 += y >> 16; c0 += z & 0xffffu; c1 += z >> 16;
+      if (s < HB_BUCKETS) { u0 += x & 0xffffu; u1 += x >> 16; }
     }
+    s_part[g][0][2 * w] = a0; s_part[g][0][2 * w + 1] = a1; s_part[g][1][2 * w] = b0; s_part[g][1][2 * w + 1] = b1;
+    s_part[g][2][2 * w] = c0; s_part[g][2][2 * w + 1] = c1; s_part[g][3][2 * w] = u0; s_part[g][3][2 * w + 1] = u1;
+  }
+  __syncthreads();
+  if (rows) {
+    h0 = s_part[0][0][tid] + s_part[1][0][tid]; h1 = s_part[0][1][tid] + s_part[1][1][tid];
+    h2 = s_part[0][2][tid] + s_part[1][2][tid]; hsub = s_part[0][3][tid] + s_part[1][3][tid];
     // bucket rows whose scatter counted every first-stream record by bin: their FP histogram is what is left of it
     if (P.all_hist && tid < nb) h1 += P.all_hist[(size_t)v * SEG_HIST_WORDS + 1 + tid] - hsub;
   }
