@@ -177,3 +177,64 @@ def test_workflows_on_two_ranks_of_this_gpu_write_what_one_gpu_writes(tmp_path, 
     workflow.run_vareval(vcfs, str(snps), str(tmp_path / "v2"), gpus=2, _backend="gloo", _same_device=True)
     assert (tmp_path / "v2" / "results" / "final_tables" / "snpcall_benchmark.txt").read_bytes() == \
            (tmp_path / "v1" / "results" / "final_tables" / "snpcall_benchmark.txt").read_bytes()
+
+
+def test_bench_line_contract_on_a_small_batch(qmlib):
+    """`python bench.py` as the driver runs it (N = 1), on a reduced batch: ONE JSON line with the contract's keys, the roofline object
+    (kernel time by HIP events, the whole step over the timed batch and its re-creations with their median), the CPU baselines (the
+    oracle on one and on all cores; the reference's five shell commands per VCF, serial and one VCF job per core) and the shuffled side
+    lines reporting the first-seen figure.  The numbers of a 40-VCF batch mean nothing; the shape of the line is the driver's contract."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, QM_BENCH_SHELL_JOBS="4")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--vcfs", "40", "--steps", "3", "--warmup", "1", "--cpu-sample", "3000000",
+                        "--shell-sample", "1", "--shuffled-vcfs", "40", "--shuffled3-vcfs", "2", "--alleles-vcfs", "40", "--shuffled-alleles-vcfs", "40",
+                        "--shuffled4-vcfs", "6", "--alloc-reps", "2"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "classifications/s" and d["vs_baseline"] is None
+    assert abs(d["value"] - 40e6 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["config"]["vcfs_per_gpu"] == 40 and "workload" in d["config"] and d["config"]["collective"] == "none"
+    assert d["config"]["vcfs_checked_against_oracle_per_rank"] == 3 and d["config"]["oracle_checks"]["roc_rows"] == 3
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["algorithmic_bytes_per_launch"] == 40 * (17e6 + 12 * 1e5) and r["kernel_ms"] > 0 and r["kernels_build"] == r["kernels_build"]
+    assert len(r["alloc_spread"]["step_ms"]) == 3 and r["step_frac_min"] <= r["step_frac_median"] <= r["step_frac_max"]
+    assert r["traffic"] is None and "another workload" in r["traffic_note"]          # the PMC figure is quoted for the full-size batch only
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["all_cores"]["cores"] >= 1
+    s = d["cpu_baseline_shell"]
+    assert s["kind"] == "reference-mechanism" and s["value"] > 0 and s["all_cores"]["jobs"] == 4 and s["all_cores"]["value"] > 0
+    for k in ("shuffled_variant", "shuffled_config3_variant", "shuffled_alleles_variant", "shuffled_config4_variant"):
+        v = d[k]
+        assert v["ms_per_step_unseen"] >= 0 and v["value"] > 0 and v["value_repeated_run"] > 0
+        assert abs(v["value"] - v["vcfs"] * v.get("records_per_vcf", 1_000_000) / (v["ms_per_step_unseen"] * 1e-3)) < 1e-6 * v["value"]
+        assert v.get("roc_equals_sorted_variant", v.get("equals_sorted_variant")) is True
+    assert d["alleles_variant"]["equals_oracle_on_vcf0"] is True
+
+
+def test_the_three_bucket_joins_agree_behind_one_scatter(qmlib):
+    """k_join_lean (default), round 3's k_join_direct (QM_JOIN=direct) and the hashed join (QM_JOIN=hash) behind the same scatter, on the
+    same 24 shuffled VCFs of configs[2]'s shape: one digest over ROC rows, scalars, an index list and a VCF's class bits.  (The choice is
+    read once per process, so every variant is a process of its own; with and without the look at the highest bucket, with and without
+    the batch's memory.)"""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for name, extra in (("lean", {}), ("direct", {"QM_JOIN": "direct"}), ("hash", {"QM_JOIN": "hash"}), ("lean, loose", {"QM_NO_TIGHT_NBK": "1"}),
+                        ("lean, first-seen", {"QM_MEMO": "0"})):
+        p = subprocess.run([sys.executable, os.path.join(root, "tools", "join_ab.py"), "24", "1000000"], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, **extra))
+        assert p.returncode == 0, (name, p.stderr[-1500:])
+        m = re.search(r"digest ([0-9a-f]+)", p.stdout)
+        assert m and "'radix': 0" in p.stdout and "'radix_after_overflow': 0" in p.stdout, (name, p.stdout[-500:])
+        got[name] = m.group(1)
+    assert len(set(got.values())) == 1, got
