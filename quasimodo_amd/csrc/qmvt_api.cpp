@@ -459,6 +459,17 @@ struct qm_batch {
   struct Chunk { int v0, v1, s0, s1; };
   std::vector<Chunk> chunks;
   hipEvent_t ev_sync[MAX_CHUNKS + 2] = {};   // ordering between the two streams (no timing)
+  // behind the k_finalize part of the run that writes the per-VCF flags (and their host-mapped mirrors): qm_batch_finish waits for
+  // THIS, not for the whole stream -- what it then queues (the bucket path of the VCFs found out of order) is built and launched
+  // while the run's compaction and row sums are still going, and starts right behind them
+  hipEvent_t ev_flags = nullptr;
+  bool flags_recorded = false;
+  // bucket chunks whose flags (overflow, bad position, highest bucket) nobody has looked at yet: their last kernels were queued
+  // without a round trip through the host (k_sort_copy_rows looks at the chunk's "bad" word itself); qm_batch_finish settles them
+  // behind its last wait and sends a chunk that did not fit through the radix sort then
+  struct Pending { std::vector<int> vs; int off; int nbk_launch; bool tight, direct; };
+  std::vector<Pending> pend;
+  int pend_segs = 0;   // mirror words handed out to the chunks of this finish
   // timing
   bool timing = false;
   static constexpr int EV_RING = 32;   // per-kernel events of the latest runs
@@ -500,6 +511,10 @@ static bool memo_on() {   // read at every run / finish: bench.py times a batch 
   const char* e = getenv("QM_MEMO");
   return !e || atoi(e) != 0;
 }
+static bool flags_event_on() {   // QM_FLAGS_WAIT=stream: qm_batch_finish waits for the whole stream before it looks at the flags (rounds 1-4)
+  const char* e = getenv("QM_FLAGS_WAIT");
+  return !(e && strcmp(e, "stream") == 0);
+}
 static void forget_known(qm_batch* b, int v) {   // v < 0: every VCF
   if (!b->known_nbk.empty()) { if (v < 0) std::fill(b->known_nbk.begin(), b->known_nbk.end(), 0u); else b->known_nbk[(size_t)v] = 0u; }
   if (b->known.empty() || b->n_known == 0) return;
@@ -523,6 +538,7 @@ static void batch_free(qm_batch* b) {
   if (b->h_summary) (void)hipHostFree(b->h_summary);
   for (auto& r : b->ev) for (auto& e : r) if (e) (void)hipEventDestroy(e);
   for (auto& e : b->ev_sync) if (e) (void)hipEventDestroy(e);
+  if (b->ev_flags) (void)hipEventDestroy(b->ev_flags);
   delete b;
 }
 
@@ -602,6 +618,7 @@ static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int
     for (auto& e : b->ev_sync) {
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rc = fail(QM_E_HIP, "hipEventCreate failed"); break; }
     }
+    if (rc == QM_OK && hipEventCreateWithFlags(&b->ev_flags, hipEventDisableTiming) != hipSuccess) rc = fail(QM_E_HIP, "hipEventCreate failed");
   }
   if (rc == QM_OK && !packed) {
     // padding lanes are masked in the kernels, but keep the columns defined.  On the context's
@@ -783,6 +800,7 @@ static FinalizeParams finalize_params(qm_batch* b, uint64_t* global) {
   F.all_hist = nullptr;
   F.row_cap = nullptr;
   F.host_flags = nullptr; F.host_aux = nullptr;
+  F.chunk_bad = nullptr; F.row_cap_limit = 0u; F.lazy_unsorted = 0;
   return F;
 }
 static CompactParams compact_params(qm_batch* b) {
@@ -835,6 +853,7 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
     b->known_dirty = false;
   }
   b->run_used_known = use_known;
+  b->flags_recorded = false;
   if (nch > 1) {
     HIPCHK(hipEventRecord(b->ev_sync[qm_batch::MAX_CHUNKS], st));
     HIPCHK(hipStreamWaitEvent(aux, b->ev_sync[qm_batch::MAX_CHUNKS], 0));
@@ -865,6 +884,7 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
     F.flag_summary = b->d_summary;
     if (b->d_summary) { F.host_flags = b->d_summary + 16; F.host_aux = b->d_summary + 16 + b->n_vcf; }
     if (use_known) F.known = b->d_known;
+    F.lazy_unsorted = getenv("QM_NO_LAZY_FINALIZE") ? 0 : 1;
     // In one piece (the default), the compaction waits only for what it needs of k_finalize -- per-VCF flags and tile offsets --
     // and the rows (ROC, scalars, per-truth sums: 96 MB of span histograms to sum) go to the second stream beside it.
     const bool split = finalize_split_on() && nch == 1 && b->ev_sync[0] != nullptr;
@@ -877,6 +897,7 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
       F.parts = 1;
     }
     launch_finalize(F, ck.v1 - ck.v0, st);
+    if (k == nch - 1 && b->ev_flags && flags_event_on()) { HIPCHK(hipEventRecord(b->ev_flags, st)); b->flags_recorded = true; }   // every VCF's flags are written
     if (T) HIPCHK(hipEventRecord(e5[2], st));
     CompactParams K = compact_params(b);
     K.span_base = ck.s0;
@@ -927,6 +948,10 @@ extern "C" int qm_batch_timings(qm_batch* b, float* ms4) {
 
 // ---- sort path: unsorted VCFs are redone in chunks; every step of a chunk is one launch ----
 constexpr int64_t SORT_CHUNK_RECORDS = 1ll << 28;
+static int64_t sort_chunk_records() {   // QM_SORT_CHUNK_RECORDS (tests, tools/gpu_fuzz.py): small chunks, several of them per finish
+  if (const char* e = getenv("QM_SORT_CHUNK_RECORDS")) { const long long v = atoll(e); if (v > 0) return std::min<int64_t>(v, SORT_CHUNK_RECORDS); }
+  return SORT_CHUNK_RECORDS;
+}
 
 template <typename T>
 static int regrow(T** p, int64_t* cap, int64_t need, int64_t* bytes) {
@@ -1096,7 +1121,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     if (rc == QM_OK) rc = regrow(&b->d_bk_vcfs, &b->cap_bk_vcfs, (int64_t)nseg, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_ent, &b->cap_bk_ent, bk_ents, &b->dev_bytes);
     if (rc == QM_OK) rc = regrow(&b->bk_rows, &b->cap_bk_rowdesc, rows, &b->dev_bytes);
-    if (rc == QM_OK) rc = regrow(&b->bk_cursor, &b->cap_bk_cursor, rows * HB_SUBS + nseg + 32 + 16 * 65 + (int64_t)nseg * (SEG_HIST_WORDS + 1), &b->dev_bytes);   // + 32 + 16 * 65: phase clocks of a profiling build
+    if (rc == QM_OK) rc = regrow(&b->bk_cursor, &b->cap_bk_cursor, rows * HB_SUBS + nseg + 32 + 16 * 65 + (int64_t)nseg * (SEG_HIST_WORDS + 1) + 1, &b->dev_bytes);   // + 32 + 16 * 65: phase clocks of a profiling build; + 1: the chunk's "bad" word
     if (rc == QM_OK) rc = ensure_bucket_rows(b, nseg);
     if (rc == QM_OK && (int64_t)nbt > b->cap_bk_tiles) {
       b->bk_tiles_valid = false;
@@ -1121,7 +1146,6 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     b->last_segs = segs;
     b->bk_tiles_valid = try_buckets;
   }
-  HIPCHK(hipMemsetAsync(b->sorbits, 0, 4, st));
   SortCols src = {b->pos, b->ref, b->alt, b->qual, b->flags};
   if (try_buckets) {
     // --- bucket path: ONE scatter on each VCF's top eight key bits into fixed-size bucket regions, then the hash-join per bucket
@@ -1138,8 +1162,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
       b->bk_fake_valid = true;
     }
     const size_t nhist0 = (size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg + 32 + 16 * 65;   // the scatter's per-segment histograms lie behind the cursors, flags and phase clocks
-  const size_t ncur = (nhist0 + (size_t)nseg * (SEG_HIST_WORDS + 1)) * 4;   // (+ 1: seg_maxd behind the histograms)
-    HIPCHK(hipMemsetAsync(b->bk_cursor, 0, ncur, st));
+  const size_t ncur = (nhist0 + (size_t)nseg * (SEG_HIST_WORDS + 1) + 1) * 4;   // (+ 1: seg_maxd behind the histograms; + 1: the chunk's "bad" word behind them)
     BucketScatterParams S;
     S.segs = b->d_segs; S.tile_seg = b->d_bk_tile_seg; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
     S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
@@ -1148,6 +1171,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     uint32_t* const seg_hist = direct && join_lean_on() ? b->bk_cursor + nhist0 : nullptr;   // k_join_lean follows: the scatter counts every record by bin
     S.seg_hist = seg_hist; S.l1_half = nullptr;
     uint32_t* const seg_maxd = b->bk_cursor + nhist0 + (size_t)nseg * SEG_HIST_WORDS;
+    uint32_t* const chunk_bad = seg_maxd + nseg;
     S.seg_maxd = seg_maxd;
     if (xstream) HIPCHK(hipMemsetAsync(b->bk_xcursor, 0, (size_t)nseg * HB_BUCKETS * HB_SUBS * 4, st));
     HashParams H;
@@ -1156,7 +1180,9 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     H.xrows = xstream ? b->bk_xrows : nullptr; H.xent = b->bk_xent; H.xcursor = b->bk_xcursor; H.out_stride = out_stride; H.ext = xstream ? 1 : 0;
     H.scatter_hist = seg_hist ? 1 : 0;
     H.seg_maxd = nullptr;   // (set below once the launch shape is known)
+    H.zero = b->bk_cursor; H.n_zero = (uint32_t)(ncur / 4);   // the scatter's cursors, flags, counts: cleared by the kernel that writes the rows
     launch_bucket_rows(H, nseg, st);
+    H.zero = nullptr; H.n_zero = 0u;
     // The scatter streams (memory-bound, its SIMDs half idle), the join issues instructions (and hardly waits for memory): in a
     // few segment ranges, the join of one range on the second stream beside the scatter of the next, they fill each other's gaps.
     // k_classify_hash issues instructions where the scatter waits for memory: a few segment ranges, the join of one on the second
@@ -1212,11 +1238,26 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
       HIPCHK(hipStreamWaitEvent(st, b->ev_sync[qm_batch::MAX_CHUNKS + 1], 0));
     }
     const bool mirrors = b->d_summary != nullptr && nseg <= b->n_vcf;   // (one segment per VCF on this path)
+    // No round trip through the host between the rows' k_finalize and the kernels that hand the chunk's results over: they are queued
+    // at once, k_sort_copy_rows looks at the chunk's "bad" word on the device, and qm_batch_finish reads the mirrors behind its last
+    // wait (settle_pending) -- 15-25 us per chunk of 2.5 ms.  Every chunk of a finish has mirror words of its own (b->pend_segs).
+    const bool speculate = mirrors && b->pend_segs + nseg <= b->n_vcf && !getenv("QM_HB_PROFILE") && !(getenv("QM_SPECULATE") && atoi(getenv("QM_SPECULATE")) == 0);
+    const int moff = speculate ? b->pend_segs : 0;
     {
       FinalizeParams F = bucket_rows_finalize(b, seg_hist);
       if (tight_nbk) F.row_cap = seg_maxd;   // (the rows above were not written by this run)
-      if (mirrors) { F.host_flags = b->d_summary + 16 + 2 * b->n_vcf; F.host_aux = b->d_summary + 16 + 3 * b->n_vcf; }   // (a place of their own: the run's flags may still be unread)
+      if (mirrors) { F.host_flags = b->d_summary + 16 + 2 * b->n_vcf + moff; F.host_aux = b->d_summary + 16 + 3 * b->n_vcf + moff; }   // (a place of their own: the run's flags may still be unread)
+      if (speculate) { F.chunk_bad = chunk_bad; F.row_cap_limit = (uint32_t)nbk_launch; }
       launch_finalize(F, nseg, st);
+    }
+    if (speculate) {
+      launch_sort_copy_rows(b->d_segs, nseg, b->bk_roc, b->bk_rscal, b->roc, b->scalars, b->n_bins, st, global, b->d_vcfs, nullptr, chunk_bad);
+      launch_tile_counts(b->d_segs, b->d_ktile_seg, b->d_ktile_local, nkt, b->mask_pass, b->mask_tp, b->tile_tp, b->tile_fp, st);
+      HIPCHK(hipGetLastError());
+      b->path_stats[QM_PATH_BUCKET_CHUNKS] += 1;
+      b->pend.push_back(qm_batch::Pending{vs, moff, nbk_launch, tight_nbk, direct});
+      b->pend_segs += nseg;
+      return QM_OK;
     }
     HIPCHK(hipGetLastError());
     std::vector<uint32_t> hfl((size_t)nseg), hmd((size_t)nseg, 0u);
@@ -1286,6 +1327,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   if (rc == QM_OK) b->cap_sort_n = std::max(b->cap_sort_n, koff);
   if (rc == QM_OK) rc = regrow(&b->shist, &b->cap_sort_hist, hoff, &b->dev_bytes);
   if (rc != QM_OK) return rc;
+  HIPCHK(hipMemsetAsync(b->sorbits, 0, 4, st));
   launch_sort_first_hist(b->d_segs, b->d_tile_seg, nst, b->pos, b->shist, b->sorbits, st);
   uint32_t orbits = 0;
   HIPCHK(hipMemcpyAsync(&orbits, b->sorbits, 4, hipMemcpyDeviceToHost, st));
@@ -1729,12 +1771,13 @@ static int redo_unsorted(qm_batch* b, const std::vector<int>& todo, const std::v
     const bool force2 = getenv("QM_BUCKET2") && atoi(getenv("QM_BUCKET2")) == 2 && bucket2_takes(b, n);
     part[bucketx_takes(b, n, posor[(size_t)v]) ? 3 : force2 ? 2 : bucket_path_takes(b, n) ? 1 : bucket2_takes(b, n) ? 2 : 0].push_back(v);
   }
+  const int64_t chunk_records = sort_chunk_records();
   for (int kind = 3; kind >= 0; --kind) {
     std::vector<int> chunk;
     int64_t chunk_n = 0;
     for (size_t i = 0; i <= part[kind].size(); ++i) {
       const int64_t wgt = i < part[kind].size() ? b->L.vcfs[(size_t)part[kind][i]].n * (kind == 3 ? ext_parts_of(posor[(size_t)part[kind][i]]) : 1) : 0;   // (a partition reads its whole VCF)
-      const bool flush = i == part[kind].size() || (!chunk.empty() && chunk_n + wgt > SORT_CHUNK_RECORDS) ||
+      const bool flush = i == part[kind].size() || (!chunk.empty() && chunk_n + wgt > chunk_records) ||
                          (kind >= 1 && chunk.size() >= (size_t)(kind == 3 ? 4096 / PX_MAX_PARTS : 4096));   // 256 rows of 1.5 KB and >= 1 MB of bucket regions per VCF: bounded per chunk
       if (flush && !chunk.empty()) {
         int rc = QM_OK;
@@ -1758,6 +1801,43 @@ static int redo_unsorted(qm_batch* b, const std::vector<int>& todo, const std::v
   return QM_OK;
 }
 
+// The bucket chunks queued without a look at their flags (sort_chunk: speculate), behind the wait that ended the step: the mirrors
+// of their rows' k_finalize say whether a chunk fitted.  One that did not was left alone by k_sort_copy_rows (nothing of it joined
+// the per-truth sums) and goes through the radix sort now, followed by another rescan.
+static int settle_pending(qm_batch* b, const std::vector<uint32_t>& posor, hipStream_t st) {
+  std::vector<qm_batch::Pending> pend;
+  pend.swap(b->pend);
+  b->pend_segs = 0;
+  bool again = false;
+  for (const qm_batch::Pending& p : pend) {
+    const int nseg = (int)p.vs.size();
+    bool overflow = false;
+    for (int i = 0; i < nseg; ++i) {
+      uint32_t fl = b->h_summary[16 + 2 * (size_t)b->n_vcf + (size_t)p.off + (size_t)i];
+      if (p.tight) {
+        const uint32_t md = b->h_summary[16 + 3 * (size_t)b->n_vcf + (size_t)p.off + (size_t)i];
+        if (md > (uint32_t)p.nbk_launch) fl |= SPANF_OVERFLOW;   // (a remembered bound that no longer holds: cannot happen while the columns stay the same)
+        else if (memo_on()) {
+          if (b->known_nbk.empty()) b->known_nbk.assign((size_t)b->n_vcf, 0u);
+          b->known_nbk[(size_t)p.vs[(size_t)i]] = std::max(md, 1u);
+        }
+      }
+      if (fl & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", p.vs[(size_t)i]);
+      overflow = overflow || (fl & SPANF_OVERFLOW);
+    }
+    if (!overflow) { b->path_stats[p.direct ? QM_PATH_DIRECT : QM_PATH_HASHED] += nseg; continue; }
+    // a bucket did not fit its tables (dense positions, a dense truth set): the radix sort redoes the chunk from the columns
+    if (p.tight && !b->known_nbk.empty()) for (int v : p.vs) b->known_nbk[(size_t)v] = 0u;
+    b->path_stats[QM_PATH_OVERFLOW_CHUNKS] += 1;
+    b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += nseg;
+    const int rc = sort_chunk(b, p.vs, st, b->last_global, posor, false);
+    if (rc != QM_OK) return rc;
+    b->path_stats[QM_PATH_RADIX] -= nseg;
+    again = true;
+  }
+  return again ? rescan_and_compact(b, st) : QM_OK;
+}
+
 extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
   if (!b || !b->ran) return fail(QM_E_STATE, "qm_batch_finish: nothing was run");
   qm_ctx* c = b->ctx;
@@ -1765,6 +1845,7 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   if (b->finished) { HIPCHK(hipStreamSynchronize(st)); return QM_OK; }
   for (auto& x : b->path_stats) x = 0;
+  b->pend.clear(); b->pend_segs = 0;
   std::vector<uint32_t> posor((size_t)b->n_vcf, 0u);
   bool redone = false;
   if (b->run_used_known) {
@@ -1773,22 +1854,32 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
     for (int v = 0; v < b->n_vcf; ++v) if (b->known[(size_t)v]) { kn.push_back(v); posor[(size_t)v] = b->known_posor[(size_t)v]; }
     b->path_stats[QM_PATH_UNSORTED] += (int64_t)kn.size();
     const int rc = redo_unsorted(b, kn, posor, st);
-    if (rc != QM_OK) { forget_known(b, -1); return rc; }
+    if (rc != QM_OK) { (void)hipStreamSynchronize(st); b->pend.clear(); b->pend_segs = 0; forget_known(b, -1); return rc; }
     redone = !kn.empty();
   }
   // every VCF known to be out of order: the run launched no optimistic pass, nothing can have raised a flag, and the rescan below
   // goes onto the stream behind the bucket path without a round trip through the host in between
   const bool nothing_ran = b->run_used_known && b->n_known == b->n_vcf && b->h_summary != nullptr;
-  if (!nothing_ran) HIPCHK(hipStreamSynchronize(st));
+  // the flags (and their mirrors) are complete behind the k_finalize part that writes them: the wait is for that kernel, while the
+  // run's compaction and row sums go on -- the bucket path of what is found out of order is built and queued beside them
+  // (QM_FLAGS_WAIT=stream: wait for everything, as rounds 1-4 did)
+  bool idle = nothing_ran;   // has the stream been waited for?
+  if (!nothing_ran) {
+    if (b->flags_recorded && b->h_summary && flags_event_on()) HIPCHK(hipEventSynchronize(b->ev_flags));
+    else { HIPCHK(hipStreamSynchronize(st)); idle = true; }
+  }
   std::vector<int> todo;
   if (!nothing_ran && (!b->h_summary || *reinterpret_cast<volatile uint32_t*>(b->h_summary) != 0u)) {   // else: no VCF of the run carries a flag nobody knew of
     std::vector<uint32_t> fl((size_t)b->n_vcf);
     if (b->h_summary) memcpy(fl.data(), b->h_summary + 16, 4 * fl.size());   // k_finalize's host-mapped mirror: complete behind the wait above
     else HIPCHK(hipMemcpy(fl.data(), b->vcf_flags, 4 * fl.size(), hipMemcpyDeviceToHost));
     for (int v = 0; v < b->n_vcf; ++v) {
-      if (fl[(size_t)v] & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", v);
-      if (fl[(size_t)v] & SPANF_RUNLIMIT)
+      if (fl[(size_t)v] & (SPANF_BADPOS | SPANF_RUNLIMIT)) {
+        (void)hipStreamSynchronize(st);   // nothing of this run is left in flight behind the error
+        b->pend.clear(); b->pend_segs = 0;
+        if (fl[(size_t)v] & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", v);
         return fail(QM_E_LIMIT, "VCF %d repeats one position more than %d times between equal alleles (allele-extended de-duplication limit)", v, 1 << 14);
+      }
       if ((fl[(size_t)v] & SPANF_UNSORTED) && !(b->run_used_known && b->known[(size_t)v])) todo.push_back(v);
     }
     if (!todo.empty()) {
@@ -1798,14 +1889,15 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
       for (int v : todo) posor[(size_t)v] = po[(size_t)v];
       b->path_stats[QM_PATH_UNSORTED] += (int64_t)todo.size();
       const int rc = redo_unsorted(b, todo, posor, st);
-      if (rc != QM_OK) return rc;
+      if (rc != QM_OK) { (void)hipStreamSynchronize(st); b->pend.clear(); b->pend_segs = 0; return rc; }
       redone = true;
     }
   }
   if (redone) {
-    const int rc = rescan_and_compact(b, st);
-    if (rc != QM_OK) return rc;
-  } else if (nothing_ran) {
+    int rc = rescan_and_compact(b, st);
+    if (rc == QM_OK && !b->pend.empty()) rc = settle_pending(b, posor, st);
+    if (rc != QM_OK) { (void)hipStreamSynchronize(st); b->pend.clear(); b->pend_segs = 0; if (memo_on()) forget_known(b, -1); return rc; }
+  } else if (nothing_ran || !idle) {
     HIPCHK(hipStreamSynchronize(st));
   }
   if (memo_on() && !todo.empty()) {

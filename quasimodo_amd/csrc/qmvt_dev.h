@@ -153,6 +153,13 @@ struct FinalizeParams {
   // that the host reads them behind its wait for the stream without a copy of its own (two round trips of a first-seen step)
   uint32_t* host_flags;
   uint32_t* host_aux;
+  // bucket rows only, or null: ONE word of the chunk, raised when a "VCF" of the launch carries SPANF_OVERFLOW / SPANF_BADPOS or
+  // reached a bucket at or above row_cap_limit (the join was launched for the buckets below it): the kernels queued behind
+  // (k_sort_copy_rows) then leave the chunk's rows alone -- the host looks at the mirrors only at the end of the step and sends
+  // such a chunk through the radix sort
+  uint32_t* chunk_bad;
+  uint32_t row_cap_limit;
+  int32_t lazy_unsorted;   // 1 (qm_batch_run): a VCF found out of order gets its flags written and nothing else -- everything else of it is redone
 };
 
 struct CompactParams {
@@ -329,6 +336,8 @@ struct HashParams {
   int32_t seg_base;           // first segment of this launch of k_classify_hash
   int32_t scatter_hist;       // 1: the scatter counted every record by bin (BucketScatterParams.seg_hist): k_join_lean adds no histogram of its own but the true positives'
   const uint32_t* seg_maxd;   // or null: BucketScatterParams.seg_maxd of the scatter in front -- the workgroups of the buckets above leave at once (k_join_lean)
+  uint32_t* zero = nullptr;   // k_bucket_rows only, or null: n_zero words it clears on the way (the cursors, flags and counts of the scatter behind it:
+  uint32_t n_zero = 0;        // one dispatch instead of a memset's two in front of every chunk)
 };
 struct SortCols { const int32_t* pos; const int32_t* ref; const int32_t* alt; const float* qual; const uint8_t* flags; };
 
@@ -452,7 +461,7 @@ void launch_tile_counts(const SortSeg* segs, const int32_t* ktile_seg, const int
                         const uint64_t* mt, uint32_t* tile_tp, uint32_t* tile_fp, hipStream_t st);
 void launch_sort_copy_rows(const SortSeg* segs, int nseg, const uint64_t* sub_roc, const int64_t* sub_scal, uint64_t* roc,
                            int64_t* scal, int n_bins, hipStream_t st, uint64_t* global_add = nullptr, const VcfDesc* vcfs = nullptr,
-                           const int32_t* nparts = nullptr);
+                           const int32_t* nparts = nullptr, const uint32_t* gate = nullptr);
 void launch_bw_probe(int mode, const uint8_t* src, uint8_t* dst, int64_t bytes, uint32_t* sink, hipStream_t st);
 void launch_add_u64(uint64_t* dst, const uint64_t* src, int64_t n, hipStream_t st);
 void launch_overlap_pack(const int32_t* pos, const int32_t* ref, const int32_t* alt, const int32_t* set_of, int64_t n,

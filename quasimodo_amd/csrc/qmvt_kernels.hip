@@ -799,6 +799,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
   if (tb + 256 < sp_end) load_raw<EXT>(C, tb + 256 + lane * 4, N2);
 #endif
   SegBounds B = seg_bounds<PACKED>(C, tb, te, vn);
+#ifndef K1_NO_EARLY_LEAVE
+  if constexpr (!PACKED) {
+    // A span whose FIRST round is out of order leaves here, three round trips in (descriptor, positions, this look), instead of
+    // after its first tile (the truth side's chain of three more, four rounds of work, the epilogue's rows): the pass over a batch
+    // of shuffled VCFs is what a first-seen step pays before its bucket path can start (68 -> 2x us per 256 x 10^6 records).
+    // What is left behind is what anybody reads of an unsorted VCF's spans: the flag and the position bits (of the round's
+    // records: the buckets' bound, as before an estimate the scatter checks).  Only positions in range count -- a round with a
+    // bad one takes the long way and is flagged there -- and the record in front of the span is not looked at.
+    const int n0 = te - tb < 256 ? te - tb : 256;
+    const int j = lane * 4;
+    const int pl = __shfl_up(N.p.w, 1);
+    const bool ooo = (j + 1 < n0 && N.p.y < N.p.x) || (j + 2 < n0 && N.p.z < N.p.y) || (j + 3 < n0 && N.p.w < N.p.z) || (lane > 0 && j < n0 && N.p.x < pl);
+    uint32_t po = (j < n0 ? (uint32_t)N.p.x : 0u) | (j + 1 < n0 ? (uint32_t)N.p.y : 0u) | (j + 2 < n0 ? (uint32_t)N.p.z : 0u) | (j + 3 < n0 ? (uint32_t)N.p.w : 0u);
+    if (ballot64(ooo) != 0ull && ballot64((po >> 28) != 0u) == 0ull) {
+      for (int o = 32; o > 0; o >>= 1) po |= (uint32_t)__shfl_xor((int)po, o);
+      if (lane < 8) P.span_scal[(size_t)span_id * 8 + lane] = lane == 5 ? (uint32_t)SPANF_UNSORTED : lane == 6 ? po : 0u;
+      return;
+    }
+  }
+#endif
   int lo, hi;
   slice_range(tr, B.a, B.b, lo, hi);
   Slice S;
@@ -1047,6 +1067,29 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
   // P.parts: bit 0 = the part the compaction waits for (per-VCF flags, tile offsets), bit 1 = the rows (ROC, scalars, per-truth
   // sums).  qm_batch_run launches the two apart, the rows on the second stream beside the compaction; everybody else wants both.
   const bool rows = (P.parts & 2) != 0, offsets = (P.parts & 1) != 0;
+  // the per-VCF flags, the position bits and their host-mapped mirrors (what qm_batch_finish reads behind the run)
+  auto write_flags = [&](uint32_t fl) {
+    if (P.vcf_posor) P.vcf_posor[v] = s_or;
+    const uint32_t out = fl & (SPANF_UNSORTED | SPANF_BADPOS | SPANF_RUNLIMIT | SPANF_OVERFLOW);
+    P.vcf_flags[v] = out;
+    if (P.host_flags) {
+      __hip_atomic_store(P.host_flags + v, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(P.host_aux + v, P.row_cap ? P.row_cap[v] : s_or, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (out && P.flag_summary && !(out == SPANF_UNSORTED && P.known && P.known[v])) __hip_atomic_store(P.flag_summary, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-mapped: tells qm_batch_finish that the per-VCF flags are worth a copy
+    if (P.chunk_bad && ((out & (SPANF_OVERFLOW | SPANF_BADPOS)) || (P.row_cap && P.row_cap[v] > P.row_cap_limit))) atomicOr(P.chunk_bad, 1u);
+  };
+  // the run's own k_finalize (P.lazy_unsorted): a VCF its spans found out of order is redone from the columns -- rows, scalars,
+  // tile counts and offsets are all written again behind that (k_sort_copy_rows, k_tile_counts, the rescan) and the compaction of
+  // this run skips it: the flags are all anybody reads, and the workgroup leaves behind them (two of a first-seen step's
+  // dependent round trips: the rows' sums, or the tile counts and their scan)
+  if (P.lazy_unsorted) {
+    __syncthreads();
+    if (s_fl & SPANF_UNSORTED) {
+      if (offsets && tid == 5) write_flags(s_fl);
+      return;
+    }
+  }
   // sum span histograms.  A row is three histograms of 128 words (two u16 bins per word): thread t takes word t & 127 of the rows
   // t >> 7, t >> 7 + 2, ... -- every word is read once (thread = bin read every word twice) and a VCF's rows are walked by two
   // halves of the workgroup side by side, which is what matters for the few hundred workgroups this kernel has: the loop is bound
@@ -1107,16 +1150,7 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
       else if (tid == 6) sc[6] = vd.n;
       else sc[7] = P.ext ? P.truths[vd.truth].xn : P.truths[vd.truth].n;
     }
-    if (offsets && tid == 5) {
-      if (P.vcf_posor) P.vcf_posor[v] = s_or;
-      const uint32_t out = fl & (SPANF_UNSORTED | SPANF_BADPOS | SPANF_RUNLIMIT | SPANF_OVERFLOW);
-      P.vcf_flags[v] = out;
-      if (P.host_flags) {
-        __hip_atomic_store(P.host_flags + v, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(P.host_aux + v, P.row_cap ? P.row_cap[v] : s_or, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-      if (out && P.flag_summary && !(out == SPANF_UNSORTED && P.known && P.known[v])) __hip_atomic_store(P.flag_summary, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-mapped: tells qm_batch_finish that the per-VCF flags are worth a copy
-    }
+    if (offsets && tid == 5) write_flags(fl);
   }
   if (!offsets) return;
   // exclusive scan of the tile counts (TP and FP together) over the VCF's tiles: four consecutive tiles
@@ -2346,6 +2380,7 @@ __device__ __forceinline__ int hb_find(const uint32_t* tab, uint32_t log2n, uint
 
 // one descriptor per (segment, bucket) for k_classify_hash (qmvt_dev.h HashRow): grid = segments, thread = bucket
 __global__ __launch_bounds__(HB_BUCKETS) void k_bucket_rows(HashParams P) {
+  for (uint32_t i = blockIdx.x * HB_BUCKETS + threadIdx.x; i < P.n_zero; i += gridDim.x * HB_BUCKETS) P.zero[i] = 0u;
   const SortSeg sg = P.segs[blockIdx.x];
   const TruthDev tr = P.truths[P.vcfs[sg.main_vcf].truth];
   const uint32_t d = threadIdx.x, shift = (uint32_t)sg.pad;
@@ -3928,7 +3963,10 @@ __global__ __launch_bounds__(256) void k_tile_counts(const SortSeg* segs, const 
 // (every count of a row is additive over disjoint ranges of positions; T' is the truth set's, the same in every part)
 __global__ __launch_bounds__(256) void k_sort_copy_rows(const SortSeg* segs, const uint64_t* sub_roc, const int64_t* sub_scal,
                                                         uint64_t* roc, int64_t* scal, int n_bins, uint64_t* global_add, const VcfDesc* vcfs,
-                                                        const int32_t* nparts) {
+                                                        const int32_t* nparts, const uint32_t* gate) {
+  // gate (bucket path, or null): the chunk's "bad" word of k_finalize, final before this kernel starts -- a bucket overflowed, a
+  // position was out of range: the rows are not the VCFs' and the radix sort, which the host starts once it has looked, writes them
+  if (gate && *gate) return;
   const SortSeg sg = segs[blockIdx.x];
   const int n = 3 * n_bins;
   const int np = nparts ? nparts[blockIdx.x] : 1;
@@ -4102,8 +4140,9 @@ void launch_tile_counts(const SortSeg* segs, const int32_t* ktile_seg, const int
                        tile_tp, tile_fp);
 }
 void launch_sort_copy_rows(const SortSeg* segs, int nseg, const uint64_t* sub_roc, const int64_t* sub_scal, uint64_t* roc,
-                           int64_t* scal, int n_bins, hipStream_t st, uint64_t* global_add, const VcfDesc* vcfs, const int32_t* nparts) {
-  if (nseg > 0) hipLaunchKernelGGL(k_sort_copy_rows, dim3(nseg), dim3(256), 0, st, segs, sub_roc, sub_scal, roc, scal, n_bins, global_add, vcfs, nparts);
+                           int64_t* scal, int n_bins, hipStream_t st, uint64_t* global_add, const VcfDesc* vcfs, const int32_t* nparts,
+                           const uint32_t* gate) {
+  if (nseg > 0) hipLaunchKernelGGL(k_sort_copy_rows, dim3(nseg), dim3(256), 0, st, segs, sub_roc, sub_scal, roc, scal, n_bins, global_add, vcfs, nparts, gate);
 }
 void launch_classify_hash(const HashParams& P, int nseg, hipStream_t st) {
   if (nseg > 0) hipLaunchKernelGGL(k_classify_hash, dim3(HB_BUCKETS, nseg), dim3(HB_THREADS), 0, st, P);

@@ -929,6 +929,50 @@ def test_positions_above_what_the_optimistic_pass_saw(engine, oracle):
     b.close()
 
 
+@pytest.mark.parametrize("knobs", [{}, {"QM_SPECULATE": "0"}, {"QM_FLAGS_WAIT": "stream", "QM_NO_LAZY_FINALIZE": "1"}], ids=["queued", "looked-at", "round-4-waits"])
+def test_several_bucket_chunks_in_one_finish_one_of_which_does_not_fit(engine, oracle, monkeypatch, knobs):
+    """qm_batch_finish queues the last kernels of a bucket chunk without looking at the chunk's flags first (a round trip through
+    the host per chunk) and settles all chunks behind its last wait: a chunk whose buckets did not fit must not have added its
+    rows to the per-truth sums, goes through the radix sort then, and the compaction runs again.  Five unsorted VCFs in five
+    chunks (QM_SORT_CHUNK_RECORDS), the third of them 60 000 records on 16 positions; twice, the second time with the batch's
+    memory of the first; the knobs switch the round trips of round 4 back on, one by one."""
+    from conftest import random_columns, random_truth
+    from quasimodo_amd.engine import SCALAR_NAMES
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("QM_SORT_CHUNK_RECORDS", "50000")
+    rng = np.random.default_rng(515)
+    L = 400_000
+    truth = random_truth(rng, 8000, L)
+    tid = engine.truth_load(*truth)
+    cols = [random_columns(rng, n, L, truth, sorted_=False) for n in (40_000, 33_000)]
+    n = 60_000
+    pos = rng.integers(1000, 1016, n).astype(np.int32)
+    ref = rng.integers(0, 4, n).astype(np.int32)
+    alt = rng.integers(0, 4, n).astype(np.int32)
+    qual = rng.integers(0, 300, n).astype(np.float32)
+    cols.append((pos, ref, alt, qual, ((qual >= 20).astype(np.uint8) | 2).astype(np.uint8)))
+    cols += [random_columns(rng, n, L, truth, sorted_=s) for n, s in ((45_000, False), (20_000, True), (38_000, False))]
+    b = engine.batch([len(c[0]) for c in cols], [tid] * len(cols))
+    for v, c in enumerate(cols):
+        b.upload(v, *c)
+    for _ in range(2):
+        b.run()
+        b.finish()
+        want = np.zeros((3, 256), np.uint64)
+        for v, c in enumerate(cols):
+            sc = dict(zip(SCALAR_NAMES, b.scalars()[v].tolist()))
+            reg = b.idx(v)
+            res = {"cls": b.cls(v), "roc": b.roc()[v], "scalars": sc, "tp_idx": reg[:sc["tp_lines"]].copy(), "fp_idx": reg[len(c[0]) - sc["fp_lines"]:].copy()}
+            check_vcf(oracle, res, c, truth, expect_sorted=(v == 4))
+            want += res["roc"]
+        assert np.array_equal(b.global_counts()[tid], want)   # nothing of the chunk that did not fit was added twice
+        st = b.path_stats()
+        assert st["bucket_chunks"] == 5 and st["overflow_chunks"] == 1 and st["radix_after_overflow"] == 1 and st["bucket_direct"] == 4, st
+    b.close()
+    engine.truth_release(tid)
+
+
 def test_the_compaction_on_lists_of_every_density(engine, oracle):
     """k_compact stores a list chunk by chunk: a wave the chunks that begin among its entries, completed from the ONE tile behind
     its own; what lies beyond that reach is stored by the wave whose tiles hold it.  The lists must come out whole

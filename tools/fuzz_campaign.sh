@@ -19,5 +19,10 @@ SEED=112 run QM_BUCKET2=2 QM_MEMO=0
 SEED=113 run QM_NO_TIGHT_NBK=1
 SEED=115 run QM_TIGHT_NBK_ALL=1 QM_BUCKET2=2
 SEED=116 run QM_TIGHT_NBK_ALL=1 QM_BUCKETX=2
+# round 5, second half: finish without its round trips (flags event, queued chunk tails, lazy k_finalize) against the old waits; several chunks per finish
+SEED=117 run QM_SPECULATE=0
+SEED=118 run QM_FLAGS_WAIT=stream QM_NO_LAZY_FINALIZE=1
+SEED=119 run QM_SORT_CHUNK_RECORDS=60000
+SEED=120 run QM_SORT_CHUNK_RECORDS=60000 QM_MEMO=0
 SEED=114 run QM_COL_SLAB=1280                                   # the columns as pieces of one allocation
 cat $OUT
