@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -881,7 +882,10 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
     if (T) HIPCHK(hipEventRecord(e5[1], st));
     FinalizeParams F = finalize_params(b, g);
     F.vcf_base = ck.v0;
-    F.flag_summary = b->d_summary;
+    // (no summary word: with the mirrors, qm_batch_finish looks through the VCFs' flag words itself -- and every workgroup of a
+    // batch of shuffled VCFs storing to that ONE word of host memory made this kernel 50 us instead of 15: same-address stores
+    // to system memory queue up.  QM_FLAG_SUMMARY=1: as before.)
+    F.flag_summary = getenv("QM_FLAG_SUMMARY") ? b->d_summary : nullptr;
     if (b->d_summary) { F.host_flags = b->d_summary + 16; F.host_aux = b->d_summary + 16 + b->n_vcf; }
     if (use_known) F.known = b->d_known;
     F.lazy_unsorted = getenv("QM_NO_LAZY_FINALIZE") ? 0 : 1;
@@ -1846,6 +1850,11 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
   if (b->finished) { HIPCHK(hipStreamSynchronize(st)); return QM_OK; }
   for (auto& x : b->path_stats) x = 0;
   b->pend.clear(); b->pend_segs = 0;
+  // QM_FINISH_TRACE=1: the host's clock at the stations of this call, in us since it was entered (stderr)
+  static const bool ftrace = getenv("QM_FINISH_TRACE") != nullptr;
+  double ft[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto now_us = []() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; };
+  if (ftrace) ft[0] = now_us();
   std::vector<uint32_t> posor((size_t)b->n_vcf, 0u);
   bool redone = false;
   if (b->run_used_known) {
@@ -1868,8 +1877,9 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
     if (b->flags_recorded && b->h_summary && flags_event_on()) HIPCHK(hipEventSynchronize(b->ev_flags));
     else { HIPCHK(hipStreamSynchronize(st)); idle = true; }
   }
+  if (ftrace) ft[1] = now_us();
   std::vector<int> todo;
-  if (!nothing_ran && (!b->h_summary || *reinterpret_cast<volatile uint32_t*>(b->h_summary) != 0u)) {   // else: no VCF of the run carries a flag nobody knew of
+  if (!nothing_ran) {
     std::vector<uint32_t> fl((size_t)b->n_vcf);
     if (b->h_summary) memcpy(fl.data(), b->h_summary + 16, 4 * fl.size());   // k_finalize's host-mapped mirror: complete behind the wait above
     else HIPCHK(hipMemcpy(fl.data(), b->vcf_flags, 4 * fl.size(), hipMemcpyDeviceToHost));
@@ -1888,8 +1898,10 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
       else HIPCHK(hipMemcpy(po.data(), b->vcf_posor, 4 * po.size(), hipMemcpyDeviceToHost));
       for (int v : todo) posor[(size_t)v] = po[(size_t)v];
       b->path_stats[QM_PATH_UNSORTED] += (int64_t)todo.size();
+      if (ftrace) ft[2] = now_us();
       const int rc = redo_unsorted(b, todo, posor, st);
       if (rc != QM_OK) { (void)hipStreamSynchronize(st); b->pend.clear(); b->pend_segs = 0; return rc; }
+      if (ftrace) ft[3] = now_us();
       redone = true;
     }
   }
@@ -1906,6 +1918,11 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
   }
   for (int k = 0; k < QM_N_PATH_STATS; ++k) c->path_total[k] += b->path_stats[k];
   b->finished = true;
+  if (ftrace) {
+    ft[4] = now_us();
+    fprintf(stderr, "finish trace: flags waited for %.1f us, read %.1f, bucket path queued %.1f, everything done %.1f\n", ft[1] - ft[0],
+            ft[2] ? ft[2] - ft[0] : 0.0, ft[3] ? ft[3] - ft[0] : 0.0, ft[4] - ft[0]);
+  }
   return QM_OK;
 }
 
