@@ -808,7 +808,7 @@ static CompactParams compact_params(qm_batch* b) {
   CompactParams C;
   C.vcfs = b->d_vcfs; C.spans = b->d_spans; C.mask_pass = b->mask_pass; C.mask_tp = b->mask_tp;
   C.tile_fp = b->tile_fp; C.tile_tp_off = b->tile_tp_off; C.tile_fp_off = b->tile_fp_off; C.vcf_tot = b->vcf_tot; C.idx = b->idx;
-  C.vcf_flags = b->vcf_flags; C.skip_unsorted = 1; C.span_base = 0;
+  C.vcf_flags = b->vcf_flags; C.skip_unsorted = 1; C.span_base = 0; C.span_scal = b->span_scal;
   return C;
 }
 
@@ -892,16 +892,12 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
     // In one piece (the default), the compaction waits only for what it needs of k_finalize -- per-VCF flags and tile offsets --
     // and the rows (ROC, scalars, per-truth sums: 96 MB of span histograms to sum) go to the second stream beside it.
     const bool split = finalize_split_on() && nch == 1 && b->ev_sync[0] != nullptr;
-    if (split) {
-      HIPCHK(hipEventRecord(b->ev_sync[0], st));
-      HIPCHK(hipStreamWaitEvent(c->aux, b->ev_sync[0], 0));
-      F.parts = 2;
-      launch_finalize(F, ck.v1 - ck.v0, c->aux);
-      HIPCHK(hipEventRecord(b->ev_sync[1], c->aux));
-      F.parts = 1;
-    }
+    // (host order: what the compaction -- and a first-seen step's look at the flags -- waits for is queued first, the rows' part
+    // behind it; it starts beside the compaction either way)
+    if (split) F.parts = 1;
     launch_finalize(F, ck.v1 - ck.v0, st);
     if (k == nch - 1 && b->ev_flags && flags_event_on()) { HIPCHK(hipEventRecord(b->ev_flags, st)); b->flags_recorded = true; }   // every VCF's flags are written
+    if (split) HIPCHK(hipEventRecord(b->ev_sync[0], st));
     if (T) HIPCHK(hipEventRecord(e5[2], st));
     CompactParams K = compact_params(b);
     K.span_base = ck.s0;
@@ -911,6 +907,12 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
     }
     if (T) HIPCHK(hipEventRecord(e5[3], aux));
     launch_compact(K, ck.s1 - ck.s0, aux);
+    if (split) {
+      HIPCHK(hipStreamWaitEvent(c->aux, b->ev_sync[0], 0));
+      F.parts = 2;
+      launch_finalize(F, ck.v1 - ck.v0, c->aux);
+      HIPCHK(hipEventRecord(b->ev_sync[1], c->aux));
+    }
     if (T) HIPCHK(hipEventRecord(e5[4], aux));
   }
   if (all_known) {
@@ -975,12 +977,30 @@ static int regrow(T** p, int64_t* cap, int64_t need, int64_t* bytes) {
 // worth 256 workgroups and 256 histogram rows (smaller ones are sorted in no time); small enough for 256 buckets x 8 sub-regions
 // x 1 024 entries at five eighths full and for the 21 index bits of an entry.  QM_SORT_PATH=radix keeps everything on the sort,
 // QM_BUCKET_MIN moves the lower limit.
+// The knobs that say which path an unsorted VCF takes, read from the environment ONCE per qm_batch_finish (redo_unsorted): the
+// predicates below run once per VCF, and ten getenv calls per VCF were 22 us of a first-seen step's host time (256 VCFs) -- between
+// the flags' arrival and the first launch of the bucket path, with the device waiting.
+struct PathEnv {
+  bool radix_only = false;     // QM_SORT_PATH=radix
+  int bucket_ext = -1;         // QM_BUCKET_EXT (-1: unset)
+  int bucket2 = -1;            // QM_BUCKET2
+  int bucketx = -1;            // QM_BUCKETX
+  int64_t bucket_min = HB_MIN_RECORDS;   // QM_BUCKET_MIN: tests and tools/gpu_fuzz.py send their small VCFs through the buckets too
+};
+static thread_local PathEnv g_penv;
+static void refresh_path_env() {
+  PathEnv e;
+  if (const char* v = getenv("QM_SORT_PATH")) e.radix_only = strcmp(v, "radix") == 0;
+  if (const char* v = getenv("QM_BUCKET_EXT")) e.bucket_ext = atoi(v);
+  if (const char* v = getenv("QM_BUCKET2")) e.bucket2 = atoi(v);
+  if (const char* v = getenv("QM_BUCKETX")) e.bucketx = atoi(v);
+  if (const char* v = getenv("QM_BUCKET_MIN")) e.bucket_min = atoll(v);
+  g_penv = e;
+}
 static bool bucket_path_takes(const qm_batch* b, int64_t n) {
-  if (b->ext) if (const char* e = getenv("QM_BUCKET_EXT")) if (atoi(e) == 0) return false;   // allele-extended batches on the radix sort only
-  if (const char* e = getenv("QM_SORT_PATH")) if (strcmp(e, "radix") == 0) return false;
-  int64_t lo = HB_MIN_RECORDS;
-  if (const char* e = getenv("QM_BUCKET_MIN")) lo = atoll(e);   // tests and tools/gpu_fuzz.py send their small VCFs through the buckets too
-  return n >= lo && n <= (int64_t)HB_BUCKETS * HB_MAX_RECORDS * 5 / 8 && n <= ((int64_t)1 << HB_INDEX_BITS);
+  if (b->ext && g_penv.bucket_ext == 0) return false;   // allele-extended batches on the radix sort only
+  if (g_penv.radix_only) return false;
+  return n >= g_penv.bucket_min && n <= (int64_t)HB_BUCKETS * HB_MAX_RECORDS * 5 / 8 && n <= ((int64_t)1 << HB_INDEX_BITS);
 }
 
 static bool join_hash_forced() {
@@ -1033,7 +1053,10 @@ static FinalizeParams bucket_rows_finalize(qm_batch* b, const uint32_t* all_hist
 }
 
 // posor[v]: OR of the positions the optimistic pass saw in VCF v (which position bits are in use)
+static double g_ftrace[4];   // QM_FINISH_TRACE: host clock inside the latest sort_chunk (entered, tables ready, scatter queued)
+static double ftrace_now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; }
 static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, const std::vector<uint32_t>& posor, bool buckets) {
+  g_ftrace[0] = ftrace_now();
   const int nseg = (int)vs.size();
   std::vector<int32_t> tids((size_t)nseg);
   for (int i = 0; i < nseg; ++i) tids[(size_t)i] = b->L.vcfs[(size_t)vs[(size_t)i]].truth;
@@ -1185,6 +1208,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     H.scatter_hist = seg_hist ? 1 : 0;
     H.seg_maxd = nullptr;   // (set below once the launch shape is known)
     H.zero = b->bk_cursor; H.n_zero = (uint32_t)(ncur / 4);   // the scatter's cursors, flags, counts: cleared by the kernel that writes the rows
+    g_ftrace[1] = ftrace_now();
     launch_bucket_rows(H, nseg, st);
     H.zero = nullptr; H.n_zero = 0u;
     // The scatter streams (memory-bound, its SIMDs half idle), the join issues instructions (and hardly waits for memory): in a
@@ -1213,6 +1237,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
         const int t0 = segs[(size_t)i0].bk_tile0, t1 = i1 < nseg ? segs[(size_t)i1].bk_tile0 : nbt;
         S.tile_base = t0;
         launch_bucket_scatter(S, t1 - t0, st);
+        g_ftrace[2] = ftrace_now();
         if (parts > 1) {
           HIPCHK(hipEventRecord(b->ev_sync[p], st));
           HIPCHK(hipStreamWaitEvent(aux, b->ev_sync[p], 0));
@@ -1377,11 +1402,11 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
 // ---- two-level bucket path (qmvt_dev.h): VCFs too large for 256 buckets of 8 192 records ----
 static bool bucket2_takes(const qm_batch* b, int64_t n) {
   if (b->ext) return false;
-  if (const char* e = getenv("QM_SORT_PATH")) if (strcmp(e, "radix") == 0) return false;
-  if (const char* e = getenv("QM_BUCKET2")) if (atoi(e) == 0) return false;
+  if (g_penv.radix_only) return false;
+  if (g_penv.bucket2 == 0) return false;
   if (join_hash_forced()) return false;
   if (n > (int64_t)P2_MAX_HALVES << P2_INDEX_BITS) return false;   // (VCFs above 2^24 records: in runs of 2^24, level-1 segments of their own)
-  if (const char* e = getenv("QM_BUCKET2")) if (atoi(e) == 2) return n > 0;   // tests and tools/gpu_fuzz.py: every unsorted VCF takes the two levels
+  if (g_penv.bucket2 == 2) return n > 0;   // tests and tools/gpu_fuzz.py: every unsorted VCF takes the two levels
   return !bucket_path_takes(b, n) && n >= HB_MIN_RECORDS;
 }
 
@@ -1608,13 +1633,14 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
 constexpr int PX_MAX_PARTS = 4;
 static int ext_parts_of(uint32_t posor) { return (int)((((uint64_t)posor << 4) | 15u) >> P2_SHIFT) + 1; }
 static bool bucketx_takes(const qm_batch* b, int64_t n, uint32_t posor) {
-  if (b->ext) if (const char* e = getenv("QM_BUCKET_EXT")) if (atoi(e) == 0) return false;
-  if (const char* e = getenv("QM_SORT_PATH")) if (strcmp(e, "radix") == 0) return false;
+  if (b->ext && g_penv.bucket_ext == 0) return false;
+  if (g_penv.radix_only) return false;
   if (join_hash_forced()) return false;
   if (n < HB_MIN_RECORDS || n > ((int64_t)1 << HB_INDEX_BITS)) return false;
   const int parts = ext_parts_of(posor);
   if (parts > PX_MAX_PARTS) return false;
-  if (const char* e = getenv("QM_BUCKETX")) { if (atoi(e) == 0) return false; if (atoi(e) == 2) return true; }   // 2: every unsorted VCF that fits (tests, fuzz)
+  if (g_penv.bucketx == 0) return false;
+  if (g_penv.bucketx == 2) return true;   // 2: every unsorted VCF that fits (tests, fuzz)
   if (b->ext) return parts > 1 || !bucket_path_takes(b, n);
   // default mode: a reference of 8.4 ... 16.8 M positions is ONE pair of partitions = one pass of the 512-digit scatter and the
   // bit-map join, where the one-level path would need the hashed join (bucket key ranges of 2^20) and larger VCFs two levels
@@ -1769,10 +1795,11 @@ static int redo_unsorted(qm_batch* b, const std::vector<int>& todo, const std::v
   // the VCFs the bucket path takes (by size: a VCF costs it 256 workgroups and 256 rows whatever it holds, and its
   // buckets hold 8 192 records at most) in chunks of their own, the others on the radix sort
   // kind 3: allele-extended VCFs in partitions read from the columns (bucketx_chunk)
+  refresh_path_env();
   std::vector<int> part[4];
   for (int v : todo) {
     const int64_t n = b->L.vcfs[(size_t)v].n;
-    const bool force2 = getenv("QM_BUCKET2") && atoi(getenv("QM_BUCKET2")) == 2 && bucket2_takes(b, n);
+    const bool force2 = g_penv.bucket2 == 2 && bucket2_takes(b, n);
     part[bucketx_takes(b, n, posor[(size_t)v]) ? 3 : force2 ? 2 : bucket_path_takes(b, n) ? 1 : bucket2_takes(b, n) ? 2 : 0].push_back(v);
   }
   const int64_t chunk_records = sort_chunk_records();
@@ -1920,8 +1947,8 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
   b->finished = true;
   if (ftrace) {
     ft[4] = now_us();
-    fprintf(stderr, "finish trace: flags waited for %.1f us, read %.1f, bucket path queued %.1f, everything done %.1f\n", ft[1] - ft[0],
-            ft[2] ? ft[2] - ft[0] : 0.0, ft[3] ? ft[3] - ft[0] : 0.0, ft[4] - ft[0]);
+    fprintf(stderr, "finish trace: flags waited for %.1f us, read %.1f, bucket path queued %.1f, everything done %.1f (the latest chunk: entered %.1f, tables %.1f, scatter queued %.1f)\n", ft[1] - ft[0],
+            ft[2] ? ft[2] - ft[0] : 0.0, ft[3] ? ft[3] - ft[0] : 0.0, ft[4] - ft[0], g_ftrace[0] - ft[0], g_ftrace[1] - ft[0], g_ftrace[2] - ft[0]);
   }
   return QM_OK;
 }

@@ -175,6 +175,7 @@ struct CompactParams {
   const uint32_t* vcf_flags;   // written by k_finalize of the same run
   int32_t skip_unsorted;       // 1: leave VCFs flagged unsorted alone (they are redone); 0: compact everything
   int32_t span_base;           // first span of this launch
+  const uint32_t* span_scal;   // (skip_unsorted) the spans' scalar rows of k_classify: word 5 = the span's own flags
 };
 
 // one unsorted VCF inside a sort chunk

@@ -1419,6 +1419,14 @@ __global__ __launch_bounds__(64 * K3_WAVES) void k_compact(CompactParams P) {
   constexpr int NLUT = (256 + 64 * K3_WAVES - 1) / (64 * K3_WAVES);
   constexpr int NPRE = K3_NPASS + K3_EXTRA;                 // passes whose mask bytes are asked for at the start
   const int L = (int)blockIdx.x;   // launch order (an XCD-contiguous tile order was measured with the other ownership form only; not kept)
+#ifndef K3_NO_OWN_LOOK
+  // A span that k_classify itself left as out of order belongs to a VCF this launch skips (its flags say so, below): the span's
+  // own word, asked for beside its descriptor, lets the workgroup go one round trip earlier -- the launch over a batch of
+  // shuffled VCFs is 7 rounds of workgroups that all do just that (28 -> 1x us of a first-seen step)
+  const uint32_t own_fl = P.skip_unsorted ? P.span_scal[(size_t)(L / BPS + P.span_base) * 8 + 5] : 0u;
+#else
+  const uint32_t own_fl = 0u;
+#endif
   const SpanDesc sp = P.spans[L / BPS + P.span_base];
   // everything the wave needs is asked for at once, behind the span descriptor: the table, the VCF's flags and list sizes, the
   // offsets of its first tile, of its neighbours' and of the tiles behind them, the mask bytes of its passes and of the tile behind
@@ -1428,6 +1436,7 @@ __global__ __launch_bounds__(64 * K3_WAVES) void k_compact(CompactParams P) {
     const int i = tid + k * 64 * K3_WAVES;
     lut[k] = reinterpret_cast<const uint2*>(k3_lut.w)[i < 256 ? i : 0];
   }
+  if (own_fl & SPANF_UNSORTED) return;   // (the whole workgroup: one span)
   const int tl = ((L % BPS) * K3_WAVES + wave) * K3_TILES;     // the wave's first tile inside the span
   const int rb = (int)(sp.begin - sp.voff) + tl * K1_TILE;     // its first record inside the VCF (a multiple of K1_TILE)
   const bool live = (int64_t)sp.voff + rb < sp.end;
