@@ -886,8 +886,8 @@ def test_unsorted_vcfs_on_a_reference_of_ten_million_positions_take_a_pair_of_pa
 
 
 def test_positions_above_what_the_optimistic_pass_saw(engine, oracle):
-    """The optimistic pass leaves a span at its first tile out of order, so the OR of the positions it saw can miss the highest
-    ones; the bucket path sizes its join by that OR.  A shuffled VCF (every span is left after its first tile) whose first tiles
+    """The optimistic pass leaves a span at its first ROUND out of order (256 records; its first tile until round 5), so the OR of the
+    positions it saw can miss the highest ones; the bucket path sizes its join by that OR.  A shuffled VCF (every span is left at once) whose first tiles
     hold no position with bit 21 or above 0x5fffff -- an OR of 0x5fffff: 192 buckets of 256 -- while a quarter of the other
     records lie at 0x600000 and above (buckets 192..255): those records must be classified (by the radix sort, after the scatter
     flags the VCF), not dropped (the join was trimmed to the buckets below the estimate and nothing noticed).
@@ -896,7 +896,7 @@ def test_positions_above_what_the_optimistic_pass_saw(engine, oracle):
     n, span = 40000, 16384
     seen = np.zeros(n, bool)
     for s0 in range(0, n, span):
-        seen[s0:s0 + 1024] = True   # the first tile of every span: all the optimistic pass sees of a shuffled VCF
+        seen[s0:s0 + 1024] = True   # the first tile of every span: all the optimistic pass ever saw of a shuffled VCF (its first 256 records now)
     lo = rng.choice(np.concatenate([np.arange(1, 0x200000), np.arange(0x400000, 0x600000)]), size=n - n // 4, replace=False)
     hi = rng.choice(np.arange(0x600000, 0x800000), size=n // 4, replace=False)
     pos = np.empty(n, np.int32)
