@@ -635,7 +635,8 @@ static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int
   if (rc == QM_OK && !packed) {   // (the scratch batches of the sort path are finalized without it)
     void* h = nullptr;
     void* d = nullptr;
-    if (hipHostMalloc(&h, 64 + 16 * (size_t)std::max(n_vcf, 1), hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+    // (QM_NO_MIRRORS=1, tests: as if the mapping had failed -- the flags come back by copies, every chunk is looked at before its last kernels)
+    if (!getenv("QM_NO_MIRRORS") && hipHostMalloc(&h, 64 + 16 * (size_t)std::max(n_vcf, 1), hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
       b->h_summary = static_cast<uint32_t*>(h);
       b->d_summary = static_cast<uint32_t*>(d);
       memset(h, 0, 64 + 16 * (size_t)std::max(n_vcf, 1));   // [16 words: the summary][n_vcf flags][n_vcf position bits][n_vcf bucket-row flags][n_vcf highest buckets]: k_finalize's host-mapped mirrors

@@ -929,7 +929,8 @@ def test_positions_above_what_the_optimistic_pass_saw(engine, oracle):
     b.close()
 
 
-@pytest.mark.parametrize("knobs", [{}, {"QM_SPECULATE": "0"}, {"QM_FLAGS_WAIT": "stream", "QM_NO_LAZY_FINALIZE": "1"}], ids=["queued", "looked-at", "round-4-waits"])
+@pytest.mark.parametrize("knobs", [{}, {"QM_SPECULATE": "0"}, {"QM_FLAGS_WAIT": "stream", "QM_NO_LAZY_FINALIZE": "1"}, {"QM_NO_MIRRORS": "1"}],
+                         ids=["queued", "looked-at", "round-4-waits", "no-host-mapped-mirrors"])
 def test_several_bucket_chunks_in_one_finish_one_of_which_does_not_fit(engine, oracle, monkeypatch, knobs):
     """qm_batch_finish queues the last kernels of a bucket chunk without looking at the chunk's flags first (a round trip through
     the host per chunk) and settles all chunks behind its last wait: a chunk whose buckets did not fit must not have added its

@@ -24,5 +24,6 @@ SEED=117 run QM_SPECULATE=0
 SEED=118 run QM_FLAGS_WAIT=stream QM_NO_LAZY_FINALIZE=1
 SEED=119 run QM_SORT_CHUNK_RECORDS=60000
 SEED=120 run QM_SORT_CHUNK_RECORDS=60000 QM_MEMO=0
+SEED=121 run QM_NO_MIRRORS=1
 SEED=114 run QM_COL_SLAB=1280                                   # the columns as pieces of one allocation
 cat $OUT
