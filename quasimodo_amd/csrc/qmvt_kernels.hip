@@ -803,7 +803,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
   if constexpr (!PACKED) {
     // A span whose FIRST round is out of order leaves here, three round trips in (descriptor, positions, this look), instead of
     // after its first tile (the truth side's chain of three more, four rounds of work, the epilogue's rows): the pass over a batch
-    // of shuffled VCFs is what a first-seen step pays before its bucket path can start (68 -> 2x us per 256 x 10^6 records).
+    // of shuffled VCFs is what a first-seen step pays before its bucket path can start (68 -> 20 us per 256 x 10^6 records).
     // What is left behind is what anybody reads of an unsorted VCF's spans: the flag and the position bits (of the round's
     // records: the buckets' bound, as before an estimate the scatter checks).  Only positions in range count -- a round with a
     // bad one takes the long way and is flagged there -- and the record in front of the span is not looked at.
@@ -1422,7 +1422,7 @@ __global__ __launch_bounds__(64 * K3_WAVES) void k_compact(CompactParams P) {
 #ifndef K3_NO_OWN_LOOK
   // A span that k_classify itself left as out of order belongs to a VCF this launch skips (its flags say so, below): the span's
   // own word, asked for beside its descriptor, lets the workgroup go one round trip earlier -- the launch over a batch of
-  // shuffled VCFs is 7 rounds of workgroups that all do just that (28 -> 1x us of a first-seen step)
+  // shuffled VCFs is 7 rounds of workgroups that all do just that (28 -> 8 us of device time on a first-seen step)
   const uint32_t own_fl = P.skip_unsorted ? P.span_scal[(size_t)(L / BPS + P.span_base) * 8 + 5] : 0u;
 #else
   const uint32_t own_fl = 0u;
@@ -1925,7 +1925,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   if (!L2 && tid >= 256 && tid < 272) s_flut[tid - 256] = flag_info((uint32_t)(tid - 256));
   const uint32_t dlim = NB == 512 && (sg.part & 4) ? 512u : (uint32_t)HB_BUCKETS;   // buckets this tile's segment stands for
   // a whole VCF in one segment (part 0): the host joins and sums only the sg.nbk buckets up to the highest position the optimistic
-  // pass SAW -- and that pass leaves a span at its first tile out of order, so later tiles can hold higher positions: a record
+  // pass SAW -- and that pass leaves a span at its first round out of order, so later records can hold higher positions: a record
   // beyond the estimate flags the VCF (the radix sort redoes it) instead of landing in a bucket nobody looks at
   const uint32_t olim = sg.part == 0 ? (uint32_t)sg.nbk : dlim;
   __syncthreads();
