@@ -485,8 +485,8 @@ struct qm_batch {
   // same context change neither the size of global_acc nor what qm_batch_get_global copies.
   int n_truth = 1;
   std::vector<std::pair<int, uint32_t>> truth_gens;   // (truth id, generation) of every truth set a VCF names
-  // one word of host memory the device can write: k_finalize sets it when any VCF carries a flag (unsorted, bad position, ...), so
-  // that qm_batch_finish reads the per-VCF flags back only then
+  // host memory the device can write: [16 words, unused since the summary word went][n_vcf flags][n_vcf position bits][n_vcf
+  // bucket-row flags][n_vcf highest buckets] -- k_finalize's mirrors of the per-VCF words qm_batch_finish looks at (no copies)
   uint32_t* h_summary = nullptr;
   uint32_t* d_summary = nullptr;
   // where the unsorted VCFs of the last qm_batch_finish went (qm_batch_path_stats)
