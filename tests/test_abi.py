@@ -181,3 +181,23 @@ def test_traffic_json_names_the_current_device_code():
         import warnings
         warnings.warn("profiles/traffic.json was measured on device code %s, the tree holds %s: bench.py will print roofline.traffic = null "
                       "until tools/final_profiles.sh has run on the GPU again" % (t["kernels_build"], quasimodo_amd.kernel_source_id()))
+
+
+def test_every_knob_the_sources_read_is_named_in_integration_md():
+    """INTEGRATION.md's Environment section is the list of QM_* variables: a knob added to the library, the package or the CLI
+    without a line there is a knob nobody can find (round 5 found five).  bench.py's own QM_BENCH_* are the defaults of its
+    flags and are named as a family."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    named = set(re.findall(r"QM_[A-Z0-9_]+", doc))
+    assert "QM_BENCH_" in doc
+    read = set()
+    for f in glob.glob(os.path.join(root, "quasimodo_amd", "csrc", "*.[ch]*")):
+        read |= set(re.findall(r'getenv\("(QM_[A-Z0-9_]+)"\)', open(f, errors="replace").read()))
+    for f in glob.glob(os.path.join(root, "quasimodo_amd", "*.py")) + [os.path.join(root, n) for n in ("run_benchmark.py", "__graft_entry__.py")] + \
+            glob.glob(os.path.join(root, "program", "*.py")):
+        read |= set(re.findall(r'environ[^\n"]*"(QM_[A-Z0-9_]+)"', open(f).read()))
+    missing = sorted(k for k in read if k not in named and not k.startswith("QM_BENCH_"))
+    assert not missing, "not named in INTEGRATION.md: %s" % ", ".join(missing)
