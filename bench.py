@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--alleles-vcfs", type=int, default=int(os.environ.get("QM_BENCH_ALLELES_VCFS", "1000")),
                     help="also time the allele-extended variant (config 4's record shape) on this many VCFs at N=1, config 2; 0 disables")
     ap.add_argument("--shuffled-alleles-vcfs", type=int, default=int(os.environ.get("QM_BENCH_SHUFFLED_ALLELES_VCFS", "256")),
-                    help="also time shuffled allele-extended VCFs (config 4's record shape: two entry streams, k_join_direct + k_join_ext) on this many VCFs at N=1, config 2; 0 disables")
+                    help="also time shuffled allele-extended VCFs (config 4's record shape: two entry streams, k_join_lean + k_join_ext) on this many VCFs at N=1, config 2; 0 disables")
     ap.add_argument("--shuffled4-vcfs", type=int, default=int(os.environ.get("QM_BENCH_SHUFFLED4_VCFS", "48")),
                     help="also time shuffled VCFs of configs[4]'s shape (2 M records on a 10 Mb reference, 30 % variable-length alleles, three truth sets: partitions of buckets) on this many VCFs at N=1, config 2; 0 disables")
     ap.add_argument("--alloc-reps", type=int, default=int(os.environ.get("QM_BENCH_ALLOC_REPS", "3")),
@@ -417,6 +417,22 @@ def _timed_with_and_without_memory(b, steps):
     return dt, dt0
 
 
+def _timed_fresh_columns(b, steps, rewrite):
+    """First-seen without any knob: the columns are written again before every step (`rewrite(i)`, untimed) -- what a caller does who
+    streams new VCFs through one batch object; the write itself clears the batch's memory of what it found (include/qmvt.h).  Every step is
+    timed on its own, from an idle device to the end of qm_batch_finish."""
+    import torch
+    tot = 0.0
+    for i in range(steps):
+        rewrite(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        b.run()
+        b.finish()
+        tot += time.perf_counter() - t0
+    return tot / steps
+
+
 def shuffled_variant(eng, tid, P, bins, nv, tseed, sorted_roc):
     """Config 3's second variant: the same VCFs with their records permuted, so every VCF takes the
     optimistic pass, is found out of order and goes through the batched radix-sort path.  A side
@@ -430,13 +446,20 @@ def shuffled_variant(eng, tid, P, bins, nv, tseed, sorted_roc):
         b.finish()
     steps = 3
     dt, dt0 = _timed_with_and_without_memory(b, steps)
+    # the same shape with OTHER records every step (other seeds), then the first records again for the comparison below
+    dtf = _timed_fresh_columns(b, steps, lambda i: b.synth(P["genome"], P["truth"], tseed, P["seed"] + 104729 * (i + 1), shuffled=True))
+    b.synth(P["genome"], P["truth"], tseed, P["seed"], shuffled=True)
+    b.run()
+    b.finish()
     ok = bool(np.array_equal(b.roc(), sorted_roc[:nv])) and int(b.scalars()[:, 5].sum()) == 0
     paths = b.path_stats()
     b.close()
     return {"value": nv * float(P["records"]) / dt0, "value_repeated_run": nv * float(P["records"]) / dt, "unit": "classifications/s", "vcfs": nv, "steps": steps,
-            "ms_per_step": dt * 1e3, "ms_per_step_unseen": dt0 * 1e3, "roc_equals_sorted_variant": ok, "paths": paths,
-            "note": "records permuted: optimistic pass (stops early) + bucket path (one scatter pass into 256 position buckets per VCF, k_join_direct: one bit per "
-                    "key of the bucket in LDS, no sort and no hashing inside a bucket, TP bits straight into the input-order mask); `paths` says where the VCFs went"}
+            "ms_per_step": dt * 1e3, "ms_per_step_unseen": dt0 * 1e3, "ms_per_step_fresh_columns": dtf * 1e3, "value_fresh_columns": nv * float(P["records"]) / dtf,
+            "roc_equals_sorted_variant": ok, "paths": paths,
+            "note": "records permuted: optimistic pass (stops early) + bucket path (one scatter pass into 256 position buckets per VCF, k_join_lean: two bits per "
+                    "POSITION of the bucket in LDS, no sort and no hashing inside a bucket, TP bits straight into the input-order mask); `value` = first-seen (QM_MEMO=0 on the same "
+                    "records), `value_fresh_columns` = the columns written again with other records before every step, no knob; `paths` says where the VCFs went"}
 
 
 def shuffled_config3_variant(eng, bins, nv):
@@ -464,7 +487,7 @@ def shuffled_config3_variant(eng, bins, nv):
     return {"value": nv * float(P3["records"]) / dt0, "value_repeated_run": nv * float(P3["records"]) / dt, "unit": "classifications/s", "vcfs": nv, "records_per_vcf": P3["records"], "steps": steps,
             "ms_per_step": dt * 1e3, "ms_per_step_unseen": dt0 * 1e3, "equals_sorted_variant": ok, "paths": paths,
             "note": "10 M-record VCFs permuted: k_part_hist + k_part_scatter (level 1: partitions of 2^27 keys, exact regions), then k_bucket_scatter from the "
-                    "level-1 entries and k_join_direct per partition"}
+                    "level-1 entries and k_join_lean per partition"}
 
 
 def alleles_variant(eng, P, bins, nv):
@@ -504,7 +527,7 @@ def alleles_variant(eng, P, bins, nv):
 
 def shuffled_alleles_variant(eng, P, bins, nv):
     """BASELINE configs[4]'s record shape (30 % of the records with variable-length alleles) with the records permuted: the bucket
-    path with two entry streams -- single-base records through k_join_direct, the others (16-byte entries with their allele
+    path with two entry streams -- single-base records through k_join_lean, the others (16-byte entries with their allele
     codes) through k_join_ext, exact on (position, REF, ALT).  A side measurement; the counters must equal the sorted run's."""
     import numpy as np
     import torch
@@ -525,7 +548,7 @@ def shuffled_alleles_variant(eng, P, bins, nv):
     ok = bool(np.array_equal(rows[True][0], rows[False][0]) and np.array_equal(rows[True][1], rows[False][1]))
     return {"value": nv * float(P["records"]) / dt0, "value_repeated_run": nv * float(P["records"]) / dt, "unit": "classifications/s", "vcfs": nv, "steps": steps, "ms_per_step": dt * 1e3, "ms_per_step_unseen": dt0 * 1e3,
             "indel_pct": pct, "equals_sorted_variant": ok, "paths": paths,
-            "note": "allele-extended VCFs permuted: one scatter into two entry streams per bucket, k_join_direct (single-base records) + k_join_ext (the others)"}
+            "note": "allele-extended VCFs permuted: one scatter into two entry streams per bucket, k_join_lean (single-base records) + k_join_ext (the others)"}
 
 
 def shuffled_config4_variant(eng, bins, nv):
@@ -553,7 +576,7 @@ def shuffled_config4_variant(eng, bins, nv):
     return {"value": nv * float(P4["records"]) / dt0, "value_repeated_run": nv * float(P4["records"]) / dt, "unit": "classifications/s", "vcfs": nv, "records_per_vcf": P4["records"], "steps": steps,
             "ms_per_step": dt * 1e3, "ms_per_step_unseen": dt0 * 1e3, "indel_pct": P4["indel_pct"], "equals_sorted_variant": ok, "paths": paths,
             "note": "2 M-record allele-extended VCFs on a 10 Mb reference permuted: two partitions of 2^27 keys per VCF, each a segment of the one-level "
-                    "scatter reading the VCF's columns (SortSeg.part); k_join_direct + k_join_ext per bucket; `paths` counts them as bucket_two_level"}
+                    "scatter reading the VCF's columns (SortSeg.part); k_join_lean + k_join_ext per bucket; `paths` counts them as bucket_two_level"}
 
 
 def shell_baseline(batch, P, n_sample, tseed):
