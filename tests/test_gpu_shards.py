@@ -216,6 +216,8 @@ def test_bench_line_contract_on_a_small_batch(qmlib):
         assert v["ms_per_step_unseen"] >= 0 and v["value"] > 0 and v["value_repeated_run"] > 0
         assert abs(v["value"] - v["vcfs"] * v.get("records_per_vcf", 1_000_000) / (v["ms_per_step_unseen"] * 1e-3)) < 1e-6 * v["value"]
         assert v.get("roc_equals_sorted_variant", v.get("equals_sorted_variant")) is True
+    sv = d["shuffled_variant"]   # first-seen a third way: the columns written again with other records before every step (and the first ones back for the comparison above)
+    assert sv["value_fresh_columns"] > 0 and abs(sv["value_fresh_columns"] - sv["vcfs"] * 1_000_000 / (sv["ms_per_step_fresh_columns"] * 1e-3)) < 1e-6 * sv["value_fresh_columns"]
     assert d["alleles_variant"]["equals_oracle_on_vcf0"] is True
 
 
