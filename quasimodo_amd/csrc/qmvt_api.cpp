@@ -1054,7 +1054,7 @@ static FinalizeParams bucket_rows_finalize(qm_batch* b, const uint32_t* all_hist
 }
 
 // posor[v]: OR of the positions the optimistic pass saw in VCF v (which position bits are in use)
-static double g_ftrace[4];   // QM_FINISH_TRACE: host clock inside the latest sort_chunk (entered, tables ready, scatter queued)
+static thread_local double g_ftrace[4];   // QM_FINISH_TRACE: host clock inside the latest sort_chunk (entered, tables ready, scatter queued)
 static double ftrace_now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; }
 static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, const std::vector<uint32_t>& posor, bool buckets) {
   g_ftrace[0] = ftrace_now();
