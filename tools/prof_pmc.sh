@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes for k_classify (separate from any trace run, as the pool requires).
-# usage: bash tools/prof_pmc.sh <tag> [n_vcf]
+# usage: bash tools/prof_pmc.sh <tag> [n_vcf]      RARGS="0 30": run_once.py's further arguments (shuffled, indel_pct) -- the allele-extended instantiation
 set -e
 TAG=${1:-x}; NV=${2:-256}
 export TMPDIR=/tmp
@@ -8,7 +8,7 @@ OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 run() { # name counters...
   local name=$1; shift
-  (cd /tmp && rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $OLDPWD/tools/run_once.py $NV 2 > $OUT/$name.log 2>&1) || true
+  (cd /tmp && rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 $OLDPWD/tools/run_once.py $NV 2 ${RARGS:-} > $OUT/$name.log 2>&1) || true
 }
 OLDPWD=$PWD
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM
