@@ -75,9 +75,13 @@ def main():
                     help="also time shuffled allele-extended VCFs (config 4's record shape: two entry streams, k_join_lean + k_join_ext) on this many VCFs at N=1, config 2; 0 disables")
     ap.add_argument("--shuffled4-vcfs", type=int, default=int(os.environ.get("QM_BENCH_SHUFFLED4_VCFS", "48")),
                     help="also time shuffled VCFs of configs[4]'s shape (2 M records on a 10 Mb reference, 30 % variable-length alleles, three truth sets: partitions of buckets) on this many VCFs at N=1, config 2; 0 disables")
+    ap.add_argument("--multicontig-vcfs", type=int, default=int(os.environ.get("QM_BENCH_MULTICONTIG_VCFS", "256")),
+                    help="also time VCFs sorted per contig (24 ascending runs one behind the other; CHROM is never compared) on this many VCFs at N=1, config 2; 0 disables")
     ap.add_argument("--alloc-reps", type=int, default=int(os.environ.get("QM_BENCH_ALLOC_REPS", "3")),
                     help="re-create the timed batch this many times after the timed region and report k_classify's time for each "
                          "(roofline.alloc_spread: the kernel moves by several per cent with where a batch lands in memory); N=1, config 2; 0 disables")
+    ap.add_argument("--detail", default=os.environ.get("QM_BENCH_DETAIL", os.path.join(ROOT, "gpurun_out", "bench_detail.json")),
+                    help="where the full record goes (every side measurement with its notes, nested); the ONE line on stdout is the flat summary of it")
     ap.add_argument("--check-vcfs", type=int, default=2, help="VCFs of this rank's batch checked against the oracle after the timed region (N > 1 and configs 3 / 4)")
     args = ap.parse_args()
     P = dict(PRESETS[args.config])
@@ -259,6 +263,11 @@ def main():
         P["name"], " (custom shape)" if custom else "", n_vcf, P["records"], "mixed SNP + indel records" if alleles else "SNPs",
         P["genome"], t_unique, " x %d truth sets" % len(tids) if len(tids) > 1 else "", args.bins,
         ", records shuffled (radix-sort path)" if args.shuffled else ", position sorted")
+    # the line's own copy stays under the 120 characters the driver's record keeps of a string
+    mb = lambda x: "%g M" % (x / 1e6) if x % 100_000 == 0 else str(x)
+    workload_short = "BASELINE configs[%d]%s%s: %d VCFs x %s %s/GPU, %sb ref, %d truth keys%s, %d-bin ROC, %s" % (
+        args.config, " shard" if args.config != 2 else "", " (custom)" if custom else "", n_vcf, mb(P["records"]), "SNP+indel" if alleles else "SNPs", mb(P["genome"]), t_unique,
+        " x%d" % len(tids) if len(tids) > 1 else "", args.bins, "shuffled" if args.shuffled else "sorted")
     out = {
         "metric": "variant TP/FP classifications/sec across all caller x sample VCFs",
         "value": value,
@@ -272,7 +281,7 @@ def main():
         "vs_baseline": None,
         "dtype": "int32",
         "data": "synthetic (generated on device; VCF seeds %d+v, truth seed%s %s)" % (P["seed"], "s" if len(tseeds) > 1 else "", ",".join(map(str, tseeds))),
-        "config": {"workload": workload, "baseline_config_index": args.config,
+        "config": {"workload": workload_short, "workload_long": workload, "baseline_config_index": args.config,
                    "vcfs_per_gpu": n_vcf, "records_per_vcf": P["records"], "parallelism": "vcf-shard x%d" % world,
                    "collective": ("1 all-reduce of [%d x 3 x %d] int64 per step" % (batch.n_truth, args.bins)
                                   + (" (QM_BENCH_FORCE_PG: a process group of one rank)" if force_pg else "")) if world > 1 or force_pg else "none",
@@ -348,12 +357,92 @@ def main():
         out["shuffled_alleles_variant"] = shuffled_alleles_variant(eng, P, args.bins, min(args.shuffled_alleles_vcfs, n_vcf))
     if side and args.config == 2 and not custom and not args.shuffled and args.shuffled4_vcfs > 0:
         out["shuffled_config4_variant"] = shuffled_config4_variant(eng, args.bins, args.shuffled4_vcfs)
+    if side and args.config == 2 and not custom and not args.shuffled and args.multicontig_vcfs > 0:
+        out["multicontig_variant"] = multicontig_variant(eng, tids[0], P, args.bins, min(args.multicontig_vcfs, n_vcf), tseeds[0], roc, scal)
     if rank == 0:
-        print(json.dumps(out))
+        write_detail(out, args.detail)
+        print(json.dumps(compact_line(out)))
     batch.close()
     eng.close()
     if world > 1 or force_pg:
         dist.destroy_process_group()
+
+
+LINE_LIMIT = 2000   # the driver keeps the last 2 000 characters of the output and only flat scalars of `roofline` / `cpu_baseline` / `config`
+
+
+def _sig(x, n=5):
+    """floats to n significant digits (a line of 60 figures has no room for 17 each)"""
+    if isinstance(x, float) and x == x and x not in (float("inf"), float("-inf")):
+        return float("%.*g" % (n, x))
+    return x
+
+
+def write_detail(out, path):
+    """the full record (nested, with every note) beside the line: profiles/rNN_bench_*.json are copies of this file"""
+    if not path:
+        return
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path + ".tmp", "w") as f:
+            json.dump(out, f)
+        os.replace(path + ".tmp", path)
+    except OSError as e:   # a read-only tree: the line on stdout is what counts
+        print("bench.py: detail file not written: %s" % e, file=sys.stderr)
+
+
+def compact_line(out):
+    """The ONE line rank 0 prints: the contract's keys, and every figure of record as a FLAT scalar of `roofline` or `cpu_baseline`
+    (round 5's line was 9 KB of nested side measurements: the driver's record kept its last 2 000 characters and dropped the nested
+    objects, so the shuffled, all-cores and shell figures never reached it).  At most LINE_LIMIT characters: the keys at the END of
+    the priority lists below are dropped first if a line ever grows beyond that."""
+    g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
+    cfg, rf, cb = out["config"], out["roofline"], out.get("cpu_baseline") or {}
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["value"], line["ms_per_step"] = _sig(out["value"], 7), _sig(out["ms_per_step"], 6)
+    line["config"] = {k: cfg[k] for k in ("workload", "baseline_config_index", "vcfs_per_gpu", "records_per_vcf", "parallelism", "collective",
+                                          "vcfs_checked_against_oracle_per_rank") if k in cfg}
+    # (key in the line, value), in the order they are given up when the line is too long (last first)
+    sh, s3, al, sa, s4, mc = (out.get(k) or {} for k in ("shuffled_variant", "shuffled_config3_variant", "alleles_variant", "shuffled_alleles_variant",
+                                                         "shuffled_config4_variant", "multicontig_variant"))
+    alg_per_rec = rf["algorithmic_bytes_per_launch"] / max(1.0, float(cfg["vcfs_per_gpu"]) * cfg["records_per_vcf"])
+    sfrac = lambda v: None if not v else v * alg_per_rec / 1e9 / HBM_PEAK_GBS     # SURVEY 8d's formula on a side workload's rate (same bytes per record)
+    asp = rf.get("alloc_spread") or {}
+    r = [("bound", rf["bound"]), ("kernel", rf["kernel"]), ("achieved", rf["achieved"]), ("peak", rf["peak"]), ("unit", rf["unit"]), ("frac", rf["frac"]),
+         ("traffic", rf["traffic"]), ("kernel_ms", rf["kernel_ms"]), ("step_frac", rf["step_frac"]), ("algorithmic_bytes_per_launch", rf["algorithmic_bytes_per_launch"]),
+         ("kernels_build", rf["kernels_build"]), ("step_frac_median", rf.get("step_frac_median")), ("step_frac_min", rf.get("step_frac_min")),
+         ("step_frac_max", rf.get("step_frac_max")), ("alloc_step_ms_min", min(asp["step_ms"]) if asp else None), ("alloc_step_ms_max", max(asp["step_ms"]) if asp else None),
+         ("shuffled_value_first_seen", sh.get("value")), ("shuffled_step_frac", sfrac(sh.get("value"))),
+         ("alleles_step_frac", g(al, "step_frac")), ("alleles_classify_frac", g(al, "classify_frac")),
+         ("shuffled3_value_first_seen", s3.get("value")), ("shuffled3_two_level", g(s3, "paths", "bucket_two_level")),
+         ("multicontig_value", mc.get("value")), ("multicontig_path", mc.get("path")),
+         ("shuffled4_value_first_seen", s4.get("value")), ("shuffled_alleles_value_first_seen", sa.get("value")),
+         ("measured_read_GBps", rf.get("measured_read_GBps")), ("measured_copy_GBps", rf.get("measured_copy_GBps")),
+         ("shuffled_value_repeated", sh.get("value_repeated_run")), ("traffic_build", rf.get("traffic_build") if rf.get("traffic_build") != rf["kernels_build"] else None),
+         ("compact_ms", g(out, "kernels_ms", "compact_ms")), ("finalize_ms", g(out, "kernels_ms", "finalize_ms")),
+         ("variants_equal_sorted", None if not (sh or s3 or sa or s4 or mc) else all(v.get("roc_equals_sorted_variant", v.get("equals_sorted_variant")) is True
+                                                                                  for v in (sh, s3, sa, s4, mc) if v))]
+    shell = out.get("cpu_baseline_shell") or {}
+    c = [("value", cb.get("value")), ("unit", cb.get("unit")), ("cores", cb.get("cores")), ("kind", cb.get("kind")), ("sample", cb.get("sample")),
+         ("all_cores_value", g(cb, "all_cores", "value")), ("all_cores_n", g(cb, "all_cores", "cores")),
+         ("shell_value", shell.get("value")), ("shell_all_cores_value", g(shell, "all_cores", "value")), ("shell_all_cores_jobs", g(shell, "all_cores", "jobs")),
+         ("awk", shell.get("awk")), ("cpu_quota", g(shell, "all_cores", "cpu_quota")), ("shell_error", shell.get("error"))]
+    keep_r, keep_c = [kv for kv in r if kv[1] is not None or kv[0] == "traffic"], [kv for kv in c if kv[1] is not None]
+
+    def build():
+        line["roofline"] = {k: _sig(v) for k, v in keep_r}
+        if cb:
+            line["cpu_baseline"] = {k: _sig(v) for k, v in keep_c}
+        if out.get("per_rank"):
+            line["per_rank_ms_min_max"] = [_sig(out["per_rank"]["ms_per_step"]["min"]), _sig(out["per_rank"]["ms_per_step"]["max"])]
+        return json.dumps(line)
+    fixed_r, fixed_c = 11, 5          # the contract's own keys are never dropped
+    while len(build()) > LINE_LIMIT and (len(keep_r) > fixed_r or len(keep_c) > fixed_c):
+        if len(keep_r) - fixed_r >= len(keep_c) - fixed_c:
+            keep_r.pop()
+        else:
+            keep_c.pop()
+    return line
 
 
 def truth_of(P, tseeds, gv):
@@ -462,6 +551,25 @@ def shuffled_variant(eng, tid, P, bins, nv, tseed, sorted_roc):
                     "records), `value_fresh_columns` = the columns written again with other records before every step, no knob; `paths` says where the VCFs went"}
 
 
+def multicontig_variant(eng, tid, P, bins, nv, tseed, sorted_roc, sorted_scal, contigs=24):
+    """The same VCFs sorted PER CONTIG: 24 ascending runs one behind the other, POS restarting with every CHROM (the reference never
+    compares CHROM -- extract_TP_FP_SNPs.py:47 --, so the runs share one position space and a key may repeat across them).  What
+    `vareval` on a multi-contig genome hands over.  The records are the sorted VCF's, so every counter must equal the sorted run's."""
+    import numpy as np
+    b = eng.batch([P["records"]] * nv, [tid] * nv, n_bins=bins)
+    b.synth(P["genome"], P["truth"], tseed, P["seed"], shuffled=contigs)
+    b.run(); b.finish()
+    steps = 3
+    dt, dt0 = _timed_with_and_without_memory(b, steps)
+    ok = bool(np.array_equal(b.roc(), sorted_roc[:nv]) and np.array_equal(b.scalars()[:, :5], sorted_scal[:nv, :5]))
+    paths = b.path_stats()
+    b.close()
+    took = [k for k, v in paths.items() if isinstance(v, int) and v > 0 and k != "finishes"] if isinstance(paths, dict) else []
+    return {"value": nv * float(P["records"]) / dt0, "value_repeated_run": nv * float(P["records"]) / dt, "unit": "classifications/s", "vcfs": nv, "contigs": contigs,
+            "steps": steps, "ms_per_step": dt * 1e3, "ms_per_step_unseen": dt0 * 1e3, "equals_sorted_variant": ok, "paths": paths, "path": ",".join(took)[:40],
+            "note": "every VCF = %d ascending runs (per-contig sorted); `value` = first-seen" % contigs}
+
+
 def shuffled_config3_variant(eng, bins, nv):
     """configs[3]'s VCF shape (10 M records, 50 Mb reference, 10^6 truth keys) with the records permuted: too large for 256
     buckets of 8 192 records, so the VCFs take the two-level bucket path (a first scatter into partitions of 2^27 keys sized
@@ -521,6 +629,7 @@ def alleles_variant(eng, P, bins, nv):
     alg = nv * (17.0 * P["records"] + 12.0 * t_ext)
     return {"value": nv * float(P["records"]) * steps / dt, "unit": "classifications/s", "vcfs": nv, "steps": steps,
             "ms_per_step": dt / steps * 1e3, "classify_ms": tm["classify_ms"], "classify_GBps": alg / tm["classify_ms"] / 1e6,
+            "classify_frac": alg / tm["classify_ms"] / 1e6 / HBM_PEAK_GBS, "step_frac": alg / (dt / steps) / 1e9 / HBM_PEAK_GBS,
             "indel_pct": pct, "equals_oracle_on_vcf0": ok,
             "note": "k_classify<false,true>: allele codes staged in LDS beside the keys, (key, ref, alt) equality"}
 
@@ -689,8 +798,7 @@ def cpu_baseline(batch, P, tseeds, alleles, bins, n_sample):
     assert np.array_equal(batch.cls(0), res[0][0]), "GPU class bits differ from the oracle"
     n = float(sum(len(c[0]) for c in cols))
     out = {"value": n / dt, "unit": "classifications/s", "cores": 1, "kind": "port",
-           "sample": "first %d VCFs of the batch (%d records), oracle/qm_oracle.c classify_columns, 1 thread, %.1f s"
-                     % (n_sample, int(n), dt),
+           "sample": "first %d VCFs (%.3g records), oracle/qm_oracle.c, 1 thread, %.1f s" % (n_sample, n, dt),
            "checked": {"roc_rows": len(res), "class_bits_vcfs": 1}}
     # the same sample with one oracle call in flight per host core (ctypes drops the GIL during the call)
     from concurrent.futures import ThreadPoolExecutor

@@ -166,7 +166,8 @@ typedef struct qm_synth_cfg {
   uint64_t truth_seed;  /* must equal the seed passed to qm_truth_synth, or QM_SYNTH_TRUTH_PER_VCF: every VCF is
                            generated against the synthetic truth set it was assigned at qm_batch_create */
   int64_t truth_n;      /* T of that truth set                                  */
-  int32_t shuffled;     /* 0 = position sorted, 1 = records permuted            */
+  int32_t shuffled;     /* 0 = position sorted, 1 = records permuted, R >= 2 = R ascending runs one behind the other
+                           (a VCF of R contigs: run c holds the generated records c, c + R, c + 2 R, ...; needs R <= records) */
   int32_t indel_pct;    /* 0 = single-base records only (configs 3/4); > 0: that share of the
                            generated records / truth entries carries longer alleles (config 5;
                            allele-extended batches only; must equal qm_truth_synth_ext's) */

@@ -118,7 +118,16 @@ def synth_vcf_columns(L, N, T, tseed, seed, indel_pct=0, shuffled=False, vcf_siz
         qi = (hash3(seed, i, u(13)) & u(255)).astype(np.int64)
         qual = qi.astype(np.float32)
         flags = (2 | (qi >= 20)).astype(np.uint8)
-    if shuffled:
+    if shuffled is True or shuffled == 1:
         p = synth_perm(N, vcf_sizes)
         pos, ref, alt, qual, flags = pos[p], ref[p], alt[p], qual[p], flags[p]
+    elif shuffled:
+        p = synth_runs_perm(N, int(shuffled))
+        pos, ref, alt, qual, flags = pos[p], ref[p], alt[p], qual[p], flags[p]
     return pos, ref, alt, qual, flags
+
+
+def synth_runs_perm(n, runs):
+    """qm_batch_synth with shuffled = R >= 2 (a VCF of R contigs): R ascending runs one behind the other, run c = the generated
+    records c, c + R, c + 2 R, ...; returns the generated record every slot holds"""
+    return np.concatenate([np.arange(c, n, runs, dtype=np.int64) for c in range(runs)])

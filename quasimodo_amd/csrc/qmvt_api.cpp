@@ -744,6 +744,9 @@ extern "C" int qm_batch_synth(qm_batch* b, const qm_synth_cfg* cfg) {
     S.per_vcf_truth = 1;
   }
   S.shuffled = cfg->shuffled;
+  if (cfg->shuffled < 0) return fail(QM_E_INVAL, "qm_batch_synth: shuffled must be 0, 1 or a number of runs");
+  if (cfg->shuffled > 1)
+    for (const VcfDesc& d : L.vcfs) if (d.n > 0 && d.n < cfg->shuffled) return fail(QM_E_INVAL, "qm_batch_synth: %d runs need at least as many records per VCF", cfg->shuffled);
   S.indel_pct = cfg->indel_pct;
   if (cfg->indel_pct < 0 || cfg->indel_pct > 100) return fail(QM_E_INVAL, "qm_batch_synth: indel_pct must be 0..100");
   if (cfg->indel_pct > 0 && !b->ext) return fail(QM_E_INVAL, "qm_batch_synth: indel_pct > 0 needs an allele-extended batch");

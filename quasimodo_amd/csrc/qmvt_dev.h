@@ -44,16 +44,13 @@ __host__ __device__ inline bool allele_valid(int32_t c) {
   const uint32_t u = (uint32_t)c;
   return u < 4u || (u - ALLELE_EXT_MIN) < (0x80000000u - ALLELE_EXT_MIN);
 }
-// low nibble of the 32-bit key: exact for single-base pairs, a hash for the others
+// low nibble of the 32-bit key: exact for single-base pairs (ref << 2 | alt: the XOR of two disjoint bit pairs, nothing above
+// them), a fold of both codes for the others -- ONE branch-free expression (round 6: the rotate-and-fold of rounds 2-5 behind a
+// select was 13 vector instructions and an exec-mask branch per record of an allele-extended batch, which is bound by exactly
+// those: profiles/r06_pmc_per_launch_alleles.json).  Bits 2..7 of either code take part: the bases behind an indel's anchor.
 __host__ __device__ inline uint32_t allele_nib(int32_t r, int32_t a) {
-  if ((uint32_t)(r | a) < 4u) return ((uint32_t)r << 2) | (uint32_t)a;
-  // a 4-bit fold of the two codes: shifts and XORs only (32-bit multiplies run at a quarter of the VALU rate, and every
-  // record of an allele-extended batch pays for this line)
-  uint32_t h = (uint32_t)r ^ (((uint32_t)a << 13) | ((uint32_t)a >> 19));
-  h ^= h >> 16;
-  h ^= h >> 8;
-  h ^= h >> 4;
-  return h & 15u;
+  const uint32_t ur = (uint32_t)r, ua = (uint32_t)a;
+  return ((ur << 2) ^ ua ^ ((ur ^ ua) >> 4)) & 15u;
 }
 
 struct TruthDev {

@@ -159,19 +159,16 @@ __device__ __forceinline__ void pack_record_fast(int p, int r, int a, float q, u
 }
 
 // The allele-extended counterpart (any valid allele code takes part, include/qmvt.h): the same key and info as
-// pack_record<true> for a record whose position is in range.  A code is valid iff it is < 4 or in [0x08000000, 0x80000000),
-// i.e. iff ((c >> 27) - 1) < 15 for the latter; the nibble of a pair that is not two single bases is allele_nib's fold.
+// pack_record<true> for a record whose position is in range.  A code is valid iff it is < 4 or in [2^27, 2^31): by its number
+// of leading zeros -- 30 and more, or 1..4 -- which one shift of a constant turns into a bit (c | 1 has c's count for c >= 2 and
+// stands for 0 and 1 alike); the nibble is allele_nib's branch-free fold.
 __device__ __forceinline__ void pack_record_fast_ext(int p, int r, int a, float q, uint32_t f4x4, float nbm1f, const uint32_t* flut,
                                                      uint32_t& key, uint32_t& inf) {
   const uint32_t ur = (uint32_t)r, ua = (uint32_t)a;
-  const bool single = (ur | ua) < 4u;
-  const bool longs = ((ur < 4u) | (((ur >> 27) - 1u) < 15u)) & ((ua < 4u) | (((ua >> 27) - 1u) < 15u));
-  const bool live = (((uint32_t)p >> 28) == 0u) & (single | longs);
-  uint32_t h = ur ^ __builtin_amdgcn_alignbit(ua, ua, 19);   // rotl(a, 13)
-  h ^= h >> 16;
-  h ^= h >> 8;
-  h ^= h >> 4;
-  const uint32_t nib = single ? ((ur << 2) | ua) : (h & 15u);
+  constexpr uint32_t VALID_BY_CLZ = 0xC000001Eu;            // bit z: a code with z leading zeros is an allele code
+  const uint32_t ok = (VALID_BY_CLZ >> __builtin_clz(ur | 1u)) & (VALID_BY_CLZ >> __builtin_clz(ua | 1u)) & 1u;
+  const bool live = ((uint32_t)p >> 28) < ok;              // 0 <= p < 2^28 and both codes valid
+  const uint32_t nib = ((ur << 2) ^ ua ^ ((ur ^ ua) >> 4)) & 15u;
   key = ((uint32_t)p << 4) | (live ? nib : 0u);
   const float c = fminf(fmaxf(q, -1.0f), nbm1f);            // NaN -> -1
   const uint32_t b1 = (uint32_t)((int)floorf(c) + 1);
@@ -1548,7 +1545,16 @@ __global__ void k_synth(SynthParams S) {
   if (i >= vd.n) return;
   const uint64_t seed = S.seed + (uint64_t)v;
   int64_t src = i;
-  if (S.shuffled) src = (int64_t)(((unsigned __int128)(uint64_t)i * S.perm_a + S.perm_b) % (uint64_t)vd.n);
+  if (S.shuffled == 1) src = (int64_t)(((unsigned __int128)(uint64_t)i * S.perm_a + S.perm_b) % (uint64_t)vd.n);
+  else if (S.shuffled > 1) {
+    // a VCF of R contigs (CHROM is never compared: SURVEY Q1): R ascending runs one behind the other, run c = the generated
+    // records c, c + R, c + 2 R, ... -- every run spans the whole position range, the multiset of records is the sorted VCF's
+    const int64_t R = S.shuffled, q = vd.n / R, rem = vd.n % R;
+    int64_t c, t;
+    if (i < rem * (q + 1)) { c = i / (q + 1); t = i % (q + 1); }
+    else { const int64_t i2 = i - rem * (q + 1); c = rem + i2 / q; t = i2 % q; }
+    src = t * R + c;
+  }
   int32_t p, r, a;
   float q;
   uint8_t f;

@@ -237,7 +237,7 @@ class Batch:
     def synth(self, genome_len, truth_n, truth_seed, seed, shuffled=False, indel_pct=0):
         """truth_seed=None: every VCF is generated against the synthetic truth set it was assigned (per-VCF truth sets)"""
         ts = 0xffffffffffffffff if truth_seed is None else int(truth_seed)
-        cfg = SynthCfg(int(genome_len), int(seed), ts, int(truth_n), int(bool(shuffled)), int(indel_pct))
+        cfg = SynthCfg(int(genome_len), int(seed), ts, int(truth_n), int(shuffled), int(indel_pct))   # True = 1: permuted; R >= 2: R ascending runs
         self._ck(self._L.qm_batch_synth(self._h, C.byref(cfg)))
 
     def set_timing(self, on=True):
