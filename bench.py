@@ -413,15 +413,15 @@ def compact_line(out):
          ("kernels_build", rf["kernels_build"]), ("step_frac_median", rf.get("step_frac_median")), ("step_frac_min", rf.get("step_frac_min")),
          ("step_frac_max", rf.get("step_frac_max")), ("alloc_step_ms_min", min(asp["step_ms"]) if asp else None), ("alloc_step_ms_max", max(asp["step_ms"]) if asp else None),
          ("shuffled_value_first_seen", sh.get("value")), ("shuffled_step_frac", sfrac(sh.get("value"))),
+         ("variants_equal_sorted", None if not (sh or s3 or sa or s4 or mc) else all(v.get("roc_equals_sorted_variant", v.get("equals_sorted_variant")) is True
+                                                                                  for v in (sh, s3, sa, s4, mc) if v)),
          ("alleles_step_frac", g(al, "step_frac")), ("alleles_classify_frac", g(al, "classify_frac")),
          ("shuffled3_value_first_seen", s3.get("value")), ("shuffled3_two_level", g(s3, "paths", "bucket_two_level")),
          ("multicontig_value", mc.get("value")), ("multicontig_path", mc.get("path")),
          ("shuffled4_value_first_seen", s4.get("value")), ("shuffled_alleles_value_first_seen", sa.get("value")),
          ("measured_read_GBps", rf.get("measured_read_GBps")), ("measured_copy_GBps", rf.get("measured_copy_GBps")),
          ("shuffled_value_repeated", sh.get("value_repeated_run")), ("traffic_build", rf.get("traffic_build") if rf.get("traffic_build") != rf["kernels_build"] else None),
-         ("compact_ms", g(out, "kernels_ms", "compact_ms")), ("finalize_ms", g(out, "kernels_ms", "finalize_ms")),
-         ("variants_equal_sorted", None if not (sh or s3 or sa or s4 or mc) else all(v.get("roc_equals_sorted_variant", v.get("equals_sorted_variant")) is True
-                                                                                  for v in (sh, s3, sa, s4, mc) if v))]
+         ("compact_ms", g(out, "kernels_ms", "compact_ms")), ("finalize_ms", g(out, "kernels_ms", "finalize_ms"))]
     shell = out.get("cpu_baseline_shell") or {}
     c = [("value", cb.get("value")), ("unit", cb.get("unit")), ("cores", cb.get("cores")), ("kind", cb.get("kind")), ("sample", cb.get("sample")),
          ("all_cores_value", g(cb, "all_cores", "value")), ("all_cores_n", g(cb, "all_cores", "cores")),

@@ -1,14 +1,16 @@
-# eval_variant_custom.smk -- the vareval workflow (run_benchmark.py vareval) with the path's two rules re-authored.
+# eval_variant_custom.smk -- the two rules of the vareval workflow (run_benchmark.py vareval) that lie on the path, re-authored.
 #
-# The reference's workflow of the same name: load_config_custom.smk (config/customize_data.yaml: refs, outpath, threads),
-# vcfs / labels / novenn from the config, `rule gdiff` (nucmer + show-snps -> <g1>_<g2>.maskrepeat.snps), `rule extract_TP` (one
-# worker process per caller VCF, :58-74) and `rule snp_benchmark` (scripts/custom_snp_benchmark.R, :76-92).  Here:
-#   * the settings come through quasimodo_amd.workflow.vareval_settings (the same precedence, restated from
-#     rules/load_config_custom.smk:1-19 and :3-34 of the reference's workflow; same two error messages);
-#   * `rule gdiff` is the reference's tool invocation (nucmer / delta-filter / show-snps are upstream of the path: not rebuilt);
-#   * `rule extract_TP` declares the reference's outputs (:63-64) for EVERY caller at once and hands them to one engine batch;
-#   * `rule snp_benchmark` declares the reference's outputs (:82-83): the table from the engine's counts over the filtered VCFs
-#     (as R reads them), the figure as a text page of the same table (drawing is R's, out of scope).
+# This file holds ONLY `rule extract_TP` and `rule snp_benchmark` and the names they need.  The reference's workflow of the same
+# name also carries the target rule and the genome-difference rule (nucmer + show-snps, upstream of the path: not rebuilt); a
+# maintainer keeps those two in their own file and replaces its two path rules with
+#     include: "<this file>"
+# behind them (INTEGRATION.md, level 2).  The table the genome-difference rule writes enters here as a PATH --
+# `genome_diff_snps`, the name below is where the reference's rule puts it -- not as a reference to another rule's output.
+#   * the settings come through quasimodo_amd.workflow.vareval_settings (the precedence of rules/load_config_custom.smk and of
+#     the reference workflow's first lines, restated; same two error messages);
+#   * `rule extract_TP` declares the reference's outputs (its :63-64) for EVERY caller at once and hands them to one engine batch;
+#   * `rule snp_benchmark` declares the reference's outputs (its :82-83): the table from the engine's counts over the filtered
+#     VCFs (as R reads them), the figure as a text page of the same table (drawing is R's, out of scope).
 import os
 from quasimodo_amd.workflow import vareval_settings
 
@@ -30,31 +32,13 @@ novenn = config.get("novenn")
 callers = _cfg["labels"] if _cfg["labels"] else [os.path.splitext(os.path.basename(vcf))[0] for vcf in vcfs]
 caller_vcf_dict = dict(zip(callers, vcfs))
 
+genome_diff_snps = snp_dir + "/nucmer/" + gdiff_name + ".maskrepeat.snps"    # show-snps -CTHIlr of the two references: 12 tab-separated columns
 
-rule all:
-    input:
-        snp_benchmark_figure = results_dir + "/final_figures/snpcall_benchmark.pdf",
-        snp_benchmark_table = results_dir + "/final_tables/snpcall_benchmark.txt"
-
-# The first given ref should be the ref used to generate the VCFs
-rule gdiff:
-    input:
-        refs
-    output:
-        delta = snp_dir + "/nucmer/" + gdiff_name + ".delta",
-        snps = snp_dir + "/nucmer/" + gdiff_name + ".maskrepeat.snps"
-    params:
-        genome_diff_prefix = snp_dir + "/nucmer/" + gdiff_name
-    shell:
-        """
-        nucmer --prefix={params.genome_diff_prefix} {input}
-        show-snps -CTHIlr <(delta-filter -r -q {output.delta}) > {output.snps}
-        """
 
 rule extract_TP:
     input:
         vcf = [caller_vcf_dict[c] for c in callers],
-        genome_diff = rules.gdiff.output.snps
+        genome_diff = genome_diff_snps
     output:
         filtered = expand(snpcall_dir + "/{snpcaller}.filtered.vcf", snpcaller=callers),
         fp = expand(snpcall_dir + "/fp/{snpcaller}.fp.vcf", snpcaller=callers)
@@ -70,7 +54,7 @@ rule snp_benchmark:
     input:
         vcfs = expand(snpcall_dir + "/{snpcaller}.filtered.vcf",
                       snpcaller=callers),
-        genome_diff = rules.gdiff.output.snps
+        genome_diff = genome_diff_snps
     output:
         snp_benchmark_table = results_dir + "/final_tables/snpcall_benchmark.txt",
         snp_benchmark_figure = results_dir + "/final_figures/snpcall_benchmark.pdf"

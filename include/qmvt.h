@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define QM_ABI_VERSION 5
+#define QM_ABI_VERSION 6
 
 #define QM_OK 0
 #define QM_E_INVAL (-1)     /* bad argument */
@@ -53,6 +53,7 @@ extern "C" {
 #define QM_E_NONCANON (-8)  /* text input the engine refuses to guess about (strict mode) */
 #define QM_E_LIMIT (-9)     /* allele-extended batch: too many records at one position */
 #define QM_E_UNSORTED (-10) /* qm_bgzf_write_tbi: sequences not in blocks or positions stepping backwards (tabix refuses such a VCF too) */
+#define QM_E_COMM (-11)     /* the collective library (RCCL) is missing or one of its calls failed */
 
 /* ---- allele-extended mode (QM_BATCH_ALLELES) ---------------------------------------------
  * BASELINE.json configs[4] (mixed SNP + indel, variable-length alleles).  The reference drops
@@ -240,6 +241,32 @@ int qm_path_stats_total(qm_ctx* ctx, int64_t* out /*[QM_N_PATH_STATS]*/);
  * qm_batch_run was given one): valid until the batch runs again or is destroyed.  For callers that hand the counters to a
  * collective without a trip through the host. */
 int qm_batch_global_device(qm_batch* b, void** dev);
+/* ---- the path's one exchange: the all-reduce of the confusion counters (SURVEY.md 8b's all-reduced `out_global`, 8e) ----
+ * Replaces nothing in the reference (its per-VCF processes never add anything up: R does, from files); it is what makes the
+ * sums of a batch sharded over GPUs one number.  RCCL directly -- ncclCommInitAll / ncclCommInitRank, ONE
+ * ncclAllReduce(ncclUint64, ncclSum) in place on the batch's per-truth sums ([qm_batch_n_truth][3][n_bins] uint64: the buffer
+ * qm_batch_global_device names) -- so that a host that is not Python has the collective too (the Python host may keep
+ * torch.distributed on the same buffer).  librccl is opened when a communicator is first asked for (QM_RCCL_LIB names another
+ * file); a build or a box without it fails there with QM_E_COMM and nowhere else.  Unmeasured beyond one device (no multi-GPU
+ * box was available to any round; two ranks on one card are refused by RCCL).
+ *
+ * qm_comm_create: one process, n contexts on n DISTINCT devices (one host thread per context: examples/qm_multi.c).
+ * qm_comm_create_rank: one process per GPU; rank 0 makes the id with qm_comm_make_id and hands its 128 bytes to the others
+ *   (a file, the environment, MPI: the caller's).
+ * qm_allreduce_counters: every member calls it once per step, behind qm_batch_finish; the all-reduce is enqueued on `stream`
+ *   (NULL = the context's own) behind the batch's run, and the call returns when THIS member's copy of the sums is complete
+ *   (qm_batch_get_global / qm_batch_global_device then hold the sums over all members).  Batches of all members must have the same
+ *   n_truth and n_bins.  From one process, call it from one thread per member (a member blocks until all have arrived).
+ * qm_comm_collectives: collectives this communicator has issued for `ctx`'s member (tests: exactly one per step). */
+typedef struct qm_comm qm_comm;
+typedef struct qm_comm_id { char bytes[128]; } qm_comm_id;
+int qm_comm_create(qm_ctx* const* ctxs, int n, qm_comm** out);
+int qm_comm_make_id(qm_comm_id* out);
+int qm_comm_create_rank(qm_ctx* ctx, int rank, int n_ranks, const qm_comm_id* id, qm_comm** out);
+int qm_allreduce_counters(qm_batch* b, qm_comm* comm, void* stream);
+int64_t qm_comm_collectives(const qm_comm* comm, const qm_ctx* ctx);
+void qm_comm_destroy(qm_comm* comm);
+
 /* Bytes the engine holds in HBM for this batch. */
 int64_t qm_batch_device_bytes(qm_batch* b);
 /* Rows of the per-truth sums ([n][3][n_bins]; qm_batch_get_global, qm_batch_run's global_dev): the number of

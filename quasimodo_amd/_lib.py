@@ -10,10 +10,10 @@ _SO = os.environ.get("QM_LIBQMVT") or os.path.join(_CSRC, "libqmvt.so")   # over
 QM_N_SCALARS = 8
 SCALAR_NAMES = ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R", "sorted", "n_records", "truth_unique")
 ERRORS = {-1: "QM_E_INVAL", -2: "QM_E_NODEVICE", -3: "QM_E_HIP", -4: "QM_E_NOMEM", -5: "QM_E_RANGE",
-          -6: "QM_E_STATE", -7: "QM_E_IO", -8: "QM_E_NONCANON", -9: "QM_E_LIMIT", -10: "QM_E_UNSORTED"}
+          -6: "QM_E_STATE", -7: "QM_E_IO", -8: "QM_E_NONCANON", -9: "QM_E_LIMIT", -10: "QM_E_UNSORTED", -11: "QM_E_COMM"}
 QM_E_UNSORTED = -10
 QM_BATCH_ALLELES = 1
-QM_ABI_VERSION = 5
+QM_ABI_VERSION = 6
 
 # every symbol include/qmvt.h declares
 EXPORTS = (
@@ -27,6 +27,7 @@ EXPORTS = (
     "qm_bench_synth", "qm_truth_release", "qm_batch_n_truth",
     "qm_bw_probe", "qm_bgzf_write", "qm_bgzf_write_tbi", "qm_extract_files", "qm_extract_files_ex", "qm_batch_global_device", "qm_batch_path_stats", "qm_path_stats_total", "qm_batch_upload_async", "qm_batch_get_masks", "qm_patterns_create", "qm_patterns_destroy", "qm_patterns_info", "qm_vcf_hostpath",
     "qm_mummer2vcf", "qm_free",
+    "qm_comm_create", "qm_comm_make_id", "qm_comm_create_rank", "qm_allreduce_counters", "qm_comm_collectives", "qm_comm_destroy",
 )
 
 

@@ -13,8 +13,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
+
+#include <dlfcn.h>
 
 #include "../../include/qmvt.h"
 #include "qmvt_dev.h"
@@ -2283,4 +2287,144 @@ extern "C" int qm_fp_overlap(qm_ctx* c, int n_sets, const int64_t* set_offsets, 
   if (hbad) return fail(QM_E_INVAL, "qm_fp_overlap: a key is not a single-base variant with 0 <= pos < 2^28");
   for (int i = 0; i < nreg; ++i) regions[i] = (int64_t)hreg[(size_t)i];
   return QM_OK;
+}
+
+// ---------------------------------------------------------------------------
+// The path's one exchange behind the C ABI (round 6; include/qmvt.h "the path's one exchange"): RCCL itself, opened at run
+// time -- the library links without it, and a process that never asks for a communicator never loads it.  Only the six entry
+// points below are used; their prototypes are RCCL's (rccl.h), restated here so that the build needs no RCCL header either.
+// ---------------------------------------------------------------------------
+namespace {
+typedef struct ncclComm* rcclComm_t;
+struct RcclId { char internal[128]; };
+enum { RCCL_UINT64 = 5, RCCL_SUM = 0 };   // ncclUint64, ncclSum
+struct Rccl {
+  void* h = nullptr;
+  int (*CommInitAll)(rcclComm_t*, int, const int*) = nullptr;
+  int (*GetUniqueId)(RcclId*) = nullptr;
+  int (*CommInitRank)(rcclComm_t*, int, RcclId, int) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
+  int (*CommDestroy)(rcclComm_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string err;
+};
+Rccl* rccl() {
+  static Rccl R;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (R.h) return &R;
+  const char* names[] = {getenv("QM_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) {
+    if (!n || !*n) continue;
+    R.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (R.h) break;
+    R.err = dlerror();
+  }
+  if (!R.h) return &R;
+  bool ok = true;
+  auto sym = [&](const char* n) { void* p = dlsym(R.h, n); if (!p) { ok = false; R.err = std::string("librccl lacks ") + n; } return p; };
+  R.CommInitAll = (decltype(R.CommInitAll))sym("ncclCommInitAll");
+  R.GetUniqueId = (decltype(R.GetUniqueId))sym("ncclGetUniqueId");
+  R.CommInitRank = (decltype(R.CommInitRank))sym("ncclCommInitRank");
+  R.AllReduce = (decltype(R.AllReduce))sym("ncclAllReduce");
+  R.CommDestroy = (decltype(R.CommDestroy))sym("ncclCommDestroy");
+  R.GetErrorString = (decltype(R.GetErrorString))sym("ncclGetErrorString");
+  if (!ok) { dlclose(R.h); R.h = nullptr; }
+  return &R;
+}
+}  // namespace
+
+struct qm_comm {
+  std::vector<qm_ctx*> ctxs;          // members this process holds (one for qm_comm_create_rank)
+  std::vector<rcclComm_t> comms;      // theirs, in the same order
+  std::vector<int64_t> issued;        // collectives per member
+  int n_ranks = 0;
+};
+static_assert(sizeof(qm_comm_id) == sizeof(RcclId), "qm_comm_id carries an ncclUniqueId");
+
+#define RCCLCHK(R, expr)                                                                                        \
+  do {                                                                                                          \
+    const int e_ = (expr);                                                                                      \
+    if (e_ != 0) return fail(QM_E_COMM, "%s failed: %s", #expr, (R)->GetErrorString ? (R)->GetErrorString(e_) : "?"); \
+  } while (0)
+
+extern "C" int qm_comm_create(qm_ctx* const* ctxs, int n, qm_comm** out) {
+  if (!ctxs || n < 1 || !out) return fail(QM_E_INVAL, "qm_comm_create: bad arguments");
+  *out = nullptr;
+  std::vector<int> devs;
+  for (int i = 0; i < n; ++i) {
+    if (!ctxs[i]) return fail(QM_E_INVAL, "qm_comm_create: context %d is NULL", i);
+    for (int d : devs) if (d == ctxs[i]->dev) return fail(QM_E_INVAL, "qm_comm_create: two contexts on device %d (RCCL refuses two ranks on one card)", d);
+    devs.push_back(ctxs[i]->dev);
+  }
+  Rccl* R = rccl();
+  if (!R->h) return fail(QM_E_COMM, "qm_comm_create: RCCL could not be opened: %s", R->err.c_str());
+  std::unique_ptr<qm_comm> c(new qm_comm);
+  c->ctxs.assign(ctxs, ctxs + n);
+  c->comms.assign((size_t)n, nullptr);
+  c->issued.assign((size_t)n, 0);
+  c->n_ranks = n;
+  RCCLCHK(R, R->CommInitAll(c->comms.data(), n, devs.data()));
+  *out = c.release();
+  return QM_OK;
+}
+
+extern "C" int qm_comm_make_id(qm_comm_id* out) {
+  if (!out) return fail(QM_E_INVAL, "qm_comm_make_id: NULL");
+  Rccl* R = rccl();
+  if (!R->h) return fail(QM_E_COMM, "qm_comm_make_id: RCCL could not be opened: %s", R->err.c_str());
+  RcclId id;
+  RCCLCHK(R, R->GetUniqueId(&id));
+  memcpy(out->bytes, id.internal, sizeof id.internal);
+  return QM_OK;
+}
+
+extern "C" int qm_comm_create_rank(qm_ctx* ctx, int rank, int n_ranks, const qm_comm_id* id, qm_comm** out) {
+  if (!ctx || !id || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(QM_E_INVAL, "qm_comm_create_rank: bad arguments");
+  *out = nullptr;
+  Rccl* R = rccl();
+  if (!R->h) return fail(QM_E_COMM, "qm_comm_create_rank: RCCL could not be opened: %s", R->err.c_str());
+  HIPCHK(hipSetDevice(ctx->dev));
+  std::unique_ptr<qm_comm> c(new qm_comm);
+  c->ctxs.assign(1, ctx);
+  c->comms.assign(1, nullptr);
+  c->issued.assign(1, 0);
+  c->n_ranks = n_ranks;
+  RcclId rid;
+  memcpy(rid.internal, id->bytes, sizeof rid.internal);
+  RCCLCHK(R, R->CommInitRank(&c->comms[0], n_ranks, rid, rank));
+  *out = c.release();
+  return QM_OK;
+}
+
+extern "C" int qm_allreduce_counters(qm_batch* b, qm_comm* comm, void* stream) {
+  NEED_FINISHED(b, "qm_allreduce_counters");
+  if (!comm) return fail(QM_E_INVAL, "qm_allreduce_counters: no communicator");
+  size_t m = 0;
+  while (m < comm->ctxs.size() && comm->ctxs[m] != b->ctx) ++m;
+  if (m == comm->ctxs.size()) return fail(QM_E_INVAL, "qm_allreduce_counters: the batch's context is not a member of this communicator");
+  Rccl* R = rccl();
+  if (!R->h) return fail(QM_E_COMM, "qm_allreduce_counters: RCCL is gone");
+  HIPCHK(hipSetDevice(b->ctx->dev));
+  hipStream_t st = stream ? (hipStream_t)stream : b->ctx->stream;
+  const size_t count = (size_t)b->n_truth * 3 * (size_t)b->n_bins;
+  // in place on the per-truth sums of the last run (the caller's global_dev when the run was given one); the one collective of a step
+  RCCLCHK(R, R->AllReduce(b->last_global, b->last_global, count, RCCL_UINT64, RCCL_SUM, comm->comms[m], st));
+  comm->issued[m] += 1;
+  HIPCHK(hipStreamSynchronize(st));
+  return QM_OK;
+}
+
+extern "C" int64_t qm_comm_collectives(const qm_comm* comm, const qm_ctx* ctx) {
+  if (!comm) return -1;
+  for (size_t m = 0; m < comm->ctxs.size(); ++m) if (comm->ctxs[m] == ctx) return comm->issued[m];
+  return -1;
+}
+
+extern "C" void qm_comm_destroy(qm_comm* comm) {
+  if (!comm) return;
+  Rccl* R = rccl();
+  for (size_t m = 0; m < comm->comms.size(); ++m)
+    if (comm->comms[m] && R->h) { (void)hipSetDevice(comm->ctxs[m]->dev); (void)R->CommDestroy(comm->comms[m]); }
+  delete comm;
 }
