@@ -5,9 +5,12 @@
  *
  * The path shards by VCF with no exchange between the shards: one host thread and one qm_ctx per device, each
  * with the truth set and a contiguous range of the synthetic VCFs (BASELINE config 3 shape; VCF v has seed 3000 + v wherever
- * it lands).  The only thing that crosses devices is the sum of the [n_truth][3][n_bins] confusion counters; a Python host
- * does it with ONE RCCL all-reduce (quasimodo_amd/multigpu.py, bench.py), a single C process simply adds the vectors up.
- * A device may be named more than once ("0,0": two contexts on one card) to rehearse the threading without a second GPU.
+ * it lands).  The only thing that crosses devices is the sum of the [n_truth][3][n_bins] confusion counters: ONE RCCL
+ * all-reduce per step through the library's own collective (qm_comm_create over the contexts, qm_allreduce_counters from
+ * every shard's thread, in place on the batch's device buffer) -- what a Python host does with torch.distributed
+ * (quasimodo_amd/multigpu.py, bench.py).  A device may be named more than once ("0,0": two contexts on one card) to rehearse
+ * the threading without a second GPU; RCCL refuses two ranks on one card, so such a run adds the vectors up on the host
+ * and says so ("exchange": "host-sum").
  * check = 1: the same VCFs once more in one batch on the first device; the summed counters must be identical.
  * Exit status 2 without a usable HIP device: there is no CPU path. */
 #include <pthread.h>
@@ -23,6 +26,9 @@ enum { N_BINS = 256, MAX_DEV = 16 };
 
 typedef struct shard {
   int device, v0, n_vcf, steps;
+  qm_ctx* ctx;                    /* made by main: the communicator wants all of them */
+  qm_comm* comm;                  /* NULL: host sum */
+  long long collectives;
   long long records;
   int rc;
   char err[256];
@@ -41,14 +47,12 @@ static pthread_barrier_t g_start, g_stop;
 
 static void* run_shard(void* arg) {
   shard* s = (shard*)arg;
-  qm_ctx* ctx = NULL;
+  qm_ctx* ctx = s->ctx;
   qm_batch* b = NULL;
   int64_t* nrec = NULL;
   int32_t* tids = NULL;
   int64_t* scal = NULL;
   int tid = -1, armed = 0;
-  s->rc = qm_init(s->device, &ctx);
-  if (s->rc != QM_OK) { snprintf(s->err, sizeof s->err, "qm_init(%d): %s", s->device, qm_last_error(NULL)); goto out; }
   s->rc = qm_truth_synth(ctx, 5000000, 100000, 3, &tid);
   if (s->rc != QM_OK) goto fail;
   nrec = (int64_t*)malloc(sizeof(int64_t) * (size_t)s->n_vcf);
@@ -74,12 +78,14 @@ static void* run_shard(void* arg) {
     for (int k = 0; k < s->steps && s->rc == QM_OK; ++k) {
       s->rc = qm_batch_run(b, NULL, NULL);
       if (s->rc == QM_OK) s->rc = qm_batch_finish(b, NULL);
+      if (s->rc == QM_OK && s->comm) s->rc = qm_allreduce_counters(b, s->comm, NULL);   /* the step's one collective */
     }
     s->seconds = now() - t0;
   }
   pthread_barrier_wait(&g_stop);
   if (s->rc != QM_OK) goto fail;
-  s->rc = qm_batch_get_global(b, s->glob);
+  if (s->comm) s->collectives = (long long)qm_comm_collectives(s->comm, ctx);
+  s->rc = qm_batch_get_global(b, s->glob);            /* with a communicator: the sums over ALL shards, on every shard */
   if (s->rc == QM_OK) s->rc = qm_batch_get_scalars(b, scal);
   if (s->rc != QM_OK) goto fail;
   for (int v = 0; v < s->n_vcf; ++v) { s->kept += scal[v * QM_N_SCALARS + QM_S_NPASS]; s->tp += scal[v * QM_N_SCALARS + QM_S_TP_LINES]; s->fp += scal[v * QM_N_SCALARS + QM_S_FP_LINES]; }
@@ -89,7 +95,6 @@ fail:
 out:
   if (!armed) { pthread_barrier_wait(&g_start); pthread_barrier_wait(&g_stop); }   /* nobody waits for a shard that failed early */
   if (b) qm_batch_destroy(b);
-  if (ctx) qm_destroy(ctx);
   free(nrec); free(tids); free(scal);
   return NULL;
 }
@@ -112,8 +117,22 @@ int main(int argc, char** argv) {
   memset(sh, 0, sizeof sh);
   pthread_barrier_init(&g_start, NULL, (unsigned)n_dev);
   pthread_barrier_init(&g_stop, NULL, (unsigned)n_dev);
+  /* one context per device, then the communicator over them (distinct devices only) */
+  qm_ctx* ctxs[MAX_DEV];
+  qm_comm* comm = NULL;
+  int distinct = 1;
+  for (int r = 0; r < n_dev; ++r) for (int q = 0; q < r; ++q) if (dev[q] == dev[r]) distinct = 0;
+  for (int r = 0; r < n_dev; ++r) {
+    const int rc = qm_init(dev[r], &ctxs[r]);
+    if (rc != QM_OK) { fprintf(stderr, "qm_init(%d) failed (%d): %s\n", dev[r], rc, qm_last_error(NULL)); return rc == QM_E_NODEVICE ? 2 : 1; }
+  }
+  if (distinct) {
+    const int rc = qm_comm_create(ctxs, n_dev, &comm);
+    if (rc != QM_OK) { fprintf(stderr, "qm_comm_create failed (%d): %s\n", rc, qm_last_error(NULL)); return 5; }
+  }
   for (int r = 0, v0 = 0; r < n_dev; ++r) {   /* equal VCFs: contiguous, near-equal ranges (unequal ones: longest-processing-time first, as quasimodo_amd/sharding.py) */
     const int n = n_vcf / n_dev + (r < n_vcf % n_dev ? 1 : 0);
+    sh[r].ctx = ctxs[r]; sh[r].comm = comm;
     sh[r].device = dev[r]; sh[r].v0 = v0; sh[r].n_vcf = n; sh[r].records = records; sh[r].steps = steps;
     v0 += n;
     pthread_create(&th[r], NULL, run_shard, &sh[r]);
@@ -125,7 +144,9 @@ int main(int argc, char** argv) {
   for (int r = 0; r < n_dev; ++r) {
     pthread_join(th[r], NULL);
     if (sh[r].rc != QM_OK) { fprintf(stderr, "shard %d on device %d failed (%d): %s\n", r, sh[r].device, sh[r].rc, sh[r].err); bad = sh[r].rc == QM_E_NODEVICE ? 2 : 1; }
-    for (int i = 0; i < 3 * N_BINS; ++i) glob[i] += sh[r].glob[i];      /* the path's only exchange */
+    if (!comm) for (int i = 0; i < 3 * N_BINS; ++i) glob[i] += sh[r].glob[i];      /* (a device named twice: the exchange on the host) */
+    else if (r == 0) memcpy(glob, sh[0].glob, sizeof glob);                          /* all-reduced on the devices: every shard holds the sums */
+    else if (memcmp(glob, sh[r].glob, sizeof glob) != 0 || sh[r].collectives != steps) { fprintf(stderr, "shard %d disagrees after the all-reduce\n", r); bad = 1; }
     kept += sh[r].kept; tp += sh[r].tp; fp += sh[r].fp;
     if (sh[r].seconds > seconds) seconds = sh[r].seconds;                /* the slowest shard is the job */
   }
@@ -135,14 +156,17 @@ int main(int argc, char** argv) {
     pthread_barrier_destroy(&g_start); pthread_barrier_destroy(&g_stop);
     pthread_barrier_init(&g_start, NULL, 1); pthread_barrier_init(&g_stop, NULL, 1);
     shard* one = &sh[MAX_DEV];
+    one->ctx = ctxs[0]; one->comm = NULL;
     one->device = dev[0]; one->v0 = 0; one->n_vcf = n_vcf; one->records = records; one->steps = 1;
     run_shard(one);
     if (one->rc != QM_OK) { fprintf(stderr, "reference run failed (%d): %s\n", one->rc, one->err); return 1; }
     same = memcmp(one->glob, glob, sizeof glob) == 0 && one->kept == kept && one->tp == tp && one->fp == fp;
   }
-  printf("{\"devices\": %d, \"vcfs\": %d, \"records_per_vcf\": %lld, \"steps\": %d, \"classifications_per_s\": %.6g, \"ms_per_step\": %.4f, "
+  if (comm) qm_comm_destroy(comm);
+  for (int r = 0; r < n_dev; ++r) qm_destroy(ctxs[r]);
+  printf("{\"devices\": %d, \"exchange\": \"%s\", \"vcfs\": %d, \"records_per_vcf\": %lld, \"steps\": %d, \"classifications_per_s\": %.6g, \"ms_per_step\": %.4f, "
          "\"kept\": %lld, \"tp_lines\": %lld, \"fp_lines\": %lld, \"roc_tp_at_20\": %llu, \"equals_one_batch\": %s}\n",
-         n_dev, n_vcf, records, steps, (double)n_vcf * (double)records * steps / seconds, seconds / steps * 1e3, kept, tp, fp,
+         n_dev, distinct ? "rccl all-reduce (qm_allreduce_counters), one per step" : "host-sum", n_vcf, records, steps, (double)n_vcf * (double)records * steps / seconds, seconds / steps * 1e3, kept, tp, fp,
          (unsigned long long)glob[20], same < 0 ? "null" : same ? "true" : "false");
   return same == 0 ? 4 : 0;
 }

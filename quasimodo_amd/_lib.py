@@ -202,6 +202,14 @@ def lib():
     L.qm_mummer2vcf.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_uint, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.qm_free.argtypes = [vp]
     L.qm_free.restype = None
+    L.qm_comm_create.argtypes = [C.POINTER(vp), i32, C.POINTER(vp)]
+    L.qm_comm_make_id.argtypes = [vp]
+    L.qm_comm_create_rank.argtypes = [vp, i32, i32, vp, C.POINTER(vp)]
+    L.qm_allreduce_counters.argtypes = [vp, vp, vp]
+    L.qm_comm_collectives.argtypes = [vp, vp]
+    L.qm_comm_collectives.restype = i64
+    L.qm_comm_destroy.argtypes = [vp]
+    L.qm_comm_destroy.restype = None
     L.qm_batch_upload_async.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
     L.qm_batch_get_masks.argtypes = [vp, i32, vp, vp]
     L.qm_bgzf_write.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, i32]

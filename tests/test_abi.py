@@ -22,7 +22,7 @@ def test_header_symbols_exported(qmlib):
     for n in names:
         assert hasattr(qmlib, n), "libqmvt.so does not export %s" % n
     assert sorted(_lib.EXPORTS) == names
-    assert qmlib.qm_abi_version() == 5
+    assert qmlib.qm_abi_version() == 6
 
 
 def test_the_library_says_which_sources_it_was_built_from(qmlib, tmp_path):
@@ -164,8 +164,61 @@ def test_multi_device_c_program_shards_sum_to_the_single_batch(qmlib, tmp_path):
     r = subprocess.run([exe, "0,0", "10", "1000000", "2", "1"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     d = json.loads(r.stdout)
-    assert d["devices"] == 2 and d["vcfs"] == 10 and d["equals_one_batch"] is True
+    assert d["devices"] == 2 and d["vcfs"] == 10 and d["equals_one_batch"] is True and d["exchange"] == "host-sum"   # RCCL refuses two ranks on one card
     assert d["kept"] == d["tp_lines"] + d["fp_lines"] and d["roc_tp_at_20"] == d["tp_lines"]
+    # one device: the exchange is the library's own collective over RCCL (a communicator of one member), one per step
+    r = subprocess.run([exe, "0", "6", "1000000", "3", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout)
+    assert d["devices"] == 1 and d["exchange"].startswith("rccl all-reduce") and d["equals_one_batch"] is True and d["roc_tp_at_20"] == d["tp_lines"]
+
+
+def test_the_collective_entry_points_refuse_bad_arguments_without_touching_a_device(qmlib):
+    """qm_comm_* / qm_allreduce_counters (include/qmvt.h: the path's one exchange behind the C ABI): argument checks come first --
+    no RCCL, no GPU is needed to be told so"""
+    import ctypes as C
+    out = C.c_void_p()
+    assert qmlib.qm_comm_create(None, 1, C.byref(out)) == -1 and out.value is None
+    assert qmlib.qm_comm_create_rank(None, 0, 1, None, C.byref(out)) == -1
+    assert qmlib.qm_allreduce_counters(None, None, None) == -6        # QM_E_STATE: nothing was run
+    assert qmlib.qm_comm_collectives(None, None) == -1
+    qmlib.qm_comm_destroy(None)
+
+
+@pytest.mark.gpu
+def test_the_library_collective_over_rccl_with_one_member(qmlib):
+    """qm_comm_create over ONE context (all a one-GPU box allows: RCCL refuses two ranks on a card), a step = run + finish +
+    qm_allreduce_counters: RCCL initialises on this device, exactly one collective per step is issued, and the all-reduced sums of
+    a communicator of one member are the batch's own.  The same through qm_comm_make_id + qm_comm_create_rank (rank 0 of 1: the
+    one-process-per-GPU form)."""
+    import ctypes as C
+    import numpy as np
+    import quasimodo_amd as q
+    with q.Engine(0) as eng:
+        tid = eng.truth_synth(5_000_000, 100_000, 3)
+        b = eng.batch([1_000_000] * 6, [tid] * 6)
+        b.synth(5_000_000, 100_000, 3, 3000)
+        b.run(); b.finish()
+        before = b.global_counts().copy()
+        assert before.sum() > 0
+        for how in ("all", "rank"):
+            comm = C.c_void_p()
+            if how == "all":
+                arr = (C.c_void_p * 1)(eng._h)
+                q._lib.check(qmlib.qm_comm_create(arr, 1, C.byref(comm)), eng._h)
+            else:
+                cid = (C.c_char * 128)()
+                q._lib.check(qmlib.qm_comm_make_id(cid), eng._h)
+                q._lib.check(qmlib.qm_comm_create_rank(eng._h, 0, 1, cid, C.byref(comm)), eng._h)
+            try:
+                for step in range(3):
+                    b.run(); b.finish()
+                    q._lib.check(qmlib.qm_allreduce_counters(b._h, comm, None), eng._h)
+                    assert qmlib.qm_comm_collectives(comm, eng._h) == step + 1
+                    assert np.array_equal(b.global_counts(), before)
+            finally:
+                qmlib.qm_comm_destroy(comm)
+        b.close()
 
 
 
