@@ -53,6 +53,11 @@ static void* run_shard(void* arg) {
   int32_t* tids = NULL;
   int64_t* scal = NULL;
   int tid = -1, armed = 0;
+  const int own_ctx = ctx == NULL;   /* the check run brings none: a fresh context (one truth set, so one row of sums) */
+  if (own_ctx) {
+    s->rc = qm_init(s->device, &ctx);
+    if (s->rc != QM_OK) { snprintf(s->err, sizeof s->err, "qm_init(%d): %s", s->device, qm_last_error(NULL)); goto out; }
+  }
   s->rc = qm_truth_synth(ctx, 5000000, 100000, 3, &tid);
   if (s->rc != QM_OK) goto fail;
   nrec = (int64_t*)malloc(sizeof(int64_t) * (size_t)s->n_vcf);
@@ -95,6 +100,7 @@ fail:
 out:
   if (!armed) { pthread_barrier_wait(&g_start); pthread_barrier_wait(&g_stop); }   /* nobody waits for a shard that failed early */
   if (b) qm_batch_destroy(b);
+  if (own_ctx && ctx) qm_destroy(ctx);
   free(nrec); free(tids); free(scal);
   return NULL;
 }
@@ -156,7 +162,7 @@ int main(int argc, char** argv) {
     pthread_barrier_destroy(&g_start); pthread_barrier_destroy(&g_stop);
     pthread_barrier_init(&g_start, NULL, 1); pthread_barrier_init(&g_stop, NULL, 1);
     shard* one = &sh[MAX_DEV];
-    one->ctx = ctxs[0]; one->comm = NULL;
+    one->ctx = NULL; one->comm = NULL;
     one->device = dev[0]; one->v0 = 0; one->n_vcf = n_vcf; one->records = records; one->steps = 1;
     run_shard(one);
     if (one->rc != QM_OK) { fprintf(stderr, "reference run failed (%d): %s\n", one->rc, one->err); return 1; }
