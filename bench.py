@@ -117,6 +117,12 @@ def main():
             print(json.dumps(out))
         return
 
+    # ONE line on stdout: whatever a library prints there on the way (RCCL's version banner when a communicator is made) goes to
+    # stderr -- file descriptor 1 is pointed at 2 until rank 0 prints its line
+    sys.stdout.flush()
+    fd_out = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -361,7 +367,10 @@ def main():
         out["multicontig_variant"] = multicontig_variant(eng, tids[0], P, args.bins, min(args.multicontig_vcfs, n_vcf), tseeds[0], roc, scal)
     if rank == 0:
         write_detail(out, args.detail)
-        print(json.dumps(compact_line(out)))
+        sys.stdout.flush()
+        os.dup2(fd_out, 1)
+        print(json.dumps(compact_line(out)), flush=True)
+        os.dup2(2, 1)
     batch.close()
     eng.close()
     if world > 1 or force_pg:
