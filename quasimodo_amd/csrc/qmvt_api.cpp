@@ -77,24 +77,11 @@ struct qm_ctx {
   int64_t path_total[QM_N_PATH_STATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // qm_path_stats_total: every finish of every batch of this context
 };
 
-// QM_ALLOC_CONTIG=<MB>: arrays of at least that many MB are asked for as physically contiguous memory (hipDeviceMallocContiguous;
-// plain hipMalloc when the driver cannot give it).  An experiment knob (k_compact's two modes follow WHERE the index
-// lists landed in physical memory); 0 / unset = plain hipMalloc.
-static size_t alloc_contig_bytes() {
-  static const size_t v = [] { const char* e = getenv("QM_ALLOC_CONTIG"); return e && atoll(e) > 0 ? (size_t)atoll(e) << 20 : (size_t)0; }();
-  return v;
-}
 template <typename T>
 static int dalloc(T** p, size_t count) {
   *p = nullptr;
   if (count == 0) count = 1;
   const size_t bytes = count * sizeof(T);
-  if (alloc_contig_bytes() && bytes >= alloc_contig_bytes()) {
-    if (hipExtMallocWithFlags((void**)p, bytes, hipDeviceMallocContiguous) == hipSuccess) return QM_OK;
-    (void)hipGetLastError();
-    *p = nullptr;
-    if (getenv("QM_DEBUG_PTRS")) fprintf(stderr, "qmvt: no contiguous %zu MB, plain hipMalloc\n", bytes >> 20);
-  }
   hipError_t e = hipMalloc((void**)p, bytes);
   if (e != hipSuccess) return fail(QM_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
   return QM_OK;
@@ -390,10 +377,6 @@ struct qm_batch {
   int32_t *pos = nullptr, *ref = nullptr, *alt = nullptr;
   float* qual = nullptr;
   uint8_t* flags = nullptr;
-#ifdef K1_IL_PROBE
-  uint8_t* il = nullptr;      // probe builds: the round-interleaved copy of the columns (QM_IL_PROBE=1; made at the first launch that asks for it)
-#endif
-  char* col_slab = nullptr;   // QM_COL_SLAB (experiment): the five columns in one allocation, column k shifted by k x that many bytes
   // outputs / workspace
   uint64_t *mask_pass = nullptr, *mask_tp = nullptr;
   int32_t* idx = nullptr;
@@ -531,10 +514,6 @@ static void batch_free(qm_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->ctx->dev);
   if (b->sub) { batch_free(b->sub); b->sub = nullptr; }
-#ifdef K1_IL_PROBE
-  (void)hipFree(b->il);
-#endif
-  if (b->col_slab) { (void)hipFree(b->col_slab); b->pos = b->ref = b->alt = nullptr; b->qual = nullptr; b->flags = nullptr; }
   void* ptrs[] = {b->pkey, b->pinf, b->pos, b->ref, b->alt, b->qual, b->flags, b->mask_pass, b->mask_tp, b->idx, b->tile_tp, b->tile_fp,
                   b->tile_tp_off, b->tile_fp_off, b->vcf_tot, b->span_hist, b->span_scal, b->vcf_flags, b->vcf_posor, b->bk_hist, b->bk_scal, b->d_bk_vcfs, b->bk_ent, b->bk_cursor, b->d_bk_tile_seg, b->bk_rows, b->bk_xent, b->bk_xcursor, b->bk_xrows, b->bk_roc, b->bk_rscal, b->bk_vflags, b->p_segs, b->p_tile_seg, b->p_cnt, b->p_off, b->p_half, b->p_cursor, b->p_flags, b->p_ent, b->d_vsegs, b->d_vparts, b->rs_roc, b->rs_scal, b->rs_flags, b->roc, b->global_acc,
                   b->scalars, b->d_vcfs, b->d_spans, b->d_tile_vcf, b->cls_scratch, b->sk[0], b->sk[1], b->sv[0],
@@ -578,18 +557,6 @@ static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int
     A_(b->pkey, np) A_(b->pinf, np)
     if (packed_alleles) { A_(b->ref, np) A_(b->alt, np) }   // sorted copies of the allele codes
   }
-  else if (const char* e = getenv("QM_COL_SLAB")) {
-    const size_t skew = (size_t)atoll(e), pitch = ((np * 4 + (2u << 20) - 1) >> 21 << 21);
-    rc = dalloc(&b->col_slab, 5 * pitch + 5 * skew);
-    if (rc == QM_OK) {
-      b->dev_bytes += (int64_t)(5 * pitch + 5 * skew);
-      b->pos = reinterpret_cast<int32_t*>(b->col_slab);
-      b->ref = reinterpret_cast<int32_t*>(b->col_slab + pitch + skew);
-      b->alt = reinterpret_cast<int32_t*>(b->col_slab + 2 * (pitch + skew));
-      b->qual = reinterpret_cast<float*>(b->col_slab + 3 * (pitch + skew));
-      b->flags = reinterpret_cast<uint8_t*>(b->col_slab + 4 * (pitch + skew));
-    }
-  }
   else { A_(b->pos, np) A_(b->ref, np) A_(b->alt, np) A_(b->qual, np) A_(b->flags, np) }
   A_(b->mask_pass, np / 64 + 64) A_(b->mask_tp, np / 64 + 64) A_(b->idx, np)
   A_(b->tile_tp, b->cap_tiles) A_(b->tile_fp, b->cap_tiles) A_(b->tile_tp_off, b->cap_tiles + SPAN_TILES) A_(b->tile_fp_off, b->cap_tiles + SPAN_TILES) A_(b->vcf_tot, (size_t)n_vcf * 2)
@@ -597,17 +564,14 @@ static int batch_alloc(qm_ctx* c, int n_vcf, const int64_t* n_records, const int
   A_(b->roc, (size_t)n_vcf * 3 * (size_t)n_bins) A_(b->global_acc, nt * 3 * (size_t)n_bins) A_(b->scalars, (size_t)n_vcf * 8)
   A_(b->d_vcfs, (size_t)n_vcf) A_(b->d_spans, b->cap_spans) A_(b->d_tile_vcf, b->cap_tiles) A_(b->cls_scratch, (size_t)L.max_n)
 #undef A_
-  if (rc == QM_OK && getenv("QM_DEBUG_PTRS"))   // where the batch landed (tools/alloc_probe.py: the step varies with it)
-    fprintf(stderr, "qmvt: batch pos %p flags %p mask_pass %p mask_tp %p idx %p\n", (void*)b->pos, (void*)b->flags, (void*)b->mask_pass, (void*)b->mask_tp, (void*)b->idx);
   if (rc == QM_OK) rc = upload_layout(b);
   if (rc == QM_OK) {
     // ranges of whole VCFs with about equal numbers of spans; small batches stay in one piece
     int want = 1;   // measured on MI355X: more than one range is SLOWER (the two kernels slow each other down by more than the overlap gains; profiles/README.md)
-    if (const char* e = getenv("QM_PIPE_CHUNKS")) want = atoi(e);
+    int min_spans = 4096;   // a range should fill the chip (5 120 waves) a few times over
+    if (const char* e = getenv("QM_PIPE_CHUNKS")) { want = atoi(e); min_spans = 1; }   // (tests, tools/gpu_fuzz.py: the ranges asked for, however small the batch)
     want = std::max(1, std::min(want, (int)qm_batch::MAX_CHUNKS));
     const int ns = (int)L.spans.size();
-    int min_spans = 4096;   // a range should fill the chip (5 120 waves) a few times over
-    if (const char* e = getenv("QM_PIPE_MIN_SPANS")) min_spans = std::max(1, atoi(e));
     if (ns < min_spans * want) want = std::max(1, ns / min_spans);
     int v = 0;
     for (int k = 0; k < want && v < n_vcf; ++k) {
@@ -778,19 +742,6 @@ static ClassifyParams classify_params(qm_batch* b) {
   P.spans = b->d_spans; P.vcfs = b->d_vcfs; P.truths = b->ctx->d_truths;
   P.mask_pass = b->mask_pass; P.mask_tp = b->mask_tp; P.tile_tp = b->tile_tp; P.tile_fp = b->tile_fp;
   P.span_hist = b->span_hist; P.span_scal = b->span_scal; P.n_bins = b->n_bins;
-  const char* ab = getenv("QM_ABLATE");
-  P.ablate = ab ? atoi(ab) : 0;
-#ifdef K1_IL_PROBE
-  P.il = nullptr;
-  if (const char* e = getenv("QM_IL_PROBE")) if (atoi(e) && b->pos) {
-    const int64_t n_rounds = b->L.n_pad / 256;   // (n_pad = whole rounds + one tile)
-    if (!b->il) {
-      if (dalloc(&b->il, (size_t)n_rounds * 4352 + 8192) == QM_OK) launch_repack_il(b->pos, b->ref, b->alt, b->qual, b->flags, b->il, n_rounds, b->ctx->stream);
-      (void)hipStreamSynchronize(b->ctx->stream);
-    }
-    P.il = b->il;
-  }
-#endif
   P.ext = b->ext ? 1 : 0;
   P.span_base = 0;
   P.zero_acc = nullptr; P.zero_words = 0;
@@ -803,7 +754,6 @@ static FinalizeParams finalize_params(qm_batch* b, uint64_t* global) {
   F.tile_tp = b->tile_tp; F.tile_fp = b->tile_fp; F.tile_tp_off = b->tile_tp_off; F.tile_fp_off = b->tile_fp_off; F.vcf_tot = b->vcf_tot;
   F.roc = b->roc; F.scalars = b->scalars; F.vcf_flags = b->vcf_flags; F.vcf_posor = b->vcf_posor; F.global_acc = global; F.n_bins = b->n_bins; F.ext = b->ext ? 1 : 0;
   F.vcf_base = 0;
-  F.flag_summary = nullptr;
   F.parts = 3;
   F.known = nullptr;
   F.all_hist = nullptr;
@@ -829,12 +779,6 @@ extern "C" int qm_batch_set_timing(qm_batch* b, int on) {
   return QM_OK;
 }
 
-// QM_FINALIZE_SPLIT=0: k_finalize in one launch in front of the compaction (tools/ab_split.sh)
-static bool finalize_split_on() {
-  static const bool on = !getenv("QM_FINALIZE_SPLIT") || atoi(getenv("QM_FINALIZE_SPLIT")) != 0;
-  return on;
-}
-
 extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
   if (!b) return fail(QM_E_INVAL, "qm_batch_run: NULL batch");
   qm_ctx* c = b->ctx;
@@ -845,7 +789,6 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
     if (tg.first >= (int)c->truths.size() || c->truths[(size_t)tg.first].released || c->truths[(size_t)tg.first].gen != tg.second)
       return fail(QM_E_STATE, "qm_batch_run: truth set %d was released after the batch was created", tg.first);
   const size_t gbytes = (size_t)b->n_truth * 3 * (size_t)b->n_bins * 8;   // as allocated at batch creation
-  if (b->h_summary) *reinterpret_cast<volatile uint32_t*>(b->h_summary) = 0u;
   hipEvent_t* ev = b->ev[b->n_timed % qm_batch::EV_RING];
   const int nch = (int)b->chunks.size();
   const bool T = b->timing;
@@ -892,14 +835,13 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
     F.vcf_base = ck.v0;
     // (no summary word: with the mirrors, qm_batch_finish looks through the VCFs' flag words itself -- and every workgroup of a
     // batch of shuffled VCFs storing to that ONE word of host memory made this kernel 50 us instead of 15: same-address stores
-    // to system memory queue up.  QM_FLAG_SUMMARY=1: as before.)
-    F.flag_summary = getenv("QM_FLAG_SUMMARY") ? b->d_summary : nullptr;
+    // to system memory queue up.)
     if (b->d_summary) { F.host_flags = b->d_summary + 16; F.host_aux = b->d_summary + 16 + b->n_vcf; }
     if (use_known) F.known = b->d_known;
-    F.lazy_unsorted = getenv("QM_NO_LAZY_FINALIZE") ? 0 : 1;
+    F.lazy_unsorted = 1;
     // In one piece (the default), the compaction waits only for what it needs of k_finalize -- per-VCF flags and tile offsets --
     // and the rows (ROC, scalars, per-truth sums: 96 MB of span histograms to sum) go to the second stream beside it.
-    const bool split = finalize_split_on() && nch == 1 && b->ev_sync[0] != nullptr;
+    const bool split = nch == 1 && b->ev_sync[0] != nullptr;
     // (host order: what the compaction -- and a first-seen step's look at the flags -- waits for is queued first, the rows' part
     // behind it; it starts beside the compaction either way)
     if (split) F.parts = 1;
@@ -927,7 +869,7 @@ extern "C" int qm_batch_run(qm_batch* b, void* stream, void* global_dev) {
   } else if (nch > 1) {
     HIPCHK(hipEventRecord(b->ev_sync[qm_batch::MAX_CHUNKS + 1], aux));
     HIPCHK(hipStreamWaitEvent(st, b->ev_sync[qm_batch::MAX_CHUNKS + 1], 0));
-  } else if (b->ev_sync[0] != nullptr && finalize_split_on()) {
+  } else if (b->ev_sync[0] != nullptr) {
     HIPCHK(hipStreamWaitEvent(st, b->ev_sync[1], 0));   // the rows of k_finalize
   }
   if (T) { HIPCHK(hipEventRecord(ev[1], st)); b->n_timed++; }
@@ -1203,7 +1145,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
     S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = nullptr;
     S.xent = xstream ? b->bk_xent : nullptr; S.xcursor = xstream ? b->bk_xcursor : nullptr; S.ext = xstream ? 1 : 0; S.pairs = 0;
-    uint32_t* const seg_hist = direct && join_lean_on() ? b->bk_cursor + nhist0 : nullptr;   // k_join_lean follows: the scatter counts every record by bin
+    uint32_t* const seg_hist = direct ? b->bk_cursor + nhist0 : nullptr;   // k_join_lean follows: the scatter counts every record by bin
     S.seg_hist = seg_hist; S.l1_half = nullptr;
     uint32_t* const seg_maxd = b->bk_cursor + nhist0 + (size_t)nseg * SEG_HIST_WORDS;
     uint32_t* const chunk_bad = seg_maxd + nseg;
@@ -1227,9 +1169,8 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     // against 3.11 - 3.22 in 2 - 8 ranges, same box)
     int nbk_launch = nbk_all;
     int parts = nseg >= 8 && b->ev_sync[0] && !direct ? 4 : 1;
-    if (const char* e = getenv("QM_BUCKET_PARTS")) parts = std::max(1, std::min({atoi(e), nseg, (int)qm_batch::MAX_CHUNKS}));
     if (!b->ev_sync[0]) parts = 1;
-    const bool tight_nbk = direct && join_lean_on() && parts == 1 && !getenv("QM_NO_TIGHT_NBK");
+    const bool tight_nbk = direct && parts == 1;
     if (tight_nbk) H.seg_maxd = seg_maxd;
     hipStream_t aux = parts > 1 ? b->ctx->aux : st;
     int i0 = 0;
@@ -1264,7 +1205,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
         }
         // the join: one bit per key of the bucket in LDS where a bucket's key range allows it (k_join_direct), the hashed
         // tables of k_classify_hash otherwise (QM_JOIN=hash: always)
-        if (direct) launch_join_direct(H, i1 - i0, lb_all, nbk_launch, aux);
+        if (direct) launch_join_lean(H, i1 - i0, lb_all, nbk_launch, aux);
         else launch_classify_hash(H, i1 - i0, aux);
         if (xstream) launch_join_ext(H, i1 - i0, nbk_all, aux);
       }
@@ -1278,7 +1219,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     // No round trip through the host between the rows' k_finalize and the kernels that hand the chunk's results over: they are queued
     // at once, k_sort_copy_rows looks at the chunk's "bad" word on the device, and qm_batch_finish reads the mirrors behind its last
     // wait (settle_pending) -- 15-25 us per chunk of 2.5 ms.  Every chunk of a finish has mirror words of its own (b->pend_segs).
-    const bool speculate = mirrors && b->pend_segs + nseg <= b->n_vcf && !getenv("QM_HB_PROFILE") && !(getenv("QM_SPECULATE") && atoi(getenv("QM_SPECULATE")) == 0);
+    const bool speculate = mirrors && b->pend_segs + nseg <= b->n_vcf && !(getenv("QM_SPECULATE") && atoi(getenv("QM_SPECULATE")) == 0);
     const int moff = speculate ? b->pend_segs : 0;
     {
       FinalizeParams F = bucket_rows_finalize(b, seg_hist);
@@ -1312,22 +1253,6 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
       if (memo_on()) {
         if (b->known_nbk.empty()) b->known_nbk.assign((size_t)b->n_vcf, 0u);
         for (int i = 0; i < nseg; ++i) b->known_nbk[(size_t)vs[(size_t)i]] = std::max(hmd[(size_t)i], 1u);
-      }
-    }
-    if (getenv("QM_HB_PROFILE")) {   // kernels built with -DHB_PROFILE: clock ticks per phase, summed over the workgroups
-      uint32_t pr[32];
-      HIPCHK(hipMemcpy(pr, b->bk_cursor + (size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg, sizeof(pr), hipMemcpyDeviceToHost));
-      fprintf(stderr, "hb profile: wgs %u;", pr[0]);
-      for (int i = 1; i < 12; ++i) fprintf(stderr, " p%d %.0f", i, pr[0] ? (double)pr[i] * 16.0 / pr[0] : 0.0);
-      fprintf(stderr, " (ticks per workgroup)\n");
-      uint32_t pj[16 * 65];   // k_join_direct: 64 replicas of [workgroups, phase 1 .. 15] behind the first sixteen words
-      HIPCHK(hipMemcpy(pj, b->bk_cursor + (size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg, sizeof(pj), hipMemcpyDeviceToHost));
-      double sum[16] = {0};
-      for (int r = 1; r <= 64; ++r) for (int i = 0; i < 16; ++i) sum[i] += pj[16 * r + i];
-      if (sum[0] > 0) {
-        fprintf(stderr, "dj profile: wgs %.0f;", sum[0]);
-        for (int i = 1; i < 14; ++i) fprintf(stderr, " p%d %.0f", i, sum[i] * 16.0 / sum[0]);
-        fprintf(stderr, " (ticks per workgroup)\n");
       }
     }
     bool overflow = false;
@@ -1597,10 +1522,10 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   S.segs = b->d_segs; S.tile_seg = b->d_bk_tile_seg; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
   S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
   S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = b->p_ent; S.xent = nullptr; S.xcursor = nullptr; S.ext = 0; S.pairs = 0;
-  uint32_t* const seg_hist = join_lean_on() ? b->bk_cursor + nhist0 : nullptr;
+  uint32_t* const seg_hist = b->bk_cursor + nhist0;
   // (no look at the highest bucket here: every partition but a VCF's last fills its 256 buckets, and the look costs the scatter more than
   // the few empty workgroups cost the join -- 2.81 against 2.71 ms per 16 x 10 M records)
-  uint32_t* const seg_maxd = getenv("QM_TIGHT_NBK_ALL") && join_lean_on() ? b->bk_cursor + nhist0 + (size_t)nseg * SEG_HIST_WORDS : nullptr;
+  uint32_t* const seg_maxd = nullptr;   // (the look at the highest filled bucket was measured on this path and lost: 2.08 against 2.02 ms per 64 x 2 M)
   S.seg_hist = seg_hist; S.seg_maxd = seg_maxd; S.l1_half = b->last2_halves ? b->p_half : nullptr;
   HashParams H;
   H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
@@ -1608,7 +1533,7 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   H.xrows = nullptr; H.xent = nullptr; H.xcursor = nullptr; H.out_stride = HB_BUCKETS; H.ext = 0; H.scatter_hist = seg_hist ? 1 : 0; H.seg_maxd = seg_maxd;
   launch_bucket_rows(H, nseg, st);
   launch_bucket_scatter(S, (int)nbt, st);
-  launch_join_direct(H, nseg, DJ_MAX_SHIFT, HB_BUCKETS, st);
+  launch_join_lean(H, nseg, DJ_MAX_SHIFT, HB_BUCKETS, st);
   {
     FinalizeParams F = bucket_rows_finalize(b, seg_hist);
     F.row_cap = seg_maxd;
@@ -1761,8 +1686,8 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
   S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = nullptr; S.xent = xs ? b->bk_xent : nullptr; S.xcursor = xs ? b->bk_xcursor : nullptr; S.ext = xs ? 1 : 0;
   S.pairs = 1;   // (tiles of single partitions run through the 512-digit instantiation as well)
-  uint32_t* const seg_hist = join_lean_on() ? b->bk_cursor + nhist0 : nullptr;
-  uint32_t* const seg_maxd = getenv("QM_TIGHT_NBK_ALL") && join_lean_on() ? b->bk_cursor + nhist0 + (size_t)nseg * SEG_HIST_WORDS : nullptr;   // (as on the two-level path: 2.08 against 2.02 ms per 64 x 2 M)
+  uint32_t* const seg_hist = b->bk_cursor + nhist0;
+  uint32_t* const seg_maxd = nullptr;   // (the look at the highest filled bucket was measured on this path and lost: 2.08 against 2.02 ms per 64 x 2 M)
   S.seg_hist = seg_hist; S.seg_maxd = seg_maxd; S.l1_half = nullptr;
   HashParams H;
   H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
@@ -1770,7 +1695,7 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   H.xrows = xs ? b->bk_xrows : nullptr; H.xent = b->bk_xent; H.xcursor = b->bk_xcursor; H.out_stride = out_stride; H.ext = xs ? 1 : 0; H.scatter_hist = seg_hist ? 1 : 0; H.seg_maxd = seg_maxd;
   launch_bucket_rows(H, nseg, st);
   launch_bucket_scatter(S, (int)nbt, st);
-  launch_join_direct(H, nseg, DJ_MAX_SHIFT, HB_BUCKETS, st);
+  launch_join_lean(H, nseg, DJ_MAX_SHIFT, HB_BUCKETS, st);
   if (xs) launch_join_ext(H, nseg, HB_BUCKETS, st);
   {
     FinalizeParams F = bucket_rows_finalize(b, seg_hist);

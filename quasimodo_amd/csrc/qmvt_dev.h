@@ -107,16 +107,12 @@ struct ClassifyParams {
   uint32_t* span_hist;  // [n_spans][SPAN_HIST_WORDS]
   uint32_t* span_scal;  // [n_spans][8]
   int32_t n_bins;
-  int32_t ablate;  // debug only (QM_ABLATE): skip phases to price them; results are wrong when non-zero
   int32_t ext;     // allele-extended batch: k_classify<false, true> against the truth sets' extended tables
   int32_t span_base;   // first span of this launch (the batch is run in a few span ranges so that compaction overlaps classification)
   uint64_t* zero_acc;  // or null: the per-truth sums k_finalize adds to, cleared by the first wave of this launch (saves a memset node per run)
   int32_t zero_words;
   const uint8_t* known;   // or null: known[v] != 0 = an earlier run of this batch found VCF v out of order and its columns have not changed since:
                           // its spans return at once (their rows still say so) and qm_batch_finish sends it down the bucket path without asking
-#ifdef K1_IL_PROBE
-  const uint8_t* il;      // probe builds: or null; a copy of the five columns with every 256-record round in 4 352 contiguous bytes
-#endif
 };
 
 struct FinalizeParams {
@@ -137,7 +133,6 @@ struct FinalizeParams {
   int32_t n_bins;
   int32_t ext;           // allele-extended batch: T' is the size of the extended truth table
   int32_t vcf_base;      // first VCF of this launch
-  uint32_t* flag_summary; // or null: host-mapped word, set to 1 if any VCF of the launch carries a flag
   int32_t parts;          // 1 = flags and tile offsets (what k_compact needs), 2 = ROC / scalars / per-truth sums, 3 = both
   const uint8_t* known;   // or null (ClassifyParams.known): a VCF known to be out of order does not raise the summary for being out of order
   // bucket rows only, or null: [n_vcf][SEG_HIST_WORDS] every first-stream record of the "VCF" (a segment of the bucket path) by
@@ -430,9 +425,6 @@ __host__ __device__ inline void synth_record(int64_t L, int64_t N, int64_t T, ui
 
 // ---- launchers ---------------------------------------------------------------
 void launch_classify(const ClassifyParams& P, int n_spans, hipStream_t st);
-#ifdef K1_IL_PROBE
-void launch_repack_il(const int32_t* pos, const int32_t* ref, const int32_t* alt, const float* qual, const uint8_t* flags, uint8_t* il, int64_t n_rounds, hipStream_t st);
-#endif
 void launch_finalize(const FinalizeParams& P, int n_vcf, hipStream_t st);
 void launch_compact(const CompactParams& P, int n_spans, hipStream_t st);
 void launch_masks_to_cls(const uint64_t* mp, const uint64_t* mt, int64_t off, int64_t n, uint8_t* cls, hipStream_t st);
@@ -440,8 +432,7 @@ void launch_synth(const SynthParams& S, int n_vcf, int64_t max_n, hipStream_t st
 void launch_classify_hash(const HashParams& P, int nseg, hipStream_t st);   // segments P.seg_base .. + nseg
 void launch_bucket_rows(const HashParams& P, int nseg, hipStream_t st);
 void launch_join_ext(const HashParams& P, int nseg, int nbk, hipStream_t st);     // the second stream of an allele-extended batch
-bool join_lean_on();
-void launch_join_direct(const HashParams& P, int nseg, int lb, int nbk, hipStream_t st);   // segments P.seg_base .. + nseg, every bucket shift <= lb <= DJ_MAX_SHIFT
+void launch_join_lean(const HashParams& P, int nseg, int lb, int nbk, hipStream_t st);   // segments P.seg_base .. + nseg, every bucket shift <= lb <= DJ_MAX_SHIFT
 void launch_bucket_scatter(const BucketScatterParams& P, int ntiles, hipStream_t st);   // tiles P.tile_base .. + ntiles; P.l1_ent: from level-1 entries
 void launch_sort_first_hist(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const int32_t* pos_col, uint32_t* hist, uint32_t* orbits,
                             hipStream_t st);

@@ -39,18 +39,10 @@ namespace qm {
 // ---------------------------------------------------------------------------
 // streaming accesses (touched once per pass): keep them out of the way of what L2 should hold
 template <typename T> __device__ __forceinline__ T ntl(const T* p) {
-#ifdef QM_NO_NT
-  return *p;
-#else
   return __builtin_nontemporal_load(p);
-#endif
 }
 template <typename T> __device__ __forceinline__ void nts(T* p, T v) {
-#ifdef QM_NO_NT
-  *p = v;
-#else
   __builtin_nontemporal_store(v, p);
-#endif
 }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
@@ -184,9 +176,6 @@ struct Cols {  // bases of one VCF: the five columns, or the packed pair
   const uint8_t* flags;
   const uint32_t* pkey;
   const uint32_t* pinf;
-#ifdef K1_IL_PROBE
-  const uint8_t* il;   // or null: the VCF's first round in the round-interleaved copy
-#endif
 };
 
 template <bool PACKED> struct Raw4;   // one round's loads, still in flight
@@ -199,21 +188,6 @@ __device__ __forceinline__ void load_raw(const Cols& C, int idx, Raw4<false>& R)
   // outputs in L2 (same-box A/B: +3.5 % on this kernel, k_finalize 10 % faster)
   typedef int v4i __attribute__((ext_vector_type(4)));
   typedef float v4f __attribute__((ext_vector_type(4)));
-#ifdef K1_IL_PROBE
-  if (C.il) {   // wave-uniform; idx = first record of the round + 4 x lane
-    const uint8_t* t = C.il + (int64_t)(idx >> 8) * 4352 + (idx & 255) * 4;
-    const v4i vp = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(t));
-    const v4i vr = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(t + 1024));
-    const v4i va = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(t + 2048));
-    const v4f vq = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(t + 3072));
-    R.p = make_int4(vp.x, vp.y, vp.z, vp.w);
-    R.r = make_int4(vr.x, vr.y, vr.z, vr.w);
-    R.a = make_int4(va.x, va.y, va.z, va.w);
-    R.q = make_float4(vq.x, vq.y, vq.z, vq.w);
-    R.f = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(C.il + (int64_t)(idx >> 8) * 4352 + 4096 + (idx & 255)));
-    return;
-  }
-#endif
   const v4i vp = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(C.pos + idx));
   const v4i vr = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(C.ref + idx));
   const v4i va = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(C.alt + idx));
@@ -246,7 +220,6 @@ struct In4 {   // the lane's 4 records of the round, packed
 template <bool EXT>
 __device__ __forceinline__ void unpack_raw(const Raw4<false>& R, int nb, In4& X, const uint32_t* flut) {
   X.posor = 0u;
-#ifndef QM_NO_FAST_PACK
   if (!EXT) {
     const float nbm1f = (float)(nb - 1);
     pack_record_fast(R.p.x, R.r.x, R.a.x, R.q.x, (R.f << 2) & 0x3cu, nbm1f, flut, X.key[0], X.inf[0]);
@@ -256,8 +229,6 @@ __device__ __forceinline__ void unpack_raw(const Raw4<false>& R, int nb, In4& X,
     X.posor = (uint32_t)R.p.x | (uint32_t)R.p.y | (uint32_t)R.p.z | (uint32_t)R.p.w;
     return;
   }
-#endif
-#ifndef QM_NO_FAST_PACK_EXT
   if (EXT) {
     const float nbm1f = (float)(nb - 1);
     pack_record_fast_ext(R.p.x, R.r.x, R.a.x, R.q.x, (R.f << 2) & 0x3cu, nbm1f, flut, X.key[0], X.inf[0]);
@@ -266,7 +237,6 @@ __device__ __forceinline__ void unpack_raw(const Raw4<false>& R, int nb, In4& X,
     pack_record_fast_ext(R.p.w, R.r.w, R.a.w, R.q.w, (R.f >> 22) & 0x3cu, nbm1f, flut, X.key[3], X.inf[3]);
     X.posor = (uint32_t)R.p.x | (uint32_t)R.p.y | (uint32_t)R.p.z | (uint32_t)R.p.w;   // anything at or above bit 28: out of range (SPANF_BADPOS)
   } else
-#endif
   {
   pack_record<EXT>(R.p.x, R.r.x, R.a.x, R.q.x, R.f, nb, X.key[0], X.inf[0]);
   pack_record<EXT>(R.p.y, R.r.y, R.a.y, R.q.y, R.f >> 8, nb, X.key[1], X.inf[1]);
@@ -335,19 +305,11 @@ __device__ __forceinline__ TruthG truth_global(const TruthDev& t) {
 // LDS layout of the wave (dword offsets into one array, so every access is a ds_ op)
 // The three histograms of the span are u16 pairs (a span holds < 65 536 records): slot s lives in the (s & 1) half of dword s >> 1.
 // That is the layout span_hist has in memory, and 1.5 KB of LDS less per wave than a dword per slot.
-#ifndef QM_HIST_U32
 constexpr int H_PACK = 1;
 constexpr int L_HTP = 0;                                // [130] TP histogram, slot = bin + 1; slot 0 swallows the uncounted records
 constexpr int L_HFP = 130;                              // [130] FP histogram, same indexing
 constexpr int L_HU = 260;                               // [128] distinct-truth-key histogram, slot = bin
 constexpr int L_KEYS = 388;                             // [K1_SLICE] staged truth keys of the tile
-#else
-constexpr int H_PACK = 0;
-constexpr int L_HTP = 0;                                // [257] a dword per slot (A/B builds only)
-constexpr int L_HFP = 257;
-constexpr int L_HU = 514;
-constexpr int L_KEYS = 772;
-#endif
 __device__ __forceinline__ void hist_add(uint32_t* lds, int table, uint32_t slot) {
   if (H_PACK) atomicAdd(&lds[table + (slot >> 1)], 1u << (16u * (slot & 1u)));
   else atomicAdd(&lds[table + slot], 1u);
@@ -391,11 +353,7 @@ static_assert(K1_ROUNDS >= 3 && K1_SLICE % 64 == 0, "the next tile's slice is fe
 // The record keys of a round are bisected by the truth keys: probe k of every lane lands on indices that differ by
 // multiples of 256 >> k, i.e. on ONE bank of the 32.  Four dwords of padding after every 32 keys put the eight 32-key
 // blocks on eight different banks (and keep every lane's four keys one aligned 16-byte store).
-#ifndef QM_NO_RKEY_PAD
 __device__ __forceinline__ int rk(int i) { return L_RKEY + i + ((i >> 5) << 2); }
-#else
-__device__ __forceinline__ int rk(int i) { return L_RKEY + i; }
-#endif
 
 struct Slice {
   int keys, smax, srf;  // dword offsets of the active buffer
@@ -468,12 +426,8 @@ __device__ __forceinline__ void stage_round(uint32_t* lds, In4& X, int i0, int t
     uint4 rv, av;
     rv.x = (uint32_t)X.r[0]; rv.y = (uint32_t)X.r[1]; rv.z = (uint32_t)X.r[2]; rv.w = (uint32_t)X.r[3];
     av.x = (uint32_t)X.a[0]; av.y = (uint32_t)X.a[1]; av.z = (uint32_t)X.a[2]; av.w = (uint32_t)X.a[3];
-#ifndef K1X_ABL_NOSTAGE   // (timing builds: what do the two stores cost?  results are wrong without them)
     *reinterpret_cast<uint4*>(&lds[L_XRREF + lane * 4]) = rv;
     *reinterpret_cast<uint4*>(&lds[L_XRALT + lane * 4]) = av;
-#else
-    asm volatile("" :: "v"(rv.x), "v"(rv.y), "v"(rv.z), "v"(rv.w), "v"(av.x), "v"(av.y), "v"(av.z), "v"(av.w));
-#endif
   }
   if (lane < 8) lds[L_HITS + lane] = 0;
 }
@@ -501,7 +455,6 @@ __device__ __forceinline__ void join_round(uint32_t* lds, const Slice& S, int nr
       const uint32_t kpos = kkey >> 4;
       const uint32_t kfloor = kkey & ~15u;   // smallest key at this position: (rk >> 4) < kpos  <=>  rk < kfloor
       // first staged record with position >= kpos: a branch-free lower bound over the 256 keys
-#if !defined(QM_NO_RKEY_PAD) && !defined(QM_NO_PADWALK)
       // ... walked in the PADDED index space (36 dwords per block of 32 keys): three steps pick the block, five the
       // key inside it, none of them crosses padding; three vector instructions and one LDS read per step
       int pp = 0;
@@ -513,15 +466,6 @@ __device__ __forceinline__ void join_round(uint32_t* lds, const Slice& S, int nr
         if (lds[L_RKEY + pp + st - 1] < kfloor) pp += st;
       int s = pp - 4 * ((pp * 1821) >> 16);   // back to the logical index: pp / 36 blocks of padding lie below (exact for pp < 288)
       if (s < 256 && lds[L_RKEY + pp] < kfloor) s += 1;   // s == 255 still below (pp = 283: the last key)
-#else
-      int s = 0;
-#pragma unroll
-      for (int step = 128; step > 0; step >>= 1) {
-        const int idx = s + step;
-        if (lds[rk(idx - 1)] < kfloor) s = idx;   // idx - 1 <= 254
-      }
-      if (s < 256 && lds[rk(s)] < kfloor) s += 1;   // s == 255 still below
-#endif
       uint32_t mx = 0, rf = 0;
       for (; s < nrec; ++s) {   // the run of records at this position
         const uint32_t rkey = lds[rk(s)];
@@ -634,7 +578,7 @@ __device__ __forceinline__ uint32_t or_reduce8(uint32_t v) {
 // prev_last = position of the record before the round (INT32_MIN at the VCF start).
 template <bool PACKED, bool EXT>
 __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, const In4& X, int rbase, int te, int prev_last, int nb,
-                                               int ablate, int mslot, Acc& A, int lane) {   // mslot: the round's first word inside the batch's kept half
+                                               int mslot, Acc& A, int lane) {   // mslot: the round's first word inside the batch's kept half
   const uint32_t hit = (lds[L_HITS + (lane >> 3)] >> (4 * (lane & 7))) & 15u;
   uint32_t nib = 0, anyinf = 0;   // nib: kept in bits 0..3, ID-is-'.' in 4..7, host-decided TP line in 8..11 (one bit per record)
 #pragma unroll
@@ -652,10 +596,10 @@ __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, con
   A.n_tp += (uint32_t)__popc(tp);
   A.fpr += (uint32_t)__popc(fpkey);
   // natural-order mask words: 8 lanes x 4 records = one 32-bit word; parked in LDS, the tile stores them at once
-  if (!(ablate & 4)) {
+  {
     const uint32_t sh = 4u * (uint32_t)(lane & 7);
-    const uint32_t wp = (ablate & 16) ? pass << sh : or_reduce8(pass << sh);   // (16: the DPP reductions priced alone)
-    const uint32_t wt = (ablate & 16) ? tp << sh : or_reduce8(tp << sh);
+    const uint32_t wp = or_reduce8(pass << sh);
+    const uint32_t wt = or_reduce8(tp << sh);
     if ((lane & 7) == 7) {
       lds[L_MASK + mslot + (lane >> 3)] = wp;
       lds[L_MASK + 32 * mask_tiles<EXT>() + mslot + (lane >> 3)] = wt;
@@ -673,7 +617,7 @@ __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, con
     // ROC histograms: slot = bin + 1 in the TP or FP table (slot 0 swallows records without a bin).
     // The saturated top bin, where real QUALs pile up, is counted with wave ballots into scalar
     // registers instead: those lanes sit out the LDS add, so they never serialise on one address.
-    if (!(ablate & 2)) {
+    {
       const uint32_t b1 = X.inf[k] & I_BIN1;
       const uint32_t notp = ((~tpkey) >> k) & 1u;
       const bool top = b1 == (uint32_t)nb;
@@ -689,7 +633,7 @@ __device__ __forceinline__ void classify_round(uint32_t* lds, const Cols& C, con
   }
   // R path: a kept key outside the truth set counts once per VCF
   cand &= fpkey;
-  if (cand && !(ablate & 8)) {
+  if (cand) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if ((cand >> k) & 1u) {
@@ -714,18 +658,6 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-#ifndef K1_LDS_PAD
-#define K1_LDS_PAD 0
-#endif
-#ifndef K1_PREFETCH
-#define K1_PREFETCH 1
-#endif
-#ifndef K1_MAP
-#define K1_MAP 0
-#endif
-#ifndef K1_MAP_STRIDE
-#define K1_MAP_STRIDE 61
-#endif
 #ifndef K1_WAVES_PER_EU
 #define K1_WAVES_PER_EU 5   // the register allocator is told to stay within 96 VGPRs (5 waves per SIMD)
 #endif
@@ -738,44 +670,21 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 
 template <bool PACKED, bool EXT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAVES_EXT_MIN : K1_WAVES_PER_EU, K1_WAVES_MAX))) void k_classify(ClassifyParams P) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds[(EXT ? L_TOTAL_X : L_TOTAL) + K1_LDS_PAD];
+  __shared__ __attribute__((aligned(16))) uint32_t lds[(EXT ? L_TOTAL_X : L_TOTAL)];
 
   const int lane = (int)threadIdx.x;
-#if defined(QM_ABLATE_SUPPORT)   // debug builds: QM_ABLATE bits 9-10 pick the span order per launch (0 linear, 1 an eighth per XCD, 2 / 3 neighbours 61 / 1 021 apart)
-  int bid_ = (int)blockIdx.x;
-  {
-    const int mode_ = (P.ablate >> 9) & 3, nblk_ = (int)gridDim.x;
-    if (mode_ == 1) { const int x_ = bid_ & 7, j_ = bid_ >> 3, per_ = nblk_ >> 3; if (j_ < per_) bid_ = x_ * per_ + j_; }
-    else if (mode_ >= 2) { const int st_ = mode_ == 2 ? 61 : 1021, full_ = nblk_ / st_ * st_; if (bid_ < full_) bid_ = (bid_ % st_) * (full_ / st_) + bid_ / st_; }
-  }
-#elif K1_MAP == 1     // (A/B) every XCD a contiguous eighth of the spans
-  const int nblk_ = (int)gridDim.x, x_ = (int)blockIdx.x & 7, j_ = (int)blockIdx.x >> 3, per_ = nblk_ >> 3;
-  const int bid_ = j_ < per_ ? x_ * per_ + j_ : (int)blockIdx.x;
-#elif K1_MAP == 2   // (A/B) neighbours in the launch order far apart in memory
-  const int nblk_ = (int)gridDim.x, full_ = nblk_ / K1_MAP_STRIDE * K1_MAP_STRIDE;
-  const int bid_ = (int)blockIdx.x < full_ ? ((int)blockIdx.x % K1_MAP_STRIDE) * (full_ / K1_MAP_STRIDE) + (int)blockIdx.x / K1_MAP_STRIDE : (int)blockIdx.x;
-#else
   const int bid_ = (int)blockIdx.x;
-#endif
   const int span_id = bid_ + P.span_base;
   const SpanDesc sp = P.spans[span_id];
   const TruthG tr = truth_global<EXT>(P.truths[sp.truth]);
   Cols C;
   C.pos = P.pos + sp.voff; C.ref = P.ref + sp.voff; C.alt = P.alt + sp.voff; C.qual = P.qual + sp.voff; C.flags = P.flags + sp.voff;
   C.pkey = P.pkey + sp.voff; C.pinf = P.pinf + sp.voff;
-#ifdef K1_IL_PROBE
-  C.il = P.il ? P.il + (sp.voff >> 8) * 4352 : nullptr;
-#endif
   uint32_t* const mpass32 = reinterpret_cast<uint32_t*>(P.mask_pass + (sp.voff >> 6));
   uint32_t* const mtp32 = reinterpret_cast<uint32_t*>(P.mask_tp + (sp.voff >> 6));
   const int vn = sp.vn;
   const int sp_end = (int)(sp.end - sp.voff);
   const int nb = P.n_bins;
-#ifdef QM_ABLATE_SUPPORT
-  const int ablate = P.ablate;   // debug builds only: phases can be switched off to price them
-#else
-  constexpr int ablate = 0;
-#endif
 
   for (int i = lane; i < L_KEYS; i += 64) lds[i] = 0;   // histograms
   if (lane < 16) lds[L_FLUT + lane] = flag_info((uint32_t)lane);
@@ -791,12 +700,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
   int te = (tb + K1_TILE < sp_end) ? tb + K1_TILE : sp_end;
   Raw4<PACKED> N;
   load_raw<EXT>(C, tb + lane * 4, N);
-#if K1_PREFETCH == 2
-  Raw4<PACKED> N2 = N;
-  if (tb + 256 < sp_end) load_raw<EXT>(C, tb + 256 + lane * 4, N2);
-#endif
   SegBounds B = seg_bounds<PACKED>(C, tb, te, vn);
-#ifndef K1_NO_EARLY_LEAVE
   if constexpr (!PACKED) {
     // A span whose FIRST round is out of order leaves here, three round trips in (descriptor, positions, this look), instead of
     // after its first tile (the truth side's chain of three more, four rounds of work, the epilogue's rows): the pass over a batch
@@ -815,7 +719,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
       return;
     }
   }
-#endif
   int lo, hi;
   slice_range(tr, B.a, B.b, lo, hi);
   Slice S;
@@ -865,15 +768,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
         }
       }
       // then the following rounds' records into flight (rounds are contiguous across the span's tiles)
-#if K1_PREFETCH == 2
-      N = N2;
-      if (rbase + 512 < sp_end) load_raw<EXT>(C, rbase + 512 + lane * 4, N2);
-#else
       if (rbase + 256 < sp_end) load_raw<EXT>(C, rbase + 256 + lane * 4, N);
-#endif
       stage_round<EXT>(lds, X, rbase + lane * 4, te, lane);
       __syncthreads();
-      if (!(ablate & 1)) {
+      {
         if (!oversize) {
           join_round<EXT>(lds, S, rend - rbase, own_a, lane);
         } else {
@@ -906,13 +804,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
         }
       }
       __syncthreads();
-      classify_round<PACKED, EXT>(lds, C, X, rbase, te, prev_last, nb, ablate, 32 * ((tile - sp.tile0) % mask_tiles<EXT>()) + 8 * r, A, lane);
+      classify_round<PACKED, EXT>(lds, C, X, rbase, te, prev_last, nb, 32 * ((tile - sp.tile0) % mask_tiles<EXT>()) + 8 * r, A, lane);
       prev_last = (int)(lds[rk(255)] >> 4);
       __syncthreads();
     }
 
     // ---- tile epilogue: run continuation, per-truth-entry state -> histogram, counts ----
-    if (!(ablate & 1) && !oversize) {
+    if (!oversize) {
       if (B.nextp == B.b && owns_b) continue_run<PACKED, EXT>(C, lds, S, te, vn, B.b, nb, lane);
       __syncthreads();
       acc_tpr += flush_slice(lds, S, lane);
@@ -928,7 +826,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
       acc_tp += tile_nt;
     }
     const bool stop_unsorted = !PACKED && ballot64(A.bad & 1u) != 0ull;
-    if (!(ablate & 4)) {
+    {
       // a full batch of mask words, or the span's last tiles: one 16-byte store per lane and mask (dword stores for a ragged end)
       constexpr int MT = mask_tiles<EXT>();
       const int tin = (tile - sp.tile0) % MT;
@@ -939,20 +837,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
           uint32_t* dst = (half ? mtp32 : mpass32) + (b0 >> 5);
-#ifdef QM_ABLATE_SUPPORT
-          if (half && (ablate & 2048)) dst = mpass32 + (b0 >> 5) + 32 * MT;   // (2048: the TP words right behind the batch's kept words instead of in their own array -- timing only: they land on the next batch's)
-#endif
-          if (ablate & 64) dst = reinterpret_cast<uint32_t*>(half ? P.mask_tp : P.mask_pass) + ((int)(blockIdx.x & 1023) << 10);   // (64: the same stores into 4 MB that stay in L2 -- is it the HBM traffic or the store itself?)
           const int src = L_MASK + half * 32 * MT;
           for (int w = 4 * lane; w < 32 * MT; w += 256) {
-            if (ablate & 32) { asm volatile("" :: "v"(lds[src + w])); continue; }   // (32: the masks' global stores priced alone)
-#if defined(QM_ABLATE_SUPPORT)
-            const bool mask_nt = (ablate & 128) == 0;   // (128: cached instead of streaming stores for the mask words)
-#elif defined(K1_MASK_PLAIN)
-            constexpr bool mask_nt = false;             // (A/B)
-#else
             constexpr bool mask_nt = true;   // streaming: 0.8 % of the kernel on every one of 14 allocations (profiles/r04_classify_mask_nt.log)
-#endif
             if (w + 3 < nd) {
               typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
               if (mask_nt) __builtin_nontemporal_store(*reinterpret_cast<const v4u_*>(&lds[src + w]), reinterpret_cast<v4u_*>(dst + w));
@@ -1001,13 +888,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
   uint32_t* oh = P.span_hist + (size_t)span_id * SPAN_HIST_WORDS;
   for (int i = lane; i < 128; i += 64) {
     const int b0 = 2 * i, b1 = 2 * i + 1;
-#if defined(QM_ABLATE_SUPPORT)   // debug builds: QM_ABLATE=256
-#define K1_HST(p, x) do { if (ablate & 256) __builtin_nontemporal_store((uint32_t)(x), (p)); else *(p) = (x); } while (0)
-#elif defined(K1_HIST_NT)   // (A/B) streaming stores for the span's histograms
-#define K1_HST(p, x) __builtin_nontemporal_store((uint32_t)(x), (p))
-#else
 #define K1_HST(p, x) (*(p) = (x))
-#endif
     K1_HST(&oh[i], (hist_get(lds, L_HTP, 1 + b0) + (b0 == nb - 1 ? top_tp : 0u)) | ((hist_get(lds, L_HTP, 1 + b1) + (b1 == nb - 1 ? top_tp : 0u)) << 16));
     K1_HST(&oh[128 + i], (hist_get(lds, L_HFP, 1 + b0) + (b0 == nb - 1 ? top_fp : 0u)) | ((hist_get(lds, L_HFP, 1 + b1) + (b1 == nb - 1 ? top_fp : 0u)) << 16));
     K1_HST(&oh[256 + i], hist_get(lds, L_HU, b0) | (hist_get(lds, L_HU, b1) << 16));
@@ -1073,7 +954,6 @@ __global__ __launch_bounds__(256) void k_finalize(FinalizeParams P) {
       __hip_atomic_store(P.host_flags + v, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(P.host_aux + v, P.row_cap ? P.row_cap[v] : s_or, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (out && P.flag_summary && !(out == SPANF_UNSORTED && P.known && P.known[v])) __hip_atomic_store(P.flag_summary, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host-mapped: tells qm_batch_finish that the per-VCF flags are worth a copy
     if (P.chunk_bad && ((out & (SPANF_OVERFLOW | SPANF_BADPOS)) || (P.row_cap && P.row_cap[v] > P.row_cap_limit))) atomicOr(P.chunk_bad, 1u);
   };
   // the run's own k_finalize (P.lazy_unsorted): a VCF its spans found out of order is redone from the columns -- rows, scalars,
@@ -1330,15 +1210,9 @@ struct K3List {
   uint32_t n;               // entries in buf (the first wave-offset & 255 of them are not there: below lo, never stored)
 };
 __device__ __forceinline__ void k3_store4(int32_t* p, k3_v4i w) {
-#ifdef K3_ABL_NOSTORE
-  asm volatile("" :: "v"(w));
-#elif defined(K3_PLAIN_STORE)
-  *reinterpret_cast<k3_v4i*>(p) = w;
-#else
   // non-temporal: nobody reads the lists on the device, and plain stores leave their dirty lines to be written back while the next
   // step's k_classify streams (same-box A/B over 5 processes each: k_compact alike, k_classify + 0.19 ms with plain stores)
   __builtin_nontemporal_store(w, reinterpret_cast<k3_v4i*>(p));
-#endif
 }
 // entries [lo, hi) of the chunk that starts at buf index c0 (a multiple of 256; entry g0 + c0): whole quads with one
 // 16-byte store per lane, the <= 3 + 3 entries around them with one masked dword store.  Only where a LIST begins or ends
@@ -1352,9 +1226,7 @@ __device__ __forceinline__ void k3_store_part(const K3List& X, uint32_t c0, uint
     const uint32_t lo4 = (lo + 3u) & ~3u, hi4 = hi & ~3u;
     uint32_t i = lane < 3 ? lo + (uint32_t)lane : hi4 + (uint32_t)(lane - 3);
     const bool ok = lane < 3 ? (i < lo4 && i < hi) : (i < hi && i >= lo && i >= lo4);
-#ifndef K3_ABL_NOSTORE
     if (ok) X.out[i] = (int32_t)X.buf[i - X.g0];
-#endif
   }
 }
 // Complete chunks of 2^CL entries leave -- those the wave owns --, the partial chunk behind them moves to the front (all
@@ -1416,14 +1288,10 @@ __global__ __launch_bounds__(64 * K3_WAVES) void k_compact(CompactParams P) {
   constexpr int NLUT = (256 + 64 * K3_WAVES - 1) / (64 * K3_WAVES);
   constexpr int NPRE = K3_NPASS + K3_EXTRA;                 // passes whose mask bytes are asked for at the start
   const int L = (int)blockIdx.x;   // launch order (an XCD-contiguous tile order was measured with the other ownership form only; not kept)
-#ifndef K3_NO_OWN_LOOK
   // A span that k_classify itself left as out of order belongs to a VCF this launch skips (its flags say so, below): the span's
   // own word, asked for beside its descriptor, lets the workgroup go one round trip earlier -- the launch over a batch of
   // shuffled VCFs is 7 rounds of workgroups that all do just that (28 -> 8 us of device time on a first-seen step)
   const uint32_t own_fl = P.skip_unsorted ? P.span_scal[(size_t)(L / BPS + P.span_base) * 8 + 5] : 0u;
-#else
-  const uint32_t own_fl = 0u;
-#endif
   const SpanDesc sp = P.spans[L / BPS + P.span_base];
   // everything the wave needs is asked for at once, behind the span descriptor: the table, the VCF's flags and list sizes, the
   // offsets of its first tile, of its neighbours' and of the tiles behind them, the mask bytes of its passes and of the tile behind
@@ -1486,10 +1354,8 @@ __global__ __launch_bounds__(64 * K3_WAVES) void k_compact(CompactParams P) {
     uint32_t tot;
     const uint32_t ex = k3_scan(c, tot) - c;
     const uint32_t base = (uint32_t)(rb + p * K3_PASS + 8 * lane);
-#ifndef K3_ABL_NOEMIT
     if (wantF && (tot & 0xffffu)) k3_emit(F.buf, s_lut, F.n + (ex & 0xffffu), wf, base);
     if (wantT && (tot >> 16)) k3_emit(T.buf, s_lut, T.n + (ex >> 16), wt, base);
-#endif
     asm volatile("" ::: "memory");
     if (wantF) { F.n += tot & 0xffffu; k3_drain<K3_FCH_LOG>(F, lane); }
     if (wantT) { T.n += tot >> 16; k3_drain<K3_TCH_LOG>(T, lane); }
@@ -1590,13 +1456,9 @@ __global__ __launch_bounds__(256) void k_sort_gather_alleles(const SortSeg* segs
 // workgroups go round-robin to the 8 XCDs, each with its own L2; giving each XCD a CONTIGUOUS range of tiles lets
 // one L2 merge the pieces into whole lines before they leave for HBM.
 __device__ __forceinline__ int xcd_contiguous_block() {
-#ifndef QM_SORT_NO_XCD_MAP
   const int nblk = (int)gridDim.x, xcd = (int)blockIdx.x & 7, jx = (int)blockIdx.x >> 3;
   const int per = nblk >> 3, rem = nblk & 7;
   return xcd * per + (xcd < rem ? xcd : rem) + jx;
-#else
-  return (int)blockIdx.x;
-#endif
 }
 
 // the digit of a key in one pass of the LSD sort: 8 bits at `shift`
@@ -1877,13 +1739,6 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
 #ifndef BK_WAVES_PER_EU
 #define BK_WAVES_PER_EU 6
 #endif
-#if defined(HB_PROFILE) && defined(BKS_PROFILE)   // phase clocks of the scatter (instead of the joins': they share the counters)
-#define BKS_TICK(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); s_prof[i] = (uint32_t)((t_ - hb_t) >> 4); hb_t = t_; } } while (0)
-#define BKS_FLUSH() do { if (threadIdx.x < 16) atomicAdd(hb_prof + 16 * (1 + (blockIdx.x & 63)) + threadIdx.x, threadIdx.x == 0 ? 1u : s_prof[threadIdx.x]); } while (0)
-#else
-#define BKS_TICK(i) do { } while (0)
-#define BKS_FLUSH() do { } while (0)
-#endif
 // L2: the segment is one partition of a large VCF (two-level path): its records come as level-1 entries (P.l1_ent + sg.koff,
 // sg.n of them, no holes) instead of columns, keys are relative to the partition (sg.key_base), the kept mask was written
 // by the first level.
@@ -1912,12 +1767,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   const SortSeg sg = P.segs[seg];
   const int sub = bid & (HB_SUBS - 1);
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#if defined(HB_PROFILE) && defined(BKS_PROFILE)
-  uint32_t* hb_prof = P.cursor + (size_t)P.n_seg * HB_BUCKETS * HB_SUBS + (size_t)P.n_seg;
-  unsigned long long hb_t = __builtin_amdgcn_s_memtime();
-  __shared__ uint32_t s_prof[16];
-  if (threadIdx.x < 16) s_prof[threadIdx.x] = 0u;
-#endif
   if (tid < NB) { s_cnt[tid] = 0u; if (EXT) s_cntx[tid] = 0u; }
   const bool count_all = P.seg_hist != nullptr;
   if (count_all) for (int i = tid; i < (NB / 256) * SEG_HIST_WORDS; i += 512) (&s_hall[0][0])[i] = 0u;
@@ -1935,7 +1784,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   // beyond the estimate flags the VCF (the radix sort redoes it) instead of landing in a bucket nobody looks at
   const uint32_t olim = sg.part == 0 ? (uint32_t)sg.nbk : dlim;
   __syncthreads();
-  BKS_TICK(1);
   const int64_t tbase = (int64_t)(bid - sg.bk_tile0) * BK_TILE;
   const uint32_t shift = (uint32_t)sg.pad;
   uint64_t ent[PER];
@@ -1996,7 +1844,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
       f[j] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(P.flags + g));
     }
   }
-  BKS_TICK(2);
   const float nbm1f = (float)(P.n_bins - 1);
 #pragma unroll
   for (int j = 0; j < PER / 4; ++j) {
@@ -2010,15 +1857,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
       ent[k] = 0ull;
       if (i4 + u < sg.n) {
         uint32_t key, inf;
-#ifdef BK_SLOW_PACK   // (A/B builds: the general packer)
-        pack_record<EXT>(p[j][u], r[j][u], a[j][u], q[j][u], f[j] >> (8 * u), P.n_bins, key, inf);
-        segfl |= (inf & I_BADPOS) ? SPANF_BADPOS : 0u;
-#else
         const uint32_t f4x4 = ((f[j] >> (8 * u)) & 15u) << 2;
         if (EXT) pack_record_fast_ext(p[j][u], r[j][u], a[j][u], q[j][u], f4x4, nbm1f, s_flut, key, inf);
         else pack_record_fast(p[j][u], r[j][u], a[j][u], q[j][u], f4x4, nbm1f, s_flut, key, inf);
         segfl |= ((uint32_t)p[j][u] >> 28) ? SPANF_BADPOS : 0u;
-#endif
         if (inf & I_LIVE) {
           kept |= ((inf >> 16) & 1u) << u;
           const uint32_t rel = key - sg.key_base;   // (key_base = 0 unless the segment is a partition of its VCF)
@@ -2054,9 +1896,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
     if (ballot64(top_all != 0u)) { top_all = wave_sum(top_all); if (lane == 0) atomicAdd(&s_hall[0][nbins], top_all); }
     if (NB == 512 && ballot64(top_all2 != 0u)) { top_all2 = wave_sum(top_all2); if (lane == 0) atomicAdd(&s_hall[NB / 256 - 1][nbins], top_all2); }
   }
-  BKS_TICK(3);
   __syncthreads();
-  BKS_TICK(4);
   if (P.seg_maxd && tid < NB) {   // 1 + the highest bucket this tile fills, per wave: one atomic each
     uint32_t m = (s_cnt[tid] || (EXT && s_cntx[tid])) ? (uint32_t)(tid & 255) + 1u : 0u;   // (either stream)
 #pragma unroll
@@ -2083,9 +1923,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   uint32_t cnt = 0, incl = 0, cnt_odd = 0;
   if (tid < NB) {
     cnt = s_cnt[tid];
-#ifdef BK_PAIRS
-    cnt_odd = cnt & 1u;
-#endif
     cnt += cnt_odd;
     incl = cnt;
 #pragma unroll
@@ -2119,9 +1956,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
     cnt = s_cntx[tid - 256];
     if (cnt) g = atomicAdd(&P.xcursor[((size_t)seg * HB_BUCKETS + (tid - 256)) * HB_SUBS + sub], cnt);
   }
-  BKS_TICK(5);
   __syncthreads();
-  BKS_TICK(6);
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     if (dr[k] != 0xffffffffu) {
@@ -2140,9 +1975,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
       s_cntx[tid] = gx2;
     }
   }
-  BKS_TICK(7);
   __syncthreads();
-  BKS_TICK(8);
   if (EXT) {
     typedef unsigned long long v2ull __attribute__((ext_vector_type(2)));
     v2ull* xout = reinterpret_cast<v2ull*>(P.xent) + sg.bk_off;   // (the second stream's regions are laid out like the first's)
@@ -2162,35 +1995,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   }
   const int total = (int)s_scan[NB / 64];
   uint64_t* out = P.ent + sg.bk_off;
-#ifdef BK_PAIRS
-  {
-    typedef unsigned long long v2e __attribute__((ext_vector_type(2)));
-    for (int idx = 2 * tid; idx < total; idx += 1024) {   // (total, every run's start and every run's place are even)
-      const uint32_t d = s_d[idx];
-      const int32_t w = s_glob[d] + idx;
-      if (w < sg.bk_cap) *reinterpret_cast<v2e*>(&out[((size_t)d * HB_SUBS + sub) * (size_t)sg.bk_cap + (size_t)w]) = *reinterpret_cast<const v2e*>(&s_e[idx]);   // beyond: the VCF is flagged and redone
-    }
-  }
-#else
   for (int idx = tid; idx < total; idx += 512) {
     const uint32_t d = s_d[idx];
     const int32_t w = s_glob[d] + idx;
-#ifdef BK_ABL_NOSTORE   // (timing builds: the entries' stores switched off -- what do the 8 bytes per record cost inside 17 bytes of reads?)
-    if (w < sg.bk_cap) asm volatile("" :: "v"(s_e[idx]));
-#elif defined(BK_ABL_L2STORE)   // (the same stores, same shape, wrapped into 2 MB that stay in L2: the instructions without the HBM traffic)
-    if (w < sg.bk_cap) out[(((size_t)d * HB_SUBS + sub) * (size_t)sg.bk_cap + (size_t)w) & 0x3ffffu] = s_e[idx];
-#elif defined(BK_NT_STORE)      // (A/B: streaming stores for the entries)
-    if (w < sg.bk_cap) __builtin_nontemporal_store(s_e[idx], &out[((size_t)d * HB_SUBS + sub) * (size_t)sg.bk_cap + (size_t)w]);
-#else
     if (w < sg.bk_cap) out[((size_t)d * HB_SUBS + sub) * (size_t)sg.bk_cap + (size_t)w] = s_e[idx];   // beyond: the VCF is flagged and redone
-#endif
   }
-#endif
-  BKS_TICK(9);
-#if defined(HB_PROFILE) && defined(BKS_PROFILE)
-  __syncthreads();
-#endif
-  BKS_FLUSH();
 }
 
 // ---------------------------------------------------------------------------
@@ -2292,13 +2101,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(BK_WAVES_PE
       ent[k] = 0ull;
       if (i4 + u < sg.n) {
         uint32_t key, inf;
-#ifdef BK_SLOW_PACK
-        pack_record<false>(p[j][u], r[j][u], a[j][u], q[j][u], f[j] >> (8 * u), P.n_bins, key, inf);
-        if (!(inf & I_BADPOS)) {   // (the counting pass has flagged the VCF otherwise)
-#else
         pack_record_fast(p[j][u], r[j][u], a[j][u], q[j][u], ((f[j] >> (8 * u)) & 15u) << 2, nbm1f, s_flut, key, inf);
         if (!((uint32_t)p[j][u] >> 28)) {   // (the counting pass has flagged the VCF otherwise)
-#endif
           const bool live = (inf & I_LIVE) != 0u;
           kept |= ((inf >> 16) & 1u) << u;
           const uint32_t d = key >> P2_SHIFT;
@@ -2448,35 +2252,6 @@ __device__ __forceinline__ uint32_t wave_reserve(uint32_t* ctr, bool want) {
   base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(m));
   return base + rank;
 }
-#ifdef HB_PROFILE   // phase clocks of wave 0 (s_memtime), summed in 16-tick units behind the segment flags
-#define HB_TICK(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(hb_prof + (i), (uint32_t)((t_ - hb_t) >> 4)); hb_t = t_; } } while (0)
-// the same kept in LDS and flushed once, at the end of the workgroup, into one of 64 replicas (k_join_direct: twelve atomics of
-// every workgroup on the same twelve words doubled the kernel's time and with it every share)
-#define LDS_TICK(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); s_prof[i] = (uint32_t)((t_ - hb_t) >> 4); hb_t = t_; } } while (0)
-#define LDS_FLUSH() do { if (threadIdx.x < 16) atomicAdd(hb_prof + 16 * (1 + (blockIdx.x & 63)) + threadIdx.x, threadIdx.x == 0 ? 1u : s_prof[threadIdx.x]); } while (0)
-#if defined(BKS_PROFILE)
-#define DJ_TICK(i) do { } while (0)
-#define DJ_FLUSH() do { } while (0)
-#define XJ_TICK(i) do { } while (0)
-#define XJ_FLUSH() do { } while (0)
-#elif defined(XJ_PROFILE)   // the clocks of k_join_ext instead of k_join_direct's (they share the counters)
-#define DJ_TICK(i) do { } while (0)
-#define DJ_FLUSH() do { } while (0)
-#define XJ_TICK(i) LDS_TICK(i)
-#define XJ_FLUSH() LDS_FLUSH()
-#else
-#define DJ_TICK(i) LDS_TICK(i)
-#define DJ_FLUSH() LDS_FLUSH()
-#define XJ_TICK(i) do { } while (0)
-#define XJ_FLUSH() do { } while (0)
-#endif
-#else
-#define DJ_TICK(i) do { } while (0)
-#define DJ_FLUSH() do { } while (0)
-#define XJ_TICK(i) do { } while (0)
-#define XJ_FLUSH() do { } while (0)
-#define HB_TICK(i) do { } while (0)
-#endif
 // Waves of a bucket's workgroup meet at three barriers only and walk their records independently in between: versions that
 // split the record loop into workgroup-wide phases (filter pass, a queue of the filter-positive records settled with full
 // waves, ...) removed the divergent steps but put every wave in the same phase at the same time, and lost 20-40 %.
@@ -2503,10 +2278,6 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
   const int d = (int)blockIdx.x;
   const int seg_id = (int)blockIdx.y + P.seg_base;
   const size_t row = (size_t)seg_id * HB_BUCKETS + (size_t)d;
-#ifdef HB_PROFILE
-  uint32_t* hb_prof = const_cast<uint32_t*>(P.cursor) + (size_t)P.n_seg * HB_BUCKETS * HB_SUBS + (size_t)P.n_seg;
-  unsigned long long hb_t = __builtin_amdgcn_s_memtime();
-#endif
   const HashRow R = P.rows[row];                                 // one scalar load beside the cursors: nothing below waits for more than
   const uint32_t* cur = P.cursor + row * HB_SUBS;                // one further round trip (the entries and the truth keys, together)
   const uint32_t segfl = d == 0 ? P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg_id] : 0u;   // the segment's flags travel in its first row
@@ -2532,9 +2303,6 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
     if (tid < 8) P.row_scal[row * 8 + tid] = tid == 5 ? segfl : 0u;
     return;
   }
-#ifdef HB_PROFILE
-  if (threadIdx.x == 0) atomicAdd(hb_prof, 1u);
-#endif
   // A trip gives every thread four consecutive entries of one sub-region (32 bytes, two 16-byte loads: dword loads are bound
   // by the rate of memory instructions).  The first trip and the thread's truth key are in flight before the tables are
   // even cleared; later trips are fetched one ahead.
@@ -2562,11 +2330,7 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
   const uint32_t kbase = R.kbase;                            // every key of the bucket is >= kbase
   const uint32_t klast = kbase + ((1u << shift) - 1u);
   uint32_t tkey0 = 0u, tkey1 = 0u;
-#ifndef HB_SKIP_TRUTH   // (timing builds only: phases of the kernel switched off, results wrong)
   const int tn = over ? 0 : R.tn;
-#else
-  const int tn = 0;
-#endif
   if (tid < tn) tkey0 = g_tkeys[tid];
   if (tid + HB_THREADS < tn) tkey1 = g_tkeys[tid + HB_THREADS];   // up to 1 024 keys: all a bucket can take are in flight here
   for (int i = tid; i < (1 << LTR); i += HB_THREADS) { s_tk[i] = HB_EMPTY; s_ts[i] = 0u; }
@@ -2576,9 +2340,7 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
   if (tid < (1 << LNK)) s_nk[tid] = HB_EMPTY;
   if (tid < 3 * 128) s_h[tid] = 0u;
   if (tid < 9) s_c[tid] = tid == 4 ? (segfl | (over ? SPANF_OVERFLOW : 0u)) : 0u;
-  HB_TICK(1);
   __syncthreads();
-  HB_TICK(2);
   // ---- the truth keys of the bucket's positions (the coarse position index hands out whole cells) ----
   for (int j0 = 0; j0 < tn; j0 += HB_THREADS) {   // wave-uniform trip count
     const int j = j0 + tid;
@@ -2597,9 +2359,7 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
       }
     }
   }
-  HB_TICK(3);
   __syncthreads();
-  HB_TICK(4);
   uint32_t n_pass = 0, n_tp = 0, fpr = 0;
   uint32_t vq[PER];          // the thread's records stay in registers for the second pass
   uint32_t cand = 0;         // bit k: record k is a kept key outside the truth set (with a comparable key)
@@ -2632,7 +2392,6 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
     const uint32_t h = hb_hash(v) >> (32u - LFB), bt = 1u << (h & 31u);
     if (atomicOr(&s_b1[h >> 5], bt) & bt) atomicOr(&s_b2[h >> 5], bt);
   };
-#ifndef HB_SKIP_RECORDS
   if (!(s_c[4] & SPANF_OVERFLOW)) {
     // The records whose key passes the truth filter (1 in 10; most of them true matches) are what costs here: their way
     // through the tables is a chain of dependent, divergent steps, and walked where they stand it runs in EVERY step of
@@ -2714,21 +2473,16 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
           }
         }
       }
-#ifndef HB_SKIP_FPR
       // the four fetch-ORs of a trip in flight together (a zero bit changes nothing)
 #pragma unroll
       for (int u = 0; u < 4; ++u) old[u] = atomicOr(&s_b1[wd[u]], bit[u]);
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (old[u] & bit[u]) atomicOr(&s_b2[wd[u]], bit[u]);   // seen before (or a collision): both meet again below
-#endif
     }
     while (tail != head) drain(tail - head < 64u ? tail - head : 64u);
   }
-#endif
-  HB_TICK(5);
   __syncthreads();   // the rings are empty: their room becomes the exact set of the keys on marked bits
-  HB_TICK(6);
   for (int i = tid; i < (1 << LX); i += HB_THREADS) s_x[i] = HB_EMPTY;
   __syncthreads();
   // second pass: keys on unmarked bits are distinct; keys on marked bits are counted exactly -- the thread's own candidates
@@ -2791,12 +2545,10 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
       }
     }
   }
-  HB_TICK(7);
   // ---- bucket epilogue: per-entry state -> U histogram and TP_R, counters, the row ----
   n_pass = wave_sum(n_pass); n_tp = wave_sum(n_tp); fpr = wave_sum(fpr);   // (not atomics of per-lane values on one address: hipcc makes a 64-step serial loop of each)
   if ((tid & 63) == 0) { atomicAdd(&s_c[0], n_pass); atomicAdd(&s_c[1], n_tp); atomicAdd(&s_c[2], fpr); }
   __syncthreads();
-  HB_TICK(8);
   uint32_t tpr = 0;
   for (int t = tid; t < (1 << LTR); t += HB_THREADS) {
     if (s_tk[t] == HB_EMPTY) continue;
@@ -2806,9 +2558,7 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
   }
   tpr = wave_sum(tpr);
   if ((tid & 63) == 0 && tpr) atomicAdd(&s_c[3], tpr);
-  HB_TICK(9);
   __syncthreads();
-  HB_TICK(10);
   uint32_t* oh = P.row_hist + row * SPAN_HIST_WORDS;
   if (tid < 3 * 128) oh[tid] = s_h[tid];
   if (tid == 0) {
@@ -2816,402 +2566,11 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
     const uint32_t fl = s_c[4];
     sc[0] = s_c[0]; sc[1] = s_c[1]; sc[2] = s_c[0] - s_c[1]; sc[3] = s_c[3]; sc[4] = s_c[2]; sc[5] = fl; sc[6] = 0u; sc[7] = 0u;
   }
-  HB_TICK(11);
 }
 
-// ---------------------------------------------------------------------------
-// k_join_direct -- the join of one bucket whose whole key range fits ONE bit map in LDS (round 3).
-//
-// k_classify_hash is bound by instruction issue: every record is hashed, filtered, looked up and de-duplicated through
-// small tables, and the branches around those steps are what the SIMDs issue (~350 vector instructions per record slot).
-// A bucket of the one-pass scatter covers 2^shift consecutive keys (pos << 4 | nibble); when shift <= 19 a bit per KEY
-// is 64 KB of LDS, and then nothing has to be hashed, probed or settled twice:
-//   * the truth keys of the bucket set their bits; "is this record's key in the truth set" is ONE LDS read and a shift;
-//   * the same map then takes the kept keys OUTSIDE the truth set (a key is in the truth set or it is not, so the two
-//     kinds of bits never meet): one non-returning ds_or per record in a second pass over the thread's registers, and
-//     FP_R = popcount(map) - truth bits.  Exact, no collisions, no second look at anything;
-//   * the records that hit a truth key (a few per cent) are parked in a ring of their wave and settled 64 at a time with
-//     every lane busy: their truth entry is found by bisection of the bucket's sorted slice of the truth keys (no hash
-//     table), best bin / matched-by-kept state and the input-order TP bit follow.
-// Two workgroups of 512 threads per CU at shift 19 (80 KB each), more for smaller key ranges (LB = log2 of the map's bits is
-// a template parameter).  Rows, flags and overflow behaviour are those of k_classify_hash, which stays for buckets with
-// wider key ranges.
-// ---------------------------------------------------------------------------
-constexpr int DJ_THREADS = 512;
+// staged truth keys per bucket and the coarse index over them (k_join_lean)
 constexpr int DJ_TRUTH_MAX = 1024;   // staged truth keys per bucket (whole cells of the coarse position index)
-constexpr int DJ_NK_LOG2 = 7;        // exact set of the kept records without a comparable key
-constexpr uint32_t DJ_RING = 64;     // parked records per wave
 constexpr int DJ_CI_LOG2 = 10;       // coarse index over the staged truth keys: one entry per 2^10 keys (64 positions)
-template <int LB>
-__global__ __launch_bounds__(DJ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_join_direct(HashParams P) {
-  constexpr int PER = 16;                                // records per thread at most: four trips of four
-  constexpr int BM_WORDS = LB >= 7 ? (1 << (LB - 5)) : 4;
-  static_assert(HB_MAX_RECORDS <= DJ_THREADS * PER && BM_WORDS % 4 == 0, "table sizes");
-  __shared__ __attribute__((aligned(16))) uint32_t s_bm[BM_WORDS];   // bit v: key kbase + v is a truth key, or (second pass) a kept key outside the truth set
-  __shared__ uint32_t s_tk[DJ_TRUTH_MAX + 2];        // the staged truth keys, sorted (absolute keys); two more so that a look-up may read past its key
-  __shared__ uint16_t s_ci[LB > DJ_CI_LOG2 ? 1 << (LB - DJ_CI_LOG2) : 1];   // per block of 2^DJ_CI_LOG2 keys: index of its first staged truth key (written for blocks that hold one)
-  __shared__ uint32_t s_ts[DJ_TRUTH_MAX];            // per staged key: best bin + 1 of a '.'-ID match
-  __shared__ uint32_t s_tf[DJ_TRUTH_MAX / 32];       // matched by a kept record (ID ignored)
-  __shared__ uint32_t s_htp[130], s_hfp[130];        // TP / FP histograms: slot = bin + 1 (slot 0 swallows records without a bin), two u16 slots per dword
-  __shared__ uint32_t s_hu[128];                     // distinct-truth-key histogram, two u16 bins per dword
-  __shared__ __attribute__((aligned(8))) uint2 s_ring[(DJ_THREADS / 64) * DJ_RING];
-  __shared__ uint32_t s_nk[1 << DJ_NK_LOG2];
-  __shared__ uint32_t s_c[10];                       // kept, TP lines, keyless distinct, matched truth keys, flags, truth bits in range, keyless inserts, top-bin TP, top-bin FP, map bits
-  const int tid = (int)threadIdx.x;
-  const int d = (int)blockIdx.x;
-  const int seg_id = (int)blockIdx.y + P.seg_base;
-  const size_t row = (size_t)seg_id * HB_BUCKETS + (size_t)d;
-#ifdef HB_PROFILE
-  uint32_t* hb_prof = const_cast<uint32_t*>(P.cursor) + (size_t)P.n_seg * HB_BUCKETS * HB_SUBS + (size_t)P.n_seg;
-  unsigned long long hb_t = __builtin_amdgcn_s_memtime();
-  __shared__ uint32_t s_prof[16];
-  if (threadIdx.x < 16) s_prof[threadIdx.x] = 0u;
-#endif
-  const HashRow R = P.rows[row];
-  const uint32_t* cur = P.cursor + row * HB_SUBS;
-  const uint32_t segfl = d == 0 ? P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg_id] : 0u;   // the segment's flags travel in its first row
-  // the map, the truth state and the histograms are cleared while the descriptor and the cursors are on their way (nothing
-  // here depends on them: the whole map of the instantiation, not only the 2^shift bits in use)
-  for (int i = tid; i < BM_WORDS / 4; i += DJ_THREADS) *reinterpret_cast<uint4*>(&s_bm[4 * i]) = make_uint4(0u, 0u, 0u, 0u);
-  s_ts[tid] = 0u; s_ts[tid + DJ_THREADS] = 0u;
-  if (tid < DJ_TRUTH_MAX / 32) s_tf[tid] = 0u;
-  if (tid < 130) { s_htp[tid] = 0u; s_hfp[tid] = 0u; }
-  if (tid < 128) s_hu[tid] = 0u;
-  if (tid < (1 << DJ_NK_LOG2)) s_nk[tid] = HB_EMPTY;
-  typedef unsigned v4u __attribute__((ext_vector_type(4)));
-  typedef const __attribute__((address_space(1))) v4u* gv4p;
-  const gv4p g_ent = (gv4p)R.ent;
-  const gu32p g_tkeys = (gu32p)R.tkeys;
-  const uint32_t cap = R.cap;
-  uint32_t nsub[HB_SUBS];     // wave-uniform (scalar loads)
-  uint32_t nrec = 0, over = 0;
-#pragma unroll
-  for (int k = 0; k < HB_SUBS; ++k) {
-    const uint32_t c = cur[k];
-    over |= c > cap ? 1u : 0u;
-    nsub[k] = c < cap ? c : cap;
-    nrec += nsub[k];
-  }
-  const size_t orow = (size_t)seg_id * (size_t)P.out_stride + (size_t)d;   // where the bucket's row goes (allele-extended batches: the second stream's rows follow)
-  uint32_t* oh = P.row_hist + orow * SPAN_HIST_WORDS;
-  if (nrec == 0u) {   // an empty bucket: a row of zeros, nothing else
-    if (tid < 3 * 128) oh[tid] = 0u;
-    if (tid < 8) P.row_scal[orow * 8 + tid] = tid == 5 ? segfl : 0u;
-    return;
-  }
-  over |= R.shift > (uint32_t)LB ? 1u : 0u;                  // (the host never launches this instantiation for such a segment)
-  const uint32_t shift = R.shift > (uint32_t)LB ? (uint32_t)LB : R.shift;   // 4 <= shift <= LB: a bucket is a whole range of positions
-  const uint32_t kbase = R.kbase;                            // every key of the bucket is >= kbase
-  const uint32_t klast = kbase + ((1u << shift) - 1u);
-  const int tn_all = R.tn;
-  over |= tn_all > DJ_TRUTH_MAX ? 1u : 0u;
-  const int tn = over ? 0 : tn_all;
-  // The threads walk the FILLED part of the bucket's sub-regions, four consecutive entries (32 bytes) of one sub-region at a time:
-  // quad q of the bucket is quad q - qoff[k] of sub-region k.  (The regions are about half full; walking their whole capacity
-  // cost every record two slots' worth of instructions, and this kernel is bound by instruction issue: 71 % VALU busy.)
-  uint32_t qoff[HB_SUBS + 1];   // wave-uniform
-  qoff[0] = 0u;
-#pragma unroll
-  for (int k = 0; k < HB_SUBS; ++k) qoff[k + 1] = qoff[k] + ((nsub[k] + 3u) >> 2);
-  const uint32_t nquads = qoff[HB_SUBS];
-  over |= nquads > (uint32_t)(DJ_THREADS * PER / 4) ? 1u : 0u;   // (a bucket filled to its last entries with ragged sub-regions: the fallback's)
-  const int ntrips_dense = (int)((nquads + DJ_THREADS - 1) / DJ_THREADS) < PER / 4 ? (int)((nquads + DJ_THREADS - 1) / DJ_THREADS) : PER / 4;
-#ifndef DJ_SPARSE_WALK
-  const int ntrips = ntrips_dense;
-#endif
-  // every trip of the thread is in flight before anything else happens: with two workgroups per CU nothing hides a memory
-  // round trip (3 000+ cycles under load), and a workgroup that fetched trip by trip paid one per trip
-  v4u ea[PER / 4], eb[PER / 4];
-  uint32_t nv[PER / 4];      // valid entries of the trip's four
-  const v4u z4 = {0u, 0u, 0u, 0u};
-#ifdef DJ_SPARSE_WALK   // (A/B builds: the walk over the regions' whole capacity)
-  const uint32_t lcap_ = 31u - (uint32_t)__clz(cap);
-  const uint32_t nslots_ = (HB_SUBS * cap) >> 2;
-  const int ntrips_ = (int)((nslots_ + DJ_THREADS - 1) / DJ_THREADS) < PER / 4 ? (int)((nslots_ + DJ_THREADS - 1) / DJ_THREADS) : PER / 4;
-#define ntrips ntrips_
-#endif
-  auto fetch = [&](int g, int buf) {
-#ifdef DJ_SPARSE_WALK
-    const uint32_t slot = (uint32_t)g * DJ_THREADS + (uint32_t)tid;
-    const uint32_t e0 = slot << 2, sb = e0 >> lcap_, w_ = e0 & (cap - 1u);
-    uint32_t n_ = 0;
-#pragma unroll
-    for (int k = 0; k < HB_SUBS; ++k) n_ = sb == (uint32_t)k ? nsub[k] : n_;
-    ea[buf] = z4; eb[buf] = z4; nv[buf] = 0u;
-    if (slot < nslots_ && w_ < n_ && !over) {
-      nv[buf] = n_ - w_ < 4u ? n_ - w_ : 4u;
-      const gv4p src = g_ent + (e0 >> 1);
-      ea[buf] = __builtin_nontemporal_load(src);
-      eb[buf] = __builtin_nontemporal_load(src + 1);
-    }
-    return;
-#endif
-    const uint32_t q = (uint32_t)g * DJ_THREADS + (uint32_t)tid;
-    uint32_t base = 0u, n = nsub[0], reg = 0u;
-#pragma unroll
-    for (int k = 1; k < HB_SUBS; ++k) {
-      const bool ge = q >= qoff[k];
-      base = ge ? qoff[k] : base; n = ge ? nsub[k] : n; reg = ge ? (uint32_t)k * cap : reg;
-    }
-    const uint32_t w = (q - base) << 2;
-    ea[buf] = z4; eb[buf] = z4; nv[buf] = 0u;
-    if (g < ntrips && q < nquads && !over) {
-      nv[buf] = n - w < 4u ? n - w : 4u;
-      const gv4p src = g_ent + ((reg + w) >> 1);   // two entries per 16 bytes
-      ea[buf] = __builtin_nontemporal_load(src);
-      eb[buf] = __builtin_nontemporal_load(src + 1);
-    }
-  };
-  DJ_TICK(1);
-#pragma unroll
-  for (int g = 0; g < PER / 4; ++g) fetch(g, g);   // (trips beyond the bucket's capacity load nothing)
-  uint32_t tkey0 = 0xffffffffu, tkey1 = 0xffffffffu, tprev0 = 0u, tprev1 = 0u;   // (tprev: the key in front, for the coarse index; 0 is below every bucket's first key that matters)
-  if (tid < tn) tkey0 = g_tkeys[tid];
-  if (tid + DJ_THREADS < tn) tkey1 = g_tkeys[tid + DJ_THREADS];
-  if (tid > 0 && tid < tn) tprev0 = g_tkeys[tid - 1];
-  if (tid + DJ_THREADS < tn) tprev1 = g_tkeys[tid + DJ_THREADS - 1];
-  const int nw4 = (int)(((1u << shift) + 127u) >> 7);        // 16-byte pieces of the map in use
-  if (tid < 10) s_c[tid] = tid == 4 ? (segfl | (over ? SPANF_OVERFLOW : 0u)) : 0u;
-  DJ_TICK(2);
-  __syncthreads();
-  DJ_TICK(3);
-  // ---- the truth keys of the bucket's positions: the sorted slice as it is (its keys outside the bucket match nothing), a bit per key inside ----
-  {
-    uint32_t nin = 0;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int j = tid + h * DJ_THREADS;
-      const uint32_t k = h ? tkey1 : tkey0;
-      const bool in = j < tn && k >= kbase && k <= klast;
-      if (j < tn) s_tk[j] = k;
-      if (in) atomicOr(&s_bm[(k - kbase) >> 5], 1u << ((k - kbase) & 31u));
-      {   // the first key of its block of 2^DJ_CI_LOG2 keys names itself in the coarse index (the slice is sorted)
-        const uint32_t kp = h ? tprev1 : tprev0;
-        const bool pin = j > 0 && kp >= kbase;                      // (kp <= k <= klast)
-        if (in && (!pin || ((kp - kbase) >> DJ_CI_LOG2) != ((k - kbase) >> DJ_CI_LOG2))) s_ci[(k - kbase) >> DJ_CI_LOG2] = (uint16_t)j;
-      }
-      nin += (uint32_t)popc64(ballot64(in));
-    }
-    if ((tid & 63) == 0 && nin) atomicAdd(&s_c[5], nin);
-  }
-  DJ_TICK(4);
-  __syncthreads();
-  DJ_TICK(5);
-  const int nb = P.n_bins;
-  int ttop = 0;                                              // largest power of two <= tn
-  if (tn > 0) ttop = 1 << (31 - __clz(tn));
-  uint32_t n_pass = 0, n_tp = 0;
-  uint32_t top_tp = 0, top_fp = 0;                           // per lane: records of the saturated top bin
-  uint32_t vq[PER];          // the thread's keys stay in registers for the second pass
-  uint32_t cand = 0;         // bit k: record k is a kept key outside the truth set (with a comparable key)
-  uint32_t candnk = 0;       // the same without a comparable key
-  unsigned long long* mtp = reinterpret_cast<unsigned long long*>(P.mask_tp);
-  // a record that hit a truth key, or a TP line by the host's decision: truth-entry state and the input-order TP bit
-  auto settle = [&](uint32_t elo, uint32_t ehi) {
-    const uint32_t v = elo & 0xffffffu;
-    const uint32_t inf = (elo >> 24) | ((ehi & 0x1fu) << 8);     // bits 0..11 as in the info word, bit 12 = TP line
-    const uint32_t b1 = inf & I_BIN1;
-    const bool kept = (inf & I_PASS) != 0u;
-    const bool hit = ((s_bm[v >> 5] >> (v & 31u)) & 1u) && !(inf & I_NOKEY);
-    if (hit) {
-      // the key IS among the staged ones: at or behind the first key of its block (most blocks hold one or two)
-      int j = (int)s_ci[v >> DJ_CI_LOG2];
-      {
-        const uint32_t k0 = s_tk[j], k1 = s_tk[j + 1];
-        if (k0 != kbase + v) j = k1 == kbase + v ? j + 1 : lds_lower_bound(s_tk, tn, ttop, kbase + v);
-      }
-      if ((inf & I_IDDOT) && b1) atomicMax(&s_ts[j], b1);
-      if (kept) atomicOr(&s_tf[j >> 5], 1u << (j & 31));
-    }
-#ifndef DJ_NO_TPATOMIC   // (timing builds only: phases of the kernel switched off, results wrong)
-    if (kept && ((hit && (inf & I_IDDOT)) || (inf & 0x1000u))) {
-      const int64_t o = R.src_off + (int64_t)(ehi >> 5);
-      atomicOr(mtp + (o >> 6), 1ull << (o & 63));
-    }
-#endif
-  };
-  if (!(s_c[4] & SPANF_OVERFLOW)) {
-    uint2* ring = s_ring + (tid >> 6) * DJ_RING;
-    const uint32_t lane = (uint32_t)tid & 63u;
-    uint32_t head = 0, tail = 0;                                   // wave-uniform
-    auto drain = [&](uint32_t n) {                                 // the first n <= 64 parked records, one per lane
-#ifndef DJ_NO_DRAIN   // (timing builds only)
-      if (lane < n) {
-        const uint2 e = ring[(head + lane) & (DJ_RING - 1u)];
-        settle(e.x, e.y);
-      }
-#endif
-      head += n;
-    };
-    // the map reads of all the thread's records first, in flight together (as the compiler orders the loop below, every read
-    // would be waited for on the spot: sixteen LDS round trips one after the other)
-    uint32_t hitm = 0, vmask = 0;
-    {
-      uint32_t w[PER];
-#pragma unroll
-      for (int g = 0; g < PER / 4; ++g) {
-        vmask |= ((1u << nv[g]) - 1u) << (4 * g);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint32_t elo_ = u == 0 ? ea[g][0] : u == 1 ? ea[g][2] : u == 2 ? eb[g][0] : eb[g][2];
-          vq[4 * g + u] = elo_ & 0xffffffu;
-          w[4 * g + u] = 0u;
-        }
-        if (g < ntrips) {                                          // wave-uniform
-#pragma unroll
-          for (int u = 0; u < 4; ++u) w[4 * g + u] = s_bm[vq[4 * g + u] >> 5];
-        }
-      }
-#pragma unroll
-      for (int k2 = 0; k2 < PER; ++k2) hitm |= ((w[k2] >> (vq[k2] & 31u)) & 1u) << k2;
-      hitm &= vmask;
-    }
-#pragma unroll
-    for (int g = 0; g < PER / 4; ++g) {
-      if (g < ntrips) {                                            // wave-uniform
-        uint32_t elo[4], ehi[4], mb = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          elo[u] = u == 0 ? ea[g][0] : u == 1 ? ea[g][2] : u == 2 ? eb[g][0] : eb[g][2];
-          ehi[u] = u == 0 ? ea[g][1] : u == 1 ? ea[g][3] : u == 2 ? eb[g][1] : eb[g][3];
-          const uint32_t valid = (vmask >> (4 * g + u)) & 1u;
-          const uint32_t inf = (elo[u] >> 24) | ((ehi[u] & 0x1fu) << 8);
-          const uint32_t keyed = ~(inf >> 11) & 1u;                 // I_NOKEY clear
-          const uint32_t hit = (hitm >> (4 * g + u)) & keyed;
-          const uint32_t kept = (inf >> 9) & valid & 1u;            // every valid entry is a live record
-          const uint32_t tplh = (inf >> 12) & valid & 1u;           // a TP line by the host's decision
-          const uint32_t tpl = (hit & (inf >> 10)) | tplh;
-          const uint32_t b1 = inf & I_BIN1;
-          // ROC histograms; the saturated top bin, where real QUALs pile up, is counted in registers (the lanes of a wave
-          // would serialise on its one address); the empty slots of a trip sit the add out for the same reason
-          const uint32_t top = (b1 == (uint32_t)nb ? 1u : 0u) & valid;
-          top_tp += top & tpl;
-          top_fp += top & ~tpl;
-#ifndef DJ_NO_HIST
-          if (valid & ~top) atomicAdd(tpl ? &s_htp[b1 >> 1] : &s_hfp[b1 >> 1], 1u << (16u * (b1 & 1u)));
-#endif
-          n_pass += kept;
-          n_tp += kept & tpl;
-#ifndef DJ_NO_SETTLE
-          mb |= (hit | (kept & tplh)) << u;
-#endif
-          cand |= (kept & ~hit & keyed) << (4 * g + u);
-          candnk |= (kept & ~hit & ~keyed & 1u) << (4 * g + u);
-        }
-        uint64_t m[4];
-        uint32_t tot = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { m[u] = ballot64((mb >> u) & 1u); tot += (uint32_t)popc64(m[u]); }
-        while (tail - head >= 64u || (tail != head && tail - head + tot > DJ_RING)) drain(tail - head < 64u ? tail - head : 64u);
-        if (tot <= DJ_RING) {                                       // wave-uniform
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if ((mb >> u) & 1u) {
-              const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[u], 0u));
-              ring[(tail + r) & (DJ_RING - 1u)] = make_uint2(elo[u], ehi[u]);
-            }
-            tail += (uint32_t)popc64(m[u]);
-          }
-        } else {                                                    // a VCF that mostly matches: settled where they stand
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if ((mb >> u) & 1u) settle(elo[u], ehi[u]);
-        }
-      }
-    }
-    while (tail != head) drain(tail - head < 64u ? tail - head : 64u);
-  }
-  DJ_TICK(6);
-  __syncthreads();   // every read of a truth bit is done: the map now also takes the kept keys outside the truth set
-#ifndef DJ_NO_PASS2
-#pragma unroll
-  for (int g = 0; g < PER / 4; ++g) {
-    if (g < ntrips) {                                              // wave-uniform
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int k = 4 * g + u;
-        if ((cand >> k) & 1u) atomicOr(&s_bm[vq[k] >> 5], 1u << (vq[k] & 31u));   // no return value: ds_or_b32
-      }
-    }
-  }
-#endif
-  uint32_t fpr_nk = 0;
-  if (ballot64(candnk != 0u)) {   // rare: keyless records are keys of their own, in an exact set, every insertion reserved
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      const bool want = (candnk >> k) & 1u;
-      const uint32_t at = wave_reserve(&s_c[6], want);
-      if (want) {
-        if (at >= (1u << DJ_NK_LOG2) / 2u) { atomicOr(&s_c[4], SPANF_OVERFLOW); }
-        else {
-          bool fresh;
-          (void)hb_insert(s_nk, DJ_NK_LOG2, vq[k], &fresh);
-          fpr_nk += fresh ? 1u : 0u;
-        }
-      }
-    }
-  }
-  // (hipcc turns an LDS atomic add of a per-lane value on ONE address into a serial loop over the 64 lanes -- readlane, add,
-  // next lane: 2 000+ cycles each, a quarter of this workgroup's life when there were five of them; DPP sums instead)
-  n_pass = wave_sum(n_pass); n_tp = wave_sum(n_tp);
-  if (ballot64(fpr_nk != 0u)) fpr_nk = wave_sum(fpr_nk);
-  if (ballot64((top_tp | top_fp) != 0u)) { top_tp = wave_sum(top_tp); top_fp = wave_sum(top_fp); }
-  if ((tid & 63) == 0) {
-    atomicAdd(&s_c[0], n_pass); atomicAdd(&s_c[1], n_tp);
-    if (fpr_nk) atomicAdd(&s_c[2], fpr_nk);
-    if (top_tp) atomicAdd(&s_c[7], top_tp);
-    if (top_fp) atomicAdd(&s_c[8], top_fp);
-  }
-  DJ_TICK(7);
-  __syncthreads();
-  DJ_TICK(8);
-  // ---- bucket epilogue: bits of the map, per-entry state -> U histogram and TP_R, counters, the row ----
-  {
-    uint32_t bits = 0;
-    for (int i = tid; i < nw4; i += DJ_THREADS) {
-      const uint4 w = *reinterpret_cast<const uint4*>(&s_bm[4 * i]);
-      bits += (uint32_t)__popc(w.x) + (uint32_t)__popc(w.y) + (uint32_t)__popc(w.z) + (uint32_t)__popc(w.w);
-    }
-    bits = wave_sum(bits);
-    if ((tid & 63) == 0 && bits) atomicAdd(&s_c[9], bits);
-  }
-  uint32_t tpr = 0;
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int j = tid + h * DJ_THREADS;
-    if (j < tn) {
-      const uint32_t mx = s_ts[j];
-      if (mx) atomicAdd(&s_hu[(mx - 1u) >> 1], 1u << (16u * ((mx - 1u) & 1u)));
-      tpr += (s_tf[j >> 5] >> (j & 31)) & 1u;
-    }
-  }
-  tpr = wave_sum(tpr);
-  if ((tid & 63) == 0 && tpr) atomicAdd(&s_c[3], tpr);
-  DJ_TICK(9);
-  __syncthreads();
-  DJ_TICK(10);
-  if (tid < 128) {
-    const uint32_t ttp = s_c[7], tfp = s_c[8];
-    const int b0 = 2 * tid, b1 = 2 * tid + 1;
-    auto get = [&](const uint32_t* t, int slot) { return (t[slot >> 1] >> (16 * (slot & 1))) & 0xffffu; };
-    oh[tid] = (get(s_htp, 1 + b0) + (b0 == nb - 1 ? ttp : 0u)) | ((get(s_htp, 1 + b1) + (b1 == nb - 1 ? ttp : 0u)) << 16);
-    oh[128 + tid] = (get(s_hfp, 1 + b0) + (b0 == nb - 1 ? tfp : 0u)) | ((get(s_hfp, 1 + b1) + (b1 == nb - 1 ? tfp : 0u)) << 16);
-    oh[256 + tid] = s_hu[tid];
-  }
-  if (tid == 0) {
-    uint32_t* sc = P.row_scal + orow * 8;
-    const uint32_t fl = s_c[4];
-    sc[0] = s_c[0]; sc[1] = s_c[1]; sc[2] = s_c[0] - s_c[1]; sc[3] = s_c[3];
-    sc[4] = s_c[9] - s_c[5] + s_c[2];   // distinct kept keys outside the truth set: bits of the map minus the truth bits, plus the keyless ones
-    sc[5] = fl; sc[6] = 0u; sc[7] = 0u;
-  }
-  DJ_TICK(11);
-  __syncthreads();
-  DJ_FLUSH();
-#ifdef DJ_SPARSE_WALK
-#undef ntrips
-#endif
-}
 
 // ---------------------------------------------------------------------------
 // k_join_lean -- k_join_direct's join of one bucket, rewritten (round 5).
@@ -3238,7 +2597,7 @@ __global__ __launch_bounds__(DJ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
 //     32-bit atomic OR), the exact set.
 //   * Records without a comparable key and host-decided TP lines are rare: a wave that holds one (one OR over its entries'
 //     flag words tells) runs the same pass with two extra masks.
-// Same rows, flags and limits as k_join_direct (QM_JOIN=direct still launches it).
+// (Round 3's k_join_direct, one bit per KEY of a bucket, is kept as text under tools/probe/.)
 // ---------------------------------------------------------------------------
 constexpr int LJ_THREADS = 512;
 constexpr int LJ_SET_LOG2 = 11;      // exact set of the keys on positions claimed more than once, and of the kept records without a comparable key
@@ -3278,12 +2637,6 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
   // empty holds a slot of its CU for a whole memory round trip), k_finalize sums no row of theirs (FinalizeParams.row_cap).
   // Bucket 0 always stays: it carries the segment's flags.
   if (P.seg_maxd && d > 0 && (uint32_t)d >= P.seg_maxd[seg_id]) return;
-#ifdef HB_PROFILE
-  uint32_t* hb_prof = const_cast<uint32_t*>(P.cursor) + (size_t)P.n_seg * HB_BUCKETS * HB_SUBS + (size_t)P.n_seg;
-  unsigned long long hb_t = __builtin_amdgcn_s_memtime();
-  __shared__ uint32_t s_prof[16];
-  if (threadIdx.x < 16) s_prof[threadIdx.x] = 0u;
-#endif
   const HashRow R = P.rows[row];
   const uint32_t* cur = P.cursor + row * HB_SUBS;
   const uint32_t segfl = d == 0 ? P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg_id] : 0u;   // the segment's flags travel in its first row
@@ -3335,24 +2688,10 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
     const uint32_t q = (uint32_t)g * 64u + (uint32_t)lane;
     ea[g] = z4; eb[g] = z4;
     if (4u * q < nw) {
-#ifdef LJ_PLAIN_LOAD
-      ea[g] = wbase[2u * q]; eb[g] = wbase[2u * q + 1u];
-#else
       ea[g] = __builtin_nontemporal_load(wbase + 2u * q);
       eb[g] = __builtin_nontemporal_load(wbase + 2u * q + 1u);
-#endif
     }
   }
-#ifdef LJ_ONLY_LOAD   // (timing builds only: what does it take to get a bucket's entries into registers, and nothing else?)
-  {
-    uint32_t x = 0;
-#pragma unroll
-    for (int g = 0; g < PER / 4; ++g) x ^= ea[g][0] ^ ea[g][1] ^ ea[g][2] ^ ea[g][3] ^ eb[g][0] ^ eb[g][1] ^ eb[g][2] ^ eb[g][3];
-    if (x == 0x12345678u) oh[tid] = x;
-    if (tid < 8) P.row_scal[orow * 8 + tid] = 0u;
-    return;
-  }
-#endif
   uint32_t tkey0 = 0xffffffffu, tkey1 = 0xffffffffu, tprev0 = 0u, tprev1 = 0u;   // (tprev: the key in front, for the coarse index; 0 is below every bucket's first key that matters)
   if (tid < tn) tkey0 = g_tkeys[tid];
   if (tid + LJ_THREADS < tn) tkey1 = g_tkeys[tid + LJ_THREADS];
@@ -3360,9 +2699,7 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
   if (tid + LJ_THREADS < tn) tprev1 = g_tkeys[tid + LJ_THREADS - 1];
   const int nw4 = (int)(((1u << shift) + 1023u) >> 10);      // 16-byte pieces of W in use (64 positions each); S2 has half as many
   if (tid < 8) s_c[tid] = tid == 4 ? (segfl | (over ? SPANF_OVERFLOW : 0u)) : 0u;
-  DJ_TICK(1);
   __syncthreads();
-  DJ_TICK(2);
   // ---- the truth keys of the bucket's positions: the sorted slice as it is (its keys outside the bucket match nothing), a bit per position inside ----
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -3377,9 +2714,7 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
     if (in && (!pin || ((kp - kbase) >> DJ_CI_LOG2) != ((k - kbase) >> DJ_CI_LOG2))) s_ci[(k - kbase) >> DJ_CI_LOG2] = (uint16_t)j;
   }
   if (tid < 2) s_tk[tn + tid] = 0xffffffffu;                 // behind the last staged key: a look-up may read past its key
-  DJ_TICK(3);
   __syncthreads();
-  DJ_TICK(4);
   const uint32_t nb = (uint32_t)P.n_bins;
   int ttop = 0;                                              // largest power of two <= tn
   if (tn > 0) ttop = 1 << (31 - __clz(tn));
@@ -3403,7 +2738,6 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
   uint32_t orall = 0, tplm = 0;
 #pragma unroll
   for (int g = 0; g < PER / 4; ++g) orall |= ea[g][1] | ea[g][3] | eb[g][1] | eb[g][3];
-#ifndef LJ_NO_CAREFUL
   if (ballot64((orall & 0x18u) != 0u)) {
 #pragma unroll
     for (int g = 0; g < PER / 4; ++g) {
@@ -3418,7 +2752,6 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
       }
     }
   }
-#endif
   const bool run = !(s_c[4] & SPANF_OVERFLOW);
   auto pass = [&]() {
 #pragma unroll
@@ -3451,11 +2784,8 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
       }
     }
   };
-  DJ_TICK(5);
   if (run) pass();
-  DJ_TICK(6);
   __syncthreads();   // every kept record has marked its position: S2 says which positions were claimed more than once
-  DJ_TICK(7);
   if (run) {
     // ---- the second look: kept records (with a key) on positions claimed more than once ----
     uint32_t collm = 0;
@@ -3479,9 +2809,7 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
         vmask |= (left >= 4 ? 15u : left <= 0 ? 0u : (1u << left) - 1u) << (4 * g);
       }
     }
-    DJ_TICK(8);
     const uint32_t postm = (((hitm | tplm) & vmask) | (collm & keptm) | nkm);   // on truth positions (a keyless record there settles as no hit), host-decided TP lines, keys to be counted exactly, keyless kept records
-#ifndef LJ_NO_SETTLE
     // ---- one compaction per wave: a prefix sum over the lanes' counts, sixteen masked 8-byte stores; then 64 at a time ----
     uint2* const ring = s_ring + (size_t)wave * LJ_RING;
     uint32_t* const mtp = reinterpret_cast<uint32_t*>(P.mask_tp);
@@ -3549,9 +2877,7 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the ring is read before the next round overwrites it
     }
-#endif
   }
-  DJ_TICK(9);
   // (hipcc turns an LDS atomic add of a per-lane value on ONE address into a serial loop over the 64 lanes: DPP sums instead)
   // one sum for two counts (a wave holds <= 1 024 records: 16 bits each), one for the rarer third
   const uint32_t packed = wave_sum((uint32_t)__popc(keptm | nkm) | (n_tp << 16));
@@ -3577,9 +2903,7 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
     const uint32_t b = wave_sum((uint32_t)bits);
     if (lane == 0 && b) atomicAdd(&s_c[7], b);
   }
-  DJ_TICK(10);
   __syncthreads();
-  DJ_TICK(11);
   uint32_t tpr = 0;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -3610,11 +2934,6 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
     sc[4] = s_c[7] + s_c[2] - s_c[3];   // distinct kept keys outside the truth set: positions claimed once + the exact set's keys, minus those that are truth keys
     sc[5] = fl; sc[6] = 0u; sc[7] = 0u;
   }
-  DJ_TICK(12);
-#ifdef HB_PROFILE
-  __syncthreads();
-#endif
-  DJ_FLUSH();
 }
 
 // ---------------------------------------------------------------------------
@@ -3654,12 +2973,6 @@ __global__ __launch_bounds__(XJ_THREADS) void k_join_ext(HashParams P) {
   const int seg_id = (int)blockIdx.y + P.seg_base;
   const size_t row = (size_t)seg_id * HB_BUCKETS + (size_t)d;
   if (P.seg_maxd && d > 0 && (uint32_t)d >= P.seg_maxd[seg_id]) return;   // no entry of either stream above the segment's highest bucket (k_join_lean)
-#ifdef HB_PROFILE
-  uint32_t* hb_prof = const_cast<uint32_t*>(P.cursor) + (size_t)P.n_seg * HB_BUCKETS * HB_SUBS + (size_t)P.n_seg;
-  unsigned long long hb_t = __builtin_amdgcn_s_memtime();
-  __shared__ uint32_t s_prof[16];
-  if (threadIdx.x < 16) s_prof[threadIdx.x] = 0u;
-#endif
   const HashRowX R = P.xrows[row];
   const uint32_t* cur = P.xcursor + row * HB_SUBS;
   const size_t orow = (size_t)seg_id * (size_t)P.out_stride + (size_t)HB_BUCKETS + (size_t)d;   // the second stream's rows follow the first's
@@ -3727,9 +3040,7 @@ __global__ __launch_bounds__(XJ_THREADS) void k_join_ext(HashParams P) {
     uint32_t k0 = 0, r0 = 0, a0 = 0, k1 = 0, r1 = 0, a1 = 0;
     if (tid < tn) { k0 = gk[tid]; r0 = (uint32_t)gr[tid]; a0 = (uint32_t)ga[tid]; }
     if (tid + XJ_THREADS < tn) { k1 = gk[tid + XJ_THREADS]; r1 = (uint32_t)gr[tid + XJ_THREADS]; a1 = (uint32_t)ga[tid + XJ_THREADS]; }
-    XJ_TICK(1);
     __syncthreads();   // the maps are clear
-    XJ_TICK(2);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int j = tid + h * XJ_THREADS;
@@ -3740,9 +3051,7 @@ __global__ __launch_bounds__(XJ_THREADS) void k_join_ext(HashParams P) {
       }
     }
   }
-  XJ_TICK(3);
   __syncthreads();
-  XJ_TICK(4);
   const int nb = P.n_bins;
   int ttop = 0;
   if (tn > 0) ttop = 1 << (31 - __clz(tn));
@@ -3811,9 +3120,7 @@ __global__ __launch_bounds__(XJ_THREADS) void k_join_ext(HashParams P) {
     }
     if (nring) drain();
   }
-  XJ_TICK(5);
   __syncthreads();
-  XJ_TICK(6);
   // ---- pass 2: histograms and counts (the hit bits are final); kept records outside the truth set claim their position ----
   uint32_t n_pass = 0, n_tp = 0, top_tp = 0, top_fp = 0;
   uint32_t fpm = 0, nkm = 0;   // bit t: the record of trip t is a kept key outside the truth set / the same without a comparable key
@@ -3841,9 +3148,7 @@ __global__ __launch_bounds__(XJ_THREADS) void k_join_ext(HashParams P) {
       nkm |= (kept & ~hit & ~keyed & 1u) << t;
     }
   }
-  XJ_TICK(7);
   __syncthreads();
-  XJ_TICK(8);
   // ---- pass 3: a record alone on its position is a distinct key; the others, and the keyless ones, are listed ----
   uint32_t fpr = 0;
 #pragma unroll
@@ -3867,9 +3172,7 @@ __global__ __launch_bounds__(XJ_THREADS) void k_join_ext(HashParams P) {
     }
     }
   }
-  XJ_TICK(9);
   __syncthreads();
-  XJ_TICK(10);
   {
     const uint32_t m = s_c[6] < (uint32_t)XJ_LIST_MAX ? s_c[6] : (uint32_t)XJ_LIST_MAX;
     for (uint32_t i = (uint32_t)tid; i < m; i += XJ_THREADS) {   // all against all: the first of equal records counts
@@ -3911,11 +3214,6 @@ __global__ __launch_bounds__(XJ_THREADS) void k_join_ext(HashParams P) {
     uint32_t* sc = P.row_scal + orow * 8;
     sc[0] = s_c[0]; sc[1] = s_c[1]; sc[2] = s_c[0] - s_c[1]; sc[3] = s_c[3]; sc[4] = s_c[2]; sc[5] = s_c[4]; sc[6] = 0u; sc[7] = 0u;
   }
-  XJ_TICK(11);
-#ifdef XJ_PROFILE
-  __syncthreads();
-#endif
-  XJ_FLUSH();
 }
 
 // TP bits of the sorted scratch VCFs back to input order: only the records that ARE true positives
@@ -4079,21 +3377,6 @@ void launch_bw_probe(int mode, const uint8_t* src, uint8_t* dst, int64_t bytes, 
   else if (mode == 1) hipLaunchKernelGGL((k_bw_probe<1>), grid, block, 0, st, (const uint4*)src, (uint4*)dst, n16, sink);
   else hipLaunchKernelGGL((k_bw_probe<2>), grid, block, 0, st, (const uint4*)src, (uint4*)dst, n16, sink);
 }
-#ifdef K1_IL_PROBE
-__global__ __launch_bounds__(256) void k_repack_il(const int32_t* pos, const int32_t* ref, const int32_t* alt, const float* qual, const uint8_t* flags, uint8_t* il) {
-  const int64_t r = blockIdx.x;
-  const int t = (int)threadIdx.x;
-  uint8_t* o = il + r * 4352;
-  reinterpret_cast<int32_t*>(o)[t] = pos[r * 256 + t];
-  reinterpret_cast<int32_t*>(o + 1024)[t] = ref[r * 256 + t];
-  reinterpret_cast<int32_t*>(o + 2048)[t] = alt[r * 256 + t];
-  reinterpret_cast<float*>(o + 3072)[t] = qual[r * 256 + t];
-  o[4096 + t] = flags[r * 256 + t];
-}
-void launch_repack_il(const int32_t* pos, const int32_t* ref, const int32_t* alt, const float* qual, const uint8_t* flags, uint8_t* il, int64_t n_rounds, hipStream_t st) {
-  if (n_rounds > 0) hipLaunchKernelGGL(k_repack_il, dim3((unsigned)n_rounds), dim3(256), 0, st, pos, ref, alt, qual, flags, il);
-}
-#endif
 void launch_classify(const ClassifyParams& P, int n_spans, hipStream_t st) {   // spans P.span_base .. + n_spans
   if (n_spans <= 0) return;
   if (P.pkey && P.ext) hipLaunchKernelGGL((k_classify<true, true>), dim3(n_spans), dim3(64), 0, st, P);
@@ -4164,28 +3447,15 @@ void launch_classify_hash(const HashParams& P, int nseg, hipStream_t st) {
 }
 // lb: log2 of the widest bucket key range among the launch's segments (SortSeg.pad), <= DJ_MAX_SHIFT
 // nbk: buckets in use at most among the launch's segments (the grid; buckets above a VCF's highest position hold nothing)
-// which bit-map join launch_join_direct launches: k_join_lean unless QM_JOIN=direct (the host side asks too: the scatter counts
-// the histogram of all records only for k_join_lean)
-bool join_lean_on() {
-  static const bool on = !(getenv("QM_JOIN") && strcmp(getenv("QM_JOIN"), "direct") == 0);
-  return on;
-}
-void launch_join_direct(const HashParams& P, int nseg, int lb, int nbk, hipStream_t st) {
+void launch_join_lean(const HashParams& P, int nseg, int lb, int nbk, hipStream_t st) {
   if (nseg <= 0) return;
-  static const int pad = getenv("QM_DJ_PAD") ? atoi(getenv("QM_DJ_PAD")) : 0;   // experiment: extra (unused) dynamic LDS bounds the workgroups per CU
-  const bool old = !join_lean_on();   // (QM_JOIN=direct: round 3's kernel)
-  if (!old) {
-    if (P.scatter_hist) {
-      if (lb <= 16) hipLaunchKernelGGL((k_join_lean<16, false>), dim3(nbk, nseg), dim3(LJ_THREADS), pad, st, P);
-      else hipLaunchKernelGGL((k_join_lean<DJ_MAX_SHIFT, false>), dim3(nbk, nseg), dim3(LJ_THREADS), pad, st, P);
-    } else {
-      if (lb <= 16) hipLaunchKernelGGL((k_join_lean<16, true>), dim3(nbk, nseg), dim3(LJ_THREADS), pad, st, P);
-      else hipLaunchKernelGGL((k_join_lean<DJ_MAX_SHIFT, true>), dim3(nbk, nseg), dim3(LJ_THREADS), pad, st, P);
-    }
-    return;
+  if (P.scatter_hist) {
+    if (lb <= 16) hipLaunchKernelGGL((k_join_lean<16, false>), dim3(nbk, nseg), dim3(LJ_THREADS), 0, st, P);
+    else hipLaunchKernelGGL((k_join_lean<DJ_MAX_SHIFT, false>), dim3(nbk, nseg), dim3(LJ_THREADS), 0, st, P);
+  } else {
+    if (lb <= 16) hipLaunchKernelGGL((k_join_lean<16, true>), dim3(nbk, nseg), dim3(LJ_THREADS), 0, st, P);
+    else hipLaunchKernelGGL((k_join_lean<DJ_MAX_SHIFT, true>), dim3(nbk, nseg), dim3(LJ_THREADS), 0, st, P);
   }
-  if (lb <= 16) hipLaunchKernelGGL((k_join_direct<16>), dim3(nbk, nseg), dim3(DJ_THREADS), pad, st, P);
-  else hipLaunchKernelGGL((k_join_direct<DJ_MAX_SHIFT>), dim3(nbk, nseg), dim3(DJ_THREADS), pad, st, P);
 }
 void launch_join_ext(const HashParams& P, int nseg, int nbk, hipStream_t st) {
   if (nseg > 0) hipLaunchKernelGGL(k_join_ext, dim3(nbk, nseg), dim3(XJ_THREADS), 0, st, P);

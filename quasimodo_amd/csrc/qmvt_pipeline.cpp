@@ -226,7 +226,6 @@ extern "C" int qm_extract_files_ex(qm_ctx* ctx, int n_jobs, const qm_file_job* j
     std::vector<int64_t> sz((size_t)n_jobs, 0);
     for (int j = 0; j < n_jobs; ++j) { struct stat st; if (stat(jobs[j].vcf_path, &st) == 0) sz[(size_t)j] = (int64_t)st.st_size; total += sz[(size_t)j]; }
     int want = 1;
-    if (const char* e = getenv("QM_FILES_GROUP_MB")) want = (int)std::min<int64_t>(8, std::max<int64_t>(1, total / (std::max<int64_t>(1, atoll(e)) << 20)));
     if (const char* e = getenv("QM_FILES_GROUPS")) want = std::max(1, atoi(e));
     want = std::min(want, n_jobs);
     G.resize((size_t)want);

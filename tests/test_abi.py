@@ -254,3 +254,13 @@ def test_every_knob_the_sources_read_is_named_in_integration_md():
         read |= set(re.findall(r'environ[^\n"]*"(QM_[A-Z0-9_]+)"', open(f).read()))
     missing = sorted(k for k in read if k not in named and not k.startswith("QM_BENCH_"))
     assert not missing, "not named in INTEGRATION.md: %s" % ", ".join(missing)
+    # round 6 cut the library's knobs to those a user or a test needs: the count is part of the contract (<= 20)
+    lib = set()
+    for f in glob.glob(os.path.join(root, "quasimodo_amd", "csrc", "*.[ch]*")):
+        lib |= set(re.findall(r'getenv\("(QM_[A-Z0-9_]+)"\)', open(f, errors="replace").read()))
+    assert len(lib) <= 20, sorted(lib)
+    # ... and the shipped kernels compile ONE way: no ablation / profiling conditionals, only #ifndef defaults of tuning constants
+    ksrc = open(os.path.join(root, "quasimodo_amd", "csrc", "qmvt_kernels.hip")).read()
+    conds = re.findall(r"^#\s*(?:if|ifdef|elif)\b.*$", ksrc, flags=re.M)
+    assert not conds, conds
+    assert ksrc.count("\n") <= 3600 or "k_join_runs" in ksrc, ksrc.count("\n")   # (<= 3 600 lines after the prune; the runs join of round 6 came on top)

@@ -63,8 +63,7 @@ def test_pipelined_ranges_give_the_same_answers(engine, oracle, monkeypatch, chu
     """qm_batch_run works through the batch in a few ranges of VCFs, the compaction of one range on a second stream
     beside the classification of the next.  Forced here on a small ragged batch (the default only splits batches
     that fill the chip several times over), sorted and unsorted VCFs mixed, run twice back to back."""
-    monkeypatch.setenv("QM_PIPE_CHUNKS", str(chunks))
-    monkeypatch.setenv("QM_PIPE_MIN_SPANS", "1")
+    monkeypatch.setenv("QM_PIPE_CHUNKS", str(chunks))      # (a test knob: the ranges asked for, however small the batch)
     rng = np.random.default_rng(500 + chunks)
     L = 90000
     truth = random_truth(rng, 3000, L)
@@ -932,7 +931,7 @@ def test_positions_above_what_the_optimistic_pass_saw(engine, oracle):
     b.close()
 
 
-@pytest.mark.parametrize("knobs", [{}, {"QM_SPECULATE": "0"}, {"QM_FLAGS_WAIT": "stream", "QM_NO_LAZY_FINALIZE": "1"}, {"QM_NO_MIRRORS": "1"}],
+@pytest.mark.parametrize("knobs", [{}, {"QM_SPECULATE": "0"}, {"QM_FLAGS_WAIT": "stream"}, {"QM_NO_MIRRORS": "1"}],
                          ids=["queued", "looked-at", "round-4-waits", "no-host-mapped-mirrors"])
 def test_several_bucket_chunks_in_one_finish_one_of_which_does_not_fit(engine, oracle, monkeypatch, knobs):
     """qm_batch_finish queues the last kernels of a bucket chunk without looking at the chunk's flags first (a round trip through
@@ -1019,17 +1018,3 @@ def test_the_compaction_on_lists_of_every_density(engine, oracle):
         check_vcf(oracle, r, c, truth)
     for r, c in zip(res[len(cols):], shapes):
         check_vcf(oracle, r, c, truth2, expect_sorted=True)
-
-
-def test_columns_in_one_slab_give_the_same_answers(engine, oracle, monkeypatch):
-    """QM_COL_SLAB (DESIGN 4.1's placement probe): the five record columns as pieces of one allocation, shifted against each
-    other -- sorted and shuffled VCFs of ragged sizes against the oracle"""
-    monkeypatch.setenv("QM_COL_SLAB", "1280")
-    rng = np.random.default_rng(4242)
-    L = 60000
-    truth = random_truth(rng, 3000, L)
-    tid = engine.truth_load(*truth)
-    cols = [random_columns(rng, n, L, truth, sorted_=(i % 3 != 2)) for i, n in enumerate([0, 1, 255, 257, 2049, 5000, 16385, 40000])]
-    res, _ = engine.classify_batch(cols, [tid] * len(cols))
-    for r, c in zip(res, cols):
-        check_vcf(oracle, r, c, truth)

@@ -3,7 +3,9 @@
 #   ROUNDS=6 bash tools/ab_median.sh "<tag>=<flags>" ...
 # (the allocation noise of this part is +-3 % from process to process -- DESIGN 5 -- so single draws cannot rank variants that
 # differ by a few per cent)
-S=$GRAFT_REPO_ROOT/quasimodo_amd/csrc
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+GRAFT_REPO_ROOT=$ROOT
+S=$ROOT/quasimodo_amd/csrc
 cd /tmp
 for spec in "$@"; do
   TAG=${spec%%=*}; FLAGS=${spec#*=}

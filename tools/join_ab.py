@@ -27,4 +27,4 @@ dt = (time.time() - t0) / steps
 h = hashlib.sha1()
 for a in (b.roc(), b.scalars(), b.idx(0), b.cls(nv - 1)):
     h.update(np.ascontiguousarray(a).tobytes())
-print("paths", b.path_stats()); print("join=%s %d x %d: %.3f ms per step, %.3e classifications/s, digest %s" % (os.environ.get("QM_JOIN", "direct"), nv, N, dt * 1e3, nv * N / dt, h.hexdigest()[:12]), flush=True)
+print("paths", b.path_stats()); print("join=%s %d x %d: %.3f ms per step, %.3e classifications/s, digest %s" % (os.environ.get("QM_JOIN", "lean"), nv, N, dt * 1e3, nv * N / dt, h.hexdigest()[:12]), flush=True)

@@ -2,6 +2,8 @@
 # the kernels of the LAST step of a command, with start offsets, durations and the gaps in front of them (rocprofv3 --kernel-trace):
 #   bash tools/step_timeline.sh <tag> <first kernel of a step, substring> <command ...>
 TAG=$1; FIRST=$2; shift; shift
+case "$(basename -- "$1")" in env|bash|sh|taskset|numactl) echo "$0: give the program itself (python3 ..., ./bench ...): a launcher in front of it is an exec hop behind the profiler's preloaded library, which this pool forbids; export variables before calling this script" >&2; exit 2;; esac
+mkdir -p gpurun_out
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/tl_$TAG; rm -rf $OUT; mkdir -p $OUT
 (cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $OUT -- "$@" > $OUT/cmd.log 2>&1)
