@@ -74,7 +74,7 @@ struct qm_ctx {
   std::vector<Truth> truths;
   TruthDev* d_truths = nullptr;  // device copy of the descriptors
   int d_truths_cap = 0;
-  int64_t path_total[QM_N_PATH_STATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // qm_path_stats_total: every finish of every batch of this context
+  int64_t path_total[QM_N_PATH_STATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // qm_path_stats_total: every finish of every batch of this context
 };
 
 template <typename T>
@@ -1563,21 +1563,27 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
 // instantiation of the scatter: the first one's tiles fill both), so a 10 Mb genome costs ONE read of the columns, four partitions
 // two; nothing else is new -- bucket rows, the two joins, the rows per segment and their sum per VCF are the one-level and
 // two-level paths'.
-constexpr int PX_MAX_PARTS = 4;
+constexpr int PX_MAX_PARTS = 8;        // default mode: one group of up to eight partitions (the 2 048-digit scatter); allele-extended: pairs, four partitions
+constexpr int PX_MAX_PARTS_EXT = 4;
 static int ext_parts_of(uint32_t posor) { return (int)((((uint64_t)posor << 4) | 15u) >> P2_SHIFT) + 1; }
 static bool bucketx_takes(const qm_batch* b, int64_t n, uint32_t posor) {
   if (b->ext && g_penv.bucket_ext == 0) return false;
   if (g_penv.radix_only) return false;
   if (join_hash_forced()) return false;
-  if (n < HB_MIN_RECORDS || n > ((int64_t)1 << HB_INDEX_BITS)) return false;
+  if (n < HB_MIN_RECORDS || n > ((int64_t)1 << (b->ext ? HB_INDEX_BITS : 26))) return false;   // (the second stream's entries hold 21 index bits, the first stream's 26)
   const int parts = ext_parts_of(posor);
-  if (parts > PX_MAX_PARTS) return false;
+  if (parts > (b->ext ? PX_MAX_PARTS_EXT : PX_MAX_PARTS)) return false;
   if (g_penv.bucketx == 0) return false;
-  if (g_penv.bucketx == 2) return true;   // 2: every unsorted VCF that fits (tests, fuzz)
+  if (g_penv.bucketx >= 2) return true;   // 2: every unsorted VCF that fits (tests, fuzz); 3: ... default-mode ones through the 2 048-digit scatter whatever their width
   if (b->ext) return parts > 1 || !bucket_path_takes(b, n);
   // default mode: a reference of 8.4 ... 16.8 M positions is ONE pair of partitions = one pass of the 512-digit scatter and the
   // bit-map join, where the one-level path would need the hashed join (bucket key ranges of 2^20) and larger VCFs two levels
-  return parts == 2;
+  if (parts == 2) return true;
+  // ... and up to eight partitions (67 M positions) are one pass of the 2 048-digit scatter, where the two-level path moves every
+  // record twice (round 6: configs[3]'s 10 M records on 50 Mb).  Worth it when the buckets are reasonably full -- every bucket costs
+  // its join a workgroup and two bit maps whatever it holds -- and they must not be fuller than their eight sub-regions take.
+  const int64_t buckets = ((((int64_t)posor << 4) | 15) >> DJ_MAX_SHIFT) + 1;
+  return parts >= 3 && n >= buckets * 1024 && n <= buckets * (HB_MAX_RECORDS * 13 / 16);
 }
 
 static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, const std::vector<uint32_t>& posor, bool* taken) {
@@ -1590,6 +1596,9 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   int64_t nbt = b->lastx_nbt, nkt = b->lastx_nkt;
   const bool xs = b->ext;                                  // two entry streams (allele-extended batches)
   const int out_stride = xs ? 2 * HB_BUCKETS : HB_BUCKETS;
+  int maxparts = 1;
+  for (int i = 0; i < nv; ++i) maxparts = std::max(maxparts, ext_parts_of(por[(size_t)i]));
+  const int G = !xs && (maxparts > 2 || g_penv.bucketx == 3) ? 8 : 2;   // partitions per pass over the columns
   if (!same) {
   nbt = 0; nkt = 0;
   std::vector<SortSeg> segs, vsegs((size_t)nv);
@@ -1606,11 +1615,13 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
       memset(&g, 0, sizeof g);
       g.src_off = d.off; g.n = d.n; g.main_vcf = vs[(size_t)i]; g.sub_vcf = i; g.main_tile0 = d.tile0;
       g.pad = DJ_MAX_SHIFT; g.key_base = (uint32_t)p << P2_SHIFT;
-      // two neighbouring partitions share ONE pass over the columns: the tiles belong to the first of the pair, whose 512 digits
-      // reach into the second one's cursors, regions and rows (same capacity, laid out one behind the other)
-      const bool lead = (p & 1) == 0 && p + 1 < parts, follow = (p & 1) == 1;
-      const bool pair_last = lead ? p + 2 == parts : p + 1 == parts;
-      g.part = (pair_last ? 2 : 1) | (lead ? 4 : 0);
+      // neighbouring partitions share ONE pass over the columns: the tiles belong to the first of the group (two partitions with
+      // the 512-digit scatter, up to eight with the 2 048-digit one), whose digits reach into the others' cursors, regions and rows
+      // (same capacity, laid out one behind the other)
+      const int gfirst = p / G * G, gsize = std::min(G, parts - gfirst);
+      const bool lead = p == gfirst && gsize > 1, follow = p != gfirst;
+      const bool pair_last = gfirst + gsize == parts;
+      g.part = (pair_last ? 2 : 1) | (lead ? 4 | (gsize << 4) : 0);
       g.nbk = p + 1 == parts ? std::min<int>(HB_BUCKETS, (int)((kor - g.key_base) >> DJ_MAX_SHIFT) + 1) : HB_BUCKETS;
       int64_t want = d.n / (128 * HB_SUBS) * 3 / 2 + 16, cap2 = 16;   // (how the records spread over the partitions is not known: room as for all of them)
       while (cap2 < want && cap2 < HB_SUB_MAX) cap2 *= 2;
@@ -1685,7 +1696,7 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   S.segs = b->d_segs; S.tile_seg = b->d_bk_tile_seg; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
   S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
   S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = nullptr; S.xent = xs ? b->bk_xent : nullptr; S.xcursor = xs ? b->bk_xcursor : nullptr; S.ext = xs ? 1 : 0;
-  S.pairs = 1;   // (tiles of single partitions run through the 512-digit instantiation as well)
+  S.pairs = G == 8 ? 2 : 1;   // (tiles of single partitions run through the same instantiation as well)
   uint32_t* const seg_hist = b->bk_cursor + nhist0;
   uint32_t* const seg_maxd = nullptr;   // (the look at the highest filled bucket was measured on this path and lost: 2.08 against 2.02 ms per 64 x 2 M)
   S.seg_hist = seg_hist; S.seg_maxd = seg_maxd; S.l1_half = nullptr;
@@ -1714,7 +1725,7 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   launch_sort_copy_rows(b->d_vsegs, nv, b->bk_roc, b->bk_rscal, b->roc, b->scalars, b->n_bins, st, global, b->d_vcfs, b->d_vparts);
   launch_tile_counts(b->d_vsegs, b->d_ktile_seg, b->d_ktile_local, (int)nkt, b->mask_pass, b->mask_tp, b->tile_tp, b->tile_fp, st);
   HIPCHK(hipGetLastError());
-  b->path_stats[QM_PATH_DIRECT2] += nv;
+  b->path_stats[QM_PATH_PARTITIONS] += nv;
   *taken = true;
   return QM_OK;
 }

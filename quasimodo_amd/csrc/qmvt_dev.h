@@ -187,7 +187,8 @@ struct SortSeg {
   int32_t part;              // one-level scatter over a PARTITION of a VCF's key range, read from the columns (allele-extended VCFs too
                              // large or too wide for 256 buckets): 0 = the whole VCF; 1 = keys outside [key_base, key_base + 256 << pad)
                              // belong to another segment of the same VCF; 2 = the VCF's last partition: keys above it flag the VCF;
-                             // + 4: the segment's tiles fill the buckets of the NEXT segment too (two partitions, 512 buckets, one read)
+                             // + 4: the segment's tiles fill the buckets of the segments that FOLLOW it too (bits 4..7: partitions of the group,
+                             //      itself included: 2 with the 512-digit scatter, up to 8 with the 2 048-digit one -- one read of the columns)
 };
 // bucket path (k_bucket_scatter + k_classify_hash): one workgroup per (segment, bucket of the one scatter pass)
 #ifndef QM_BK_TILE

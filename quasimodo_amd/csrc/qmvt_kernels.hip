@@ -1745,20 +1745,25 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
 // EXT (allele-extended batches): every record with valid allele codes is live; those whose REF / ALT are not two single bases
 // leave in a second stream of 16-byte entries (the ordinary entry with the position's first key, then the two codes), written
 // straight to their bucket's second region -- k_join_ext joins them exactly, k_join_direct the single-base ones.
-// NB = 512 (allele-extended VCFs in partitions, SortSeg.part & 4): the tile's segment stands for TWO neighbouring partitions of its
-// VCF -- 512 buckets whose cursors, regions and rows lie one behind the other -- so that the columns are read once for both.
+// NB = 512 / 2048 (VCFs in partitions, SortSeg.part & 4): the tile's segment stands for the two / up to eight neighbouring partitions
+// of its VCF that follow it -- 512 ... 2 048 buckets whose cursors, regions and rows lie one behind the other -- so that the columns
+// are read ONCE for all of them (2 048: default-mode VCFs of up to 67 M positions, e.g. configs[3]'s 10 M records on 50 Mb, which
+// took a level-1 scatter of their own through round 5).  A thread then scans NB / 512 digits; the pieces a tile writes per bucket
+// are a few entries long, and it is the XCD's L2 that makes whole lines of them (a sub-region is filled by one XCD).
 template <bool L2, bool EXT, int NB = 256>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : BK_WAVES_PER_EU, 8))) void k_bucket_scatter(BucketScatterParams P) {
   constexpr int PER = BK_TILE / 512;          // records per thread, in groups of four consecutive ones
   static_assert(BK_TILE % 2048 == 0 && PER >= 4, "whole 16-byte loads, 256 records per wave and group");
-  static_assert(NB == 256 || (NB == 512 && !L2), "one digit per thread at most");
+  static_assert(NB == 256 || (NB == 512 && !L2) || (NB == 2048 && !L2 && !EXT), "instantiations");
+  constexpr int DPT = NB > 512 ? NB / 512 : 1;   // digits per thread of the scan
+  constexpr int NDT = NB / DPT;                  // threads that scan: 256, 512, 512
   typedef typename std::conditional<NB == 256, uint8_t, uint16_t>::type digit_t;
   __shared__ uint32_t s_cnt[NB];              // records of digit d in the tile (running during the ranking)
   __shared__ uint32_t s_loc[NB];              // tile-local start of digit d's run
   __shared__ int32_t s_glob[NB];              // place of digit d's run in its sub-region, minus s_loc[d]
   __shared__ uint32_t s_scan[NB / 64 + 1];
-  __shared__ __attribute__((aligned(16))) uint64_t s_e[BK_TILE + NB];   // (+ NB: a run of odd length is padded to an even one, see below)
-  __shared__ digit_t s_d[BK_TILE + NB];
+  __shared__ __attribute__((aligned(16))) uint64_t s_e[BK_TILE];
+  __shared__ digit_t s_d[BK_TILE];
   __shared__ uint32_t s_cntx[EXT ? NB : 1];      // second stream: records of digit d in the tile, then where its run starts in the sub-region
   __shared__ uint32_t s_flut[16];                // flag_info of the sixteen flag nibbles (pack_record_fast)
   __shared__ uint32_t s_hall[NB / 256][SEG_HIST_WORDS];   // (P.seg_hist) the tile's first-stream entries by bin + 1, per segment the tile fills
@@ -1767,18 +1772,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   const SortSeg sg = P.segs[seg];
   const int sub = bid & (HB_SUBS - 1);
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < NB) { s_cnt[tid] = 0u; if (EXT) s_cntx[tid] = 0u; }
+  for (int d = tid; d < NB; d += 512) { s_cnt[d] = 0u; if (EXT) s_cntx[d] = 0u; }
   const bool count_all = P.seg_hist != nullptr;
   if (count_all) for (int i = tid; i < (NB / 256) * SEG_HIST_WORDS; i += 512) (&s_hall[0][0])[i] = 0u;
   uint32_t top_all = 0, top_all2 = 0;            // records of the saturated top bin (the lanes of a wave would serialise on its one address)
   const uint32_t nbins = (uint32_t)P.n_bins;
   // one first-stream entry by bin + 1 (b1 <= n_bins <= 256); digit >= 256: the entry belongs to the next segment (NB = 512)
   auto count = [&](uint32_t b1, uint32_t d) {
+    if (NB > 512) { atomicAdd(&s_hall[d >> 8][b1], 1u); return; }   // (the top bin too: a counter in registers per partition would not pay)
     if (NB == 512 && d >= 256u) { if (b1 == nbins) ++top_all2; else atomicAdd(&s_hall[NB / 256 - 1][b1], 1u); }
     else { if (b1 == nbins) ++top_all; else atomicAdd(&s_hall[0][b1], 1u); }
   };
   if (!L2 && tid >= 256 && tid < 272) s_flut[tid - 256] = flag_info((uint32_t)(tid - 256));
-  const uint32_t dlim = NB == 512 && (sg.part & 4) ? 512u : (uint32_t)HB_BUCKETS;   // buckets this tile's segment stands for
+  const uint32_t dlim = NB >= 512 && (sg.part & 4) ? (uint32_t)HB_BUCKETS * (uint32_t)((sg.part >> 4) & 15) : (uint32_t)HB_BUCKETS;   // buckets this tile's segment stands for (part bits 4..7: partitions of its group)
   // a whole VCF in one segment (part 0): the host joins and sums only the sg.nbk buckets up to the highest position the optimistic
   // pass SAW -- and that pass leaves a span at its first round out of order, so later records can hold higher positions: a record
   // beyond the estimate flags the VCF (the radix sort redoes it) instead of landing in a bucket nobody looks at
@@ -1897,7 +1903,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
     if (NB == 512 && ballot64(top_all2 != 0u)) { top_all2 = wave_sum(top_all2); if (lane == 0) atomicAdd(&s_hall[NB / 256 - 1][nbins], top_all2); }
   }
   __syncthreads();
-  if (P.seg_maxd && tid < NB) {   // 1 + the highest bucket this tile fills, per wave: one atomic each
+  if (NB <= 512 && P.seg_maxd && tid < NB) {   // 1 + the highest bucket this tile fills, per wave: one atomic each
     uint32_t m = (s_cnt[tid] || (EXT && s_cntx[tid])) ? (uint32_t)(tid & 255) + 1u : 0u;   // (either stream)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)m, o); m = y > m ? y : m; }
@@ -1920,10 +1926,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   // every join (tests, 800 fuzz rounds), and the step takes 2.639 / 2.642 ms against 2.631 / 2.635 without (same box,
   // profiles/r05_scatter_pairs_ab.log): the pads are 1.9 % more entries to write and to join, which eats what the
   // instructions save.
-  uint32_t cnt = 0, incl = 0, cnt_odd = 0;
-  if (tid < NB) {
-    cnt = s_cnt[tid];
-    cnt += cnt_odd;
+  uint32_t cnt = 0, incl = 0;          // (DPT = 1: the thread's one digit)
+  uint32_t cntk[DPT], lock[DPT], gk[DPT];
+#pragma unroll
+  for (int k = 0; k < DPT; ++k) { cntk[k] = 0u; lock[k] = 0u; gk[k] = 0u; }
+  if (tid < NDT) {
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) { cntk[k] = s_cnt[tid * DPT + k]; cnt += cntk[k]; }
     incl = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -1934,20 +1943,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   }
   __syncthreads();
   // The room for the runs is asked for (one returning atomic per digit in use) and not waited for: reordering the tile in LDS
-  // needs the tile-local run starts only, so the cursors' round trip (5 000 of a workgroup's 42 000 cycles by its phase clocks,
-  // -DHB_PROFILE -DBKS_PROFILE) passes behind it.  (Same-box A/B against waiting on the spot: 1.39 ms either way -- the kernel is
-  // bound by what the memory system does with its mix of streamed reads and scattered 100-byte writes, not by any wait of its own.)
+  // needs the tile-local run starts only, so the cursors' round trip passes behind it.
   uint32_t g = 0, loc = 0;
   uint32_t cntx2 = 0, gx2 = 0;   // NB = 512: the thread of digit d reserves for both streams
-  if (tid < NB) {
+  if (tid < NDT) {
     uint32_t woff = 0;
 #pragma unroll
-    for (int w = 0; w < NB / 64 - 1; ++w) woff += w < wave ? s_scan[w] : 0u;
+    for (int w = 0; w < NDT / 64 - 1; ++w) woff += w < wave ? s_scan[w] : 0u;
     loc = woff + incl - cnt;
-    s_loc[tid] = loc;
-    if (cnt) g = atomicAdd(&P.cursor[((size_t)seg * HB_BUCKETS + tid) * HB_SUBS + sub], cnt);   // (digits 256..511: the next partition's cursors follow)
-    if (tid == NB - 1) s_scan[NB / 64] = loc + cnt;
-    if (cnt_odd) { s_e[loc + cnt - 1u] = 0ull; s_d[loc + cnt - 1u] = (digit_t)tid; }   // the pad (the ranks of the run's records end below it)
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) {
+      const int d = tid * DPT + k;
+      lock[k] = loc; loc += cntk[k];
+      s_loc[d] = lock[k];
+      if (cntk[k]) gk[k] = atomicAdd(&P.cursor[((size_t)seg * HB_BUCKETS + d) * HB_SUBS + sub], cntk[k]);   // (digits 256 and above: the next partitions' cursors follow)
+    }
+    g = gk[0];
+    if (tid == NDT - 1) s_scan[NB / 64] = loc;
     if (EXT && NB == 512) {
       cntx2 = s_cntx[tid];
       if (cntx2) gx2 = atomicAdd(&P.xcursor[((size_t)seg * HB_BUCKETS + tid) * HB_SUBS + sub], cntx2);
@@ -1966,10 +1978,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
       s_d[lp] = (digit_t)d;
     }
   }
-  if (tid < NB || EXT) {
-    if (cnt && g + cnt > (uint32_t)sg.bk_cap) atomicOr(&P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg], SPANF_OVERFLOW);
-    if (tid < NB) s_glob[tid] = (int32_t)g - (int32_t)loc;
-    else s_cntx[tid - 256] = g;
+  if (tid < NDT || EXT) {
+    if (tid < NDT) {
+#pragma unroll
+      for (int k = 0; k < DPT; ++k) {
+        if (cntk[k] && gk[k] + cntk[k] > (uint32_t)sg.bk_cap) atomicOr(&P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg], SPANF_OVERFLOW);
+        s_glob[tid * DPT + k] = (int32_t)gk[k] - (int32_t)lock[k];
+      }
+    } else {
+      if (cnt && g + cnt > (uint32_t)sg.bk_cap) atomicOr(&P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg], SPANF_OVERFLOW);
+      s_cntx[tid - 256] = g;
+    }
     if (EXT && NB == 512) {
       if (cntx2 && gx2 + cntx2 > (uint32_t)sg.bk_cap) atomicOr(&P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg], SPANF_OVERFLOW);
       s_cntx[tid] = gx2;
@@ -3467,6 +3486,7 @@ void launch_bucket_scatter(const BucketScatterParams& P, int ntiles, hipStream_t
   if (ntiles <= 0) return;
   if (P.l1_ent) hipLaunchKernelGGL((k_bucket_scatter<true, false>), dim3(ntiles), dim3(512), 0, st, P);
   else if (P.ext && P.pairs) hipLaunchKernelGGL((k_bucket_scatter<false, true, 512>), dim3(ntiles), dim3(512), 0, st, P);
+  else if (P.pairs == 2) hipLaunchKernelGGL((k_bucket_scatter<false, false, 2048>), dim3(ntiles), dim3(512), 0, st, P);   // groups of up to eight partitions
   else if (P.pairs) hipLaunchKernelGGL((k_bucket_scatter<false, false, 512>), dim3(ntiles), dim3(512), 0, st, P);
   else if (P.ext) hipLaunchKernelGGL((k_bucket_scatter<false, true>), dim3(ntiles), dim3(512), 0, st, P);
   else hipLaunchKernelGGL((k_bucket_scatter<false, false>), dim3(ntiles), dim3(512), 0, st, P);

@@ -296,7 +296,7 @@ def test_alleles_mode_unsorted_vcfs_of_configs4_shape_take_partitions_of_buckets
             b.run(); b.finish()
             if shuffled:
                 ps = b.path_stats()
-                assert ps["unsorted"] == nv and ps["bucket_two_level"] == nv and ps["radix"] == 0 and ps["radix_after_overflow"] == 0, ps
+                assert ps["unsorted"] == nv and ps["bucket_partitions"] == nv and ps["radix"] == 0 and ps["radix_after_overflow"] == 0, ps
         rows[shuffled] = (b.roc(), b.scalars()[:, :5].copy(), b.global_counts())
         if shuffled:
             cols = b.columns(1)

@@ -268,10 +268,15 @@ def test_synthetic_batch_vs_oracle(engine, oracle, shuffled):
     b.close()
 
 
-def test_config4_shape_ten_million_record_vcfs(engine, oracle):
+@pytest.mark.parametrize("two_level", [False, True])
+def test_config3_shape_ten_million_record_vcfs(engine, oracle, monkeypatch, two_level):
     """BASELINE configs[3] shape per VCF: 10 M records on a 50 Mb reference, 1 M truth keys (611 spans,
-    9 766 tiles per VCF), sorted and shuffled, against the oracle."""
+    9 766 tiles per VCF), sorted and shuffled, against the oracle.  Shuffled, such a VCF is six partitions of 2^27 keys: ONE pass
+    of the 2 048-digit scatter over its columns since round 6 (`bucket_partitions`), a level-1 scatter and a second one from its
+    entries before (`bucket_two_level`, still there behind QM_BUCKETX=0 and for wider references)."""
     from oracle.synth import synth_truth_keys
+    if two_level:
+        monkeypatch.setenv("QM_BUCKETX", "0")
     L, N, T = 50_000_000, 10_000_000, 1_000_000
     tid = engine.truth_synth(L, T, 4)
     tk = synth_truth_keys(L, T, 4)
@@ -280,6 +285,10 @@ def test_config4_shape_ten_million_record_vcfs(engine, oracle):
         b.synth(L, T, 4, 4000, shuffled=shuffled)
         b.run()
         b.finish()
+        if shuffled:
+            ps = b.path_stats()
+            assert ps["unsorted"] == 2 and ps["radix"] == 0 and ps["radix_after_overflow"] == 0, ps
+            assert (ps["bucket_two_level"], ps["bucket_partitions"]) == ((2, 0) if two_level else (0, 2)), ps
         roc, scal = b.roc(), b.scalars()
         for v in range(2):
             cols = b.columns(v)
@@ -878,7 +887,7 @@ def test_unsorted_vcfs_on_a_reference_of_ten_million_positions_take_a_pair_of_pa
         rows[shuffled] = (b.roc(), b.scalars()[:, :5].copy(), b.global_counts())
         if shuffled:
             ps = b.path_stats()
-            assert ps["unsorted"] == 3 and ps["bucket_two_level"] == 3 and ps["bucket_hashed"] == 0 and ps["radix"] == 0, ps
+            assert ps["unsorted"] == 3 and ps["bucket_partitions"] == 3 and ps["bucket_two_level"] == 0 and ps["bucket_hashed"] == 0 and ps["radix"] == 0, ps
             cls, oroc, sc = oracle.classify_columns(*b.columns(2), *synth_truth_keys(L, T, 9))
             assert np.array_equal(b.cls(2), cls) and np.array_equal(rows[True][0][2], oroc)
         b.close()
