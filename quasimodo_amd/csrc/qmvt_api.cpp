@@ -1751,7 +1751,8 @@ static int redo_unsorted(qm_batch* b, const std::vector<int>& todo, const std::v
     std::vector<int> chunk;
     int64_t chunk_n = 0;
     for (size_t i = 0; i <= part[kind].size(); ++i) {
-      const int64_t wgt = i < part[kind].size() ? b->L.vcfs[(size_t)part[kind][i]].n * (kind == 3 ? ext_parts_of(posor[(size_t)part[kind][i]]) : 1) : 0;   // (a partition reads its whole VCF)
+      // (kind 3: every GROUP of partitions -- two of an allele-extended VCF, up to eight otherwise -- reads its whole VCF)
+      const int64_t wgt = i < part[kind].size() ? b->L.vcfs[(size_t)part[kind][i]].n * (kind == 3 ? (ext_parts_of(posor[(size_t)part[kind][i]]) + (b->ext ? 1 : 7)) / (b->ext ? 2 : 8) : 1) : 0;
       const bool flush = i == part[kind].size() || (!chunk.empty() && chunk_n + wgt > chunk_records) ||
                          (kind >= 1 && chunk.size() >= (size_t)(kind == 3 ? 4096 / PX_MAX_PARTS : 4096));   // 256 rows of 1.5 KB and >= 1 MB of bucket regions per VCF: bounded per chunk
       if (flush && !chunk.empty()) {

@@ -1981,10 +1981,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   if (tid < NDT || EXT) {
     if (tid < NDT) {
 #pragma unroll
-      for (int k = 0; k < DPT; ++k) {
-        if (cntk[k] && gk[k] + cntk[k] > (uint32_t)sg.bk_cap) atomicOr(&P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg], SPANF_OVERFLOW);
-        s_glob[tid * DPT + k] = (int32_t)gk[k] - (int32_t)lock[k];
-      }
+      for (int k = 0; k < DPT; ++k) s_glob[tid * DPT + k] = (int32_t)gk[k] - (int32_t)lock[k];   // (a run that does not fit its sub-region: below)
     } else {
       if (cnt && g + cnt > (uint32_t)sg.bk_cap) atomicOr(&P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg], SPANF_OVERFLOW);
       s_cntx[tid - 256] = g;
@@ -2017,7 +2014,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   for (int idx = tid; idx < total; idx += 512) {
     const uint32_t d = s_d[idx];
     const int32_t w = s_glob[d] + idx;
-    if (w < sg.bk_cap) out[((size_t)d * HB_SUBS + sub) * (size_t)sg.bk_cap + (size_t)w] = s_e[idx];   // beyond: the VCF is flagged and redone
+    if (w < sg.bk_cap) out[((size_t)d * HB_SUBS + sub) * (size_t)sg.bk_cap + (size_t)w] = s_e[idx];   // beyond: spilled below
+  }
+  // A run that does not fit its sub-region SPILLS into the bucket's other seven (round 6).  A sub-region takes every eighth tile:
+  // even for shuffled records, but a VCF sorted per contig sends a bucket a few LONG pieces -- one per contig -- and three of them
+  // on one sub-region were an overflow that sent the whole chunk to the radix sort (2e10 /s instead of 1e11).  The part of the run
+  // that lies below the sub-region's capacity is stored above (every slot below min(cursor, capacity) is somebody's: the joins clamp
+  // the cursor and no longer read one above the capacity as an overflow); the rest asks the next sub-regions for room, one atomic
+  // each, and its owner thread stores it there itself.  Only a run that finds no room in any of the eight flags the VCF.
+  if (tid < NDT) {
+    const uint32_t cap = (uint32_t)sg.bk_cap;
+#pragma unroll
+    for (int k = 0; k < DPT; ++k) {
+      if (cntk[k] && gk[k] + cntk[k] > cap) {
+        const uint32_t d = (uint32_t)(tid * DPT + k);
+        uint32_t done = gk[k] < cap ? cap - gk[k] : 0u;           // entries of the run stored by the loop above
+        for (int hop = 1; hop < HB_SUBS && done < cntk[k]; ++hop) {
+          const int s2 = (sub + hop) & (HB_SUBS - 1);
+          const uint32_t rest = cntk[k] - done;
+          const uint32_t g2 = atomicAdd(&P.cursor[((size_t)seg * HB_BUCKETS + d) * HB_SUBS + s2], rest);
+          const uint32_t take = g2 < cap ? (rest < cap - g2 ? rest : cap - g2) : 0u;
+          uint64_t* o2 = out + ((size_t)d * HB_SUBS + s2) * (size_t)cap + (size_t)g2;
+          for (uint32_t j = 0; j < take; ++j) o2[j] = s_e[lock[k] + done + j];
+          done += take;
+        }
+        if (done < cntk[k]) atomicOr(&P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg], SPANF_OVERFLOW);   // the bucket itself is full: the radix sort redoes the VCF
+      }
+    }
   }
 }
 
@@ -2312,7 +2335,6 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
 #pragma unroll
   for (int k = 0; k < HB_SUBS; ++k) {
     const uint32_t c = cur[k];
-    over |= c > cap ? 1u : 0u;
     nsub[k] = c < cap ? c : cap;
     nrec += nsub[k];
   }
@@ -2676,7 +2698,6 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
 #pragma unroll
   for (int k = 0; k < HB_SUBS; ++k) {
     const uint32_t c = cur[k];
-    over |= c > cap ? 1u : 0u;
     const uint32_t n = c < cap ? c : cap;
     nrec += n;
     nw = wave == k ? n : nw;
