@@ -298,8 +298,9 @@ int qm_fp_overlap(qm_ctx* ctx, int n_sets, const int64_t* set_offsets, const int
 #define QM_LINE_HEADER_KEPT 3   /* '#' line that also satisfies the A2 filter: awk does not skip it, so the reference
                                    emits it in the header block AND among the kept lines (and then in tp or fp) */
 #define QM_LINE_HEADER_KEPT_TP 4 /* the same once qm_vcf_hostpath found it selected by fgrep -wf */
-#define QM_LINE_REFUSED 5       /* kept data line holding NUL or bytes >= 0x80: the reference's answer depends on the
-                                   locale Python exports to grep (PEP 538); strict callers stop with QM_E_NONCANON */
+#define QM_LINE_REFUSED 5       /* kept data line holding a NUL or an INVALID UTF-8 sequence: grep answers "binary file matches" under the
+                                   locale Python exports to it (PEP 538); strict callers stop with QM_E_NONCANON.  Valid UTF-8 is text: such
+                                   a single-base line is QM_LINE_DATA_HOST (word characters by iswalnum on C.UTF-8, as grep -w asks) */
 #define QM_LINE_HEADER_REFUSED 6 /* the same for a '#' line that satisfies the A2 filter */
 typedef struct qm_vcf_cols {
   int64_t n_lines;      /* all lines */
@@ -326,7 +327,7 @@ int qm_vcf_scan(const uint8_t* text, size_t len, int64_t cap_lines, int64_t* lin
  * out_counts[0] = rows R counts as `genomediff`, [1] = keys emitted (rows that are not comments, with a
  * canonical position and single-base alleles: the only patterns a line can match through its columns),
  * [2] = rows whose pattern can match no such line (they live in qm_patterns only), [3] = rows refused
- * (NUL / non-ASCII bytes), [4] = '#' rows that awk turns into a pattern all the same. */
+ * (always 0 since round 6: a canonical pattern is ASCII, the row's other columns never reach it), [4] = '#' rows that awk turns into a pattern all the same. */
 int64_t qm_truth_scan(const uint8_t* text, size_t len, int mode, int64_t cap, int32_t* pos, int32_t* ref,
                       int32_t* alt, int64_t* out_counts /*[5]*/);
 /* Allele-extended tokenising (QM_BATCH_ALLELES): the filter's `^[ACGT]$` becomes `^[ACGT]+$`, ref / alt
@@ -351,7 +352,7 @@ int64_t qm_truth_scan_ext(const uint8_t* text, size_t len, int mode, int64_t cap
  * TEXT: one pattern X \t . \t Y \t Z per truth row that satisfies the awk program, '#' rows included.  mode as
  * qm_truth_scan; ext != 0 widens `^[ACGT]$` to `^[ACGT]+$` (allele-extended mode, mode 0 only).
  * info[0] = distinct patterns, [1] = patterns whose Y / Z are not one character each, [2] = canonical keys that only
- * '#' rows carry (fgrep sees them, R does not), [3] = rows refused (NUL / non-ASCII).  When [1] or [2] is non-zero the
+ * '#' rows carry (fgrep sees them, R does not), [3] = rows refused (a NUL or an invalid UTF-8 sequence inside the pattern's fields).  When [1] or [2] is non-zero the
  * columns alone cannot reproduce the reference for ANY line compared with this truth set: qm_vcf_hostpath then
  * decides every single-base data line from the text. */
 typedef struct qm_patterns qm_patterns;
@@ -390,7 +391,7 @@ int qm_vcf_split_write(const char* path, const uint8_t* text, size_t len, int mo
  * masks come back (2 bits per record) and the three files of every VCF are gathered from the mapped input with
  * writev.  Output paths are the caller's (the reference derives them, :19-22,39-41 / :71-72,91); their directories
  * must exist.  pure != 0: pure-strain sample (:33-36): fp is a copy of filtered, no tp file, the truth is never read.
- * strict != 0: QM_E_NONCANON for kept lines / truth rows holding NUL or non-ASCII bytes (their reference answer depends
+ * strict != 0: QM_E_NONCANON for kept lines / truth rows holding a NUL or an invalid UTF-8 sequence (their reference answer depends
  * on the locale); 0: such lines are classified by their columns.  mode: 0 or QM_BATCH_ALLELES.
  * stats[j] / roc[j][3][n_bins] (either may be NULL): the per-VCF rows; phase_seconds[8] (may be NULL): map + count,
  * truth sets (on a thread beside the former), batch layout, tokenise + host path + uploads, engine, masks back, write,

@@ -1563,8 +1563,7 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
 // instantiation of the scatter: the first one's tiles fill both), so a 10 Mb genome costs ONE read of the columns, four partitions
 // two; nothing else is new -- bucket rows, the two joins, the rows per segment and their sum per VCF are the one-level and
 // two-level paths'.
-constexpr int PX_MAX_PARTS = 8;        // default mode: one group of up to eight partitions (the 2 048-digit scatter); allele-extended: pairs, four partitions
-constexpr int PX_MAX_PARTS_EXT = 4;
+constexpr int PX_MAX_PARTS = 4;
 static int ext_parts_of(uint32_t posor) { return (int)((((uint64_t)posor << 4) | 15u) >> P2_SHIFT) + 1; }
 static bool bucketx_takes(const qm_batch* b, int64_t n, uint32_t posor) {
   if (b->ext && g_penv.bucket_ext == 0) return false;
@@ -1572,18 +1571,15 @@ static bool bucketx_takes(const qm_batch* b, int64_t n, uint32_t posor) {
   if (join_hash_forced()) return false;
   if (n < HB_MIN_RECORDS || n > ((int64_t)1 << (b->ext ? HB_INDEX_BITS : 26))) return false;   // (the second stream's entries hold 21 index bits, the first stream's 26)
   const int parts = ext_parts_of(posor);
-  if (parts > (b->ext ? PX_MAX_PARTS_EXT : PX_MAX_PARTS)) return false;
+  if (parts > PX_MAX_PARTS) return false;
   if (g_penv.bucketx == 0) return false;
-  if (g_penv.bucketx >= 2) return true;   // 2: every unsorted VCF that fits (tests, fuzz); 3: ... default-mode ones through the 2 048-digit scatter whatever their width
+  if (g_penv.bucketx == 2) return true;   // 2: every unsorted VCF that fits (tests, fuzz)
   if (b->ext) return parts > 1 || !bucket_path_takes(b, n);
   // default mode: a reference of 8.4 ... 16.8 M positions is ONE pair of partitions = one pass of the 512-digit scatter and the
   // bit-map join, where the one-level path would need the hashed join (bucket key ranges of 2^20) and larger VCFs two levels
-  if (parts == 2) return true;
-  // ... and up to eight partitions (67 M positions) are one pass of the 2 048-digit scatter, where the two-level path moves every
-  // record twice (round 6: configs[3]'s 10 M records on 50 Mb).  Worth it when the buckets are reasonably full -- every bucket costs
-  // its join a workgroup and two bit maps whatever it holds -- and they must not be fuller than their eight sub-regions take.
-  const int64_t buckets = ((((int64_t)posor << 4) | 15) >> DJ_MAX_SHIFT) + 1;
-  return parts >= 3 && n >= buckets * 1024 && n <= buckets * (HB_MAX_RECORDS * 13 / 16);
+  // (more partitions per pass were tried in round 6 -- eight, a 2 048-digit scatter -- and lost to the two levels by 2.6x: the
+  // pieces a tile leaves per bucket fall below an L2 line and are evicted half written, profiles/r06_pmc_scatter2048_not_kept.json)
+  return parts == 2;
 }
 
 static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, const std::vector<uint32_t>& posor, bool* taken) {
@@ -1596,9 +1592,7 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   int64_t nbt = b->lastx_nbt, nkt = b->lastx_nkt;
   const bool xs = b->ext;                                  // two entry streams (allele-extended batches)
   const int out_stride = xs ? 2 * HB_BUCKETS : HB_BUCKETS;
-  int maxparts = 1;
-  for (int i = 0; i < nv; ++i) maxparts = std::max(maxparts, ext_parts_of(por[(size_t)i]));
-  const int G = !xs && (maxparts > 2 || g_penv.bucketx == 3) ? 8 : 2;   // partitions per pass over the columns
+  constexpr int G = 2;                                     // partitions per pass over the columns
   if (!same) {
   nbt = 0; nkt = 0;
   std::vector<SortSeg> segs, vsegs((size_t)nv);
@@ -1696,7 +1690,7 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   S.segs = b->d_segs; S.tile_seg = b->d_bk_tile_seg; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
   S.cursor = b->bk_cursor; S.ent = b->bk_ent; S.mask_pass = reinterpret_cast<uint32_t*>(b->mask_pass); S.mask_tp = reinterpret_cast<uint32_t*>(b->mask_tp);
   S.n_seg = nseg; S.n_bins = b->n_bins; S.tile_base = 0; S.l1_ent = nullptr; S.xent = xs ? b->bk_xent : nullptr; S.xcursor = xs ? b->bk_xcursor : nullptr; S.ext = xs ? 1 : 0;
-  S.pairs = G == 8 ? 2 : 1;   // (tiles of single partitions run through the same instantiation as well)
+  S.pairs = 1;   // (tiles of single partitions run through the 512-digit instantiation as well)
   uint32_t* const seg_hist = b->bk_cursor + nhist0;
   uint32_t* const seg_maxd = nullptr;   // (the look at the highest filled bucket was measured on this path and lost: 2.08 against 2.02 ms per 64 x 2 M)
   S.seg_hist = seg_hist; S.seg_maxd = seg_maxd; S.l1_half = nullptr;
@@ -1751,8 +1745,8 @@ static int redo_unsorted(qm_batch* b, const std::vector<int>& todo, const std::v
     std::vector<int> chunk;
     int64_t chunk_n = 0;
     for (size_t i = 0; i <= part[kind].size(); ++i) {
-      // (kind 3: every GROUP of partitions -- two of an allele-extended VCF, up to eight otherwise -- reads its whole VCF)
-      const int64_t wgt = i < part[kind].size() ? b->L.vcfs[(size_t)part[kind][i]].n * (kind == 3 ? (ext_parts_of(posor[(size_t)part[kind][i]]) + (b->ext ? 1 : 7)) / (b->ext ? 2 : 8) : 1) : 0;
+      // (kind 3: every PAIR of partitions reads its whole VCF)
+      const int64_t wgt = i < part[kind].size() ? b->L.vcfs[(size_t)part[kind][i]].n * (kind == 3 ? (ext_parts_of(posor[(size_t)part[kind][i]]) + 1) / 2 : 1) : 0;
       const bool flush = i == part[kind].size() || (!chunk.empty() && chunk_n + wgt > chunk_records) ||
                          (kind >= 1 && chunk.size() >= (size_t)(kind == 3 ? 4096 / PX_MAX_PARTS : 4096));   // 256 rows of 1.5 KB and >= 1 MB of bucket regions per VCF: bounded per chunk
       if (flush && !chunk.empty()) {

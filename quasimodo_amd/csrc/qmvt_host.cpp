@@ -25,6 +25,8 @@
 #include <vector>
 
 #include <fcntl.h>
+#include <locale.h>
+#include <wctype.h>
 #include <sys/uio.h>
 #include <unistd.h>
 #include <sched.h>
@@ -76,6 +78,59 @@ int32_t allele_code(qm_dict* d, Span f) {
   return (int32_t)(QM_ALLELE_DICT | id);
 }
 inline bool is_word(uint8_t c) { return (c >= '0' && c <= '9') || (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == '_'; }
+// Non-ASCII text (round 6).  The reference's grep runs under the locale CPython exports -- LC_CTYPE=C.UTF-8 when the caller's is
+// C / POSIX (PEP 538; tests/golden/PROVENANCE.md) -- where `grep -w` asks iswalnum() about the CHARACTER next to a match and a line
+// that is not valid UTF-8 turns the output into "binary file matches".  The same question to the same glibc locale here: a kept line
+// of valid UTF-8 is decided from its text on the host (qm_vcf_hostpath), one with a NUL or an invalid sequence is still refused --
+// and so is every non-ASCII line on a host without that locale.  Pinned by tests/golden/utf8/ (written by the reference).
+inline locale_t utf8_locale() {
+  static locale_t loc = newlocale(LC_CTYPE_MASK, "C.UTF-8", (locale_t)0);
+  return loc;
+}
+// length of the valid UTF-8 sequence at p (1..4), 0 if there is none
+inline int utf8_at(const uint8_t* p, size_t n, uint32_t* cp) {
+  if (!n) return 0;
+  const uint8_t c = p[0];
+  if (c < 0x80) { *cp = c; return 1; }
+  int len; uint32_t v, min;
+  if (c >= 0xc2 && c <= 0xdf) { len = 2; v = c & 0x1fu; min = 0x80; }
+  else if (c >= 0xe0 && c <= 0xef) { len = 3; v = c & 0x0fu; min = 0x800; }
+  else if (c >= 0xf0 && c <= 0xf4) { len = 4; v = c & 0x07u; min = 0x10000; }
+  else return 0;
+  if ((size_t)len > n) return 0;
+  for (int k = 1; k < len; ++k) { if ((p[k] & 0xc0) != 0x80) return 0; v = (v << 6) | (p[k] & 0x3fu); }
+  if (v < min || v > 0x10ffff || (v >= 0xd800 && v <= 0xdfff)) return 0;
+  *cp = v;
+  return len;
+}
+inline bool utf8_text(const uint8_t* p, size_t n) {   // valid UTF-8 without a NUL, on a host that has the locale to read it with
+  if (!utf8_locale()) return false;
+  for (size_t i = 0; i < n;) {
+    uint32_t cp;
+    const int l = p[i] ? utf8_at(p + i, n - i, &cp) : 0;
+    if (!l) return false;
+    i += (size_t)l;
+  }
+  return true;
+}
+inline bool word_cp(uint32_t cp) {
+  if (cp < 0x80) return is_word((uint8_t)cp);
+  const locale_t loc = utf8_locale();
+  return loc && iswalnum_l((wint_t)cp, loc) != 0;
+}
+// is the character that ends right before s[i] (i > lo) / that starts at s[i] (i < hi) a word character?
+inline bool word_before(const uint8_t* s, size_t lo, size_t i) {
+  if (s[i - 1] < 0x80) return is_word(s[i - 1]);
+  size_t b = i - 1;
+  while (b > lo && (s[b] & 0xc0) == 0x80 && i - b < 4) --b;
+  uint32_t cp = 0;
+  return utf8_at(s + b, i - b, &cp) == (int)(i - b) && word_cp(cp);
+}
+inline bool word_at(const uint8_t* s, size_t i, size_t hi) {
+  if (s[i] < 0x80) return is_word(s[i]);
+  uint32_t cp = 0;
+  return utf8_at(s + i, hi - i, &cp) != 0 && word_cp(cp);
+}
 // begins with [ACGT]+ that ends at the field's end or before a non-word character (what `grep -w` needs)
 inline bool acgt_prefix_word(Span f) {
   size_t k = 0;
@@ -454,7 +509,7 @@ static void scan_chunk(const uint8_t* text, ScanChunk& c, bool count_only, int64
           const Span empty = {(const uint8_t*)"", 0};
           (void)effective_qual(nf > 5 ? f[5] : empty, &ge20);
           if (ge20) {
-            if (dirty()) { kind = QM_LINE_HEADER_REFUSED; ++c.nref; if (!c.first_ref) c.first_ref = gl + 1; }
+            if (dirty() && !utf8_text(s, n)) { kind = QM_LINE_HEADER_REFUSED; ++c.nref; if (!c.first_ref) c.first_ref = gl + 1; }
             else { kind = QM_LINE_HEADER_KEPT; ++c.nhost; }
           }
         }
@@ -472,9 +527,11 @@ static void scan_chunk(const uint8_t* text, ScanChunk& c, bool count_only, int64
         int32_t p = -1;
         const bool cpos = canon_pos(fpos, &p);
         if (cpos) { last_pos = p; any_pos = true; } else { p = last_pos; if (!any_pos) c.lead_nokey++; }
-        if (pass && dirty()) {
+        const bool high = dirty() && snp;                 // NUL or non-ASCII bytes in a single-base line
+        const bool text_ok = high && utf8_text(s, n);     // ... that is valid UTF-8: grep compares it as text, and so does the host path
+        if (pass && high && !text_ok) {
           kind = QM_LINE_REFUSED; ++c.nref; if (!c.first_ref) c.first_ref = gl + 1;
-        } else if (snp && (!cpos || (nf > 5 && (indexed ? pattern_at_later_fields_indexed(s, L, dict != nullptr) : pattern_at_later_fields(f[4].p, s + n, dict != nullptr))))) {
+        } else if (snp && (text_ok || !cpos || (nf > 5 && (indexed ? pattern_at_later_fields_indexed(s, L, dict != nullptr) : pattern_at_later_fields(f[4].p, s + n, dict != nullptr))))) {
           // every single-base line, whatever its QUAL: the ROC sweep moves the threshold.  fgrep compares POS as
           // text, so only canonical spellings are safe on the device
           kind = QM_LINE_DATA_HOST; ++c.nhost;
@@ -667,8 +724,6 @@ extern "C" int64_t qm_truth_scan_ext(const uint8_t* text, size_t len, int mode, 
     }
     if (!pattern) continue;
     if (comment) { ++ncomment; continue; }  // awk makes a pattern of it, R skips it: never a device key (qm_patterns keeps it)
-    bool ascii = true;
-    for (size_t i = 0; i < n && ascii; ++i) ascii = s[i] != 0 && s[i] < 0x80;
     int32_t p;
     if (!allele_ok(Y) || !allele_ok(Z)) { ++never; continue; }   // Y must equal a single-base REF field
     if (!canon_pos(X, &p)) {
@@ -676,7 +731,8 @@ extern "C" int64_t qm_truth_scan_ext(const uint8_t* text, size_t len, int mode, 
       ++never;
       continue;
     }
-    if (!ascii) { ++refused; continue; }
+    // (a canonical pattern is ASCII by construction; what the row's OTHER columns hold -- a non-ASCII INFO text, say -- never
+    // reaches the pattern list the reference's awk prints: such rows were refused through round 5)
     if (pos) {
       if (nkeys >= cap) return QM_E_INVAL;
       pos[nkeys] = p;
@@ -785,10 +841,12 @@ extern "C" qm_patterns* qm_patterns_create(const uint8_t* text, size_t len, int 
       X = f[0]; Y = f[1]; Z = f[2];
       if (is_dot(Y) || is_dot(Z)) continue;
     }
-    bool ascii = true;
-    for (size_t i = 0; i < n && ascii; ++i) ascii = s[i] != 0 && s[i] < 0x80;
-    if (!ascii) { ++P->n_refused; continue; }
     join3(pat, X, "\t.\t", Y, "\t", Z);
+    {   // the PATTERN's bytes: valid UTF-8 is text that grep compares bytewise; a NUL or an invalid sequence is refused
+      bool high = false;
+      for (size_t i = 0; i < pat.size() && !high; ++i) high = pat[i] == 0 || (uint8_t)pat[i] >= 0x80;
+      if (high && !utf8_text((const uint8_t*)pat.data(), pat.size())) { ++P->n_refused; continue; }
+    }
     const bool fresh = P->pats.add((const uint8_t*)pat.data(), pat.size());
     if (fresh && (ext ? !(acgt_all(Y) && acgt_all(Z)) : (Y.n != 1 || Z.n != 1))) ++P->n_exotic;
     const bool comment = n && s[0] == '#';
@@ -830,9 +888,10 @@ bool fgrep_w_selects(const qm_patterns& P, const uint8_t* s, size_t n) {
     size_t ze = zb;
     while (ze < n && s[ze] != '\t') ++ze;
     for (size_t i = fb; i <= j; ++i) {
-      if (i > fb && is_word(s[i - 1])) continue;    // i == fb: a tab or the line start precedes
+      if (i > fb && word_before(s, fb, i)) continue;    // i == fb: a tab or the line start precedes
+      if (i < j && (s[i] & 0xc0) == 0x80) continue;     // (a match starts and ends on a character boundary)
       for (size_t e = zb; e <= ze; ++e) {
-        if (e < ze && is_word(s[e])) continue;      // e == ze: a tab or the line end follows
+        if (e < ze && (word_at(s, e, ze) || (s[e] & 0xc0) == 0x80)) continue;      // e == ze: a tab or the line end follows
         if (P.pats.has(s + i, e - i)) return true;
       }
     }

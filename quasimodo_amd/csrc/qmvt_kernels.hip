@@ -1745,18 +1745,18 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const SortSeg* segs, const
 // EXT (allele-extended batches): every record with valid allele codes is live; those whose REF / ALT are not two single bases
 // leave in a second stream of 16-byte entries (the ordinary entry with the position's first key, then the two codes), written
 // straight to their bucket's second region -- k_join_ext joins them exactly, k_join_direct the single-base ones.
-// NB = 512 / 2048 (VCFs in partitions, SortSeg.part & 4): the tile's segment stands for the two / up to eight neighbouring partitions
-// of its VCF that follow it -- 512 ... 2 048 buckets whose cursors, regions and rows lie one behind the other -- so that the columns
-// are read ONCE for all of them (2 048: default-mode VCFs of up to 67 M positions, e.g. configs[3]'s 10 M records on 50 Mb, which
-// took a level-1 scatter of their own through round 5).  A thread then scans NB / 512 digits; the pieces a tile writes per bucket
-// are a few entries long, and it is the XCD's L2 that makes whole lines of them (a sub-region is filled by one XCD).
+// NB = 512 (VCFs in partitions, SortSeg.part & 4): the tile's segment stands for TWO neighbouring partitions of its VCF -- 512
+// buckets whose cursors, regions and rows lie one behind the other -- so that the columns are read once for both.  (Round 6 tried
+// eight partitions per pass with a 2 048-digit instantiation, for configs[3]'s shuffled 10 M-record VCFs: a tile then leaves 21
+// bytes per bucket, the L2 evicts such pieces before the next tile completes their lines, and 4.1x the entries' bytes reach HBM --
+// 3.5 ms per 1.6e8 records against the two levels' 1.34: profiles/r06_pmc_scatter2048_not_kept.json.  Not kept.)
 template <bool L2, bool EXT, int NB = 256>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : BK_WAVES_PER_EU, 8))) void k_bucket_scatter(BucketScatterParams P) {
   constexpr int PER = BK_TILE / 512;          // records per thread, in groups of four consecutive ones
   static_assert(BK_TILE % 2048 == 0 && PER >= 4, "whole 16-byte loads, 256 records per wave and group");
-  static_assert(NB == 256 || (NB == 512 && !L2) || (NB == 2048 && !L2 && !EXT), "instantiations");
-  constexpr int DPT = NB > 512 ? NB / 512 : 1;   // digits per thread of the scan
-  constexpr int NDT = NB / DPT;                  // threads that scan: 256, 512, 512
+  static_assert(NB == 256 || (NB == 512 && !L2), "one digit per thread at most");
+  constexpr int DPT = 1;                         // digits per thread of the scan
+  constexpr int NDT = NB / DPT;                  // threads that scan
   typedef typename std::conditional<NB == 256, uint8_t, uint16_t>::type digit_t;
   __shared__ uint32_t s_cnt[NB];              // records of digit d in the tile (running during the ranking)
   __shared__ uint32_t s_loc[NB];              // tile-local start of digit d's run
@@ -1779,7 +1779,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   const uint32_t nbins = (uint32_t)P.n_bins;
   // one first-stream entry by bin + 1 (b1 <= n_bins <= 256); digit >= 256: the entry belongs to the next segment (NB = 512)
   auto count = [&](uint32_t b1, uint32_t d) {
-    if (NB > 512) { atomicAdd(&s_hall[d >> 8][b1], 1u); return; }   // (the top bin too: a counter in registers per partition would not pay)
     if (NB == 512 && d >= 256u) { if (b1 == nbins) ++top_all2; else atomicAdd(&s_hall[NB / 256 - 1][b1], 1u); }
     else { if (b1 == nbins) ++top_all; else atomicAdd(&s_hall[0][b1], 1u); }
   };
@@ -3507,7 +3506,6 @@ void launch_bucket_scatter(const BucketScatterParams& P, int ntiles, hipStream_t
   if (ntiles <= 0) return;
   if (P.l1_ent) hipLaunchKernelGGL((k_bucket_scatter<true, false>), dim3(ntiles), dim3(512), 0, st, P);
   else if (P.ext && P.pairs) hipLaunchKernelGGL((k_bucket_scatter<false, true, 512>), dim3(ntiles), dim3(512), 0, st, P);
-  else if (P.pairs == 2) hipLaunchKernelGGL((k_bucket_scatter<false, false, 2048>), dim3(ntiles), dim3(512), 0, st, P);   // groups of up to eight partitions
   else if (P.pairs) hipLaunchKernelGGL((k_bucket_scatter<false, false, 512>), dim3(ntiles), dim3(512), 0, st, P);
   else if (P.ext) hipLaunchKernelGGL((k_bucket_scatter<false, true>), dim3(ntiles), dim3(512), 0, st, P);
   else hipLaunchKernelGGL((k_bucket_scatter<false, false>), dim3(ntiles), dim3(512), 0, st, P);

@@ -141,7 +141,7 @@ def _pure_only(file_jobs, strict):
         with open(j["vcf"], "rb") as fh:
             sv = scan_vcf(fh.read())
         if sv.n_refused and strict:
-            raise QmvtError(-8, "%s line %d: a kept line holds NUL or non-ASCII bytes -- the reference's answer for it depends on the "
+            raise QmvtError(-8, "%s line %d: a kept line holds a NUL or bytes that are not valid UTF-8 -- the reference's answer for it depends on the "
                                 "locale Python exports to grep; set QM_LENIENT=1 to classify it by its columns" % (j["vcf"], sv.first_refused_line))
         cls = (sv.flags & 1).astype(np.uint8)
         sv.write(j["filtered"], cls, 0)

@@ -23,7 +23,7 @@ class ScannedVcf:
     n_lines: int
     line_off: np.ndarray   # int64 [n_lines + 1]
     line_kind: np.ndarray  # uint8 [n_lines]: QM_LINE_* of include/qmvt.h (0 data, 1 header, 2 data for the host path,
-                           # 3 / 4 header line that passes the A2 filter (4: selected by fgrep), 5 / 6 refused: NUL or non-ASCII)
+                           # 3 / 4 header line that passes the A2 filter (4: selected by fgrep), 5 / 6 refused: NUL or invalid UTF-8)
     pos: np.ndarray
     ref: np.ndarray
     alt: np.ndarray
@@ -163,7 +163,7 @@ class TruthKeys:
     alt: np.ndarray
     genomediff: int   # rows R counts as `genomediff` (caller_performance_compare.R:90)
     n_never: int      # rows whose pattern can never match a line through its columns (they live in Patterns only)
-    n_refused: int    # rows holding NUL / non-ASCII bytes (strict mode stops)
+    n_refused: int    # rows whose pattern holds a NUL or invalid UTF-8 (strict mode stops)
     n_comment: int    # '#' rows awk turns into patterns all the same (Patterns keeps them; R does not read them)
 
 

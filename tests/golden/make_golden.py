@@ -254,6 +254,33 @@ def quirks_case(canonical_only=False):
     return vt, ("\n".join(truth) + "\n").encode()
 
 
+def utf8_case():
+    """Valid UTF-8 in kept lines, headers and truth rows (round 6).  The reference's grep runs under the locale CPython exports
+    (PEP 538: LC_CTYPE=C.UTF-8 here), so `fgrep -w` asks iswalnum() about the CHARACTER next to a match: a letter, a digit of
+    another script or '_' abutting a pattern is a word character (no match there), an arrow or a no-break space is not."""
+    hdr = "##fileformat=VCFv4.2\n##source=\u00fcber-caller \u65e5\u672c\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n"
+    truth = hdr + "chrT\t1000\t.\tA\tG\t30\tPASS\tX\nchrT\t30\t.\tA\tC\t30\tPASS\tX\n" \
+                  "chrT\t1100\t.\tT\tC\t30\tPASS\tNOTE=\u00e9\nchrT\t1200\t.\tG\tT\t30\tPASS\t\u2192\n"
+    v = ["chrT\t1000\t.\tA\tG\t50\tPASS\tNOTE=\u00e9",           # TP, non-ASCII INFO
+         "chrT\t1001\t.\tA\tG\t50\tPASS\tNOTE=\u65e5\u672c",    # FP, non-ASCII INFO
+         "chr\u00dc\t1100\t.\tT\tC\t77\tPASS\tDP=1",             # TP, non-ASCII CHROM; the truth row's INFO is non-ASCII too
+         "chrT\t1200\t\u00e9\tG\tT\t77\tPASS\tDP=1",             # ID is a non-ASCII string, not '.': FP
+         "chrT\t995\t.\tA\tC\t\u00e930\t.\tA\tC\tz",           # a letter abuts the pattern '30 . A C' at the later fields: word
+         "chrT\t994\t.\tA\tC\t\u219230\t.\tA\tC\tz",           # an arrow abuts it: not a word character -> TP
+         "chrT\t993\t.\tA\tC\t30\t.\tA\tC\u00e9",               # a letter behind Z
+         "chrT\t992\t.\tA\tC\t30\t.\tA\tC\u2192",               # an arrow behind Z -> TP
+         "chrT\t991\t.\tA\tC\t\u066330\t.\tA\tC\tz",           # an Arabic-Indic digit abuts: alnum
+         "chrT\t990\t.\tA\tC\t_30\t.\tA\tC\tz",                 # underscore
+         "chrT\t989\t.\tA\tC\t\u00a030\t.\tA\tC\tz",           # no-break space -> TP
+         "chrT\t988\t.\tA\tC\t\U0001d7d130\t.\tA\tC\tz",       # a four-byte character (mathematical bold digit three): alnum
+         "chrT\t1000\t.\tA\tG\t\u00e9\tPASS\tX",                 # QUAL is a non-ASCII string: awk compares it bytewise with "20" -> kept
+         "chrT\t1000\t.\tA\tG\t19\tPASS\tNOTE=\u00e9",           # fails QUAL
+         "#comment \u00e9",
+         "chrT\t1002\t.\tA\tG\t50\tPASS\t\u00e9\t.\tA\tG"]    # a letter field, then '. A G': no digits before the dot
+    snps = "1000\tA\tG\t1\t1\t1\t9\t9\t1\t1\tr\u00e9f\tr2\n30\tA\tC\t1\t1\t1\t9\t9\t1\t1\tr1\tr2\n1100\tT\tC\t1\t1\t1\t9\t9\t1\t1\tr1\tr2\n"
+    return (hdr + "\n".join(v) + "\n").encode("utf-8"), truth.encode("utf-8"), snps.encode("utf-8")
+
+
 def snps_tsv(rng, snvs, ref1, ref2):
     """show-snps -CTHIlr dialect (eval_variant_custom.smk:51): 12 tab columns, SNPs only."""
     rows = []
@@ -342,7 +369,7 @@ def write(path, data):
 
 def gen_all():
     manifest = []
-    for fam in ("quirks", "quirks_canon", "hcmv", "config1", "custom", "edge"):
+    for fam in ("quirks", "quirks_canon", "hcmv", "config1", "custom", "edge", "utf8"):
         shutil.rmtree(os.path.join(HERE, fam), ignore_errors=True)
     refs = {k: read_fasta(k) for k in FASTA}
 
@@ -413,6 +440,18 @@ def gen_all():
             store_case("custom", manifest, w, rel, "nucmer/Merlin.BAC_TB40E.GFP.maskrepeat.snps", "custom", "callers",
                        "TM-1-1.Merlin.%s" % caller)
 
+    # ---- valid UTF-8 (the reference's grep runs under C.UTF-8: PEP 538) -------
+    with tempfile.TemporaryDirectory() as w:
+        v, t, snps = utf8_case()
+        write(os.path.join(w, "u/U8-1-10.R.u.vcf"), v)
+        write(os.path.join(w, "nucmer/U8.maskrepeat.variants.vcf"), t)
+        store_case("utf8", manifest, w, "u/U8-1-10.R.u.vcf", "nucmer/U8.maskrepeat.variants.vcf", "hcmv", "u", "u")
+        write(os.path.join(w, "nucmer/r1_r2.maskrepeat.snps"), snps)
+        write(os.path.join(w, "in/utf8.vcf"), v)
+        store_case("utf8", manifest, w, "in/utf8.vcf", "nucmer/r1_r2.maskrepeat.snps", "custom", "callers", "utf8")
+        write(os.path.join(w, "u/U8-1-0.R.u.vcf"), v)          # pure strain: filtered copied to fp
+        store_case("utf8", manifest, w, "u/U8-1-0.R.u.vcf", "nucmer/U8.maskrepeat.variants.vcf", "hcmv", "u", "u")
+
     # ---- edge cases ----------------------------------------------------------
     with tempfile.TemporaryDirectory() as w:
         hdr = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n"
@@ -445,7 +484,7 @@ def gen_all():
         fh.write("# Golden fixture provenance\n\n"
                  "Generated by `tests/golden/make_golden.py`; expected outputs written by the reference script\n"
                  "`program/extract_TP_FP_SNPs.py` (hzi-bifo/Quasimodo v0.4.2) run unmodified in the build container.\n\n"
-                 "* awk: %s\n* grep: %s\n* bash: %s\n* python: %s\n* locale: POSIX\n* cases: %d\n\n"
+                 "* awk: %s\n* grep: %s\n* bash: %s\n* python: %s\n* locale: POSIX (CPython exports LC_CTYPE=C.UTF-8 to the reference's children: PEP 538)\n* cases: %d\n\n"
                  "mawk's numeric-string rule as observed here (probe list `QUAL_PROBES` in make_golden.py, outputs in\n"
                  "`quirks/expected/`): strip blanks; last char digit or '.', first char digit/+/-/.; glibc strtod must\n"
                  "consume the field; any ERANGE (overflow, underflow, subnormal) makes the field a plain string, which\n"
@@ -453,8 +492,10 @@ def gen_all():
                  "Locale: the reference runs its children under whatever locale Python exports (CPython >= 3.7 coerces\n"
                  "POSIX to LC_CTYPE=C.UTF-8, PEP 538).  GNU grep then suppresses selected lines holding bytes that are\n"
                  "not valid UTF-8 ('binary file matches') and classifies non-ASCII letters as word characters, so the\n"
-                 "reference's output for non-ASCII data lines is locale dependent.  The fixtures are ASCII only; the\n"
-                 "engine and the oracle reject kept data lines containing NUL or bytes >= 0x80 instead of guessing.\n"
+                 "reference's output for non-ASCII data lines is locale dependent.  Round 6: the `utf8` family holds VALID\n"
+                 "UTF-8 in kept lines, headers and truth rows, written by the reference under that exported locale; the engine\n"
+                 "and the oracle ask the same glibc question (iswalnum_l on C.UTF-8) about the character next to a match.\n"
+                 "Kept data lines holding a NUL or an invalid UTF-8 sequence are still rejected instead of guessed about.\n"
                  % (awkv, grepv, bashv, sys.version.split()[0], len(manifest)))
     print("wrote %d cases" % len(manifest))
 

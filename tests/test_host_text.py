@@ -67,7 +67,7 @@ def test_pack_classify_write_roundtrip(qmlib, oracle, tmp_path, e):
     from quasimodo_amd import scan_vcf
     vcf, truth, exp = read_case(e)
     sv = scan_vcf(vcf)
-    assert sv.n_refused == 0 and (sv.n_host == 0 or e["family"] == "quirks")
+    assert sv.n_refused == 0 and (sv.n_host == 0 or e["family"] in ("quirks", "utf8"))   # (utf8: valid UTF-8 single-base lines are decided from their text)
     tk, cls, roc, sc = host_classify(oracle, sv, truth, custom=e["mode"] == "custom")
     assert tk.n_refused == 0
     for sel, kind in ((0, "filtered"), (1, "tp"), (2, "fp")):
@@ -101,29 +101,41 @@ def test_noncanonical_lines_are_flagged(qmlib):
 
 @pytest.mark.gpu
 def test_strict_mode_refuses_only_locale_dependent_lines(qmlib, tmp_path):
-    """extract_many refuses (before any kernel runs) when a kept line holds NUL / non-ASCII bytes -- the one kind of
-    input left whose reference answer the engine does not reproduce (it depends on the locale grep runs under);
-    QM_LENIENT / strict=False classifies such lines by their columns."""
+    """extract_many refuses (before any kernel runs) when a kept line holds a NUL or an INVALID UTF-8 sequence -- the one kind of
+    input left whose reference answer the engine does not reproduce (grep says "binary file matches" under the locale Python
+    exports); QM_LENIENT / strict=False classifies such lines by their columns.  Valid UTF-8 is text (round 6: tests/golden/utf8/)."""
     import quasimodo_amd as q
     from quasimodo_amd.extract import Job
     d = tmp_path / "q"
     d.mkdir()
-    (d / "QK-1-10.R.q.vcf").write_bytes(b"#h\nc\t5\t.\tA\tG\t50\tPASS\tname=\xc3\xa9\n")
+    (d / "QK-1-10.R.q.vcf").write_bytes(b"#h\nc\t5\t.\tA\tG\t50\tPASS\tname=\xe9\n")          # Latin-1 e-acute: not UTF-8
     (tmp_path / "t.vcf").write_bytes(b"c\t5\t.\tA\tG\n")
     with pytest.raises(q.QmvtError) as ei:
         q.extract_many([Job(str(d / "QK-1-10.R.q.vcf"), str(tmp_path / "t.vcf"), "hcmv")], strict=True)
     assert ei.value.code == -8 and "line 2" in str(ei.value)
     job = q.extract_many([Job(str(d / "QK-1-10.R.q.vcf"), str(tmp_path / "t.vcf"), "hcmv")], strict=False)[0]
     assert job.stats["tp_lines"] == 1 and open(job.tp_out, "rb").read().count(b"\n") == 2
+    (d / "QK-1-10.R.q.vcf").write_bytes(b"#h\nc\t5\t.\tA\tG\t50\tPASS\tname=\xc3\xa9\n")      # the same letter in UTF-8: accepted, a TP line
+    job = q.extract_many([Job(str(d / "QK-1-10.R.q.vcf"), str(tmp_path / "t.vcf"), "hcmv")], strict=True)[0]
+    assert job.stats["tp_lines"] == 1 and open(job.tp_out, "rb").read() == b"#h\nc\t5\t.\tA\tG\t50\tPASS\tname=\xc3\xa9\n"
 
 
-def test_non_ascii_kept_line_flagged(qmlib, oracle):
+def test_non_utf8_kept_line_flagged(qmlib, oracle):
     from quasimodo_amd import scan_vcf
-    vcf = b"c\t5\t.\tA\tG\t50\tPASS\tname=\xc3\xa9\nc\t6\t.\tA\tG\t5\tPASS\tname=\xc3\xa9\n#c\t7\t.\tA\tG\t50\t\xc3\xa9\n"
+    vcf = b"c\t5\t.\tA\tG\t50\tPASS\tname=\xe9\nc\t6\t.\tA\tG\t5\tPASS\tname=\xe9\n#c\t7\t.\tA\tG\t50\t\xc3\n"
     sv = scan_vcf(vcf)
     assert list(sv.line_kind) == [5, 0, 6] and sv.n_refused == 2 and sv.first_refused_line == 1   # only KEPT lines matter
     with pytest.raises(ValueError):
         oracle.extract_text(vcf, b"", False, False)
+    for bad in (b"c\t5\t.\tA\tG\t50\tPASS\tx\x00y\n", b"c\t5\t.\tA\tG\t50\tPASS\t\xc0\xaf\n", b"c\t5\t.\tA\tG\t50\tPASS\t\xed\xa0\x80\n",
+                b"c\t5\t.\tA\tG\t50\tPASS\t\xf4\x90\x80\x80\n", b"c\t5\t.\tA\tG\t50\tPASS\t\xe2\x82\n"):   # NUL, overlong, surrogate, > U+10FFFF, truncated
+        assert scan_vcf(bad).n_refused == 1, bad
+        with pytest.raises(ValueError):
+            oracle.extract_text(bad, b"", False, False)
+    ok = "c\t5\t.\tA\tG\t50\tPASS\tname=\u00e9 \u65e5\u672c \U0001d7d1\n".encode("utf-8")          # valid: kept, decided on the host path from its text
+    sv = scan_vcf(ok)
+    assert sv.n_refused == 0 and list(sv.line_kind) == [2] and sv.n_host == 1
+    oracle.extract_text(ok, b"", False, False)
 
 
 def test_pure_strain_paths_and_copy(qmlib, tmp_path):
