@@ -488,6 +488,12 @@ struct qm_batch {
   int64_t lastx_nbt = 0, lastx_nkt = 0;
   std::vector<uint8_t> known;         // per VCF: 1 = out of order, as the last finish found it
   std::vector<uint32_t> known_posor;  // its position bits (vcf_posor of that finish)
+  // The position bits a VCF is remembered with come from what the optimistic pass SAW before it left (the first 256 records of a
+  // span): an estimate that can lie below the VCF's highest position -- the scatter then flags the chunk, the radix sort redoes it,
+  // and with the batch's memory on the same would happen on every run.  The radix sort's first pass ORs ALL keys of its chunk
+  // (sorbits): those bits are kept here and join the estimate of the chunk's VCFs, so the next finish sizes their buckets for
+  // what they really hold.  Cleared with the batch's memory.
+  std::vector<uint32_t> posor_seen;
   std::vector<uint32_t> known_nbk;    // 1 + the highest bucket its records reached on the one-level bucket path (0: not known)
   int n_known = 0;
   bool known_dirty = false;           // the device copy is stale
@@ -504,6 +510,7 @@ static bool flags_event_on() {   // QM_FLAGS_WAIT=stream: qm_batch_finish waits 
   return !(e && strcmp(e, "stream") == 0);
 }
 static void forget_known(qm_batch* b, int v) {   // v < 0: every VCF
+  if (!b->posor_seen.empty()) { if (v < 0) std::fill(b->posor_seen.begin(), b->posor_seen.end(), 0u); else b->posor_seen[(size_t)v] = 0u; }
   if (!b->known_nbk.empty()) { if (v < 0) std::fill(b->known_nbk.begin(), b->known_nbk.end(), 0u); else b->known_nbk[(size_t)v] = 0u; }
   if (b->known.empty() || b->n_known == 0) return;
   if (v < 0) { std::fill(b->known.begin(), b->known.end(), (uint8_t)0); b->n_known = 0; b->known_dirty = true; return; }
@@ -909,9 +916,13 @@ static int64_t sort_chunk_records() {   // QM_SORT_CHUNK_RECORDS (tests, tools/g
   return SORT_CHUNK_RECORDS;
 }
 
+// (Growing an array frees the old one.  A speculative bucket chunk returns with its last kernels still queued -- they read d_segs,
+// the cursors' "bad" word, the rows -- and the NEXT chunk of the same finish may grow exactly those: the device is drained first,
+// explicitly.  hipFree would do so implicitly; the code must not depend on that.  ADVICE round 5.)
 template <typename T>
 static int regrow(T** p, int64_t* cap, int64_t need, int64_t* bytes) {
   if (need <= *cap) return QM_OK;
+  if (*p) (void)hipDeviceSynchronize();
   (void)hipFree(*p);
   *p = nullptr;
   *bytes -= *cap * (int64_t)sizeof(T);
@@ -1294,6 +1305,13 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   uint32_t orbits = 0;
   HIPCHK(hipMemcpyAsync(&orbits, b->sorbits, 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));   // also makes the host tables above safe to free
+  if (memo_on()) {   // every position bit in use in this chunk: corrects an under-estimate the VCFs were (or will be) remembered with
+    if (b->posor_seen.empty()) b->posor_seen.assign((size_t)b->n_vcf, 0u);
+    for (int v : vs) {
+      b->posor_seen[(size_t)v] |= orbits >> 4;
+      if (!b->known_posor.empty() && b->known[(size_t)v]) b->known_posor[(size_t)v] |= orbits >> 4;
+    }
+  }
   int npass = 1;
   while (4 + 8 * npass < 32 && (orbits >> (4 + 8 * npass)) != 0) ++npass;
   int cur = 0;
@@ -1798,6 +1816,7 @@ static int settle_pending(qm_batch* b, const std::vector<uint32_t>& posor, hipSt
     if (!overflow) { b->path_stats[p.direct ? QM_PATH_DIRECT : QM_PATH_HASHED] += nseg; continue; }
     // a bucket did not fit its tables (dense positions, a dense truth set): the radix sort redoes the chunk from the columns
     if (p.tight && !b->known_nbk.empty()) for (int v : p.vs) b->known_nbk[(size_t)v] = 0u;
+    // (what the radix sort below learns about the chunk's positions corrects the estimate such a VCF is remembered with: posor_seen)
     b->path_stats[QM_PATH_OVERFLOW_CHUNKS] += 1;
     b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += nseg;
     const int rc = sort_chunk(b, p.vs, st, b->last_global, posor, false);
@@ -1880,7 +1899,10 @@ extern "C" int qm_batch_finish(qm_batch* b, void* stream) {
   }
   if (memo_on() && !todo.empty()) {
     if (b->known.empty()) { b->known.assign((size_t)b->n_vcf, (uint8_t)0); b->known_posor.assign((size_t)b->n_vcf, 0u); }
-    for (int v : todo) if (!b->known[(size_t)v]) { b->known[(size_t)v] = 1; b->known_posor[(size_t)v] = posor[(size_t)v]; ++b->n_known; b->known_dirty = true; }
+    for (int v : todo) if (!b->known[(size_t)v]) {
+      b->known[(size_t)v] = 1; b->known_posor[(size_t)v] = posor[(size_t)v] | (b->posor_seen.empty() ? 0u : b->posor_seen[(size_t)v]);
+      ++b->n_known; b->known_dirty = true;
+    }
   }
   for (int k = 0; k < QM_N_PATH_STATS; ++k) c->path_total[k] += b->path_stats[k];
   b->finished = true;

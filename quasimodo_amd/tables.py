@@ -129,24 +129,32 @@ def performance_row(stats):
 
 
 def write_caller_performance(path, rows, strict=None):
-    """rows: iterable of (caller_lower, sample, stats)."""
+    """rows: iterable of (caller_lower, sample, stats).  Returns the (name, kept lines, truth rows) of the rows that were written as
+    R's empty vector (strict mode; a caller can fail its CI on a non-empty answer)."""
     rows = list(rows)
     if strict is None:
         strict = os.environ.get("QM_LENIENT", "0") in ("", "0")
-    check_r_readable([("%s/%s" % (c, smp), st) for c, smp, st in rows], strict)
+    bad = check_r_readable([("%s/%s" % (c, smp), st) for c, smp, st in rows], strict)   # (both reads of this script sit in a tryCatch: make_snp_vector, :29-55)
     with open(path, "w") as fh:
         fh.write("\t".join(["caller", "mixture", "genomediff", "calleridentify", "TP", "FP", "Precision", "Recall", "F1"]) + "\n")
         for caller, sample, stats in rows:
             vals = performance_row(_as_r_reads(stats, strict))
             fh.write("\t".join([CALLER_MAP.get(caller, caller), sample] + [r_str(v) for v in vals]) + "\n")
+    return bad if strict else []
 
 
 def write_snpcall_benchmark(path, rows, strict=None):
-    """rows: iterable of (label, stats).  custom_snp_benchmark.R:30-95."""
+    """rows: iterable of (label, stats).  custom_snp_benchmark.R:30-95.
+    The custom script reads the genome-difference table with NO tryCatch (:23-24): a truth file R cannot read as tab-split lines
+    stops the script -- so the strict writer refuses it too (RTableError, nothing written) instead of writing a table the
+    reference can never produce; only a CALLER file R gives up on (its read has a tryCatch, :45-48) gets the
+    empty-vector row.  Returns the (name, kept lines, truth rows) of the rows written as R's empty vector."""
     rows = list(rows)
     if strict is None:
         strict = os.environ.get("QM_LENIENT", "0") in ("", "0")
-    check_r_readable(rows, strict)
+    if strict and any(st.get("truth_r_hostile") for _, st in rows):
+        check_r_readable([(n, st) for n, st in rows if st.get("truth_r_hostile")], "refuse")
+    bad = check_r_readable(rows, strict)
     with open(path, "w") as fh:
         fh.write("\t".join(["caller", "genomediff", "calleridentify", "TP", "FP", "precision", "recall", "f1"]) + "\n")
         for label, stats in rows:
@@ -154,6 +162,7 @@ def write_snpcall_benchmark(path, rows, strict=None):
             st["pure_strain"] = False     # the custom script has no pure-strain branch
             vals = performance_row(st)
             fh.write("\t".join([label] + [r_str(v) for v in vals]) + "\n")
+    return bad if strict else []
 
 
 def write_fp_overlap(path, per_sample, callers):

@@ -898,7 +898,9 @@ def test_positions_above_what_the_optimistic_pass_saw(engine, oracle):
     hold no position with bit 21 or above 0x5fffff -- an OR of 0x5fffff: 192 buckets of 256 -- while a quarter of the other
     records lie at 0x600000 and above (buckets 192..255): those records must be classified (by the radix sort, after the scatter
     flags the VCF), not dropped (the join was trimmed to the buckets below the estimate and nothing noticed).
-    Run twice: the batch's memory of the VCF carries the same estimate forward."""
+    Run three times: the first run pays for the radix sort, whose first pass ORs every key of its chunk -- those bits correct the
+    estimate the batch remembers the VCF with (round 6, ADVICE 5: until then the same overflow came back on every run), so the
+    later runs size the buckets for what the VCF really holds and stay on them."""
     rng = np.random.default_rng(4242)
     n, span = 40000, 16384
     seen = np.zeros(n, bool)
@@ -925,14 +927,15 @@ def test_positions_above_what_the_optimistic_pass_saw(engine, oracle):
     b = engine.batch([n], [tid])
     b.upload(0, *cols)
     from quasimodo_amd.engine import SCALAR_NAMES
-    for _ in range(2):
+    for rep in range(3):
         b.run()
         b.finish()
         sc = dict(zip(SCALAR_NAMES, b.scalars()[0].tolist()))
         reg = b.idx(0)
         res = {"cls": b.cls(0), "roc": b.roc()[0], "scalars": sc, "tp_idx": reg[:sc["tp_lines"]].copy(), "fp_idx": reg[n - sc["fp_lines"]:].copy()}
         check_vcf(oracle, res, cols, truth, expect_sorted=False)
-        assert b.path_stats()["radix_after_overflow"] == 1
+        ps = b.path_stats()
+        assert ps["radix_after_overflow"] == (1 if rep == 0 else 0) and ps["bucket_direct"] == (0 if rep == 0 else 1), (rep, ps)
     b.close()
 
 

@@ -98,8 +98,13 @@ def test_lines_r_read_table_would_not_split_at_tabs_are_counted_and_written_as_r
     assert (tmp_path / "cp.tsv").read_text().splitlines()[1:] == ["LoFreq\tTA-1-10\t4\t6\t2\t2\t0.333\t0.5\t0.4",
                                                                    "VarScan2\tTA-1-10\t4\t0\t0\t0\tNA\tNA\tNA",        # :101-108
                                                                    "CLC\tTA-1-10\t0\t6\t0\t4\t0\tNaN\tNaN"]            # an empty truth vector: :84-99
-    write_snpcall_benchmark(str(tmp_path / "sb.txt"), [("lab", bad), ("lab2", ok)])
+    assert write_snpcall_benchmark(str(tmp_path / "sb.txt"), [("lab", bad), ("lab2", ok)]) == [("lab", 3, 0)]      # what was substituted is reported
     assert (tmp_path / "sb.txt").read_text().splitlines()[1:] == ["lab\t4\t0\t0\t0\tNA\tNA\tNA", "lab2\t4\t6\t2\t2\t0.333\t0.5\t0.4"]
+    # the custom script reads its truth table without a tryCatch (custom_snp_benchmark.R:23-24): R stops, and so does the strict writer
+    (tmp_path / "sb2.txt").unlink(missing_ok=True)
+    with pytest.raises(RTableError):
+        write_snpcall_benchmark(str(tmp_path / "sb2.txt"), [("lab", badt), ("lab2", ok)])
+    assert not (tmp_path / "sb2.txt").exists()
     monkeypatch.setenv("QM_LENIENT", "1")
     write_caller_performance(str(tmp_path / "cp.tsv"), [("lofreq", "TA-1-10", bad)])
     assert (tmp_path / "cp.tsv").read_text().splitlines()[1] == "LoFreq\tTA-1-10\t4\t6\t2\t2\t0.333\t0.5\t0.4"
