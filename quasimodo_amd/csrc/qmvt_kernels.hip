@@ -700,6 +700,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
   int te = (tb + K1_TILE < sp_end) ? tb + K1_TILE : sp_end;
   Raw4<PACKED> N;
   load_raw<EXT>(C, tb + lane * 4, N);
+  // (sorted columns only) sixty-four records spread evenly over the WHOLE VCF, one per lane, asked for beside the first round:
+  // the same 64 lines for every span of the VCF, so all but the first span find them in L2
+  int spos = 0;
+  if constexpr (!PACKED) if (vn >= 4096) spos = C.pos[(int)(((int64_t)lane * vn) >> 6)];
   SegBounds B = seg_bounds<PACKED>(C, tb, te, vn);
   if constexpr (!PACKED) {
     // A span whose FIRST round is out of order leaves here, three round trips in (descriptor, positions, this look), instead of
@@ -713,7 +717,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(EXT ? K1_WAV
     const int pl = __shfl_up(N.p.w, 1);
     const bool ooo = (j + 1 < n0 && N.p.y < N.p.x) || (j + 2 < n0 && N.p.z < N.p.y) || (j + 3 < n0 && N.p.w < N.p.z) || (lane > 0 && j < n0 && N.p.x < pl);
     uint32_t po = (j < n0 ? (uint32_t)N.p.x : 0u) | (j + 1 < n0 ? (uint32_t)N.p.y : 0u) | (j + 2 < n0 ? (uint32_t)N.p.z : 0u) | (j + 3 < n0 ? (uint32_t)N.p.w : 0u);
-    if (ballot64(ooo) != 0ull && ballot64((po >> 28) != 0u) == 0ull) {
+    // ... and a span whose VCF is out of order ANYWHERE leaves as well, when the sixty-four samples tell (round 6): a VCF sorted
+    // per contig -- two dozen ascending runs -- has its descents inside a third of its spans only; the others found nothing wrong,
+    // classified their records (on the slow path: a run is sparse against the truth set) and were thrown away: 2.9 ms per 256 such
+    // VCFs before the bucket path started.  Samples out of order prove the VCF unsorted; samples in order prove nothing.
+    const int spl = __shfl_up(spos, 1);
+    const bool sooo = vn >= 4096 && lane > 0 && spos < spl;
+    po |= vn >= 4096 ? (uint32_t)spos : 0u;
+    if (ballot64(ooo || sooo) != 0ull && ballot64((po >> 28) != 0u) == 0ull) {
       for (int o = 32; o > 0; o >>= 1) po |= (uint32_t)__shfl_xor((int)po, o);
       if (lane < 8) P.span_scal[(size_t)span_id * 8 + lane] = lane == 5 ? (uint32_t)SPANF_UNSORTED : lane == 6 ? po : 0u;
       return;

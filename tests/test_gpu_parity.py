@@ -814,6 +814,68 @@ def test_synthetic_workload_is_what_the_specification_says(engine, shuffled, pct
     engine.truth_release(tid)
 
 
+@pytest.mark.parametrize("memo", ["1", "0"], ids=["memo", "first-seen"])
+def test_vcfs_sorted_per_contig(engine, oracle, monkeypatch, memo):
+    """A VCF of several contigs is sorted PER CONTIG: POS restarts with every CHROM, and the reference never compares CHROM
+    (extract_TP_FP_SNPs.py:47: the pattern is POS . REF ALT), so the contigs share one position space and a key may repeat across
+    them (such input fell to the radix sort -- a bucket's pieces are long, one per contig, and three of them on
+    one sub-region were an overflow).  Synthetic VCFs of 24 ascending runs (qm_synth_cfg.shuffled = 24; the device's columns equal
+    oracle/synth.py's), ragged hand-made ones with keys REPEATED across the runs (the cross-run counts TP_R / FP_R / U(t)), against the
+    oracle; the generated ones also against the same records in one ascending run.  Nothing takes the radix sort."""
+    from oracle.synth import synth_truth_keys, synth_vcf_columns
+    monkeypatch.setenv("QM_MEMO", memo)
+    L, T, N = 5_000_000, 100_000, 1_000_000
+    tid = engine.truth_synth(L, T, 3)
+    tk = synth_truth_keys(L, T, 3)
+    rows = {}
+    for runs in (0, 24):
+        b = engine.batch([N, N // 3, N], [tid] * 3)
+        b.synth(L, T, 3, 3000, shuffled=runs)
+        for rep in range(2):
+            b.run(); b.finish()
+        rows[runs] = (b.roc(), b.scalars()[:, :5].copy(), b.global_counts())
+        if runs:
+            ps = b.path_stats()
+            assert ps["unsorted"] == 3 and ps["radix"] == 0 and ps["radix_after_overflow"] == 0, ps
+            want = synth_vcf_columns(L, N // 3, T, 3, 3001, shuffled=24)
+            cols = b.columns(1)
+            assert all(np.array_equal(g, w) for g, w in zip(cols, want))
+            assert int((np.diff(cols[0]) < 0).sum()) == 23
+            for v in (0, 1):
+                cols = b.columns(v)
+                cls, oroc, sc = oracle.classify_columns(*cols, *tk)
+                assert np.array_equal(b.cls(v), cls) and np.array_equal(rows[runs][0][v], oroc)
+                assert [int(x) for x in rows[runs][1][v]] == [sc[k] for k in ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R")]
+                idx = b.idx(v)
+                assert np.array_equal(idx[:sc["tp_lines"]], np.nonzero(cls == 3)[0]) and np.array_equal(idx[len(cls) - sc["fp_lines"]:], np.nonzero(cls == 1)[0])
+        b.close()
+    for k in range(3):
+        assert np.array_equal(rows[0][k], rows[24][k]), k
+    engine.truth_release(tid)
+    # hand-made: contigs of ragged sizes whose keys repeat across contigs (and inside one), truth keys hit from several contigs
+    rng = np.random.default_rng(77)
+    Ls = 300_000
+    truth = random_truth(rng, 9_000, Ls)
+    tid2 = engine.truth_load(*truth)
+    cols = []
+    for n_contigs, n in ((2, 20_000), (7, 60_000), (31, 200_000), (3, 4_100)):
+        parts = [random_columns(rng, max(1, int(n * w)), Ls, truth) for w in rng.dirichlet(np.ones(n_contigs))]
+        parts.append(tuple(a[: len(a) // 2].copy() for a in parts[0]))           # a contig that repeats half of another one's records
+        cols.append(tuple(np.concatenate([p[k] for p in parts]) for k in range(5)))
+    b = engine.batch([len(c[0]) for c in cols], [tid2] * len(cols))
+    for v, c in enumerate(cols):
+        b.upload(v, *c)
+    for rep in range(2):
+        b.run(); b.finish()
+        roc, scal = b.roc(), b.scalars()
+        for v, c in enumerate(cols):
+            cls, oroc, sc = oracle.classify_columns(*c, *truth)
+            assert np.array_equal(b.cls(v), cls) and np.array_equal(roc[v], oroc), (rep, v)
+            assert [int(x) for x in scal[v][:5]] == [sc[k] for k in ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R")], (rep, v)
+    b.close()
+    engine.truth_release(tid2)
+
+
 @pytest.mark.parametrize("memo", ["1", "0"], ids=["memo", "no-memo"])
 def test_a_batch_remembers_which_vcfs_were_out_of_order_until_their_columns_change(engine, oracle, monkeypatch, memo):
     """What a finish found stays known to the batch while the columns stay the same: on the next run the VCFs found out of order
