@@ -829,7 +829,7 @@ def test_vcfs_sorted_per_contig(engine, oracle, monkeypatch, memo):
     tk = synth_truth_keys(L, T, 3)
     rows = {}
     for runs in (0, 24):
-        b = engine.batch([N, N // 3, N], [tid] * 3)
+        b = engine.batch([N, N // 2, N], [tid] * 3)
         b.synth(L, T, 3, 3000, shuffled=runs)
         for rep in range(2):
             b.run(); b.finish()
@@ -837,7 +837,7 @@ def test_vcfs_sorted_per_contig(engine, oracle, monkeypatch, memo):
         if runs:
             ps = b.path_stats()
             assert ps["unsorted"] == 3 and ps["radix"] == 0 and ps["radix_after_overflow"] == 0, ps
-            want = synth_vcf_columns(L, N // 3, T, 3, 3001, shuffled=24)
+            want = synth_vcf_columns(L, N // 2, T, 3, 3001, shuffled=24)
             cols = b.columns(1)
             assert all(np.array_equal(g, w) for g, w in zip(cols, want))
             assert int((np.diff(cols[0]) < 0).sum()) == 23
