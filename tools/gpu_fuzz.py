@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity hunt: many small batches of adversarial shape through the engine (C ABI) against the
 oracle.  Shapes: runs of equal positions straddling rounds / tiles / spans, dense truth against sparse
-VCFs (oversize slices), many truth entries per position, unsorted VCFs mixed with sorted ones, n_bins < 256,
+VCFs (oversize slices), many truth entries per position, unsorted and per-contig-sorted VCFs mixed with sorted ones, n_bins < 256,
 saturated QUALs, records without keys, non-'.' IDs -- in both the default and the allele-extended mode.
 usage: python3 tools/gpu_fuzz.py [rounds] [seed]"""
 import os
@@ -68,6 +68,10 @@ def run(rounds, seed, eng=None):
         flags = passed.astype(np.uint8) | ((rng.random(n) > 0.07).astype(np.uint8) << 1) | ((rng.random(n) < 0.03).astype(np.uint8) << 2)
         if sorted_ and n:
             o = np.argsort(pos, kind="stable")
+            if sorted_ > 1 and n > 1:      # sorted PER CONTIG: `sorted_` ascending runs of random lengths one behind the other (the runs path)
+                cuts = np.sort(rng.choice(np.arange(1, n), size=min(sorted_ - 1, n - 1), replace=False))
+                o = np.concatenate([np.sort(part) for part in np.split(rng.permutation(n), cuts)])
+                o = np.concatenate([part[np.argsort(pos[part], kind="stable")] for part in np.split(o, cuts)])
             pos, ref, alt, qual, flags = pos[o], ref[o], alt[o], qual[o], flags[o]
         c = lambda a, dt: np.ascontiguousarray(a, dt)
         return c(pos, np.int32), c(ref, np.int32), c(alt, np.int32), c(qual, np.float32), c(flags, np.uint8)
@@ -89,7 +93,9 @@ def run(rounds, seed, eng=None):
         cols = []
         for v in range(nv):
             n = int(rng.choice([0, 1, 63, 64, 255, 256, 257, 1023, 1024, 1025, 4096, 16383, 16384, 16385, 33000, 70000]))
-            cols.append(make_vcf(n, L, truth, ext, nb, rng.random() < 0.75, int(rng.integers(0, 4))))
+            how = rng.random()             # in position order / shuffled / sorted per contig (2 ... 100 runs; beyond 64 the scatter takes them)
+            order = 1 if how < 0.6 else 0 if how < 0.8 else int(rng.choice([2, 3, 7, 24, 63, 64, 65, 100]))
+            cols.append(make_vcf(n, L, truth, ext, nb, order, int(rng.integers(0, 4))))
         try:
             res, glob = eng.classify_batch(cols, [tid] * nv, n_bins=nb, alleles=ext)
         except q.QmvtError as e:
