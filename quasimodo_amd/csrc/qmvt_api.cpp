@@ -502,7 +502,12 @@ struct qm_batch {
   int32_t* runs_bnd = nullptr;        // [segments of the chunk][RUNS_MAX][257]
   uint32_t *runs_n = nullptr, *runs_sflags = nullptr;
   int64_t cap_runs_bnd = 0, cap_runs_n = 0, cap_runs_sflags = 0;
+  SortSeg* runs_psegs = nullptr;      // runs_probe's own segment table and tile map (it runs in front of the chunks and must not touch theirs)
+  int32_t* runs_ptile = nullptr;
+  int64_t cap_runs_psegs = 0, cap_runs_ptile = 0;
+  std::vector<int> lastp_vs;          // ... as they are on the device
   std::vector<int> lastr_vs;          // runs_chunk: the chunk whose tables are on the device
+  std::vector<uint32_t> lastr_geo;    // ... and the highest positions its bucket geometry was made from
   int lastr_nkt = 0, lastr_lb = 0, lastr_nbk = 0;
   int n_known = 0;
   bool known_dirty = false;           // the device copy is stale
@@ -536,7 +541,7 @@ static void batch_free(qm_batch* b) {
                   b->tile_tp_off, b->tile_fp_off, b->vcf_tot, b->span_hist, b->span_scal, b->vcf_flags, b->vcf_posor, b->bk_hist, b->bk_scal, b->d_bk_vcfs, b->bk_ent, b->bk_cursor, b->d_bk_tile_seg, b->bk_rows, b->bk_xent, b->bk_xcursor, b->bk_xrows, b->bk_roc, b->bk_rscal, b->bk_vflags, b->p_segs, b->p_tile_seg, b->p_cnt, b->p_off, b->p_half, b->p_cursor, b->p_flags, b->p_ent, b->d_vsegs, b->d_vparts, b->rs_roc, b->rs_scal, b->rs_flags, b->roc, b->global_acc,
                   b->scalars, b->d_vcfs, b->d_spans, b->d_tile_vcf, b->cls_scratch, b->sk[0], b->sk[1], b->sv[0],
                   b->sv[1], b->si[0], b->si[1], b->shist, b->sorbits, b->d_segs, b->d_tile_seg, b->d_ktile_seg, b->d_ktile_local, b->d_known,
-                  b->runs_cnt, b->runs_idx, b->runs_maxpos, b->runs_vflags, b->runs_bnd, b->runs_n, b->runs_sflags};
+                  b->runs_cnt, b->runs_idx, b->runs_maxpos, b->runs_vflags, b->runs_bnd, b->runs_n, b->runs_sflags, b->runs_psegs, b->runs_ptile};
   for (void* p : ptrs) (void)hipFree(p);
   if (b->h_summary) (void)hipHostFree(b->h_summary);
   for (auto& r : b->ev) for (auto& e : r) if (e) (void)hipEventDestroy(e);
@@ -1780,32 +1785,46 @@ static int runs_probe(qm_batch* b, const std::vector<int>& cand, hipStream_t st)
     if (rc != QM_OK) return rc;
     b->dev_bytes += (int64_t)b->n_vcf * (3 + RUNS_MAX) * 4;
   }
-  std::vector<SortSeg> segs((size_t)nseg);
-  std::vector<int32_t> tile_seg;
   int64_t nbt = 0;
-  for (int i = 0; i < nseg; ++i) {
-    const VcfDesc& d = b->L.vcfs[(size_t)todo[(size_t)i]];
-    SortSeg& g = segs[(size_t)i];
-    memset(&g, 0, sizeof g);
-    g.src_off = d.off; g.n = d.n; g.main_vcf = todo[(size_t)i]; g.sub_vcf = i; g.bk_tile0 = (int32_t)nbt;
-    const int64_t t = (d.n + BK_TILE - 1) / BK_TILE;
-    tile_seg.insert(tile_seg.end(), (size_t)t, (int32_t)i);
-    nbt += t;
-  }
+  for (int v : todo) nbt += (b->L.vcfs[(size_t)v].n + BK_TILE - 1) / BK_TILE;
   if (nbt > INT32_MAX) return fail(QM_E_LIMIT, "runs path: too many tiles");
-  int64_t cap;
-  { cap = b->cap_segs; rc = regrow(&b->d_segs, &cap, (int64_t)nseg, &b->dev_bytes); b->cap_segs = (int)cap; }
-  if (rc == QM_OK) rc = regrow(&b->d_bk_tile_seg, &b->cap_bk_tiles, nbt, &b->dev_bytes);
-  if (rc != QM_OK) return rc;
-  b->last_segs.clear(); b->bk_tiles_valid = false; b->bk_fake_valid = false; b->last2_vs.clear(); b->lastx_vs.clear(); b->lastr_vs.clear();   // (the tables of every path share these arrays)
-  HIPCHK(hipMemcpyAsync(b->d_segs, segs.data(), sizeof(SortSeg) * segs.size(), hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemcpyAsync(b->d_bk_tile_seg, tile_seg.data(), 4 * tile_seg.size(), hipMemcpyHostToDevice, st));
-  HIPCHK(hipMemsetAsync(b->runs_cnt, 0, (size_t)b->n_vcf * 4, st));   // (only the probed VCFs' words are read back)
-  HIPCHK(hipMemsetAsync(b->runs_maxpos, 0, (size_t)b->n_vcf * 4, st));
-  HIPCHK(hipMemsetAsync(b->runs_vflags, 0, (size_t)b->n_vcf * 4, st));
+  if (b->lastp_vs != todo) {   // (a first-seen step over the same columns probes the same VCFs again: the tables stay)
+    std::vector<SortSeg> segs((size_t)nseg);
+    std::vector<int32_t> tile_seg;
+    int64_t t0 = 0;
+    for (int i = 0; i < nseg; ++i) {
+      const VcfDesc& d = b->L.vcfs[(size_t)todo[(size_t)i]];
+      SortSeg& g = segs[(size_t)i];
+      memset(&g, 0, sizeof g);
+      g.src_off = d.off; g.n = d.n; g.main_vcf = todo[(size_t)i]; g.sub_vcf = i; g.bk_tile0 = (int32_t)t0;
+      const int64_t t = (d.n + BK_TILE - 1) / BK_TILE;
+      tile_seg.insert(tile_seg.end(), (size_t)t, (int32_t)i);
+      t0 += t;
+    }
+    b->lastp_vs.clear();
+    rc = regrow(&b->runs_psegs, &b->cap_runs_psegs, (int64_t)nseg, &b->dev_bytes);
+    if (rc == QM_OK) rc = regrow(&b->runs_ptile, &b->cap_runs_ptile, nbt, &b->dev_bytes);
+    if (rc != QM_OK) return rc;
+    HIPCHK(hipMemcpyAsync(b->runs_psegs, segs.data(), sizeof(SortSeg) * segs.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b->runs_ptile, tile_seg.data(), 4 * tile_seg.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));   // the host tables die with this block
+    b->lastp_vs = todo;
+  }
+  // the counters of the probed VCFs start at zero; what is known of the others stays on the device (k_runs_prepare reads it every step)
+  if (nseg == b->n_vcf) {
+    HIPCHK(hipMemsetAsync(b->runs_cnt, 0, (size_t)b->n_vcf * 4, st));
+    HIPCHK(hipMemsetAsync(b->runs_maxpos, 0, (size_t)b->n_vcf * 4, st));
+    HIPCHK(hipMemsetAsync(b->runs_vflags, 0, (size_t)b->n_vcf * 4, st));
+  } else {
+    for (int v : todo) {
+      HIPCHK(hipMemsetAsync(b->runs_cnt + v, 0, 4, st));
+      HIPCHK(hipMemsetAsync(b->runs_maxpos + v, 0, 4, st));
+      HIPCHK(hipMemsetAsync(b->runs_vflags + v, 0, 4, st));
+    }
+  }
   RunsParams P;
   memset(&P, 0, sizeof P);
-  P.segs = b->d_segs; P.tile_seg = b->d_bk_tile_seg; P.pos = b->pos; P.cnt = b->runs_cnt; P.idx = b->runs_idx; P.maxpos = b->runs_maxpos; P.vflags = b->runs_vflags;
+  P.segs = b->runs_psegs; P.tile_seg = b->runs_ptile; P.pos = b->pos; P.cnt = b->runs_cnt; P.idx = b->runs_idx; P.maxpos = b->runs_maxpos; P.vflags = b->runs_vflags;
   launch_runs_find(P, (int)nbt, st);
   HIPCHK(hipGetLastError());
   std::vector<uint32_t> cnt((size_t)b->n_vcf), mx((size_t)b->n_vcf), fl((size_t)b->n_vcf);
@@ -1845,7 +1864,9 @@ static int runs_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   const int nseg = (int)vs.size();
   int rc = ensure_bucket_rows(b, nseg);
   if (rc != QM_OK) return rc;
-  const bool same = memo_on() && !b->lastr_vs.empty() && b->lastr_vs == vs;   // the tables of this chunk are still on the device
+  std::vector<uint32_t> geo((size_t)nseg);
+  for (int i = 0; i < nseg; ++i) geo[(size_t)i] = b->known_maxpos[(size_t)vs[(size_t)i]];
+  const bool same = !b->lastr_vs.empty() && b->lastr_vs == vs && b->lastr_geo == geo;   // the tables of this chunk are still on the device
   int nkt = b->lastr_nkt, lb_all = b->lastr_lb, nbk_all = b->lastr_nbk;
   if (!same) {
     std::vector<SortSeg> segs((size_t)nseg);
@@ -1899,7 +1920,7 @@ static int runs_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     HIPCHK(hipMemcpyAsync(b->d_ktile_local, ktile_local.data(), 4 * ktile_local.size(), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(b->d_bk_vcfs, fake.data(), sizeof(VcfDesc) * fake.size(), hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));   // the host tables die with this block
-    b->lastr_vs = vs; b->lastr_nkt = nkt; b->lastr_lb = lb_all; b->lastr_nbk = nbk_all;
+    b->lastr_vs = vs; b->lastr_geo = geo; b->lastr_nkt = nkt; b->lastr_lb = lb_all; b->lastr_nbk = nbk_all;
   }
   HashParams H;
   memset((void*)&H, 0, sizeof H);

@@ -2762,10 +2762,11 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(RUNS
   int ntrips = (int)((nw + 255u) >> 8);                             // wave-uniform
   uint32_t vmask_runs = 0;                                          // RUNS: the lane's slots that hold a record of the bucket
   if constexpr (RUNS) {
-    // wave w, trip g, lanes 8 k .. 8 k + 7: mask word (w * PER / 4 + g) * 8 + k of the bucket's ranges, four records per lane
+    // trip g of wave w, lanes 8 k .. 8 k + 7: mask word (8 g + w) * 8 + k of the bucket's ranges, four records per lane -- trip
+    // by trip across the waves, so that all eight of them are busy for the same number of trips
     const uint32_t total = over ? 0u : nrec;
-    const int first = wave * (PER / 4) * 8;
-    ntrips = (int)total <= first ? 0 : ((int)total - first + 7) >> 3;
+    const int first = wave * 8;
+    ntrips = (int)total <= first ? 0 : ((int)total - first + 63) >> 6;
     ntrips = ntrips > PER / 4 ? PER / 4 : ntrips;
     typedef int v4i __attribute__((ext_vector_type(4)));
     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -2775,7 +2776,7 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(RUNS
     int cbase[PER / 4], clo[PER / 4], chi[PER / 4];
 #pragma unroll
     for (int g = 0; g < PER / 4; ++g) {          // all loads first
-      const uint32_t gi = (uint32_t)(first + 8 * g + (lane >> 3));
+      const uint32_t gi = (uint32_t)(first + 64 * g + (lane >> 3));
       cbase[g] = 0; clo[g] = 0; chi[g] = 0; cf[g] = 0u;
       cp[g] = v4i{0, 0, 0, 0}; cr[g] = v4i{4, 4, 4, 4}; ca[g] = v4i{4, 4, 4, 4}; cq[g] = v4f{0.f, 0.f, 0.f, 0.f};
       if (gi < total) {
@@ -3090,6 +3091,9 @@ __global__ __launch_bounds__(512) void k_runs_find(RunsParams P) {
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int64_t i0 = (int64_t)(bid - sg.bk_tile0) * BK_TILE + (int64_t)tid * (BK_TILE / 512);
   constexpr int PT = BK_TILE / 512;    // 8 records per thread
+  // a VCF that has shown more descents than the path takes is not looked at any further (a shuffled VCF: half a million of them,
+  // every one an atomic on the VCF's one counter)
+  if (__hip_atomic_load(&P.cnt[sg.main_vcf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)RUNS_MAX) return;
   typedef int v4i __attribute__((ext_vector_type(4)));
   int p[PT];
 #pragma unroll
@@ -3100,25 +3104,23 @@ __global__ __launch_bounds__(512) void k_runs_find(RunsParams P) {
   }
   int prev = __shfl_up(p[PT - 1], 1);
   if (lane == 0) prev = i0 > 0 && i0 < sg.n ? P.pos[sg.src_off + i0 - 1] : INT32_MIN;
-  uint32_t mx = 0, bad = 0;
+  // the highest position of a VCF of ascending runs is the END of one of them: the record in front of a descent, or the last
+  // record -- a few atomics per VCF (a maximum per wave would be an atomic per wave on ascending data: every wave sees a new one)
+  uint32_t bad = 0;
 #pragma unroll
   for (int j = 0; j < PT; ++j) {
     if (i0 + j < sg.n) {
       bad |= (uint32_t)p[j] >> 28;
-      mx = (uint32_t)p[j] > mx ? (uint32_t)p[j] : mx;
       if (p[j] < prev) {
         const uint32_t slot = atomicAdd(&P.cnt[sg.main_vcf], 1u);
         if (slot < (uint32_t)(RUNS_MAX - 1)) P.idx[(size_t)sg.main_vcf * RUNS_MAX + slot] = (uint32_t)(i0 + j);
+        if (prev >= 0) atomicMax(&P.maxpos[sg.main_vcf], (uint32_t)prev);
       }
+      if (i0 + j == sg.n - 1 && p[j] >= 0) atomicMax(&P.maxpos[sg.main_vcf], (uint32_t)p[j]);
       prev = p[j];
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)mx, o); mx = y > mx ? y : mx; bad |= (uint32_t)__shfl_xor((int)bad, o); }
-  if (lane == 0) {
-    if (!bad && mx > __hip_atomic_load(&P.maxpos[sg.main_vcf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&P.maxpos[sg.main_vcf], mx);
-    if (bad) atomicOr(&P.vflags[sg.main_vcf], SPANF_BADPOS);
-  }
+  if (ballot64(bad != 0u) != 0ull && lane == 0) atomicOr(&P.vflags[sg.main_vcf], SPANF_BADPOS);
 }
 
 __global__ __launch_bounds__(320) void k_runs_prepare(RunsParams P) {
