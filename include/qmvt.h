@@ -232,8 +232,7 @@ enum {
   QM_PATH_BUCKET_CHUNKS = 5, QM_PATH_OVERFLOW_CHUNKS = 6, QM_PATH_RADIX_CHUNKS = 7,
   QM_PATH_DIRECT2 = 8,               /* ... too large for 256 buckets: dealt to partitions of 2^27 keys by a first scatter (two levels), then as QM_PATH_DIRECT */
   QM_PATH_PARTITIONS = 9,            /* ... too large or too wide for 256 buckets: every partition of 2^27 keys a segment of ONE scatter that reads the columns */
-  QM_PATH_RUNS = 10,                 /* ... a few ascending runs (sorted per contig): joined bucket by bucket straight from the columns, no scatter */
-  QM_N_PATH_STATS = 11
+  QM_N_PATH_STATS = 10
 };
 int qm_batch_path_stats(qm_batch* b, int64_t* out /*[QM_N_PATH_STATS]*/);
 /* The same counters summed over every qm_batch_finish of every batch of the context since qm_init, the batches that

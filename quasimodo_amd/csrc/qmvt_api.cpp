@@ -74,7 +74,7 @@ struct qm_ctx {
   std::vector<Truth> truths;
   TruthDev* d_truths = nullptr;  // device copy of the descriptors
   int d_truths_cap = 0;
-  int64_t path_total[QM_N_PATH_STATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // qm_path_stats_total: every finish of every batch of this context
+  int64_t path_total[QM_N_PATH_STATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // qm_path_stats_total: every finish of every batch of this context
 };
 
 template <typename T>
@@ -477,7 +477,7 @@ struct qm_batch {
   uint32_t* h_summary = nullptr;
   uint32_t* d_summary = nullptr;
   // where the unsorted VCFs of the last qm_batch_finish went (qm_batch_path_stats)
-  int64_t path_stats[QM_N_PATH_STATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t path_stats[QM_N_PATH_STATS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   // What a finish found stays known while the columns stay the same (only qm_batch_upload* / qm_batch_synth write them): a VCF found out
   // of order is not streamed by the optimistic pass again, and qm_batch_finish queues its bucket path behind the run without first
   // waiting for the flags (a host round trip of ~ 0.15 ms per step).  QM_MEMO=0: off.
@@ -495,20 +495,6 @@ struct qm_batch {
   // what they really hold.  Cleared with the batch's memory.
   std::vector<uint32_t> posor_seen;
   std::vector<uint32_t> known_nbk;    // 1 + the highest bucket its records reached on the one-level bucket path (0: not known)
-  // the runs path (VCFs sorted per contig: runs_probe / runs_chunk).  What k_runs_find found stays valid while the columns do:
-  std::vector<int32_t> known_runs;    // per VCF: places where its positions step down, -1 = not looked at
-  std::vector<uint32_t> known_maxpos; // its highest position
-  uint32_t *runs_cnt = nullptr, *runs_idx = nullptr, *runs_maxpos = nullptr, *runs_vflags = nullptr;   // [n_vcf] (idx: [n_vcf][RUNS_MAX])
-  int32_t* runs_bnd = nullptr;        // [segments of the chunk][RUNS_MAX][257]
-  uint32_t *runs_n = nullptr, *runs_sflags = nullptr;
-  int64_t cap_runs_bnd = 0, cap_runs_n = 0, cap_runs_sflags = 0;
-  SortSeg* runs_psegs = nullptr;      // runs_probe's own segment table and tile map (it runs in front of the chunks and must not touch theirs)
-  int32_t* runs_ptile = nullptr;
-  int64_t cap_runs_psegs = 0, cap_runs_ptile = 0;
-  std::vector<int> lastp_vs;          // ... as they are on the device
-  std::vector<int> lastr_vs;          // runs_chunk: the chunk whose tables are on the device
-  std::vector<uint32_t> lastr_geo;    // ... and the highest positions its bucket geometry was made from
-  int lastr_nkt = 0, lastr_lb = 0, lastr_nbk = 0;
   int n_known = 0;
   bool known_dirty = false;           // the device copy is stale
   uint8_t* d_known = nullptr;
@@ -524,8 +510,6 @@ static bool flags_event_on() {   // QM_FLAGS_WAIT=stream: qm_batch_finish waits 
   return !(e && strcmp(e, "stream") == 0);
 }
 static void forget_known(qm_batch* b, int v) {   // v < 0: every VCF
-  if (!b->known_runs.empty()) { if (v < 0) std::fill(b->known_runs.begin(), b->known_runs.end(), -1); else b->known_runs[(size_t)v] = -1; }
-  b->lastr_vs.clear();
   if (!b->posor_seen.empty()) { if (v < 0) std::fill(b->posor_seen.begin(), b->posor_seen.end(), 0u); else b->posor_seen[(size_t)v] = 0u; }
   if (!b->known_nbk.empty()) { if (v < 0) std::fill(b->known_nbk.begin(), b->known_nbk.end(), 0u); else b->known_nbk[(size_t)v] = 0u; }
   if (b->known.empty() || b->n_known == 0) return;
@@ -540,8 +524,7 @@ static void batch_free(qm_batch* b) {
   void* ptrs[] = {b->pkey, b->pinf, b->pos, b->ref, b->alt, b->qual, b->flags, b->mask_pass, b->mask_tp, b->idx, b->tile_tp, b->tile_fp,
                   b->tile_tp_off, b->tile_fp_off, b->vcf_tot, b->span_hist, b->span_scal, b->vcf_flags, b->vcf_posor, b->bk_hist, b->bk_scal, b->d_bk_vcfs, b->bk_ent, b->bk_cursor, b->d_bk_tile_seg, b->bk_rows, b->bk_xent, b->bk_xcursor, b->bk_xrows, b->bk_roc, b->bk_rscal, b->bk_vflags, b->p_segs, b->p_tile_seg, b->p_cnt, b->p_off, b->p_half, b->p_cursor, b->p_flags, b->p_ent, b->d_vsegs, b->d_vparts, b->rs_roc, b->rs_scal, b->rs_flags, b->roc, b->global_acc,
                   b->scalars, b->d_vcfs, b->d_spans, b->d_tile_vcf, b->cls_scratch, b->sk[0], b->sk[1], b->sv[0],
-                  b->sv[1], b->si[0], b->si[1], b->shist, b->sorbits, b->d_segs, b->d_tile_seg, b->d_ktile_seg, b->d_ktile_local, b->d_known,
-                  b->runs_cnt, b->runs_idx, b->runs_maxpos, b->runs_vflags, b->runs_bnd, b->runs_n, b->runs_sflags, b->runs_psegs, b->runs_ptile};
+                  b->sv[1], b->si[0], b->si[1], b->shist, b->sorbits, b->d_segs, b->d_tile_seg, b->d_ktile_seg, b->d_ktile_local, b->d_known};
   for (void* p : ptrs) (void)hipFree(p);
   if (b->h_summary) (void)hipHostFree(b->h_summary);
   for (auto& r : b->ev) for (auto& e : r) if (e) (void)hipEventDestroy(e);
@@ -1134,7 +1117,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     }
   }
   if (rc != QM_OK) return rc;
-  b->last2_vs.clear(); b->lastx_vs.clear(); b->lastr_vs.clear();   // (the two-level path and the partitions path keep their tables in the same arrays)
+  b->last2_vs.clear(); b->lastx_vs.clear();   // (the two-level path and the partitions path keep their tables in the same arrays)
   const bool same_tables = b->last_segs.size() == segs.size() && memcmp(b->last_segs.data(), segs.data(), sizeof(SortSeg) * segs.size()) == 0;
   if (!same_tables || (try_buckets && !b->bk_tiles_valid)) {
     build_tile_maps();
@@ -1508,7 +1491,7 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   const int nseg = (int)segs.size();
   if (nbt > INT32_MAX || nkt > INT32_MAX) return fail(QM_E_LIMIT, "bucket path: too many tiles");
   // --- the arrays of the one-level path, sized for the level-2 segments (its cached tables are gone after this)
-  b->last_segs.clear(); b->bk_tiles_valid = false; b->bk_fake_valid = false; b->lastx_vs.clear(); b->lastr_vs.clear();
+  b->last_segs.clear(); b->bk_tiles_valid = false; b->bk_fake_valid = false; b->lastx_vs.clear();
   int64_t cap;
   if (rc == QM_OK) { cap = b->cap_segs; rc = regrow(&b->d_segs, &cap, (int64_t)nseg, &b->dev_bytes); b->cap_segs = (int)cap; }
   if (rc == QM_OK) rc = regrow(&b->d_vsegs, &b->cap_vsegs, (int64_t)nv, &b->dev_bytes);
@@ -1677,7 +1660,7 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   nseg = (int)segs.size();
   if (nbt > INT32_MAX || nkt > INT32_MAX) return fail(QM_E_LIMIT, "bucket path: too many tiles");
   // the arrays of the one-level path, sized for these segments (its cached tables, and the two-level path's, are gone after this)
-  b->last_segs.clear(); b->bk_tiles_valid = false; b->bk_fake_valid = false; b->last2_vs.clear(); b->lastx_vs.clear(); b->lastr_vs.clear();
+  b->last_segs.clear(); b->bk_tiles_valid = false; b->bk_fake_valid = false; b->last2_vs.clear(); b->lastx_vs.clear();
   int rc = QM_OK;
   int64_t cap;
   { cap = b->cap_segs; rc = regrow(&b->d_segs, &cap, (int64_t)nseg, &b->dev_bytes); b->cap_segs = (int)cap; }
@@ -1749,206 +1732,12 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   b->path_stats[QM_PATH_BUCKET_CHUNKS] += 1;
   for (int i = 0; i < nseg; ++i) {
     if (hfl[(size_t)i] & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", b->lastx_seg_vcf[(size_t)i]);
-    if (hfl[(size_t)i] & SPANF_OVERFLOW) { b->path_stats[QM_PATH_OVERFLOW_CHUNKS] += 1; b->lastx_vs.clear(); b->lastr_vs.clear(); return QM_OK; }   // a bucket did not fit: the radix sort redoes the chunk
+    if (hfl[(size_t)i] & SPANF_OVERFLOW) { b->path_stats[QM_PATH_OVERFLOW_CHUNKS] += 1; b->lastx_vs.clear(); return QM_OK; }   // a bucket did not fit: the radix sort redoes the chunk
   }
   launch_sort_copy_rows(b->d_vsegs, nv, b->bk_roc, b->bk_rscal, b->roc, b->scalars, b->n_bins, st, global, b->d_vcfs, b->d_vparts);
   launch_tile_counts(b->d_vsegs, b->d_ktile_seg, b->d_ktile_local, (int)nkt, b->mask_pass, b->mask_tp, b->tile_tp, b->tile_fp, st);
   HIPCHK(hipGetLastError());
   b->path_stats[QM_PATH_PARTITIONS] += nv;
-  *taken = true;
-  return QM_OK;
-}
-
-// ---- the runs path: unsorted VCFs that consist of a FEW ascending runs (sorted per contig) ----
-// POS restarts with every CHROM, and the reference never compares CHROM (extract_TP_FP_SNPs.py:47): such a VCF is out of order as a
-// whole, but the records of one position bucket are ONE contiguous range of every run.  No scatter: k_runs_find (once per set of
-// columns) finds where the positions step down and the highest position, k_runs_prepare (every step) turns that into a table of
-// bounds per (run, bucket) and clears the class masks, and k_join_lean<.., RUNS> joins every bucket straight from the columns.
-// QM_RUNS=0 switches the path off (tests, fuzz: the scatter takes these VCFs then).
-static bool runs_path_on() {
-  const char* e = getenv("QM_RUNS");
-  return !(e && atoi(e) == 0);
-}
-// looks at every VCF of `cand` whose runs are not known yet; afterwards known_runs / known_maxpos hold what k_runs_find found
-static int runs_probe(qm_batch* b, const std::vector<int>& cand, hipStream_t st) {
-  if (b->known_runs.empty()) { b->known_runs.assign((size_t)b->n_vcf, -1); b->known_maxpos.assign((size_t)b->n_vcf, 0u); }
-  std::vector<int> todo;
-  for (int v : cand) if (!memo_on() || b->known_runs[(size_t)v] < 0) todo.push_back(v);
-  if (todo.empty()) return QM_OK;
-  const int nseg = (int)todo.size();
-  int rc = QM_OK;
-  if (!b->runs_cnt) {
-    rc = dalloc(&b->runs_cnt, (size_t)b->n_vcf);
-    if (rc == QM_OK) rc = dalloc(&b->runs_idx, (size_t)b->n_vcf * RUNS_MAX);
-    if (rc == QM_OK) rc = dalloc(&b->runs_maxpos, (size_t)b->n_vcf);
-    if (rc == QM_OK) rc = dalloc(&b->runs_vflags, (size_t)b->n_vcf);
-    if (rc != QM_OK) return rc;
-    b->dev_bytes += (int64_t)b->n_vcf * (3 + RUNS_MAX) * 4;
-  }
-  int64_t nbt = 0;
-  for (int v : todo) nbt += (b->L.vcfs[(size_t)v].n + BK_TILE - 1) / BK_TILE;
-  if (nbt > INT32_MAX) return fail(QM_E_LIMIT, "runs path: too many tiles");
-  if (b->lastp_vs != todo) {   // (a first-seen step over the same columns probes the same VCFs again: the tables stay)
-    std::vector<SortSeg> segs((size_t)nseg);
-    std::vector<int32_t> tile_seg;
-    int64_t t0 = 0;
-    for (int i = 0; i < nseg; ++i) {
-      const VcfDesc& d = b->L.vcfs[(size_t)todo[(size_t)i]];
-      SortSeg& g = segs[(size_t)i];
-      memset(&g, 0, sizeof g);
-      g.src_off = d.off; g.n = d.n; g.main_vcf = todo[(size_t)i]; g.sub_vcf = i; g.bk_tile0 = (int32_t)t0;
-      const int64_t t = (d.n + BK_TILE - 1) / BK_TILE;
-      tile_seg.insert(tile_seg.end(), (size_t)t, (int32_t)i);
-      t0 += t;
-    }
-    b->lastp_vs.clear();
-    rc = regrow(&b->runs_psegs, &b->cap_runs_psegs, (int64_t)nseg, &b->dev_bytes);
-    if (rc == QM_OK) rc = regrow(&b->runs_ptile, &b->cap_runs_ptile, nbt, &b->dev_bytes);
-    if (rc != QM_OK) return rc;
-    HIPCHK(hipMemcpyAsync(b->runs_psegs, segs.data(), sizeof(SortSeg) * segs.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(b->runs_ptile, tile_seg.data(), 4 * tile_seg.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));   // the host tables die with this block
-    b->lastp_vs = todo;
-  }
-  // the counters of the probed VCFs start at zero; what is known of the others stays on the device (k_runs_prepare reads it every step)
-  if (nseg == b->n_vcf) {
-    HIPCHK(hipMemsetAsync(b->runs_cnt, 0, (size_t)b->n_vcf * 4, st));
-    HIPCHK(hipMemsetAsync(b->runs_maxpos, 0, (size_t)b->n_vcf * 4, st));
-    HIPCHK(hipMemsetAsync(b->runs_vflags, 0, (size_t)b->n_vcf * 4, st));
-  } else {
-    for (int v : todo) {
-      HIPCHK(hipMemsetAsync(b->runs_cnt + v, 0, 4, st));
-      HIPCHK(hipMemsetAsync(b->runs_maxpos + v, 0, 4, st));
-      HIPCHK(hipMemsetAsync(b->runs_vflags + v, 0, 4, st));
-    }
-  }
-  RunsParams P;
-  memset(&P, 0, sizeof P);
-  P.segs = b->runs_psegs; P.tile_seg = b->runs_ptile; P.pos = b->pos; P.cnt = b->runs_cnt; P.idx = b->runs_idx; P.maxpos = b->runs_maxpos; P.vflags = b->runs_vflags;
-  launch_runs_find(P, (int)nbt, st);
-  HIPCHK(hipGetLastError());
-  std::vector<uint32_t> cnt((size_t)b->n_vcf), mx((size_t)b->n_vcf), fl((size_t)b->n_vcf);
-  HIPCHK(hipMemcpyAsync(cnt.data(), b->runs_cnt, 4 * cnt.size(), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(mx.data(), b->runs_maxpos, 4 * mx.size(), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipMemcpyAsync(fl.data(), b->runs_vflags, 4 * fl.size(), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));   // (also: the host tables above may go)
-  for (int v : todo) {
-    if (fl[(size_t)v] & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", v);
-    b->known_runs[(size_t)v] = (int32_t)std::min<uint32_t>(cnt[(size_t)v], 1u << 30);
-    b->known_maxpos[(size_t)v] = mx[(size_t)v];
-  }
-  return QM_OK;
-}
-// the bucket geometry of a VCF on the runs path, from its exact highest position (the scatter path works from an estimate)
-static void runs_geometry(uint32_t maxpos, int* pad, int* nbk) {
-  const uint32_t kor = (maxpos << 4) | 15u;
-  int msb = 31;
-  while (msb > 0 && !((kor >> msb) & 1u)) --msb;
-  *pad = std::max(4, msb - 7);
-  *nbk = std::min((int)(kor >> *pad) + 1, (int)HB_BUCKETS);
-}
-static bool runs_path_takes(const qm_batch* b, int v) {
-  if (b->ext || b->known_runs.empty()) return false;
-  const int32_t nd = b->known_runs[(size_t)v];
-  if (nd < 1 || nd > RUNS_MAX - 1) return false;
-  int pad, nbk;
-  runs_geometry(b->known_maxpos[(size_t)v], &pad, &nbk);
-  if (pad > DJ_MAX_SHIFT) return false;                                   // (the bit maps of the join)
-  // a bucket's records lie in (nd + 1) ranges whose end words are part empty: the workgroup holds 320 words of 32 records
-  const int64_t words = b->L.vcfs[(size_t)v].n / nbk / 32 + (nd + 1);
-  return words <= (int64_t)(LJ_WORDS_RUNS * 15 / 16);
-}
-// *taken = false: a bucket did not fit the join's registers (or its tables): the caller sends the chunk through the scatter
-static int runs_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, bool* taken) {
-  *taken = false;
-  const int nseg = (int)vs.size();
-  int rc = ensure_bucket_rows(b, nseg);
-  if (rc != QM_OK) return rc;
-  std::vector<uint32_t> geo((size_t)nseg);
-  for (int i = 0; i < nseg; ++i) geo[(size_t)i] = b->known_maxpos[(size_t)vs[(size_t)i]];
-  const bool same = !b->lastr_vs.empty() && b->lastr_vs == vs && b->lastr_geo == geo;   // the tables of this chunk are still on the device
-  int nkt = b->lastr_nkt, lb_all = b->lastr_lb, nbk_all = b->lastr_nbk;
-  if (!same) {
-    std::vector<SortSeg> segs((size_t)nseg);
-    std::vector<VcfDesc> fake((size_t)nseg);
-    std::vector<int32_t> ktile_seg, ktile_local;
-    int64_t nkt64 = 0;
-    lb_all = 0; nbk_all = 1;
-    for (int i = 0; i < nseg; ++i) {
-      const VcfDesc& d = b->L.vcfs[(size_t)vs[(size_t)i]];
-      SortSeg& g = segs[(size_t)i];
-      memset(&g, 0, sizeof g);
-      g.src_off = d.off; g.n = d.n; g.main_vcf = vs[(size_t)i]; g.sub_vcf = i; g.main_tile0 = d.tile0;
-      int pad, nbk;
-      runs_geometry(b->known_maxpos[(size_t)vs[(size_t)i]], &pad, &nbk);
-      g.pad = pad; g.nbk = nbk; g.key_base = 0u;
-      lb_all = std::max(lb_all, pad); nbk_all = std::max(nbk_all, nbk);
-      VcfDesc& f = fake[(size_t)i];
-      f = VcfDesc();
-      f.off = 0; f.n = d.n; f.truth = d.truth; f.tile0 = 0; f.ntiles = 0; f.span0 = i * HB_BUCKETS; f.nspans = nbk; f.pad = 0;
-      const size_t k0 = ktile_seg.size();
-      ktile_seg.insert(ktile_seg.end(), (size_t)d.ntiles, (int32_t)i);
-      ktile_local.resize(k0 + (size_t)d.ntiles);
-      for (int t = 0; t < d.ntiles; ++t) ktile_local[k0 + (size_t)t] = t;
-      nkt64 += d.ntiles;
-    }
-    if (nkt64 > INT32_MAX) return fail(QM_E_LIMIT, "runs path: too many tiles");
-    nkt = (int)nkt64;
-    b->last_segs.clear(); b->bk_tiles_valid = false; b->bk_fake_valid = false; b->last2_vs.clear(); b->lastx_vs.clear(); b->lastr_vs.clear();
-    int64_t cap;
-    { cap = b->cap_segs; rc = regrow(&b->d_segs, &cap, (int64_t)nseg, &b->dev_bytes); b->cap_segs = (int)cap; }
-    if (rc == QM_OK) {
-      cap = b->cap_ktiles; rc = regrow(&b->d_ktile_seg, &cap, (int64_t)nkt, &b->dev_bytes);
-      if (rc == QM_OK) { cap = b->cap_ktiles; rc = regrow(&b->d_ktile_local, &cap, (int64_t)nkt, &b->dev_bytes); }
-      if (rc == QM_OK) b->cap_ktiles = std::max(b->cap_ktiles, nkt);
-    }
-    {
-      const int64_t rows = (int64_t)nseg * HB_BUCKETS;
-      int64_t c1 = b->cap_bk_rows * SPAN_HIST_WORDS, c2 = b->cap_bk_rows * 8;
-      if (rc == QM_OK) rc = regrow(&b->bk_hist, &c1, rows * SPAN_HIST_WORDS, &b->dev_bytes);
-      if (rc == QM_OK) rc = regrow(&b->bk_scal, &c2, rows * 8, &b->dev_bytes);
-      if (rc == QM_OK) b->cap_bk_rows = std::max(b->cap_bk_rows, rows);
-      if (rc == QM_OK) rc = regrow(&b->d_bk_vcfs, &b->cap_bk_vcfs, (int64_t)nseg, &b->dev_bytes);
-      if (rc == QM_OK) rc = regrow(&b->bk_rows, &b->cap_bk_rowdesc, rows, &b->dev_bytes);
-      if (rc == QM_OK) rc = regrow(&b->runs_bnd, &b->cap_runs_bnd, (int64_t)nseg * RUNS_MAX * (HB_BUCKETS + 1), &b->dev_bytes);
-      if (rc == QM_OK) rc = regrow(&b->runs_n, &b->cap_runs_n, (int64_t)nseg, &b->dev_bytes);
-      if (rc == QM_OK) rc = regrow(&b->runs_sflags, &b->cap_runs_sflags, (int64_t)nseg, &b->dev_bytes);
-    }
-    if (rc != QM_OK) return rc;
-    HIPCHK(hipMemcpyAsync(b->d_segs, segs.data(), sizeof(SortSeg) * segs.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(b->d_ktile_seg, ktile_seg.data(), 4 * ktile_seg.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(b->d_ktile_local, ktile_local.data(), 4 * ktile_local.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(b->d_bk_vcfs, fake.data(), sizeof(VcfDesc) * fake.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));   // the host tables die with this block
-    b->lastr_vs = vs; b->lastr_geo = geo; b->lastr_nkt = nkt; b->lastr_lb = lb_all; b->lastr_nbk = nbk_all;
-  }
-  HashParams H;
-  memset((void*)&H, 0, sizeof H);
-  H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
-  H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.out_stride = HB_BUCKETS;
-  H.runs_bnd = b->runs_bnd; H.runs_n = b->runs_n; H.runs_flags = b->runs_sflags;
-  H.pos = b->pos; H.ref = b->ref; H.alt = b->alt; H.qual = b->qual; H.flags = b->flags; H.mask_pass32 = reinterpret_cast<uint32_t*>(b->mask_pass);
-  if (!same) launch_bucket_rows(H, nseg, st);   // (the descriptors depend on the segment table only)
-  RunsParams P;
-  memset(&P, 0, sizeof P);
-  P.segs = b->d_segs; P.pos = b->pos; P.cnt = b->runs_cnt; P.idx = b->runs_idx; P.maxpos = b->runs_maxpos; P.vflags = b->runs_vflags;
-  P.bnd = b->runs_bnd; P.runs_n = b->runs_n; P.seg_flags = b->runs_sflags; P.mask_pass = b->mask_pass; P.mask_tp = b->mask_tp;
-  launch_runs_prepare(P, nseg, st);
-  launch_join_runs(H, nseg, lb_all, nbk_all, st);
-  launch_finalize(bucket_rows_finalize(b, nullptr), nseg, st);
-  HIPCHK(hipGetLastError());
-  std::vector<uint32_t> hfl((size_t)nseg);
-  HIPCHK(hipMemcpyAsync(hfl.data(), b->bk_vflags, 4 * hfl.size(), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  b->path_stats[QM_PATH_BUCKET_CHUNKS] += 1;
-  for (int i = 0; i < nseg; ++i) {
-    if (hfl[(size_t)i] & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", vs[(size_t)i]);
-    if (hfl[(size_t)i] & SPANF_OVERFLOW) { b->path_stats[QM_PATH_OVERFLOW_CHUNKS] += 1; b->lastr_vs.clear(); return QM_OK; }   // a bucket did not fit: the scatter redoes the chunk
-  }
-  launch_sort_copy_rows(b->d_segs, nseg, b->bk_roc, b->bk_rscal, b->roc, b->scalars, b->n_bins, st, global, b->d_vcfs);
-  launch_tile_counts(b->d_segs, b->d_ktile_seg, b->d_ktile_local, nkt, b->mask_pass, b->mask_tp, b->tile_tp, b->tile_fp, st);
-  HIPCHK(hipGetLastError());
-  b->path_stats[QM_PATH_RUNS] += nseg;
   *taken = true;
   return QM_OK;
 }
@@ -1963,23 +1752,14 @@ static int redo_unsorted(qm_batch* b, const std::vector<int>& todo, const std::v
   // buckets hold 8 192 records at most) in chunks of their own, the others on the radix sort
   // kind 3: allele-extended VCFs in partitions read from the columns (bucketx_chunk)
   refresh_path_env();
-  std::vector<int> part[5];   // 4: the runs path (VCFs of a few ascending runs, joined from their columns)
+  std::vector<int> part[4];
   for (int v : todo) {
     const int64_t n = b->L.vcfs[(size_t)v].n;
     const bool force2 = g_penv.bucket2 == 2 && bucket2_takes(b, n);
     part[bucketx_takes(b, n, posor[(size_t)v]) ? 3 : force2 ? 2 : bucket_path_takes(b, n) ? 1 : bucket2_takes(b, n) ? 2 : 0].push_back(v);
   }
-  if (!b->ext && runs_path_on() && !part[1].empty()) {
-    // Which of the one-level candidates consist of a few ascending runs?  One look at their positions (4 bytes per record, once
-    // per set of columns), then they leave the scatter's list.
-    const int rc = runs_probe(b, part[1], st);
-    if (rc != QM_OK) return rc;
-    std::vector<int> rest;
-    for (int v : part[1]) (runs_path_takes(b, v) ? part[4] : rest).push_back(v);
-    part[1].swap(rest);
-  }
   const int64_t chunk_records = sort_chunk_records();
-  for (int kind = 4; kind >= 0; --kind) {
+  for (int kind = 3; kind >= 0; --kind) {
     std::vector<int> chunk;
     int64_t chunk_n = 0;
     for (size_t i = 0; i <= part[kind].size(); ++i) {
@@ -1990,10 +1770,7 @@ static int redo_unsorted(qm_batch* b, const std::vector<int>& todo, const std::v
       if (flush && !chunk.empty()) {
         int rc = QM_OK;
         bool taken = false;
-        if (kind == 4) {
-          rc = runs_chunk(b, chunk, st, b->last_global, &taken);
-          if (rc == QM_OK && !taken) rc = sort_chunk(b, chunk, st, b->last_global, posor, true);   // a bucket too full for the join's registers: the scatter
-        } else if (kind == 3) {
+        if (kind == 3) {
           rc = bucketx_chunk(b, chunk, st, b->last_global, posor, &taken);
           if (rc == QM_OK && !taken) { b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += (int64_t)chunk.size(); rc = sort_chunk(b, chunk, st, b->last_global, posor, false); b->path_stats[QM_PATH_RADIX] -= (int64_t)chunk.size(); }
         } else if (kind == 2) {

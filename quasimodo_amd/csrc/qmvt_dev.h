@@ -332,32 +332,6 @@ struct HashParams {
   const uint32_t* seg_maxd;   // or null: BucketScatterParams.seg_maxd of the scatter in front -- the workgroups of the buckets above leave at once (k_join_lean)
   uint32_t* zero = nullptr;   // k_bucket_rows only, or null: n_zero words it clears on the way (the cursors, flags and counts of the scatter behind it:
   uint32_t n_zero = 0;        // one dispatch instead of a memset's two in front of every chunk)
-  // the runs path (k_join_lean<.., RUNS = true>: VCFs sorted per contig, joined straight from their columns) -- null / unused otherwise
-  const int32_t* runs_bnd = nullptr;    // [n_seg][RUNS_MAX][257]: first record of run r whose key is at or above bucket d's first key
-  const uint32_t* runs_n = nullptr;     // [n_seg] ascending runs of the segment's VCF (<= RUNS_MAX)
-  const uint32_t* runs_flags = nullptr; // [n_seg] SPANF_* of the segment (k_runs_find)
-  const int32_t* pos = nullptr; const int32_t* ref = nullptr; const int32_t* alt = nullptr; const float* qual = nullptr; const uint8_t* flags = nullptr;
-  uint32_t* mask_pass32 = nullptr;      // main batch: kept bits in input order (cleared by k_runs_prepare)
-};
-// The runs path: an unsorted VCF that consists of a FEW ascending runs (a VCF sorted per contig: POS restarts with every CHROM,
-// and CHROM is never compared).  The records of one position bucket then are one contiguous range of every run -- the scatter
-// is a table of bounds, and the bucket's join reads its records from the columns.
-constexpr int RUNS_MAX = 64;              // ascending runs per VCF the path takes (more: the scatter)
-constexpr int RUNS_PER = 20;              // records per thread of the join: five trips of four (320 mask words of 32 records per bucket)
-constexpr int LJ_WORDS_RUNS = 512 / 8 * (RUNS_PER / 4);   // mask words a bucket's workgroup holds
-struct RunsParams {
-  const SortSeg* segs;
-  const int32_t* tile_seg;    // scatter-tile map (BK_TILE records per tile)
-  const int32_t* pos;
-  uint32_t* cnt;              // [n_vcf] descents found (k_runs_find; by main VCF)
-  uint32_t* idx;              // [n_vcf][RUNS_MAX] where (unordered; the first RUNS_MAX - 1 of them)
-  uint32_t* maxpos;           // [n_vcf] highest position
-  uint32_t* vflags;           // [n_vcf] SPANF_BADPOS
-  // k_runs_prepare
-  int32_t* bnd;               // [n_seg][RUNS_MAX][257]
-  uint32_t* runs_n;           // [n_seg]
-  uint32_t* seg_flags;        // [n_seg]
-  uint64_t* mask_pass; uint64_t* mask_tp;
 };
 struct SortCols { const int32_t* pos; const int32_t* ref; const int32_t* alt; const float* qual; const uint8_t* flags; };
 
@@ -459,10 +433,7 @@ void launch_synth(const SynthParams& S, int n_vcf, int64_t max_n, hipStream_t st
 void launch_classify_hash(const HashParams& P, int nseg, hipStream_t st);   // segments P.seg_base .. + nseg
 void launch_bucket_rows(const HashParams& P, int nseg, hipStream_t st);
 void launch_join_ext(const HashParams& P, int nseg, int nbk, hipStream_t st);     // the second stream of an allele-extended batch
-void launch_join_lean(const HashParams& P, int nseg, int lb, int nbk, hipStream_t st);
-void launch_join_runs(const HashParams& P, int nseg, int lb, int nbk, hipStream_t st);   // the same join fed from the columns through HashParams.runs_*
-void launch_runs_find(const RunsParams& P, int ntiles, hipStream_t st);
-void launch_runs_prepare(const RunsParams& P, int nseg, hipStream_t st);   // segments P.seg_base .. + nseg, every bucket shift <= lb <= DJ_MAX_SHIFT
+void launch_join_lean(const HashParams& P, int nseg, int lb, int nbk, hipStream_t st);   // segments P.seg_base .. + nseg, every bucket shift <= lb <= DJ_MAX_SHIFT
 void launch_bucket_scatter(const BucketScatterParams& P, int ntiles, hipStream_t st);   // tiles P.tile_base .. + ntiles; P.l1_ent: from level-1 entries
 void launch_sort_first_hist(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const int32_t* pos_col, uint32_t* hist, uint32_t* orbits,
                             hipStream_t st);

@@ -2658,22 +2658,13 @@ constexpr uint32_t LJ_NOKEY_TAG = 1u << 24;   // (a key inside a bucket is below
 #define LJ_WAVES 6   // 80 VGPRs, three workgroups per CU: with 64 (four per CU) the kernel spills and is 4 % slower (same-box A/B)
 #endif
 // HIST = false: the scatter counted every record by bin (HashParams.scatter_hist): no histogram here but the true positives'
-// RUNS = true (round 6): no scatter at all.  The VCF consists of a few ascending runs (it is sorted per contig), so the records of
-// this bucket's positions are ONE contiguous range of every run (HashParams.runs_bnd, from k_runs_prepare): the join reads them
-// from the COLUMNS -- mask word by mask word: eight lanes take the 32 records of one word of the class masks, a trip of a wave eight
-// consecutive words of one run where it can --, packs them as the scatter would have, writes the kept bits on the way (whole words
-// with a store, the two words at a range's ends with an atomic OR: k_runs_prepare cleared the masks) and goes on exactly as below.
-// 17 bytes read per record instead of 17 + 8 + 8; five trips per thread (the words at the ends of two dozen ranges are part empty).
-template <int LB, bool HIST, bool RUNS = false>
-__global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(RUNS ? 4 : LJ_WAVES, 8))) void k_join_lean(HashParams P) {
-  constexpr int PER = RUNS ? RUNS_PER : 16;              // records per thread at most: trips of four
+template <int LB, bool HIST>
+__global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_WAVES, 8))) void k_join_lean(HashParams P) {
+  constexpr int PER = 16;                                // records per thread at most: four trips of four
   constexpr int W_WORDS = LB >= 10 ? (1 << (LB - 8)) : 4;    // sixteen positions per word: T in bits 0..15, S1 in 16..31
   constexpr int W2_WORDS = LB >= 11 ? (1 << (LB - 9)) : 4;   // S2: a bit per position
   constexpr int CI_N = LB > DJ_CI_LOG2 ? 1 << (LB - DJ_CI_LOG2) : 1;
-  static_assert((RUNS || HB_SUB_MAX == 64 * PER) && HB_SUBS * 64 == LJ_THREADS && W_WORDS % 4 == 0 && W2_WORDS % 4 == 0 && (!RUNS || HIST), "a wave per sub-region");
-  __shared__ uint32_t s_rp[RUNS ? RUNS_MAX + 1 : 1];       // RUNS: mask words of the bucket's ranges in front of run r
-  __shared__ int32_t s_rlo[RUNS ? RUNS_MAX : 1], s_rhi[RUNS ? RUNS_MAX : 1];
-  __shared__ uint32_t s_flut[RUNS ? 16 : 1];               // RUNS: flag_info of the sixteen flag nibbles (pack_record_fast)
+  static_assert(HB_SUB_MAX == 64 * PER && HB_SUBS * 64 == LJ_THREADS && W_WORDS % 4 == 0 && W2_WORDS % 4 == 0, "a wave per sub-region");
   __shared__ __attribute__((aligned(16))) uint32_t s_W[W_WORDS];
   __shared__ __attribute__((aligned(16))) uint32_t s_W2[W2_WORDS];
   __shared__ uint32_t s_tk[DJ_TRUTH_MAX + 2];        // the staged truth keys, sorted (absolute keys), 0xffffffff behind the last
@@ -2696,22 +2687,10 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(RUNS
   // the workgroups above leave behind ONE scalar load (a workgroup that waits for its descriptor and cursors to find its bucket
   // empty holds a slot of its CU for a whole memory round trip), k_finalize sums no row of theirs (FinalizeParams.row_cap).
   // Bucket 0 always stays: it carries the segment's flags.
-  if (!RUNS && P.seg_maxd && d > 0 && (uint32_t)d >= P.seg_maxd[seg_id]) return;
+  if (P.seg_maxd && d > 0 && (uint32_t)d >= P.seg_maxd[seg_id]) return;
   const HashRow R = P.rows[row];
   const uint32_t* cur = P.cursor + row * HB_SUBS;
-  const uint32_t segfl = d != 0 ? 0u : RUNS ? P.runs_flags[seg_id] : P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg_id];   // the segment's flags travel in its first row
-  if constexpr (RUNS) {   // the bucket's range of every run, and how many mask words it touches: one lane per run
-    if (tid < 64) {
-      const int nr = (int)P.runs_n[seg_id];
-      int lo = 0, hi = 0;
-      if (lane < nr) { const int32_t* bp = P.runs_bnd + ((size_t)seg_id * RUNS_MAX + (size_t)lane) * (HB_BUCKETS + 1) + d; lo = bp[0]; hi = bp[1]; }
-      uint32_t incl = hi > lo ? (uint32_t)(((hi - 1) >> 5) - (lo >> 5) + 1) : 0u;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if (lane >= o) incl += y; }
-      s_rp[lane + 1] = incl; s_rlo[lane] = lo; s_rhi[lane] = hi;
-      if (lane == 0) s_rp[0] = 0u;
-    } else if (tid < 80) s_flut[tid - 64] = flag_info((uint32_t)(tid - 64));
-  }
+  const uint32_t segfl = d == 0 ? P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg_id] : 0u;   // the segment's flags travel in its first row
   // maps, truth state and histograms are cleared while the descriptor and the cursors are on their way
   for (int i = tid; i < W_WORDS / 4; i += LJ_THREADS) *reinterpret_cast<uint4*>(&s_W[4 * i]) = make_uint4(0u, 0u, 0u, 0u);
   for (int i = tid; i < W2_WORDS / 4; i += LJ_THREADS) *reinterpret_cast<uint4*>(&s_W2[4 * i]) = make_uint4(0u, 0u, 0u, 0u);
@@ -2726,18 +2705,12 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(RUNS
   const gu32p g_tkeys = (gu32p)R.tkeys;
   const uint32_t cap = R.cap;
   uint32_t nrec = 0, over = 0, nw = 0;     // wave-uniform (scalar loads); nw: entries of this wave's sub-region
-  if constexpr (RUNS) {
-    __syncthreads();
-    nrec = s_rp[RUNS_MAX];                 // mask words the bucket's ranges touch
-    over |= nrec > (uint32_t)(LJ_THREADS / 8 * (PER / 4)) ? 1u : 0u;   // more than the workgroup holds: the VCF is flagged (the scatter path redoes it)
-  } else {
 #pragma unroll
   for (int k = 0; k < HB_SUBS; ++k) {
     const uint32_t c = cur[k];
     const uint32_t n = c < cap ? c : cap;
     nrec += n;
     nw = wave == k ? n : nw;
-  }
   }
   const size_t orow = (size_t)seg_id * (size_t)P.out_stride + (size_t)d;   // where the bucket's row goes (allele-extended batches: the second stream's rows follow)
   uint32_t* oh = P.row_hist + orow * SPAN_HIST_WORDS;
@@ -2746,7 +2719,7 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(RUNS
     if (tid < 8) P.row_scal[orow * 8 + tid] = tid == 5 ? segfl : 0u;
     return;
   }
-  over |= (R.shift > (uint32_t)LB || (!RUNS && cap > (uint32_t)HB_SUB_MAX)) ? 1u : 0u;   // (the host never launches this instantiation for such a segment)
+  over |= (R.shift > (uint32_t)LB || cap > (uint32_t)HB_SUB_MAX) ? 1u : 0u;   // (the host never launches this instantiation for such a segment)
   const uint32_t shift = R.shift > (uint32_t)LB ? (uint32_t)LB : R.shift;   // 4 <= shift <= LB: a bucket is a whole range of positions
   const uint32_t kbase = R.kbase;                            // every key of the bucket is >= kbase
   const uint32_t klast = kbase + ((1u << shift) - 1u);
@@ -2759,69 +2732,7 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(RUNS
   const gv4p wbase = (gv4p)R.ent + (size_t)wave * (cap >> 1);     // two entries per 16 bytes (cap is even: a power of two)
   v4u ea[PER / 4], eb[PER / 4];
   const v4u z4 = {0u, 0u, 0u, 0u};
-  int ntrips = (int)((nw + 255u) >> 8);                             // wave-uniform
-  uint32_t vmask_runs = 0;                                          // RUNS: the lane's slots that hold a record of the bucket
-  if constexpr (RUNS) {
-    // trip g of wave w, lanes 8 k .. 8 k + 7: mask word (8 g + w) * 8 + k of the bucket's ranges, four records per lane -- trip
-    // by trip across the waves, so that all eight of them are busy for the same number of trips
-    const uint32_t total = over ? 0u : nrec;
-    const int first = wave * 8;
-    ntrips = (int)total <= first ? 0 : ((int)total - first + 63) >> 6;
-    ntrips = ntrips > PER / 4 ? PER / 4 : ntrips;
-    typedef int v4i __attribute__((ext_vector_type(4)));
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    v4i cp[PER / 4], cr[PER / 4], ca[PER / 4];
-    v4f cq[PER / 4];
-    uint32_t cf[PER / 4];
-    int cbase[PER / 4], clo[PER / 4], chi[PER / 4];
-#pragma unroll
-    for (int g = 0; g < PER / 4; ++g) {          // all loads first
-      const uint32_t gi = (uint32_t)(first + 64 * g + (lane >> 3));
-      cbase[g] = 0; clo[g] = 0; chi[g] = 0; cf[g] = 0u;
-      cp[g] = v4i{0, 0, 0, 0}; cr[g] = v4i{4, 4, 4, 4}; ca[g] = v4i{4, 4, 4, 4}; cq[g] = v4f{0.f, 0.f, 0.f, 0.f};
-      if (gi < total) {
-        int r = 0;                               // the run of the word: the last r with s_rp[r] <= gi
-#pragma unroll
-        for (int st = RUNS_MAX / 2; st > 0; st >>= 1) if (s_rp[r + st] <= gi) r += st;
-        clo[g] = s_rlo[r]; chi[g] = s_rhi[r];
-        cbase[g] = (((clo[g] >> 5) + (int)(gi - s_rp[r])) << 5) + 4 * (lane & 7);
-        const int64_t at = R.src_off + cbase[g];
-        cp[g] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(P.pos + at));
-        cr[g] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(P.ref + at));
-        ca[g] = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(P.alt + at));
-        cq[g] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(P.qual + at));
-        cf[g] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(P.flags + at));
-      }
-    }
-    const float nbm1f = (float)(P.n_bins - 1);
-#pragma unroll
-    for (int g = 0; g < PER / 4; ++g) {
-      uint32_t e[8];
-      uint32_t kept = 0;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        uint32_t key, inf;
-        pack_record_fast(cp[g][u], cr[g][u], ca[g][u], cq[g][u], ((cf[g] >> (8 * u)) & 15u) << 2, nbm1f, s_flut, key, inf);
-        const int i = cbase[g] + u;
-        const bool mine = i >= clo[g] && i < chi[g] && (inf & I_LIVE);     // (slots of no word: clo = chi = 0)
-        kept |= (mine ? (inf >> 16) & 1u : 0u) << u;
-        vmask_runs |= (mine ? 1u : 0u) << (4 * g + u);
-        // the scatter's entry (qmvt_dev.h "bucket entry"): key inside the bucket, bin + 1 and the flag bits, the record's index
-        e[2 * u] = mine ? ((key - R.kbase) & 0xffffffu) | ((inf & 0xffu) << 24) : 0u;
-        e[2 * u + 1] = mine ? ((inf >> 8) & 0xfu) | (((inf >> 24) & 1u) << 4) | ((uint32_t)i << 5) : 0u;
-      }
-      ea[g] = v4u{e[0], e[1], e[2], e[3]};
-      eb[g] = v4u{e[4], e[5], e[6], e[7]};
-      // the kept bits of the word: 8 lanes x 4 records
-      const uint32_t kw = or_reduce8(kept << (4u * (uint32_t)(lane & 7)));
-      if ((lane & 7) == 7 && chi[g] > clo[g]) {
-        const int w0 = cbase[g] - 28;                                     // first record of the word
-        uint32_t* mp = P.mask_pass32 + ((R.src_off + w0) >> 5);
-        if (w0 >= clo[g] && w0 + 32 <= chi[g]) *mp = kw;                   // the whole word is this range's
-        else if (kw) atomicOr(mp, kw);                                     // shared with the neighbouring bucket's range (or another run's)
-      }
-    }
-  } else {
+  const int ntrips = (int)((nw + 255u) >> 8);                       // wave-uniform
 #pragma unroll
   for (int g = 0; g < PER / 4; ++g) {
     const uint32_t q = (uint32_t)g * 64u + (uint32_t)lane;
@@ -2830,7 +2741,6 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(RUNS
       ea[g] = __builtin_nontemporal_load(wbase + 2u * q);
       eb[g] = __builtin_nontemporal_load(wbase + 2u * q + 1u);
     }
-  }
   }
   uint32_t tkey0 = 0xffffffffu, tkey1 = 0xffffffffu, tprev0 = 0u, tprev1 = 0u;   // (tprev: the key in front, for the coarse index; 0 is below every bucket's first key that matters)
   if (tid < tn) tkey0 = g_tkeys[tid];
@@ -2863,7 +2773,7 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(RUNS
   // the partly filled quad at the end of the sub-region: what lies behind the cursor there is left over from an earlier run
 #pragma unroll
   for (int g = 0; g < PER / 4; ++g) {
-    if (!RUNS && nw > (uint32_t)g * 256u && nw < (uint32_t)(g + 1) * 256u) {   // wave-uniform
+    if (nw > (uint32_t)g * 256u && nw < (uint32_t)(g + 1) * 256u) {   // wave-uniform
       const int left = (int)nw - 4 * (g * 64 + lane);         // entries of the lane's quad in front of the cursor
       if (left < 4) { eb[g][2] = 0u; eb[g][3] = 0u; }
       if (left < 3) { eb[g][0] = 0u; eb[g][1] = 0u; }
@@ -2940,10 +2850,9 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(RUNS
       }
     }
     // the lane's slots in front of the cursor (a zero entry may sit on a truth position: it is not to be settled)
-    uint32_t vmask = vmask_runs;
+    uint32_t vmask = 0;
 #pragma unroll
     for (int g = 0; g < PER / 4; ++g) {
-      if (RUNS) continue;
       if (nw >= (uint32_t)(g + 1) * 256u) vmask |= 15u << (4 * g);             // wave-uniform: the whole trip lies in front of the cursor
       else if (nw > (uint32_t)g * 256u) {
         const int left = (int)nw - 4 * (g * 64 + lane);
@@ -3075,91 +2984,6 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(RUNS
     sc[4] = s_c[7] + s_c[2] - s_c[3];   // distinct kept keys outside the truth set: positions claimed once + the exact set's keys, minus those that are truth keys
     sc[5] = fl; sc[6] = 0u; sc[7] = 0u;
   }
-}
-
-// ---------------------------------------------------------------------------
-// The runs path's two small kernels (k_join_lean<.., RUNS>: VCFs sorted per contig).
-// k_runs_find, once per set of columns: where a VCF's positions step DOWN (the first RUNS_MAX - 1 places, unordered), how many
-// such places it has, its highest position (the buckets' exact bound: no estimate on this path) and whether one is out of range.
-// 4 bytes read per record.  k_runs_prepare, every step: the runs in order, the table of bounds -- for run r and bucket d the first
-// record of the run at or above the bucket's first position, one bisection per (r, d) -- and the VCF's class masks cleared.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_runs_find(RunsParams P) {
-  const int bid = (int)blockIdx.x;
-  const int seg = P.tile_seg[bid];
-  const SortSeg sg = P.segs[seg];
-  const int tid = (int)threadIdx.x, lane = tid & 63;
-  const int64_t i0 = (int64_t)(bid - sg.bk_tile0) * BK_TILE + (int64_t)tid * (BK_TILE / 512);
-  constexpr int PT = BK_TILE / 512;    // 8 records per thread
-  // a VCF that has shown more descents than the path takes is not looked at any further (a shuffled VCF: half a million of them,
-  // every one an atomic on the VCF's one counter)
-  if (__hip_atomic_load(&P.cnt[sg.main_vcf], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)RUNS_MAX) return;
-  typedef int v4i __attribute__((ext_vector_type(4)));
-  int p[PT];
-#pragma unroll
-  for (int j = 0; j < PT / 4; ++j) {
-    v4i v = {0, 0, 0, 0};
-    if (i0 + 4 * j < sg.n) v = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(P.pos + sg.src_off + i0 + 4 * j));   // (the columns are padded past every VCF)
-    p[4 * j] = v.x; p[4 * j + 1] = v.y; p[4 * j + 2] = v.z; p[4 * j + 3] = v.w;
-  }
-  int prev = __shfl_up(p[PT - 1], 1);
-  if (lane == 0) prev = i0 > 0 && i0 < sg.n ? P.pos[sg.src_off + i0 - 1] : INT32_MIN;
-  // the highest position of a VCF of ascending runs is the END of one of them: the record in front of a descent, or the last
-  // record -- a few atomics per VCF (a maximum per wave would be an atomic per wave on ascending data: every wave sees a new one)
-  uint32_t bad = 0;
-#pragma unroll
-  for (int j = 0; j < PT; ++j) {
-    if (i0 + j < sg.n) {
-      bad |= (uint32_t)p[j] >> 28;
-      if (p[j] < prev) {
-        const uint32_t slot = atomicAdd(&P.cnt[sg.main_vcf], 1u);
-        if (slot < (uint32_t)(RUNS_MAX - 1)) P.idx[(size_t)sg.main_vcf * RUNS_MAX + slot] = (uint32_t)(i0 + j);
-        if (prev >= 0) atomicMax(&P.maxpos[sg.main_vcf], (uint32_t)prev);
-      }
-      if (i0 + j == sg.n - 1 && p[j] >= 0) atomicMax(&P.maxpos[sg.main_vcf], (uint32_t)p[j]);
-      prev = p[j];
-    }
-  }
-  if (ballot64(bad != 0u) != 0ull && lane == 0) atomicOr(&P.vflags[sg.main_vcf], SPANF_BADPOS);
-}
-
-__global__ __launch_bounds__(320) void k_runs_prepare(RunsParams P) {
-  const int seg = (int)blockIdx.y, r = (int)blockIdx.x;      // one workgroup per (VCF, run slot): thread d bisects for bucket d
-  const SortSeg sg = P.segs[seg];
-  const int tid = (int)threadIdx.x;
-  __shared__ uint32_t s_in[RUNS_MAX], s_rs[RUNS_MAX + 1];
-  const uint32_t nd = P.cnt[sg.main_vcf];                    // descents (< RUNS_MAX: the host sends nothing else here)
-  const int nr = (int)nd + 1;
-  if (tid < RUNS_MAX) s_in[tid] = tid < (int)nd ? P.idx[(size_t)sg.main_vcf * RUNS_MAX + tid] : 0xffffffffu;
-  __syncthreads();
-  if (tid < (int)nd) {                                       // rank among the descents (they are distinct)
-    const uint32_t me = s_in[tid];
-    int rank = 0;
-    for (int k = 0; k < (int)nd; ++k) rank += s_in[k] < me ? 1 : 0;
-    s_rs[rank + 1] = me;
-  }
-  if (tid == 0) { s_rs[0] = 0u; P.runs_n[seg] = (uint32_t)nr; P.seg_flags[seg] = P.vflags[sg.main_vcf]; }
-  __syncthreads();
-  {   // the class masks of the VCF: cleared in nr stripes of whole 64-bit words (the joins OR their bits in)
-    const int64_t words = ((sg.n + 255) & ~(int64_t)255) >> 6, w0 = sg.src_off >> 6;
-    const int64_t a = words * r / RUNS_MAX, b = words * (r + 1) / RUNS_MAX;
-    for (int64_t w = a + tid; w < b; w += 320) { P.mask_pass[w0 + w] = 0ull; P.mask_tp[w0 + w] = 0ull; }
-  }
-  if (r >= nr) return;
-  const int lo = (int)s_rs[r], hi = r + 1 < nr ? (int)s_rs[r + 1] : (int)sg.n;
-  if (tid > HB_BUCKETS) return;
-  int32_t* out = P.bnd + ((size_t)seg * RUNS_MAX + (size_t)r) * (HB_BUCKETS + 1);
-  int at;
-  if (tid == 0) at = lo;
-  else if (tid >= sg.nbk) at = hi;                           // (buckets above the VCF's highest position hold nothing)
-  else {
-    const int thr = (int)((uint32_t)tid << ((uint32_t)sg.pad - 4u));   // bucket d's first position (key = pos << 4; pad >= 4)
-    const int32_t* q = P.pos + sg.src_off;
-    int a = lo, n = hi - lo;
-    while (n > 0) { const int h = n >> 1; if (q[a + h] < thr) { a += h + 1; n -= h + 1; } else n = h; }
-    at = a;
-  }
-  out[tid] = at;
 }
 
 // ---------------------------------------------------------------------------
@@ -3682,17 +3506,6 @@ void launch_join_lean(const HashParams& P, int nseg, int lb, int nbk, hipStream_
     if (lb <= 16) hipLaunchKernelGGL((k_join_lean<16, true>), dim3(nbk, nseg), dim3(LJ_THREADS), 0, st, P);
     else hipLaunchKernelGGL((k_join_lean<DJ_MAX_SHIFT, true>), dim3(nbk, nseg), dim3(LJ_THREADS), 0, st, P);
   }
-}
-void launch_join_runs(const HashParams& P, int nseg, int lb, int nbk, hipStream_t st) {
-  if (nseg <= 0) return;
-  if (lb <= 16) hipLaunchKernelGGL((k_join_lean<16, true, true>), dim3(nbk, nseg), dim3(LJ_THREADS), 0, st, P);
-  else hipLaunchKernelGGL((k_join_lean<DJ_MAX_SHIFT, true, true>), dim3(nbk, nseg), dim3(LJ_THREADS), 0, st, P);
-}
-void launch_runs_find(const RunsParams& P, int ntiles, hipStream_t st) {
-  if (ntiles > 0) hipLaunchKernelGGL(k_runs_find, dim3(ntiles), dim3(512), 0, st, P);
-}
-void launch_runs_prepare(const RunsParams& P, int nseg, hipStream_t st) {
-  if (nseg > 0) hipLaunchKernelGGL(k_runs_prepare, dim3(RUNS_MAX, nseg), dim3(320), 0, st, P);
 }
 void launch_join_ext(const HashParams& P, int nseg, int nbk, hipStream_t st) {
   if (nseg > 0) hipLaunchKernelGGL(k_join_ext, dim3(nbk, nseg), dim3(XJ_THREADS), 0, st, P);

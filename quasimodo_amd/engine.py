@@ -9,7 +9,7 @@ from ._lib import SCALAR_NAMES, QmvtError, SynthCfg, check
 
 # include/qmvt.h QM_PATH_*: where the VCFs a finish found out of order went
 PATH_NAMES = ("unsorted", "bucket_direct", "bucket_hashed", "radix", "radix_after_overflow", "bucket_chunks", "overflow_chunks",
-              "radix_chunks", "bucket_two_level", "bucket_partitions", "bucket_runs")
+              "radix_chunks", "bucket_two_level", "bucket_partitions")
 
 
 def _p(a):

@@ -263,4 +263,4 @@ def test_every_knob_the_sources_read_is_named_in_integration_md():
     ksrc = open(os.path.join(root, "quasimodo_amd", "csrc", "qmvt_kernels.hip")).read()
     conds = re.findall(r"^#\s*(?:if|ifdef|elif)\b.*$", ksrc, flags=re.M)
     assert not conds, conds
-    assert ksrc.count("\n") <= 3800, ksrc.count("\n")   # (4 219 before the prune of round 6, 3 496 after it; the runs path came on top)
+    assert ksrc.count("\n") <= 3600, ksrc.count("\n")   # (4 219 before the prune of round 6)

@@ -968,6 +968,7 @@ def test_positions_above_what_the_optimistic_pass_saw(engine, oracle):
     seen = np.zeros(n, bool)
     for s0 in range(0, n, span):
         seen[s0:s0 + 1024] = True   # the first tile of every span: all the optimistic pass ever saw of a shuffled VCF (its first 256 records now)
+    seen[(np.arange(64) * n) >> 6] = True   # ... and the sixty-four records every span samples over the whole VCF (round 6)
     lo = rng.choice(np.concatenate([np.arange(1, 0x200000), np.arange(0x400000, 0x600000)]), size=n - n // 4, replace=False)
     hi = rng.choice(np.arange(0x600000, 0x800000), size=n // 4, replace=False)
     pos = np.empty(n, np.int32)
