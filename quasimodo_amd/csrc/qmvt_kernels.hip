@@ -1766,8 +1766,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   constexpr int PER = BK_TILE / 512;          // records per thread, in groups of four consecutive ones
   static_assert(BK_TILE % 2048 == 0 && PER >= 4, "whole 16-byte loads, 256 records per wave and group");
   static_assert(NB == 256 || (NB == 512 && !L2), "one digit per thread at most");
-  constexpr int DPT = 1;                         // digits per thread of the scan
-  constexpr int NDT = NB / DPT;                  // threads that scan
   typedef typename std::conditional<NB == 256, uint8_t, uint16_t>::type digit_t;
   __shared__ uint32_t s_cnt[NB];              // records of digit d in the tile (running during the ranking)
   __shared__ uint32_t s_loc[NB];              // tile-local start of digit d's run
@@ -1929,20 +1927,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
     }
   }
   // thread d: exclusive scan over the digit counts = tile-local run starts; room for the run in the bucket's sub-region.
-  // -DBK_PAIRS (measured, not the default): entries leave as PAIRS -- a run is reserved, laid out in LDS and stored at an even
-  // length (an odd one gets a ZERO entry behind its last: inert in every join -- not kept, no bin, no ID '.'), every sub-region
-  // fills from an even place, so a lane stores two neighbouring entries of one run with ONE 16-byte instruction (32 wave-stores
-  // per tile instead of 64; VERDICT 4 priced the store instructions at 0.17 of the kernel's 1.42 ms).  Bit-identical through
-  // every join (tests, 800 fuzz rounds), and the step takes 2.639 / 2.642 ms against 2.631 / 2.635 without (same box,
-  // profiles/r05_scatter_pairs_ab.log): the pads are 1.9 % more entries to write and to join, which eats what the
-  // instructions save.
-  uint32_t cnt = 0, incl = 0;          // (DPT = 1: the thread's one digit)
-  uint32_t cntk[DPT], lock[DPT], gk[DPT];
-#pragma unroll
-  for (int k = 0; k < DPT; ++k) { cntk[k] = 0u; lock[k] = 0u; gk[k] = 0u; }
-  if (tid < NDT) {
-#pragma unroll
-    for (int k = 0; k < DPT; ++k) { cntk[k] = s_cnt[tid * DPT + k]; cnt += cntk[k]; }
+  uint32_t cnt = 0, incl = 0;
+  if (tid < NB) {
+    cnt = s_cnt[tid];
     incl = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -1956,20 +1943,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   // needs the tile-local run starts only, so the cursors' round trip passes behind it.
   uint32_t g = 0, loc = 0;
   uint32_t cntx2 = 0, gx2 = 0;   // NB = 512: the thread of digit d reserves for both streams
-  if (tid < NDT) {
+  if (tid < NB) {
     uint32_t woff = 0;
 #pragma unroll
-    for (int w = 0; w < NDT / 64 - 1; ++w) woff += w < wave ? s_scan[w] : 0u;
+    for (int w = 0; w < NB / 64 - 1; ++w) woff += w < wave ? s_scan[w] : 0u;
     loc = woff + incl - cnt;
-#pragma unroll
-    for (int k = 0; k < DPT; ++k) {
-      const int d = tid * DPT + k;
-      lock[k] = loc; loc += cntk[k];
-      s_loc[d] = lock[k];
-      if (cntk[k]) gk[k] = atomicAdd(&P.cursor[((size_t)seg * HB_BUCKETS + d) * HB_SUBS + sub], cntk[k]);   // (digits 256 and above: the next partitions' cursors follow)
-    }
-    g = gk[0];
-    if (tid == NDT - 1) s_scan[NB / 64] = loc;
+    s_loc[tid] = loc;
+    if (cnt) g = atomicAdd(&P.cursor[((size_t)seg * HB_BUCKETS + tid) * HB_SUBS + sub], cnt);   // (digits 256..511: the next partition's cursors follow)
+    if (tid == NB - 1) s_scan[NB / 64] = loc + cnt;
     if (EXT && NB == 512) {
       cntx2 = s_cntx[tid];
       if (cntx2) gx2 = atomicAdd(&P.xcursor[((size_t)seg * HB_BUCKETS + tid) * HB_SUBS + sub], cntx2);
@@ -1988,10 +1969,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
       s_d[lp] = (digit_t)d;
     }
   }
-  if (tid < NDT || EXT) {
-    if (tid < NDT) {
-#pragma unroll
-      for (int k = 0; k < DPT; ++k) s_glob[tid * DPT + k] = (int32_t)gk[k] - (int32_t)lock[k];   // (a run that does not fit its sub-region: below)
+  if (tid < NB || EXT) {
+    if (tid < NB) {
+      s_glob[tid] = (int32_t)g - (int32_t)loc;   // (a run that does not fit its sub-region: below)
     } else {
       if (cnt && g + cnt > (uint32_t)sg.bk_cap) atomicOr(&P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg], SPANF_OVERFLOW);
       s_cntx[tid - 256] = g;
@@ -2032,24 +2012,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(EXT ? 5 : B
   // that lies below the sub-region's capacity is stored above (every slot below min(cursor, capacity) is somebody's: the joins clamp
   // the cursor and no longer read one above the capacity as an overflow); the rest asks the next sub-regions for room, one atomic
   // each, and its owner thread stores it there itself.  Only a run that finds no room in any of the eight flags the VCF.
-  if (tid < NDT) {
+  if (tid < NB) {
     const uint32_t cap = (uint32_t)sg.bk_cap;
-#pragma unroll
-    for (int k = 0; k < DPT; ++k) {
-      if (cntk[k] && gk[k] + cntk[k] > cap) {
-        const uint32_t d = (uint32_t)(tid * DPT + k);
-        uint32_t done = gk[k] < cap ? cap - gk[k] : 0u;           // entries of the run stored by the loop above
-        for (int hop = 1; hop < HB_SUBS && done < cntk[k]; ++hop) {
-          const int s2 = (sub + hop) & (HB_SUBS - 1);
-          const uint32_t rest = cntk[k] - done;
-          const uint32_t g2 = atomicAdd(&P.cursor[((size_t)seg * HB_BUCKETS + d) * HB_SUBS + s2], rest);
-          const uint32_t take = g2 < cap ? (rest < cap - g2 ? rest : cap - g2) : 0u;
-          uint64_t* o2 = out + ((size_t)d * HB_SUBS + s2) * (size_t)cap + (size_t)g2;
-          for (uint32_t j = 0; j < take; ++j) o2[j] = s_e[lock[k] + done + j];
-          done += take;
-        }
-        if (done < cntk[k]) atomicOr(&P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg], SPANF_OVERFLOW);   // the bucket itself is full: the radix sort redoes the VCF
+    if (cnt && g + cnt > cap) {
+      uint32_t done = g < cap ? cap - g : 0u;                  // entries of the run stored by the loop above
+      for (int hop = 1; hop < HB_SUBS && done < cnt; ++hop) {
+        const int s2 = (sub + hop) & (HB_SUBS - 1);
+        const uint32_t rest = cnt - done;
+        const uint32_t g2 = atomicAdd(&P.cursor[((size_t)seg * HB_BUCKETS + (size_t)tid) * HB_SUBS + s2], rest);
+        const uint32_t take = g2 < cap ? (rest < cap - g2 ? rest : cap - g2) : 0u;
+        uint64_t* o2 = out + ((size_t)tid * HB_SUBS + s2) * (size_t)cap + (size_t)g2;
+        for (uint32_t j = 0; j < take; ++j) o2[j] = s_e[loc + done + j];
+        done += take;
       }
+      if (done < cnt) atomicOr(&P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg], SPANF_OVERFLOW);   // the bucket itself is full: the radix sort redoes the VCF
     }
   }
 }

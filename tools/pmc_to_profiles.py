@@ -22,7 +22,18 @@ for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
         cnt[(k, row["Counter_Name"])] += 1
 out = {k: {c: v / cnt[(k, c)] for c, v in sorted(d.items())} for k, d in sorted(agg.items())}
-json.dump(out, open(os.path.join(root, "%s_pmc_per_launch.json" % prefix), "w"), indent=1)
+suffix = sys.argv[4] if len(sys.argv) > 4 else ""          # "alleles": the allele-extended instantiation's passes (RARGS="0 30"): its own file, traffic.json untouched
+for k, d in out.items():                                     # per round of 256 records: what the instruction counts mean
+    if "k_classify" in k and "SQ_INSTS_VALU" in d:
+        rounds = nv * 1000000 / 256.0
+        d["derived"] = {"valu_per_round": d["SQ_INSTS_VALU"] / rounds, "salu_per_round": d.get("SQ_INSTS_SALU", 0) / rounds, "lds_per_round": d.get("SQ_INSTS_LDS", 0) / rounds,
+                        "valu_busy_of_kernel_cycles": d["SQ_INSTS_VALU"] * 4 / 1024 / (d["GRBM_GUI_ACTIVE"] / 8) if d.get("GRBM_GUI_ACTIVE") else None,
+                        "hbm_bytes": (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in d and "WRITE_SIZE" in d else None,
+                        "note": "wave-instructions per round of 256 records; VALU busy = instructions x 4 cycles / 1 024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs"}
+json.dump(out, open(os.path.join(root, "%s_pmc_per_launch%s.json" % (prefix, "_" + suffix if suffix else "")), "w"), indent=1)
+if suffix:
+    print(json.dumps({k: v.get("derived") for k, v in out.items() if "k_classify" in k}))
+    sys.exit(0)
 kc = next(v for k, v in out.items() if "k_classify<false, false>" in k or k.endswith("k_classify<false>"))
 fetch_kb, write_kb = kc["FETCH_SIZE"], kc["WRITE_SIZE"]
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
