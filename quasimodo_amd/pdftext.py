@@ -12,15 +12,19 @@ def _esc(s):
     return s.replace("\\", "\\\\").replace("(", "\\(").replace(")", "\\)")
 
 
+MARKER = "[qmvt: a text-only stand-in for the figure -- the numbers of the rule's table; drawing is R's (not rebuilt)]"
+
+
 def write_text_pdf(path, pages, title=""):
     """pages: list of lists of text lines (ASCII; anything else is replaced by '?').  Letter-size pages, Courier 9 pt,
-    66 lines per page at most (longer pages are split).  Deterministic bytes: no dates, no ids."""
-    per_page = 66
+    65 lines per page at most (longer pages are split) behind a marker line that says what the file is (nobody
+    should take it for the reference's plot).  Deterministic bytes: no dates, no ids."""
+    per_page = 65       # + the marker line every page starts with
     flat = []
     for lines in pages or [[]]:
         lines = [str(x) for x in lines] or [""]
         for i in range(0, len(lines), per_page):
-            flat.append(lines[i:i + per_page])
+            flat.append([MARKER] + lines[i:i + per_page])
     objs = []   # object k + 1 = objs[k] (bytes, without the "n 0 obj" frame)
 
     def add(body):

@@ -239,7 +239,8 @@ def test_text_pdf_is_a_pdf(tmp_path):
     p = tmp_path / "t.pdf"
     n = write_text_pdf(str(p), [["a (b) \\ c", "x"], ["line %d" % i for i in range(100)]], title="t")
     data = p.read_bytes()
-    assert n == 3 and data.count(b"/Type /Page ") == 3            # the 100-line page is split at 66 lines
+    assert n == 3 and data.count(b"/Type /Page ") == 3            # the 100-line page is split at 65 lines
+    assert data.count(b"text-only stand-in for the figure") == 3  # every page says what the file is
     xref = int(re.search(rb"startxref\n(\d+)\n%%EOF", data).group(1))
     assert data[xref:xref + 4] == b"xref"
     count = int(data[xref:].split(b"\n")[1].split()[1])
