@@ -508,7 +508,10 @@ def fuzz(n_rounds, seed):
     from oracle import qm_oracle as O
     rng = random.Random(seed)
     alphabet_field = ["A", "C", "G", "T", ".", "N", "a", "AC", "A,C", "", "PASS", "20", "19", "30", "5", "1e2", "0x14",
-                      "rs1", "-", "1-5", "5_", "x.y", " 20", "20 ", "2e-400", "7\r", "100", "10", "1"]
+                      "rs1", "-", "1-5", "5_", "x.y", " 20", "20 ", "2e-400", "7\r", "100", "10", "1",
+                      # valid UTF-8 (round 6): letters, a digit of another script, a four-byte digit, an arrow, a no-break space -- alone and
+                      # abutting the digits / bases a pattern could end or begin with
+                      "\u00e9", "\u00e95", "5\u00e9", "\u21925", "5\u2192", "\u06633", "\U0001d7d17", "\u00a02", "A\u00e9", "C\u2192", "\u65e5\u672c", "\u00e9A"]
     bad = 0
     for r in range(n_rounds):
         with tempfile.TemporaryDirectory() as w:
@@ -543,7 +546,7 @@ def fuzz(n_rounds, seed):
             ttxt = "\n".join(tl) + ("\n" if tl and rng.random() < 0.9 else "")
             name = rng.choice(["S-1-10", "S-1-1", "S-1-0", "S-0-1", "X"])
             vcf = os.path.join(w, "c", name + ".R.c.vcf")
-            write(vcf, vtxt.encode("latin1")); truth = os.path.join(w, "truth.x"); write(truth, ttxt.encode("latin1"))
+            write(vcf, vtxt.encode("utf-8")); truth = os.path.join(w, "truth.x"); write(truth, ttxt.encode("utf-8"))
             os.makedirs(os.path.join(w, "c", "fp")); os.makedirs(os.path.join(w, "out", "fp"))
             mode = "custom" if custom else "hcmv"
             pure = is_pure(vcf)

@@ -193,9 +193,11 @@ def test_truth_scan_modes(qmlib):
 
 
 def _random_case(rng):
-    """Hostile but ASCII VCF / truth texts (same generator family as make_golden.py --fuzz)."""
+    """Hostile VCF / truth texts, ASCII and valid UTF-8 (same generator family as make_golden.py --fuzz)."""
     fields = ["A", "C", "G", "T", ".", "N", "a", "AC", "A,C", "", "PASS", "20", "19", "30", "5", "1e2", "0x14", "rs1", "-",
-              "5_", "x.y", " 20", "20 ", "2e-400", "7\r", "100", "10", "1", "19.9999999", "20.0000001", "1e400", "+20", "nan"]
+              "5_", "x.y", " 20", "20 ", "2e-400", "7\r", "100", "10", "1", "19.9999999", "20.0000001", "1e400", "+20", "nan",
+              # (round 6) letters, a digit of another script, a four-byte digit, an arrow, a no-break space: alone and abutting what a pattern ends or begins with
+              "\u00e9", "\u00e95", "5\u00e9", "\u21925", "5\u2192", "\u06633", "\U0001d7d17", "\u00a02", "A\u00e9", "C\u2192", "\u65e5\u672c", "\u00e9A"]
     npos = int(rng.integers(1, 40))
 
     def line(ncol_max=10):
@@ -228,12 +230,12 @@ def _random_case(rng):
         if rng.random() < 0.08:
             t[-1] = "#" + t[-1]          # awk makes a pattern of a '#' row all the same; R does not read it
     ttxt = "\n".join(t) + ("\n" if t else "")
-    return vtxt.encode("latin1"), ttxt.encode("latin1"), custom
+    return vtxt.encode("utf-8"), ttxt.encode("utf-8"), custom
 
 
 @pytest.mark.parametrize("seed", range(8))
 def test_columns_equal_text_semantics_on_random_inputs(qmlib, oracle, tmp_path, seed):
-    """Property: for every ASCII input, packing to columns, deciding what the columns cannot describe on the host
+    """Property: for every input of ASCII and valid UTF-8, packing to columns, deciding what the columns cannot describe on the host
     path, classifying the columns (oracle as checker) and writing back gives exactly the text-level result, which
     is pinned to the reference by the golden vectors and the live fuzz of make_golden.py.  The generator makes
     POS spellings like "20 " and "x.y", pattern-shaped runs of later fields, '#' lines that pass the filter,
