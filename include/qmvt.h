@@ -225,7 +225,7 @@ int qm_batch_get_columns(qm_batch* b, int vcf, int32_t* pos, int32_t* ref, int32
  * the radix sort -- correct, several times slower -- and these counters say how often that happened. */
 enum {
   QM_PATH_UNSORTED = 0,              /* VCFs found out of order */
-  QM_PATH_DIRECT = 1,                /* ... joined bucket by bucket with one bit per key in LDS (k_join_direct) */
+  QM_PATH_DIRECT = 1,                /* ... joined bucket by bucket with two bits per position in LDS (k_join_lean) */
   QM_PATH_HASHED = 2,                /* ... joined bucket by bucket through hashed tables (k_classify_hash: wide key ranges) */
   QM_PATH_RADIX = 3,                 /* ... radix-sorted because the bucket path does not take them (size, allele-extended batch) */
   QM_PATH_RADIX_AFTER_OVERFLOW = 4,  /* ... radix-sorted after a bucket of their chunk overflowed */

@@ -1087,7 +1087,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
   int lb_all = 0, nbk_all = 1;
   for (int i = 0; i < nseg; ++i) { lb_all = std::max(lb_all, (int)segs[(size_t)i].pad); nbk_all = std::max(nbk_all, std::min(nbk_used[(size_t)i], (int)HB_BUCKETS)); }
   const bool direct = lb_all <= DJ_MAX_SHIFT && !join_hash_forced();
-  // allele-extended batches: two entry streams and two joins per bucket (k_join_direct for the single-base records, k_join_ext
+  // allele-extended batches: two entry streams and two joins per bucket (k_join_lean for the single-base records, k_join_ext
   // for the others), both of which need the bucket's key range to fit the bit maps; wider key ranges take the radix sort
   const bool xstream = b->ext;
   if (xstream && !direct) try_buckets = false;
@@ -1175,7 +1175,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     // The scatter streams (memory-bound, its SIMDs half idle), the join issues instructions (and hardly waits for memory): in a
     // few segment ranges, the join of one range on the second stream beside the scatter of the next, they fill each other's gaps.
     // k_classify_hash issues instructions where the scatter waits for memory: a few segment ranges, the join of one on the second
-    // stream beside the scatter of the next, fill each other's gaps (- 7 %).  k_join_direct is bound by the latency of a
+    // stream beside the scatter of the next, fill each other's gaps (- 7 %).  The bit-map join (then k_join_direct) was bound by the latency of a
     // workgroup's serial steps and wants every LDS slot of the chip: beside a scatter it only loses (3.06 ms in one piece
     // against 3.11 - 3.22 in 2 - 8 ranges, same box)
     int nbk_launch = nbk_all;
@@ -1214,7 +1214,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
           if (have) for (int i = 0; i < nseg && have; ++i) { const uint32_t k = b->known_nbk[(size_t)vs[(size_t)i]]; have = k != 0u; m = std::max(m, k); }
           if (have && !xstream) nbk_launch = (int)std::min<uint32_t>(std::max(m, 1u), (uint32_t)nbk_all);   // (two streams: every bucket is launched, the rows of the second follow at a fixed distance)
         }
-        // the join: one bit per key of the bucket in LDS where a bucket's key range allows it (k_join_direct), the hashed
+        // the join: one bit per key of the bucket in LDS where a bucket's key range allows it (k_join_lean: two bits per position), the hashed
         // tables of k_classify_hash otherwise (QM_JOIN=hash: always)
         if (direct) launch_join_lean(H, i1 - i0, lb_all, nbk_launch, aux);
         else launch_classify_hash(H, i1 - i0, aux);

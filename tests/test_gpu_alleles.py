@@ -199,7 +199,7 @@ def test_alleles_mode_gives_up_on_overlong_runs(engine):
 
 
 def test_alleles_mode_unsorted_vcfs_on_the_bucket_path(engine, oracle):
-    """Allele-extended VCFs out of order take the bucket path with TWO entry streams: single-base records through k_join_direct,
+    """Allele-extended VCFs out of order take the bucket path with TWO entry streams: single-base records through k_join_lean,
     the others -- 16-byte entries with their allele codes -- through k_join_ext (exact on position, REF, ALT).  Synthetic config-5
     VCFs against the sorted run, and an adversarial VCF (multi-allelic positions: many different and repeated alleles on one
     position, on truth positions and off them, keyless and non-'.' records) against the oracle."""
