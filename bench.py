@@ -603,8 +603,8 @@ def shuffled_config3_variant(eng, bins, nv):
     ok = bool(np.array_equal(rocs[True][0], rocs[False][0]) and np.array_equal(rocs[True][1], rocs[False][1]))
     return {"value": nv * float(P3["records"]) / dt0, "value_repeated_run": nv * float(P3["records"]) / dt, "unit": "classifications/s", "vcfs": nv, "records_per_vcf": P3["records"], "steps": steps,
             "ms_per_step": dt * 1e3, "ms_per_step_unseen": dt0 * 1e3, "equals_sorted_variant": ok, "paths": paths,
-            "note": "10 M-record VCFs permuted: k_part_hist + k_part_scatter (level 1: partitions of 2^27 keys, exact regions), then k_bucket_scatter from the "
-                    "level-1 entries and k_join_lean per partition"}
+            "note": "10 M-record VCFs permuted: two partitions of 256 WIDE buckets (2^17 positions, up to 32 768 records) filled by ONE pass of the 512-digit "
+                    "k_bucket_scatter over the columns, k_join_lean<.., BIG> per bucket (`paths.bucket_partitions`; through round 5: two levels, `bucket_two_level`)"}
 
 
 def alleles_variant(eng, P, bins, nv):

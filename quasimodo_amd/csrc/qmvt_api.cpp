@@ -483,6 +483,7 @@ struct qm_batch {
   // waiting for the flags (a host round trip of ~ 0.15 ms per step).  QM_MEMO=0: off.
   std::vector<int> lastx_vs;          // bucketx_chunk: the chunk whose tables are on the device (a batch run again)
   std::vector<uint32_t> lastx_por;
+  bool lastx_wide = false;            // ... with the wide buckets of 2^17 positions (bucketw_takes)
   std::vector<int> lastx_seg_vcf;     // VCF of every segment
   int lastx_nseg = 0;
   int64_t lastx_nbt = 0, lastx_nkt = 0;
@@ -1582,7 +1583,21 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
 // two; nothing else is new -- bucket rows, the two joins, the rows per segment and their sum per VCF are the one-level and
 // two-level paths'.
 constexpr int PX_MAX_PARTS = 4;
-static int ext_parts_of(uint32_t posor) { return (int)((((uint64_t)posor << 4) | 15u) >> P2_SHIFT) + 1; }
+static int ext_parts_of(uint32_t posor, int pshift = P2_SHIFT) { return (int)((((uint64_t)posor << 4) | 15u) >> pshift) + 1; }
+// WIDE buckets (round 6): 2^17 positions and up to 32 768 records per bucket, 256 of them per partition of 2^29 keys.  A shuffled
+// default-mode VCF of 1.3 ... 67 M records on a reference of up to 67 M positions -- configs[3]'s 10 M records on 50 Mb -- is then
+// TWO partitions = ONE pass of the 512-digit scatter over its columns (pieces of 64 bytes and more: whole sectors) and
+// k_join_lean<.., BIG> per bucket, where the two-level path moves every record twice.
+constexpr int PW_SHIFT = DJ_BIG_SHIFT + 8;   // 29
+static bool join_hash_forced();
+static bool bucketw_takes(const qm_batch* b, int64_t n, uint32_t posor) {
+  if (b->ext || g_penv.radix_only || join_hash_forced() || g_penv.bucketx == 0) return false;
+  if (n > ((int64_t)1 << 26) || ext_parts_of(posor, PW_SHIFT) > 2) return false;    // (26 index bits of an entry; wider references: two levels)
+  if (g_penv.bucketx == 3) return n >= g_penv.bucket_min;                          // 3: every default-mode unsorted VCF that fits (tests, fuzz)
+  if (n < HB_MIN_RECORDS || ext_parts_of(posor) < 3) return false;                 // narrower references have cheaper paths
+  const int64_t buckets = ((((int64_t)posor << 4) | 15) >> DJ_BIG_SHIFT) + 1;
+  return n >= buckets * HB_MAX_RECORDS && n <= buckets * (4 * HB_MAX_RECORDS * 13 / 16);   // fuller than a narrow bucket, not fuller than eight sub-regions of 4 096 take
+}
 static bool bucketx_takes(const qm_batch* b, int64_t n, uint32_t posor) {
   if (b->ext && g_penv.bucket_ext == 0) return false;
   if (g_penv.radix_only) return false;
@@ -1600,12 +1615,14 @@ static bool bucketx_takes(const qm_batch* b, int64_t n, uint32_t posor) {
   return parts == 2;
 }
 
-static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, const std::vector<uint32_t>& posor, bool* taken) {
+static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, const std::vector<uint32_t>& posor, bool* taken, bool wide = false) {
   *taken = false;
   const int nv = (int)vs.size();
+  const int pshift = wide ? PW_SHIFT : P2_SHIFT, bshift = wide ? DJ_BIG_SHIFT : DJ_MAX_SHIFT;
+  const int64_t sub_max = wide ? 4 * HB_SUB_MAX : HB_SUB_MAX;
   std::vector<uint32_t> por((size_t)nv);
   for (int i = 0; i < nv; ++i) por[(size_t)i] = posor[(size_t)vs[(size_t)i]];
-  const bool same = !b->lastx_vs.empty() && b->lastx_vs == vs && b->lastx_por == por;   // the tables of this chunk are still on the device
+  const bool same = !b->lastx_vs.empty() && b->lastx_vs == vs && b->lastx_por == por && b->lastx_wide == wide;   // the tables of this chunk are still on the device
   int nseg = b->lastx_nseg;
   int64_t nbt = b->lastx_nbt, nkt = b->lastx_nkt;
   const bool xs = b->ext;                                  // two entry streams (allele-extended batches)
@@ -1620,13 +1637,13 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   for (int i = 0; i < nv; ++i) {
     const VcfDesc& d = b->L.vcfs[(size_t)vs[(size_t)i]];
     const uint32_t kor = (posor[(size_t)vs[(size_t)i]] << 4) | 15u;
-    const int parts = ext_parts_of(posor[(size_t)vs[(size_t)i]]);
+    const int parts = ext_parts_of(posor[(size_t)vs[(size_t)i]], pshift);
     const int seg0 = (int)segs.size();
     for (int p = 0; p < parts; ++p) {
       SortSeg g;
       memset(&g, 0, sizeof g);
       g.src_off = d.off; g.n = d.n; g.main_vcf = vs[(size_t)i]; g.sub_vcf = i; g.main_tile0 = d.tile0;
-      g.pad = DJ_MAX_SHIFT; g.key_base = (uint32_t)p << P2_SHIFT;
+      g.pad = bshift; g.key_base = (uint32_t)p << pshift;
       // neighbouring partitions share ONE pass over the columns: the tiles belong to the first of the group (two partitions with
       // the 512-digit scatter, up to eight with the 2 048-digit one), whose digits reach into the others' cursors, regions and rows
       // (same capacity, laid out one behind the other)
@@ -1634,9 +1651,9 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
       const bool lead = p == gfirst && gsize > 1, follow = p != gfirst;
       const bool pair_last = gfirst + gsize == parts;
       g.part = (pair_last ? 2 : 1) | (lead ? 4 | (gsize << 4) : 0);
-      g.nbk = p + 1 == parts ? std::min<int>(HB_BUCKETS, (int)((kor - g.key_base) >> DJ_MAX_SHIFT) + 1) : HB_BUCKETS;
+      g.nbk = p + 1 == parts ? std::min<int>(HB_BUCKETS, (int)((kor - g.key_base) >> bshift) + 1) : HB_BUCKETS;
       int64_t want = d.n / (128 * HB_SUBS) * 3 / 2 + 16, cap2 = 16;   // (how the records spread over the partitions is not known: room as for all of them)
-      while (cap2 < want && cap2 < HB_SUB_MAX) cap2 *= 2;
+      while (cap2 < want && cap2 < sub_max) cap2 *= 2;
       g.bk_cap = (int32_t)cap2; g.bk_off = bk_ents; g.bk_tile0 = (int32_t)nbt;
       bk_ents += (int64_t)HB_BUCKETS * HB_SUBS * cap2;
       const int64_t t = follow ? 0 : (d.n + BK_TILE - 1) / BK_TILE;   // (the second of a pair has no tiles of its own)
@@ -1696,13 +1713,12 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   HIPCHK(hipMemcpyAsync(b->d_bk_vcfs, fake.data(), sizeof(VcfDesc) * fake.size(), hipMemcpyHostToDevice, st));
   HIPCHK(hipMemcpyAsync(b->d_vparts, vparts.data(), 4 * vparts.size(), hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));   // the host tables die with this block
-  b->lastx_vs = vs; b->lastx_por = por; b->lastx_nseg = nseg; b->lastx_nbt = nbt; b->lastx_nkt = nkt;
+  b->lastx_vs = vs; b->lastx_por = por; b->lastx_wide = wide; b->lastx_nseg = nseg; b->lastx_nbt = nbt; b->lastx_nkt = nkt;
   b->lastx_seg_vcf.resize((size_t)nseg);
   for (int i = 0; i < nseg; ++i) b->lastx_seg_vcf[(size_t)i] = segs[(size_t)i].main_vcf;
   }   // !same
   const size_t nhist0 = (size_t)nseg * HB_BUCKETS * HB_SUBS + (size_t)nseg + 32 + 16 * 65;   // the scatter's per-segment histograms lie behind the cursors, flags and phase clocks
   const size_t ncur = (nhist0 + (size_t)nseg * (SEG_HIST_WORDS + 1)) * 4;   // (+ 1: seg_maxd behind the histograms)
-  HIPCHK(hipMemsetAsync(b->bk_cursor, 0, ncur, st));
   if (xs) HIPCHK(hipMemsetAsync(b->bk_xcursor, 0, (size_t)nseg * HB_BUCKETS * HB_SUBS * 4, st));
   BucketScatterParams S;
   S.segs = b->d_segs; S.tile_seg = b->d_bk_tile_seg; S.pos = b->pos; S.ref = b->ref; S.alt = b->alt; S.qual = b->qual; S.flags = b->flags;
@@ -1716,9 +1732,12 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   H.segs = b->d_segs; H.rows = b->bk_rows; H.rows_out = b->bk_rows; H.ent = b->bk_ent; H.cursor = b->bk_cursor; H.truths = b->ctx->d_truths; H.vcfs = b->d_vcfs;
   H.mask_tp = b->mask_tp; H.row_hist = b->bk_hist; H.row_scal = b->bk_scal; H.n_seg = nseg; H.n_bins = b->n_bins; H.seg_base = 0;
   H.xrows = xs ? b->bk_xrows : nullptr; H.xent = b->bk_xent; H.xcursor = b->bk_xcursor; H.out_stride = out_stride; H.ext = xs ? 1 : 0; H.scatter_hist = seg_hist ? 1 : 0; H.seg_maxd = seg_maxd;
+  H.zero = b->bk_cursor; H.n_zero = (uint32_t)(ncur / 4);   // the scatter's cursors, flags and counts: cleared by the kernel that writes the rows (one dispatch instead of a memset's two)
   launch_bucket_rows(H, nseg, st);
+  H.zero = nullptr; H.n_zero = 0u;
   launch_bucket_scatter(S, (int)nbt, st);
-  launch_join_lean(H, nseg, DJ_MAX_SHIFT, HB_BUCKETS, st);
+  if (wide) launch_join_big(H, nseg, HB_BUCKETS, st);
+  else launch_join_lean(H, nseg, DJ_MAX_SHIFT, HB_BUCKETS, st);
   if (xs) launch_join_ext(H, nseg, HB_BUCKETS, st);
   {
     FinalizeParams F = bucket_rows_finalize(b, seg_hist);
@@ -1752,25 +1771,32 @@ static int redo_unsorted(qm_batch* b, const std::vector<int>& todo, const std::v
   // buckets hold 8 192 records at most) in chunks of their own, the others on the radix sort
   // kind 3: allele-extended VCFs in partitions read from the columns (bucketx_chunk)
   refresh_path_env();
-  std::vector<int> part[4];
+  std::vector<int> part[5];   // 4: partitions of WIDE buckets (bucketw_takes)
   for (int v : todo) {
     const int64_t n = b->L.vcfs[(size_t)v].n;
     const bool force2 = g_penv.bucket2 == 2 && bucket2_takes(b, n);
-    part[bucketx_takes(b, n, posor[(size_t)v]) ? 3 : force2 ? 2 : bucket_path_takes(b, n) ? 1 : bucket2_takes(b, n) ? 2 : 0].push_back(v);
+    const bool forcew = g_penv.bucketx == 3 && bucketw_takes(b, n, posor[(size_t)v]);
+    part[forcew ? 4 : bucketx_takes(b, n, posor[(size_t)v]) ? 3 : force2 ? 2 : bucket_path_takes(b, n) ? 1 : bucketw_takes(b, n, posor[(size_t)v]) ? 4 : bucket2_takes(b, n) ? 2 : 0].push_back(v);
   }
   const int64_t chunk_records = sort_chunk_records();
-  for (int kind = 3; kind >= 0; --kind) {
+  for (int kind = 4; kind >= 0; --kind) {
     std::vector<int> chunk;
     int64_t chunk_n = 0;
     for (size_t i = 0; i <= part[kind].size(); ++i) {
       // (kind 3: every PAIR of partitions reads its whole VCF)
       const int64_t wgt = i < part[kind].size() ? b->L.vcfs[(size_t)part[kind][i]].n * (kind == 3 ? (ext_parts_of(posor[(size_t)part[kind][i]]) + 1) / 2 : 1) : 0;
       const bool flush = i == part[kind].size() || (!chunk.empty() && chunk_n + wgt > chunk_records) ||
-                         (kind >= 1 && chunk.size() >= (size_t)(kind == 3 ? 4096 / PX_MAX_PARTS : 4096));   // 256 rows of 1.5 KB and >= 1 MB of bucket regions per VCF: bounded per chunk
+                         (kind >= 1 && chunk.size() >= (size_t)(kind == 3 ? 4096 / PX_MAX_PARTS : kind == 4 ? 64 : 4096));   // (kind 4: 2 x 67 MB of bucket regions per VCF)   // 256 rows of 1.5 KB and >= 1 MB of bucket regions per VCF: bounded per chunk
       if (flush && !chunk.empty()) {
         int rc = QM_OK;
         bool taken = false;
-        if (kind == 3) {
+        if (kind == 4) {
+          rc = bucketx_chunk(b, chunk, st, b->last_global, posor, &taken, true);
+          if (rc == QM_OK && !taken) {   // a bucket did not fit after all: two levels, then the radix sort
+            rc = bucket2_chunk(b, chunk, st, b->last_global, &taken);
+            if (rc == QM_OK && !taken) { b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += (int64_t)chunk.size(); rc = sort_chunk(b, chunk, st, b->last_global, posor, false); b->path_stats[QM_PATH_RADIX] -= (int64_t)chunk.size(); }
+          }
+        } else if (kind == 3) {
           rc = bucketx_chunk(b, chunk, st, b->last_global, posor, &taken);
           if (rc == QM_OK && !taken) { b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += (int64_t)chunk.size(); rc = sort_chunk(b, chunk, st, b->last_global, posor, false); b->path_stats[QM_PATH_RADIX] -= (int64_t)chunk.size(); }
         } else if (kind == 2) {

@@ -203,6 +203,7 @@ constexpr int HB_TRUTH_SLOTS = 2048;     // truth keys of the bucket's positions
 constexpr int HB_NOKEY_SLOTS = 512;      // kept records without a comparable key
 constexpr int HB_MIN_RECORDS = 16384;    // smaller unsorted VCFs take the radix sort
 constexpr int HB_INDEX_BITS = 21;        // a bucket entry holds the record's index inside its VCF
+constexpr int DJ_BIG_SHIFT = 21;         // the wide buckets of shuffled 10 M-record VCFs: 2^17 positions (k_join_lean<.., BIG>: 48 KB of position maps)
 constexpr int DJ_MAX_SHIFT = 19;         // k_join_direct: a bucket's key range (2^shift keys) as ONE bit map in LDS, 64 KB at most
 // a bucket entry (8 bytes): key - (bucket << shift) in bits 0..23, info bits 0..11 (bin + 1, PASS, IDDOT, NOKEY) in 24..35,
 // the host-decided TP-line bit in 36, the record's index inside the VCF in 37..57
@@ -433,7 +434,8 @@ void launch_synth(const SynthParams& S, int n_vcf, int64_t max_n, hipStream_t st
 void launch_classify_hash(const HashParams& P, int nseg, hipStream_t st);   // segments P.seg_base .. + nseg
 void launch_bucket_rows(const HashParams& P, int nseg, hipStream_t st);
 void launch_join_ext(const HashParams& P, int nseg, int nbk, hipStream_t st);     // the second stream of an allele-extended batch
-void launch_join_lean(const HashParams& P, int nseg, int lb, int nbk, hipStream_t st);   // segments P.seg_base .. + nseg, every bucket shift <= lb <= DJ_MAX_SHIFT
+void launch_join_lean(const HashParams& P, int nseg, int lb, int nbk, hipStream_t st);
+void launch_join_big(const HashParams& P, int nseg, int nbk, hipStream_t st);   // k_join_lean<DJ_BIG_SHIFT, false, BIG>: buckets of 2^17 positions, up to 32 768 records   // segments P.seg_base .. + nseg, every bucket shift <= lb <= DJ_MAX_SHIFT
 void launch_bucket_scatter(const BucketScatterParams& P, int ntiles, hipStream_t st);   // tiles P.tile_base .. + ntiles; P.l1_ent: from level-1 entries
 void launch_sort_first_hist(const SortSeg* segs, const int32_t* tile_seg, int ntiles, const int32_t* pos_col, uint32_t* hist, uint32_t* orbits,
                             hipStream_t st);

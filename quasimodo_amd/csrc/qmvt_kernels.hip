@@ -2634,24 +2634,35 @@ constexpr uint32_t LJ_NOKEY_TAG = 1u << 24;   // (a key inside a bucket is below
 #define LJ_WAVES 6   // 80 VGPRs, three workgroups per CU: with 64 (four per CU) the kernel spills and is 4 % slower (same-box A/B)
 #endif
 // HIST = false: the scatter counted every record by bin (HashParams.scatter_hist): no histogram here but the true positives'
-template <int LB, bool HIST>
-__global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_WAVES, 8))) void k_join_lean(HashParams P) {
-  constexpr int PER = 16;                                // records per thread at most: four trips of four
+// BIG = true (round 6): buckets of 2^17 positions and up to 32 768 records -- a shuffled 10 M-record VCF on 50 Mb is TWO partitions
+// of 256 such buckets, filled by ONE pass of the 512-digit scatter whose pieces stay whole 64-byte sectors (with 2^15 positions per
+// bucket the VCF took a level-1 scatter of its own, or 21-byte pieces: LABNOTES round 6).  The same join with everything four times
+// as large: 1 024 threads, 32 records per thread (two waves per sub-region), 4 096 staged truth keys, 48 KB of position maps --
+// 120 KB of LDS, one workgroup per CU at four waves per SIMD.
+template <int LB, bool HIST, bool BIG = false>
+__global__ __launch_bounds__(BIG ? 1024 : LJ_THREADS) __attribute__((amdgpu_waves_per_eu(BIG ? 4 : LJ_WAVES, BIG ? 4 : 8))) void k_join_lean(HashParams P) {
+  constexpr int THREADS = BIG ? 1024 : LJ_THREADS;
+  constexpr int PER = BIG ? 32 : 16;                     // records per thread at most: trips of four
+  constexpr int TMAX = BIG ? 4 * DJ_TRUTH_MAX : DJ_TRUTH_MAX;   // staged truth keys
+  constexpr int TPT = TMAX / THREADS;                    // ... per thread
+  constexpr int SETL = BIG ? LJ_SET_LOG2 + 1 : LJ_SET_LOG2;
+  constexpr uint32_t SUBCAP = BIG ? 4u * HB_SUB_MAX : (uint32_t)HB_SUB_MAX;   // entries per sub-region at most
+  constexpr uint32_t WCAP = 64u * PER;                   // entries a wave holds: a whole sub-region, or (BIG) one half of one
   constexpr int W_WORDS = LB >= 10 ? (1 << (LB - 8)) : 4;    // sixteen positions per word: T in bits 0..15, S1 in 16..31
   constexpr int W2_WORDS = LB >= 11 ? (1 << (LB - 9)) : 4;   // S2: a bit per position
   constexpr int CI_N = LB > DJ_CI_LOG2 ? 1 << (LB - DJ_CI_LOG2) : 1;
-  static_assert(HB_SUB_MAX == 64 * PER && HB_SUBS * 64 == LJ_THREADS && W_WORDS % 4 == 0 && W2_WORDS % 4 == 0, "a wave per sub-region");
+  static_assert(SUBCAP == WCAP * (BIG ? 2 : 1) && HB_SUBS * 64 * (BIG ? 2 : 1) == THREADS && W_WORDS % 4 == 0 && W2_WORDS % 4 == 0 && TPT * THREADS == TMAX, "a wave (two) per sub-region");
   __shared__ __attribute__((aligned(16))) uint32_t s_W[W_WORDS];
   __shared__ __attribute__((aligned(16))) uint32_t s_W2[W2_WORDS];
-  __shared__ uint32_t s_tk[DJ_TRUTH_MAX + 2];        // the staged truth keys, sorted (absolute keys), 0xffffffff behind the last
+  __shared__ uint32_t s_tk[TMAX + 2];        // the staged truth keys, sorted (absolute keys), 0xffffffff behind the last
   __shared__ uint16_t s_ci[CI_N];                    // per block of 2^DJ_CI_LOG2 keys: index of its first staged truth key (written for blocks that hold one)
-  __shared__ uint32_t s_ts[DJ_TRUTH_MAX];            // per staged key: best bin + 1 of a '.'-ID match
-  __shared__ uint32_t s_tf[DJ_TRUTH_MAX / 32];       // matched by a kept record (ID ignored)
+  __shared__ uint32_t s_ts[TMAX];            // per staged key: best bin + 1 of a '.'-ID match
+  __shared__ uint32_t s_tf[TMAX / 32];       // matched by a kept record (ID ignored)
   __shared__ uint32_t s_ha[258];                     // every record by bin + 1 (slot 0: no bin; the top bin is counted in registers)
   __shared__ uint32_t s_htp[130];                    // TP records by bin + 1, two u16 slots per dword
   __shared__ uint32_t s_hu[128];                     // distinct-truth-key histogram, two u16 bins per dword
-  __shared__ uint32_t s_set[1 << LJ_SET_LOG2];
-  __shared__ __attribute__((aligned(8))) uint2 s_ring[(LJ_THREADS / 64) * LJ_RING];
+  __shared__ uint32_t s_set[1 << SETL];
+  __shared__ __attribute__((aligned(8))) uint2 s_ring[(THREADS / 64) * LJ_RING];
   __shared__ uint32_t s_c[8];                        // kept, TP lines, fresh keys of the exact set, matched truth keys, flags, top-bin records, set inserts, S1 - S2 bits
   const int tid = (int)threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2668,11 +2679,12 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
   const uint32_t* cur = P.cursor + row * HB_SUBS;
   const uint32_t segfl = d == 0 ? P.cursor[(size_t)P.n_seg * HB_BUCKETS * HB_SUBS + seg_id] : 0u;   // the segment's flags travel in its first row
   // maps, truth state and histograms are cleared while the descriptor and the cursors are on their way
-  for (int i = tid; i < W_WORDS / 4; i += LJ_THREADS) *reinterpret_cast<uint4*>(&s_W[4 * i]) = make_uint4(0u, 0u, 0u, 0u);
-  for (int i = tid; i < W2_WORDS / 4; i += LJ_THREADS) *reinterpret_cast<uint4*>(&s_W2[4 * i]) = make_uint4(0u, 0u, 0u, 0u);
-  for (int i = tid; i < (1 << LJ_SET_LOG2) / 4; i += LJ_THREADS) *reinterpret_cast<uint4*>(&s_set[4 * i]) = make_uint4(HB_EMPTY, HB_EMPTY, HB_EMPTY, HB_EMPTY);
-  s_ts[tid] = 0u; s_ts[tid + LJ_THREADS] = 0u;
-  if (tid < DJ_TRUTH_MAX / 32) s_tf[tid] = 0u;
+  for (int i = tid; i < W_WORDS / 4; i += THREADS) *reinterpret_cast<uint4*>(&s_W[4 * i]) = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = tid; i < W2_WORDS / 4; i += THREADS) *reinterpret_cast<uint4*>(&s_W2[4 * i]) = make_uint4(0u, 0u, 0u, 0u);
+  for (int i = tid; i < (1 << SETL) / 4; i += THREADS) *reinterpret_cast<uint4*>(&s_set[4 * i]) = make_uint4(HB_EMPTY, HB_EMPTY, HB_EMPTY, HB_EMPTY);
+#pragma unroll
+  for (int h = 0; h < TPT; ++h) s_ts[tid + h * THREADS] = 0u;
+  if (tid < TMAX / 32) s_tf[tid] = 0u;
   if (tid < 258) s_ha[tid] = 0u;
   if (tid < 130) s_htp[tid] = 0u;
   if (tid < 128) s_hu[tid] = 0u;
@@ -2686,7 +2698,8 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
     const uint32_t c = cur[k];
     const uint32_t n = c < cap ? c : cap;
     nrec += n;
-    nw = wave == k ? n : nw;
+    if (BIG) { const uint32_t off = (uint32_t)(wave & 1) * WCAP; if ((wave >> 1) == k) nw = n > off ? (n - off < WCAP ? n - off : WCAP) : 0u; }
+    else nw = wave == k ? n : nw;
   }
   const size_t orow = (size_t)seg_id * (size_t)P.out_stride + (size_t)d;   // where the bucket's row goes (allele-extended batches: the second stream's rows follow)
   uint32_t* oh = P.row_hist + orow * SPAN_HIST_WORDS;
@@ -2695,17 +2708,18 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
     if (tid < 8) P.row_scal[orow * 8 + tid] = tid == 5 ? segfl : 0u;
     return;
   }
-  over |= (R.shift > (uint32_t)LB || cap > (uint32_t)HB_SUB_MAX) ? 1u : 0u;   // (the host never launches this instantiation for such a segment)
+  over |= (R.shift > (uint32_t)LB || cap > SUBCAP) ? 1u : 0u;   // (the host never launches this instantiation for such a segment)
   const uint32_t shift = R.shift > (uint32_t)LB ? (uint32_t)LB : R.shift;   // 4 <= shift <= LB: a bucket is a whole range of positions
   const uint32_t kbase = R.kbase;                            // every key of the bucket is >= kbase
   const uint32_t klast = kbase + ((1u << shift) - 1u);
   const int tn_all = R.tn;
-  over |= tn_all > DJ_TRUTH_MAX ? 1u : 0u;
+  over |= tn_all > TMAX ? 1u : 0u;
   const int tn = over ? 0 : tn_all;
   if (over) nw = 0u;
   // every trip of the thread is in flight before anything else happens.  Lane l of wave w takes the quads l, l + 64, ... of
   // sub-region w: four consecutive entries, 32 bytes.
-  const gv4p wbase = (gv4p)R.ent + (size_t)wave * (cap >> 1);     // two entries per 16 bytes (cap is even: a power of two)
+  const gv4p wbase = BIG ? (gv4p)R.ent + (size_t)(wave >> 1) * (cap >> 1) + (size_t)(wave & 1) * (WCAP >> 1)
+                         : (gv4p)R.ent + (size_t)wave * (cap >> 1);     // two entries per 16 bytes (cap is even: a power of two)
   v4u ea[PER / 4], eb[PER / 4];
   const v4u z4 = {0u, 0u, 0u, 0u};
   const int ntrips = (int)((nw + 255u) >> 8);                       // wave-uniform
@@ -2718,23 +2732,25 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
       eb[g] = __builtin_nontemporal_load(wbase + 2u * q + 1u);
     }
   }
-  uint32_t tkey0 = 0xffffffffu, tkey1 = 0xffffffffu, tprev0 = 0u, tprev1 = 0u;   // (tprev: the key in front, for the coarse index; 0 is below every bucket's first key that matters)
-  if (tid < tn) tkey0 = g_tkeys[tid];
-  if (tid + LJ_THREADS < tn) tkey1 = g_tkeys[tid + LJ_THREADS];
-  if (tid > 0 && tid < tn) tprev0 = g_tkeys[tid - 1];
-  if (tid + LJ_THREADS < tn) tprev1 = g_tkeys[tid + LJ_THREADS - 1];
+  uint32_t tkey[TPT], tprev[TPT];   // (tprev: the key in front, for the coarse index; 0 is below every bucket's first key that matters)
+#pragma unroll
+  for (int h = 0; h < TPT; ++h) {
+    const int j = tid + h * THREADS;
+    tkey[h] = j < tn ? g_tkeys[j] : 0xffffffffu;
+    tprev[h] = j > 0 && j < tn ? g_tkeys[j - 1] : 0u;
+  }
   const int nw4 = (int)(((1u << shift) + 1023u) >> 10);      // 16-byte pieces of W in use (64 positions each); S2 has half as many
   if (tid < 8) s_c[tid] = tid == 4 ? (segfl | (over ? SPANF_OVERFLOW : 0u)) : 0u;
   __syncthreads();
   // ---- the truth keys of the bucket's positions: the sorted slice as it is (its keys outside the bucket match nothing), a bit per position inside ----
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int j = tid + h * LJ_THREADS;
-    const uint32_t k = h ? tkey1 : tkey0;
+  for (int h = 0; h < TPT; ++h) {
+    const int j = tid + h * THREADS;
+    const uint32_t k = tkey[h];
     const bool in = j < tn && k >= kbase && k <= klast;
     if (j < tn) s_tk[j] = k;
     if (in) atomicOr(&s_W[(k - kbase) >> 8], 1u << (((k - kbase) >> 4) & 15u));
-    const uint32_t kp = h ? tprev1 : tprev0;
+    const uint32_t kp = tprev[h];
     const bool pin = j > 0 && kp >= kbase;                    // (kp <= k <= klast)
     // the first key of its block of 2^DJ_CI_LOG2 keys names itself in the coarse index (the slice is sorted)
     if (in && (!pin || ((kp - kbase) >> DJ_CI_LOG2) != ((k - kbase) >> DJ_CI_LOG2))) s_ci[(k - kbase) >> DJ_CI_LOG2] = (uint16_t)j;
@@ -2892,10 +2908,10 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
         if (ballot64(coll)) {
           const uint32_t at = wave_reserve(&s_c[6], coll);
           if (coll) {
-            if (at >= (1u << LJ_SET_LOG2) / 2u) atomicOr(&s_c[4], SPANF_OVERFLOW);
+            if (at >= (1u << SETL) / 2u) atomicOr(&s_c[4], SPANF_OVERFLOW);
             else {
               bool fr;
-              (void)hb_insert(s_set, LJ_SET_LOG2, nokey ? (v | LJ_NOKEY_TAG) : v, &fr);
+              (void)hb_insert(s_set, SETL, nokey ? (v | LJ_NOKEY_TAG) : v, &fr);
               fresh += fr ? 1u : 0u;
             }
           }
@@ -2918,11 +2934,11 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
   // (S1 and S2 are final since the barrier above: only the exact set and the truth state were written behind it)
   {
     int32_t bits = 0;
-    for (int i = tid; i < nw4; i += LJ_THREADS) {
+    for (int i = tid; i < nw4; i += THREADS) {
       const uint4 w = *reinterpret_cast<const uint4*>(&s_W[4 * i]);
       bits += __popc(w.x >> 16) + __popc(w.y >> 16) + __popc(w.z >> 16) + __popc(w.w >> 16);
     }
-    for (int i = tid; i < (nw4 + 1) / 2; i += LJ_THREADS) {
+    for (int i = tid; i < (nw4 + 1) / 2; i += THREADS) {
       const uint4 w = *reinterpret_cast<const uint4*>(&s_W2[4 * i]);
       bits -= __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
     }
@@ -2932,8 +2948,8 @@ __global__ __launch_bounds__(LJ_THREADS) __attribute__((amdgpu_waves_per_eu(LJ_W
   __syncthreads();
   uint32_t tpr = 0;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int j = tid + h * LJ_THREADS;
+  for (int h = 0; h < TPT; ++h) {
+    const int j = tid + h * THREADS;
     if (j < tn) {
       const uint32_t mx = s_ts[j];
       if (mx) atomicAdd(&s_hu[(mx - 1u) >> 1], 1u << (16u * ((mx - 1u) & 1u)));
@@ -3482,6 +3498,9 @@ void launch_join_lean(const HashParams& P, int nseg, int lb, int nbk, hipStream_
     if (lb <= 16) hipLaunchKernelGGL((k_join_lean<16, true>), dim3(nbk, nseg), dim3(LJ_THREADS), 0, st, P);
     else hipLaunchKernelGGL((k_join_lean<DJ_MAX_SHIFT, true>), dim3(nbk, nseg), dim3(LJ_THREADS), 0, st, P);
   }
+}
+void launch_join_big(const HashParams& P, int nseg, int nbk, hipStream_t st) {   // buckets of 2^17 positions (SortSeg.pad = DJ_BIG_SHIFT), the scatter's histogram
+  if (nseg > 0) hipLaunchKernelGGL((k_join_lean<DJ_BIG_SHIFT, false, true>), dim3(nbk, nseg), dim3(1024), 0, st, P);
 }
 void launch_join_ext(const HashParams& P, int nseg, int nbk, hipStream_t st) {
   if (nseg > 0) hipLaunchKernelGGL(k_join_ext, dim3(nbk, nseg), dim3(XJ_THREADS), 0, st, P);

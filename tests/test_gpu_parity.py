@@ -268,11 +268,16 @@ def test_synthetic_batch_vs_oracle(engine, oracle, shuffled):
     b.close()
 
 
-def test_config3_shape_ten_million_record_vcfs(engine, oracle):
+@pytest.mark.parametrize("two_level", [False, True])
+def test_config3_shape_ten_million_record_vcfs(engine, oracle, monkeypatch, two_level):
     """BASELINE configs[3] shape per VCF: 10 M records on a 50 Mb reference, 1 M truth keys (611 spans,
-    9 766 tiles per VCF), sorted and shuffled, against the oracle.  Shuffled, such a VCF is six partitions of 2^27 keys and takes the
-    two-level bucket path (a one-pass 2 048-digit scatter was measured in round 6 and lost: LABNOTES.md)."""
+    9 766 tiles per VCF), sorted and shuffled, against the oracle.  Shuffled, such a VCF is two partitions of 256 WIDE buckets
+    (2^17 positions, up to 32 768 records: k_join_lean<.., BIG>) filled by ONE pass of the 512-digit scatter since round 6
+    (`bucket_partitions`); a level-1 scatter and a second one from its entries before (`bucket_two_level`, still there behind
+    QM_BUCKETX=0 and for wider references)."""
     from oracle.synth import synth_truth_keys
+    if two_level:
+        monkeypatch.setenv("QM_BUCKETX", "0")
     L, N, T = 50_000_000, 10_000_000, 1_000_000
     tid = engine.truth_synth(L, T, 4)
     tk = synth_truth_keys(L, T, 4)
@@ -284,7 +289,7 @@ def test_config3_shape_ten_million_record_vcfs(engine, oracle):
         if shuffled:
             ps = b.path_stats()
             assert ps["unsorted"] == 2 and ps["radix"] == 0 and ps["radix_after_overflow"] == 0, ps
-            assert (ps["bucket_two_level"], ps["bucket_partitions"]) == (2, 0), ps
+            assert (ps["bucket_two_level"], ps["bucket_partitions"]) == ((2, 0) if two_level else (0, 2)), ps
         roc, scal = b.roc(), b.scalars()
         for v in range(2):
             cols = b.columns(v)

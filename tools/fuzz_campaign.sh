@@ -12,6 +12,7 @@ SEED=105 run QM_BUCKET_EXT=0
 SEED=106 run QM_MEMO=0
 SEED=108 run QM_PIPE_CHUNKS=3
 SEED=109 run QM_BUCKETX=2
+SEED=110 run QM_BUCKETX=3
 SEED=112 run QM_BUCKET2=2 QM_MEMO=0
 # finish without its round trips (flags event, queued chunk tails) against the old waits; several chunks per finish
 SEED=117 run QM_SPECULATE=0
