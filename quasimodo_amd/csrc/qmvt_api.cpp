@@ -1590,13 +1590,26 @@ static int ext_parts_of(uint32_t posor, int pshift = P2_SHIFT) { return (int)(((
 // k_join_lean<.., BIG> per bucket, where the two-level path moves every record twice.
 constexpr int PW_SHIFT = DJ_BIG_SHIFT + 8;   // 29
 static bool join_hash_forced();
-static bool bucketw_takes(const qm_batch* b, int64_t n, uint32_t posor) {
+static bool bucketw_takes(const qm_batch* b, int v, int64_t n, uint32_t posor) {
   if (b->ext || g_penv.radix_only || join_hash_forced() || g_penv.bucketx == 0) return false;
   if (n > ((int64_t)1 << 26) || ext_parts_of(posor, PW_SHIFT) > 2) return false;    // (26 index bits of an entry; wider references: two levels)
   if (g_penv.bucketx == 3) return n >= g_penv.bucket_min;                          // 3: every default-mode unsorted VCF that fits (tests, fuzz)
   if (n < HB_MIN_RECORDS || ext_parts_of(posor) < 3) return false;                 // narrower references have cheaper paths
-  const int64_t buckets = ((((int64_t)posor << 4) | 15) >> DJ_BIG_SHIFT) + 1;
-  return n >= buckets * HB_MAX_RECORDS && n <= buckets * (4 * HB_MAX_RECORDS * 13 / 16);   // fuller than a narrow bucket, not fuller than eight sub-regions of 4 096 take
+  const int64_t kor = ((int64_t)posor << 4) | 15;
+  const int64_t buckets = (kor >> DJ_BIG_SHIFT) + 1;
+  const int64_t truth = b->ctx->truths[(size_t)b->L.vcfs[(size_t)v].truth].n;
+  // not fuller than eight sub-regions of 4 096 take; a bucket stages 4 096 truth keys (three quarters of that on average: the rest
+  // is room for an uneven truth set)
+  if (n > buckets * (4 * HB_MAX_RECORDS * 13 / 16) || truth > buckets * (4 * DJ_TRUTH_MAX * 3 / 4)) return false;
+  if (!bucket_path_takes(b, n)) return true;   // (above the one-level path's 1.31 M records.  Measured on 50 Mb, 1.6e8 records per step: 2 M-record VCFs 4.3e10 /s against the two levels' 2.8e10, 5 M 6.7e10 against 3.6e10)
+  // Up to 1.31 M records the one-level path takes a VCF of such a reference with the hashed join (7.5e10 /s where it fits, the
+  // wide buckets 3.9e10: their workgroups have a fixed cost and few records each) -- but a one-level bucket is 2^18+ positions
+  // here and the hashed join stages 1 024 truth keys: a denser truth set flags the chunk and the radix sort redoes it
+  // (1.3-1.7e10 /s; wide buckets: 2.7-3.4e10).
+  int msb = 31;
+  while (msb > 0 && !((kor >> msb) & 1)) --msb;
+  const int64_t one_level_buckets = (kor >> std::max(4, msb - 7)) + 1;
+  return truth > one_level_buckets * (HB_TRUTH_SLOTS / 2 * 5 / 8);
 }
 static bool bucketx_takes(const qm_batch* b, int64_t n, uint32_t posor) {
   if (b->ext && g_penv.bucket_ext == 0) return false;
@@ -1775,8 +1788,8 @@ static int redo_unsorted(qm_batch* b, const std::vector<int>& todo, const std::v
   for (int v : todo) {
     const int64_t n = b->L.vcfs[(size_t)v].n;
     const bool force2 = g_penv.bucket2 == 2 && bucket2_takes(b, n);
-    const bool forcew = g_penv.bucketx == 3 && bucketw_takes(b, n, posor[(size_t)v]);
-    part[forcew ? 4 : bucketx_takes(b, n, posor[(size_t)v]) ? 3 : force2 ? 2 : bucket_path_takes(b, n) ? 1 : bucketw_takes(b, n, posor[(size_t)v]) ? 4 : bucket2_takes(b, n) ? 2 : 0].push_back(v);
+    const bool wide = bucketw_takes(b, v, n, posor[(size_t)v]);
+    part[wide && g_penv.bucketx == 3 ? 4 : bucketx_takes(b, n, posor[(size_t)v]) ? 3 : force2 ? 2 : wide ? 4 : bucket_path_takes(b, n) ? 1 : bucket2_takes(b, n) ? 2 : 0].push_back(v);
   }
   const int64_t chunk_records = sort_chunk_records();
   for (int kind = 4; kind >= 0; --kind) {

@@ -203,6 +203,7 @@ constexpr int HB_TRUTH_SLOTS = 2048;     // truth keys of the bucket's positions
 constexpr int HB_NOKEY_SLOTS = 512;      // kept records without a comparable key
 constexpr int HB_MIN_RECORDS = 16384;    // smaller unsorted VCFs take the radix sort
 constexpr int HB_INDEX_BITS = 21;        // a bucket entry holds the record's index inside its VCF
+constexpr int DJ_TRUTH_MAX = 1024;   // k_join_lean: staged truth keys per bucket (whole cells of the coarse position index); four times as many per wide bucket
 constexpr int DJ_BIG_SHIFT = 21;         // the wide buckets of shuffled 10 M-record VCFs: 2^17 positions (k_join_lean<.., BIG>: 48 KB of position maps)
 constexpr int DJ_MAX_SHIFT = 19;         // k_join_direct: a bucket's key range (2^shift keys) as ONE bit map in LDS, 64 KB at most
 // a bucket entry (8 bytes): key - (bucket << shift) in bits 0..23, info bits 0..11 (bin + 1, PASS, IDDOT, NOKEY) in 24..35,

@@ -2596,7 +2596,6 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(HB_W
 }
 
 // staged truth keys per bucket and the coarse index over them (k_join_lean)
-constexpr int DJ_TRUTH_MAX = 1024;   // staged truth keys per bucket (whole cells of the coarse position index)
 constexpr int DJ_CI_LOG2 = 10;       // coarse index over the staged truth keys: one entry per 2^10 keys (64 positions)
 
 // ---------------------------------------------------------------------------

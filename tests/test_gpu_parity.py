@@ -303,6 +303,37 @@ def test_config3_shape_ten_million_record_vcfs(engine, oracle, monkeypatch, two_
         b.close()
 
 
+@pytest.mark.parametrize("records, truth, path", [(2_000_000, 100_000, "bucket_partitions"), (1_000_000, 100_000, "bucket_hashed"),
+                                                 (1_000_000, 1_000_000, "bucket_partitions")])
+def test_shuffled_vcfs_on_a_50_mb_reference_by_size_and_truth_density(engine, oracle, records, truth, path):
+    """Which buckets a shuffled default-mode VCF of a 50 Mb reference takes: above the one-level path's 1.31 M records the wide
+    ones (round 6; two levels before, 2.8e10 /s against 4.3e10); below, the one-level path with the hashed join -- unless the
+    truth set is so dense that a one-level bucket (2^18 positions here) would hold more truth keys than that join stages: then
+    the wide buckets as well (the chunk used to overflow and take the radix sort).  Against the oracle and the sorted run."""
+    from oracle.synth import synth_truth_keys
+    L = 50_000_000
+    tid = engine.truth_synth(L, truth, 4)
+    tk = synth_truth_keys(L, truth, 4)
+    res = {}
+    for shuffled in (False, True):
+        b = engine.batch([records, records], [tid, tid])
+        b.synth(L, truth, 4, 4000, shuffled=shuffled)
+        b.run()
+        b.finish()
+        if shuffled:
+            ps = b.path_stats()
+            assert ps["unsorted"] == 2 and ps["radix"] == 0 and ps["radix_after_overflow"] == 0 and ps["overflow_chunks"] == 0, ps
+            assert ps[path] == 2, ps
+            cols = b.columns(0)
+            cls, oroc, sc = oracle.classify_columns(*cols, *tk)
+            assert np.array_equal(b.cls(0), cls)
+            assert np.array_equal(b.roc()[0], oroc)
+            assert [int(x) for x in b.scalars()[0][:5]] == [sc[k] for k in ("n_pass", "tp_lines", "fp_lines", "TP_R", "FP_R")]
+        res[shuffled] = (b.roc().copy(), np.array(b.scalars())[:, :5].copy())
+        b.close()
+    assert np.array_equal(res[False][0], res[True][0]) and np.array_equal(res[False][1], res[True][1])
+
+
 def test_shuffled_vcfs_above_the_level_one_index_stay_on_buckets(engine, oracle):
     """Two shuffled VCFs of 32 M records: a level-1 entry of the two-level bucket path holds 24 index bits, so a
     VCF above 16.7 M records used to fall onto the radix sort (4x slower).  It is dealt out in runs of 2^24 records now, level-1
