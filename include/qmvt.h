@@ -231,7 +231,7 @@ enum {
   QM_PATH_RADIX_AFTER_OVERFLOW = 4,  /* ... radix-sorted after a bucket of their chunk overflowed */
   QM_PATH_BUCKET_CHUNKS = 5, QM_PATH_OVERFLOW_CHUNKS = 6, QM_PATH_RADIX_CHUNKS = 7,
   QM_PATH_DIRECT2 = 8,               /* ... too large for 256 buckets: dealt to partitions of 2^27 keys by a first scatter (two levels), then as QM_PATH_DIRECT */
-  QM_PATH_PARTITIONS = 9,            /* ... too large or too wide for 256 buckets: every partition of 2^27 keys a segment of ONE scatter that reads the columns */
+  QM_PATH_PARTITIONS = 9,            /* ... too large or too wide for 256 buckets: every partition (256 buckets of 2^15 positions, or of 2^17: up to 32 768 records each) a segment of ONE scatter that reads the columns */
   QM_N_PATH_STATS = 10
 };
 int qm_batch_path_stats(qm_batch* b, int64_t* out /*[QM_N_PATH_STATS]*/);

@@ -1657,9 +1657,8 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
       memset(&g, 0, sizeof g);
       g.src_off = d.off; g.n = d.n; g.main_vcf = vs[(size_t)i]; g.sub_vcf = i; g.main_tile0 = d.tile0;
       g.pad = bshift; g.key_base = (uint32_t)p << pshift;
-      // neighbouring partitions share ONE pass over the columns: the tiles belong to the first of the group (two partitions with
-      // the 512-digit scatter, up to eight with the 2 048-digit one), whose digits reach into the others' cursors, regions and rows
-      // (same capacity, laid out one behind the other)
+      // two neighbouring partitions share ONE pass over the columns: the tiles belong to the first of the pair, whose digits (512
+      // of them) reach into the second's cursors, regions and rows (same capacity, laid out one behind the other)
       const int gfirst = p / G * G, gsize = std::min(G, parts - gfirst);
       const bool lead = p == gfirst && gsize > 1, follow = p != gfirst;
       const bool pair_last = gfirst + gsize == parts;
