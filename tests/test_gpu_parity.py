@@ -334,6 +334,90 @@ def test_shuffled_vcfs_on_a_50_mb_reference_by_size_and_truth_density(engine, or
     assert np.array_equal(res[False][0], res[True][0]) and np.array_equal(res[False][1], res[True][1])
 
 
+def test_unsorted_vcfs_of_a_wide_reference_take_every_path_in_one_finish(engine, oracle, monkeypatch):
+    """One batch on a 40 Mb reference, uploaded columns with everything random_columns knows (repeats, multi-allelic sites,
+    keyless records, non-'.' IDs, infinite QUALs): a 1.5 M-record VCF out of order (wide buckets), one of 200 000 (one level,
+    hashed join), one of 5 000 (radix sort), a sorted one, and a second 1.5 M-record VCF with 30 % of its records on 3 000
+    positions -- its wide buckets overflow, the two levels behind them as well, and the radix sort redoes it (a chunk falls back
+    as a whole: QM_SORT_CHUNK_RECORDS keeps the two large VCFs in chunks of their own).  Twice: the second run with the batch's
+    memory of the first.  Every VCF against the oracle, the per-truth sums against the VCFs' rows."""
+    from conftest import random_columns, random_truth
+    from quasimodo_amd.engine import SCALAR_NAMES
+    monkeypatch.setenv("QM_SORT_CHUNK_RECORDS", "1600000")
+    rng = np.random.default_rng(6061)
+    L = 40_000_000
+    truth = random_truth(rng, 60_000, L)
+    tid = engine.truth_load(*truth)
+    cols = [random_columns(rng, n, L, truth, sorted_=s) for n, s in ((1_500_000, False), (200_000, False), (5_000, False), (300_000, True))]
+    pos, ref, alt, qual, flags = random_columns(rng, 1_500_000, L, truth, sorted_=False)
+    crowd = rng.random(len(pos)) < 0.3
+    pos = np.where(crowd, 20_000_000 + rng.integers(0, 3000, len(pos)), pos).astype(np.int32)
+    cols.append((pos, ref, alt, qual, flags))
+    b = engine.batch([len(c[0]) for c in cols], [tid] * len(cols))
+    for v, c in enumerate(cols):
+        b.upload(v, *c)
+    for rep in range(2):
+        b.run()
+        b.finish()
+        want = np.zeros((3, 256), np.uint64)
+        for v, c in enumerate(cols):
+            sc = dict(zip(SCALAR_NAMES, b.scalars()[v].tolist()))
+            reg = b.idx(v)
+            res = {"cls": b.cls(v), "roc": b.roc()[v], "scalars": sc, "tp_idx": reg[:sc["tp_lines"]].copy(), "fp_idx": reg[len(c[0]) - sc["fp_lines"]:].copy()}
+            check_vcf(oracle, res, c, truth, expect_sorted=(v == 3))
+            want += res["roc"]
+        assert np.array_equal(b.global_counts()[tid], want)
+        ps = b.path_stats()
+        assert ps["unsorted"] == 4 and ps["bucket_partitions"] == 1 and ps["bucket_hashed"] == 1 and ps["radix"] == 1 and ps["radix_after_overflow"] == 1, (rep, ps)
+    b.close()
+    engine.truth_release(tid)
+
+
+def test_wide_buckets_and_positions_above_what_the_optimistic_pass_saw(engine, oracle):
+    """test_positions_above_what_the_optimistic_pass_saw for the wide buckets: a 1.5 M-record VCF out of order whose records the
+    optimistic pass looks at (the first round of every span, the 64 samples) lie below 2^25 -- one wide partition by that
+    estimate -- while a quarter of the others lie between 2^25 and 60 M.  The scatter flags the records beyond the partition,
+    the radix sort redoes the VCF and its key OR corrects the estimate: the second run takes two wide partitions."""
+    from quasimodo_amd.engine import SCALAR_NAMES
+    rng = np.random.default_rng(6062)
+    n, span = 1_500_000, 16384
+    seen = np.zeros(n, bool)
+    for s0 in range(0, n, span):
+        seen[s0:s0 + 256] = True
+    seen[(np.arange(64) * n) >> 6] = True
+    lo = rng.integers(1, 1 << 25, n - n // 4).astype(np.int32)
+    hi = rng.integers(1 << 25, 60_000_000, n // 4).astype(np.int32)
+    pos = np.empty(n, np.int32)
+    pos[seen] = lo[:seen.sum()]
+    rest = np.concatenate([lo[seen.sum():], hi])
+    rng.shuffle(rest)
+    pos[~seen] = rest
+    pos[0], pos[1] = (1 << 25) - 1, 5          # the estimate is 2^25 - 1 exactly; the first span is out of order at once
+    ref = rng.integers(0, 4, n).astype(np.int32)
+    alt = ((ref + 1 + rng.integers(0, 3, n)) & 3).astype(np.int32)
+    qual = rng.integers(0, 256, n).astype(np.float32)
+    flags = (2 | (qual >= 20)).astype(np.uint8)
+    take = rng.random(n) < 0.2
+    tp_, tr_, ta_ = pos[take], ref[take], alt[take]
+    o = np.lexsort((ta_, tr_, tp_))
+    truth = (tp_[o], tr_[o], ta_[o])
+    tid = engine.truth_load(*truth)
+    cols = (pos, ref, alt, qual, flags)
+    b = engine.batch([n], [tid])
+    b.upload(0, *cols)
+    for rep in range(3):
+        b.run()
+        b.finish()
+        sc = dict(zip(SCALAR_NAMES, b.scalars()[0].tolist()))
+        reg = b.idx(0)
+        res = {"cls": b.cls(0), "roc": b.roc()[0], "scalars": sc, "tp_idx": reg[:sc["tp_lines"]].copy(), "fp_idx": reg[n - sc["fp_lines"]:].copy()}
+        check_vcf(oracle, res, cols, truth, expect_sorted=False)
+        ps = b.path_stats()
+        assert ps["radix_after_overflow"] == (1 if rep == 0 else 0) and ps["bucket_partitions"] == (0 if rep == 0 else 1), (rep, ps)
+    b.close()
+    engine.truth_release(tid)
+
+
 def test_shuffled_vcfs_above_the_level_one_index_stay_on_buckets(engine, oracle):
     """Two shuffled VCFs of 32 M records: a level-1 entry of the two-level bucket path holds 24 index bits, so a
     VCF above 16.7 M records used to fall onto the radix sort (4x slower).  It is dealt out in runs of 2^24 records now, level-1
