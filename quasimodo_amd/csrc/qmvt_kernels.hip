@@ -2715,28 +2715,21 @@ __global__ __launch_bounds__(BIG ? 1024 : LJ_THREADS) __attribute__((amdgpu_wave
   over |= tn_all > TMAX ? 1u : 0u;
   const int tn = over ? 0 : tn_all;
   if (over) nw = 0u;
-  // every trip of the thread is in flight before anything else happens.  Lane l of wave w takes the quads l, l + 64, ... of
-  // sub-region w: four consecutive entries, 32 bytes.
-  const gv4p wbase = BIG ? (gv4p)R.ent + (size_t)(wave >> 1) * (cap >> 1) + (size_t)(wave & 1) * (WCAP >> 1)
-                         : (gv4p)R.ent + (size_t)wave * (cap >> 1);     // two entries per 16 bytes (cap is even: a power of two)
-  v4u ea[PER / 4], eb[PER / 4];
-  const v4u z4 = {0u, 0u, 0u, 0u};
-  const int ntrips = (int)((nw + 255u) >> 8);                       // wave-uniform
-#pragma unroll
-  for (int g = 0; g < PER / 4; ++g) {
-    const uint32_t q = (uint32_t)g * 64u + (uint32_t)lane;
-    ea[g] = z4; eb[g] = z4;
-    if (4u * q < nw) {
-      ea[g] = __builtin_nontemporal_load(wbase + 2u * q);
-      eb[g] = __builtin_nontemporal_load(wbase + 2u * q + 1u);
-    }
-  }
-  uint32_t tkey[TPT], tprev[TPT];   // (tprev: the key in front, for the coarse index; 0 is below every bucket's first key that matters)
+  // The order of the loads (round 6, from clock stations in the wide join, where a workgroup is alone on its CU: with every trip
+  // asked for up front, as rounds 3-5 had it, the workgroup reached its first barrier after 11 of its 31 us -- a CU's memory
+  // pipeline takes a few KB of requests at a time, so ISSUING 200 KB of loads is waiting for them): the truth keys first; the
+  // entries only behind the truth bits, so that the pass takes the trips one at a time while the later ones are still on their
+  // way and no barrier stands behind the loads.  Wide buckets: 0.70 -> 0.65 ms per 1.6e8 records, narrow ones 0.81 -> 0.79 per
+  // 2.56e8 (same-box A/B; lightly filled wide buckets lose 2 %: their dummy loads).
+  // EVERY load is issued by every lane, whatever the bucket holds -- a lane with nothing to fetch reads a word that is there
+  // anyway (the slice's first key, its sub-region's first quad: one request for all such lanes) and throws it away: behind a
+  // branch the compiler cannot count the loads in flight and waits for all of them (s_waitcnt vmcnt(0)) at the first use.
+  uint32_t tkey[TPT];
+  const gu32p tk_safe = tn > 0 ? g_tkeys : (gu32p)P.rows;   // (an empty slice may lie at the end of the truth table)
 #pragma unroll
   for (int h = 0; h < TPT; ++h) {
     const int j = tid + h * THREADS;
-    tkey[h] = j < tn ? g_tkeys[j] : 0xffffffffu;
-    tprev[h] = j > 0 && j < tn ? g_tkeys[j - 1] : 0u;
+    tkey[h] = tk_safe[j < tn ? j : 0];
   }
   const int nw4 = (int)(((1u << shift) + 1023u) >> 10);      // 16-byte pieces of W in use (64 positions each); S2 has half as many
   if (tid < 8) s_c[tid] = tid == 4 ? (segfl | (over ? SPANF_OVERFLOW : 0u)) : 0u;
@@ -2745,59 +2738,70 @@ __global__ __launch_bounds__(BIG ? 1024 : LJ_THREADS) __attribute__((amdgpu_wave
 #pragma unroll
   for (int h = 0; h < TPT; ++h) {
     const int j = tid + h * THREADS;
-    const uint32_t k = tkey[h];
+    const uint32_t k = j < tn ? tkey[h] : 0xffffffffu;
     const bool in = j < tn && k >= kbase && k <= klast;
     if (j < tn) s_tk[j] = k;
     if (in) atomicOr(&s_W[(k - kbase) >> 8], 1u << (((k - kbase) >> 4) & 15u));
-    const uint32_t kp = tprev[h];
-    const bool pin = j > 0 && kp >= kbase;                    // (kp <= k <= klast)
-    // the first key of its block of 2^DJ_CI_LOG2 keys names itself in the coarse index (the slice is sorted)
-    if (in && (!pin || ((kp - kbase) >> DJ_CI_LOG2) != ((k - kbase) >> DJ_CI_LOG2))) s_ci[(k - kbase) >> DJ_CI_LOG2] = (uint16_t)j;
   }
   if (tid < 2) s_tk[tn + tid] = 0xffffffffu;                 // behind the last staged key: a look-up may read past its key
   __syncthreads();
+  // ---- the entries: lane l of wave w takes the quads l, l + 64, ... of sub-region w, four consecutive entries = 32 bytes ----
+  const gv4p wbase = BIG ? (gv4p)R.ent + (size_t)(wave >> 1) * (cap >> 1) + (size_t)(wave & 1) * (WCAP >> 1)
+                         : (gv4p)R.ent + (size_t)wave * (cap >> 1);     // two entries per 16 bytes (cap is even: a power of two)
+  v4u ea[PER / 4], eb[PER / 4];
+  const int ntrips = (int)((nw + 255u) >> 8);                       // wave-uniform
+#pragma unroll
+  for (int g = 0; g < PER / 4; ++g) {
+    const uint32_t q = (uint32_t)g * 64u + (uint32_t)lane;
+    const uint32_t qq = 4u * q < nw ? q : 0u;                       // (behind the cursor: the first quad again; the pass zeroes it, trips >= ntrips are never looked at)
+    ea[g] = __builtin_nontemporal_load(wbase + 2u * qq);
+    eb[g] = __builtin_nontemporal_load(wbase + 2u * qq + 1u);
+  }
+  // the coarse index (read by the settle step, two barriers on): the first key of its block of 2^DJ_CI_LOG2 keys names itself
+  // (the slice is sorted; the key in front comes from LDS now that the slice is staged)
+#pragma unroll
+  for (int h = 0; h < TPT; ++h) {
+    const int j = tid + h * THREADS;
+    const uint32_t k = tkey[h];
+    const bool in = j < tn && k >= kbase && k <= klast;
+    const uint32_t kp = j > 0 && j < tn ? s_tk[j - 1] : 0u;   // (0 is below every bucket's first key that matters)
+    const bool pin = j > 0 && kp >= kbase;                    // (kp <= k <= klast)
+    if (in && (!pin || ((kp - kbase) >> DJ_CI_LOG2) != ((k - kbase) >> DJ_CI_LOG2))) s_ci[(k - kbase) >> DJ_CI_LOG2] = (uint16_t)j;
+  }
   const uint32_t nb = (uint32_t)P.n_bins;
   int ttop = 0;                                              // largest power of two <= tn
   if (tn > 0) ttop = 1 << (31 - __clz(tn));
   uint32_t n_tp = 0, fresh = 0;
   uint32_t hitm = 0, keptm = 0, top = 0, nkm = 0;            // bit k: record k sits on a truth position (or is a host-decided TP line) / is kept / (rare) is kept without a key
-  // the partly filled quad at the end of the sub-region: what lies behind the cursor there is left over from an earlier run
-#pragma unroll
-  for (int g = 0; g < PER / 4; ++g) {
-    if (nw > (uint32_t)g * 256u && nw < (uint32_t)(g + 1) * 256u) {   // wave-uniform
-      const int left = (int)nw - 4 * (g * 64 + lane);         // entries of the lane's quad in front of the cursor
-      if (left < 4) { eb[g][2] = 0u; eb[g][3] = 0u; }
-      if (left < 3) { eb[g][0] = 0u; eb[g][1] = 0u; }
-      if (left < 2) { ea[g][2] = 0u; ea[g][3] = 0u; }
-      if (left < 1) { ea[g][0] = 0u; ea[g][1] = 0u; }
-    }
-  }
-  // Records without a comparable key and host-decided TP lines are rare.  A wave that holds one (one OR over its entries' flag
-  // words tells) rewrites those entries in its registers so that the one pass below needs no mask for them: a keyless record
+  // Records without a comparable key and host-decided TP lines are rare.  A wave that holds one in a trip (one OR over the trip's
+  // flag words tells) rewrites those entries in its registers so that the ORs below need no mask for them: a keyless record
   // loses its PASS bit (it marks no position and is counted as kept through nkm), which moves to bit 31 of its flag word for
   // the settle step; host-decided TP lines are added to the records to be settled afterwards.
-  uint32_t orall = 0, tplm = 0;
-#pragma unroll
-  for (int g = 0; g < PER / 4; ++g) orall |= ea[g][1] | ea[g][3] | eb[g][1] | eb[g][3];
-  if (ballot64((orall & 0x18u) != 0u)) {
-#pragma unroll
-    for (int g = 0; g < PER / 4; ++g) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t ehi = u == 0 ? ea[g][1] : u == 1 ? ea[g][3] : u == 2 ? eb[g][1] : eb[g][3];
-        const uint32_t nokey = (ehi >> 3) & 1u, kb = (ehi >> 1) & 1u;
-        tplm |= ((ehi >> 4) & 1u) << (4 * g + u);
-        nkm |= (kb & nokey) << (4 * g + u);
-        const uint32_t nhi = nokey ? ((ehi & ~2u) | (kb << 31)) : ehi;
-        if (u == 0) ea[g][1] = nhi; else if (u == 1) ea[g][3] = nhi; else if (u == 2) eb[g][1] = nhi; else eb[g][3] = nhi;
-      }
-    }
-  }
+  uint32_t tplm = 0;
   const bool run = !(s_c[4] & SPANF_OVERFLOW);
   auto pass = [&]() {
 #pragma unroll
     for (int g = 0; g < PER / 4; ++g) {
       if (g < ntrips) {                                        // wave-uniform
+        // the partly filled quad at the end of the sub-region: what lies behind the cursor there is left over from an earlier run
+        if (nw < (uint32_t)(g + 1) * 256u) {                   // wave-uniform (nw > g * 256: g < ntrips)
+          const int left = (int)nw - 4 * (g * 64 + lane);      // entries of the lane's quad in front of the cursor
+          if (left < 4) { eb[g][2] = 0u; eb[g][3] = 0u; }
+          if (left < 3) { eb[g][0] = 0u; eb[g][1] = 0u; }
+          if (left < 2) { ea[g][2] = 0u; ea[g][3] = 0u; }
+          if (left < 1) { ea[g][0] = 0u; ea[g][1] = 0u; }
+        }
+        if (ballot64(((ea[g][1] | ea[g][3] | eb[g][1] | eb[g][3]) & 0x18u) != 0u)) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t ehi = u == 0 ? ea[g][1] : u == 1 ? ea[g][3] : u == 2 ? eb[g][1] : eb[g][3];
+            const uint32_t nokey = (ehi >> 3) & 1u, kb = (ehi >> 1) & 1u;
+            tplm |= ((ehi >> 4) & 1u) << (4 * g + u);
+            nkm |= (kb & nokey) << (4 * g + u);
+            const uint32_t nhi = nokey ? ((ehi & ~2u) | (kb << 31)) : ehi;
+            if (u == 0) ea[g][1] = nhi; else if (u == 1) ea[g][3] = nhi; else if (u == 2) eb[g][1] = nhi; else eb[g][3] = nhi;
+          }
+        }
         uint32_t old[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {                          // the four returning ORs of the trip first, in flight together
@@ -3061,26 +3065,28 @@ __global__ __launch_bounds__(XJ_THREADS) void k_join_ext(HashParams P) {
     for (int q = 0; q < HB_SUBS; ++q) b0 = k == (uint32_t)q ? pre[q] : b0;
     return g_ent + ((size_t)k * cap + (size_t)(e - b0));
   };
-  // the first four trips' entries (all of them but for the fullest buckets) are asked for before anything else: they arrive while
-  // the truth slice is staged (asked for when pass 1 wanted them, a workgroup spent half its life waiting for them)
+  // The truth slice is asked for first, then the first four trips' entries (all of them but for the fullest buckets): loads come
+  // back in the order they were issued, so the slice is staged while the entries are on their way.  Every lane issues every load
+  // -- one with nothing to fetch reads the slice's / the bucket's first entry and ignores it: a load behind a branch made the
+  // compiler wait for ALL loads in flight at the first use of any of them (k_join_lean; here it waited for the entries before
+  // it had even asked for the slice).
   v4u q4[4];
   auto ask = [&](int t0) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      q4[u] = v4u{0u, 0u, 0u, 0u};
       const uint32_t e = (uint32_t)(t0 + u) * XJ_THREADS + (uint32_t)tid;
-      if (t0 + u < ntrips && e < nrec) q4[u] = __builtin_nontemporal_load(entry_at(e));
+      q4[u] = __builtin_nontemporal_load(entry_at(t0 + u < ntrips && e < nrec ? e : 0u));   // (nrec > 0 here: entry 0 is there)
     }
   };
-  ask(0);
   // ---- the truth entries of the bucket's positions: the sorted slice as it is; a bit per position that holds an extended one ----
   {
-    const gu32p gk = (gu32p)R.xkeys;
-    const gi32p gr = (gi32p)R.xref, ga = (gi32p)R.xalt;
+    const gu32p gk = tn > 0 ? (gu32p)R.xkeys : (gu32p)P.xrows;   // (an empty slice may lie at the end of the table)
+    const gi32p gr = tn > 0 ? (gi32p)R.xref : (gi32p)P.xrows, ga = tn > 0 ? (gi32p)R.xalt : (gi32p)P.xrows;
     const uint32_t klast = kbase + ((1u << (R.shift > (uint32_t)DJ_MAX_SHIFT ? (uint32_t)DJ_MAX_SHIFT : R.shift)) - 1u);
-    uint32_t k0 = 0, r0 = 0, a0 = 0, k1 = 0, r1 = 0, a1 = 0;
-    if (tid < tn) { k0 = gk[tid]; r0 = (uint32_t)gr[tid]; a0 = (uint32_t)ga[tid]; }
-    if (tid + XJ_THREADS < tn) { k1 = gk[tid + XJ_THREADS]; r1 = (uint32_t)gr[tid + XJ_THREADS]; a1 = (uint32_t)ga[tid + XJ_THREADS]; }
+    const int j0 = tid < tn ? tid : 0, j1 = tid + XJ_THREADS < tn ? tid + XJ_THREADS : 0;
+    const uint32_t k0 = gk[j0], r0 = (uint32_t)gr[j0], a0 = (uint32_t)ga[j0];
+    const uint32_t k1 = gk[j1], r1 = (uint32_t)gr[j1], a1 = (uint32_t)ga[j1];
+    ask(0);
     __syncthreads();   // the maps are clear
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
