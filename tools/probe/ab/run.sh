@@ -1,6 +1,8 @@
 #!/bin/bash
 # A/B of a kernels build on ONE box: the same shuffled batches through the default library and through tools/probe/ab/libqmvt_<tag>.so,
 # interleaved; step times and the trace's per-kernel averages.   usage: bash tools/probe/ab/run.sh <tag> [reps]
+# (the other build: `git archive <rev> quasimodo_amd/csrc include | tar -x -C /tmp/x`, `make` in its csrc with include/ two levels up, copy libqmvt.so to
+# tools/probe/ab/libqmvt_<tag>.so -- git-ignored, travels with gpurun)
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 cd $ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
 TAG=$1; REPS=${2:-3}
