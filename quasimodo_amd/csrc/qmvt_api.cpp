@@ -1788,7 +1788,14 @@ static int redo_unsorted(qm_batch* b, const std::vector<int>& todo, const std::v
     const int64_t n = b->L.vcfs[(size_t)v].n;
     const bool force2 = g_penv.bucket2 == 2 && bucket2_takes(b, n);
     const bool wide = bucketw_takes(b, v, n, posor[(size_t)v]);
-    part[wide && g_penv.bucketx == 3 ? 4 : bucketx_takes(b, n, posor[(size_t)v]) ? 3 : force2 ? 2 : wide ? 4 : bucket_path_takes(b, n) ? 1 : bucket2_takes(b, n) ? 2 : 0].push_back(v);
+    // A default-mode VCF with more records than the narrow buckets of its reference hold (8 192 per 2^15 positions, the
+    // sub-regions 13/16 full on average: 0.2 records per position) overflows the partitions and the two levels alike, and a
+    // chunk falls back as a whole: such a VCF goes to the radix sort alone instead of taking its neighbours with it.  (The
+    // position bits are an upper bound of up to twice the highest position: this errs towards trying the buckets.)
+    const int64_t narrow_buckets = ((((int64_t)posor[(size_t)v] << 4) | 15) >> DJ_MAX_SHIFT) + 1;
+    const bool dense = !b->ext && g_penv.bucketx != 2 && g_penv.bucket2 != 2 && n > narrow_buckets * (HB_MAX_RECORDS * 13 / 16);
+    part[wide && g_penv.bucketx == 3 ? 4 : !dense && bucketx_takes(b, n, posor[(size_t)v]) ? 3 : force2 ? 2 : wide ? 4 : bucket_path_takes(b, n) ? 1
+         : !dense && bucket2_takes(b, n) ? 2 : 0].push_back(v);
   }
   const int64_t chunk_records = sort_chunk_records();
   for (int kind = 4; kind >= 0; --kind) {

@@ -2746,16 +2746,19 @@ __global__ __launch_bounds__(BIG ? 1024 : LJ_THREADS) __attribute__((amdgpu_wave
   if (tid < 2) s_tk[tn + tid] = 0xffffffffu;                 // behind the last staged key: a look-up may read past its key
   __syncthreads();
   // ---- the entries: lane l of wave w takes the quads l, l + 64, ... of sub-region w, four consecutive entries = 32 bytes ----
-  const gv4p wbase = BIG ? (gv4p)R.ent + (size_t)(wave >> 1) * (cap >> 1) + (size_t)(wave & 1) * (WCAP >> 1)
-                         : (gv4p)R.ent + (size_t)wave * (cap >> 1);     // two entries per 16 bytes (cap is even: a power of two)
+  const gv4p sbase = (gv4p)R.ent + (size_t)(BIG ? wave >> 1 : wave) * (cap >> 1);   // the wave's sub-region; two entries per 16 bytes (cap is even: a power of two)
+  const uint32_t qoff = BIG ? (uint32_t)(wave & 1) * (WCAP / 4u) : 0u;             // (BIG: the quads of the sub-region's first half belong to the wave in front)
   v4u ea[PER / 4], eb[PER / 4];
   const int ntrips = (int)((nw + 255u) >> 8);                       // wave-uniform
 #pragma unroll
   for (int g = 0; g < PER / 4; ++g) {
     const uint32_t q = (uint32_t)g * 64u + (uint32_t)lane;
-    const uint32_t qq = 4u * q < nw ? q : 0u;                       // (behind the cursor: the first quad again; the pass zeroes it, trips >= ntrips are never looked at)
-    ea[g] = __builtin_nontemporal_load(wbase + 2u * qq);
-    eb[g] = __builtin_nontemporal_load(wbase + 2u * qq + 1u);
+    // behind the cursor: the SUB-REGION's first quad again (the pass zeroes it, trips >= ntrips are never looked at) -- not the
+    // half's: a sub-region of fewer than 4 096 entries ends in front of its second half, the last one of the last bucket at the
+    // end of the allocation (tools/gpu_fuzz_big.py found that one: a fault)
+    const uint32_t qq = 4u * q < nw ? qoff + q : 0u;
+    ea[g] = __builtin_nontemporal_load(sbase + 2u * qq);
+    eb[g] = __builtin_nontemporal_load(sbase + 2u * qq + 1u);
   }
   // the coarse index (read by the settle step, two barriers on): the first key of its block of 2^DJ_CI_LOG2 keys names itself
   // (the slice is sorted; the key in front comes from LDS now that the slice is staged)

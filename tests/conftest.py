@@ -56,7 +56,7 @@ def engine(qmlib):
     eng.close()
 
 
-def random_columns(rng, n, genome_len, truth, frac_truth=0.3, sorted_=True, dup_frac=0.05, weird=True):
+def random_columns(rng, n, genome_len, truth, frac_truth=0.3, sorted_=True, dup_frac=0.05, weird=True, near_frac=0.05):
     """Seeded column-level test input: (pos, ref, alt, qual, flags) with hits, duplicates,
     same-position runs, non-SNP codes, non-'.' IDs and failing QUALs."""
     tpos, tref, talt = truth
@@ -70,7 +70,7 @@ def random_columns(rng, n, genome_len, truth, frac_truth=0.3, sorted_=True, dup_
         ref = np.where(take, tref[j], ref).astype(np.int32)
         alt = np.where(take, talt[j], alt).astype(np.int32)
         # same position as a truth key but another allele
-        near = rng.random(n) < 0.05
+        near = rng.random(n) < near_frac
         pos = np.where(near, tpos[j], pos).astype(np.int32)
     if n:
         d = rng.random(n) < dup_frac                 # duplicate of another record

@@ -418,6 +418,63 @@ def test_wide_buckets_and_positions_above_what_the_optimistic_pass_saw(engine, o
     engine.truth_release(tid)
 
 
+def test_a_vcf_too_dense_for_any_bucket_goes_to_the_radix_sort_alone(engine, oracle):
+    """Three VCFs out of order on 10.6 M positions (a pair of narrow partitions): 150 000 and 570 000 records, and 3.7 M -- 0.35
+    records per position, more than the buckets of such a reference hold.  A chunk falls back as a whole, so the dense VCF used
+    to take its neighbours to the radix sort with it; the routing now sends it there alone (tools/gpu_fuzz_big.py, round 6)."""
+    from conftest import random_columns, random_truth
+    from quasimodo_amd.engine import SCALAR_NAMES
+    rng = np.random.default_rng(6064)
+    L = 10_600_000
+    truth = random_truth(rng, 200_000, L)
+    tid = engine.truth_load(*truth)
+    cols = [random_columns(rng, n, L, truth, frac_truth=0.05, sorted_=False, dup_frac=0.01, near_frac=0.01) for n in (150_000, 3_700_000, 570_000)]
+    b = engine.batch([len(c[0]) for c in cols], [tid] * 3)
+    for v, c in enumerate(cols):
+        b.upload(v, *c)
+    for rep in range(2):
+        b.run()
+        b.finish()
+        ps = b.path_stats()
+        assert ps["unsorted"] == 3 and ps["radix"] == 1 and ps["radix_after_overflow"] == 0 and ps["bucket_partitions"] == 2, (rep, ps)
+        for v, c in enumerate(cols):
+            sc = dict(zip(SCALAR_NAMES, b.scalars()[v].tolist()))
+            reg = b.idx(v)
+            res = {"cls": b.cls(v), "roc": b.roc()[v], "scalars": sc, "tp_idx": reg[:sc["tp_lines"]].copy(), "fp_idx": reg[len(c[0]) - sc["fp_lines"]:].copy()}
+            check_vcf(oracle, res, c, truth, expect_sorted=False)
+    b.close()
+    engine.truth_release(tid)
+
+
+def test_wide_buckets_up_to_the_end_of_their_regions(engine, oracle):
+    """A 1 M-record VCF out of order on 67.1 M positions against 400 000 truth keys (too dense for the hashed join: wide
+    buckets): two wide partitions whose LAST bucket is in use, sub-regions of 2 048 entries -- half of what a wave pair of the
+    wide join covers.  The lanes of the join that have nothing to fetch read their sub-region's first quad (every lane issues
+    every load, k_join_lean); in round 6's first form they read the first quad of the wave's HALF, which for such a sub-region
+    lies behind it -- for the last bucket's last sub-region behind the allocation: tools/gpu_fuzz_big.py found the fault."""
+    from conftest import random_columns, random_truth
+    from quasimodo_amd.engine import SCALAR_NAMES
+    rng = np.random.default_rng(6063)
+    L, n = 67_100_000, 1_000_000
+    truth = random_truth(rng, 400_000, L)
+    tid = engine.truth_load(*truth)
+    cols = random_columns(rng, n, L, truth, frac_truth=0.3, sorted_=False, near_frac=0.02)
+    assert int(cols[0].max()) >= 511 * (1 << 17)
+    b = engine.batch([n], [tid])
+    b.upload(0, *cols)
+    for rep in range(2):
+        b.run()
+        b.finish()
+        ps = b.path_stats()
+        assert ps["bucket_partitions"] == 1 and ps["radix_after_overflow"] == 0, ps
+        sc = dict(zip(SCALAR_NAMES, b.scalars()[0].tolist()))
+        reg = b.idx(0)
+        res = {"cls": b.cls(0), "roc": b.roc()[0], "scalars": sc, "tp_idx": reg[:sc["tp_lines"]].copy(), "fp_idx": reg[n - sc["fp_lines"]:].copy()}
+        check_vcf(oracle, res, cols, truth, expect_sorted=False)
+    b.close()
+    engine.truth_release(tid)
+
+
 def test_shuffled_vcfs_above_the_level_one_index_stay_on_buckets(engine, oracle):
     """Two shuffled VCFs of 32 M records: a level-1 entry of the two-level bucket path holds 24 index bits, so a
     VCF above 16.7 M records used to fall onto the radix sort (4x slower).  It is dealt out in runs of 2^24 records now, level-1

@@ -20,4 +20,6 @@ SEED=118 run QM_FLAGS_WAIT=stream
 SEED=119 run QM_SORT_CHUNK_RECORDS=60000
 SEED=120 run QM_SORT_CHUNK_RECORDS=60000 QM_MEMO=0
 SEED=121 run QM_NO_MIRRORS=1
+# the sizes where the paths hand over to one another, with the library's own routing (VCFs of 20 000 ... 4 M records on 3 ... 120 Mb)
+echo "== tools/gpu_fuzz_big.py" >> $OUT; python3 tools/gpu_fuzz_big.py 80 301 2>&1 | tail -1 >> $OUT
 cat $OUT
