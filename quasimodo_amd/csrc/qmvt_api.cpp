@@ -1017,7 +1017,23 @@ static FinalizeParams bucket_rows_finalize(qm_batch* b, const uint32_t* all_hist
 // posor[v]: OR of the positions the optimistic pass saw in VCF v (which position bits are in use)
 static thread_local double g_ftrace[4];   // QM_FINISH_TRACE: host clock inside the latest sort_chunk (entered, tables ready, scatter queued)
 static double ftrace_now() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; }
-static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, const std::vector<uint32_t>& posor, bool buckets) {
+static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, const std::vector<uint32_t>& posor, bool buckets, bool may_speculate);
+// A one-level bucket chunk one of whose VCFs did not fit: `bad` (the VCFs with the flag) through the radix sort, `good` (the others)
+// through the buckets once more, looked at before they are handed over.  (Through round 5 the whole chunk took the radix sort: one
+// VCF with a crowd of records on a few positions sent up to 4 096 others onto the path that is four times slower.)
+static int redo_overflowed(qm_batch* b, const std::vector<int>& bad, const std::vector<int>& good, hipStream_t st, uint64_t* global, const std::vector<uint32_t>& posor) {
+  int rc = QM_OK;
+  if (!good.empty()) rc = sort_chunk(b, good, st, global, posor, true, false);
+  if (rc == QM_OK && !bad.empty()) {
+    b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += (int64_t)bad.size();
+    rc = sort_chunk(b, bad, st, global, posor, false, false);
+    b->path_stats[QM_PATH_RADIX] -= (int64_t)bad.size();
+  }
+  return rc;
+}
+
+// may_speculate = false: the chunk's flags are looked at before its results are handed over (the re-run of the VCFs that fitted, above)
+static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, const std::vector<uint32_t>& posor, bool buckets, bool may_speculate = true) {
   g_ftrace[0] = ftrace_now();
   const int nseg = (int)vs.size();
   std::vector<int32_t> tids((size_t)nseg);
@@ -1231,7 +1247,7 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
     // No round trip through the host between the rows' k_finalize and the kernels that hand the chunk's results over: they are queued
     // at once, k_sort_copy_rows looks at the chunk's "bad" word on the device, and qm_batch_finish reads the mirrors behind its last
     // wait (settle_pending) -- 15-25 us per chunk of 2.5 ms.  Every chunk of a finish has mirror words of its own (b->pend_segs).
-    const bool speculate = mirrors && b->pend_segs + nseg <= b->n_vcf && !(getenv("QM_SPECULATE") && atoi(getenv("QM_SPECULATE")) == 0);
+    const bool speculate = may_speculate && mirrors && b->pend_segs + nseg <= b->n_vcf && !(getenv("QM_SPECULATE") && atoi(getenv("QM_SPECULATE")) == 0);
     const int moff = speculate ? b->pend_segs : 0;
     {
       FinalizeParams F = bucket_rows_finalize(b, seg_hist);
@@ -1280,11 +1296,12 @@ static int sort_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, u
       HIPCHK(hipGetLastError());
       return QM_OK;   // no wait: the rescan that follows is on the same stream and ends with one
     }
-    rc = ensure_sub(b, vs, tids);   // the radix sort needs room for the sorted copies after all
-    if (rc != QM_OK) return rc;
-    // a bucket did not fit its tables (dense positions, a dense truth set): the radix sort redoes the chunk from the columns
+    // a bucket did not fit its tables (dense positions, a dense truth set): the radix sort redoes THAT VCF from the columns; the
+    // VCFs of the chunk that fitted take the buckets again, among themselves (nothing of a chunk with a flag is handed over)
     b->path_stats[QM_PATH_OVERFLOW_CHUNKS] += 1;
-    b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += nseg;
+    std::vector<int> bad, good;
+    for (int i = 0; i < nseg; ++i) ((hfl[(size_t)i] & SPANF_OVERFLOW) ? bad : good).push_back(vs[(size_t)i]);
+    return redo_overflowed(b, bad, good, st, global, posor);
   } else {
     b->path_stats[QM_PATH_RADIX] += nseg;
   }
@@ -1628,8 +1645,11 @@ static bool bucketx_takes(const qm_batch* b, int64_t n, uint32_t posor) {
   return parts == 2;
 }
 
-static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, const std::vector<uint32_t>& posor, bool* taken, bool wide = false) {
+// bad (when the chunk is not taken): the VCFs whose buckets overflowed -- the others would have fitted among themselves
+static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, const std::vector<uint32_t>& posor, bool* taken, bool wide = false,
+                         std::vector<int>* bad = nullptr) {
   *taken = false;
+  if (bad) bad->clear();
   const int nv = (int)vs.size();
   const int pshift = wide ? PW_SHIFT : P2_SHIFT, bshift = wide ? DJ_BIG_SHIFT : DJ_MAX_SHIFT;
   const int64_t sub_max = wide ? 4 * HB_SUB_MAX : HB_SUB_MAX;
@@ -1761,10 +1781,15 @@ static int bucketx_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   HIPCHK(hipMemcpyAsync(hfl.data(), b->bk_vflags, 4 * hfl.size(), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   b->path_stats[QM_PATH_BUCKET_CHUNKS] += 1;
+  bool overflow = false;
   for (int i = 0; i < nseg; ++i) {
     if (hfl[(size_t)i] & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", b->lastx_seg_vcf[(size_t)i]);
-    if (hfl[(size_t)i] & SPANF_OVERFLOW) { b->path_stats[QM_PATH_OVERFLOW_CHUNKS] += 1; b->lastx_vs.clear(); return QM_OK; }   // a bucket did not fit: the radix sort redoes the chunk
+    if (hfl[(size_t)i] & SPANF_OVERFLOW) {   // a bucket did not fit: nothing of the chunk is handed over
+      overflow = true;
+      if (bad && (bad->empty() || bad->back() != b->lastx_seg_vcf[(size_t)i])) bad->push_back(b->lastx_seg_vcf[(size_t)i]);   // (a VCF's segments lie one behind the other)
+    }
   }
+  if (overflow) { b->path_stats[QM_PATH_OVERFLOW_CHUNKS] += 1; b->lastx_vs.clear(); return QM_OK; }
   launch_sort_copy_rows(b->d_vsegs, nv, b->bk_roc, b->bk_rscal, b->roc, b->scalars, b->n_bins, st, global, b->d_vcfs, b->d_vparts);
   launch_tile_counts(b->d_vsegs, b->d_ktile_seg, b->d_ktile_local, (int)nkt, b->mask_pass, b->mask_tp, b->tile_tp, b->tile_fp, st);
   HIPCHK(hipGetLastError());
@@ -1809,15 +1834,23 @@ static int redo_unsorted(qm_batch* b, const std::vector<int>& todo, const std::v
       if (flush && !chunk.empty()) {
         int rc = QM_OK;
         bool taken = false;
-        if (kind == 4) {
-          rc = bucketx_chunk(b, chunk, st, b->last_global, posor, &taken, true);
-          if (rc == QM_OK && !taken) {   // a bucket did not fit after all: two levels, then the radix sort
-            rc = bucket2_chunk(b, chunk, st, b->last_global, &taken);
-            if (rc == QM_OK && !taken) { b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += (int64_t)chunk.size(); rc = sort_chunk(b, chunk, st, b->last_global, posor, false); b->path_stats[QM_PATH_RADIX] -= (int64_t)chunk.size(); }
+        if (kind == 4 || kind == 3) {
+          // a chunk one of whose VCFs overflowed is not handed over: the VCFs that fitted take the same buckets again, among
+          // themselves; the others go on to the next path (wide buckets: two levels, then the radix sort)
+          std::vector<int> bad, rest = chunk;
+          rc = bucketx_chunk(b, chunk, st, b->last_global, posor, &taken, kind == 4, &bad);
+          if (rc == QM_OK && !taken && !bad.empty() && bad.size() < chunk.size()) {
+            std::vector<int> good;
+            for (int v : chunk) if (std::find(bad.begin(), bad.end(), v) == bad.end()) good.push_back(v);
+            bool taken_good = false;
+            rc = bucketx_chunk(b, good, st, b->last_global, posor, &taken_good, kind == 4);
+            if (taken_good) rest = bad;
           }
-        } else if (kind == 3) {
-          rc = bucketx_chunk(b, chunk, st, b->last_global, posor, &taken);
-          if (rc == QM_OK && !taken) { b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += (int64_t)chunk.size(); rc = sort_chunk(b, chunk, st, b->last_global, posor, false); b->path_stats[QM_PATH_RADIX] -= (int64_t)chunk.size(); }
+          if (rc == QM_OK && !taken) {
+            bool taken2 = false;
+            if (kind == 4) rc = bucket2_chunk(b, rest, st, b->last_global, &taken2);
+            if (rc == QM_OK && !taken2) { b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += (int64_t)rest.size(); rc = sort_chunk(b, rest, st, b->last_global, posor, false); b->path_stats[QM_PATH_RADIX] -= (int64_t)rest.size(); }
+          }
         } else if (kind == 2) {
           rc = bucket2_chunk(b, chunk, st, b->last_global, &taken);
           if (rc == QM_OK && !taken) { b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += (int64_t)chunk.size(); rc = sort_chunk(b, chunk, st, b->last_global, posor, false); b->path_stats[QM_PATH_RADIX] -= (int64_t)chunk.size(); }
@@ -1841,10 +1874,12 @@ static int settle_pending(qm_batch* b, const std::vector<uint32_t>& posor, hipSt
   std::vector<qm_batch::Pending> pend;
   pend.swap(b->pend);
   b->pend_segs = 0;
-  bool again = false;
-  for (const qm_batch::Pending& p : pend) {
+  // every chunk's mirror words first: a re-run below writes its own over them
+  std::vector<std::vector<uint32_t>> flags(pend.size());
+  for (size_t k = 0; k < pend.size(); ++k) {
+    const qm_batch::Pending& p = pend[k];
     const int nseg = (int)p.vs.size();
-    bool overflow = false;
+    flags[k].resize((size_t)nseg);
     for (int i = 0; i < nseg; ++i) {
       uint32_t fl = b->h_summary[16 + 2 * (size_t)b->n_vcf + (size_t)p.off + (size_t)i];
       if (p.tight) {
@@ -1856,17 +1891,23 @@ static int settle_pending(qm_batch* b, const std::vector<uint32_t>& posor, hipSt
         }
       }
       if (fl & SPANF_BADPOS) return fail(QM_E_RANGE, "VCF %d holds a position outside [0, 2^28)", p.vs[(size_t)i]);
-      overflow = overflow || (fl & SPANF_OVERFLOW);
+      flags[k][(size_t)i] = fl;
     }
-    if (!overflow) { b->path_stats[p.direct ? QM_PATH_DIRECT : QM_PATH_HASHED] += nseg; continue; }
-    // a bucket did not fit its tables (dense positions, a dense truth set): the radix sort redoes the chunk from the columns
+  }
+  bool again = false;
+  for (size_t k = 0; k < pend.size(); ++k) {
+    const qm_batch::Pending& p = pend[k];
+    const int nseg = (int)p.vs.size();
+    std::vector<int> bad, good;
+    for (int i = 0; i < nseg; ++i) ((flags[k][(size_t)i] & SPANF_OVERFLOW) ? bad : good).push_back(p.vs[(size_t)i]);
+    if (bad.empty()) { b->path_stats[p.direct ? QM_PATH_DIRECT : QM_PATH_HASHED] += nseg; continue; }
+    // a bucket of a VCF did not fit its tables (dense positions, a dense truth set): nothing of the chunk was handed over
+    // (k_sort_copy_rows saw its "bad" word).  The radix sort redoes that VCF from the columns, the others take the buckets again.
     if (p.tight && !b->known_nbk.empty()) for (int v : p.vs) b->known_nbk[(size_t)v] = 0u;
-    // (what the radix sort below learns about the chunk's positions corrects the estimate such a VCF is remembered with: posor_seen)
+    // (what the radix sort learns about its chunk's positions corrects the estimate such a VCF is remembered with: posor_seen)
     b->path_stats[QM_PATH_OVERFLOW_CHUNKS] += 1;
-    b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += nseg;
-    const int rc = sort_chunk(b, p.vs, st, b->last_global, posor, false);
+    const int rc = redo_overflowed(b, bad, good, st, b->last_global, posor);
     if (rc != QM_OK) return rc;
-    b->path_stats[QM_PATH_RADIX] -= nseg;
     again = true;
   }
   return again ? rescan_and_compact(b, st) : QM_OK;

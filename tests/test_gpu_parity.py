@@ -338,12 +338,11 @@ def test_unsorted_vcfs_of_a_wide_reference_take_every_path_in_one_finish(engine,
     """One batch on a 40 Mb reference, uploaded columns with everything random_columns knows (repeats, multi-allelic sites,
     keyless records, non-'.' IDs, infinite QUALs): a 1.5 M-record VCF out of order (wide buckets), one of 200 000 (one level,
     hashed join), one of 5 000 (radix sort), a sorted one, and a second 1.5 M-record VCF with 30 % of its records on 3 000
-    positions -- its wide buckets overflow, the two levels behind them as well, and the radix sort redoes it (a chunk falls back
-    as a whole: QM_SORT_CHUNK_RECORDS keeps the two large VCFs in chunks of their own).  Twice: the second run with the batch's
-    memory of the first.  Every VCF against the oracle, the per-truth sums against the VCFs' rows."""
+    positions -- its wide buckets overflow, the two levels behind them as well, and the radix sort redoes it, while the other
+    large VCF of the same chunk takes the wide buckets again without it (through round 5 a chunk fell back as a whole).  Twice:
+    the second run with the batch's memory of the first.  Every VCF against the oracle, the per-truth sums against the VCFs' rows."""
     from conftest import random_columns, random_truth
     from quasimodo_amd.engine import SCALAR_NAMES
-    monkeypatch.setenv("QM_SORT_CHUNK_RECORDS", "1600000")
     rng = np.random.default_rng(6061)
     L = 40_000_000
     truth = random_truth(rng, 60_000, L)
@@ -414,6 +413,47 @@ def test_wide_buckets_and_positions_above_what_the_optimistic_pass_saw(engine, o
         check_vcf(oracle, res, cols, truth, expect_sorted=False)
         ps = b.path_stats()
         assert ps["radix_after_overflow"] == (1 if rep == 0 else 0) and ps["bucket_partitions"] == (0 if rep == 0 else 1), (rep, ps)
+    b.close()
+    engine.truth_release(tid)
+
+
+@pytest.mark.parametrize("knobs", [{}, {"QM_SPECULATE": "0"}], ids=["queued", "looked-at"])
+def test_one_overflowing_vcf_does_not_take_its_chunk_to_the_radix_sort(engine, oracle, monkeypatch, knobs):
+    """Five VCFs out of order in ONE chunk of the one-level bucket path, the third of them 60 000 records on sixteen positions: its
+    buckets overflow, nothing of the chunk is handed over -- and (round 6) only that VCF goes through the radix sort, the other
+    four take the buckets again among themselves.  Both ways a chunk is settled (queued without a look at its flags; looked at)."""
+    from conftest import random_columns, random_truth
+    from quasimodo_amd.engine import SCALAR_NAMES
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(6065)
+    L = 400_000
+    truth = random_truth(rng, 8000, L)
+    tid = engine.truth_load(*truth)
+    cols = [random_columns(rng, n, L, truth, sorted_=False) for n in (40_000, 33_000)]
+    n = 60_000
+    pos = rng.integers(1000, 1016, n).astype(np.int32)
+    ref = rng.integers(0, 4, n).astype(np.int32)
+    alt = rng.integers(0, 4, n).astype(np.int32)
+    qual = rng.integers(0, 300, n).astype(np.float32)
+    cols.append((pos, ref, alt, qual, ((qual >= 20).astype(np.uint8) | 2).astype(np.uint8)))
+    cols += [random_columns(rng, n, L, truth, sorted_=False) for n in (45_000, 38_000)]
+    b = engine.batch([len(c[0]) for c in cols], [tid] * len(cols))
+    for v, c in enumerate(cols):
+        b.upload(v, *c)
+    for rep in range(2):
+        b.run()
+        b.finish()
+        want = np.zeros((3, 256), np.uint64)
+        for v, c in enumerate(cols):
+            sc = dict(zip(SCALAR_NAMES, b.scalars()[v].tolist()))
+            reg = b.idx(v)
+            res = {"cls": b.cls(v), "roc": b.roc()[v], "scalars": sc, "tp_idx": reg[:sc["tp_lines"]].copy(), "fp_idx": reg[len(c[0]) - sc["fp_lines"]:].copy()}
+            check_vcf(oracle, res, c, truth, expect_sorted=False)
+            want += res["roc"]
+        assert np.array_equal(b.global_counts()[tid], want)   # nothing was added twice
+        st = b.path_stats()
+        assert st["unsorted"] == 5 and st["overflow_chunks"] == 1 and st["radix_after_overflow"] == 1 and st["bucket_direct"] == 4, (rep, st)
     b.close()
     engine.truth_release(tid)
 
