@@ -32,8 +32,10 @@ def run(rounds, seed):
     for it in range(rounds):
         ext = rng.random() < 0.25
         L = int(np.exp(rng.uniform(np.log(3e6), np.log(1.2e8 if not ext else 3.0e7))))
-        nv = int(rng.integers(1, 4))
-        sizes = [int(np.exp(rng.uniform(np.log(2e4), np.log(4e6)))) for _ in range(nv)]
+        many = rng.random() < 0.2      # a fifth of the rounds: up to twelve VCFs (smaller ones), several chunks' worth of work for the fallbacks
+        nv = int(rng.integers(4, 13)) if many else int(rng.integers(1, 4))
+        sizes = [int(np.exp(rng.uniform(np.log(2e4), np.log(1.5e6 if many else 4e6)))) for _ in range(nv)]
+        nb = int(rng.choice([256, 256, 256, 100, 21]))
         T = int(np.exp(rng.uniform(np.log(1e3), np.log(3e6))))
         if rng.random() < 0.7:
             T = max(T, max(sizes) // 8)   # (random_columns puts 5 % of the records on truth POSITIONS: against a small truth set every bucket overflows and the round only tests the radix sort)
@@ -44,6 +46,9 @@ def run(rounds, seed):
             k = rng.random(T) < 0.3
             truth = (truth[0], truth[1], np.where(k, (2 << 26) | rng.integers(0, 16, T), truth[2]).astype(np.int32))
         tid = None if dry else eng.truth_load(*truth)
+        # a second truth set (a subset of the first) for every other VCF in a third of the rounds
+        truth2 = tuple(a[::3] for a in truth) if rng.random() < 0.33 else None
+        tid2 = None if (dry or truth2 is None) else eng.truth_load(*truth2)
         cols, notes = [], []
         for v in range(nv):
             n = sizes[v]
@@ -81,7 +86,8 @@ def run(rounds, seed):
                                                                              [bool((np.diff(c[0]) >= 0).all()) for c in cols]), flush=True)
             continue
         try:
-            b = eng.batch([len(c[0]) for c in cols], [tid] * nv, alleles=ext)
+            tids = [tid2 if (tid2 is not None and v % 2) else tid for v in range(nv)]
+            b = eng.batch([len(c[0]) for c in cols], tids, n_bins=nb, alleles=ext)
             for v, c in enumerate(cols):
                 b.upload(v, *c)
             for rep in range(2):
@@ -91,7 +97,7 @@ def run(rounds, seed):
                     if x and k not in ("bucket_chunks", "overflow_chunks", "radix_chunks"):
                         paths[k] += x
                 for v, c in enumerate(cols):
-                    cls, roc, sc = O.classify_columns(*c, *truth, ext=ext)
+                    cls, roc, sc = O.classify_columns(*c, *(truth2 if tids[v] == tid2 and tid2 is not None else truth), n_bins=nb, ext=ext)
                     s = dict(zip(SCALAR_NAMES, b.scalars()[v].tolist()))
                     reg = b.idx(v)
                     ok = (np.array_equal(b.cls(v), cls) and np.array_equal(b.roc()[v], roc)
@@ -109,6 +115,8 @@ def run(rounds, seed):
             else:
                 raise
         eng.truth_release(tid)
+        if tid2 is not None:
+            eng.truth_release(tid2)
         if (it + 1) % 10 == 0:
             print("  %d rounds, %d mismatches, %.0f s, paths %s" % (it + 1, bad, time.time() - t0, dict(paths)), flush=True)
     print("gpu fuzz (big): %d rounds, seed %d, %d mismatches, %.0f s; VCFs by path: %s" % (rounds, seed, bad, time.time() - t0, dict(paths)))
