@@ -411,6 +411,7 @@ struct qm_batch {
   SortSeg* d_vsegs = nullptr;
   int32_t* d_vparts = nullptr;          // partitions in use per VCF
   int64_t cap_vparts = 0;
+  std::vector<int> last2_seg_vcf;       // VCF of every level-2 segment of that chunk
   std::vector<int> last2_vs;            // the chunk these tables were built for, and its counts: a batch run again with the same
   std::vector<uint32_t> last2_cnt;      // VCFs out of order keeps them on the device (as last_segs does on the one-level path)
   int last2_nseg = 0;
@@ -1381,7 +1382,9 @@ static bool bucket2_takes(const qm_batch* b, int64_t n) {
 
 // *taken = false: the chunk is not for this path after all (a partition too dense for its buckets, a bucket overflowed): the
 // caller sends it through the radix sort; nothing the path wrote is kept in that case (the sort rewrites masks, counts and rows)
-static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, bool* taken) {
+// bad (when the chunk is not taken): the VCF with a partition too dense for its buckets, or the VCFs whose buckets overflowed
+static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st, uint64_t* global, bool* taken, std::vector<int>* bad = nullptr) {
+  if (bad) bad->clear();
   *taken = false;
   const int nv = (int)vs.size();
   std::vector<int32_t> tids((size_t)nv);
@@ -1475,7 +1478,7 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
       const int64_t np = (int64_t)run - start;
       if (np == 0) continue;
       half_off.insert(half_off.end(), hb, hb + 4);
-      if (np > (int64_t)HB_BUCKETS * HB_MAX_RECORDS * 13 / 16) return QM_OK;   // all 256 buckets of a partition are in use: more than 6 656 records per bucket on average will not fit 8 x 1 024 (not for this path: *taken stays false)
+      if (np > (int64_t)HB_BUCKETS * HB_MAX_RECORDS * 13 / 16) { if (bad) bad->push_back(vs[(size_t)i]); return QM_OK; }   // all 256 buckets of a partition are in use: more than 6 656 records per bucket on average will not fit 8 x 1 024 (not for this path: *taken stays false)
       SortSeg g;
       memset(&g, 0, sizeof g);
       g.src_off = d.off; g.koff = ps[(size_t)h0].ent_off + start; g.n = np;   // (the halves of a VCF share its level-1 region)
@@ -1546,6 +1549,8 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   HIPCHK(hipMemcpyAsync(b->d_vparts, vparts.data(), 4 * vparts.size(), hipMemcpyHostToDevice, st));
   HIPCHK(hipStreamSynchronize(st));   // the host tables die with this block
   b->last2_vs = vs; b->last2_cnt = cnt; b->last2_nseg = nseg; b->last2_nbt = nbt; b->last2_nkt = nkt;
+  b->last2_seg_vcf.resize(segs.size());
+  for (size_t i = 0; i < segs.size(); ++i) b->last2_seg_vcf[i] = segs[i].main_vcf;
   }   // !same_cnt
   const int nseg = b->last2_nseg;
   const int64_t nbt = b->last2_nbt, nkt = b->last2_nkt;
@@ -1580,8 +1585,13 @@ static int bucket2_chunk(qm_batch* b, const std::vector<int>& vs, hipStream_t st
   HIPCHK(hipMemcpyAsync(hfl.data(), b->bk_vflags, 4 * hfl.size(), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   b->path_stats[QM_PATH_BUCKET_CHUNKS] += 1;
+  bool overflow = false;
   for (int i = 0; i < nseg; ++i)
-    if (hfl[(size_t)i] & SPANF_OVERFLOW) { b->path_stats[QM_PATH_OVERFLOW_CHUNKS] += 1; b->last2_vs.clear(); return QM_OK; }   // a bucket did not fit: the radix sort redoes the chunk
+    if (hfl[(size_t)i] & SPANF_OVERFLOW) {   // a bucket did not fit: nothing of the chunk is handed over
+      overflow = true;
+      if (bad && (size_t)i < b->last2_seg_vcf.size() && (bad->empty() || bad->back() != b->last2_seg_vcf[(size_t)i])) bad->push_back(b->last2_seg_vcf[(size_t)i]);
+    }
+  if (overflow) { b->path_stats[QM_PATH_OVERFLOW_CHUNKS] += 1; b->last2_vs.clear(); return QM_OK; }
   launch_sort_copy_rows(b->d_vsegs, nv, b->bk_roc, b->bk_rscal, b->roc, b->scalars, b->n_bins, st, global, b->d_vcfs, b->d_vparts);
   launch_tile_counts(b->d_vsegs, b->d_ktile_seg, b->d_ktile_local, (int)nkt, b->mask_pass, b->mask_tp, b->tile_tp, b->tile_fp, st);
   HIPCHK(hipGetLastError());
@@ -1823,6 +1833,27 @@ static int redo_unsorted(qm_batch* b, const std::vector<int>& todo, const std::v
          : !dense && bucket2_takes(b, n) ? 2 : 0].push_back(v);
   }
   const int64_t chunk_records = sort_chunk_records();
+  // the two levels for a chunk; the VCFs of it that do not fit (a partition too dense, a bucket that overflowed) go through the
+  // radix sort, the others through the two levels again among themselves
+  auto two_levels_or_sort = [&](const std::vector<int>& chunk) -> int {
+    std::vector<int> pending = chunk, bad;   // pending: the VCFs without a result so far
+    for (int round = 0; round < 3; ++round) {   // (a partition too dense names one VCF at a time: three tries, then everything left is sorted)
+      std::vector<int> good, named;
+      for (int v : pending) if (std::find(bad.begin(), bad.end(), v) == bad.end()) good.push_back(v);
+      if (good.empty()) break;
+      bool taken = false;
+      const int rc = bucket2_chunk(b, good, st, b->last_global, &taken, &named);
+      if (rc != QM_OK) return rc;
+      if (taken) { pending = bad; break; }
+      if (named.empty() || named.size() >= good.size()) break;
+      bad.insert(bad.end(), named.begin(), named.end());
+    }
+    if (pending.empty()) return QM_OK;
+    b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += (int64_t)pending.size();
+    const int rc = sort_chunk(b, pending, st, b->last_global, posor, false);
+    b->path_stats[QM_PATH_RADIX] -= (int64_t)pending.size();
+    return rc;
+  };
   for (int kind = 4; kind >= 0; --kind) {
     std::vector<int> chunk;
     int64_t chunk_n = 0;
@@ -1847,13 +1878,11 @@ static int redo_unsorted(qm_batch* b, const std::vector<int>& todo, const std::v
             if (taken_good) rest = bad;
           }
           if (rc == QM_OK && !taken) {
-            bool taken2 = false;
-            if (kind == 4) rc = bucket2_chunk(b, rest, st, b->last_global, &taken2);
-            if (rc == QM_OK && !taken2) { b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += (int64_t)rest.size(); rc = sort_chunk(b, rest, st, b->last_global, posor, false); b->path_stats[QM_PATH_RADIX] -= (int64_t)rest.size(); }
+            if (kind == 4) rc = two_levels_or_sort(rest);
+            else { b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += (int64_t)rest.size(); rc = sort_chunk(b, rest, st, b->last_global, posor, false); b->path_stats[QM_PATH_RADIX] -= (int64_t)rest.size(); }
           }
         } else if (kind == 2) {
-          rc = bucket2_chunk(b, chunk, st, b->last_global, &taken);
-          if (rc == QM_OK && !taken) { b->path_stats[QM_PATH_RADIX_AFTER_OVERFLOW] += (int64_t)chunk.size(); rc = sort_chunk(b, chunk, st, b->last_global, posor, false); b->path_stats[QM_PATH_RADIX] -= (int64_t)chunk.size(); }
+          rc = two_levels_or_sort(chunk);
         } else {
           rc = sort_chunk(b, chunk, st, b->last_global, posor, kind == 1);
         }

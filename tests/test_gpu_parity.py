@@ -417,17 +417,18 @@ def test_wide_buckets_and_positions_above_what_the_optimistic_pass_saw(engine, o
     engine.truth_release(tid)
 
 
-@pytest.mark.parametrize("knobs", [{}, {"QM_SPECULATE": "0"}], ids=["queued", "looked-at"])
+@pytest.mark.parametrize("knobs", [{}, {"QM_SPECULATE": "0"}, {"QM_BUCKET2": "2"}], ids=["queued", "looked-at", "two-levels"])
 def test_one_overflowing_vcf_does_not_take_its_chunk_to_the_radix_sort(engine, oracle, monkeypatch, knobs):
     """Five VCFs out of order in ONE chunk of the one-level bucket path, the third of them 60 000 records on sixteen positions: its
     buckets overflow, nothing of the chunk is handed over -- and (round 6) only that VCF goes through the radix sort, the other
-    four take the buckets again among themselves.  Both ways a chunk is settled (queued without a look at its flags; looked at)."""
+    four take the buckets again among themselves.  Both ways a one-level chunk is settled (queued without a look at its flags;
+    looked at), and the two levels (QM_BUCKET2=2: the dense VCF's partition is named before anything is scattered)."""
     from conftest import random_columns, random_truth
     from quasimodo_amd.engine import SCALAR_NAMES
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     rng = np.random.default_rng(6065)
-    L = 400_000
+    L = 4_000_000 if knobs.get("QM_BUCKET2") else 400_000   # (the two levels size a partition's buckets for 128 ... 256 of them in use: 4 M positions are 123)
     truth = random_truth(rng, 8000, L)
     tid = engine.truth_load(*truth)
     cols = [random_columns(rng, n, L, truth, sorted_=False) for n in (40_000, 33_000)]
@@ -453,7 +454,8 @@ def test_one_overflowing_vcf_does_not_take_its_chunk_to_the_radix_sort(engine, o
             want += res["roc"]
         assert np.array_equal(b.global_counts()[tid], want)   # nothing was added twice
         st = b.path_stats()
-        assert st["unsorted"] == 5 and st["overflow_chunks"] == 1 and st["radix_after_overflow"] == 1 and st["bucket_direct"] == 4, (rep, st)
+        good = "bucket_two_level" if knobs.get("QM_BUCKET2") else "bucket_direct"
+        assert st["unsorted"] == 5 and st["radix_after_overflow"] == 1 and st[good] == 4, (rep, st)
     b.close()
     engine.truth_release(tid)
 
