@@ -30,7 +30,7 @@ def run(rounds, seed):
     paths = collections.Counter()
     t0 = time.time()
     for it in range(rounds):
-        ext = rng.random() < 0.25
+        ext = rng.random() < float(os.environ.get("QM_FUZZ_EXT", "0.25"))   # share of the rounds in the allele-extended mode
         L = int(np.exp(rng.uniform(np.log(3e6), np.log(1.2e8 if not ext else 3.0e7))))
         many = rng.random() < 0.2      # a fifth of the rounds: up to twelve VCFs (smaller ones), several chunks' worth of work for the fallbacks
         nv = int(rng.integers(4, 13)) if many else int(rng.integers(1, 4))
